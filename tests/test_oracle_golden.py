@@ -1,0 +1,110 @@
+"""Pin the CPU oracle against outputs of the REAL reference (tests/golden, tools/make_fixtures.py)
+and against the reference's own known answers.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import tables as T
+from oracle.engine import OracleEngine, da_func, hubble
+from oracle.fftlog import FFTLogGrid
+from oracle_util import oracle_engine
+
+TOL = 1e-10  # oracle vs reference: same algorithm, same libraries -> rounding-level agreement
+
+
+def test_known_answers(golden):
+    """reference tests/test_pybird.py:5-11"""
+    g = golden("tables")
+    assert np.isclose(hubble(0.2, 1.0), 1.549193338482967, atol=0.0)
+    assert np.isclose(da_func(0.2, 1.0), 0.4117451980802465, atol=0.0)
+    assert np.isclose(hubble(0.2, 1.0), g["known_Hubble_0.2_1.0"][1], rtol=1e-15)
+    assert np.isclose(da_func(0.2, 1.0), g["known_DAfunc_0.2_1.0"][1], rtol=1e-14)
+    assert np.allclose([OracleEngine.chain_coeff(l) for l in (0, 2, 4)], g["chain_coeff"], rtol=1e-15)
+
+
+def test_fftlog_reference_vector(golden):
+    """reference tests/compare/test_fftlog.py:5-23 (vectorised == per-row, and == reference output)"""
+    g = golden("tables")
+    fft = FFTLogGrid(256, 10**-5, 10, -0.3)
+    c = fft.coef(g["fftlog_gauss_k"], g["fftlog_gauss_p"], extrap="padding", window=0.3)
+    assert relerr(c, g["fftlog_gauss_coef"]) < 1e-13
+    cb = fft.coef(g["fftlog_gauss_k"], np.vstack([g["fftlog_gauss_p"], 2 * g["fftlog_gauss_p"]]), extrap="padding", window=0.3)
+    assert relerr(cb, g["fftlog_gauss_coef_batch"]) < 1e-13
+    np.testing.assert_allclose(cb[0], c, rtol=1e-6, atol=0.0)
+
+
+def test_constant_tables(golden):
+    g = golden("tables")
+    fft = FFTLogGrid(256, 1.5e-5, 1000.0, -1.6)
+    assert np.max(np.abs(fft.Pow - g["Pow"])) == 0.0
+    nu = -0.5 * fft.Pow
+    idx = g["M22_idx"]
+    got = np.array([T.m22a(nu[n], nu[m]) * T.m22b(b, nu[n], nu[m]) for b, n, m in idx])
+    assert np.max(np.abs(got - g["M22_val"]) / np.abs(g["M22_val"])) < 1e-12
+    m13 = np.stack([T.m13a(nu) * T.m13b(b, nu) for b in range(10)])
+    assert np.max(np.abs(m13 - g["M13"]) / np.abs(g["M13"])) < 1e-12
+    lidx = g["Ml_idx"]
+    ml = np.array([T.mpc(2 * l, nu[n] + nu[m] - 1.5) for l, n, m in lidx])
+    assert np.max(np.abs(ml - g["Ml_val"]) / np.abs(g["Ml_val"])) < 1e-12
+    for Nl in (2, 3):
+        w = T.mu_weights(Nl)
+        for n in ("l11", "lct", "l22", "l13"):
+            assert np.array_equal(w[n], g[f"{n}_Nl{Nl}"])
+        for i, f in enumerate(g["Q_fvals"]):
+            q = T.q_matrix(f, Nl)
+            assert q.shape == g[f"Q_f_Nl{Nl}"][i].shape
+            assert relerr(q.reshape(-1, q.shape[-1]), g[f"Q_f_Nl{Nl}"][i].reshape(-1, q.shape[-1])) < 1e-13
+
+
+@pytest.mark.parametrize("name", ["caseA", "caseB", "caseC", "caseD", "caseE"])
+def test_stages(golden, name):
+    g = golden(name)
+    eng = oracle_engine(g, name)
+    assert np.array_equal(eng.k, g["k"])
+    taps = {}
+    f = float(g["f"])
+    st = eng.evaluate(g["kin"], g["Pin"], f, float(g["DA"]), float(g["H"]), taps=taps)
+    assert relerr(taps["pscf"]["coef"], g["coef"]) < 1e-13
+    for n in ("P11", "P22", "P13", "C11", "Cct", "C22", "C13"):
+        assert relerr(taps["pscf"][n], g["pscf_" + n]) < TOL, n
+    for n in ("P11l", "Pctl", "Ploopl", "Cloopl", "Pstl"):
+        assert relerr(taps["setpscfl"][n], g["setpscfl_" + n]) < TOL, n
+    if "resum_X" in g:
+        assert relerr(taps["resum"]["X"], g["resum_X"]) < TOL
+        assert relerr(taps["resum"]["Y"], g["resum_Y"]) < TOL
+        for n in ("P11l", "Pctl", "Ploopl"):
+            assert relerr(taps["resum"][n], g["resum_" + n]) < TOL, n
+    if "ap_P11l" in g:
+        assert np.isclose(eng.DA_fid, g["DA_AP"], rtol=1e-14) and np.isclose(eng.H_fid, g["H_AP"], rtol=1e-15)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            assert relerr(taps["ap"][n], g["ap_" + n]) < TOL, n
+    if "window_P11l" in g:
+        assert np.array_equal(eng.p, g["window_p"])
+        assert relerr(eng.Waldk[:, :, 10, :], g["window_Waldk_k10"]) < 1e-9
+        assert relerr(eng.Waldk.sum(axis=-1), g["window_Waldk_sum_p"]) < 1e-9
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            assert relerr(taps["window"][n], g["window_" + n]) < 1e-9, n
+    bsA, bsB, es = list(g["bsA"]), list(g["bsB"]), tuple(g["es"])
+    assert relerr(eng.reduce_plk(f, st, bsA, es=es), g["plk_auto"]) < TOL
+    last = st
+    if "binned_P11l" in g:
+        assert np.allclose(eng.keff, g["keff"], rtol=1e-14)
+        last = eng.binning(st)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc"):
+            assert relerr(last[n], g["binned_" + n]) < TOL, n
+        ch = eng.chained(last)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc"):
+            assert relerr(ch[n], g["chained_" + n]) < TOL, n
+        assert relerr(eng.reduce_plk(f, last, bsA, es=es), g["plk_binned_auto"]) < TOL
+    eng.kmB, eng.krB, eng.ndB = 0.6, 0.3, 2.3e-4
+    assert relerr(eng.reduce_plk(f, last, bsA, bsB, es=es), g["plk_cross"]) < TOL
+
+
+def test_final_nk2048(golden):
+    g = golden("caseF")
+    eng = oracle_engine(g, "caseF")
+    f = float(g["f"])
+    st = eng.evaluate(g["kin"], g["Pin"], f, float(g["DA"]), float(g["H"]), pairwise=True)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        assert relerr(st[n], g["ap_" + n]) < 1e-9, n
+    assert relerr(eng.reduce_plk(f, st, list(g["bsA"]), es=tuple(g["es"])), g["plk_auto"]) < 1e-9

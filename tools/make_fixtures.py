@@ -1,0 +1,189 @@
+"""Generate golden fixtures under tests/golden/ by running the REAL reference (build container only).
+
+The reference (zhaoruiyang98/eftpipe, /root/reference) is imported through tools/refimport.py
+(cobaya logging stub) and driven exactly as ``EFTLeafKernel.calculate_power_spectrum``
+does (reference theory.py:557-609).  Only inputs + outputs are stored (data, no reference code).
+
+    python tools/make_fixtures.py            # all cases
+    python tools/make_fixtures.py caseD      # one case
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+from refimport import REFERENCE_ROOT, load_reference  # noqa: E402
+
+from eftpipe_amd import synth  # noqa: E402
+
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+warnings.filterwarnings("ignore", category=DeprecationWarning)
+
+# west-coast biases of reference tests/compare/default_params.yaml:9-20 (b2,b4 from c2,c4)
+_c2, _c4 = 0.77616816, 0.0
+BS_A = [2.1401334, (_c2 + _c4) / np.sqrt(2.0), 0.77003455, (_c2 - _c4) / np.sqrt(2.0), -1.8396613, -1.8918368, -1.4856405]
+BS_B = [1.3, 0.4, -0.2, 0.1, -0.7, -1.1, 0.3]
+ES = [0.26033594, 0.0, -0.92895016]
+
+CASES = {
+    # name: (Nl, Nk or None=native, resum, ap, APst, window, binning, z, draws)
+    "caseA": dict(Nl=2, Nk=None, resum=False, ap=False, z=0.7),
+    "caseB": dict(Nl=2, Nk=256, resum=False, ap=False, z=0.7),
+    "caseC": dict(Nl=3, Nk=None, resum=True, ap=True, APst=True, window=True, binning=True, z=0.7),
+    "caseD": dict(Nl=3, Nk=512, resum=True, ap=True, z=0.7),
+    "caseE": dict(Nl=2, Nk=None, resum=True, ap=True, z=0.7, draw=3),
+    "caseF": dict(Nl=3, Nk=2048, resum=True, ap=True, z=0.7, final_only=True),
+}
+
+
+def make_common(pb, Nl, Nk, **kw):
+    co = pb.Common(Nl=Nl, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5, **kw)
+    if Nk is not None:
+        k = synth.survey_kgrid(Nk)
+        co.k, co.Nk = k, k.size
+        co.kr = k[0.02 <= k]
+        co.Nkr = co.kr.size
+        co.Nklow = co.Nk - co.Nkr
+    return co
+
+
+def stage(bird, names=("P11l", "Pctl", "Ploopl", "Pstl")):
+    return {n: np.array(getattr(bird, n), dtype=np.float64, copy=True) for n in names}
+
+
+def run_case(ref, name, spec):
+    pb = ref.pybird
+    Nl, Nk = spec["Nl"], spec["Nk"]
+    z = spec["z"]
+    co = make_common(pb, Nl, Nk)
+    if "draw" in spec:
+        b = synth.draw_batch(spec["draw"] + 1, z=z)
+        cos = dict(kin=b["kin"], Pin=b["Pin"][-1], f=float(b["f"][-1]), DA=float(b["DA"][-1]), H=float(b["H"][-1]))
+    else:
+        cos = synth.cosmology(z=z)
+    out = dict(k=co.k, kin=cos["kin"], Pin=cos["Pin"], f=cos["f"], DA=cos["DA"], H=cos["H"], z=z,
+               Nl=Nl, bsA=BS_A, bsB=BS_B, es=ES)
+    nl = pb.NonLinear(load=False, save=False, co=co)
+    bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+    nl.PsCf(bird)
+    final_only = spec.get("final_only", False)
+    if not final_only:
+        out["coef"] = nl.Coef(bird, window=0.2)
+        for n in ("P11", "P22", "P13", "C11", "Cct", "C22", "C13"):
+            out["pscf_" + n] = np.array(getattr(bird, n), copy=True)
+    bird.setPsCfl()
+    if not final_only:
+        for n, v in stage(bird, ("P11l", "Pctl", "Ploopl", "Cloopl", "Pstl")).items():
+            out["setpscfl_" + n] = v
+    if spec.get("resum"):
+        rs = pb.Resum(co=co)
+        if not final_only:
+            X, Y = rs.IRFilters(bird)
+            out["resum_X"], out["resum_Y"] = X, Y
+        rs.Ps(bird)
+        if not final_only:
+            out["resum_Q"] = rs.Q.copy()
+            for n, v in stage(bird, ("P11l", "Pctl", "Ploopl")).items():
+                out["resum_" + n] = v
+    if spec.get("ap"):
+        ap = pb.APeffect(Om_AP=synth.OM_AP, z_AP=z, co=co, APst=spec.get("APst", False))
+        out["DA_AP"], out["H_AP"] = ap.DA, ap.H
+        ap.AP(bird)
+        for n, v in stage(bird).items():
+            out["ap_" + n] = v
+    if spec.get("window"):
+        wfile = os.path.join(REFERENCE_ROOT, "data", "DR16_noric", "win_NGC_LRG.txt")
+        win = ref.window.Window(window_configspace_file=wfile, co=co, load=False, save=False)
+        out["window_p"] = win.p
+        # spot values of the precomputed window matrix (full Waldk is too large to commit)
+        out["window_Waldk_sum_p"] = win.Waldk.sum(axis=-1)
+        out["window_Waldk_k10"] = win.Waldk[:, :, 10, :]
+        win.Window(bird)
+        for n, v in stage(bird).items():
+            out["window_" + n] = v
+    last = bird
+    out["plk_auto"] = ref.parambasis.reduce_Plk(bird, BS_A, es=ES).sum()
+    if spec.get("binning"):
+        kout = np.arange(0.025, 0.2, 0.01)
+        bn = ref.binning.Binning(kout=kout, co=co)
+        out["kout"], out["keff"] = kout, bn.keff
+        binned = bn.transform(bird)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc"):
+            out["binned_" + n] = np.array(getattr(binned, n), copy=True)
+        ch = ref.chained.Chained().transform(binned)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc"):
+            out["chained_" + n] = np.array(getattr(ch, n), copy=True)
+        last = binned
+        out["plk_binned_auto"] = ref.parambasis.reduce_Plk(binned, BS_A, es=ES).sum()
+    # cross-spectrum style contraction A x B (different km/kr/nd for B)
+    cox = make_common(pb, Nl, Nk, kmB=0.6, krB=0.3, ndB=2.3e-4)
+    holder = ref.transformer.PlainBird(f=last.f, co=cox, P11l=last.P11l, Ploopl=last.Ploopl, Pctl=last.Pctl,
+                                       Pstl=last.Pstl, Picc=last.Picc, PctNNLOl=None)
+    out["plk_cross"] = ref.parambasis.reduce_Plk(holder, BS_A, BS_B, es=ES).sum()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "written:", {k: np.shape(v) for k, v in out.items() if np.ndim(v) > 0 and k.startswith(("ap_", "plk"))})
+
+
+def tables_fixture(ref):
+    """Spot checks of the constant tables + the reference's own FFTLog test vector + known answers."""
+    pb = ref.pybird
+    out = {}
+    rng = np.random.default_rng(99)
+    for Nl in (2, 3):
+        co = pb.Common(Nl=Nl, kmax=0.3)
+        nl = pb.NonLinear(load=False, save=False, co=co)
+        if Nl == 3:
+            idx = np.stack([rng.integers(0, 28, 96), rng.integers(0, 257, 96), rng.integers(0, 257, 96)], axis=1)
+            # make sure the anti-diagonal (n + m = 256) and the centre are represented
+            idx[:16, 2] = 256 - idx[:16, 1]
+            idx[16] = (0, 128, 128)
+            out["M22_idx"] = idx
+            out["M22_val"] = nl.M22[idx[:, 0], idx[:, 1], idx[:, 2]]
+            out["M13"] = nl.M13
+            out["Pow"] = nl.fft.Pow
+            lidx = np.stack([rng.integers(0, 3, 64), rng.integers(0, 257, 64), rng.integers(0, 257, 64)], axis=1)
+            out["Ml_idx"], out["Ml_val"] = lidx, nl.Ml[lidx[:, 0], lidx[:, 1], lidx[:, 2]]
+        out[f"Mcf11_Nl{Nl}"], out[f"Mcfct_Nl{Nl}"] = nl.Mcf11, nl.Mcfct
+        out[f"l11_Nl{Nl}"], out[f"lct_Nl{Nl}"], out[f"l22_Nl{Nl}"], out[f"l13_Nl{Nl}"] = co.l11, co.lct, co.l22, co.l13
+        rs = pb.Resum(co=co)
+        out[f"resumM_Nl{Nl}"], out[f"XM_Nl{Nl}"] = rs.M, rs.XM
+        fs = np.array([0.0, 0.5, 0.8, 1.0])
+        qs = []
+        for f in fs:
+            rs.makeQ(f)
+            qs.append(rs.Q.copy())
+        out[f"Q_f_Nl{Nl}"], out["Q_fvals"] = np.array(qs), fs
+    # reference tests/compare/test_fftlog.py:5-16 (Gaussian in log k, padding, window 0.3)
+    klim = np.logspace(-4, 0, 200)
+    pklim = np.exp(-((np.log(klim) - np.log(klim[klim.size // 2])) ** 2))
+    fft = ref.fftlog.FFTLog(Nmax=256, xmin=10**-5, xmax=10, bias=-0.3)
+    out["fftlog_gauss_k"], out["fftlog_gauss_p"] = klim, pklim
+    out["fftlog_gauss_coef"] = fft.Coef(klim, pklim, extrap="padding", window=0.3)
+    out["fftlog_gauss_coef_batch"] = fft.Coef(klim, np.vstack([pklim, 2 * pklim]), extrap="padding", window=0.3)
+    # reference tests/test_pybird.py:5-11 known answers (stated values) and what the code returns here
+    out["known_Hubble_0.2_1.0"] = np.array([1.549193338482967, pb.Hubble(0.2, 1.0)])
+    out["known_DAfunc_0.2_1.0"] = np.array([0.4117451980802465, pb.DAfunc(0.2, 1.0)])
+    out["chain_coeff"] = np.array([ref.chained.chain_coeff(l) for l in (0, 2, 4)])
+    np.savez_compressed(os.path.join(GOLD, "tables.npz"), **out)
+    print("tables written")
+
+
+def main():
+    ref = load_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    want = sys.argv[1:] or (["tables"] + list(CASES))
+    for name in want:
+        if name == "tables":
+            tables_fixture(ref)
+        else:
+            run_case(ref, name, CASES[name])
+
+
+if __name__ == "__main__":
+    main()
