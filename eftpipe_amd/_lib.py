@@ -1,0 +1,82 @@
+"""ctypes binding of libeftbird.so (include/eftbird.h).  Thin on purpose: no numerics live here.
+
+The library is built in-tree (``eftpipe_amd/libeftbird.so``) by ``eftpipe_amd.build.build()``
+(``hipcc --offload-arch=gfx950``).  There is no CPU fallback: if the shared object is missing, or no
+HIP device is visible when an engine is created, the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeftbird.so")
+
+
+class EftbError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    """struct eftb_config (include/eftbird.h)"""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "device", "Nl", "Nk", "Nkin", "max_batch", "with_resum", "with_ap", "ap_stochastic", "nmu",
+        "ntail", "nxtail", "nsteps", "ncolsC", "NIR", "Na", "Nklow", "nproj", "nproj_l")]
+
+
+# enum eftb_table / eftb_buffer / eftb_stage (same order as the header)
+TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL KPOW SPOW PAIRS22 PAIRSC PLAN M13R C11R CCTR L11 LCT L22 L13 GRP "
+          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H MU WMU LEGMU SPDX SPLOWER SPINV SPCP APFID PROJ").split()
+T = {n: i for i, n in enumerate(TABLES)}
+BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK PROJ COEF".split()
+B = {n: i for i, n in enumerate(BUFFERS)}
+S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE = (1 << i for i in range(8))
+
+EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_destroy eftb_put eftb_get eftb_buffer_size eftb_run "
+           "eftb_sync eftb_run_timed eftb_eval_batch eftb_mfma_f64_peak eftb_last_error eftb_version").split()
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare the prototypes; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EftbError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950); eftpipe_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    dp, vp, sz, i32 = C.POINTER(C.c_double), C.c_void_p, C.c_size_t, C.c_int
+    lib.eftb_create.argtypes, lib.eftb_create.restype = [C.POINTER(Config), C.POINTER(vp)], i32
+    lib.eftb_set_table.argtypes, lib.eftb_set_table.restype = [vp, i32, vp, sz], i32
+    lib.eftb_finalize.argtypes, lib.eftb_finalize.restype = [vp], i32
+    lib.eftb_destroy.argtypes, lib.eftb_destroy.restype = [vp], None
+    lib.eftb_put.argtypes, lib.eftb_put.restype = [vp, i32, sz, dp, sz], i32
+    lib.eftb_get.argtypes, lib.eftb_get.restype = [vp, i32, sz, dp, sz], i32
+    lib.eftb_buffer_size.argtypes, lib.eftb_buffer_size.restype = [vp, i32], sz
+    lib.eftb_run.argtypes, lib.eftb_run.restype = [vp, i32, i32], i32
+    lib.eftb_sync.argtypes, lib.eftb_sync.restype = [vp], i32
+    lib.eftb_run_timed.argtypes, lib.eftb_run_timed.restype = [vp, i32, i32, i32, C.POINTER(C.c_float)], i32
+    lib.eftb_eval_batch.argtypes, lib.eftb_eval_batch.restype = [vp, i32, dp, dp, dp, dp, dp, dp, dp], i32
+    lib.eftb_mfma_f64_peak.argtypes, lib.eftb_mfma_f64_peak.restype = [i32, dp], i32
+    lib.eftb_last_error.argtypes, lib.eftb_last_error.restype = [], C.c_char_p
+    lib.eftb_version.argtypes, lib.eftb_version.restype = [], C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EftbError(load().eftb_last_error().decode())
+
+
+def dptr(a):
+    """float64 C-contiguous ndarray -> double* (None -> NULL)"""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))

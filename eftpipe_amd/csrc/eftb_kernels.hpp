@@ -1,0 +1,619 @@
+// eftb_kernels.hpp -- HIP kernels of the one-loop engine, written for gfx950 (MI355X, CDNA4) only.
+//
+// Everything is FP64.  The two dense contractions (P22 and the xi-space C22/C13) run on the FP64
+// matrix cores (v_mfma_f64_16x16x4_f64) as a "pair GEMM": rows = (cosmology, k) points, K = the
+// 33 153 unordered index pairs (n <= m) of the real-reduced FFTLog vector u[257], N = loop matrices.
+// The A operand u_n*u_m is formed in registers from an LDS-resident tile of u; the B operand streams
+// from HBM/L2 in a layout that is exactly one MFMA fragment per 512 contiguous bytes.
+// The remaining stages are small streaming kernels (wave reductions, Horner sums, spline sweeps).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eftb {
+
+constexpr int NS = 80;       // |sbird|                         reference pybird.py:481-482
+constexpr int NPOW = 257;    // FFTLog powers (NFFT + 1)         reference pybird.py:919
+constexpr int NHALF = 128;
+constexpr int NCH = 129;     // independent complex coefficients
+constexpr int UPAD = 260;    // HBM row stride of u (doubles), 16-byte aligned rows
+constexpr int ULDS = 258;    // LDS row stride of u: 258 = 2 (mod 32) -> conflict-free ds_read_b64
+constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl) + 12 (Ploopl) + 3 (Pstl)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// prep: P11 = spline(kin -> k) and the 129 independent FFTLog coefficients, both as pre-folded real
+// operators on Pin, plus the high-k power-law tail (reference pybird.py:694-695, fftlog.py:84-166).
+// One workgroup per cosmology.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, const double* __restrict__ Pin,
+                                                   const double* __restrict__ lnkin, const double* __restrict__ SkT,
+                                                   const double* __restrict__ GcT, const double* __restrict__ EcT,
+                                                   const double* __restrict__ lnxtail, double* __restrict__ P11,
+                                                   double* __restrict__ coef) {
+    extern __shared__ double sm[];
+    double* pin = sm;
+    double* tail = sm + Nkin;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < Nkin; j += blockDim.x) pin[j] = Pin[(size_t)w * Nkin + j];
+    __syncthreads();
+    // slope / amplitude from the last two samples (reference fftlog.py:146-151)
+    const double slope = (log(pin[Nkin - 1]) - log(pin[Nkin - 2])) / (lnkin[Nkin - 1] - lnkin[Nkin - 2]);
+    const double amp = pin[Nkin - 1] * exp(-slope * lnkin[Nkin - 1]);
+    for (int i = tid; i < ntail; i += blockDim.x) tail[i] = amp * exp(slope * lnxtail[i]);
+    __syncthreads();
+    for (int k = tid; k < Nk; k += blockDim.x) {
+        double acc = 0.0;
+        for (int j = 0; j < Nkin; ++j) acc = fma(SkT[(size_t)j * Nk + k], pin[j], acc);
+        P11[(size_t)w * Nk + k] = acc;
+    }
+    for (int idx = tid; idx < 2 * NCH; idx += blockDim.x) {
+        const int c = idx / NCH, n = idx % NCH;
+        const double* g = GcT + (size_t)c * Nkin * NCH + n;
+        double acc = 0.0;
+        for (int j = 0; j < Nkin; ++j) acc = fma(g[(size_t)j * NCH], pin[j], acc);
+        const double* e = EcT + (size_t)c * ntail * NCH + n;
+        for (int i = 0; i < ntail; ++i) acc = fma(e[(size_t)i * NCH], tail[i], acc);
+        coef[(size_t)w * 2 * NCH + idx] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// uvec: u[row] = (Re x_0..Re x_127, x_128, Im x_0..Im x_127), x_n = Coef_n * r^{p_n} with r^{p_n} from
+// the pow table of the row's abscissa (k^Pow or s^(-Pow-3); reference pybird.py:1066-1072).
+// grid (rows, B), lanes along n -> coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uvec_kernel(int rows, const double* __restrict__ coef, const double* __restrict__ pw,
+                                                   double* __restrict__ U) {
+    const int row = blockIdx.x, w = blockIdx.y;
+    const double* c = coef + (size_t)w * 2 * NCH;
+    const double* p = pw + (size_t)row * 2 * NCH;
+    double* u = U + ((size_t)w * rows + row) * UPAD;
+    for (int n = threadIdx.x; n < UPAD; n += blockDim.x) {
+        double v = 0.0;
+        if (n < NHALF) v = c[n] * p[n] - c[NCH + n] * p[NCH + n];
+        else if (n == NHALF) v = c[NHALF] * p[NHALF];
+        else if (n < NPOW) {
+            const int q = n - NCH;
+            v = c[q] * p[NCH + q] + c[NCH + q] * p[q];
+        }
+        u[n] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair GEMM on the FP64 matrix cores.
+//   out[row, col] = scale[row] * sum_{t, g} u[row, n_t] u[row, m_t + g] * frag[t][col/16][g][col%16]
+// Workgroup = 4 waves = MT*16 rows, the whole K range split 4 ways over the waves (one wave per SIMD,
+// each with MT*NT independent accumulator tiles); the u tile lives in LDS (stride 258 doubles), the B
+// fragments are read once per workgroup straight into registers (8 B/lane, 512 B per instruction).
+// MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][j = lane & 15], D reg q -> row (lane >> 4) + 4 q, col lane & 15.
+// Output element (row, col) is written to out[w][col][r] (w = row / rows_per_w, r = row % rows_per_w).
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
+                                                           const int* __restrict__ plan, int rows_total, int rows_per_w,
+                                                           int ncols_out, const double* __restrict__ rowscale,
+                                                           double* __restrict__ out) {
+    constexpr int ROWS = MT * 16;
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS;
+
+    // ---- stage the u tile: 130 x 16-byte pieces per row (cols 0..259), LDS stride 258
+    for (int idx = tid; idx < ROWS * 130; idx += 256) {
+        const int r = idx / 130, c = idx % 130;
+        double2 v = make_double2(0.0, 0.0);
+        if (row0 + r < rows_total) v = *reinterpret_cast<const double2*>(U + (size_t)(row0 + r) * UPAD + 2 * c);
+        if (c < 129) *reinterpret_cast<double2*>(sm + r * ULDS + 2 * c) = v;
+    }
+    if (tid < 8) sm[ROWS * ULDS + tid] = 0.0;  // slack read by the zero-weight pad pairs of the last row
+    __syncthreads();
+
+    const int r = lane & 15, g = lane >> 4;
+    int n = plan[wave * 4 + 0], m0 = plan[wave * 4 + 1];
+    const int t0 = plan[wave * 4 + 2], nsteps = plan[wave * 4 + 3];
+    const double* fp = frag + ((size_t)t0 * NT) * 64 + lane;
+
+    v4d acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    double un[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) un[i] = sm[(r + 16 * i) * ULDS + n];
+
+    double bcur[NT], bnxt[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bcur[j] = fp[j * 64];
+    fp += NT * 64;
+
+    for (int it = 0; it < nsteps; ++it) {
+        // prefetch the next step's B fragments (the table has one zero step of padding at the end)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bnxt[j] = fp[j * 64];
+        fp += NT * 64;
+        double a[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = un[i] * sm[(r + 16 * i) * ULDS + m0 + g];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bcur[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
+        m0 += 4;
+        if (m0 > 2 * NHALF) {  // wave-uniform: next n-run
+            ++n;
+            m0 = n;
+            if (n < NPOW) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) un[i] = sm[(r + 16 * i) * ULDS + n];
+            }
+        }
+    }
+
+    // ---- reduce the 4 K-slices through LDS (the u tile is dead now) and write out
+    __syncthreads();
+    constexpr int PER_WAVE = MT * NT * 4 * 64;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sm[wave * PER_WAVE + ((i * NT + j) * 4 + q) * 64 + lane] = acc[i][j][q];
+    __syncthreads();
+    for (int e = tid; e < ROWS * NT * 16; e += 256) {
+        const int row = e % ROWS, col = e / ROWS;
+        if (col >= ncols_out || row0 + row >= rows_total) continue;
+        const int i = row >> 4, rr = row & 15, q = rr >> 2, gg = rr & 3;
+        const int j = col >> 4, ln = gg * 16 + (col & 15);
+        const int off = ((i * NT + j) * 4 + q) * 64 + ln;
+        double v = (sm[off] + sm[PER_WAVE + off]) + (sm[2 * PER_WAVE + off] + sm[3 * PER_WAVE + off]);
+        const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
+        if (rowscale) v *= rowscale[rw];
+        out[((size_t)w * ncols_out + col) * rows_per_w + rw] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rowdot: out[v] = sum_n u[row][n] * vec[v][n] for a handful of real-reduced vectors (P13: 10; C11 and
+// Cct: 2*Nl).  One wave per row, lanes along n, shuffle reduction (reference pybird.py:1080-1101).
+// mode 0: P13[w][b][k] = k^3 P11[k] dot_b ; mode 1: C11[w][l][s] = dot_l, Cct[w][l][s] = s^-2 dot_{Nl+l}
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void rowdot_kernel(int mode, int rows, int Nl, const double* __restrict__ U,
+                                                     const double* __restrict__ vecA, const double* __restrict__ vecB,
+                                                     const double* __restrict__ absc, const double* __restrict__ P11,
+                                                     double* __restrict__ outA, double* __restrict__ outB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave, w = blockIdx.y;
+    if (row >= rows) return;
+    const double* u = U + ((size_t)w * rows + row) * UPAD;
+    const int nv = (mode == 0) ? 10 : 2 * Nl;
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (int n = lane; n < NPOW; n += 64) {
+        const double x = u[n];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv) {
+                const double* vec = (mode == 0 || v < Nl) ? vecA + (size_t)v * NPOW : vecB + (size_t)(v - Nl) * NPOW;
+                acc[v] = fma(vec[n], x, acc[v]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[v] += __shfl_down(acc[v], o, 64);
+    if (lane == 0) {
+        const double x = absc[row];
+        if (mode == 0) {
+            const double sc = x * x * x * P11[(size_t)w * rows + row];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (v < 10) outA[((size_t)w * 10 + v) * rows + row] = sc * acc[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v < Nl) outA[((size_t)w * Nl + v) * rows + row] = acc[v];
+                else if (v < 2 * Nl) outB[((size_t)w * Nl + (v - Nl)) * rows + row] = acc[v] / (x * x);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// regroup: Bird.setPsCfl -- multipole weights, 28+10 -> 12 bias groups with powers of f, shot-noise
+// subtraction, stochastic templates (reference pybird.py:737-866).  grp[b] = (group, power of f).
+// Writes the template block T[w][l][24][Nk].
+// ------------------------------------------------------------------------------------------------
+__device__ inline double ipow(double f, int p) {
+    double r = 1.0;
+    for (int i = 0; i < p; ++i) r *= f;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ fgrow,
+                                                      const double* __restrict__ P11, const double* __restrict__ P22,
+                                                      const double* __restrict__ P13, const double* __restrict__ l11,
+                                                      const double* __restrict__ lct, const double* __restrict__ l22,
+                                                      const double* __restrict__ l13, const int* __restrict__ grp,
+                                                      double* __restrict__ T) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y % NROW, l = blockIdx.y / NROW, w = blockIdx.z;
+    if (k >= Nk) return;
+    const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
+    double v = 0.0;
+    if (row < 3) v = l11[l * 3 + row] * p11;
+    else if (row < 9) v = lct[l * 6 + (row - 3)] * kv * kv * p11;
+    else if (row < 21) {
+        const int i = row - 9;
+        const double f = fgrow[w];
+        double a = 0.0, a0 = 0.0;
+        for (int b = 0; b < 28; ++b)
+            if (grp[2 * b] == i) {
+                const double c = ipow(f, grp[2 * b + 1]) * l22[l * 28 + b];
+                const double* p = P22 + ((size_t)w * 28 + b) * Nk;
+                a += c * p[k];
+                a0 += c * p[0];
+            }
+        for (int b = 0; b < 10; ++b)
+            if (grp[2 * (28 + b)] == i) {
+                const double c = ipow(f, grp[2 * (28 + b) + 1]) * l13[l * 10 + b];
+                const double* p = P13 + ((size_t)w * 10 + b) * Nk;
+                a += c * p[k];
+                a0 += c * p[0];
+            }
+        v = a - a0;
+    } else {
+        const int j = row - 21;
+        if (l == 0 && j == 0) v = 1.0;
+        else if ((l == 0 && j == 1) || (l == 1 && j == 2)) v = kv * kv;
+    }
+    T[(((size_t)w * Nl + l) * NROW + row) * Nk + k] = v;
+}
+
+// Cloopl[w][l][12][80] from CC[w][Nl*38][80] (C22 then C13; reference pybird.py:752-753, 805-846)
+__global__ __launch_bounds__(128) void regroup_cf_kernel(int Nl, const double* __restrict__ fgrow, const double* __restrict__ CC,
+                                                         const double* __restrict__ l22, const double* __restrict__ l13,
+                                                         const int* __restrict__ grp, double* __restrict__ Cloopl) {
+    const int s = threadIdx.x, i = blockIdx.x, l = blockIdx.y, w = blockIdx.z;
+    if (s >= NS) return;
+    const double f = fgrow[w];
+    const double* cc = CC + (size_t)w * Nl * 38 * NS;
+    double a = 0.0;
+    for (int b = 0; b < 28; ++b)
+        if (grp[2 * b] == i) a += ipow(f, grp[2 * b + 1]) * l22[l * 28 + b] * cc[(size_t)(l * 28 + b) * NS + s];
+    for (int b = 0; b < 10; ++b)
+        if (grp[2 * (28 + b)] == i)
+            a += ipow(f, grp[2 * (28 + b) + 1]) * l13[l * 10 + b] * cc[(size_t)(Nl * 28 + l * 10 + b) * NS + s];
+    Cloopl[(((size_t)w * Nl + l) * 12 + i) * NS + s] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IR filters X(s), Y(s) as folded operators on Pin + tail, and Q(f) by Horner
+// (reference pybird.py:1316-1353, 1367-1380).  One workgroup per cosmology.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void irfilter_kernel(int Nkin, int nxtail, int nq, const double* __restrict__ Pin,
+                                                       const double* __restrict__ fgrow, const double* __restrict__ lnkin,
+                                                       const double* __restrict__ BXT, const double* __restrict__ BYT,
+                                                       const double* __restrict__ TXT, const double* __restrict__ TYT,
+                                                       const double* __restrict__ lnxxtail, const double* __restrict__ wq2,
+                                                       const double* __restrict__ Qpoly, double* __restrict__ XY,
+                                                       double* __restrict__ Q) {
+    extern __shared__ double sm[];
+    double* pin = sm;
+    double* tail = sm + Nkin;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < Nkin; j += blockDim.x) pin[j] = Pin[(size_t)w * Nkin + j];
+    __syncthreads();
+    const double q1 = pin[Nkin - 1] * wq2[1], q0 = pin[Nkin - 2] * wq2[0];
+    const double slope = (log(q1) - log(q0)) / (lnkin[Nkin - 1] - lnkin[Nkin - 2]);
+    const double amp = q1 * exp(-slope * lnkin[Nkin - 1]);
+    for (int i = tid; i < nxtail; i += blockDim.x) tail[i] = amp * exp(slope * lnxxtail[i]);
+    __syncthreads();
+    for (int idx = tid; idx < 2 * NS; idx += blockDim.x) {
+        const int c = idx / NS, s = idx % NS;
+        const double* B = c ? BYT : BXT;
+        const double* Tt = c ? TYT : TXT;
+        double acc = 0.0;
+        for (int j = 0; j < Nkin; ++j) acc = fma(B[(size_t)j * NS + s], pin[j], acc);
+        for (int i = 0; i < nxtail; ++i) acc = fma(Tt[(size_t)i * NS + s], tail[i], acc);
+        XY[(size_t)w * 2 * NS + idx] = acc;
+    }
+    // Q[a] = table[1 - a] (reference pybird.py:1374-1376); nq = Nl*Nl*Nn entries per table
+    const double f = fgrow[w];
+    for (int idx = tid; idx < 2 * nq; idx += blockDim.x) {
+        const int a = idx / nq, rest = idx % nq;
+        const double* c = Qpoly + ((size_t)(1 - a) * nq + rest) * 15;
+        double acc = c[14];
+#pragma unroll
+        for (int p = 13; p >= 0; --p) acc = fma(acc, f, c[p]);
+        Q[(size_t)w * 2 * nq + idx] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resum: the whole of Resum.Ps after the filters (reference pybird.py:1409-1462) collapsed to
+//   W_a[l,l'](k,s) = sum_v H[v](k,s) * sum_j Q_a[l,l',j*Na+v] * phi_j(k,s),
+//   phi_j = (k^2 X)^(j+1) (j < NIR),  k^2 Y (k^2 X)^(j-NIR) (j >= NIR)
+//   P11l += sum_{l',s} l11[l',i] W_0 C11[l',s];  Pctl += ... lct W_1 Cct;  Ploopl += W_1 Cloopl[l',i,s]
+// H folds the 192-point FFTLog of XpYp*C and the j_{2v} Bessel sum (tables.py).  Lanes along k, the s
+// range is split over blockIdx.y (partials summed by resum_sum_kernel when nchunk > 1).
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(64) void resum_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
+                                                   const double* __restrict__ XY, const double* __restrict__ Q,
+                                                   const double* __restrict__ H, const double* __restrict__ C11,
+                                                   const double* __restrict__ Cct, const double* __restrict__ Cloopl,
+                                                   const double* __restrict__ l11, const double* __restrict__ lct,
+                                                   double* __restrict__ dst, int accumulate) {
+    constexpr int NIR = (NL == 3) ? 16 : 8;
+    constexpr int NA = (NL == 3) ? 3 : 2;
+    constexpr int NN = 2 * NIR * NA;
+    const int k = blockIdx.x * 64 + threadIdx.x, chunk = blockIdx.y, w = blockIdx.z;
+    const bool live = (k < Nk) && (k >= Nklow);
+    const int kc = live ? k : Nklow;
+    const double k2 = kk[kc] * kk[kc];
+    const double* q = Q + (size_t)w * 2 * NL * NL * NN;
+    double acc[NL][21];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int i = 0; i < 21; ++i) acc[l][i] = 0.0;
+
+    const int s0 = chunk * schunk, s1 = min(NS, s0 + schunk);
+    for (int s = s0; s < s1; ++s) {
+        const double z = k2 * XY[(size_t)w * 2 * NS + s], yk = k2 * XY[(size_t)w * 2 * NS + NS + s];
+        double phi[2 * NIR];
+        double zp = 1.0;
+#pragma unroll
+        for (int p = 0; p < NIR; ++p) {
+            phi[NIR + p] = yk * zp;
+            zp *= z;
+            phi[p] = zp;
+        }
+        double h[NA];
+#pragma unroll
+        for (int v = 0; v < NA; ++v) h[v] = H[((size_t)v * NS + s) * Nk + kc];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                double W[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const double* qa = q + ((size_t)(a * NL + l) * NL + lp) * NN;
+                    double wv = 0.0;
+#pragma unroll
+                    for (int v = 0; v < NA; ++v) {
+                        double zsum = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 2 * NIR; ++j) zsum = fma(qa[j * NA + v], phi[j], zsum);
+                        wv = fma(h[v], zsum, wv);
+                    }
+                    W[a] = wv;
+                }
+                const double c11 = W[0] * C11[((size_t)w * NL + lp) * NS + s];
+                const double cct = W[1] * Cct[((size_t)w * NL + lp) * NS + s];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[l][i] = fma(l11[lp * 3 + i], c11, acc[l][i]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) acc[l][3 + i] = fma(lct[lp * 6 + i], cct, acc[l][3 + i]);
+                const double* cl = Cloopl + (((size_t)w * NL + lp) * 12) * NS + s;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) acc[l][9 + i] = fma(W[1], cl[i * NS], acc[l][9 + i]);
+            }
+        }
+    }
+    if (k >= Nk) return;
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int i = 0; i < 21; ++i) {
+            const double v = live ? acc[l][i] : 0.0;
+            if (accumulate) dst[(((size_t)w * NL + l) * NROW + i) * Nk + k] += v;
+            else dst[((((size_t)w * gridDim.y + chunk) * NL + l) * 21 + i) * Nk + k] = v;
+        }
+}
+
+__global__ __launch_bounds__(256) void resum_sum_kernel(int Nk, int Nl, int nchunk, const double* __restrict__ part,
+                                                        double* __restrict__ T) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y % 21, l = blockIdx.y / 21, w = blockIdx.z;
+    if (k >= Nk) return;
+    double a = 0.0;
+    for (int c = 0; c < nchunk; ++c) a += part[((((size_t)w * nchunk + c) * Nl + l) * 21 + i) * Nk + k];
+    T[(((size_t)w * Nl + l) * NROW + i) * Nk + k] += a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AP: not-a-knot cubic spline of every template row (pre-factored tridiagonal system, tables.py
+// spline_factors), then for each (row, k): P(k', mu') = sum_l' spline_l'(k') L_l'(mu'), projected back
+// on (2l+1)/2 L_l(mu) with the trapezoid rule on linspace(0,1,nmu) (reference pybird.py:1581-1621).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void spline_kernel(int Nk, int nseries, const double* __restrict__ T, const double* __restrict__ dx,
+                                                    const double* __restrict__ lower, const double* __restrict__ inv,
+                                                    const double* __restrict__ cp, double* __restrict__ SD) {
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nseries) return;
+    const double* y = T + (size_t)sidx * Nk;
+    double* sd = SD + (size_t)sidx * Nk;
+    const int n = Nk;
+    // forward sweep
+    double s_prev = (y[1] - y[0]) / dx[0], s_cur = (y[2] - y[1]) / dx[1];
+    double d = dx[0] + dx[1];
+    double rhs = ((dx[0] + 2.0 * d) * dx[1] * s_prev + dx[0] * dx[0] * s_cur) / d;
+    double wprev = rhs * inv[0];
+    sd[0] = wprev;
+    for (int i = 1; i < n - 1; ++i) {
+        s_cur = (y[i + 1] - y[i]) / dx[i];
+        rhs = 3.0 * (dx[i] * s_prev + dx[i - 1] * s_cur);
+        wprev = (rhs - lower[i] * wprev) * inv[i];
+        sd[i] = wprev;
+        s_prev = s_cur;
+    }
+    {
+        // s_prev = slope[n-2]; need slope[n-3]
+        const double sl3 = (y[n - 2] - y[n - 3]) / dx[n - 3];
+        d = dx[n - 2] + dx[n - 3];
+        rhs = (dx[n - 2] * dx[n - 2] * sl3 + (2.0 * d + dx[n - 2]) * dx[n - 3] * s_prev) / d;
+        wprev = (rhs - lower[n - 1] * wprev) * inv[n - 1];
+        sd[n - 1] = wprev;
+    }
+    // back substitution
+    double nxt = wprev;
+    for (int i = n - 2; i >= 0; --i) {
+        nxt = sd[i] - cp[i] * nxt;
+        sd[i] = nxt;
+    }
+}
+
+template <int NL>
+__global__ __launch_bounds__(64) void ap_kernel(int Nk, int nmu, int nrows_ap, const double* __restrict__ kk,
+                                                const double* __restrict__ dxk, const double* __restrict__ DAw,
+                                                const double* __restrict__ Hw, const double* __restrict__ fid,
+                                                const double* __restrict__ mu, const double* __restrict__ wmu,
+                                                const double* __restrict__ legmu, const double* __restrict__ T,
+                                                const double* __restrict__ SD, double* __restrict__ Tout) {
+    const int k = blockIdx.x * 64 + threadIdx.x, row = blockIdx.y, w = blockIdx.z;
+    if (k >= Nk) return;
+    if (row >= nrows_ap) {  // rows that APeffect leaves alone (Pstl unless APst)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const size_t o = (((size_t)w * NL + l) * NROW + row) * Nk + k;
+            Tout[o] = T[o];
+        }
+        return;
+    }
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
+    const double kq = kk[k] / qperp;
+    const double* y[NL];
+    const double* sd[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        y[l] = T + (((size_t)w * NL + l) * NROW + row) * Nk;
+        sd[l] = SD + (((size_t)w * NL + l) * NROW + row) * Nk;
+    }
+    // locate the first interval by bisection, then hunt (k' is monotonic in mu)
+    int i0;
+    {
+        int lo = 0, hi = Nk - 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (kk[mid] <= kq) lo = mid; else hi = mid;
+        }
+        i0 = lo;
+    }
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    for (int j = 0; j < nmu; ++j) {
+        const double m = mu[j];
+        const double root = sqrt(1.0 + m * m * g);
+        const double kp = kq * root, mp = m / (F * root), x2 = mp * mp;
+        while (i0 < Nk - 2 && kp >= kk[i0 + 1]) ++i0;
+        while (i0 > 0 && kp < kk[i0]) --i0;
+        const double t = kp - kk[i0], h = dxk[i0];
+        double Lp[3];
+        Lp[0] = 1.0;
+        Lp[1] = 0.5 * (3.0 * x2 - 1.0);
+        Lp[2] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
+        double pk = 0.0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const double y0 = y[l][i0], y1 = y[l][i0 + 1], s0 = sd[l][i0], s1 = sd[l][i0 + 1];
+            const double sl = (y1 - y0) / h;
+            const double c3 = (s0 + s1 - 2.0 * sl) / (h * h);
+            const double c2 = (sl - s0) / h - c3 * h;
+            pk = fma(Lp[l], y0 + t * (s0 + t * (c2 + t * c3)), pk);
+        }
+        const double wj = wmu[j] * pk;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) acc[l] = fma(legmu[l * nmu + j], wj, acc[l]);
+    }
+    const double c = 2.0 / (qperp * qperp * qpar);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) Tout[(((size_t)w * NL + l) * NROW + row) * Nk + k] = c * acc[l];
+}
+
+// ------------------------------------------------------------------------------------------------
+// reduce: P_l(k) = sum_row bias[row] * T[l][row][k]  (reference parambasis.py:128-136)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const double* __restrict__ bias, const double* __restrict__ T,
+                                                     double* __restrict__ Plk) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, w = blockIdx.z;
+    if (k >= Nx) return;
+    const double* b = bias + (size_t)w * NROW;
+    const double* t = T + (((size_t)w * Nl + l) * NROW) * Nx + k;
+    double a = 0.0;
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) a = fma(b[r], t[(size_t)r * Nx], a);
+    Plk[((size_t)w * Nl + l) * Nx + k] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// project: out[w][a][row][x] = sum_{l,k} Proj[a][l][x][k] * T[w][l][row][k]  -- the window convolution,
+// the k-binning and the chained combination, each folded with its cubic spline on the host
+// (reference window.py:371-387, binning.py:131-144, chained.py:56-68).  Lanes along (row, w) columns.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void project_kernel(int Nk, int Nl, int nx, int na, const double* __restrict__ Proj,
+                                                      const double* __restrict__ T, double* __restrict__ out) {
+    // one workgroup per (x, a, w): 24 rows x Nl*Nk reduction, wave-parallel over k
+    const int x = blockIdx.x, a = blockIdx.y, w = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double red[4][NROW];
+    double acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = 0.0;
+    // wave handles rows wave*6 .. wave*6+5
+    for (int l = 0; l < Nl; ++l) {
+        const double* p = Proj + (((size_t)a * Nl + l) * nx + x) * Nk;
+        const double* t = T + (((size_t)w * Nl + l) * NROW + wave * 6) * Nk;
+        for (int k = lane; k < Nk; k += 64) {
+            const double pv = p[k];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[i] = fma(pv, t[(size_t)i * Nk + k], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_down(acc[i], o, 64);
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) red[wave][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < NROW) {
+        const int r = threadIdx.x;
+        out[(((size_t)w * na + a) * NROW + r) * nx + x] = red[r / 6][r % 6];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FP64 MFMA issue-rate microbenchmark (roofline denominator): NACC independent accumulator chains.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double* sink) {
+    v4d acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) sink[0] = s;
+}
+
+}  // namespace eftb

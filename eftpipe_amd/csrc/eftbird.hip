@@ -1,0 +1,423 @@
+// eftbird.hip -- C ABI of libeftbird.so (see include/eftbird.h) and the stage scheduler.
+// gfx950 only.  No CPU fallback: every entry point needs a HIP device.
+#include "../../include/eftbird.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "eftb_kernels.hpp"
+
+using namespace eftb;
+
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct eftb_engine {
+    eftb_config c;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool finalized = false;
+    void* tab[EFTB_T_COUNT] = {nullptr};
+    size_t tab_bytes[EFTB_T_COUNT] = {0};
+    double* buf[EFTB_B_COUNT] = {nullptr};
+    size_t buf_elems[EFTB_B_COUNT] = {0};
+    // scratch
+    double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr;
+    int resum_chunks = 1;
+    int Nn = 0;
+    double* k3 = nullptr;  // k^3 row scale of P22
+};
+
+static size_t need_table_bytes(const eftb_config& c, int id) {
+    const size_t D = sizeof(double);
+    const int Nn = 2 * c.NIR * c.Na;
+    switch (id) {
+        case EFTB_T_K: return D * c.Nk;
+        case EFTB_T_S: return D * NS;
+        case EFTB_T_LNKIN: return D * c.Nkin;
+        case EFTB_T_SKT: return D * c.Nkin * c.Nk;
+        case EFTB_T_GCT: return D * 2 * c.Nkin * NCH;
+        case EFTB_T_ECT: return D * 2 * c.ntail * NCH;
+        case EFTB_T_LNXTAIL: return D * c.ntail;
+        case EFTB_T_KPOW: return D * c.Nk * 2 * NCH;
+        case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
+        case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + 1) * 2 * 64;
+        case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + 1) * (c.ncolsC / 16) * 64 : 0;
+        case EFTB_T_PLAN: return sizeof(int32_t) * 16;
+        case EFTB_T_M13R: return D * 10 * NPOW;
+        case EFTB_T_C11R: return c.with_resum ? D * c.Nl * NPOW : 0;
+        case EFTB_T_CCTR: return c.with_resum ? D * c.Nl * NPOW : 0;
+        case EFTB_T_L11: return D * c.Nl * 3;
+        case EFTB_T_LCT: return D * c.Nl * 6;
+        case EFTB_T_L22: return D * c.Nl * 28;
+        case EFTB_T_L13: return D * c.Nl * 10;
+        case EFTB_T_GRP: return sizeof(int32_t) * 38 * 2;
+        case EFTB_T_BXT: case EFTB_T_BYT: return c.with_resum ? D * c.Nkin * NS : 0;
+        case EFTB_T_TXT: case EFTB_T_TYT: return c.with_resum ? D * c.nxtail * NS : 0;
+        case EFTB_T_LNXXTAIL: return c.with_resum ? D * c.nxtail : 0;
+        case EFTB_T_WQLAST2: return c.with_resum ? D * 2 : 0;
+        case EFTB_T_QPOLY: return c.with_resum ? D * 2 * c.Nl * c.Nl * Nn * 15 : 0;
+        case EFTB_T_H: return c.with_resum ? D * c.Na * NS * c.Nk : 0;
+        case EFTB_T_MU: case EFTB_T_WMU: return c.with_ap ? D * c.nmu : 0;
+        case EFTB_T_LEGMU: return c.with_ap ? D * c.Nl * c.nmu : 0;
+        case EFTB_T_SPDX: return c.with_ap ? D * (c.Nk - 1) : 0;
+        case EFTB_T_SPLOWER: case EFTB_T_SPINV: case EFTB_T_SPCP: return c.with_ap ? D * c.Nk : 0;
+        case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
+        case EFTB_T_PROJ: return c.nproj > 0 ? D * (size_t)c.nproj_l * c.Nl * c.nproj * c.Nk : 0;
+    }
+    return 0;
+}
+
+static size_t need_buffer_elems(const eftb_config& c, int id) {
+    const size_t B = c.max_batch;
+    const int Nn = 2 * c.NIR * c.Na;
+    switch (id) {
+        case EFTB_B_PIN: return B * c.Nkin;
+        case EFTB_B_F: case EFTB_B_DA: case EFTB_B_H: return B;
+        case EFTB_B_P11: return B * c.Nk;
+        case EFTB_B_P22: return B * 28 * c.Nk;
+        case EFTB_B_P13: return B * 10 * c.Nk;
+        case EFTB_B_C11: case EFTB_B_CCT: return c.with_resum ? B * c.Nl * NS : 0;
+        case EFTB_B_CC: return c.with_resum ? B * c.Nl * 38 * NS : 0;
+        case EFTB_B_CLOOPL: return c.with_resum ? B * c.Nl * 12 * NS : 0;
+        case EFTB_B_TEMPL: return B * c.Nl * NROW * c.Nk;
+        case EFTB_B_XY: return c.with_resum ? B * 2 * NS : 0;
+        case EFTB_B_Q: return c.with_resum ? B * 2 * c.Nl * c.Nl * Nn : 0;
+        case EFTB_B_BIAS: return B * NROW;
+        case EFTB_B_PLK: return B * c.Nl * c.Nk;
+        case EFTB_B_PROJ: return c.nproj > 0 ? B * c.nproj_l * NROW * c.nproj : 0;
+        case EFTB_B_COEF: return B * 2 * NCH;
+    }
+    return 0;
+}
+
+template <typename T>
+static inline const T* tb(const eftb_engine* e, int id) { return static_cast<const T*>(e->tab[id]); }
+
+// dynamic LDS of pair_gemm_kernel<MT, NT>: the u tile (+ slack) or the 4-way reduction buffer
+static constexpr size_t pair_lds_bytes(int MT, int NT) {
+    const size_t tile = (size_t)(MT * 16 * ULDS + 8) * sizeof(double);
+    const size_t red = (size_t)4 * MT * NT * 4 * 64 * sizeof(double);
+    return tile > red ? tile : red;
+}
+
+static int launch_stages(eftb_engine* e, int mask, int B) {
+    const eftb_config& c = e->c;
+    hipStream_t st = e->stream;
+    const int Nk = c.Nk, Nl = c.Nl;
+    double** b = e->buf;
+    if (mask & EFTB_S_PREP) {
+        const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
+        hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
+                           tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
+                           b[EFTB_B_P11], b[EFTB_B_COEF]);
+    }
+    if (mask & EFTB_S_LOOPS) {
+        hipLaunchKernelGGL(uvec_kernel, dim3(Nk, B), dim3(256), 0, st, Nk, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), e->U);
+        const int rows = B * Nk;
+        const size_t lds = pair_lds_bytes(4, 2);
+        hipLaunchKernelGGL((pair_gemm_kernel<4, 2>), dim3((rows + 63) / 64), dim3(256), lds, st, e->U, tb<double>(e, EFTB_T_PAIRS22),
+                           tb<int>(e, EFTB_T_PLAN), rows, Nk, 28, e->k3, b[EFTB_B_P22]);
+        hipLaunchKernelGGL((rowdot_kernel<10>), dim3((Nk + 3) / 4, B), dim3(256), 0, st, 0, Nk, Nl, e->U, tb<double>(e, EFTB_T_M13R),
+                           (const double*)nullptr, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], b[EFTB_B_P13], (double*)nullptr);
+    }
+    if (mask & EFTB_S_CF) {
+        if (!c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
+        hipLaunchKernelGGL(uvec_kernel, dim3(NS, B), dim3(256), 0, st, NS, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), e->Us);
+        const int rows = B * NS;
+        const size_t lds = pair_lds_bytes(2, Nl == 3 ? 8 : 5);
+        if (Nl == 3)
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 8>), dim3((rows + 31) / 32), dim3(256), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
+                               tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
+        else
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 5>), dim3((rows + 31) / 32), dim3(256), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
+                               tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
+        hipLaunchKernelGGL((rowdot_kernel<6>), dim3((NS + 3) / 4, B), dim3(256), 0, st, 1, NS, Nl, e->Us, tb<double>(e, EFTB_T_C11R),
+                           tb<double>(e, EFTB_T_CCTR), tb<double>(e, EFTB_T_S), (const double*)nullptr, b[EFTB_B_C11], b[EFTB_B_CCT]);
+    }
+    if (mask & EFTB_S_REGROUP) {
+        hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, NROW * Nl, B), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
+                           b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
+                           tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_TEMPL]);
+        if (c.with_resum)
+            hipLaunchKernelGGL(regroup_cf_kernel, dim3(12, Nl, B), dim3(128), 0, st, Nl, b[EFTB_B_F], b[EFTB_B_CC], tb<double>(e, EFTB_T_L22),
+                               tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_CLOOPL]);
+    }
+    if (mask & EFTB_S_RESUM) {
+        if (!c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
+        const size_t lds = (size_t)(c.Nkin + c.nxtail) * sizeof(double);
+        hipLaunchKernelGGL(irfilter_kernel, dim3(B), dim3(256), lds, st, c.Nkin, c.nxtail, Nl * Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
+                           tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
+                           tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
+                           b[EFTB_B_XY], b[EFTB_B_Q]);
+        const int kblocks = (Nk + 63) / 64;
+        // enough waves to fill 1024 SIMDs: split the s sum for small batches
+        int nchunk = 1;
+        while (nchunk < e->resum_chunks && (size_t)kblocks * B * nchunk < 1024) nchunk *= 2;
+        const int schunk = (NS + nchunk - 1) / nchunk;
+        double* dst = nchunk == 1 ? b[EFTB_B_TEMPL] : e->part;
+#define RESUM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), b[EFTB_B_C11], \
+                   b[EFTB_B_CCT], b[EFTB_B_CLOOPL], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), dst, (nchunk == 1 ? 1 : 0)
+        if (Nl == 3) hipLaunchKernelGGL((resum_kernel<3>), dim3(kblocks, nchunk, B), dim3(64), 0, st, RESUM_ARGS);
+        else hipLaunchKernelGGL((resum_kernel<2>), dim3(kblocks, nchunk, B), dim3(64), 0, st, RESUM_ARGS);
+#undef RESUM_ARGS
+        if (nchunk > 1)
+            hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nchunk, e->part, b[EFTB_B_TEMPL]);
+    }
+    if (mask & EFTB_S_AP) {
+        if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
+        const int nseries = B * Nl * NROW;
+        hipLaunchKernelGGL(spline_kernel, dim3((nseries + 63) / 64), dim3(64), 0, st, Nk, nseries, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPDX),
+                           tb<double>(e, EFTB_T_SPLOWER), tb<double>(e, EFTB_T_SPINV), tb<double>(e, EFTB_T_SPCP), e->SD);
+        const int nrows_ap = c.ap_stochastic ? NROW : 21;
+#define AP_ARGS Nk, c.nmu, nrows_ap, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_SPDX), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), \
+                tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), b[EFTB_B_TEMPL], e->SD, e->Talt
+        if (Nl == 3) hipLaunchKernelGGL((ap_kernel<3>), dim3((Nk + 63) / 64, NROW, B), dim3(64), 0, st, AP_ARGS);
+        else hipLaunchKernelGGL((ap_kernel<2>), dim3((Nk + 63) / 64, NROW, B), dim3(64), 0, st, AP_ARGS);
+#undef AP_ARGS
+        std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
+    }
+    if (mask & EFTB_S_PROJECT) {
+        if (c.nproj <= 0) return fail("eftb_run: stage PROJECT needs a projection operator (nproj > 0)");
+        hipLaunchKernelGGL(project_kernel, dim3(c.nproj, c.nproj_l, B), dim3(256), 0, st, Nk, Nl, c.nproj, c.nproj_l, tb<double>(e, EFTB_T_PROJ),
+                           b[EFTB_B_TEMPL], b[EFTB_B_PROJ]);
+    }
+    if (mask & EFTB_S_REDUCE) {
+        if ((mask & EFTB_S_PROJECT) && c.nproj > 0)
+            hipLaunchKernelGGL(reduce_kernel, dim3((c.nproj + 255) / 256, c.nproj_l, B), dim3(256), 0, st, c.nproj, c.nproj_l, b[EFTB_B_BIAS],
+                               b[EFTB_B_PROJ], b[EFTB_B_PLK]);
+        else
+            hipLaunchKernelGGL(reduce_kernel, dim3((Nk + 255) / 256, Nl, B), dim3(256), 0, st, Nk, Nl, b[EFTB_B_BIAS], b[EFTB_B_TEMPL], b[EFTB_B_PLK]);
+    }
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
+    return 0;
+}
+
+extern "C" {
+
+const char* eftb_last_error(void) { return g_err.c_str(); }
+const char* eftb_version(void) { return "eftbird 0.1 (gfx950, fp64 mfma pair-gemm)"; }
+
+int eftb_create(const eftb_config* cfg, eftb_engine** out) {
+    if (!cfg || !out) return fail("eftb_create: null argument");
+    const eftb_config& c = *cfg;
+    if (c.Nl != 2 && c.Nl != 3) return fail("eftb_create: Nl must be 2 or 3 (got %d)", c.Nl);
+    if (c.Nk < 8 || c.Nkin < 4 || c.max_batch < 1) return fail("eftb_create: bad dimensions Nk=%d Nkin=%d max_batch=%d", c.Nk, c.Nkin, c.max_batch);
+    if (c.with_resum && (c.ncolsC % 16 || c.ncolsC < c.Nl * 38)) return fail("eftb_create: bad ncolsC=%d", c.ncolsC);
+    if (c.with_resum && !((c.Nl == 3 && c.NIR == 16 && c.Na == 3) || (c.Nl == 2 && c.NIR == 8 && c.Na == 2)))
+        return fail("eftb_create: (Nl, NIR, Na) = (%d, %d, %d) unsupported", c.Nl, c.NIR, c.Na);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("eftb_create: no HIP device visible -- libeftbird has no CPU fallback");
+    if (c.device < 0 || c.device >= ndev) return fail("eftb_create: device %d out of range (%d visible)", c.device, ndev);
+    HIPCHK(hipSetDevice(c.device));
+    eftb_engine* e = new eftb_engine();
+    e->c = c;
+    e->Nn = 2 * c.NIR * c.Na;
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&e->ev0));
+    HIPCHK(hipEventCreate(&e->ev1));
+    for (int id = 0; id < EFTB_B_COUNT; ++id) {
+        const size_t n = need_buffer_elems(c, id);
+        e->buf_elems[id] = n;
+        if (n) {
+            HIPCHK(hipMalloc(&e->buf[id], n * sizeof(double)));
+            HIPCHK(hipMemset(e->buf[id], 0, n * sizeof(double)));
+        }
+    }
+    const size_t B = c.max_batch;
+    HIPCHK(hipMalloc(&e->U, B * c.Nk * UPAD * sizeof(double)));
+    HIPCHK(hipMalloc(&e->k3, c.Nk * sizeof(double)));
+    if (c.with_resum) HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
+    if (c.with_ap) {
+        HIPCHK(hipMalloc(&e->SD, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
+        HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
+    }
+    *out = e;
+    return 0;
+}
+
+int eftb_set_table(eftb_engine* e, int id, const void* host, size_t nbytes) {
+    if (!e || !host) return fail("eftb_set_table: null argument");
+    if (id < 0 || id >= EFTB_T_COUNT) return fail("eftb_set_table: bad table id %d", id);
+    const size_t need = need_table_bytes(e->c, id);
+    if (need == 0) return fail("eftb_set_table: table %d is not used by this configuration", id);
+    if (need != nbytes) return fail("eftb_set_table: table %d expects %zu bytes, got %zu", id, need, nbytes);
+    HIPCHK(hipSetDevice(e->c.device));
+    if (!e->tab[id]) HIPCHK(hipMalloc(&e->tab[id], nbytes));
+    HIPCHK(hipMemcpy(e->tab[id], host, nbytes, hipMemcpyHostToDevice));
+    e->tab_bytes[id] = nbytes;
+    if (id == EFTB_T_K) {
+        std::vector<double> k3(e->c.Nk);
+        const double* k = static_cast<const double*>(host);
+        for (int i = 0; i < e->c.Nk; ++i) k3[i] = k[i] * k[i] * k[i];
+        HIPCHK(hipMemcpy(e->k3, k3.data(), k3.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int eftb_finalize(eftb_engine* e) {
+    if (!e) return fail("eftb_finalize: null engine");
+    for (int id = 0; id < EFTB_T_COUNT; ++id)
+        if (need_table_bytes(e->c, id) && !e->tab[id]) return fail("eftb_finalize: table %d was never set", id);
+    HIPCHK(hipSetDevice(e->c.device));
+    const eftb_config& c = e->c;
+    if (c.with_resum) {
+        // split the s sum when the batch alone cannot fill the chip (deterministic two-pass reduction)
+        e->resum_chunks = 16;
+        HIPCHK(hipMalloc(&e->part, (size_t)c.max_batch * e->resum_chunks * c.Nl * 21 * c.Nk * sizeof(double)));
+    }
+    // opt in to the large dynamic LDS tiles of the pair GEMM
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    e->finalized = true;
+    return 0;
+}
+
+void eftb_destroy(eftb_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->c.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& p : e->tab) if (p) (void)hipFree(p);
+    for (auto& p : e->buf) if (p) (void)hipFree(p);
+    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3}) if (p) (void)hipFree(p);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+size_t eftb_buffer_size(const eftb_engine* e, int id) {
+    if (!e || id < 0 || id >= EFTB_B_COUNT) return 0;
+    return e->buf_elems[id];
+}
+
+int eftb_put(eftb_engine* e, int id, size_t offset, const double* host, size_t count) {
+    if (!e || !host) return fail("eftb_put: null argument");
+    if (id < 0 || id >= EFTB_B_COUNT || !e->buf[id]) return fail("eftb_put: buffer %d not available in this configuration", id);
+    if (offset + count > e->buf_elems[id]) return fail("eftb_put: buffer %d holds %zu elements, asked [%zu, %zu)", id, e->buf_elems[id], offset, offset + count);
+    HIPCHK(hipSetDevice(e->c.device));
+    HIPCHK(hipMemcpyAsync(e->buf[id] + offset, host, count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int eftb_get(eftb_engine* e, int id, size_t offset, double* host, size_t count) {
+    if (!e || !host) return fail("eftb_get: null argument");
+    if (id < 0 || id >= EFTB_B_COUNT || !e->buf[id]) return fail("eftb_get: buffer %d not available in this configuration", id);
+    if (offset + count > e->buf_elems[id]) return fail("eftb_get: buffer %d holds %zu elements, asked [%zu, %zu)", id, e->buf_elems[id], offset, offset + count);
+    HIPCHK(hipSetDevice(e->c.device));
+    HIPCHK(hipMemcpyAsync(host, e->buf[id] + offset, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int eftb_run(eftb_engine* e, int mask, int B) {
+    if (!e) return fail("eftb_run: null engine");
+    if (!e->finalized) return fail("eftb_run: engine not finalized");
+    if (B < 1 || B > e->c.max_batch) return fail("eftb_run: batch %d outside [1, %d]", B, e->c.max_batch);
+    HIPCHK(hipSetDevice(e->c.device));
+    return launch_stages(e, mask, B);
+}
+
+int eftb_sync(eftb_engine* e) {
+    if (!e) return fail("eftb_sync: null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int eftb_run_timed(eftb_engine* e, int mask, int B, int repeats, float* ms) {
+    if (!e || !ms) return fail("eftb_run_timed: null argument");
+    if (!e->finalized) return fail("eftb_run_timed: engine not finalized");
+    if (B < 1 || B > e->c.max_batch) return fail("eftb_run_timed: batch %d outside [1, %d]", B, e->c.max_batch);
+    if (repeats < 1) repeats = 1;
+    HIPCHK(hipSetDevice(e->c.device));
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    for (int r = 0; r < repeats; ++r)
+        if (int rc = launch_stages(e, mask, B)) return rc;
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    HIPCHK(hipEventSynchronize(e->ev1));
+    HIPCHK(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return 0;
+}
+
+int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, double* templ,
+                    const double* bias, double* plk) {
+    if (!e || !Pin || !f || !templ) return fail("eftb_eval_batch: null argument");
+    if (!e->finalized) return fail("eftb_eval_batch: engine not finalized");
+    const eftb_config& c = e->c;
+    if (B < 1 || B > c.max_batch) return fail("eftb_eval_batch: batch %d outside [1, %d]", B, c.max_batch);
+    if (c.with_ap && (!DA || !H)) return fail("eftb_eval_batch: DA and H are required when with_ap=1");
+    if (plk && !bias) return fail("eftb_eval_batch: bias is required when plk is requested");
+    HIPCHK(hipSetDevice(c.device));
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_F], f, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c.with_ap) {
+        HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_DA], DA, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_H], H, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (plk) HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_BIAS], bias, (size_t)B * NROW * sizeof(double), hipMemcpyHostToDevice, st));
+    int mask = EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_REGROUP;
+    if (c.with_resum) mask |= EFTB_S_CF | EFTB_S_RESUM;
+    if (c.with_ap) mask |= EFTB_S_AP;
+    if (plk) mask |= EFTB_S_REDUCE;
+    if (int rc = launch_stages(e, mask, B)) return rc;
+    HIPCHK(hipMemcpyAsync(templ, e->buf[EFTB_B_TEMPL], (size_t)B * c.Nl * NROW * c.Nk * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (plk) HIPCHK(hipMemcpyAsync(plk, e->buf[EFTB_B_PLK], (size_t)B * c.Nl * c.Nk * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int eftb_mfma_f64_peak(int device, double* tflops) {
+    if (!tflops) return fail("eftb_mfma_f64_peak: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("eftb_mfma_f64_peak: no HIP device visible");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    double* sink = nullptr;
+    HIPCHK(hipMalloc(&sink, sizeof(double)));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    const int iters = 20000, blocks = prop.multiProcessorCount * 2;  // 2 x 4 waves per CU = 2 waves per SIMD
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, 100, sink);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    HIPCHK(hipEventRecord(b, 0));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    const double flops = (double)blocks * 4 * iters * 8 * (2.0 * 16 * 16 * 4);
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(sink);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""Batched device engine: one object = one (process, GPU) handle of libeftbird.so.
+
+``Engine`` owns the constant tables (built on the host by ``tables.build_tables``, uploaded once)
+and the device-resident state for up to ``max_batch`` cosmologies.  ``eval_batch`` is the batched
+counterpart of ``EFTLeafKernel.calculate_power_spectrum`` (reference eftpipe/theory.py:557-585);
+the stage-by-stage methods back the PyBird-compatible classes in ``eftpipe_amd.pybird``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .tables import EngineConfig, build_tables
+
+NROW = 24
+ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
+
+
+def wave_plan(steps, nwaves=4):
+    """Split the K-steps of the pair contraction evenly over the waves of a workgroup."""
+    T = len(steps)
+    plan = np.zeros((nwaves, 4), dtype=np.int32)
+    for q in range(nwaves):
+        t0, t1 = (q * T) // nwaves, ((q + 1) * T) // nwaves
+        plan[q] = (steps[t0, 0], steps[t0, 1], t0, t1 - t0)
+    return plan
+
+
+def _padded_fragments(frag):
+    """[T, J, 4, 16] -> [(T + 1), J, 64] with one zero step (the kernel prefetches one step ahead)."""
+    T, J = frag.shape[:2]
+    out = np.zeros((T + 1, J, 64))
+    out[:T] = frag.reshape(T, J, 64)
+    return out
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig, max_batch: int = 1, device: int = 0, projection=None):
+        self.lib = L.load()
+        self.cfg = cfg
+        t = self.tables = build_tables(cfg)
+        self.Nl, self.Nk, self.Nkin = cfg.Nl, t["k"].size, t["kin"].size
+        self.k, self.kin, self.s = t["k"], t["kin"], t["s"]
+        self.max_batch = int(max_batch)
+        self.projection = None if projection is None else np.ascontiguousarray(projection, dtype=np.float64)
+        c = L.Config()
+        c.device, c.Nl, c.Nk, c.Nkin, c.max_batch = device, cfg.Nl, self.Nk, self.Nkin, self.max_batch
+        c.with_resum, c.with_ap, c.ap_stochastic = int(cfg.with_resum), int(cfg.with_ap), int(cfg.APst)
+        c.nmu = cfg.nbinsmu
+        c.ntail = t["lnx_tail"].size
+        c.nsteps = len(t["steps"])
+        if cfg.with_resum:
+            c.nxtail = t["lnx_xtail"].size
+            c.ncolsC = t["pairsC"].shape[1] * 16
+            c.NIR, c.Na, c.Nklow = (int(x) for x in t["resum_dims"])
+        if self.projection is not None:
+            c.nproj_l, _, c.nproj, _ = self.projection.shape
+        self._cconf = c
+        h = C.c_void_p()
+        L.check(self.lib.eftb_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._upload(t)
+        L.check(self.lib.eftb_finalize(self._h))
+
+    # ------------------------------------------------------------------ tables
+    def _set(self, name, arr, dtype=np.float64):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        L.check(self.lib.eftb_set_table(self._h, L.T[name], a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def _upload(self, t):
+        cfg = self.cfg
+        self._set("K", t["k"])
+        self._set("S", t["s"])
+        self._set("LNKIN", np.log(t["kin"]))
+        self._set("SKT", t["Sk"].T)
+        self._set("GCT", t["Gc"].transpose(0, 2, 1))
+        self._set("ECT", t["Ec"].transpose(0, 2, 1))
+        self._set("LNXTAIL", t["lnx_tail"])
+        self._set("KPOW", t["kpow"])
+        self._set("PAIRS22", _padded_fragments(t["pairs22"]))
+        self._set("PLAN", wave_plan(t["steps"]), np.int32)
+        self._set("M13R", t["m13r"])
+        for n in ("L11", "LCT", "L22", "L13"):
+            self._set(n, t[n.lower()])
+        self._set("GRP", np.concatenate([t["grp22"], t["grp13"]]), np.int32)
+        if cfg.with_resum:
+            self._set("SPOW", t["spow"])
+            self._set("PAIRSC", _padded_fragments(t["pairsC"]))
+            self._set("C11R", t["c11r"])
+            self._set("CCTR", t["cctr"])
+            self._set("BXT", t["BX"].T)
+            self._set("BYT", t["BY"].T)
+            self._set("TXT", t["TX"].T)
+            self._set("TYT", t["TY"].T)
+            self._set("LNXXTAIL", t["lnx_xtail"])
+            self._set("WQLAST2", t["wq_last2"])
+            self._set("QPOLY", t["Qpoly"])
+            self._set("H", t["H"].transpose(0, 2, 1))
+        if cfg.with_ap:
+            self._set("MU", t["mu"])
+            self._set("WMU", t["wmu"])
+            self._set("LEGMU", t["legmu"])
+            self._set("SPDX", t["sp_dx"])
+            self._set("SPLOWER", t["sp_lower"])
+            self._set("SPINV", t["sp_inv"])
+            self._set("SPCP", t["sp_cp"])
+            self._set("APFID", t["ap_fid"])
+        if self.projection is not None:
+            self._set("PROJ", self.projection)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.eftb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state transfer
+    def put(self, name, arr, offset=0):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        L.check(self.lib.eftb_put(self._h, L.B[name], offset, L.dptr(a), a.size))
+
+    def get(self, name, shape, offset=0):
+        out = np.empty(shape, dtype=np.float64)
+        L.check(self.lib.eftb_get(self._h, L.B[name], offset, L.dptr(out), out.size))
+        return out
+
+    def run(self, mask, B=1, sync=True):
+        L.check(self.lib.eftb_run(self._h, mask, B))
+        if sync:
+            L.check(self.lib.eftb_sync(self._h))
+
+    def sync(self):
+        L.check(self.lib.eftb_sync(self._h))
+
+    def run_timed(self, mask, B, repeats=1):
+        """Device milliseconds for `repeats` back-to-back launches of the stage set (HIP events)."""
+        ms = C.c_float()
+        L.check(self.lib.eftb_run_timed(self._h, mask, B, repeats, C.byref(ms)))
+        return ms.value / repeats
+
+    def full_mask(self, reduce=False):
+        m = L.S_PREP | L.S_LOOPS | L.S_REGROUP
+        if self.cfg.with_resum:
+            m |= L.S_CF | L.S_RESUM
+        if self.cfg.with_ap:
+            m |= L.S_AP
+        if self.projection is not None:
+            m |= L.S_PROJECT
+        if reduce:
+            m |= L.S_REDUCE
+        return m
+
+    # ------------------------------------------------------------------ whole path
+    def eval_batch(self, Pin, f, DA=None, H=None, bias=None):
+        """Pin [B, Nkin], f/DA/H [B] -> templates [B, Nl, 24, Nk] (+ P_l [B, Nl, Nk] if bias [B, 24])."""
+        Pin = np.ascontiguousarray(np.atleast_2d(Pin), dtype=np.float64)
+        B = Pin.shape[0]
+        as1 = lambda x: None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (B,)))
+        f, DA, H = as1(f), as1(DA), as1(H)
+        templ = np.empty((B, self.Nl, NROW, self.Nk))
+        plk = None
+        if bias is not None:
+            bias = np.ascontiguousarray(bias, dtype=np.float64).reshape(B, NROW)
+            plk = np.empty((B, self.Nl, self.Nk))
+        L.check(self.lib.eftb_eval_batch(self._h, B, L.dptr(Pin), L.dptr(f), L.dptr(DA), L.dptr(H), L.dptr(templ),
+                                         L.dptr(bias), L.dptr(plk)))
+        return (templ, plk) if bias is not None else templ
+
+    def load_inputs(self, Pin, f, DA=None, H=None, bias=None):
+        """Make a batch resident in HBM (what a sampler would keep there between steps)."""
+        Pin = np.atleast_2d(Pin)
+        self.put("PIN", Pin)
+        self.put("F", np.broadcast_to(f, (Pin.shape[0],)))
+        if DA is not None:
+            self.put("DA", np.broadcast_to(DA, (Pin.shape[0],)))
+            self.put("H", np.broadcast_to(H, (Pin.shape[0],)))
+        if bias is not None:
+            self.put("BIAS", bias)
+        return Pin.shape[0]
+
+
+def mfma_f64_peak(device=0):
+    """Measured v_mfma_f64_16x16x4_f64 issue rate in TFLOP/s."""
+    lib = L.load()
+    v = C.c_double()
+    L.check(lib.eftb_mfma_f64_peak(device, C.byref(v)))
+    return v.value

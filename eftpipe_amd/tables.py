@@ -1,0 +1,352 @@
+"""Host-side, init-time construction of every constant table the HIP engine consumes.
+
+The reference evaluates each stage as spline -> FFTLog -> complex einsum.  All of those steps are
+*linear* in the sampled function once the grids are fixed, and every complex sum on the path is
+conjugate-symmetric (Pow[N-n] = conj(Pow[n])), so the engine pre-multiplies them here into REAL
+operators and real-reduced pair tables; the device then only runs real FP64 contractions:
+
+  * ``Sk``        cubic not-a-knot spline  kin -> k          (Bird.__init__, pybird.py:694-695)
+  * ``G*``/``E*`` FFTLog.Coef as a matrix + power-law tails  (fftlog.py:84-166)
+  * ``kpow/spow`` k^Pow, s^(-Pow-3)                          (pybird.py:1058-1064)
+  * ``pairs22``   sum_{nm} x_n M22[b,n,m] x_m  as  sum_{n<=m} (u_n u_m) R[b,(n,m)]  with u the
+                  real/imag parts of the 129 independent x_n  (pybird.py:1074-1078, 1103-1125)
+  * ``H``         resum FFTLog(192) + Bessel sum as a real [Na, Nk, Ns] operator (pybird.py:1361-1365,1409-1411)
+  * ``BX/BY``     IR filters X(s), Y(s) as real [Ns, Nkin] operators + tails (pybird.py:1316-1353)
+  * spline LU     tridiagonal factors of the not-a-knot system on the k grid (AP, pybird.py:1586-1593)
+  * ``Wfold``     window / binning / chained projections folded with their splines (window.py:371-387,
+                  binning.py:131-144, chained.py:32-68)
+
+This is host *setup* code (NumPy/SciPy, float64/complex128); nothing here runs per evaluation.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+from scipy.interpolate import CubicSpline
+from scipy.special import legendre, spherical_jn
+
+from . import loopmath as lm
+
+NS = 80          # |sbird|
+NPOW = 257       # NFFT + 1 for the loop FFTLog
+NHALF = 128
+UPAD = 260       # row stride of the real-reduced coefficient vectors in HBM (doubles)
+
+
+# ----------------------------------------------------------------------------- FFTLog as an operator
+def edge_window(N, window):
+    """Coefficient taper (reference fftlog.py:17-40); ``window=None`` -> endpoints halved (:162-164)."""
+    if window is None:
+        w = np.ones(N + 1)
+        w[0] = w[N] = 0.5
+        return w
+    n = np.arange(-N // 2, N // 2 + 1)
+    n_cut = N // 2 if window == 1 else int(window * N // 2.0)
+    hi, lo = n[-1] - n_cut, n[0] + n_cut
+    w = np.ones(n.size)
+    sel = n > hi
+    th = (n[-1] - n[sel]) / float(n[-1] - hi - 1)
+    w[sel] = th - np.sin(2 * np.pi * th) / (2 * np.pi)
+    sel = n < lo
+    th = (n[sel] - n[0]) / float(lo - n[0] - 1)
+    w[sel] = th - np.sin(2 * np.pi * th) / (2 * np.pi)
+    return w
+
+
+class FFTLogOperator:
+    """``Coef = G @ f + E_hi @ (A_hi x_hi^n_hi) [+ E_lo @ ...]`` for samples ``f`` on fixed ``xin``.
+
+    Same arithmetic as reference fftlog.py:59-166: log grid, tilt by exp(-bias i dx), real FFT with
+    conjugate mirroring, ``xmin^-Pow / N`` normalisation and the edge window; the spline resampling
+    (CubicSpline, not-a-knot, no extrapolation) is folded in, and the power-law extrapolations keep
+    their two scalar parameters (slope, amplitude) outside the matrices.
+    """
+
+    def __init__(self, N, xmin, xmax, bias, xin, window, extrap=("extrap", "extrap"), kernel=None):
+        self.N, self.bias = N, bias
+        self.dx = np.log(xmax / xmin) / (N - 1.0)
+        i = np.arange(N)
+        self.x = xmin * np.exp(i * self.dx)
+        m = np.arange(N + 1)
+        self.Pow = bias + 1j * 2.0 * np.pi / (N * self.dx) * (m - N / 2.0)
+        coef_factor = xmin ** (-self.Pow) / float(N)
+        lo = int(np.searchsorted(self.x, xin[0]))
+        hi = int(np.searchsorted(self.x, xin[-1], side="right"))
+        self.lo, self.hi = lo, hi
+        tilt = np.exp(-bias * i * self.dx)
+        phase = np.exp(-2j * np.pi * (((m[:, None] - N // 2) * i[None, :]) % N) / N)
+        D = phase * (coef_factor * edge_window(N, window))[:, None]
+        if xin is not None:
+            S = CubicSpline(xin, np.eye(len(xin)), axis=0, extrapolate=False)(self.x[lo:hi])
+            t = tilt[lo:hi]
+            if kernel is not None:
+                t = t * kernel(self.x[lo:hi])
+            self.G = D[:, lo:hi] @ (t[:, None] * S)
+        self.low_active = extrap[0] == "extrap" and xin[0] > self.x[0]
+        self.high_active = extrap[1] == "extrap" and xin[-1] < self.x[-1]
+        self.E_lo = D[:, :lo] * tilt[:lo] if self.low_active else np.zeros((N + 1, 0), complex)
+        self.E_hi = D[:, hi:] * tilt[hi:] if self.high_active else np.zeros((N + 1, 0), complex)
+        self.lnx_lo = np.log(self.x[:lo]) if self.low_active else np.zeros(0)
+        self.lnx_hi = np.log(self.x[hi:]) if self.high_active else np.zeros(0)
+
+
+# ----------------------------------------------------------------------------- real reduction
+def realify_matrix():
+    """T with x = T u, u = (Re x_0..Re x_127, x_128, Im x_0..Im x_127), x_{256-n} = conj(x_n)."""
+    T = np.zeros((NPOW, NPOW), dtype=complex)
+    n = np.arange(NHALF)
+    T[n, n] = 1.0
+    T[n, NHALF + 1 + n] = 1j
+    T[NHALF, NHALF] = 1.0
+    T[2 * NHALF - n, n] = 1.0
+    T[2 * NHALF - n, NHALF + 1 + n] = -1j
+    return T
+
+
+def reduce_linear(vec):
+    """Re sum_n x_n v_n = u . r  for conjugate-symmetric v  ->  r[..., 257]."""
+    v = np.asarray(vec)
+    return np.concatenate([2.0 * v[..., :NHALF].real, v[..., NHALF:NHALF + 1].real, -2.0 * v[..., :NHALF].imag], axis=-1)
+
+
+def reduce_quadratic(M):
+    """Re sum_nm x_n M_nm x_m = u^T R u  ->  R[..., 257, 257] (real; imaginary residue returned too).
+
+    R = T^T M T written out block by block (x_n = a_n + i b_n, x_{256-n} = a_n - i b_n, x_128 = c)."""
+    M = np.asarray(M)
+    h, c = NHALF, NHALF
+    lo, hi = slice(0, h), slice(2 * h, h, -1)          # n and its mirror 256 - n
+    A, B, Cm, D = M[..., lo, lo], M[..., lo, hi], M[..., hi, lo], M[..., hi, hi]
+    R = np.empty(M.shape, dtype=complex)
+    R[..., :h, :h] = A + B + Cm + D
+    R[..., :h, h + 1:] = 1j * (A - B + Cm - D)
+    R[..., h + 1:, :h] = 1j * (A + B - Cm - D)
+    R[..., h + 1:, h + 1:] = -(A - B - Cm + D)
+    R[..., :h, c] = M[..., lo, c] + M[..., hi, c]
+    R[..., c, :h] = M[..., c, lo] + M[..., c, hi]
+    R[..., h + 1:, c] = 1j * (M[..., lo, c] - M[..., hi, c])
+    R[..., c, h + 1:] = 1j * (M[..., c, lo] - M[..., c, hi])
+    R[..., c, c] = M[..., c, c]
+    scale = np.max(np.abs(R.real)) or 1.0
+    return np.ascontiguousarray(R.real), float(np.max(np.abs(R.imag)) / scale)
+
+
+def pair_steps():
+    """K-steps of the pair contraction: step t covers pairs (n, m0..m0+3), n <= m0 <= 256."""
+    return np.array([(n, m0) for n in range(NPOW) for m0 in range(n, NPOW, 4)], dtype=np.int32)
+
+
+def pair_fragments(R, ncols_pad):
+    """R[cols, 257, 257] -> MFMA-B-operand fragments [T, ncols_pad/16, 4, 16] (f64).
+
+    Element [t, j, g, c] multiplies u[n]*u[m0+g] for column 16j+c; symmetric partner folded in.
+    The layout is exactly one ``v_mfma_f64_16x16x4_f64`` B fragment (lane = 16 g + c) per (t, j),
+    512 contiguous bytes, so a wave loads it with one coalesced 8-byte-per-lane instruction.
+    """
+    ncols = R.shape[0]
+    st = pair_steps()
+    frag = np.zeros((len(st), ncols_pad, 4))
+    Rs = R + np.swapaxes(R, 1, 2)
+    idx = np.arange(NPOW)
+    Rs[:, idx, idx] = R[:, idx, idx]
+    for g in range(4):
+        m = st[:, 1] + g
+        ok = m < NPOW
+        frag[ok, :ncols, g] = Rs[:, st[ok, 0], m[ok]].T
+    return np.ascontiguousarray(frag.reshape(len(st), ncols_pad // 16, 16, 4).transpose(0, 1, 3, 2))
+
+
+# ----------------------------------------------------------------------------- cubic spline (not-a-knot)
+def spline_factors(x):
+    """Tridiagonal system of scipy's not-a-knot CubicSpline for knot derivatives, pre-factored.
+
+    Unknowns s_i = S'(x_i).  Interior rows: dx_i s_{i-1} + 2(dx_{i-1}+dx_i) s_i + dx_{i-1} s_{i+1}
+    = 3(dx_i slope_{i-1} + dx_{i-1} slope_i); end rows are the not-a-knot conditions.  Returns the
+    Thomas-algorithm factors (lower, inv_pivot, cprime) so the device only substitutes.
+    """
+    x = np.asarray(x, dtype=float)
+    n = x.size
+    dx = np.diff(x)
+    lower, diag, upper = np.zeros(n), np.zeros(n), np.zeros(n)
+    diag[1:-1] = 2.0 * (dx[:-1] + dx[1:])
+    upper[1:-1] = dx[:-1]
+    lower[1:-1] = dx[1:]
+    diag[0], upper[0] = dx[1], x[2] - x[0]
+    diag[-1], lower[-1] = dx[-2], x[-1] - x[-3]
+    inv, cp = np.zeros(n), np.zeros(n)
+    piv = diag[0]
+    inv[0], cp[0] = 1.0 / piv, upper[0] / piv
+    for i in range(1, n):
+        piv = diag[i] - lower[i] * cp[i - 1]
+        inv[i] = 1.0 / piv
+        cp[i] = upper[i] / piv
+    return dict(dx=dx, lower=lower, inv=inv, cp=cp)
+
+
+def spline_matrix(x, xe):
+    """Dense operator of the same spline, end pieces extrapolated (interp1d 'extrapolate')."""
+    return CubicSpline(x, np.eye(len(x)), axis=0, extrapolate=True)(xe)
+
+
+# ----------------------------------------------------------------------------- configuration
+@dataclass
+class EngineConfig:
+    """What the hot path needs from ``Common`` + the plugin constructors
+    (reference pybird.py:498-514, 907-915, 1230, 1503-1518; window.py:121-145; binning.py:43-53)."""
+
+    Nl: int = 2
+    k: Optional[np.ndarray] = None          # None -> native grid (pybird.py:472-479)
+    kin: Optional[np.ndarray] = None        # None -> logspace(-5, 0, 200) (theory.py:562)
+    NFFT: int = 256
+    fft_window: float = 0.2                 # NonLinear.PsCf(window=0.2) (pybird.py:1143)
+    with_resum: bool = False
+    LambdaIR: float = 0.2
+    NFFT_resum: int = 192
+    with_ap: bool = False
+    DA_AP: Optional[float] = None
+    H_AP: Optional[float] = None
+    nbinsmu: int = 200
+    APst: bool = False
+    extra: dict = field(default_factory=dict)
+
+
+def legendre_table(Nl, mu):
+    return np.array([legendre(2 * l)(mu) for l in range(Nl)])
+
+
+def build_tables(cfg: EngineConfig) -> dict:
+    """-> {name: ndarray} of every constant table, float64 / int32, C-contiguous, device layout."""
+    if cfg.NFFT != 256:
+        raise ValueError("the HIP engine is specialised for NFFT=256 (the reference default, pybird.py:912)")
+    Nl = cfg.Nl
+    if Nl not in (2, 3):
+        raise ValueError("Nl must be 2 or 3")
+    k = lm.native_k() if cfg.k is None else np.ascontiguousarray(cfg.k, dtype=np.float64)
+    kin = np.logspace(-5, 0, 200) if cfg.kin is None else np.ascontiguousarray(cfg.kin, dtype=np.float64)
+    s = lm.native_s()
+    Nk, Nkin = k.size, kin.size
+    t = dict(k=k, kin=kin, s=s)
+    w = lm.mu_weights(Nl)
+    t.update(w)
+    grp22 = np.array([lm.GROUP_22[b] for b in range(28)], dtype=np.int32)
+    grp13 = np.array([lm.GROUP_13[b] for b in range(10)], dtype=np.int32)
+    t["grp22"], t["grp13"] = grp22, grp13
+
+    # ---- P11 = Sk @ Pin
+    t["Sk"] = np.ascontiguousarray(CubicSpline(kin, np.eye(Nkin), axis=0)(k))
+
+    # ---- loop FFTLog as an operator on Pin; only the 129 independent coefficients are kept
+    op = FFTLogOperator(256, 1.5e-5, 1000.0, -1.6, kin, cfg.fft_window)
+    if op.low_active:
+        raise ValueError("kin[0] must not exceed the FFTLog xmin=1.5e-5 (low-k extrapolation unsupported)")
+    nh = NHALF + 1
+    t["Gc"] = np.ascontiguousarray(np.stack([op.G[:nh].real, op.G[:nh].imag]))            # [2,129,Nkin]
+    t["Ec"] = np.ascontiguousarray(np.stack([op.E_hi[:nh].real, op.E_hi[:nh].imag]))      # [2,129,Ntail]
+    t["lnx_tail"] = op.lnx_hi
+    Pow = op.Pow
+    nu = -0.5 * Pow
+    kp = np.exp(np.outer(np.log(k), Pow[:nh]))            # [Nk,129]
+    sp = np.exp(np.outer(np.log(s), -Pow[:nh] - 3.0))     # [Ns,129]
+    t["kpow"] = np.ascontiguousarray(np.stack([kp.real, kp.imag], axis=1))   # [Nk,2,129]
+    t["spow"] = np.ascontiguousarray(np.stack([sp.real, sp.imag], axis=1))   # [Ns,2,129]
+
+    # ---- loop matrices, real-reduced
+    M22 = lm.matrices_22(nu)
+    M13 = lm.vectors_13(nu)
+    ells = 2 * np.arange(Nl)
+    Mcf11 = lm.bessel_weight(ells[:, None], nu[None, :])
+    Mcfct = lm.bessel_weight(ells[:, None], nu[None, :] - 1.0)
+    Ml = lm.bessel_weight(ells[:, None, None], nu[None, :, None] + nu[None, None, :] - 1.5)
+    R22, im22 = reduce_quadratic(M22)
+    t["steps"] = pair_steps()
+    t["pairs22"] = pair_fragments(R22, 32)
+    t["m13r"] = np.ascontiguousarray(reduce_linear(M13))                 # [10,257]
+    resid = [im22]
+    if cfg.with_resum:
+        # columns of the configuration-space contraction: [l*28+b] for C22, then [28*Nl + l*10+b] for C13
+        Rc22, imc = reduce_quadratic((Ml[:, None] * M22[None]).reshape(Nl * 28, NPOW, NPOW))
+        Rc13, imd = reduce_quadratic((Ml[:, None] * M13[None, :, :, None]).reshape(Nl * 10, NPOW, NPOW))
+        resid += [imc, imd]
+        ncol = Nl * 38
+        t["pairsC"] = pair_fragments(np.concatenate([Rc22, Rc13]), 16 * ((ncol + 15) // 16))
+        t["c11r"] = np.ascontiguousarray(reduce_linear(Mcf11))           # [Nl,257]
+        t["cctr"] = np.ascontiguousarray(reduce_linear(Mcfct))           # [Nl,257]
+    t["reduction_residue"] = np.array(resid)
+
+    # ---- IR-resummation
+    if cfg.with_resum:
+        NIR = 16 if Nl == 3 else 8
+        Na = 3 if Nl == 3 else 2
+        kr_mask = k >= 0.02
+        kr = k[kr_mask]
+        rop = FFTLogOperator(cfg.NFFT_resum, 0.1, 10000.0, -0.6, s, None, extrap=("padding", "padding"))
+        rM = np.stack([8.0 * np.pi**3 * lm.bessel_weight(2 * l, -0.5 * rop.Pow) for l in range(Na)])
+        rk = np.exp(np.outer(-rop.Pow - 3.0, np.log(kr)))                # [193,Nkr]
+        H = np.zeros((Na, Nk, NS))
+        for v in range(Na):
+            H[v, kr_mask] = np.real((rM[v][:, None] * rk).T @ rop.G)
+        t["H"] = H
+        # IR filters: q = Pin * exp(-k^2/L^2)/k^2 -> FFTLog(32) -> j0/j2 sums -> X, Y
+        wq = np.exp(-(kin**2) / cfg.LambdaIR**2) / kin**2
+        xop = FFTLogOperator(32, 1.5e-5, 10.0, -2.6, kin, None)
+        if xop.low_active:
+            raise ValueError("kin[0] must not exceed 1.5e-5")
+        XM = np.stack([lm.bessel_weight(2 * l, -0.5 * xop.Pow) for l in range(2)])
+        XsPow = np.exp(np.outer(-xop.Pow - 3.0, np.log(s)))              # [33,Ns]
+        K = lambda D: np.real(np.einsum("ln,ns,ni->lsi", XM, XsPow, D))   # [2,Ns,cols]
+        Koff = lambda D: np.real(np.einsum("n,ni->i", XM[0], D))
+        body, tail = K(xop.G), K(xop.E_hi)
+        boff, toff = Koff(xop.G), Koff(xop.E_hi)
+        t["BX"] = np.ascontiguousarray(2.0 / 3.0 * (boff[None, :] - body[0] - body[1]) * wq[None, :])
+        t["BY"] = np.ascontiguousarray(2.0 * body[1] * wq[None, :])
+        t["TX"] = np.ascontiguousarray(2.0 / 3.0 * (toff[None, :] - tail[0] - tail[1]))
+        t["TY"] = np.ascontiguousarray(2.0 * tail[1])
+        t["lnx_xtail"] = xop.lnx_hi
+        t["wq_last2"] = wq[-2:].copy()
+        t["Qpoly"] = lm.q_polynomials(Nl)
+        t["resum_dims"] = np.array([NIR, Na, int(np.sum(~kr_mask))], dtype=np.int32)
+
+    # ---- AP
+    if cfg.with_ap:
+        mu = np.linspace(0.0, 1.0, cfg.nbinsmu)
+        wmu = np.full(cfg.nbinsmu, mu[1] - mu[0])
+        wmu[0] = wmu[-1] = 0.5 * (mu[1] - mu[0])
+        t["mu"], t["wmu"] = mu, wmu
+        t["legmu"] = np.ascontiguousarray(((2 * ells + 1) / 2.0)[:, None] * legendre_table(Nl, mu))
+        f = spline_factors(k)
+        t["sp_dx"], t["sp_lower"], t["sp_inv"], t["sp_cp"] = f["dx"], f["lower"], f["inv"], f["cp"]
+        t["ap_fid"] = np.array([cfg.DA_AP, cfg.H_AP], dtype=np.float64)
+    return t
+
+
+# ----------------------------------------------------------------------------- projections after AP
+def window_pgrid(kmax, accboost=1):
+    """(reference window.py:27-33)"""
+    return np.concatenate(
+        [np.geomspace(1e-5, 0.015, 100 * accboost, endpoint=False), np.arange(0.015, kmax, 1e-3 / accboost)]
+    )
+
+
+_CALQ = np.array(
+    [
+        [[1, 0, 0, 0], [0, 1 / 5, 0, 0], [0, 0, 1 / 9, 0], [0, 0, 0, 1 / 13]],
+        [[0, 1, 0, 0], [1, 2 / 7, 2 / 7, 0], [0, 2 / 7, 100 / 693, 25 / 143], [0, 0, 25 / 143, 14 / 143]],
+        [[0, 0, 1, 0], [0, 18 / 35, 20 / 77, 45 / 143], [1, 20 / 77, 162 / 1001, 20 / 143], [0, 45 / 143, 20 / 143, 252 / 2431]],
+        [[0, 0, 0, 1], [0, 0, 5 / 11, 14 / 55], [0, 5 / 11, 20 / 99, 28 / 187], [1, 14 / 55, 28 / 187, 400 / 3553]],
+    ]
+)  # (2a+1) (a l q; 0 0 0)^2, reference window.py:286-303
+
+
+def window_fold(k, Wal, p, windowk=0.05, withmask=True):
+    """Mask + dp weights (reference window.py:348-359) folded with the k->p cubic spline
+    (window.py:376-383):  P'_a(k) = sum_{l,k'} Wfold[a,l,k,k'] P_l(k')."""
+    W = Wal
+    if withmask:
+        pp, kk = np.meshgrid(p, k, indexing="ij")
+        mask = (pp < kk + windowk) & (pp > kk - windowk)
+        W = np.einsum("alkp,pk->alkp", Wal, mask)
+    dp = np.concatenate([[0.0], np.diff(p)])
+    Waldk = W * dp
+    return np.ascontiguousarray(np.einsum("alkp,pq->alkq", Waldk, spline_matrix(k, p), optimize=True)), Waldk

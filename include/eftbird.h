@@ -1,0 +1,125 @@
+/*
+ * eftbird.h -- C ABI of the MI355X-native EFTofLSS one-loop engine (libeftbird.so).
+ *
+ * Drop-in boundary for the PyBird theory-vector hot path of zhaoruiyang98/eftpipe.  The reference has
+ * no FFI (it is pure Python); each entry point below names the reference interface it replaces
+ * (paths relative to the reference root).  The host side (the eftpipe_amd Python package) binds these with ctypes and
+ * re-exposes the reference's own class surface (Common, Bird, NonLinear.PsCf, Bird.setPsCfl, Resum.Ps,
+ * APeffect.AP, Window.Window, Binning.transform, Chained.transform, reduce_Plk).
+ *
+ * Conventions: plain C types only; all arrays are C-contiguous float64 unless stated; the caller owns
+ * every host buffer, the library owns the engine and all device memory; one engine per (process, GPU),
+ * not re-entrant per engine.  Every function returns 0 on success, non-zero on error; the message is
+ * available from eftb_last_error().  There is NO CPU fallback: without a HIP device eftb_create fails.
+ */
+#ifndef EFTBIRD_H
+#define EFTBIRD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eftb_engine eftb_engine;
+
+/* Dimensions + switches fixed at construction.  Replaces the constructor arguments of
+ * pybird.Common (eftpipe/pybird/pybird.py:498-514), pybird.NonLinear (:907-915), pybird.Resum (:1230),
+ * pybird.APeffect (:1503-1518) as used by EFTLeafKernel.initialize_with_provider (eftpipe/theory.py:423-495). */
+typedef struct eftb_config {
+    int32_t device;        /* HIP device ordinal */
+    int32_t Nl;            /* multipoles computed: 2 (l=0,2) or 3 (l=0,2,4)            Common.Nl */
+    int32_t Nk;            /* |co.k|                                                    Common.Nk */
+    int32_t Nkin;          /* |kin| of the input linear spectrum (200)                  theory.py:562 */
+    int32_t max_batch;     /* device state is sized for this many cosmologies per call */
+    int32_t with_resum;    /* IR-resummation on (needs the C11/Cct/C22/C13 pieces)      theory.py:573 */
+    int32_t with_ap;       /* Alcock-Paczynski on                                       theory.py:582 */
+    int32_t ap_stochastic; /* APeffect(APst=True): distort Pstl too                     pybird.py:1618 */
+    int32_t nmu;           /* AP mu nodes (nbinsmu*accboost)                            pybird.py:1538 */
+    int32_t ntail;         /* high-k power-law tail length of the loop FFTLog           fftlog.py:146-151 */
+    int32_t nxtail;        /* same for the 32-point IR-filter FFTLog                    pybird.py:1293 */
+    int32_t nsteps;        /* K-steps of the pair contraction (eftpipe_amd/tables.py pair_steps) */
+    int32_t ncolsC;        /* padded columns of the xi contraction (multiple of 16)     */
+    int32_t NIR, Na, Nklow;/* Resum.NIR, Resum.Na, Common.Nklow                         pybird.py:1247-1259, 560 */
+    int32_t nproj;         /* rows of the optional post-AP projection operator (0 = none) */
+    int32_t nproj_l;       /* output multipoles of the projection                       */
+} eftb_config;
+
+/* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file). */
+enum eftb_table {
+    EFTB_T_K = 0, EFTB_T_S, EFTB_T_LNKIN, EFTB_T_SKT, EFTB_T_GCT, EFTB_T_ECT, EFTB_T_LNXTAIL,
+    EFTB_T_KPOW, EFTB_T_SPOW, EFTB_T_PAIRS22, EFTB_T_PAIRSC, EFTB_T_PLAN, EFTB_T_M13R, EFTB_T_C11R,
+    EFTB_T_CCTR, EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
+    EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
+    EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPDX, EFTB_T_SPLOWER, EFTB_T_SPINV, EFTB_T_SPCP, EFTB_T_APFID,
+    EFTB_T_PROJ, EFTB_T_COUNT
+};
+
+/* Device-resident state (per engine, [max_batch] leading axis unless noted). */
+enum eftb_buffer {
+    EFTB_B_PIN = 0,   /* [B][Nkin]            Bird.Pin                            pybird.py:693 */
+    EFTB_B_F,         /* [B]                  Bird.f                                              */
+    EFTB_B_DA,        /* [B]                  Bird.DA                                             */
+    EFTB_B_H,         /* [B]                  Bird.H                                              */
+    EFTB_B_P11,       /* [B][Nk]              Bird.P11                            pybird.py:695 */
+    EFTB_B_P22,       /* [B][28][Nk]          Bird.P22                            pybird.py:1076 */
+    EFTB_B_P13,       /* [B][10][Nk]          Bird.P13                            pybird.py:1082 */
+    EFTB_B_C11,       /* [B][Nl][80]          Bird.C11                            pybird.py:1090 */
+    EFTB_B_CCT,       /* [B][Nl][80]          Bird.Cct                            pybird.py:1094 */
+    EFTB_B_CC,        /* [B][Nl*38][80]       Bird.C22 ([Nl][28][80]) then Bird.C13 ([Nl][10][80]) */
+    EFTB_B_CLOOPL,    /* [B][Nl][12][80]      Bird.Cloopl                         pybird.py:805-846 */
+    EFTB_B_TEMPL,     /* [B][Nl][24][Nk]      rows 0-2 P11l, 3-8 Pctl, 9-20 Ploopl, 21-23 Pstl  */
+    EFTB_B_XY,        /* [B][2][80]           IR filters X(s), Y(s)               pybird.py:1316-1353 */
+    EFTB_B_Q,         /* [B][2][Nl][Nl][Nn]   Resum.Q                             pybird.py:1367-1380 */
+    EFTB_B_BIAS,      /* [B][24]              b11(3), bct(6), bloop(12), bst(3)   parambasis.py:69-126 */
+    EFTB_B_PLK,       /* [B][Nl][Nk]          reduce_Plk(...).sum() without Picc  parambasis.py:128-136 */
+    EFTB_B_PROJ,      /* [B][nproj_l][24][nproj]  window/binning/chained projection of TEMPL */
+    EFTB_B_COEF,      /* [B][2][129]          FFTLog coefficients (independent half, re/im) */
+    EFTB_B_COUNT
+};
+
+/* Stages, in the order EFTLeafKernel.calculate_power_spectrum runs them (theory.py:557-609). */
+enum eftb_stage {
+    EFTB_S_PREP    = 1 << 0,  /* Bird.__init__ spline + NonLinear.Coef        pybird.py:694-695, 1127-1141 */
+    EFTB_S_LOOPS   = 1 << 1,  /* makeP22, makeP13                             pybird.py:1074-1086 */
+    EFTB_S_CF      = 1 << 2,  /* makeC11, makeCct, makeC22, makeC13           pybird.py:1088-1125 */
+    EFTB_S_REGROUP = 1 << 3,  /* Bird.setPsCfl                                pybird.py:737-866 */
+    EFTB_S_RESUM   = 1 << 4,  /* Resum.Ps                                     pybird.py:1413-1464 */
+    EFTB_S_AP      = 1 << 5,  /* APeffect.AP                                  pybird.py:1598-1621 */
+    EFTB_S_PROJECT = 1 << 6,  /* Window.Window / Binning / Chained (folded)   window.py:371-415, binning.py:131-162, chained.py:56-68 */
+    EFTB_S_REDUCE  = 1 << 7,  /* reduce_Plk                                   parambasis.py:42-136 */
+    EFTB_S_ALL     = 0xff
+};
+
+int  eftb_create(const eftb_config* cfg, eftb_engine** out);
+int  eftb_set_table(eftb_engine* e, int table_id, const void* host, size_t nbytes);
+int  eftb_finalize(eftb_engine* e);
+void eftb_destroy(eftb_engine* e);
+
+/* Host <-> device state.  `offset`/`count` are in elements (doubles). */
+int  eftb_put(eftb_engine* e, int buffer_id, size_t offset, const double* host, size_t count);
+int  eftb_get(eftb_engine* e, int buffer_id, size_t offset, double* host, size_t count);
+size_t eftb_buffer_size(const eftb_engine* e, int buffer_id); /* elements */
+
+/* Launch the selected stages for cosmologies [0, B) on the engine stream (asynchronous). */
+int  eftb_run(eftb_engine* e, int stage_mask, int B);
+int  eftb_sync(eftb_engine* e);
+/* Same, bracketed by HIP events on the engine stream; *ms receives the elapsed device time. */
+int  eftb_run_timed(eftb_engine* e, int stage_mask, int B, int repeats, float* ms);
+
+/* One call = reference theory.py:557-585 for a batch: host inputs in, templates out.
+ * templ is [B][Nl][24][Nk] (rows as EFTB_B_TEMPL); plk may be NULL, else bias must be [B][24]. */
+int  eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA,
+                     const double* H, double* templ, const double* bias, double* plk);
+
+/* Measured FP64 MFMA issue rate (v_mfma_f64_16x16x4_f64), TFLOP/s, for the roofline denominator. */
+int  eftb_mfma_f64_peak(int device, double* tflops);
+
+const char* eftb_last_error(void);
+const char* eftb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFTBIRD_H */

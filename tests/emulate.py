@@ -1,0 +1,169 @@
+"""NumPy emulation of the DEVICE algebra, driven only by eftpipe_amd.tables.build_tables output.
+
+Test-only: lets the CPU suite prove that the real-reduced / operator-folded tables reproduce the
+oracle before (and independently of) the HIP kernels, which implement exactly these contractions.
+"""
+import numpy as np
+
+NH = 128
+
+
+def tail_params(lnk, y):
+    slope = (np.log(y[-1]) - np.log(y[-2])) / (lnk[-1] - lnk[-2])
+    amp = y[-1] / np.exp(slope * lnk[-1])
+    return amp, slope
+
+
+def coef_half(t, Pin):
+    lnk = np.log(t["kin"])
+    amp, slope = tail_params(lnk, Pin)
+    tail = amp * np.exp(slope * t["lnx_tail"])
+    return t["Gc"] @ Pin + t["Ec"] @ tail  # [2,129]
+
+
+def reduced_vectors(c, pw):
+    """c [2,129], pw [rows,2,129] -> u [rows,257]"""
+    cre, cim = c
+    pr, pi = pw[:, 0], pw[:, 1]
+    a = cre[:NH] * pr[:, :NH] - cim[:NH] * pi[:, :NH]
+    b = cre[:NH] * pi[:, :NH] + cim[:NH] * pr[:, :NH]
+    mid = cre[NH] * pr[:, NH : NH + 1]
+    return np.concatenate([a, mid, b], axis=1)
+
+
+def pair_contract(u, frag, steps):
+    """u [rows,257], frag [T,J,4,16] -> [rows, 16J]"""
+    up = np.concatenate([u, np.zeros((u.shape[0], 4))], axis=1)
+    un = u[:, steps[:, 0]]  # [rows,T]
+    out = np.zeros((u.shape[0], frag.shape[1] * 16))
+    for g in range(4):
+        v = un * up[:, steps[:, 1] + g]  # [rows,T]
+        out += np.einsum("rt,tjc->rjc", v, frag[:, :, g, :]).reshape(u.shape[0], -1)
+    return out
+
+
+def pscf(t, Pin, with_cf):
+    k, s = t["k"], t["s"]
+    P11 = t["Sk"] @ Pin
+    c = coef_half(t, Pin)
+    U = reduced_vectors(c, t["kpow"])
+    out = dict(P11=P11)
+    out["P22"] = (k[:, None] ** 3 * pair_contract(U, t["pairs22"], t["steps"])[:, :28]).T
+    out["P13"] = (k**3 * P11)[None, :] * (t["m13r"] @ U.T)
+    if with_cf:
+        Nl = t["l11"].shape[0]
+        Us = reduced_vectors(c, t["spow"])
+        cc = pair_contract(Us, t["pairsC"], t["steps"])  # [80, cols]
+        out["C22"] = cc[:, : Nl * 28].T.reshape(Nl, 28, -1)
+        out["C13"] = cc[:, Nl * 28 : Nl * 38].T.reshape(Nl, 10, -1)
+        out["C11"] = t["c11r"] @ Us.T
+        out["Cct"] = s[None, :] ** -2 * (t["cctr"] @ Us.T)
+    return out
+
+
+def regroup(t, f, T22, T13):
+    out = np.zeros(T22.shape[:1] + (12,) + T22.shape[2:])
+    for b, (g, p) in enumerate(t["grp22"]):
+        out[:, g] += f**p * T22[:, b]
+    for b, (g, p) in enumerate(t["grp13"]):
+        out[:, g] += f**p * T13[:, b]
+    return out
+
+
+def setpscfl(t, f, st, with_cf):
+    k = t["k"]
+    Nl = t["l11"].shape[0]
+    P11l = t["l11"][:, :, None] * st["P11"][None, None, :]
+    Pctl = t["lct"][:, :, None] * (k**2 * st["P11"])[None, None, :]
+    Ploopl = regroup(t, f, t["l22"][:, :, None] * st["P22"][None], t["l13"][:, :, None] * st["P13"][None])
+    Ploopl = Ploopl - Ploopl[:, :, :1]
+    Pstl = np.zeros((Nl, 3, k.size))
+    Pstl[0, 0] = 1.0
+    Pstl[0, 1] = k**2
+    Pstl[1, 2] = k**2
+    out = dict(P11l=P11l, Pctl=Pctl, Ploopl=Ploopl, Pstl=Pstl)
+    if with_cf:
+        out["Cloopl"] = regroup(t, f, t["l22"][:, :, None] * st["C22"], t["l13"][:, :, None] * st["C13"])
+    return out
+
+
+def ir_filters(t, Pin):
+    q2 = Pin[-2:] * t["wq_last2"]
+    amp, slope = tail_params(np.log(t["kin"]), np.concatenate([[1.0] * (len(t["kin"]) - 2), q2]))
+    tail = amp * np.exp(slope * t["lnx_xtail"])
+    return t["BX"] @ Pin + t["TX"] @ tail, t["BY"] @ Pin + t["TY"] @ tail
+
+
+def resum(t, f, Pin, st):
+    NIR, Na, Nklow = t["resum_dims"]
+    Nl = t["l11"].shape[0]
+    k = t["k"]
+    Q = (t["Qpoly"] @ f ** np.arange(15))[::-1]  # Q[a] = table[1-a]
+    X, Y = ir_filters(t, Pin)
+    z = k[:, None] ** 2 * X[None, :]  # [Nk,Ns]
+    yk = k[:, None] ** 2 * Y[None, :]
+    # Z[a,l,l',v,k,s] = sum_p Q[a,l,l',p*Na+v] z^(p+1) + yk * sum_p Q[a,l,l',(NIR+p)*Na+v] z^p
+    Qr = Q.reshape(2, Nl, Nl, 2 * NIR, Na)
+    zp = np.stack([z**p for p in range(NIR + 1)])  # [NIR+1,Nk,Ns]
+    Z = np.einsum("albpv,pks->albvks", Qr[:, :, :, :NIR], zp[1:]) + np.einsum(
+        "albpv,pks->albvks", Qr[:, :, :, NIR:], zp[:NIR]
+    ) * yk
+    W = np.einsum("vks,albvks->albks", t["H"], Z)  # [2,Nl,Nl,Nk,Ns]
+    out = dict(st)
+    out["P11l"] = st["P11l"] + np.einsum("lpks,ps,pi->lik", W[0], st["C11"], t["l11"])
+    out["Pctl"] = st["Pctl"] + np.einsum("lpks,ps,pi->lik", W[1], st["Cct"], t["lct"])
+    out["Ploopl"] = st["Ploopl"] + np.einsum("lpks,pis->lik", W[1], st["Cloopl"])
+    out["X"], out["Y"] = X, Y
+    return out
+
+
+def spline_derivs(t, y):
+    """y [..., Nk] -> knot derivatives via the pre-factored tridiagonal system."""
+    dx, lower, inv, cp = t["sp_dx"], t["sp_lower"], t["sp_inv"], t["sp_cp"]
+    n = y.shape[-1]
+    slope = np.diff(y, axis=-1) / dx
+    rhs = np.empty_like(y)
+    rhs[..., 1:-1] = 3.0 * (dx[1:] * slope[..., :-1] + dx[:-1] * slope[..., 1:])
+    d = dx[0] + dx[1]
+    rhs[..., 0] = ((dx[0] + 2 * d) * dx[1] * slope[..., 0] + dx[0] ** 2 * slope[..., 1]) / d
+    d = dx[-1] + dx[-2]
+    rhs[..., -1] = (dx[-1] ** 2 * slope[..., -2] + (2 * d + dx[-1]) * dx[-2] * slope[..., -1]) / d
+    w = np.empty_like(y)
+    w[..., 0] = rhs[..., 0] * inv[0]
+    for i in range(1, n):
+        w[..., i] = (rhs[..., i] - lower[i] * w[..., i - 1]) * inv[i]
+    sd = np.empty_like(y)
+    sd[..., -1] = w[..., -1]
+    for i in range(n - 2, -1, -1):
+        sd[..., i] = w[..., i] - cp[i] * sd[..., i + 1]
+    return sd, slope
+
+
+def spline_eval(t, y, sd, slope, xe):
+    k, dx = t["k"], t["sp_dx"]
+    i = np.clip(np.searchsorted(k, xe, side="right") - 1, 0, k.size - 2)
+    tt = xe - k[i]
+    c3 = (sd[..., i] + sd[..., i + 1] - 2 * slope[..., i]) / dx[i] ** 2
+    c2 = (slope[..., i] - sd[..., i]) / dx[i] - c3 * dx[i]
+    return y[..., i] + tt * (sd[..., i] + tt * (c2 + tt * c3))
+
+
+def ap(t, DA, H, st, names):
+    Nl = t["l11"].shape[0]
+    k, mu, wmu = t["k"], t["mu"], t["wmu"]
+    DAf, Hf = t["ap_fid"]
+    qperp, qpar = DA / DAf, Hf / H
+    F = qpar / qperp
+    root = np.sqrt(1 + mu**2 * (F**-2 - 1))
+    kp = k[:, None] / qperp * root[None, :]
+    mup = mu / F / root
+    x2 = mup**2
+    legp = np.stack([np.ones_like(x2), 0.5 * (3 * x2 - 1), (35 * x2**2 - 30 * x2 + 3) / 8.0])[:Nl]
+    out = dict(st)
+    for n in names:
+        y = st[n]
+        sd, slope = spline_derivs(t, y)
+        val = spline_eval(t, y, sd, slope, kp)  # [Nl,rows,Nk,Nmu]
+        pkmu = np.einsum("lrkm,lm->rkm", val, legp)
+        out[n] = 2.0 / (qperp**2 * qpar) * np.einsum("rkm,lm,m->lrk", pkmu, t["legmu"], wmu)
+    return out

@@ -1,0 +1,108 @@
+"""GPU parity: every stage of the HIP engine (through the C ABI) against the CPU oracle and the
+reference-generated golden fixtures.  Tolerance: 1e-6 relative is the north-star bar; we assert
+1e-8 (row-scaled) because both sides are FP64 and only summation order differs."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from eftpipe_amd import synth
+from oracle_util import oracle_engine
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
+
+
+def make_engine(g, resum, ap, APst=False, max_batch=1):
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    native = g["k"].size == 50
+    z = float(g["z"])
+    cfg = EngineConfig(Nl=int(g["Nl"]), k=None if native else g["k"], with_resum=resum, with_ap=ap, APst=APst,
+                       DA_AP=float(synth.da_func(synth.OM_AP, z)), H_AP=float(synth.hubble(synth.OM_AP, z)))
+    return Engine(cfg, max_batch=max_batch)
+
+
+@pytest.mark.parametrize("name,resum,ap,APst", [("caseA", False, False, False), ("caseB", False, False, False),
+                                                 ("caseE", True, True, False), ("caseC", True, True, True),
+                                                 ("caseD", True, True, False)])
+def test_stage_parity(golden, name, resum, ap, APst):
+    from eftpipe_amd import _lib as L
+
+    g = golden(name)
+    Nl, Nk = int(g["Nl"]), g["k"].size
+    f, DA, H = float(g["f"]), float(g["DA"]), float(g["H"])
+    orc = oracle_engine(g, name, window_file=None, kout=None)
+    taps = {}
+    orc.evaluate(g["kin"], g["Pin"], f, DA, H, pairwise=True, taps=taps)
+    eng = make_engine(g, resum, ap, APst)
+    eng.load_inputs(g["Pin"], f, DA if ap else None, H if ap else None)
+
+    eng.run(L.S_PREP | L.S_LOOPS)
+    assert relerr(eng.get("P11", (Nk,)), g["pscf_P11"]) < 1e-12
+    c = eng.get("COEF", (2, 129))
+    assert relerr(c[0] + 1j * c[1], g["coef"][:129]) < 1e-12
+    assert relerr(eng.get("P22", (28, Nk)), g["pscf_P22"]) < TOL
+    assert relerr(eng.get("P13", (10, Nk)), g["pscf_P13"]) < TOL
+    if resum:
+        eng.run(L.S_CF)
+        assert relerr(eng.get("C11", (Nl, 80)), g["pscf_C11"]) < TOL
+        assert relerr(eng.get("CCT", (Nl, 80)), g["pscf_Cct"]) < TOL
+        cc = eng.get("CC", (Nl * 38, 80))
+        assert relerr(cc[: Nl * 28].reshape(Nl, 28, 80), g["pscf_C22"]) < TOL
+        assert relerr(cc[Nl * 28 :].reshape(Nl, 10, 80), g["pscf_C13"]) < TOL
+    eng.run(L.S_REGROUP)
+    T = eng.get("TEMPL", (Nl, 24, Nk))
+    for n, sl in ROWS.items():
+        assert relerr(T[:, sl], g["setpscfl_" + n]) < TOL, n
+    if resum:
+        assert relerr(eng.get("CLOOPL", (Nl, 12, 80)), g["setpscfl_Cloopl"]) < TOL
+        eng.run(L.S_RESUM)
+        xy = eng.get("XY", (2, 80))
+        assert relerr(xy[0], g["resum_X"]) < 1e-10 and relerr(xy[1], g["resum_Y"]) < 1e-10
+        assert relerr(eng.get("Q", g["resum_Q"].shape).reshape(-1, g["resum_Q"].shape[-1]),
+                      g["resum_Q"].reshape(-1, g["resum_Q"].shape[-1])) < 1e-12
+        T = eng.get("TEMPL", (Nl, 24, Nk))
+        for n in ("P11l", "Pctl", "Ploopl"):
+            assert relerr(T[:, ROWS[n]], g["resum_" + n]) < TOL, n
+    if ap:
+        eng.run(L.S_AP)
+        T = eng.get("TEMPL", (Nl, 24, Nk))
+        for n, sl in ROWS.items():
+            assert relerr(T[:, sl], g["ap_" + n]) < TOL, n
+            assert relerr(T[:, sl], taps["ap"][n]) < TOL, n
+    # bias contraction on the device (auto spectrum, no Picc)
+    bsA, es = list(g["bsA"]), tuple(g["es"])
+    b11, bloop, bct, bst = orc.bias_vectors(f, bsA, None, es)
+    eng.put("BIAS", np.concatenate([b11, bct, bloop, bst]))
+    eng.run(L.S_REDUCE)
+    last = taps["ap"] if ap else taps["setpscfl"]
+    assert relerr(eng.get("PLK", (Nl, Nk)), orc.reduce_plk(f, last, bsA, es=es)) < TOL
+    if name != "caseC":  # caseC's golden P_l is taken after the window stage
+        assert relerr(eng.get("PLK", (Nl, Nk)), g["plk_auto"]) < TOL
+    eng.close()
+
+
+def test_eval_batch_matches_stagewise_and_oracle(golden):
+    """Batched one-call path (host buffers in/out) over seeded draws == oracle per draw."""
+    g = golden("caseE")
+    B = 5
+    draws = synth.draw_batch(B, z=0.7)
+    eng = make_engine(g, True, True, max_batch=8)
+    templ = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"])
+    orc = oracle_engine(g, "caseE")
+    for i in range(B):
+        st = orc.evaluate(draws["kin"], draws["Pin"][i], float(draws["f"][i]), float(draws["DA"][i]), float(draws["H"][i]))
+        for n, sl in ROWS.items():
+            assert relerr(templ[i][:, sl], st[n]) < TOL, (i, n)
+    eng.close()
+
+
+def test_final_nk2048(golden):
+    g = golden("caseF")
+    eng = make_engine(g, True, True)
+    templ = eng.eval_batch(g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]))[0]
+    for n, sl in ROWS.items():
+        assert relerr(templ[:, sl], g["ap_" + n]) < TOL, n
+    eng.close()

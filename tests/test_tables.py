@@ -1,0 +1,63 @@
+"""Host logic: the real-reduced / operator-folded tables reproduce the oracle (CPU only)."""
+import numpy as np
+import pytest
+
+import emulate as E
+from conftest import relerr
+from eftpipe_amd import synth
+from eftpipe_amd.tables import EngineConfig, build_tables, spline_factors
+from oracle_util import oracle_engine
+
+
+def _tables(g, resum, ap, **kw):
+    from oracle.engine import da_func, hubble
+
+    native = g["k"].size == 50
+    cfg = EngineConfig(Nl=int(g["Nl"]), k=None if native else g["k"], with_resum=resum, with_ap=ap,
+                       DA_AP=da_func(synth.OM_AP, float(g["z"])), H_AP=hubble(synth.OM_AP, float(g["z"])), **kw)
+    return build_tables(cfg)
+
+
+@pytest.mark.parametrize("name,resum,ap", [("caseA", False, False), ("caseE", True, True), ("caseC", True, True)])
+def test_device_algebra_matches_oracle(golden, name, resum, ap):
+    g = golden(name)
+    t = _tables(g, resum, ap)
+    assert np.all(t["reduction_residue"] < 1e-12)
+    f = float(g["f"])
+    eng = oracle_engine(g, name, window_file=None, kout=None)
+    taps = {}
+    eng.evaluate(g["kin"], g["Pin"], f, float(g["DA"]), float(g["H"]), taps=taps)
+    st = E.pscf(t, g["Pin"], with_cf=resum)
+    for n in ("P11", "P22", "P13") + (("C11", "Cct", "C22", "C13") if resum else ()):
+        assert relerr(st[n], taps["pscf"][n]) < 1e-9, n
+    st.update(E.setpscfl(t, f, st, with_cf=resum))
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl") + (("Cloopl",) if resum else ()):
+        assert relerr(st[n], taps["setpscfl"][n]) < 1e-9, n
+    if resum:
+        st = E.resum(t, f, g["Pin"], st)
+        assert relerr(st["X"], taps["resum"]["X"]) < 1e-10
+        assert relerr(st["Y"], taps["resum"]["Y"]) < 1e-10
+        for n in ("P11l", "Pctl", "Ploopl"):
+            assert relerr(st[n], taps["resum"][n]) < 1e-9, n
+    if ap:
+        names = ("P11l", "Pctl", "Ploopl") + (("Pstl",) if name == "caseC" else ())
+        st = E.ap(t, float(g["DA"]), float(g["H"]), st, names)
+        for n in names:
+            assert relerr(st[n], taps["ap"][n]) < 1e-9, n
+            assert relerr(st[n], g["ap_" + n]) < 1e-9, n
+
+
+def test_spline_factors_match_scipy():
+    from scipy.interpolate import CubicSpline
+
+    k = synth.survey_kgrid(256)
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=(5, k.size)).cumsum(axis=-1)
+    t = dict(k=k)
+    f = spline_factors(k)
+    t.update(sp_dx=f["dx"], sp_lower=f["lower"], sp_inv=f["inv"], sp_cp=f["cp"])
+    sd, slope = E.spline_derivs(t, y)
+    cs = CubicSpline(k, y, axis=-1)
+    assert np.max(np.abs(sd - cs(k, 1))) < 1e-9 * np.max(np.abs(cs(k, 1)))
+    xe = np.concatenate([[0.0005], rng.uniform(0.001, 0.3, 400), [0.31]])
+    assert relerr(E.spline_eval(t, y, sd, slope, xe), cs(xe)) < 1e-12
