@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: theory P_l(k) evaluations / second (single tracer, Nk=512, l=0,2,4).
+
+Workload = BASELINE.json configs[1]: LRG z=0.7, Nl=3, Nk=512, IR-resummation + AP, SYNTH-PLIN v1
+draws (seed 12345 + rank), `--batch` cosmologies per GPU per step.  A step = one pass of the hot path
+(FFTLog coefficients -> P22/P13/C11/Cct/C22/C13 -> regroup -> resum -> AP -> bias contraction) over
+the batch, inputs resident in HBM, followed (N > 1) by the RCCL gather of P_l to rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel:
+the FP64-MFMA pair GEMM of P22, timed live with HIP events on the engine stream) and
+`cpu_baseline` (the NumPy oracle, "port", timed on this host on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NL, NK, Z = 3, 512, 0.7
+BS = [2.1401334, 0.77616816 / np.sqrt(2.0), 0.77003455, 0.77616816 / np.sqrt(2.0), -1.8396613, -1.8918368, -1.4856405]
+ES = (0.26033594, 0.0, -0.92895016)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
+NPOW = 257
+
+
+def cpu_baseline(budget_s=20.0):
+    """Time the oracle (NumPy restatement of the reference path) on this host, bounded sample."""
+    from eftpipe_amd import synth
+    from oracle import OracleConfig, OracleEngine
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    k = synth.survey_kgrid(NK)
+    orc = OracleEngine(OracleConfig(Nl=NL, k=k, ndA=4.5e-5, with_resum=True, with_ap=True, Om_AP=synth.OM_AP, z_AP=Z))
+    draws = synth.draw_batch(8, z=Z)
+
+    def run(pairwise, budget):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            i = n % 8
+            orc.evaluate(draws["kin"], draws["Pin"][i], float(draws["f"][i]), float(draws["DA"][i]), float(draws["H"][i]), pairwise=pairwise)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 64:
+                return n, el
+
+    n1, t1 = run(False, budget_s * 0.6)
+    n2, t2 = run(True, budget_s * 0.4)
+    return {
+        "value": n1 / t1, "unit": "evaluations/s", "cores": int(threads), "kind": "port",
+        "sample": f"{n1} evaluations of the cfg-2 workload with the reference's einsum paths (as-is) in {t1:.1f}s; "
+                  f"with the pairwise P22 path forced: {n2 / t2:.3f} evaluations/s ({n2} in {t2:.1f}s)",
+        "value_pairwise_path": n2 / t2,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="cosmologies per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd import dist, synth
+    from eftpipe_amd.engine import Engine, comm_unique_id, mfma_f64_peak
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    cp = dist.ControlPlane()
+    rank, world = cp.rank, cp.world
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    B = args.batch
+    cfg = EngineConfig(Nl=NL, k=synth.survey_kgrid(NK), with_resum=True, with_ap=True,
+                       DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
+    eng = Engine(cfg, max_batch=B, device=cp.local_rank)
+    if world > 1:
+        uid = cp.broadcast_bytes(comm_unique_id() if rank == 0 else None)
+        eng.comm_init(world, rank, uid)
+    draws = synth.draw_batch(B, z=Z, seed=12345 + rank)
+    bias = np.stack([bias_row(float(f), BS, None, ES, kmA=0.7, krA=0.25, ndA=4.5e-5) for f in draws["f"]])
+    eng.load_inputs(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias)
+    mask = eng.full_mask(reduce=True)
+
+    def step():
+        eng.run(mask, B, sync=False)
+        if world > 1:
+            eng.gather_plk(B, root=0)
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    cp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.sync()
+    cp.barrier()
+    elapsed = cp.max(time.perf_counter() - t0)
+
+    # sanity: finite outputs (parity itself is the job of tests/ and smoke())
+    plk = eng.get("PLK", (B, NL, NK))
+    assert np.all(np.isfinite(plk)), "non-finite P_l(k)"
+
+    if rank == 0:
+        # dominant kernel: the P22 pair GEMM, HIP events around back-to-back launches on the engine stream
+        reps = 10
+        ms_p22 = eng.run_timed(L.K_P22, B, reps)
+        ms_c22 = eng.run_timed(L.K_C22, B, reps)
+        stages = {n: eng.run_timed(m, B, 3) for n, m in (("prep", L.S_PREP), ("loops", L.S_LOOPS), ("cf", L.S_CF),
+                                                        ("regroup", L.S_REGROUP), ("resum", L.S_RESUM), ("ap", L.S_AP), ("reduce", L.S_REDUCE))}
+        # AP ping-pongs the template block; leave the state consistent
+        alg_flops = 8.0 * 28 * NK * NPOW**2 * B          # F_P22 per evaluation x B
+        exe_flops = 2.0 * 32 * 4 * eng.tables["steps"].shape[0] * NK * B   # MFMA flops actually issued (real-reduced pairs, 32 cols)
+        achieved = alg_flops / (ms_p22 * 1e-3) / 1e12
+        try:
+            measured_peak = mfma_f64_peak(cp.local_rank)
+        except Exception:
+            measured_peak = None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_p22.json")
+        if os.path.exists(pmc):
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        roofline = {
+            "bound": "mfma", "kernel": "pair_gemm_kernel<4,2> (makeP22)", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "ms_per_launch": ms_p22, "algorithmic_flops_per_launch": alg_flops,
+            "executed_mfma_flops_per_launch": exe_flops, "executed_tflops": exe_flops / (ms_p22 * 1e-3) / 1e12,
+            "executed_frac_of_peak": exe_flops / (ms_p22 * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "measured_mfma_f64_issue_peak_tflops": measured_peak,
+            "c22_pair_gemm_ms": ms_c22, "stage_ms": stages,
+        }
+        value = B * world * args.steps / elapsed
+        out = {
+            "metric": "theory P_l(k) evaluations/sec (single tracer, Nk=512, l=0,2,4)",
+            "value": value, "unit": "evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (SYNTH-PLIN v1, seed 12345+rank)",
+            "config": {"workload": "cfg2: single-tracer LRG z=0.7, Nl=3 (l=0,2,4), Nk=512, IR-resum + AP, P_l via west-coast bias contraction",
+                       "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, RCCL gather of P_l to rank 0" if world > 1 else "single GPU"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    cp.barrier()
+    eng.close()
+    cp.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,10 +33,11 @@ TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL KPOW SPOW PAIRS22 PAIRSC PLAN M13R C11R
 T = {n: i for i, n in enumerate(TABLES)}
 BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK PROJ COEF".split()
 B = {n: i for i, n in enumerate(BUFFERS)}
-S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE = (1 << i for i in range(8))
+S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22 = (1 << i for i in range(10))
 
 EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_destroy eftb_put eftb_get eftb_buffer_size eftb_run "
-           "eftb_sync eftb_run_timed eftb_eval_batch eftb_mfma_f64_peak eftb_last_error eftb_version").split()
+           "eftb_sync eftb_run_timed eftb_eval_batch eftb_comm_unique_id eftb_comm_init eftb_gather_plk "
+           "eftb_mfma_f64_peak eftb_last_error eftb_version").split()
 
 _lib = None
 
@@ -62,6 +63,9 @@ def load():
     lib.eftb_sync.argtypes, lib.eftb_sync.restype = [vp], i32
     lib.eftb_run_timed.argtypes, lib.eftb_run_timed.restype = [vp, i32, i32, i32, C.POINTER(C.c_float)], i32
     lib.eftb_eval_batch.argtypes, lib.eftb_eval_batch.restype = [vp, i32, dp, dp, dp, dp, dp, dp, dp], i32
+    lib.eftb_comm_unique_id.argtypes, lib.eftb_comm_unique_id.restype = [C.c_char_p], i32
+    lib.eftb_comm_init.argtypes, lib.eftb_comm_init.restype = [vp, i32, i32, C.c_char_p], i32
+    lib.eftb_gather_plk.argtypes, lib.eftb_gather_plk.restype = [vp, i32, i32, dp], i32
     lib.eftb_mfma_f64_peak.argtypes, lib.eftb_mfma_f64_peak.restype = [i32, dp], i32
     lib.eftb_last_error.argtypes, lib.eftb_last_error.restype = [], C.c_char_p
     lib.eftb_version.argtypes, lib.eftb_version.restype = [], C.c_char_p

@@ -3,6 +3,8 @@
 #include "../../include/eftbird.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -46,7 +48,52 @@ struct eftb_engine {
     int resum_chunks = 1;
     int Nn = 0;
     double* k3 = nullptr;  // k^3 row scale of P22
+    // RCCL gather (multi-GPU batches)
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    double* gathered = nullptr;
 };
+
+// RCCL is resolved lazily so that single-GPU users never load it
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.handle) return 0;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail("cannot load librccl.so: %s", dlerror());
+#define RSYM(field, name)                                                 \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+    if (!g_rccl.field) return fail("librccl.so lacks %s", name);
+    RSYM(GetUniqueId, "ncclGetUniqueId")
+    RSYM(CommInitRank, "ncclCommInitRank")
+    RSYM(CommDestroy, "ncclCommDestroy")
+    RSYM(GroupStart, "ncclGroupStart")
+    RSYM(GroupEnd, "ncclGroupEnd")
+    RSYM(Send, "ncclSend")
+    RSYM(Recv, "ncclRecv")
+    RSYM(GetErrorString, "ncclGetErrorString")
+#undef RSYM
+    g_rccl.handle = h;
+    return 0;
+}
+
+#define NCCLCHK(expr)                                                                            \
+    do {                                                                                         \
+        ncclResult_t _r = (expr);                                                                \
+        if (_r != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(_r));   \
+    } while (0)
 
 static size_t need_table_bytes(const eftb_config& c, int id) {
     const size_t D = sizeof(double);
@@ -132,18 +179,22 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
                            b[EFTB_B_P11], b[EFTB_B_COEF]);
     }
-    if (mask & EFTB_S_LOOPS) {
+    if (mask & EFTB_S_LOOPS)
         hipLaunchKernelGGL(uvec_kernel, dim3(Nk, B), dim3(256), 0, st, Nk, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), e->U);
+    if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
         const int rows = B * Nk;
         const size_t lds = pair_lds_bytes(4, 2);
         hipLaunchKernelGGL((pair_gemm_kernel<4, 2>), dim3((rows + 63) / 64), dim3(256), lds, st, e->U, tb<double>(e, EFTB_T_PAIRS22),
                            tb<int>(e, EFTB_T_PLAN), rows, Nk, 28, e->k3, b[EFTB_B_P22]);
+    }
+    if (mask & EFTB_S_LOOPS) {
         hipLaunchKernelGGL((rowdot_kernel<10>), dim3((Nk + 3) / 4, B), dim3(256), 0, st, 0, Nk, Nl, e->U, tb<double>(e, EFTB_T_M13R),
                            (const double*)nullptr, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], b[EFTB_B_P13], (double*)nullptr);
     }
-    if (mask & EFTB_S_CF) {
-        if (!c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
+    if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
+    if (mask & EFTB_S_CF)
         hipLaunchKernelGGL(uvec_kernel, dim3(NS, B), dim3(256), 0, st, NS, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), e->Us);
+    if (mask & (EFTB_S_CF | EFTB_K_C22)) {
         const int rows = B * NS;
         const size_t lds = pair_lds_bytes(2, Nl == 3 ? 8 : 5);
         if (Nl == 3)
@@ -152,6 +203,8 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         else
             hipLaunchKernelGGL((pair_gemm_kernel<2, 5>), dim3((rows + 31) / 32), dim3(256), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
                                tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
+    }
+    if (mask & EFTB_S_CF) {
         hipLaunchKernelGGL((rowdot_kernel<6>), dim3((NS + 3) / 4, B), dim3(256), 0, st, 1, NS, Nl, e->Us, tb<double>(e, EFTB_T_C11R),
                            tb<double>(e, EFTB_T_CCTR), tb<double>(e, EFTB_T_S), (const double*)nullptr, b[EFTB_B_C11], b[EFTB_B_CCT]);
     }
@@ -302,7 +355,8 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3}) if (p) (void)hipFree(p);
+    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered}) if (p) (void)hipFree(p);
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -388,6 +442,55 @@ int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, c
     HIPCHK(hipMemcpyAsync(templ, e->buf[EFTB_B_TEMPL], (size_t)B * c.Nl * NROW * c.Nk * sizeof(double), hipMemcpyDeviceToHost, st));
     if (plk) HIPCHK(hipMemcpyAsync(plk, e->buf[EFTB_B_PLK], (size_t)B * c.Nl * c.Nk * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int eftb_comm_unique_id(char id[128]) {
+    if (!id) return fail("eftb_comm_unique_id: null argument");
+    if (int rc = rccl_load()) return rc;
+    ncclUniqueId u;
+    NCCLCHK(g_rccl.GetUniqueId(&u));
+    static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id, &u, 128);
+    return 0;
+}
+
+int eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]) {
+    if (!e || !id) return fail("eftb_comm_init: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("eftb_comm_init: bad rank %d of %d", rank, nranks);
+    if (int rc = rccl_load()) return rc;
+    HIPCHK(hipSetDevice(e->c.device));
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    NCCLCHK(g_rccl.CommInitRank(&e->comm, nranks, u, rank));
+    e->nranks = nranks;
+    e->rank = rank;
+    return 0;
+}
+
+int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
+    if (!e) return fail("eftb_gather_plk: null engine");
+    if (B < 1 || B > e->c.max_batch) return fail("eftb_gather_plk: batch %d outside [1, %d]", B, e->c.max_batch);
+    if (root < 0 || root >= e->nranks) return fail("eftb_gather_plk: bad root %d", root);
+    HIPCHK(hipSetDevice(e->c.device));
+    const int nx = e->c.nproj > 0 ? e->c.nproj : e->c.Nk, nl = e->c.nproj > 0 ? e->c.nproj_l : e->c.Nl;
+    const size_t count = (size_t)B * nl * nx;
+    if (e->rank == root && !e->gathered)
+        HIPCHK(hipMalloc(&e->gathered, (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
+    if (e->nranks == 1) {
+        HIPCHK(hipMemcpyAsync(e->gathered, e->buf[EFTB_B_PLK], count * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    } else {
+        if (!e->comm) return fail("eftb_gather_plk: eftb_comm_init was not called");
+        NCCLCHK(g_rccl.GroupStart());
+        if (e->rank == root)
+            for (int r = 0; r < e->nranks; ++r) NCCLCHK(g_rccl.Recv(e->gathered + (size_t)r * count, count, ncclDouble, r, e->comm, e->stream));
+        NCCLCHK(g_rccl.Send(e->buf[EFTB_B_PLK], count, ncclDouble, root, e->comm, e->stream));
+        NCCLCHK(g_rccl.GroupEnd());
+    }
+    if (host_out && e->rank == root) {
+        HIPCHK(hipMemcpyAsync(host_out, e->gathered, (size_t)e->nranks * count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     return 0;
 }
 

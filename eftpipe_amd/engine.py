@@ -186,6 +186,30 @@ class Engine:
         return Pin.shape[0]
 
 
+    # ------------------------------------------------------------------ multi-GPU gather (RCCL)
+    def comm_init(self, nranks, rank, unique_id: bytes):
+        assert len(unique_id) == 128
+        L.check(self.lib.eftb_comm_init(self._h, nranks, rank, unique_id))
+        self.nranks, self.rank = nranks, rank
+
+    def gather_plk(self, B, root=0, to_host=False):
+        """RCCL gather of P_l[0:B] from every rank to `root` (asynchronous unless to_host)."""
+        out = None
+        nranks = getattr(self, "nranks", 1)
+        if to_host and getattr(self, "rank", 0) == root:
+            nx = self.projection.shape[2] if self.projection is not None else self.Nk
+            nl = self.projection.shape[0] if self.projection is not None else self.Nl
+            out = np.empty((nranks, B, nl, nx))
+        L.check(self.lib.eftb_gather_plk(self._h, B, root, L.dptr(out)))
+        return out
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    L.check(L.load().eftb_comm_unique_id(buf))
+    return buf.raw
+
+
 def mfma_f64_peak(device=0):
     """Measured v_mfma_f64_16x16x4_f64 issue rate in TFLOP/s."""
     lib = L.load()

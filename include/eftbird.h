@@ -89,7 +89,10 @@ enum eftb_stage {
     EFTB_S_AP      = 1 << 5,  /* APeffect.AP                                  pybird.py:1598-1621 */
     EFTB_S_PROJECT = 1 << 6,  /* Window.Window / Binning / Chained (folded)   window.py:371-415, binning.py:131-162, chained.py:56-68 */
     EFTB_S_REDUCE  = 1 << 7,  /* reduce_Plk                                   parambasis.py:42-136 */
-    EFTB_S_ALL     = 0xff
+    EFTB_S_ALL     = 0xff,
+    /* single-kernel selectors (profiling / roofline measurement only; need the stage's inputs in place) */
+    EFTB_K_P22     = 1 << 8,  /* the FP64-MFMA pair GEMM of makeP22 alone */
+    EFTB_K_C22     = 1 << 9   /* the FP64-MFMA pair GEMM of makeC22 + makeC13 alone */
 };
 
 int  eftb_create(const eftb_config* cfg, eftb_engine** out);
@@ -112,6 +115,16 @@ int  eftb_run_timed(eftb_engine* e, int stage_mask, int B, int repeats, float* m
  * templ is [B][Nl][24][Nk] (rows as EFTB_B_TEMPL); plk may be NULL, else bias must be [B][24]. */
 int  eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA,
                      const double* H, double* templ, const double* bias, double* plk);
+
+/* Multi-GPU: cosmologies are sharded over ranks (one process per GPU); the only exchange is the gather of
+ * the per-cosmology P_l(k) to `root` over RCCL (xGMI).  No reference counterpart: cobaya chains are
+ * independent MPI processes (reference README.md:29-34).  The 128-byte id comes from rank 0
+ * (eftb_comm_unique_id) and is handed to every rank by the host (any side channel). */
+int  eftb_comm_unique_id(char id[128]);
+int  eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]);
+/* Gather EFTB_B_PLK rows [0, B) of every rank into root's device buffer (rank-major) on the engine stream;
+ * if host_out != NULL (root only) the gathered block [nranks][B][Nl][Nx] is copied out after the gather. */
+int  eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out);
 
 /* Measured FP64 MFMA issue rate (v_mfma_f64_16x16x4_f64), TFLOP/s, for the roofline denominator. */
 int  eftb_mfma_f64_peak(int device, double* tflops);
