@@ -35,7 +35,7 @@ BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK PROJ COE
 B = {n: i for i, n in enumerate(BUFFERS)}
 S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22 = (1 << i for i in range(10))
 
-EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_destroy eftb_put eftb_get eftb_buffer_size eftb_run "
+EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_destroy eftb_put eftb_get eftb_buffer_size eftb_run "
            "eftb_sync eftb_run_timed eftb_eval_batch eftb_comm_unique_id eftb_comm_init eftb_gather_plk "
            "eftb_mfma_f64_peak eftb_last_error eftb_version").split()
 
@@ -55,6 +55,7 @@ def load():
     lib.eftb_create.argtypes, lib.eftb_create.restype = [C.POINTER(Config), C.POINTER(vp)], i32
     lib.eftb_set_table.argtypes, lib.eftb_set_table.restype = [vp, i32, vp, sz], i32
     lib.eftb_finalize.argtypes, lib.eftb_finalize.restype = [vp], i32
+    lib.eftb_set_option.argtypes, lib.eftb_set_option.restype = [vp, i32, i32], i32
     lib.eftb_destroy.argtypes, lib.eftb_destroy.restype = [vp], None
     lib.eftb_put.argtypes, lib.eftb_put.restype = [vp, i32, sz, dp, sz], i32
     lib.eftb_get.argtypes, lib.eftb_get.restype = [vp, i32, sz, dp, sz], i32

@@ -349,6 +349,14 @@ int eftb_finalize(eftb_engine* e) {
     return 0;
 }
 
+int eftb_set_option(eftb_engine* e, int option, int value) {
+    if (!e) return fail("eftb_set_option: null engine");
+    switch (option) {
+        case EFTB_O_AP_STOCHASTIC: e->c.ap_stochastic = value ? 1 : 0; return 0;
+    }
+    return fail("eftb_set_option: unknown option %d", option);
+}
+
 void eftb_destroy(eftb_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->c.device);

@@ -110,6 +110,13 @@ class Engine:
         if self.projection is not None:
             self._set("PROJ", self.projection)
 
+    def set_ap_fiducial(self, DA, H):
+        """Replace the fiducial (DA, H) of the AP stage (APeffect constructor, pybird.py:1522-1530)."""
+        self._set("APFID", np.array([DA, H], dtype=np.float64))
+
+    def set_ap_stochastic(self, flag):
+        L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.eftb_destroy(self._h)

@@ -100,6 +100,12 @@ int  eftb_set_table(eftb_engine* e, int table_id, const void* host, size_t nbyte
 int  eftb_finalize(eftb_engine* e);
 void eftb_destroy(eftb_engine* e);
 
+/* Run-time switches that the reference keeps on plugin objects rather than on Common. */
+enum eftb_option {
+    EFTB_O_AP_STOCHASTIC = 0  /* APeffect.APst                                pybird.py:1514, 1618 */
+};
+int  eftb_set_option(eftb_engine* e, int option, int value);
+
 /* Host <-> device state.  `offset`/`count` are in elements (doubles). */
 int  eftb_put(eftb_engine* e, int buffer_id, size_t offset, const double* host, size_t count);
 int  eftb_get(eftb_engine* e, int buffer_id, size_t offset, double* host, size_t count);

@@ -1,0 +1,106 @@
+"""Host logic on the CPU: Common mirror, bias vectors, wave plan, sharding, gloo control plane."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, relerr
+
+
+def test_common_mirror_matches_reference_tables(golden):
+    from eftpipe_amd import pybird
+
+    g = golden("tables")
+    for Nl in (2, 3):
+        co = pybird.Common(Nl=Nl, kmax=0.3)
+        for n in ("l11", "lct", "l22", "l13"):
+            assert np.array_equal(getattr(co, n), g[f"{n}_Nl{Nl}"])
+        assert co.Nk == 50 and co.Ns == 80 and co.Nklow == 7 and co.Nloop == 12
+    assert np.array_equal(pybird.Common(Nl=3).k, golden("caseC")["k"])
+    with pytest.raises(ValueError):
+        pybird.Common(Nl=2, No=3)
+    with pytest.raises(NotImplementedError):
+        pybird.Common(Nl=2, with_NNLO=True)
+    # reference tests/test_pybird.py:5-11
+    assert np.isclose(pybird.Hubble(0.2, 1.0), 1.549193338482967, atol=0.0)
+    assert np.isclose(pybird.DAfunc(0.2, 1.0), 0.4117451980802465, atol=0.0)
+
+
+def test_bias_vectors_match_oracle(golden):
+    from eftpipe_amd.parambasis import bias_row, bias_vectors
+    from oracle import OracleConfig, OracleEngine
+
+    g = golden("caseA")
+    orc = OracleEngine(OracleConfig(Nl=2, ndA=4.5e-5, kmB=0.6, krB=0.3, ndB=2.3e-4))
+    f = 0.77
+    want = orc.bias_vectors(f, list(g["bsA"]), list(g["bsB"]), tuple(g["es"]))  # b11, bloop, bct, bst
+    got = bias_vectors(f, list(g["bsA"]), list(g["bsB"]), tuple(g["es"]), kmA=0.7, krA=0.25, ndA=4.5e-5, kmB=0.6, krB=0.3, ndB=2.3e-4)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[2])
+    assert np.array_equal(got[2], want[1]) and np.array_equal(got[3], want[3])
+    assert bias_row(f, list(g["bsA"])).shape == (24,)
+
+
+def test_wave_plan_covers_all_steps():
+    from eftpipe_amd.engine import wave_plan
+    from eftpipe_amd.tables import pair_steps
+
+    st = pair_steps()
+    assert len(st) == sum((257 - n + 3) // 4 for n in range(257))
+    plan = wave_plan(st)
+    assert plan[:, 3].sum() == len(st) and plan[0, 2] == 0
+    for q in range(4):
+        assert tuple(st[plan[q, 2]]) == (plan[q, 0], plan[q, 1])
+    # every unordered pair appears exactly once
+    seen = set()
+    for n, m0 in st:
+        for g in range(4):
+            if m0 + g <= 256:
+                seen.add((n, m0 + g))
+    assert len(seen) == 257 * 258 // 2
+
+
+def test_shard_bounds():
+    from eftpipe_amd.dist import shard_bounds
+
+    for total in (1, 7, 128, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                a, b = shard_bounds(total, world, r)
+                cover += list(range(a, b))
+                assert b - a in (total // world, total // world + 1)
+            assert cover == list(range(total))
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from eftpipe_amd import dist
+cp = dist.ControlPlane()
+a, b = dist.shard_bounds(10, cp.world, cp.rank)
+local = np.arange(a, b, dtype=float)[:, None] * np.ones((1, 3))
+payload = cp.broadcast_bytes(b"x" * 128 if cp.rank == 0 else None)
+assert payload == b"x" * 128
+tmax = cp.max(1.0 + cp.rank)
+assert tmax == float(cp.world)
+g = cp.gather_host(local)
+cp.barrier()
+if cp.rank == 0:
+    assert g.shape == (cp.world, 5, 3) and np.array_equal(g.reshape(-1, 3)[:, 0], np.arange(10.0))
+    print("GATHER_OK")
+cp.close()
+"""
+
+
+def test_control_plane_world_size_2_gloo(tmp_path):
+    """The N > 1 control path (rendezvous bytes, barrier, max over ranks, host gather) on gloo."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
