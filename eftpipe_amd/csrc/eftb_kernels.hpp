@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void uvec_kernel(int rows, const double* __res
 // ------------------------------------------------------------------------------------------------
 // pair GEMM on the FP64 matrix cores.
 //   out[row, col] = scale[row] * sum_{t, g} u[row, n_t] u[row, m_t + g] * frag[t][col/16][g][col%16]
-// Workgroup = 4 waves = MT*16 rows, the whole K range split 4 ways over the waves (one wave per SIMD,
+// Workgroup = 8 waves = MT*16 rows, the whole K range split 8 ways over the waves (two waves per SIMD,
 // each with MT*NT independent accumulator tiles); the u tile lives in LDS (stride 258 doubles), the B
 // fragments are read once per workgroup straight into registers (8 B/lane, 512 B per instruction).
 // MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = lane >> 4],
@@ -93,28 +93,32 @@ __global__ __launch_bounds__(256) void uvec_kernel(int rows, const double* __res
 // Output element (row, col) is written to out[w][col][r] (w = row / rows_per_w, r = row % rows_per_w).
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NT>
-__global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
+__global__ __launch_bounds__(512, 2) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
                                                            const int* __restrict__ plan, int rows_total, int rows_per_w,
                                                            int ncols_out, const double* __restrict__ rowscale,
                                                            double* __restrict__ out) {
     constexpr int ROWS = MT * 16;
+    constexpr int NW = 8;  // waves per workgroup = K slices (two waves per SIMD hide each other's LDS/L2 latency)
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS;
 
     // ---- stage the u tile: 130 x 16-byte pieces per row (cols 0..259), LDS stride 258
-    for (int idx = tid; idx < ROWS * 130; idx += 256) {
+    for (int idx = tid; idx < ROWS * 130; idx += 64 * NW) {
         const int r = idx / 130, c = idx % 130;
         double2 v = make_double2(0.0, 0.0);
         if (row0 + r < rows_total) v = *reinterpret_cast<const double2*>(U + (size_t)(row0 + r) * UPAD + 2 * c);
         if (c < 129) *reinterpret_cast<double2*>(sm + r * ULDS + 2 * c) = v;
     }
-    if (tid < 8) sm[ROWS * ULDS + tid] = 0.0;  // slack read by the zero-weight pad pairs of the last row
+    if (tid < 16) sm[ROWS * ULDS + tid] = 0.0;  // slack read by the zero-weight pad pairs of the last row
     __syncthreads();
 
     const int r = lane & 15, g = lane >> 4;
-    int n = plan[wave * 4 + 0], m0 = plan[wave * 4 + 1];
-    const int t0 = plan[wave * 4 + 2], nsteps = plan[wave * 4 + 3];
+    // the wave's K range: wave-uniform, kept in SGPRs so the loops below branch on SCC, not EXEC
+    int n = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 0]);
+    int m0 = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 1]);
+    const int t0 = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 2]);
+    int nsteps = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 3]);
     const double* fp = frag + ((size_t)t0 * NT) * 64 + lane;
 
     v4d acc[MT][NT];
@@ -123,60 +127,73 @@ __global__ __launch_bounds__(256, 1) void pair_gemm_kernel(const double* __restr
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    double un[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) un[i] = sm[(r + 16 * i) * ULDS + n];
-
-    double bcur[NT], bnxt[NT];
+    double bcur[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) bcur[j] = fp[j * 64];
     fp += NT * 64;
 
-    for (int it = 0; it < nsteps; ++it) {
-        // prefetch the next step's B fragments (the table has one zero step of padding at the end)
+    const double* urow = sm + r * ULDS;
+    while (nsteps > 0) {
+        // one n-run: pairs (n, m0) ... (n, 256) in steps of 4; the inner loop is branch-free and software
+        // pipelined: B fragments (global) and u_m values (LDS) of step t+1 are in flight under step t's MFMAs
+        const int left = ((2 * NHALF - m0) >> 2) + 1;
+        const int cnt = left < nsteps ? left : nsteps;
+        double un[MT], um[MT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bnxt[j] = fp[j * 64];
-        fp += NT * 64;
-        double a[MT];
+        for (int i = 0; i < MT; ++i) un[i] = urow[i * 16 * ULDS + n];
+        const double* up = urow + m0 + g;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = un[i] * sm[(r + 16 * i) * ULDS + m0 + g];
+        for (int i = 0; i < MT; ++i) um[i] = up[i * 16 * ULDS];
+        for (int it = 0; it < cnt; ++it) {
+            double bnxt[NT], umn[MT], a[MT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bnxt[j] = fp[j * 64];  // table carries one zero step of padding at the end
+            fp += NT * 64;
+            up += 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) umn[i] = up[i * 16 * ULDS];  // at most 8 doubles past the run: inside the slack
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = un[i] * um[i];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bcur[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) um[i] = umn[i];
+        }
+        nsteps -= cnt;
+        ++n;
+        m0 = n;
+    }
+
+    // ---- reduce the 8 K-slices through LDS (the u tile is dead now) and write out, JC column tiles per pass
+    constexpr int JC = (NT <= 2) ? NT : ((NT % 3 == 0) ? NT / 3 : ((NT % 2 == 0) ? NT / 2 : 1));
+    constexpr int PER_WAVE = MT * JC * 4 * 64;
+    static_assert((size_t)NW * PER_WAVE * 8 <= 160 * 1024, "reduction buffer exceeds LDS");
+    for (int jc = 0; jc < NT; jc += JC) {
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bcur[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < JC; ++j)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
-        m0 += 4;
-        if (m0 > 2 * NHALF) {  // wave-uniform: next n-run
-            ++n;
-            m0 = n;
-            if (n < NPOW) {
+                for (int q = 0; q < 4; ++q) sm[wave * PER_WAVE + ((i * JC + j) * 4 + q) * 64 + lane] = acc[i][jc + j][q];
+        __syncthreads();
+        for (int e = tid; e < ROWS * JC * 16; e += 64 * NW) {
+            const int row = e % ROWS, col = jc * 16 + e / ROWS;
+            if (col >= ncols_out || row0 + row >= rows_total) continue;
+            const int i = row >> 4, rr = row & 15, q = rr >> 2, gg = rr & 3;
+            const int j = (e / ROWS) >> 4, ln = gg * 16 + (col & 15);
+            const int off = ((i * JC + j) * 4 + q) * 64 + ln;
+            double v = 0.0;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) un[i] = sm[(r + 16 * i) * ULDS + n];
-            }
+            for (int w8 = 0; w8 < NW; ++w8) v += sm[w8 * PER_WAVE + off];
+            const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
+            if (rowscale) v *= rowscale[rw];
+            out[((size_t)w * ncols_out + col) * rows_per_w + rw] = v;
         }
-    }
-
-    // ---- reduce the 4 K-slices through LDS (the u tile is dead now) and write out
-    __syncthreads();
-    constexpr int PER_WAVE = MT * NT * 4 * 64;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sm[wave * PER_WAVE + ((i * NT + j) * 4 + q) * 64 + lane] = acc[i][j][q];
-    __syncthreads();
-    for (int e = tid; e < ROWS * NT * 16; e += 256) {
-        const int row = e % ROWS, col = e / ROWS;
-        if (col >= ncols_out || row0 + row >= rows_total) continue;
-        const int i = row >> 4, rr = row & 15, q = rr >> 2, gg = rr & 3;
-        const int j = col >> 4, ln = gg * 16 + (col & 15);
-        const int off = ((i * NT + j) * 4 + q) * 64 + ln;
-        double v = (sm[off] + sm[PER_WAVE + off]) + (sm[2 * PER_WAVE + off] + sm[3 * PER_WAVE + off]);
-        const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
-        if (rowscale) v *= rowscale[rw];
-        out[((size_t)w * ncols_out + col) * rows_per_w + rw] = v;
     }
 }
 
@@ -476,15 +493,38 @@ __global__ __launch_bounds__(64) void spline_kernel(int Nk, int nseries, const d
     }
 }
 
+// One workgroup = 4 template rows x 64 k values of one cosmology (wave <-> row, lanes <-> k).  The
+// (cosmology, mu)-only quantities -- k'/k, Legendre(mu'), quadrature weight x (2l+1)/2 L_l(mu) -- are
+// computed once per workgroup into LDS; each lane walks its k'(mu) monotonically through the knots and
+// keeps the cubic of the current interval in registers (reloaded only when the interval changes).
 template <int NL>
-__global__ __launch_bounds__(64) void ap_kernel(int Nk, int nmu, int nrows_ap, const double* __restrict__ kk,
-                                                const double* __restrict__ dxk, const double* __restrict__ DAw,
-                                                const double* __restrict__ Hw, const double* __restrict__ fid,
-                                                const double* __restrict__ mu, const double* __restrict__ wmu,
-                                                const double* __restrict__ legmu, const double* __restrict__ T,
-                                                const double* __restrict__ SD, double* __restrict__ Tout) {
-    const int k = blockIdx.x * 64 + threadIdx.x, row = blockIdx.y, w = blockIdx.z;
-    if (k >= Nk) return;
+__global__ __launch_bounds__(256) void ap_kernel(int Nk, int nmu, int nrows_ap, const double* __restrict__ kk,
+                                                 const double* __restrict__ dxk, const double* __restrict__ DAw,
+                                                 const double* __restrict__ Hw, const double* __restrict__ fid,
+                                                 const double* __restrict__ mu, const double* __restrict__ wmu,
+                                                 const double* __restrict__ legmu, const double* __restrict__ T,
+                                                 const double* __restrict__ SD, double* __restrict__ Tout) {
+    extern __shared__ double sm[];
+    double* s_root = sm;                  // [nmu]      k'/k * qperp
+    double* s_lp = sm + nmu;              // [NL][nmu]  L_l'(mu')
+    double* s_wl = sm + (1 + NL) * nmu;   // [NL][nmu]  wmu * (2l+1)/2 L_l(mu)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, row = blockIdx.y * 4 + wave, w = blockIdx.z;
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
+    for (int j = threadIdx.x; j < nmu; j += blockDim.x) {
+        const double m = mu[j];
+        const double root = sqrt(1.0 + m * m * g);
+        const double mp = m / (F * root), x2 = mp * mp;
+        s_root[j] = root;
+        s_lp[j] = 1.0;
+        s_lp[nmu + j] = 0.5 * (3.0 * x2 - 1.0);
+        if (NL > 2) s_lp[2 * nmu + j] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) s_wl[l * nmu + j] = wmu[j] * legmu[l * nmu + j];
+    }
+    __syncthreads();
+    if (k >= Nk || row >= NROW) return;
     if (row >= nrows_ap) {  // rows that APeffect leaves alone (Pstl unless APst)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -493,8 +533,6 @@ __global__ __launch_bounds__(64) void ap_kernel(int Nk, int nmu, int nrows_ap, c
         }
         return;
     }
-    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
-    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
     const double kq = kk[k] / qperp;
     const double* y[NL];
     const double* sd[NL];
@@ -503,42 +541,49 @@ __global__ __launch_bounds__(64) void ap_kernel(int Nk, int nmu, int nrows_ap, c
         y[l] = T + (((size_t)w * NL + l) * NROW + row) * Nk;
         sd[l] = SD + (((size_t)w * NL + l) * NROW + row) * Nk;
     }
-    // locate the first interval by bisection, then hunt (k' is monotonic in mu)
+    // first interval by bisection, then hunt (k' is monotonic in mu)
     int i0;
     {
+        const double kp0 = kq * s_root[0];
         int lo = 0, hi = Nk - 1;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (kk[mid] <= kq) lo = mid; else hi = mid;
+            if (kk[mid] <= kp0) lo = mid; else hi = mid;
         }
         i0 = lo;
     }
+    int icur = -1;
+    double k0 = 0.0, k1 = 0.0, c0[NL], c1[NL], c2[NL], c3[NL];
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
     for (int j = 0; j < nmu; ++j) {
-        const double m = mu[j];
-        const double root = sqrt(1.0 + m * m * g);
-        const double kp = kq * root, mp = m / (F * root), x2 = mp * mp;
-        while (i0 < Nk - 2 && kp >= kk[i0 + 1]) ++i0;
-        while (i0 > 0 && kp < kk[i0]) --i0;
-        const double t = kp - kk[i0], h = dxk[i0];
-        double Lp[3];
-        Lp[0] = 1.0;
-        Lp[1] = 0.5 * (3.0 * x2 - 1.0);
-        Lp[2] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
+        const double kp = kq * s_root[j];
+        if (icur >= 0) {
+            while (i0 < Nk - 2 && kp >= k1) { ++i0; k1 = kk[i0 + 1]; }
+            while (i0 > 0 && kp < k0) { --i0; k0 = kk[i0]; }
+        }
+        if (i0 != icur) {
+            icur = i0;
+            k0 = kk[i0];
+            k1 = kk[i0 + 1];
+            const double h = dxk[i0], ih = 1.0 / h;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const double y0 = y[l][i0], y1 = y[l][i0 + 1], s0 = sd[l][i0], s1 = sd[l][i0 + 1];
+                const double sl = (y1 - y0) * ih;
+                c0[l] = y0;
+                c1[l] = s0;
+                c3[l] = (s0 + s1 - 2.0 * sl) * ih * ih;
+                c2[l] = (sl - s0) * ih - c3[l] * h;
+            }
+        }
+        const double t = kp - k0;
         double pk = 0.0;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const double y0 = y[l][i0], y1 = y[l][i0 + 1], s0 = sd[l][i0], s1 = sd[l][i0 + 1];
-            const double sl = (y1 - y0) / h;
-            const double c3 = (s0 + s1 - 2.0 * sl) / (h * h);
-            const double c2 = (sl - s0) / h - c3 * h;
-            pk = fma(Lp[l], y0 + t * (s0 + t * (c2 + t * c3)), pk);
-        }
-        const double wj = wmu[j] * pk;
+        for (int l = 0; l < NL; ++l) pk = fma(s_lp[l * nmu + j], c0[l] + t * (c1[l] + t * (c2[l] + t * c3[l])), pk);
 #pragma unroll
-        for (int l = 0; l < NL; ++l) acc[l] = fma(legmu[l * nmu + j], wj, acc[l]);
+        for (int l = 0; l < NL; ++l) acc[l] = fma(s_wl[l * nmu + j], pk, acc[l]);
     }
     const double c = 2.0 / (qperp * qperp * qpar);
 #pragma unroll
@@ -601,18 +646,18 @@ __global__ __launch_bounds__(256) void project_kernel(int Nk, int Nl, int nx, in
 // ------------------------------------------------------------------------------------------------
 // FP64 MFMA issue-rate microbenchmark (roofline denominator): NACC independent accumulator chains.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, double* sink) {
-    v4d acc[8];
+__global__ __launch_bounds__(512, 2) void mfma_peak_kernel(int iters, double* sink) {
+    v4d acc[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int i = 0; i < 4; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) sink[0] = s;
 }
 

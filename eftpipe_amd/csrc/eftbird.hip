@@ -110,7 +110,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
         case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + 1) * 2 * 64;
         case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + 1) * (c.ncolsC / 16) * 64 : 0;
-        case EFTB_T_PLAN: return sizeof(int32_t) * 16;
+        case EFTB_T_PLAN: return sizeof(int32_t) * 32;
         case EFTB_T_M13R: return D * 10 * NPOW;
         case EFTB_T_C11R: return c.with_resum ? D * c.Nl * NPOW : 0;
         case EFTB_T_CCTR: return c.with_resum ? D * c.Nl * NPOW : 0;
@@ -163,8 +163,9 @@ static inline const T* tb(const eftb_engine* e, int id) { return static_cast<con
 
 // dynamic LDS of pair_gemm_kernel<MT, NT>: the u tile (+ slack) or the 4-way reduction buffer
 static constexpr size_t pair_lds_bytes(int MT, int NT) {
-    const size_t tile = (size_t)(MT * 16 * ULDS + 8) * sizeof(double);
-    const size_t red = (size_t)4 * MT * NT * 4 * 64 * sizeof(double);
+    const size_t tile = (size_t)(MT * 16 * ULDS + 16) * sizeof(double);
+    const int JC = (NT <= 2) ? NT : ((NT % 3 == 0) ? NT / 3 : ((NT % 2 == 0) ? NT / 2 : 1));
+    const size_t red = (size_t)8 * MT * JC * 4 * 64 * sizeof(double);
     return tile > red ? tile : red;
 }
 
@@ -184,7 +185,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
         const int rows = B * Nk;
         const size_t lds = pair_lds_bytes(4, 2);
-        hipLaunchKernelGGL((pair_gemm_kernel<4, 2>), dim3((rows + 63) / 64), dim3(256), lds, st, e->U, tb<double>(e, EFTB_T_PAIRS22),
+        hipLaunchKernelGGL((pair_gemm_kernel<4, 2>), dim3((rows + 63) / 64), dim3(512), lds, st, e->U, tb<double>(e, EFTB_T_PAIRS22),
                            tb<int>(e, EFTB_T_PLAN), rows, Nk, 28, e->k3, b[EFTB_B_P22]);
     }
     if (mask & EFTB_S_LOOPS) {
@@ -198,10 +199,10 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         const int rows = B * NS;
         const size_t lds = pair_lds_bytes(2, Nl == 3 ? 8 : 5);
         if (Nl == 3)
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 8>), dim3((rows + 31) / 32), dim3(256), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 8>), dim3((rows + 31) / 32), dim3(512), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
                                tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
         else
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 5>), dim3((rows + 31) / 32), dim3(256), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 5>), dim3((rows + 31) / 32), dim3(512), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
                                tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
     }
     if (mask & EFTB_S_CF) {
@@ -245,8 +246,9 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         const int nrows_ap = c.ap_stochastic ? NROW : 21;
 #define AP_ARGS Nk, c.nmu, nrows_ap, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_SPDX), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), \
                 tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), b[EFTB_B_TEMPL], e->SD, e->Talt
-        if (Nl == 3) hipLaunchKernelGGL((ap_kernel<3>), dim3((Nk + 63) / 64, NROW, B), dim3(64), 0, st, AP_ARGS);
-        else hipLaunchKernelGGL((ap_kernel<2>), dim3((Nk + 63) / 64, NROW, B), dim3(64), 0, st, AP_ARGS);
+        const size_t aplds = (size_t)(1 + 2 * Nl) * c.nmu * sizeof(double);
+        if (Nl == 3) hipLaunchKernelGGL((ap_kernel<3>), dim3((Nk + 63) / 64, NROW / 4, B), dim3(256), aplds, st, AP_ARGS);
+        else hipLaunchKernelGGL((ap_kernel<2>), dim3((Nk + 63) / 64, NROW / 4, B), dim3(256), aplds, st, AP_ARGS);
 #undef AP_ARGS
         std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     }
@@ -514,16 +516,16 @@ int eftb_mfma_f64_peak(int device, double* tflops) {
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));
-    const int iters = 20000, blocks = prop.multiProcessorCount * 2;  // 2 x 4 waves per CU = 2 waves per SIMD
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, 100, sink);
+    const int iters = 40000, blocks = prop.multiProcessorCount;  // 8 waves per CU = 2 waves per SIMD
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(512), 0, 0, 100, sink);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, iters, sink);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(512), 0, 0, iters, sink);
     HIPCHK(hipEventRecord(b, 0));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, a, b));
-    const double flops = (double)blocks * 4 * iters * 8 * (2.0 * 16 * 16 * 4);
+    const double flops = (double)blocks * 8 * iters * 4 * (2.0 * 16 * 16 * 4);
     *tflops = flops / (ms * 1e-3) / 1e12;
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);

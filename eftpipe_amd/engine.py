@@ -18,7 +18,7 @@ NROW = 24
 ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
 
 
-def wave_plan(steps, nwaves=4):
+def wave_plan(steps, nwaves=8):
     """Split the K-steps of the pair contraction evenly over the waves of a workgroup."""
     T = len(steps)
     plan = np.zeros((nwaves, 4), dtype=np.int32)

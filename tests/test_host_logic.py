@@ -50,7 +50,7 @@ def test_wave_plan_covers_all_steps():
     assert len(st) == sum((257 - n + 3) // 4 for n in range(257))
     plan = wave_plan(st)
     assert plan[:, 3].sum() == len(st) and plan[0, 2] == 0
-    for q in range(4):
+    for q in range(len(plan)):
         assert tuple(st[plan[q, 2]]) == (plan[q, 0], plan[q, 1])
     # every unordered pair appears exactly once
     seen = set()
