@@ -365,80 +365,105 @@ __global__ __launch_bounds__(256) void irfilter_kernel(int Nkin, int nxtail, int
 // H folds the 192-point FFTLog of XpYp*C and the j_{2v} Bessel sum (tables.py).  Lanes along k, the s
 // range is split over blockIdx.y (partials summed by resum_sum_kernel when nchunk > 1).
 // ------------------------------------------------------------------------------------------------
+// One wave = 64 k values x one (output l, input l', a, half) block of Q x one slice of the s sum, where
+// half 0 = the X^(p+1) polynomials and half 1 = the Y X^p ones.  The NA x NIR coefficients of the block
+// stay in registers for the whole s loop and are applied by Horner, two s values at a time (2*NA
+// independent chains: v_fma_f64 has a 32-cycle dependent latency on gfx950), so the inner loop reads no
+// tables.  Partials go to part[w][chunk][l][21][k] (chunk = (l', half, slice); a = 0 fills rows 0-2, a = 1
+// rows 3-20) and are summed in a fixed order by resum_sum_kernel (deterministic, no atomics).
 template <int NL>
-__global__ __launch_bounds__(64) void resum_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
-                                                   const double* __restrict__ XY, const double* __restrict__ Q,
-                                                   const double* __restrict__ H, const double* __restrict__ C11,
-                                                   const double* __restrict__ Cct, const double* __restrict__ Cloopl,
-                                                   const double* __restrict__ l11, const double* __restrict__ lct,
-                                                   double* __restrict__ dst, int accumulate) {
+__global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
+                                                       const double* __restrict__ XY, const double* __restrict__ Q,
+                                                       const double* __restrict__ H, const double* __restrict__ C11,
+                                                       const double* __restrict__ Cct, const double* __restrict__ Cloopl,
+                                                       const double* __restrict__ l11, const double* __restrict__ lct,
+                                                       double* __restrict__ part, int nsplit) {
     constexpr int NIR = (NL == 3) ? 16 : 8;
     constexpr int NA = (NL == 3) ? 3 : 2;
     constexpr int NN = 2 * NIR * NA;
-    const int k = blockIdx.x * 64 + threadIdx.x, chunk = blockIdx.y, w = blockIdx.z;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int half = blockIdx.y & 1, a = (blockIdx.y >> 1) & 1, l = blockIdx.y >> 2;
+    const int split = blockIdx.z % nsplit, lp = (blockIdx.z / nsplit) % NL, w = blockIdx.z / (nsplit * NL);
     const bool live = (k < Nk) && (k >= Nklow);
     const int kc = live ? k : Nklow;
     const double k2 = kk[kc] * kk[kc];
-    const double* q = Q + (size_t)w * 2 * NL * NL * NN;
-    double acc[NL][21];
+    double q[NA][NIR];
+    {
+        // wave-uniform values that must live in VGPRs (NA*NIR of them, beyond the SGPR file): an opaque zero
+        // keeps hipcc from turning these into scalar loads + SGPR spills
+        int vzero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+        const double* qa = Q + (size_t)w * 2 * NL * NL * NN + ((size_t)(a * NL + l) * NL + lp) * NN + half * NIR * NA + vzero;
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
+        for (int p = 0; p < NIR; ++p)
 #pragma unroll
-        for (int i = 0; i < 21; ++i) acc[l][i] = 0.0;
-
-    const int s0 = chunk * schunk, s1 = min(NS, s0 + schunk);
-    for (int s = s0; s < s1; ++s) {
-        const double z = k2 * XY[(size_t)w * 2 * NS + s], yk = k2 * XY[(size_t)w * 2 * NS + NS + s];
-        double phi[2 * NIR];
-        double zp = 1.0;
+            for (int v = 0; v < NA; ++v) q[v][p] = qa[p * NA + v];
+    }
+    double acc[18];
 #pragma unroll
-        for (int p = 0; p < NIR; ++p) {
-            phi[NIR + p] = yk * zp;
-            zp *= z;
-            phi[p] = zp;
+    for (int i = 0; i < 18; ++i) acc[i] = 0.0;
+    // s-dependent, wave-uniform inputs of this (w, l') staged once in LDS: X, Y, C11|Cct, Cloopl[12]
+    __shared__ double sh[15 * NS];
+    for (int e = threadIdx.x; e < 15 * NS; e += 256) {
+        const int s = e % NS, c = e / NS;
+        double v;
+        if (c < 2) v = XY[(size_t)w * 2 * NS + c * NS + s];
+        else if (c == 2) v = (a == 0 ? C11 : Cct)[((size_t)w * NL + lp) * NS + s];
+        else v = Cloopl[(((size_t)w * NL + lp) * 12 + (c - 3)) * NS + s];
+        sh[e] = v;
+    }
+    __syncthreads();
+    const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
+    for (int s = s0; s < s1; s += 2) {
+        const int sb = (s + 1 < s1) ? s + 1 : s;        // second lane of the pair (weight 0 if past the end)
+        const double wb = (s + 1 < s1) ? 1.0 : 0.0;
+        double hA[NA], hB[NA];
+#pragma unroll
+        for (int v = 0; v < NA; ++v) {
+            hA[v] = H[((size_t)v * NS + s) * Nk + kc];
+            hB[v] = H[((size_t)v * NS + sb) * Nk + kc];
         }
-        double h[NA];
+        const double zA = k2 * sh[s], zB = k2 * sh[sb];
+        const double fA = half ? k2 * sh[NS + s] : zA, fB = (half ? k2 * sh[NS + sb] : zB) * wb;
+        double pA[NA], pB[NA];
 #pragma unroll
-        for (int v = 0; v < NA; ++v) h[v] = H[((size_t)v * NS + s) * Nk + kc];
+        for (int v = 0; v < NA; ++v) pA[v] = pB[v] = q[v][NIR - 1];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
+        for (int p = NIR - 2; p >= 0; --p)
 #pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                double W[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const double* qa = q + ((size_t)(a * NL + l) * NL + lp) * NN;
-                    double wv = 0.0;
-#pragma unroll
-                    for (int v = 0; v < NA; ++v) {
-                        double zsum = 0.0;
-#pragma unroll
-                        for (int j = 0; j < 2 * NIR; ++j) zsum = fma(qa[j * NA + v], phi[j], zsum);
-                        wv = fma(h[v], zsum, wv);
-                    }
-                    W[a] = wv;
-                }
-                const double c11 = W[0] * C11[((size_t)w * NL + lp) * NS + s];
-                const double cct = W[1] * Cct[((size_t)w * NL + lp) * NS + s];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) acc[l][i] = fma(l11[lp * 3 + i], c11, acc[l][i]);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) acc[l][3 + i] = fma(lct[lp * 6 + i], cct, acc[l][3 + i]);
-                const double* cl = Cloopl + (((size_t)w * NL + lp) * 12) * NS + s;
-#pragma unroll
-                for (int i = 0; i < 12; ++i) acc[l][9 + i] = fma(W[1], cl[i * NS], acc[l][9 + i]);
+            for (int v = 0; v < NA; ++v) {
+                pA[v] = fma(pA[v], zA, q[v][p]);
+                pB[v] = fma(pB[v], zB, q[v][p]);
             }
+        double wA = 0.0, wB = 0.0;
+#pragma unroll
+        for (int v = 0; v < NA; ++v) {
+            wA = fma(hA[v], pA[v], wA);
+            wB = fma(hB[v], pB[v], wB);
+        }
+        wA *= fA;
+        wB *= fB;
+        const double cA = wA * sh[2 * NS + s], cB = wB * sh[2 * NS + sb];
+        if (a == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = fma(l11[lp * 3 + i], cA + cB, acc[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[i] = fma(lct[lp * 6 + i], cA + cB, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[6 + i] = fma(wA, sh[(3 + i) * NS + s], fma(wB, sh[(3 + i) * NS + sb], acc[6 + i]));
         }
     }
     if (k >= Nk) return;
+    const int nchunk = 2 * NL * nsplit, chunk = (lp * 2 + half) + 2 * NL * split;
+    double* dst = part + ((((size_t)w * nchunk + chunk) * NL + l) * 21) * Nk + k;
+    if (a == 0) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
+        for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] = live ? acc[i] : 0.0;
+    } else {
 #pragma unroll
-        for (int i = 0; i < 21; ++i) {
-            const double v = live ? acc[l][i] : 0.0;
-            if (accumulate) dst[(((size_t)w * NL + l) * NROW + i) * Nk + k] += v;
-            else dst[((((size_t)w * gridDim.y + chunk) * NL + l) * 21 + i) * Nk + k] = v;
-        }
+        for (int i = 0; i < 18; ++i) dst[(size_t)(3 + i) * Nk] = live ? acc[i] : 0.0;
+    }
 }
 
 __global__ __launch_bounds__(256) void resum_sum_kernel(int Nk, int Nl, int nchunk, const double* __restrict__ part,

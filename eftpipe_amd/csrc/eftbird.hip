@@ -36,8 +36,8 @@ static int fail(const char* fmt, ...) {
 
 struct eftb_engine {
     eftb_config c;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJoin = nullptr;
     bool finalized = false;
     void* tab[EFTB_T_COUNT] = {nullptr};
     size_t tab_bytes[EFTB_T_COUNT] = {0};
@@ -45,7 +45,7 @@ struct eftb_engine {
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
     double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr;
-    int resum_chunks = 1;
+    int resum_splits = 1;
     int Nn = 0;
     double* k3 = nullptr;  // k^3 row scale of P22
     // RCCL gather (multi-GPU batches)
@@ -174,11 +174,19 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     hipStream_t st = e->stream;
     const int Nk = c.Nk, Nl = c.Nl;
     double** b = e->buf;
+    // the k-space (LOOPS) and xi-space (CF) contractions are independent: when both are requested the CF
+    // kernels go to a second stream so their workgroups back-fill the CUs the P22 grid leaves idle
+    const bool fork = (mask & EFTB_S_LOOPS) && (mask & EFTB_S_CF);
+    hipStream_t stc = fork ? e->stream2 : st;
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
         hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
                            b[EFTB_B_P11], b[EFTB_B_COEF]);
+    }
+    if (fork) {
+        if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(stc, e->evFork, 0) != hipSuccess)
+            return fail("eftb_run: stream fork failed");
     }
     if (mask & EFTB_S_LOOPS)
         hipLaunchKernelGGL(uvec_kernel, dim3(Nk, B), dim3(256), 0, st, Nk, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), e->U);
@@ -194,20 +202,24 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
     if (mask & EFTB_S_CF)
-        hipLaunchKernelGGL(uvec_kernel, dim3(NS, B), dim3(256), 0, st, NS, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), e->Us);
+        hipLaunchKernelGGL(uvec_kernel, dim3(NS, B), dim3(256), 0, stc, NS, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), e->Us);
     if (mask & (EFTB_S_CF | EFTB_K_C22)) {
         const int rows = B * NS;
         const size_t lds = pair_lds_bytes(2, Nl == 3 ? 8 : 5);
         if (Nl == 3)
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 8>), dim3((rows + 31) / 32), dim3(512), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 8>), dim3((rows + 31) / 32), dim3(512), lds, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC),
                                tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
         else
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 5>), dim3((rows + 31) / 32), dim3(512), lds, st, e->Us, tb<double>(e, EFTB_T_PAIRSC),
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 5>), dim3((rows + 31) / 32), dim3(512), lds, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC),
                                tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
     }
     if (mask & EFTB_S_CF) {
-        hipLaunchKernelGGL((rowdot_kernel<6>), dim3((NS + 3) / 4, B), dim3(256), 0, st, 1, NS, Nl, e->Us, tb<double>(e, EFTB_T_C11R),
+        hipLaunchKernelGGL((rowdot_kernel<6>), dim3((NS + 3) / 4, B), dim3(256), 0, stc, 1, NS, Nl, e->Us, tb<double>(e, EFTB_T_C11R),
                            tb<double>(e, EFTB_T_CCTR), tb<double>(e, EFTB_T_S), (const double*)nullptr, b[EFTB_B_C11], b[EFTB_B_CCT]);
+    }
+    if (fork) {
+        if (hipEventRecord(e->evJoin, stc) != hipSuccess || hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess)
+            return fail("eftb_run: stream join failed");
     }
     if (mask & EFTB_S_REGROUP) {
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, NROW * Nl, B), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
@@ -224,19 +236,17 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
                            tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
                            tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
                            b[EFTB_B_XY], b[EFTB_B_Q]);
-        const int kblocks = (Nk + 63) / 64;
-        // enough waves to fill 1024 SIMDs: split the s sum for small batches
-        int nchunk = 1;
-        while (nchunk < e->resum_chunks && (size_t)kblocks * B * nchunk < 1024) nchunk *= 2;
-        const int schunk = (NS + nchunk - 1) / nchunk;
-        double* dst = nchunk == 1 ? b[EFTB_B_TEMPL] : e->part;
+        const int kblocks = (Nk + 255) / 256;
+        // waves = kblocks*4 x (2*Nl) x (B*Nl*nsplit): split the s sum further only for small batches
+        int nsplit = 1;
+        while (nsplit < e->resum_splits && (size_t)kblocks * 4 * 4 * Nl * Nl * B * nsplit < 8192) nsplit *= 2;
+        const int schunk = (NS + nsplit - 1) / nsplit;
 #define RESUM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), b[EFTB_B_C11], \
-                   b[EFTB_B_CCT], b[EFTB_B_CLOOPL], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), dst, (nchunk == 1 ? 1 : 0)
-        if (Nl == 3) hipLaunchKernelGGL((resum_kernel<3>), dim3(kblocks, nchunk, B), dim3(64), 0, st, RESUM_ARGS);
-        else hipLaunchKernelGGL((resum_kernel<2>), dim3(kblocks, nchunk, B), dim3(64), 0, st, RESUM_ARGS);
+                   b[EFTB_B_CCT], b[EFTB_B_CLOOPL], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), e->part, nsplit
+        if (Nl == 3) hipLaunchKernelGGL((resum_kernel<3>), dim3(kblocks, 4 * Nl, B * Nl * nsplit), dim3(256), 0, st, RESUM_ARGS);
+        else hipLaunchKernelGGL((resum_kernel<2>), dim3(kblocks, 4 * Nl, B * Nl * nsplit), dim3(256), 0, st, RESUM_ARGS);
 #undef RESUM_ARGS
-        if (nchunk > 1)
-            hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nchunk, e->part, b[EFTB_B_TEMPL]);
+        hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, 2 * Nl * nsplit, e->part, b[EFTB_B_TEMPL]);
     }
     if (mask & EFTB_S_AP) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
@@ -291,8 +301,11 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->c = c;
     e->Nn = 2 * c.NIR * c.Na;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
+    HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming));
     for (int id = 0; id < EFTB_B_COUNT; ++id) {
         const size_t n = need_buffer_elems(c, id);
         e->buf_elems[id] = n;
@@ -340,8 +353,8 @@ int eftb_finalize(eftb_engine* e) {
     const eftb_config& c = e->c;
     if (c.with_resum) {
         // split the s sum when the batch alone cannot fill the chip (deterministic two-pass reduction)
-        e->resum_chunks = 16;
-        HIPCHK(hipMalloc(&e->part, (size_t)c.max_batch * e->resum_chunks * c.Nl * 21 * c.Nk * sizeof(double)));
+        e->resum_splits = c.max_batch >= 16 ? 1 : 8;
+        HIPCHK(hipMalloc(&e->part, (size_t)c.max_batch * e->resum_splits * 2 * c.Nl * c.Nl * 21 * c.Nk * sizeof(double)));
     }
     // opt in to the large dynamic LDS tiles of the pair GEMM
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -367,8 +380,8 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& p : e->buf) if (p) (void)hipFree(p);
     for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
