@@ -82,23 +82,30 @@ __global__ __launch_bounds__(256) void uvec_kernel(int rows, const double* __res
     }
 }
 
+// column tiles reduced per pass of the epilogue: the largest divisor of NT whose NW partial tiles fit 128 KB
+constexpr int pair_reduce_cols(int MT, int NT, int NW) {
+    int best = 1;
+    for (int jc = 1; jc <= NT; ++jc)
+        if (NT % jc == 0 && (size_t)NW * MT * jc * 4 * 64 * 8 <= 128 * 1024) best = jc;
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pair GEMM on the FP64 matrix cores.
 //   out[row, col] = scale[row] * sum_{t, g} u[row, n_t] u[row, m_t + g] * frag[t][col/16][g][col%16]
-// Workgroup = 8 waves = MT*16 rows, the whole K range split 8 ways over the waves (two waves per SIMD,
+// Workgroup = NW waves = MT*16 rows, the whole K range split NW ways over the waves (NW/4 waves per SIMD,
 // each with MT*NT independent accumulator tiles); the u tile lives in LDS (stride 258 doubles), the B
 // fragments are read once per workgroup straight into registers (8 B/lane, 512 B per instruction).
 // MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = lane >> 4],
 // B[k = lane >> 4][j = lane & 15], D reg q -> row (lane >> 4) + 4 q, col lane & 15.
-// Output element (row, col) is written to out[w][col][r] (w = row / rows_per_w, r = row % rows_per_w).
+// Output element (row, col) is written to out[w][col][r] (w = row / rows_per_w, r = row % rows_per_w; ncols_ld columns per w).
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT>
-__global__ __launch_bounds__(512, 2) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
+template <int MT, int NT, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
                                                            const int* __restrict__ plan, int rows_total, int rows_per_w,
-                                                           int ncols_out, const double* __restrict__ rowscale,
+                                                           int ncols_out, int ncols_ld, const double* __restrict__ rowscale,
                                                            double* __restrict__ out) {
-    constexpr int ROWS = MT * 16;
-    constexpr int NW = 8;  // waves per workgroup = K slices (two waves per SIMD hide each other's LDS/L2 latency)
+    constexpr int ROWS = MT * 16;  // NW waves per workgroup = K slices; NW/4 waves per SIMD hide each other's LDS/L2 latency
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void pair_gemm_kernel(const double* __restr
     }
 
     // ---- reduce the 8 K-slices through LDS (the u tile is dead now) and write out, JC column tiles per pass
-    constexpr int JC = (NT <= 2) ? NT : ((NT % 3 == 0) ? NT / 3 : ((NT % 2 == 0) ? NT / 2 : 1));
+    constexpr int JC = pair_reduce_cols(MT, NT, NW);
     constexpr int PER_WAVE = MT * JC * 4 * 64;
     static_assert((size_t)NW * PER_WAVE * 8 <= 160 * 1024, "reduction buffer exceeds LDS");
     for (int jc = 0; jc < NT; jc += JC) {
@@ -192,8 +199,120 @@ __global__ __launch_bounds__(512, 2) void pair_gemm_kernel(const double* __restr
             for (int w8 = 0; w8 < NW; ++w8) v += sm[w8 * PER_WAVE + off];
             const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
             if (rowscale) v *= rowscale[rw];
-            out[((size_t)w * ncols_out + col) * rows_per_w + rw] = v;
+            out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// General FP64-MFMA GEMM for the smaller dense stages:  C[row][col] = sum_seg sum_k A_seg[row][k] B_seg[k][col].
+//   * xi-space 13 term: V = us . Tv  (rows = (cosmology, s), K = 257, N = Nl*257; reference pybird.py:1115-1125
+//     evaluated through its rank structure  C13 = Re sum_n x_n M13[b,n] (Ml[l] x)_n)
+//   * post-AP projection: out[(w,r)][(a,x)] = sum_{l,k} T[w][l][r][k] ProjT[(l,k)][(a,x)]  (window / binning / chained)
+// Workgroup = 4 waves = 64 rows x 256 columns; wave q owns column tiles 4q..4q+3 (16 accumulator tiles); the A
+// tile (64 rows x <= 256 k) is staged in LDS per K chunk (stride KC+2 -> conflict-free ds_read_b64), B is read
+// row-major, 4 x 128 contiguous bytes per fragment.  Row/column addressing is two-level (group, member) so that
+// the template block [w][l][r][k] and the output [w][a][r][x] need no repacking.
+// ------------------------------------------------------------------------------------------------
+struct GemmDesc {
+    const double* A; long long a_group, a_row, a_seg; int rows, rows_per_group, nseg, kseg;
+    const double* B; int ldb, ncols;
+    double* C; long long c_group, c_row, c_colgroup; int cols_per_group;
+};
+
+__global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmDesc d) {
+    constexpr int MT = 4, NT = 4, ROWS = 64, KC = 256, LD = KC + 2;
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * ROWS, col0 = blockIdx.y * 256 + wave * 64;
+    v4d acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const bool wave_live = col0 < d.ncols;
+    for (int seg = 0; seg < d.nseg; ++seg) {
+        for (int kc0 = 0; kc0 < d.kseg; kc0 += KC) {
+            const int kc = min(KC, d.kseg - kc0);
+            const int kcp = (kc + 3) & ~3;
+            __syncthreads();
+            for (int idx = tid; idx < ROWS * (kcp / 2); idx += 256) {
+                const int rr = idx / (kcp / 2), c2 = idx % (kcp / 2);
+                const int grow = row0 + rr;
+                double v0 = 0.0, v1 = 0.0;
+                if (grow < d.rows) {
+                    const double* ap = d.A + (long long)(grow / d.rows_per_group) * d.a_group + (long long)(grow % d.rows_per_group) * d.a_row +
+                                       (long long)seg * d.a_seg + kc0;
+                    if (2 * c2 < kc) v0 = ap[2 * c2];
+                    if (2 * c2 + 1 < kc) v1 = ap[2 * c2 + 1];
+                }
+                sm[rr * LD + 2 * c2] = v0;
+                sm[rr * LD + 2 * c2 + 1] = v1;
+            }
+            __syncthreads();
+            if (!wave_live) continue;
+            const double* bp = d.B + ((long long)seg * d.kseg + kc0 + g) * d.ldb + col0 + r;
+            const int krows = d.nseg * d.kseg;
+            for (int t = 0; t < kcp / 4; ++t) {
+                const int kglob = seg * d.kseg + kc0 + 4 * t + g;
+                double bfr[NT], a[MT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = col0 + 16 * j + r;
+                    bfr[j] = (col < d.ncols && 4 * t + g < kc && kglob < krows) ? bp[(long long)4 * t * d.ldb + 16 * j] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = sm[(r + 16 * i) * LD + 4 * t + g];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int grow = row0 + 16 * i + g + 4 * q, col = col0 + 16 * j + r;
+                if (grow < d.rows && col < d.ncols)
+                    d.C[(long long)(grow / d.rows_per_group) * d.c_group + (long long)(grow % d.rows_per_group) * d.c_row +
+                        (long long)(col / d.cols_per_group) * d.c_colgroup + (col % d.cols_per_group)] = acc[i][j][q];
+            }
+}
+
+// C13[w][l][b][s] = y_red(l) . m13r[b],  y = x * v_l (complex, per n),  x from us, v_l from V (reference pybird.py:1115-1125)
+__global__ __launch_bounds__(256) void c13_kernel(int Nl, int ldv, const double* __restrict__ Us, const double* __restrict__ V,
+                                                  const double* __restrict__ m13r, double* __restrict__ CC) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wave, w = blockIdx.y;
+    if (s >= NS) return;
+    const size_t row = (size_t)w * NS + s;
+    const double* u = Us + row * UPAD;
+    for (int l = 0; l < Nl; ++l) {
+        const double* v = V + row * ldv + (size_t)l * NPOW;
+        double acc[10];
+#pragma unroll
+        for (int b = 0; b < 10; ++b) acc[b] = 0.0;
+        for (int n = lane; n < NPOW; n += 64) {
+            double y;
+            if (n < NHALF) y = u[n] * v[n] - u[NCH + n] * v[NCH + n];
+            else if (n == NHALF) y = u[NHALF] * v[NHALF];
+            else y = u[n - NCH] * v[n] + u[n] * v[n - NCH];
+#pragma unroll
+            for (int b = 0; b < 10; ++b) acc[b] = fma(m13r[b * NPOW + n], y, acc[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 10; ++b)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[b] += __shfl_down(acc[b], o, 64);
+        if (lane == 0)
+#pragma unroll
+            for (int b = 0; b < 10; ++b) CC[((size_t)w * Nl * 38 + Nl * 28 + l * 10 + b) * NS + s] = acc[b];
     }
 }
 

@@ -16,6 +16,10 @@
 
 using namespace eftb;
 
+constexpr int NW_P22 = 16;  // waves per workgroup (K slices) of the P22 pair GEMM
+constexpr int NW_C = 8;     // ... of the xi-space pair GEMM
+constexpr size_t GEMM_LDS = (size_t)64 * 258 * sizeof(double);  // A tile of gemm_rows_kernel
+
 static thread_local std::string g_err;
 
 static int fail(const char* fmt, ...) {
@@ -44,7 +48,8 @@ struct eftb_engine {
     double* buf[EFTB_B_COUNT] = {nullptr};
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
-    double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr;
+    double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
+    int ldtv = 0;  // padded column count of Tv / V (Nl*257 rounded up to 16)
     int resum_splits = 1;
     int Nn = 0;
     double* k3 = nullptr;  // k^3 row scale of P22
@@ -110,7 +115,9 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
         case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + 1) * 2 * 64;
         case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + 1) * (c.ncolsC / 16) * 64 : 0;
-        case EFTB_T_PLAN: return sizeof(int32_t) * 32;
+        case EFTB_T_PLAN: return sizeof(int32_t) * 4 * NW_P22;
+        case EFTB_T_PLANC: return c.with_resum ? sizeof(int32_t) * 4 * NW_C : 0;
+        case EFTB_T_TVT: return c.with_resum ? D * (size_t)NPOW * ((c.Nl * NPOW + 15) / 16 * 16) : 0;
         case EFTB_T_M13R: return D * 10 * NPOW;
         case EFTB_T_C11R: return c.with_resum ? D * c.Nl * NPOW : 0;
         case EFTB_T_CCTR: return c.with_resum ? D * c.Nl * NPOW : 0;
@@ -162,12 +169,12 @@ template <typename T>
 static inline const T* tb(const eftb_engine* e, int id) { return static_cast<const T*>(e->tab[id]); }
 
 // dynamic LDS of pair_gemm_kernel<MT, NT>: the u tile (+ slack) or the 4-way reduction buffer
-static constexpr size_t pair_lds_bytes(int MT, int NT) {
+static constexpr size_t pair_lds_bytes(int MT, int NT, int NW) {
     const size_t tile = (size_t)(MT * 16 * ULDS + 16) * sizeof(double);
-    const int JC = (NT <= 2) ? NT : ((NT % 3 == 0) ? NT / 3 : ((NT % 2 == 0) ? NT / 2 : 1));
-    const size_t red = (size_t)8 * MT * JC * 4 * 64 * sizeof(double);
+    const size_t red = (size_t)NW * MT * pair_reduce_cols(MT, NT, NW) * 4 * 64 * sizeof(double);
     return tile > red ? tile : red;
 }
+
 
 static int launch_stages(eftb_engine* e, int mask, int B) {
     const eftb_config& c = e->c;
@@ -192,9 +199,9 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         hipLaunchKernelGGL(uvec_kernel, dim3(Nk, B), dim3(256), 0, st, Nk, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), e->U);
     if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
         const int rows = B * Nk;
-        const size_t lds = pair_lds_bytes(4, 2);
-        hipLaunchKernelGGL((pair_gemm_kernel<4, 2>), dim3((rows + 63) / 64), dim3(512), lds, st, e->U, tb<double>(e, EFTB_T_PAIRS22),
-                           tb<int>(e, EFTB_T_PLAN), rows, Nk, 28, e->k3, b[EFTB_B_P22]);
+        const size_t lds = pair_lds_bytes(4, 2, NW_P22);
+        hipLaunchKernelGGL((pair_gemm_kernel<4, 2, NW_P22>), dim3((rows + 63) / 64), dim3(64 * NW_P22), lds, st, e->U, tb<double>(e, EFTB_T_PAIRS22),
+                           tb<int>(e, EFTB_T_PLAN), rows, Nk, 28, 28, e->k3, b[EFTB_B_P22]);
     }
     if (mask & EFTB_S_LOOPS) {
         hipLaunchKernelGGL((rowdot_kernel<10>), dim3((Nk + 3) / 4, B), dim3(256), 0, st, 0, Nk, Nl, e->U, tb<double>(e, EFTB_T_M13R),
@@ -205,15 +212,21 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         hipLaunchKernelGGL(uvec_kernel, dim3(NS, B), dim3(256), 0, stc, NS, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), e->Us);
     if (mask & (EFTB_S_CF | EFTB_K_C22)) {
         const int rows = B * NS;
-        const size_t lds = pair_lds_bytes(2, Nl == 3 ? 8 : 5);
         if (Nl == 3)
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 8>), dim3((rows + 31) / 32), dim3(512), lds, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC),
-                               tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 6, NW_C>), dim3((rows + 31) / 32), dim3(64 * NW_C), pair_lds_bytes(2, 6, NW_C), stc, e->Us,
+                               tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), rows, NS, Nl * 28, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
         else
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 5>), dim3((rows + 31) / 32), dim3(512), lds, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC),
-                               tb<int>(e, EFTB_T_PLAN), rows, NS, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
+            hipLaunchKernelGGL((pair_gemm_kernel<2, 4, NW_C>), dim3((rows + 31) / 32), dim3(64 * NW_C), pair_lds_bytes(2, 4, NW_C), stc, e->Us,
+                               tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), rows, NS, Nl * 28, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
     }
     if (mask & EFTB_S_CF) {
+        // 13 term through its rank structure: V = us . Tv (FP64-MFMA GEMM), then one complex product + 10 dots per row
+        GemmDesc g{};
+        g.A = e->Us; g.a_group = 0; g.a_row = UPAD; g.a_seg = 0; g.rows = B * NS; g.rows_per_group = B * NS; g.nseg = 1; g.kseg = NPOW;
+        g.B = tb<double>(e, EFTB_T_TVT); g.ldb = e->ldtv; g.ncols = Nl * NPOW;
+        g.C = e->V; g.c_group = 0; g.c_row = e->ldtv; g.c_colgroup = 0; g.cols_per_group = Nl * NPOW;
+        hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, stc, g);
+        hipLaunchKernelGGL(c13_kernel, dim3((NS + 3) / 4, B), dim3(256), 0, stc, Nl, e->ldtv, e->Us, e->V, tb<double>(e, EFTB_T_M13R), b[EFTB_B_CC]);
         hipLaunchKernelGGL((rowdot_kernel<6>), dim3((NS + 3) / 4, B), dim3(256), 0, stc, 1, NS, Nl, e->Us, tb<double>(e, EFTB_T_C11R),
                            tb<double>(e, EFTB_T_CCTR), tb<double>(e, EFTB_T_S), (const double*)nullptr, b[EFTB_B_C11], b[EFTB_B_CCT]);
     }
@@ -289,7 +302,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     const eftb_config& c = *cfg;
     if (c.Nl != 2 && c.Nl != 3) return fail("eftb_create: Nl must be 2 or 3 (got %d)", c.Nl);
     if (c.Nk < 8 || c.Nkin < 4 || c.max_batch < 1) return fail("eftb_create: bad dimensions Nk=%d Nkin=%d max_batch=%d", c.Nk, c.Nkin, c.max_batch);
-    if (c.with_resum && (c.ncolsC % 16 || c.ncolsC < c.Nl * 38)) return fail("eftb_create: bad ncolsC=%d", c.ncolsC);
+    if (c.with_resum && (c.ncolsC % 16 || c.ncolsC < c.Nl * 28)) return fail("eftb_create: bad ncolsC=%d", c.ncolsC);
     if (c.with_resum && !((c.Nl == 3 && c.NIR == 16 && c.Na == 3) || (c.Nl == 2 && c.NIR == 8 && c.Na == 2)))
         return fail("eftb_create: (Nl, NIR, Na) = (%d, %d, %d) unsupported", c.Nl, c.NIR, c.Na);
     int ndev = 0;
@@ -317,7 +330,11 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     const size_t B = c.max_batch;
     HIPCHK(hipMalloc(&e->U, B * c.Nk * UPAD * sizeof(double)));
     HIPCHK(hipMalloc(&e->k3, c.Nk * sizeof(double)));
-    if (c.with_resum) HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
+    e->ldtv = (c.Nl * NPOW + 15) / 16 * 16;
+    if (c.with_resum) {
+        HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
+        HIPCHK(hipMalloc(&e->V, B * NS * e->ldtv * sizeof(double)));
+    }
     if (c.with_ap) {
         HIPCHK(hipMalloc(&e->SD, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
         HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
@@ -357,9 +374,10 @@ int eftb_finalize(eftb_engine* e) {
         HIPCHK(hipMalloc(&e->part, (size_t)c.max_batch * e->resum_splits * 2 * c.Nl * c.Nl * 21 * c.Nk * sizeof(double)));
     }
     // opt in to the large dynamic LDS tiles of the pair GEMM
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, NW_P22>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 6, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 4, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     e->finalized = true;
     return 0;
 }
@@ -378,7 +396,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered}) if (p) (void)hipFree(p);
+    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);

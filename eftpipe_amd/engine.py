@@ -15,6 +15,7 @@ from . import _lib as L
 from .tables import EngineConfig, build_tables
 
 NROW = 24
+NW_P22, NW_C = 16, 8  # waves per workgroup (K slices) of the two pair GEMMs; must match csrc/eftbird.hip
 ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
 
 
@@ -80,7 +81,7 @@ class Engine:
         self._set("LNXTAIL", t["lnx_tail"])
         self._set("KPOW", t["kpow"])
         self._set("PAIRS22", _padded_fragments(t["pairs22"]))
-        self._set("PLAN", wave_plan(t["steps"]), np.int32)
+        self._set("PLAN", wave_plan(t["steps"], NW_P22), np.int32)
         self._set("M13R", t["m13r"])
         for n in ("L11", "LCT", "L22", "L13"):
             self._set(n, t[n.lower()])
@@ -88,6 +89,11 @@ class Engine:
         if cfg.with_resum:
             self._set("SPOW", t["spow"])
             self._set("PAIRSC", _padded_fragments(t["pairsC"]))
+            self._set("PLANC", wave_plan(t["steps"], NW_C), np.int32)
+            ld = (cfg.Nl * 257 + 15) // 16 * 16
+            tvt = np.zeros((257, ld))
+            tvt[:, : cfg.Nl * 257] = t["Tv"].transpose(2, 0, 1).reshape(257, cfg.Nl * 257)
+            self._set("TVT", tvt)
             self._set("C11R", t["c11r"])
             self._set("CCTR", t["cctr"])
             self._set("BXT", t["BX"].T)

@@ -265,12 +265,15 @@ def build_tables(cfg: EngineConfig) -> dict:
     t["m13r"] = np.ascontiguousarray(reduce_linear(M13))                 # [10,257]
     resid = [im22]
     if cfg.with_resum:
-        # columns of the configuration-space contraction: [l*28+b] for C22, then [28*Nl + l*10+b] for C13
+        # columns of the configuration-space pair contraction: [l*28+b] (C22 only)
         Rc22, imc = reduce_quadratic((Ml[:, None] * M22[None]).reshape(Nl * 28, NPOW, NPOW))
-        Rc13, imd = reduce_quadratic((Ml[:, None] * M13[None, :, :, None]).reshape(Nl * 10, NPOW, NPOW))
-        resid += [imc, imd]
-        ncol = Nl * 38
-        t["pairsC"] = pair_fragments(np.concatenate([Rc22, Rc13]), 16 * ((ncol + 15) // 16))
+        resid += [imc]
+        ncol = Nl * 28
+        t["pairsC"] = pair_fragments(Rc22, 16 * ((ncol + 15) // 16))
+        # C13 through its rank structure: v_l = Ml[l] x  as a real operator on u (then y = x*v, dotted with m13r)
+        Tm = realify_matrix()
+        W = np.einsum("lnm,ma->lna", Ml[:, :NHALF + 1, :], Tm)           # [Nl,129,257] complex
+        t["Tv"] = np.ascontiguousarray(np.concatenate([W.real, W.imag[:, :NHALF, :]], axis=1))  # [Nl,257(out),257(in)]
         t["c11r"] = np.ascontiguousarray(reduce_linear(Mcf11))           # [Nl,257]
         t["cctr"] = np.ascontiguousarray(reduce_linear(Mcfct))           # [Nl,257]
     t["reduction_residue"] = np.array(resid)
