@@ -24,18 +24,19 @@ class Config(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "device", "Nl", "Nk", "Nkin", "max_batch", "with_resum", "with_ap", "ap_stochastic", "nmu",
-        "ntail", "nxtail", "nsteps", "ncolsC", "NIR", "Na", "Nklow", "nproj", "nproj_l")]
+        "ntail", "nxtail", "nsteps", "ncolsC", "NIR", "Na", "Nklow")]
 
 
 # enum eftb_table / eftb_buffer / eftb_stage (same order as the header)
 TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL KPOW SPOW PAIRS22 PAIRSC PLAN M13R C11R CCTR L11 LCT L22 L13 GRP "
-          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H MU WMU LEGMU SPDX SPLOWER SPINV SPCP APFID PROJ PLANC TVT").split()
+          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H MU WMU LEGMU SPDX SPLOWER SPINV SPCP APFID PLANC TVT").split()
 T = {n: i for i, n in enumerate(TABLES)}
-BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK PROJ COEF".split()
+BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF".split()
 B = {n: i for i, n in enumerate(BUFFERS)}
 S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22 = (1 << i for i in range(10))
 
-EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_destroy eftb_put eftb_get eftb_buffer_size eftb_run "
+EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_destroy eftb_add_operator eftb_apply_operator "
+           "eftb_set_pipeline_operator eftb_set_template_dims eftb_put eftb_get eftb_buffer_size eftb_run "
            "eftb_sync eftb_run_timed eftb_eval_batch eftb_comm_unique_id eftb_comm_init eftb_gather_plk "
            "eftb_mfma_f64_peak eftb_last_error eftb_version").split()
 
@@ -56,6 +57,10 @@ def load():
     lib.eftb_set_table.argtypes, lib.eftb_set_table.restype = [vp, i32, vp, sz], i32
     lib.eftb_finalize.argtypes, lib.eftb_finalize.restype = [vp], i32
     lib.eftb_set_option.argtypes, lib.eftb_set_option.restype = [vp, i32, i32], i32
+    lib.eftb_add_operator.argtypes, lib.eftb_add_operator.restype = [vp, i32, i32, i32, i32, dp, C.POINTER(C.c_int)], i32
+    lib.eftb_apply_operator.argtypes, lib.eftb_apply_operator.restype = [vp, i32, i32], i32
+    lib.eftb_set_pipeline_operator.argtypes, lib.eftb_set_pipeline_operator.restype = [vp, i32], i32
+    lib.eftb_set_template_dims.argtypes, lib.eftb_set_template_dims.restype = [vp, i32, i32], i32
     lib.eftb_destroy.argtypes, lib.eftb_destroy.restype = [vp], None
     lib.eftb_put.argtypes, lib.eftb_put.restype = [vp, i32, sz, dp, sz], i32
     lib.eftb_get.argtypes, lib.eftb_get.restype = [vp, i32, sz, dp, sz], i32

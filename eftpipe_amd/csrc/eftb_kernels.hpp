@@ -750,44 +750,6 @@ __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// project: out[w][a][row][x] = sum_{l,k} Proj[a][l][x][k] * T[w][l][row][k]  -- the window convolution,
-// the k-binning and the chained combination, each folded with its cubic spline on the host
-// (reference window.py:371-387, binning.py:131-144, chained.py:56-68).  Lanes along (row, w) columns.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void project_kernel(int Nk, int Nl, int nx, int na, const double* __restrict__ Proj,
-                                                      const double* __restrict__ T, double* __restrict__ out) {
-    // one workgroup per (x, a, w): 24 rows x Nl*Nk reduction, wave-parallel over k
-    const int x = blockIdx.x, a = blockIdx.y, w = blockIdx.z;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ double red[4][NROW];
-    double acc[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] = 0.0;
-    // wave handles rows wave*6 .. wave*6+5
-    for (int l = 0; l < Nl; ++l) {
-        const double* p = Proj + (((size_t)a * Nl + l) * nx + x) * Nk;
-        const double* t = T + (((size_t)w * Nl + l) * NROW + wave * 6) * Nk;
-        for (int k = lane; k < Nk; k += 64) {
-            const double pv = p[k];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc[i] = fma(pv, t[(size_t)i * Nk + k], acc[i]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_down(acc[i], o, 64);
-    if (lane == 0)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) red[wave][i] = acc[i];
-    __syncthreads();
-    if (threadIdx.x < NROW) {
-        const int r = threadIdx.x;
-        out[(((size_t)w * na + a) * NROW + r) * nx + x] = red[r / 6][r % 6];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // FP64 MFMA issue-rate microbenchmark (roofline denominator): NACC independent accumulator chains.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(int iters, double* sink) {

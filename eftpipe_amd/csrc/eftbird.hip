@@ -50,6 +50,11 @@ struct eftb_engine {
     // scratch
     double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
     int ldtv = 0;  // padded column count of Tv / V (Nl*257 rounded up to 16)
+    // linear post-AP operators (window / binning / chained), stored K-major for gemm_rows_kernel
+    struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; };
+    std::vector<Op> ops;
+    int pipeline_op = -1;
+    int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
     int Nn = 0;
     double* k3 = nullptr;  // k^3 row scale of P22
@@ -137,7 +142,6 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_SPDX: return c.with_ap ? D * (c.Nk - 1) : 0;
         case EFTB_T_SPLOWER: case EFTB_T_SPINV: case EFTB_T_SPCP: return c.with_ap ? D * c.Nk : 0;
         case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
-        case EFTB_T_PROJ: return c.nproj > 0 ? D * (size_t)c.nproj_l * c.Nl * c.nproj * c.Nk : 0;
     }
     return 0;
 }
@@ -159,7 +163,6 @@ static size_t need_buffer_elems(const eftb_config& c, int id) {
         case EFTB_B_Q: return c.with_resum ? B * 2 * c.Nl * c.Nl * Nn : 0;
         case EFTB_B_BIAS: return B * NROW;
         case EFTB_B_PLK: return B * c.Nl * c.Nk;
-        case EFTB_B_PROJ: return c.nproj > 0 ? B * c.nproj_l * NROW * c.nproj : 0;
         case EFTB_B_COEF: return B * 2 * NCH;
     }
     return 0;
@@ -175,6 +178,25 @@ static constexpr size_t pair_lds_bytes(int MT, int NT, int NW) {
     return tile > red ? tile : red;
 }
 
+
+// out[w][a][r][x] = sum_{l,k} T[w][l][r][k] * opT[(l,k)][(a,x)] on the FP64 matrix cores; the block changes shape
+static int launch_operator(eftb_engine* e, int id, int B) {
+    if (id < 0 || id >= (int)e->ops.size()) return fail("operator id %d out of range", id);
+    const eftb_engine::Op& o = e->ops[id];
+    if (o.nl_in != e->cur_nl || o.nx_in != e->cur_nx)
+        return fail("operator %d expects templates [%d][24][%d], the block is [%d][24][%d]", id, o.nl_in, o.nx_in, e->cur_nl, e->cur_nx);
+    GemmDesc g{};
+    g.A = e->buf[EFTB_B_TEMPL]; g.a_group = (long long)o.nl_in * NROW * o.nx_in; g.a_row = o.nx_in; g.a_seg = (long long)NROW * o.nx_in;
+    g.rows = B * NROW; g.rows_per_group = NROW; g.nseg = o.nl_in; g.kseg = o.nx_in;
+    g.B = o.dev; g.ldb = o.ld; g.ncols = o.nl_out * o.nx_out;
+    g.C = e->Talt; g.c_group = (long long)o.nl_out * NROW * o.nx_out; g.c_row = o.nx_out; g.c_colgroup = (long long)NROW * o.nx_out;
+    g.cols_per_group = o.nx_out;
+    hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
+    std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
+    e->cur_nl = o.nl_out;
+    e->cur_nx = o.nx_out;
+    return 0;
+}
 
 static int launch_stages(eftb_engine* e, int mask, int B) {
     const eftb_config& c = e->c;
@@ -275,18 +297,17 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
 #undef AP_ARGS
         std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     }
+    if (mask & EFTB_S_REGROUP) {
+        e->cur_nl = Nl;
+        e->cur_nx = Nk;
+    }
     if (mask & EFTB_S_PROJECT) {
-        if (c.nproj <= 0) return fail("eftb_run: stage PROJECT needs a projection operator (nproj > 0)");
-        hipLaunchKernelGGL(project_kernel, dim3(c.nproj, c.nproj_l, B), dim3(256), 0, st, Nk, Nl, c.nproj, c.nproj_l, tb<double>(e, EFTB_T_PROJ),
-                           b[EFTB_B_TEMPL], b[EFTB_B_PROJ]);
+        if (e->pipeline_op < 0) return fail("eftb_run: stage PROJECT needs eftb_set_pipeline_operator");
+        if (int rc = launch_operator(e, e->pipeline_op, B)) return rc;
     }
-    if (mask & EFTB_S_REDUCE) {
-        if ((mask & EFTB_S_PROJECT) && c.nproj > 0)
-            hipLaunchKernelGGL(reduce_kernel, dim3((c.nproj + 255) / 256, c.nproj_l, B), dim3(256), 0, st, c.nproj, c.nproj_l, b[EFTB_B_BIAS],
-                               b[EFTB_B_PROJ], b[EFTB_B_PLK]);
-        else
-            hipLaunchKernelGGL(reduce_kernel, dim3((Nk + 255) / 256, Nl, B), dim3(256), 0, st, Nk, Nl, b[EFTB_B_BIAS], b[EFTB_B_TEMPL], b[EFTB_B_PLK]);
-    }
+    if (mask & EFTB_S_REDUCE)
+        hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],
+                           b[EFTB_B_TEMPL], b[EFTB_B_PLK]);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
     return 0;
@@ -313,6 +334,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     eftb_engine* e = new eftb_engine();
     e->c = c;
     e->Nn = 2 * c.NIR * c.Na;
+    e->cur_nl = c.Nl;
+    e->cur_nx = c.Nk;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&e->ev0));
@@ -335,10 +358,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
         HIPCHK(hipMalloc(&e->V, B * NS * e->ldtv * sizeof(double)));
     }
-    if (c.with_ap) {
-        HIPCHK(hipMalloc(&e->SD, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
-        HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
-    }
+    HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
+    if (c.with_ap) HIPCHK(hipMalloc(&e->SD, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
     *out = e;
     return 0;
 }
@@ -382,6 +403,54 @@ int eftb_finalize(eftb_engine* e) {
     return 0;
 }
 
+int eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx_in, const double* op, int* op_id) {
+    if (!e || !op || !op_id) return fail("eftb_add_operator: null argument");
+    if (nl_out < 1 || nx_out < 1 || nl_in < 1 || nx_in < 1) return fail("eftb_add_operator: bad shape");
+    if ((size_t)nl_out * nx_out > (size_t)e->c.Nl * e->c.Nk || (size_t)nl_in * nx_in > (size_t)e->c.Nl * e->c.Nk)
+        return fail("eftb_add_operator: operator shapes must not exceed the engine's [Nl=%d][Nk=%d] block", e->c.Nl, e->c.Nk);
+    HIPCHK(hipSetDevice(e->c.device));
+    eftb_engine::Op o{nl_out, nx_out, nl_in, nx_in, (nl_out * nx_out + 15) / 16 * 16, nullptr};
+    // K-major copy: opT[(l,k)][(a,x)]
+    std::vector<double> t((size_t)nl_in * nx_in * o.ld, 0.0);
+    for (int a = 0; a < nl_out; ++a)
+        for (int l = 0; l < nl_in; ++l)
+            for (int x = 0; x < nx_out; ++x) {
+                const double* src = op + (((size_t)a * nl_in + l) * nx_out + x) * nx_in;
+                for (int k = 0; k < nx_in; ++k) t[((size_t)l * nx_in + k) * o.ld + (size_t)a * nx_out + x] = src[k];
+            }
+    HIPCHK(hipMalloc(&o.dev, t.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(o.dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->ops.push_back(o);
+    *op_id = (int)e->ops.size() - 1;
+    return 0;
+}
+
+int eftb_apply_operator(eftb_engine* e, int op_id, int B) {
+    if (!e) return fail("eftb_apply_operator: null engine");
+    if (!e->finalized) return fail("eftb_apply_operator: engine not finalized");
+    if (B < 1 || B > e->c.max_batch) return fail("eftb_apply_operator: batch %d outside [1, %d]", B, e->c.max_batch);
+    HIPCHK(hipSetDevice(e->c.device));
+    if (int rc = launch_operator(e, op_id, B)) return rc;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
+    return 0;
+}
+
+int eftb_set_pipeline_operator(eftb_engine* e, int op_id) {
+    if (!e) return fail("eftb_set_pipeline_operator: null engine");
+    if (op_id >= (int)e->ops.size()) return fail("eftb_set_pipeline_operator: operator id %d out of range", op_id);
+    e->pipeline_op = op_id < 0 ? -1 : op_id;
+    return 0;
+}
+
+int eftb_set_template_dims(eftb_engine* e, int nl, int nx) {
+    if (!e) return fail("eftb_set_template_dims: null engine");
+    if (nl < 1 || nx < 1 || (size_t)nl * nx > (size_t)e->c.Nl * e->c.Nk) return fail("eftb_set_template_dims: bad shape [%d][24][%d]", nl, nx);
+    e->cur_nl = nl;
+    e->cur_nx = nx;
+    return 0;
+}
+
 int eftb_set_option(eftb_engine* e, int option, int value) {
     if (!e) return fail("eftb_set_option: null engine");
     switch (option) {
@@ -397,6 +466,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
     for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V}) if (p) (void)hipFree(p);
+    for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -478,10 +548,11 @@ int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, c
     int mask = EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_REGROUP;
     if (c.with_resum) mask |= EFTB_S_CF | EFTB_S_RESUM;
     if (c.with_ap) mask |= EFTB_S_AP;
+    if (e->pipeline_op >= 0) mask |= EFTB_S_PROJECT;
     if (plk) mask |= EFTB_S_REDUCE;
     if (int rc = launch_stages(e, mask, B)) return rc;
-    HIPCHK(hipMemcpyAsync(templ, e->buf[EFTB_B_TEMPL], (size_t)B * c.Nl * NROW * c.Nk * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (plk) HIPCHK(hipMemcpyAsync(plk, e->buf[EFTB_B_PLK], (size_t)B * c.Nl * c.Nk * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(templ, e->buf[EFTB_B_TEMPL], (size_t)B * e->cur_nl * NROW * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (plk) HIPCHK(hipMemcpyAsync(plk, e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
@@ -514,8 +585,7 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
     if (B < 1 || B > e->c.max_batch) return fail("eftb_gather_plk: batch %d outside [1, %d]", B, e->c.max_batch);
     if (root < 0 || root >= e->nranks) return fail("eftb_gather_plk: bad root %d", root);
     HIPCHK(hipSetDevice(e->c.device));
-    const int nx = e->c.nproj > 0 ? e->c.nproj : e->c.Nk, nl = e->c.nproj > 0 ? e->c.nproj_l : e->c.Nl;
-    const size_t count = (size_t)B * nl * nx;
+    const size_t count = (size_t)B * e->cur_nl * e->cur_nx;
     if (e->rank == root && !e->gathered)
         HIPCHK(hipMalloc(&e->gathered, (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
     if (e->nranks == 1) {

@@ -38,14 +38,16 @@ def _padded_fragments(frag):
 
 
 class Engine:
-    def __init__(self, cfg: EngineConfig, max_batch: int = 1, device: int = 0, projection=None):
+    def __init__(self, cfg: EngineConfig, max_batch: int = 1, device: int = 0):
         self.lib = L.load()
         self.cfg = cfg
         t = self.tables = build_tables(cfg)
         self.Nl, self.Nk, self.Nkin = cfg.Nl, t["k"].size, t["kin"].size
         self.k, self.kin, self.s = t["k"], t["kin"], t["s"]
         self.max_batch = int(max_batch)
-        self.projection = None if projection is None else np.ascontiguousarray(projection, dtype=np.float64)
+        self.dims = (cfg.Nl, self.Nk)      # shape (nl, nx) of the template block after the last stage run
+        self._op_shapes = []               # (nl_out, nx_out, nl_in, nx_in) per registered operator
+        self._pipeline_op = -1
         c = L.Config()
         c.device, c.Nl, c.Nk, c.Nkin, c.max_batch = device, cfg.Nl, self.Nk, self.Nkin, self.max_batch
         c.with_resum, c.with_ap, c.ap_stochastic = int(cfg.with_resum), int(cfg.with_ap), int(cfg.APst)
@@ -56,8 +58,6 @@ class Engine:
             c.nxtail = t["lnx_xtail"].size
             c.ncolsC = t["pairsC"].shape[1] * 16
             c.NIR, c.Na, c.Nklow = (int(x) for x in t["resum_dims"])
-        if self.projection is not None:
-            c.nproj_l, _, c.nproj, _ = self.projection.shape
         self._cconf = c
         h = C.c_void_p()
         L.check(self.lib.eftb_create(C.byref(c), C.byref(h)))
@@ -113,8 +113,6 @@ class Engine:
             self._set("SPINV", t["sp_inv"])
             self._set("SPCP", t["sp_cp"])
             self._set("APFID", t["ap_fid"])
-        if self.projection is not None:
-            self._set("PROJ", self.projection)
 
     def set_ap_fiducial(self, DA, H):
         """Replace the fiducial (DA, H) of the AP stage (APeffect constructor, pybird.py:1522-1530)."""
@@ -146,6 +144,10 @@ class Engine:
 
     def run(self, mask, B=1, sync=True):
         L.check(self.lib.eftb_run(self._h, mask, B))
+        if mask & L.S_REGROUP:
+            self.dims = (self.Nl, self.Nk)
+        if mask & L.S_PROJECT:
+            self.dims = self.out_dims()
         if sync:
             L.check(self.lib.eftb_sync(self._h))
 
@@ -158,13 +160,42 @@ class Engine:
         L.check(self.lib.eftb_run_timed(self._h, mask, B, repeats, C.byref(ms)))
         return ms.value / repeats
 
+    # ------------------------------------------------------------------ linear operators (window / binning / chained)
+    def add_operator(self, op):
+        """op [nl_out, nl_in, nx_out, nx_in]: out[a, row, x] = sum_{l,k} op[a,l,x,k] in[l, row, k]  -> operator id"""
+        op = np.ascontiguousarray(op, dtype=np.float64)
+        nl_out, nl_in, nx_out, nx_in = op.shape
+        oid = C.c_int()
+        L.check(self.lib.eftb_add_operator(self._h, nl_out, nx_out, nl_in, nx_in, L.dptr(op), C.byref(oid)))
+        self._op_shapes.append((nl_out, nx_out, nl_in, nx_in))
+        return oid.value
+
+    def apply_operator(self, op_id, B=1, sync=True):
+        L.check(self.lib.eftb_apply_operator(self._h, op_id, B))
+        self.dims = self._op_shapes[op_id][:2]
+        if sync:
+            self.sync()
+
+    def set_pipeline_operator(self, op_id):
+        """Operator applied by the PROJECT stage of run()/eval_batch (-1 = none)."""
+        L.check(self.lib.eftb_set_pipeline_operator(self._h, op_id))
+        self._pipeline_op = op_id
+
+    def set_template_dims(self, nl, nx):
+        L.check(self.lib.eftb_set_template_dims(self._h, nl, nx))
+        self.dims = (nl, nx)
+
+    def out_dims(self):
+        """(nl, nx) of the templates / P_l that a full pipeline run produces."""
+        return self._op_shapes[self._pipeline_op][:2] if self._pipeline_op >= 0 else (self.Nl, self.Nk)
+
     def full_mask(self, reduce=False):
         m = L.S_PREP | L.S_LOOPS | L.S_REGROUP
         if self.cfg.with_resum:
             m |= L.S_CF | L.S_RESUM
         if self.cfg.with_ap:
             m |= L.S_AP
-        if self.projection is not None:
+        if self._pipeline_op >= 0:
             m |= L.S_PROJECT
         if reduce:
             m |= L.S_REDUCE
@@ -172,16 +203,18 @@ class Engine:
 
     # ------------------------------------------------------------------ whole path
     def eval_batch(self, Pin, f, DA=None, H=None, bias=None):
-        """Pin [B, Nkin], f/DA/H [B] -> templates [B, Nl, 24, Nk] (+ P_l [B, Nl, Nk] if bias [B, 24])."""
+        """Pin [B, Nkin], f/DA/H [B] -> templates [B, nl, 24, nx] (+ P_l [B, nl, nx] if bias [B, 24]);
+        (nl, nx) = out_dims(): (Nl, Nk) unless a pipeline operator (window / binning / chained) is set."""
         Pin = np.ascontiguousarray(np.atleast_2d(Pin), dtype=np.float64)
         B = Pin.shape[0]
         as1 = lambda x: None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (B,)))
         f, DA, H = as1(f), as1(DA), as1(H)
-        templ = np.empty((B, self.Nl, NROW, self.Nk))
+        nl, nx = self.out_dims()
+        templ = np.empty((B, nl, NROW, nx))
         plk = None
         if bias is not None:
             bias = np.ascontiguousarray(bias, dtype=np.float64).reshape(B, NROW)
-            plk = np.empty((B, self.Nl, self.Nk))
+            plk = np.empty((B, nl, nx))
         L.check(self.lib.eftb_eval_batch(self._h, B, L.dptr(Pin), L.dptr(f), L.dptr(DA), L.dptr(H), L.dptr(templ),
                                          L.dptr(bias), L.dptr(plk)))
         return (templ, plk) if bias is not None else templ
@@ -210,8 +243,7 @@ class Engine:
         out = None
         nranks = getattr(self, "nranks", 1)
         if to_host and getattr(self, "rank", 0) == root:
-            nx = self.projection.shape[2] if self.projection is not None else self.Nk
-            nl = self.projection.shape[0] if self.projection is not None else self.Nl
+            nl, nx = self.out_dims()
             out = np.empty((nranks, B, nl, nx))
         L.check(self.lib.eftb_gather_plk(self._h, B, root, L.dptr(out)))
         return out

@@ -342,6 +342,43 @@ _CALQ = np.array(
 )  # (2a+1) (a l q; 0 0 0)^2, reference window.py:286-303
 
 
+def window_matrix(k, sw, Qq, Na, Nl, accboost=1, Nmax=4096, xmin_factor=1.0, xmax_factor=100.0, bias=-1.6,
+                  window_param=1, pmax=None):
+    """W_{a l}(k, p) [Na, Nl, Nk, Np] and the p grid from a configuration-space window Q_q(s)
+    (reference window.py:262-346): FFTLog(Nmax) of Q_{al}(s) j_{2a}(k s) followed by the j_{2l}(p s) sum.
+    One real FFT batch per (a, l) and one (Nk x Nmax+1) @ (Nmax+1 x Np) product."""
+    from numpy.fft import rfft
+
+    k = np.asarray(k, dtype=float)
+    Nq = Qq.shape[0]
+    Qal = np.einsum("alq,qs->als", _CALQ[:Na, :Nl, :Nq], Qq)
+    p = window_pgrid(float(k.max()) if pmax is None else pmax, accboost)
+    N = Nmax
+    xmin, xmax = sw[0] * xmin_factor, sw[-1] * xmax_factor
+    dx = np.log(xmax / xmin) / (N - 1.0)
+    i = np.arange(N)
+    x = xmin * np.exp(i * dx)
+    Pow = bias + 1j * 2.0 * np.pi / (N * dx) * (np.arange(N + 1) - N / 2.0)
+    cw = xmin ** (-Pow) / float(N) * edge_window(N, window_param)
+    lo, hi = int(np.searchsorted(x, sw[0])), int(np.searchsorted(x, sw[-1], side="right"))
+    Qx = CubicSpline(sw, Qal, axis=-1, extrapolate=False)(x[lo:hi])          # [Na,Nl,nx]
+    tilt = np.exp(-bias * i[lo:hi] * dx)
+    pPow = np.exp(np.outer(-Pow - 3.0, np.log(p)))                           # [N+1,Np]
+    Wal = np.empty((Na, Nl, k.size, p.size))
+    for a in range(Na):
+        jk = spherical_jn(2 * a, x[lo:hi][None, :] * k[:, None])             # [Nk,nx]
+        for l in range(Nl):
+            fx = np.zeros((k.size, N))
+            fx[:, lo:hi] = (Qx[a, l] * tilt)[None, :] * jk
+            half = rfft(fx, axis=-1)
+            c = np.empty((k.size, N + 1), dtype=complex)
+            c[:, : N // 2] = np.conj(half[:, 1:][:, ::-1])
+            c[:, N // 2 :] = half
+            weight = cw * ((-1j) ** (2 * a) * (1j) ** (2 * l)) * 4.0 * np.pi * lm.bessel_weight(2 * l, -0.5 * Pow)
+            Wal[a, l] = p**2 * np.real((c * weight[None, :]) @ pPow)
+    return Wal, p
+
+
 def window_fold(k, Wal, p, windowk=0.05, withmask=True):
     """Mask + dp weights (reference window.py:348-359) folded with the k->p cubic spline
     (window.py:376-383):  P'_a(k) = sum_{l,k'} Wfold[a,l,k,k'] P_l(k')."""
@@ -353,3 +390,52 @@ def window_fold(k, Wal, p, windowk=0.05, withmask=True):
     dp = np.concatenate([[0.0], np.diff(p)])
     Waldk = W * dp
     return np.ascontiguousarray(np.einsum("alkp,pq->alkq", Waldk, spline_matrix(k, p), optimize=True)), Waldk
+
+
+def binning_operator(k, kout=None, accboost=1, decimals=2, kstart=None, kend=None, nbins=None):
+    """k^2-weighted bin average as a matrix [nbins, Nk] (+ keff, bin edges): cubic spline of the template
+    onto 100*accboost points per bin, trapezoid rule, divided by the bin volume (reference binning.py:43-144)."""
+    k = np.asarray(k, dtype=float)
+    kout = np.asarray(kout, dtype=float)
+    if kstart is None and kend is None and nbins is None:
+        dk = np.round(kout[-1] - kout[-2], decimals)
+        centre = (kout[-1] - dk * np.arange(len(kout)))[::-1]
+        binmin, binmax = centre - dk / 2, centre + dk / 2
+    else:
+        if kstart is None or kend is None or nbins is None:
+            raise ValueError("need specify kstart, kend and nbins together")
+        edges = np.linspace(kstart, kend, nbins + 1)
+        il = np.searchsorted(edges, kout[0]) - 1
+        ir = np.searchsorted(edges, kout[-1], side="right") + 1
+        edges = edges[il:ir]
+        binmin, binmax = edges[:-1], edges[1:]
+    binvol = (binmax**3 - binmin**3) / 3.0
+    keff = (binmax**4 - binmin**4) / 4.0 / binvol
+    npts = 100 * accboost
+    op = np.empty((len(binmin), k.size))
+    for b, (lo, hi) in enumerate(zip(binmin, binmax)):
+        pts = np.linspace(lo, hi, npts)
+        w = np.full(npts, pts[1] - pts[0])
+        w[0] = w[-1] = 0.5 * (pts[1] - pts[0])
+        op[b] = (w * pts**2) @ spline_matrix(k, pts) / binvol[b]
+    return op, keff, binmin, binmax
+
+
+def chained_matrix(Nl):
+    """Q_l = P_l - A_l P_{l+2}, A_l = (2l+1) L_l(0) / ((2l+5) L_{l+2}(0)) (reference chained.py:13-54)."""
+    m = np.zeros((Nl - 1, Nl))
+    for a in range(Nl - 1):
+        l = 2 * a
+        m[a, a] = 1.0
+        m[a, a + 1] = -((2 * l + 1) * legendre(l)(0)) / ((2 * l + 5) * legendre(l + 2)(0))
+    return m
+
+
+def compose_operator(Nl, Nk, Wfold=None, binning=None, chained=False):
+    """Fold window [Na,Nl,Nk,Nk], binning [nb,Nk] and the chained matrix into one [nl_out, Nl, nx_out, Nk]."""
+    op = Wfold if Wfold is not None else np.einsum("al,xk->alxk", np.eye(Nl), np.eye(Nk))
+    if binning is not None:
+        op = np.einsum("bx,alxk->albk", binning, op)
+    if chained:
+        op = np.einsum("ca,alxk->clxk", chained_matrix(op.shape[0]), op)
+    return np.ascontiguousarray(op)

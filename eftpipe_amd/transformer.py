@@ -1,0 +1,50 @@
+"""BirdLike records and the copy transformer (same surface as reference eftpipe/transformer.py:10-38)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Optional
+
+import numpy as np
+
+from . import _lib as L
+from .engine import ROWS
+
+TEMPLATES = ("P11l", "Pctl", "Ploopl", "Pstl")
+
+
+@dataclass
+class PlainBird:
+    """(reference transformer.py:14-24)"""
+
+    f: float
+    co: Any
+    P11l: np.ndarray
+    Ploopl: np.ndarray
+    Pctl: np.ndarray
+    Pstl: np.ndarray
+    Picc: np.ndarray
+    PctNNLOl: Optional[np.ndarray] = None
+
+
+class BirdCopier:
+    """(reference transformer.py:27-38)"""
+
+    def transform(self, birdlike):
+        return PlainBird(f=birdlike.f, co=birdlike.co, P11l=birdlike.P11l.copy(), Ploopl=birdlike.Ploopl.copy(),
+                         Pctl=birdlike.Pctl.copy(), Pstl=birdlike.Pstl.copy(), Picc=birdlike.Picc.copy(),
+                         PctNNLOl=None if birdlike.PctNNLOl is None else birdlike.PctNNLOl.copy())
+
+
+def apply_operator_to_birdlike(eng, op_id, birdlike):
+    """Upload the four template arrays of a BirdLike, run one registered operator on the device, download.
+    -> dict(P11l, Pctl, Ploopl, Pstl) with the operator's output shape."""
+    nl, nx = birdlike.P11l.shape[0], birdlike.P11l.shape[-1]
+    T = np.empty((nl, 24, nx))
+    for n, sl in ROWS.items():
+        T[:, sl] = getattr(birdlike, n)
+    eng.set_template_dims(nl, nx)
+    eng.put("TEMPL", T)
+    eng.apply_operator(op_id, 1)
+    nlo, nxo = eng.dims
+    out = eng.get("TEMPL", (nlo, 24, nxo))
+    return {n: np.ascontiguousarray(out[:, sl]) for n, sl in ROWS.items()}

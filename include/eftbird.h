@@ -42,8 +42,6 @@ typedef struct eftb_config {
     int32_t nsteps;        /* K-steps of the pair contraction (eftpipe_amd/tables.py pair_steps) */
     int32_t ncolsC;        /* padded columns of the xi contraction (multiple of 16)     */
     int32_t NIR, Na, Nklow;/* Resum.NIR, Resum.Na, Common.Nklow                         pybird.py:1247-1259, 560 */
-    int32_t nproj;         /* rows of the optional post-AP projection operator (0 = none) */
-    int32_t nproj_l;       /* output multipoles of the projection                       */
 } eftb_config;
 
 /* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file). */
@@ -53,7 +51,7 @@ enum eftb_table {
     EFTB_T_CCTR, EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
     EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
     EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPDX, EFTB_T_SPLOWER, EFTB_T_SPINV, EFTB_T_SPCP, EFTB_T_APFID,
-    EFTB_T_PROJ, EFTB_T_PLANC, EFTB_T_TVT, EFTB_T_COUNT
+    EFTB_T_PLANC, EFTB_T_TVT, EFTB_T_COUNT
 };
 
 /* Device-resident state (per engine, [max_batch] leading axis unless noted). */
@@ -69,12 +67,12 @@ enum eftb_buffer {
     EFTB_B_CCT,       /* [B][Nl][80]          Bird.Cct                            pybird.py:1094 */
     EFTB_B_CC,        /* [B][Nl*38][80]       Bird.C22 ([Nl][28][80]) then Bird.C13 ([Nl][10][80]) */
     EFTB_B_CLOOPL,    /* [B][Nl][12][80]      Bird.Cloopl                         pybird.py:805-846 */
-    EFTB_B_TEMPL,     /* [B][Nl][24][Nk]      rows 0-2 P11l, 3-8 Pctl, 9-20 Ploopl, 21-23 Pstl  */
+    EFTB_B_TEMPL,     /* [B][nl][24][nx]      rows 0-2 P11l, 3-8 Pctl, 9-20 Ploopl, 21-23 Pstl; (nl, nx) = (Nl, Nk) until an
+                                              operator (window / binning / chained) is applied, then that operator's output shape */
     EFTB_B_XY,        /* [B][2][80]           IR filters X(s), Y(s)               pybird.py:1316-1353 */
     EFTB_B_Q,         /* [B][2][Nl][Nl][Nn]   Resum.Q                             pybird.py:1367-1380 */
     EFTB_B_BIAS,      /* [B][24]              b11(3), bct(6), bloop(12), bst(3)   parambasis.py:69-126 */
-    EFTB_B_PLK,       /* [B][Nl][Nk]          reduce_Plk(...).sum() without Picc  parambasis.py:128-136 */
-    EFTB_B_PROJ,      /* [B][nproj_l][24][nproj]  window/binning/chained projection of TEMPL */
+    EFTB_B_PLK,       /* [B][nl][nx]          reduce_Plk(...).sum() without Picc  parambasis.py:128-136 */
     EFTB_B_COEF,      /* [B][2][129]          FFTLog coefficients (independent half, re/im) */
     EFTB_B_COUNT
 };
@@ -87,7 +85,8 @@ enum eftb_stage {
     EFTB_S_REGROUP = 1 << 3,  /* Bird.setPsCfl                                pybird.py:737-866 */
     EFTB_S_RESUM   = 1 << 4,  /* Resum.Ps                                     pybird.py:1413-1464 */
     EFTB_S_AP      = 1 << 5,  /* APeffect.AP                                  pybird.py:1598-1621 */
-    EFTB_S_PROJECT = 1 << 6,  /* Window.Window / Binning / Chained (folded)   window.py:371-415, binning.py:131-162, chained.py:56-68 */
+    EFTB_S_PROJECT = 1 << 6,  /* the pipeline operator (eftb_set_pipeline_operator): Window.Window / Binning / Chained, folded
+                                 window.py:371-415, binning.py:131-162, chained.py:56-68 */
     EFTB_S_REDUCE  = 1 << 7,  /* reduce_Plk                                   parambasis.py:42-136 */
     EFTB_S_ALL     = 0xff,
     /* single-kernel selectors (profiling / roofline measurement only; need the stage's inputs in place) */
@@ -106,6 +105,19 @@ enum eftb_option {
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 
+/* Linear post-AP projections.  Window.Window (window.py:371-415), Binning.transform (binning.py:131-162) and
+ * Chained.transform (chained.py:56-68) are linear maps of the template block on the k axis and the multipole
+ * axis; each is registered once as a dense operator  out[a][row][x] = sum_{l,k} op[a][l][x][k] * in[l][row][k]
+ * (the cubic splines onto the window p grid / the bin quadrature points are folded in on the host) and applied
+ * on the FP64 matrix cores.  `op` is [nl_out][nl_in][nx_out][nx_in]; requires nl_out*nx_out <= Nl*Nk. */
+int  eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx_in, const double* op, int* op_id);
+/* Apply to the current template block of cosmologies [0, B); the block takes the operator's output shape. */
+int  eftb_apply_operator(eftb_engine* e, int op_id, int B);
+/* Operator run by the EFTB_S_PROJECT stage of eftb_run / eftb_eval_batch (-1 = none). */
+int  eftb_set_pipeline_operator(eftb_engine* e, int op_id);
+/* Declare the shape of the template block before eftb_put(EFTB_B_TEMPL, ...) of already-projected templates. */
+int  eftb_set_template_dims(eftb_engine* e, int nl, int nx);
+
 /* Host <-> device state.  `offset`/`count` are in elements (doubles). */
 int  eftb_put(eftb_engine* e, int buffer_id, size_t offset, const double* host, size_t count);
 int  eftb_get(eftb_engine* e, int buffer_id, size_t offset, double* host, size_t count);
@@ -118,7 +130,8 @@ int  eftb_sync(eftb_engine* e);
 int  eftb_run_timed(eftb_engine* e, int stage_mask, int B, int repeats, float* ms);
 
 /* One call = reference theory.py:557-585 for a batch: host inputs in, templates out.
- * templ is [B][Nl][24][Nk] (rows as EFTB_B_TEMPL); plk may be NULL, else bias must be [B][24]. */
+ * templ is [B][nl][24][nx] (rows as EFTB_B_TEMPL; (nl, nx) = the pipeline operator's output shape, else (Nl, Nk));
+ * plk [B][nl][nx] may be NULL, else bias must be [B][24]. */
 int  eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA,
                      const double* H, double* templ, const double* bias, double* plk);
 

@@ -1,0 +1,94 @@
+"""GPU: window / binning / chained as device operators -- the mirror classes one by one (reference
+theory.py:584-604 order) and the single folded pipeline operator of the batched path."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+from eftpipe_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+WIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "win_NGC_LRG_sQ024.npy")
+NAMES = ("P11l", "Pctl", "Ploopl", "Pstl")
+
+
+def test_window_binning_chained_mirrors(golden, tmp_path):
+    from eftpipe_amd import pybird
+    from eftpipe_amd.binning import Binning
+    from eftpipe_amd.chained import Chained
+    from eftpipe_amd.parambasis import reduce_Plk
+    from eftpipe_amd.transformer import BirdCopier
+    from eftpipe_amd.window import Window
+
+    g = golden("caseC")
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+    nl, rs = pybird.NonLinear(co=co), pybird.Resum(co=co)
+    ap = pybird.APeffect(Om_AP=synth.OM_AP, z_AP=0.7, co=co, APst=True)
+    cache = tmp_path / "win_cache.npy"
+    win = Window(window_fourier_file=cache, window_configspace_file=WIN, co=co, load=True, save=True)
+    assert cache.exists() and cache.with_suffix(".json").exists()      # reference cache format written
+    win2 = Window(window_fourier_file=cache, co=co, load=True)          # ... and read back
+    assert np.array_equal(win2.Wal, win.Wal)
+    binning = Binning(kout=g["kout"], co=co)
+    assert np.allclose(binning.keff, g["keff"], rtol=1e-13)
+
+    bird = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), 0.7, co=co)
+    nl.PsCf(bird)
+    bird.setPsCfl()
+    rs.Ps(bird)
+    snap = BirdCopier().transform(bird)
+    ap.AP(bird)
+    assert relerr(snap.Ploopl, g["resum_Ploopl"]) < TOL
+    win.Window(bird)
+    for n in NAMES:
+        assert relerr(getattr(bird, n), g["window_" + n]) < TOL, n
+    assert relerr(reduce_Plk(bird, list(g["bsA"]), es=tuple(g["es"])).sum(), g["plk_auto"]) < TOL
+    binned = binning.transform(bird)
+    for n in NAMES + ("Picc",):
+        assert relerr(getattr(binned, n), g["binned_" + n]) < TOL, n
+    assert relerr(reduce_Plk(binned, list(g["bsA"]), es=tuple(g["es"])).sum(), g["plk_binned_auto"]) < TOL
+    ch = Chained().transform(binned)
+    for n in NAMES + ("Picc",):
+        assert getattr(ch, n).shape == g["chained_" + n].shape
+        assert relerr(getattr(ch, n), g["chained_" + n]) < TOL, n
+    # cross-spectrum style contraction A x B (reference parambasis.py:69-126 with kmB/krB/ndB)
+    cox = pybird.Common(Nl=3, kmA=0.7, krA=0.25, ndA=4.5e-5, kmB=0.6, krB=0.3, ndB=2.3e-4)
+    binned.co = cox
+    assert relerr(reduce_Plk(binned, list(g["bsA"]), list(g["bsB"]), tuple(g["es"])).sum(), g["plk_cross"]) < TOL
+
+
+def test_folded_pipeline_operator_batched(golden):
+    """One operator = chained o binning o window, applied inside eval_batch for several cosmologies."""
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    k = g["k"]
+    tab = np.load(WIN)
+    Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+    Wfold, _ = TB.window_fold(k, Wal, p)
+    Bm, keff, _, _ = TB.binning_operator(k, g["kout"])
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, APst=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=4)
+    op_full = eng.add_operator(TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm, chained=True))
+    op_bin = eng.add_operator(TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm))
+    f = float(g["f"])
+    Pin = np.stack([g["Pin"], 1.05 * g["Pin"], g["Pin"]])
+    bias = np.tile(bias_row(f, list(g["bsA"]), None, tuple(g["es"]), kmA=0.7, krA=0.25, ndA=4.5e-5), (3, 1))
+    eng.set_pipeline_operator(op_full)
+    templ, plk = eng.eval_batch(Pin, f, float(g["DA"]), float(g["H"]), bias=bias)
+    assert templ.shape == (3, 2, 24, len(g["kout"])) and plk.shape == (3, 2, len(g["kout"]))
+    for i in (0, 2):
+        assert relerr(templ[i][:, 9:21], g["chained_Ploopl"]) < TOL
+        assert relerr(templ[i][:, 0:3], g["chained_P11l"]) < TOL
+    assert np.max(np.abs(templ[1] - templ[0])) > 0
+    eng.set_pipeline_operator(op_bin)
+    templ, plk = eng.eval_batch(Pin, f, float(g["DA"]), float(g["H"]), bias=bias)
+    assert relerr(plk[0], g["plk_binned_auto"]) < TOL and relerr(plk[2], g["plk_binned_auto"]) < TOL
+    eng.set_pipeline_operator(-1)
+    templ = eng.eval_batch(Pin, f, float(g["DA"]), float(g["H"]))
+    assert templ.shape == (3, 3, 24, k.size) and relerr(templ[0][:, 9:21], g["ap_Ploopl"]) < TOL
+    eng.close()

@@ -61,3 +61,31 @@ def test_spline_factors_match_scipy():
     assert np.max(np.abs(sd - cs(k, 1))) < 1e-9 * np.max(np.abs(cs(k, 1)))
     xe = np.concatenate([[0.0005], rng.uniform(0.001, 0.3, 400), [0.31]])
     assert relerr(E.spline_eval(t, y, sd, slope, xe), cs(xe)) < 1e-12
+
+
+def test_projection_operators_match_reference(golden):
+    """Host-folded window / binning / chained operators applied with NumPy == the reference's own outputs."""
+    import os
+
+    from eftpipe_amd import tables as TB
+
+    g = golden("caseC")
+    k = g["k"]
+    tab = np.load(os.path.join(os.path.dirname(__file__), "golden", "win_NGC_LRG_sQ024.npy"))
+    Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+    assert np.array_equal(p, g["window_p"])
+    Wfold, Waldk = TB.window_fold(k, Wal, p)
+    assert relerr(Waldk[:, :, 10, :], g["window_Waldk_k10"]) < 1e-9
+    assert relerr(Waldk.sum(axis=-1), g["window_Waldk_sum_p"]) < 1e-9
+    names = ("P11l", "Pctl", "Ploopl", "Pstl")
+    win = {n: np.einsum("alxk,lrk->arx", Wfold, g["ap_" + n]) for n in names}
+    for n in names:
+        assert relerr(win[n], g["window_" + n]) < 1e-9, n
+    B, keff, _, _ = TB.binning_operator(k, g["kout"])
+    assert np.allclose(keff, g["keff"], rtol=1e-13)
+    for n in names:
+        assert relerr(np.einsum("bk,lrk->lrb", B, win[n]), g["binned_" + n]) < 1e-9, n
+    full = TB.compose_operator(3, k.size, Wfold=Wfold, binning=B, chained=True)
+    assert full.shape == (2, 3, len(g["kout"]), k.size)
+    for n in names:
+        assert relerr(np.einsum("alxk,lrk->arx", full, g["ap_" + n]), g["chained_" + n]) < 1e-9, n
