@@ -596,64 +596,73 @@ __global__ __launch_bounds__(256) void resum_sum_kernel(int Nk, int Nl, int nchu
 }
 
 // ------------------------------------------------------------------------------------------------
-// AP: not-a-knot cubic spline of every template row (pre-factored tridiagonal system, tables.py
-// spline_factors), then for each (row, k): P(k', mu') = sum_l' spline_l'(k') L_l'(mu'), projected back
-// on (2l+1)/2 L_l(mu) with the trapezoid rule on linspace(0,1,nmu) (reference pybird.py:1581-1621).
+// AP: not-a-knot cubic spline of every template row, then for each (row, k): P(k', mu') = sum_l'
+// spline_l'(k') L_l'(mu'), projected back on (2l+1)/2 L_l(mu) with the trapezoid rule on linspace(0,1,nmu)
+// (reference pybird.py:1581-1621).
+//
+// spline_kernel: the knot derivatives are  s = A^-1 R y  with A the (constant) not-a-knot tridiagonal matrix;
+// A^-1 R decays like 0.27^|i-j|, so the host ships it as a band of half-width SPL_HB (truncation < 1e-18,
+// checked in tests) and the solve becomes a fully parallel, coalesced banded mat-vec.  Output: the piecewise
+// cubic in power form, CO[series][i][4] = (y_i, s_i, c2_i, c3_i) on [k_i, k_i+1].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void spline_kernel(int Nk, int nseries, const double* __restrict__ T, const double* __restrict__ dx,
-                                                    const double* __restrict__ lower, const double* __restrict__ inv,
-                                                    const double* __restrict__ cp, double* __restrict__ SD) {
-    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx >= nseries) return;
-    const double* y = T + (size_t)sidx * Nk;
-    double* sd = SD + (size_t)sidx * Nk;
-    const int n = Nk;
-    // forward sweep
-    double s_prev = (y[1] - y[0]) / dx[0], s_cur = (y[2] - y[1]) / dx[1];
-    double d = dx[0] + dx[1];
-    double rhs = ((dx[0] + 2.0 * d) * dx[1] * s_prev + dx[0] * dx[0] * s_cur) / d;
-    double wprev = rhs * inv[0];
-    sd[0] = wprev;
-    for (int i = 1; i < n - 1; ++i) {
-        s_cur = (y[i + 1] - y[i]) / dx[i];
-        rhs = 3.0 * (dx[i] * s_prev + dx[i - 1] * s_cur);
-        wprev = (rhs - lower[i] * wprev) * inv[i];
-        sd[i] = wprev;
-        s_prev = s_cur;
+constexpr int SPL_HB = 32;
+
+__global__ __launch_bounds__(256) void spline_kernel(int Nk, const double* __restrict__ T, const double* __restrict__ kk,
+                                                     const double* __restrict__ band, double* __restrict__ CO) {
+    __shared__ double ys[256 + 2 * SPL_HB + 1];
+    const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
+    const size_t series = blockIdx.y;
+    const double* y = T + series * Nk;
+    for (int e = threadIdx.x; e < 256 + 2 * SPL_HB + 1; e += 256) {
+        const int jj = i0 - SPL_HB + e;
+        ys[e] = (jj >= 0 && jj < Nk) ? y[jj] : 0.0;
     }
-    {
-        // s_prev = slope[n-2]; need slope[n-3]
-        const double sl3 = (y[n - 2] - y[n - 3]) / dx[n - 3];
-        d = dx[n - 2] + dx[n - 3];
-        rhs = (dx[n - 2] * dx[n - 2] * sl3 + (2.0 * d + dx[n - 2]) * dx[n - 3] * s_prev) / d;
-        wprev = (rhs - lower[n - 1] * wprev) * inv[n - 1];
-        sd[n - 1] = wprev;
+    __syncthreads();
+    if (i >= Nk - 1) return;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 5
+    for (int d = 0; d <= 2 * SPL_HB; ++d) {
+        s0 = fma(band[(size_t)d * Nk + i], ys[threadIdx.x + d], s0);
+        s1 = fma(band[(size_t)d * Nk + i + 1], ys[threadIdx.x + 1 + d], s1);
     }
-    // back substitution
-    double nxt = wprev;
-    for (int i = n - 2; i >= 0; --i) {
-        nxt = sd[i] - cp[i] * nxt;
-        sd[i] = nxt;
-    }
+    const double y0 = ys[threadIdx.x + SPL_HB], y1 = ys[threadIdx.x + SPL_HB + 1];
+    const double h = kk[i + 1] - kk[i], ih = 1.0 / h;
+    const double sl = (y1 - y0) * ih;
+    const double c3 = (s0 + s1 - 2.0 * sl) * ih * ih;
+    const double c2 = (sl - s0) * ih - c3 * h;
+    double4 o;
+    o.x = y0; o.y = s0; o.z = c2; o.w = c3;
+    *reinterpret_cast<double4*>(CO + (series * Nk + i) * 4) = o;
 }
 
-// One workgroup = 4 template rows x 64 k values of one cosmology (wave <-> row, lanes <-> k).  The
-// (cosmology, mu)-only quantities -- k'/k, Legendre(mu'), quadrature weight x (2l+1)/2 L_l(mu) -- are
-// computed once per workgroup into LDS; each lane walks its k'(mu) monotonically through the knots and
-// keeps the cubic of the current interval in registers (reloaded only when the interval changes).
+__device__ inline int knot_interval(const double* __restrict__ kk, int Nk, double x) {
+    int lo = 0, hi = Nk - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (kk[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ap_kernel: one lane = one k and AP_R template rows (the interval search, t = k' - k_i, Legendre(mu') and the
+// quadrature weights are shared by the AP_R * NL cubics).  (cosmology, mu)-only quantities are computed once
+// per workgroup into LDS; each lane walks k'(mu) monotonically through the knots and keeps the current
+// interval's cubics in registers, re-read (two 16-byte loads each) only when the interval changes.
+constexpr int AP_R = 2;
+
 template <int NL>
 __global__ __launch_bounds__(256) void ap_kernel(int Nk, int nmu, int nrows_ap, const double* __restrict__ kk,
-                                                 const double* __restrict__ dxk, const double* __restrict__ DAw,
-                                                 const double* __restrict__ Hw, const double* __restrict__ fid,
-                                                 const double* __restrict__ mu, const double* __restrict__ wmu,
-                                                 const double* __restrict__ legmu, const double* __restrict__ T,
-                                                 const double* __restrict__ SD, double* __restrict__ Tout) {
+                                                 const double* __restrict__ DAw, const double* __restrict__ Hw,
+                                                 const double* __restrict__ fid, const double* __restrict__ mu,
+                                                 const double* __restrict__ wmu, const double* __restrict__ legmu,
+                                                 const double* __restrict__ T, const double* __restrict__ CO,
+                                                 double* __restrict__ Tout) {
     extern __shared__ double sm[];
     double* s_root = sm;                  // [nmu]      k'/k * qperp
     double* s_lp = sm + nmu;              // [NL][nmu]  L_l'(mu')
     double* s_wl = sm + (1 + NL) * nmu;   // [NL][nmu]  wmu * (2l+1)/2 L_l(mu)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + lane, row = blockIdx.y * 4 + wave, w = blockIdx.z;
+    const int k = blockIdx.x * 64 + lane, row0 = (blockIdx.y * 4 + wave) * AP_R, w = blockIdx.z;
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
     const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
     for (int j = threadIdx.x; j < nmu; j += blockDim.x) {
@@ -668,39 +677,20 @@ __global__ __launch_bounds__(256) void ap_kernel(int Nk, int nmu, int nrows_ap, 
         for (int l = 0; l < NL; ++l) s_wl[l * nmu + j] = wmu[j] * legmu[l * nmu + j];
     }
     __syncthreads();
-    if (k >= Nk || row >= NROW) return;
-    if (row >= nrows_ap) {  // rows that APeffect leaves alone (Pstl unless APst)
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const size_t o = (((size_t)w * NL + l) * NROW + row) * Nk + k;
-            Tout[o] = T[o];
-        }
-        return;
+    if (k >= Nk || row0 >= NROW) return;
+    if (row0 >= nrows_ap) {  // rows that APeffect leaves alone (Pstl unless APst); nrows_ap is a multiple of AP_R... 21 is not:
+        // handled below row by row
     }
     const double kq = kk[k] / qperp;
-    const double* y[NL];
-    const double* sd[NL];
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        y[l] = T + (((size_t)w * NL + l) * NROW + row) * Nk;
-        sd[l] = SD + (((size_t)w * NL + l) * NROW + row) * Nk;
-    }
-    // first interval by bisection, then hunt (k' is monotonic in mu)
-    int i0;
-    {
-        const double kp0 = kq * s_root[0];
-        int lo = 0, hi = Nk - 1;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (kk[mid] <= kp0) lo = mid; else hi = mid;
-        }
-        i0 = lo;
-    }
+    int i0 = knot_interval(kk, Nk, kq * s_root[0]);
     int icur = -1;
-    double k0 = 0.0, k1 = 0.0, c0[NL], c1[NL], c2[NL], c3[NL];
-    double acc[NL];
+    double k0 = 0.0, k1 = 0.0;
+    double4 cf[AP_R][NL];
+    double acc[AP_R][NL];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    for (int r = 0; r < AP_R; ++r)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) acc[r][l] = 0.0;
     for (int j = 0; j < nmu; ++j) {
         const double kp = kq * s_root[j];
         if (icur >= 0) {
@@ -711,27 +701,41 @@ __global__ __launch_bounds__(256) void ap_kernel(int Nk, int nmu, int nrows_ap, 
             icur = i0;
             k0 = kk[i0];
             k1 = kk[i0 + 1];
-            const double h = dxk[i0], ih = 1.0 / h;
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const double y0 = y[l][i0], y1 = y[l][i0 + 1], s0 = sd[l][i0], s1 = sd[l][i0 + 1];
-                const double sl = (y1 - y0) * ih;
-                c0[l] = y0;
-                c1[l] = s0;
-                c3[l] = (s0 + s1 - 2.0 * sl) * ih * ih;
-                c2[l] = (sl - s0) * ih - c3[l] * h;
-            }
+            for (int r = 0; r < AP_R; ++r)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int row = min(row0 + r, NROW - 1);
+                    cf[r][l] = *reinterpret_cast<const double4*>(CO + ((((size_t)w * NL + l) * NROW + row) * Nk + i0) * 4);
+                }
         }
         const double t = kp - k0;
-        double pk = 0.0;
+        double lp[NL], wl[NL];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) pk = fma(s_lp[l * nmu + j], c0[l] + t * (c1[l] + t * (c2[l] + t * c3[l])), pk);
+        for (int l = 0; l < NL; ++l) {
+            lp[l] = s_lp[l * nmu + j];
+            wl[l] = s_wl[l * nmu + j];
+        }
 #pragma unroll
-        for (int l = 0; l < NL; ++l) acc[l] = fma(s_wl[l * nmu + j], pk, acc[l]);
+        for (int r = 0; r < AP_R; ++r) {
+            double pk = 0.0;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) pk = fma(lp[l], cf[r][l].x + t * (cf[r][l].y + t * (cf[r][l].z + t * cf[r][l].w)), pk);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) acc[r][l] = fma(wl[l], pk, acc[r][l]);
+        }
     }
     const double c = 2.0 / (qperp * qperp * qpar);
 #pragma unroll
-    for (int l = 0; l < NL; ++l) Tout[(((size_t)w * NL + l) * NROW + row) * Nk + k] = c * acc[l];
+    for (int r = 0; r < AP_R; ++r) {
+        const int row = row0 + r;
+        if (row >= NROW) break;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const size_t o = (((size_t)w * NL + l) * NROW + row) * Nk + k;
+            Tout[o] = (row < nrows_ap) ? c * acc[r][l] : T[o];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

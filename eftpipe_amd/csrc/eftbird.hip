@@ -139,8 +139,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_H: return c.with_resum ? D * c.Na * NS * c.Nk : 0;
         case EFTB_T_MU: case EFTB_T_WMU: return c.with_ap ? D * c.nmu : 0;
         case EFTB_T_LEGMU: return c.with_ap ? D * c.Nl * c.nmu : 0;
-        case EFTB_T_SPDX: return c.with_ap ? D * (c.Nk - 1) : 0;
-        case EFTB_T_SPLOWER: case EFTB_T_SPINV: case EFTB_T_SPCP: return c.with_ap ? D * c.Nk : 0;
+        case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
         case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
     }
     return 0;
@@ -286,14 +285,15 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & EFTB_S_AP) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
         const int nseries = B * Nl * NROW;
-        hipLaunchKernelGGL(spline_kernel, dim3((nseries + 63) / 64), dim3(64), 0, st, Nk, nseries, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPDX),
-                           tb<double>(e, EFTB_T_SPLOWER), tb<double>(e, EFTB_T_SPINV), tb<double>(e, EFTB_T_SPCP), e->SD);
+        hipLaunchKernelGGL(spline_kernel, dim3((Nk + 255) / 256, nseries), dim3(256), 0, st, Nk, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_K),
+                           tb<double>(e, EFTB_T_SPBAND), e->SD);
         const int nrows_ap = c.ap_stochastic ? NROW : 21;
-#define AP_ARGS Nk, c.nmu, nrows_ap, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_SPDX), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), \
+#define AP_ARGS Nk, c.nmu, nrows_ap, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), \
                 tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), b[EFTB_B_TEMPL], e->SD, e->Talt
         const size_t aplds = (size_t)(1 + 2 * Nl) * c.nmu * sizeof(double);
-        if (Nl == 3) hipLaunchKernelGGL((ap_kernel<3>), dim3((Nk + 63) / 64, NROW / 4, B), dim3(256), aplds, st, AP_ARGS);
-        else hipLaunchKernelGGL((ap_kernel<2>), dim3((Nk + 63) / 64, NROW / 4, B), dim3(256), aplds, st, AP_ARGS);
+        const dim3 apgrid((Nk + 63) / 64, (NROW + 4 * AP_R - 1) / (4 * AP_R), B);
+        if (Nl == 3) hipLaunchKernelGGL((ap_kernel<3>), apgrid, dim3(256), aplds, st, AP_ARGS);
+        else hipLaunchKernelGGL((ap_kernel<2>), apgrid, dim3(256), aplds, st, AP_ARGS);
 #undef AP_ARGS
         std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     }
@@ -359,7 +359,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         HIPCHK(hipMalloc(&e->V, B * NS * e->ldtv * sizeof(double)));
     }
     HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
-    if (c.with_ap) HIPCHK(hipMalloc(&e->SD, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
+    if (c.with_ap) HIPCHK(hipMalloc(&e->SD, 4 * e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // power-form cubics
     *out = e;
     return 0;
 }

@@ -108,10 +108,7 @@ class Engine:
             self._set("MU", t["mu"])
             self._set("WMU", t["wmu"])
             self._set("LEGMU", t["legmu"])
-            self._set("SPDX", t["sp_dx"])
-            self._set("SPLOWER", t["sp_lower"])
-            self._set("SPINV", t["sp_inv"])
-            self._set("SPCP", t["sp_cp"])
+            self._set("SPBAND", t["sp_band"])
             self._set("APFID", t["ap_fid"])
 
     def set_ap_fiducial(self, DA, H):

@@ -185,6 +185,24 @@ def spline_factors(x):
     return dict(dx=dx, lower=lower, inv=inv, cp=cp)
 
 
+SPL_HB = 32  # half-width of the banded knot-derivative operator (must match csrc/eftb_kernels.hpp)
+
+
+def spline_derivative_band(x):
+    """Knot derivatives of the not-a-knot cubic spline as a banded operator on the values:
+    s_i = sum_d band[d, i] * y[i + d - SPL_HB].  The exact operator is  A^-1 R  (A, R tridiagonal); its entries
+    decay like (2 - sqrt 3)^|i-j| = 0.27^|i-j|, so half-width 32 truncates below 1e-18 of the peak."""
+    x = np.asarray(x, dtype=float)
+    n = x.size
+    S = CubicSpline(x, np.eye(n), axis=0)(x, 1)            # [n(i), n(j)] exact dense operator
+    band = np.zeros((2 * SPL_HB + 1, n))
+    for d in range(2 * SPL_HB + 1):
+        j = np.arange(n) + d - SPL_HB
+        ok = (j >= 0) & (j < n)
+        band[d, ok] = S[np.arange(n)[ok], j[ok]]
+    return band
+
+
 def spline_matrix(x, xe):
     """Dense operator of the same spline, end pieces extrapolated (interp1d 'extrapolate')."""
     return CubicSpline(x, np.eye(len(x)), axis=0, extrapolate=True)(xe)
@@ -318,8 +336,7 @@ def build_tables(cfg: EngineConfig) -> dict:
         wmu[0] = wmu[-1] = 0.5 * (mu[1] - mu[0])
         t["mu"], t["wmu"] = mu, wmu
         t["legmu"] = np.ascontiguousarray(((2 * ells + 1) / 2.0)[:, None] * legendre_table(Nl, mu))
-        f = spline_factors(k)
-        t["sp_dx"], t["sp_lower"], t["sp_inv"], t["sp_cp"] = f["dx"], f["lower"], f["inv"], f["cp"]
+        t["sp_band"] = spline_derivative_band(k)
         t["ap_fid"] = np.array([cfg.DA_AP, cfg.H_AP], dtype=np.float64)
     return t
 

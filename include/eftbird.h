@@ -50,7 +50,7 @@ enum eftb_table {
     EFTB_T_KPOW, EFTB_T_SPOW, EFTB_T_PAIRS22, EFTB_T_PAIRSC, EFTB_T_PLAN, EFTB_T_M13R, EFTB_T_C11R,
     EFTB_T_CCTR, EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
     EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
-    EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPDX, EFTB_T_SPLOWER, EFTB_T_SPINV, EFTB_T_SPCP, EFTB_T_APFID,
+    EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
     EFTB_T_PLANC, EFTB_T_TVT, EFTB_T_COUNT
 };
 

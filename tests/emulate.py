@@ -121,29 +121,21 @@ def resum(t, f, Pin, st):
 
 
 def spline_derivs(t, y):
-    """y [..., Nk] -> knot derivatives via the pre-factored tridiagonal system."""
-    dx, lower, inv, cp = t["sp_dx"], t["sp_lower"], t["sp_inv"], t["sp_cp"]
+    """y [..., Nk] -> knot derivatives via the banded operator (device: spline_kernel)."""
+    band = t["sp_band"]
+    hb = (band.shape[0] - 1) // 2
     n = y.shape[-1]
-    slope = np.diff(y, axis=-1) / dx
-    rhs = np.empty_like(y)
-    rhs[..., 1:-1] = 3.0 * (dx[1:] * slope[..., :-1] + dx[:-1] * slope[..., 1:])
-    d = dx[0] + dx[1]
-    rhs[..., 0] = ((dx[0] + 2 * d) * dx[1] * slope[..., 0] + dx[0] ** 2 * slope[..., 1]) / d
-    d = dx[-1] + dx[-2]
-    rhs[..., -1] = (dx[-1] ** 2 * slope[..., -2] + (2 * d + dx[-1]) * dx[-2] * slope[..., -1]) / d
-    w = np.empty_like(y)
-    w[..., 0] = rhs[..., 0] * inv[0]
-    for i in range(1, n):
-        w[..., i] = (rhs[..., i] - lower[i] * w[..., i - 1]) * inv[i]
-    sd = np.empty_like(y)
-    sd[..., -1] = w[..., -1]
-    for i in range(n - 2, -1, -1):
-        sd[..., i] = w[..., i] - cp[i] * sd[..., i + 1]
-    return sd, slope
+    yp = np.concatenate([np.zeros(y.shape[:-1] + (hb,)), y, np.zeros(y.shape[:-1] + (hb,))], axis=-1)
+    sd = np.zeros_like(y)
+    for d in range(band.shape[0]):
+        sd += band[d] * yp[..., d : d + n]
+    dx = np.diff(t["k"])
+    return sd, np.diff(y, axis=-1) / dx
 
 
 def spline_eval(t, y, sd, slope, xe):
-    k, dx = t["k"], t["sp_dx"]
+    k = t["k"]
+    dx = np.diff(k)
     i = np.clip(np.searchsorted(k, xe, side="right") - 1, 0, k.size - 2)
     tt = xe - k[i]
     c3 = (sd[..., i] + sd[..., i + 1] - 2 * slope[..., i]) / dx[i] ** 2

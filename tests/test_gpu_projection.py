@@ -92,3 +92,25 @@ def test_folded_pipeline_operator_batched(golden):
     templ = eng.eval_batch(Pin, f, float(g["DA"]), float(g["H"]))
     assert templ.shape == (3, 3, 24, k.size) and relerr(templ[0][:, 9:21], g["ap_Ploopl"]) < TOL
     eng.close()
+
+
+def test_rccl_gather_single_rank(golden):
+    """World size 1 exercises the whole RCCL code path short of the wire: lazy dlopen, unique id,
+    ncclCommInitRank, gather into the root buffer, copy-out."""
+    from eftpipe_amd.engine import Engine, comm_unique_id
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseA")
+    eng = Engine(EngineConfig(Nl=2), max_batch=4)
+    uid = comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(1, 0, uid)
+    f = float(g["f"])
+    bias = np.tile(bias_row(f, list(g["bsA"]), None, tuple(g["es"]), kmA=0.7, krA=0.25, ndA=4.5e-5), (3, 1))
+    eng.load_inputs(np.stack([g["Pin"]] * 3), f, bias=bias)
+    eng.run(eng.full_mask(reduce=True), 3)
+    out = eng.gather_plk(3, root=0, to_host=True)
+    assert out.shape == (1, 3, 2, 50)
+    assert relerr(out[0, 0], g["plk_auto"]) < TOL and np.array_equal(out[0, 0], out[0, 2])
+    eng.close()

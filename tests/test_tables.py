@@ -5,7 +5,7 @@ import pytest
 import emulate as E
 from conftest import relerr
 from eftpipe_amd import synth
-from eftpipe_amd.tables import EngineConfig, build_tables, spline_factors
+from eftpipe_amd.tables import EngineConfig, build_tables
 from oracle_util import oracle_engine
 
 
@@ -47,20 +47,20 @@ def test_device_algebra_matches_oracle(golden, name, resum, ap):
             assert relerr(st[n], g["ap_" + n]) < 1e-9, n
 
 
-def test_spline_factors_match_scipy():
+def test_banded_spline_operator_matches_scipy():
     from scipy.interpolate import CubicSpline
 
-    k = synth.survey_kgrid(256)
-    rng = np.random.default_rng(0)
-    y = rng.normal(size=(5, k.size)).cumsum(axis=-1)
-    t = dict(k=k)
-    f = spline_factors(k)
-    t.update(sp_dx=f["dx"], sp_lower=f["lower"], sp_inv=f["inv"], sp_cp=f["cp"])
-    sd, slope = E.spline_derivs(t, y)
-    cs = CubicSpline(k, y, axis=-1)
-    assert np.max(np.abs(sd - cs(k, 1))) < 1e-9 * np.max(np.abs(cs(k, 1)))
-    xe = np.concatenate([[0.0005], rng.uniform(0.001, 0.3, 400), [0.31]])
-    assert relerr(E.spline_eval(t, y, sd, slope, xe), cs(xe)) < 1e-12
+    from eftpipe_amd.tables import spline_derivative_band
+
+    for k in (synth.survey_kgrid(256), synth.survey_kgrid(2048), np.array(__import__("eftpipe_amd.loopmath", fromlist=["x"]).native_k())):
+        rng = np.random.default_rng(0)
+        y = rng.normal(size=(5, k.size)).cumsum(axis=-1)
+        t = dict(k=k, sp_band=spline_derivative_band(k))
+        sd, slope = E.spline_derivs(t, y)
+        cs = CubicSpline(k, y, axis=-1)
+        assert np.max(np.abs(sd - cs(k, 1))) < 1e-10 * np.max(np.abs(cs(k, 1)))
+        xe = np.concatenate([[0.0005], rng.uniform(0.001, 0.3, 400), [0.31]])
+        assert relerr(E.spline_eval(t, y, sd, slope, xe), cs(xe)) < 1e-11
 
 
 def test_projection_operators_match_reference(golden):

@@ -39,6 +39,8 @@ CASES = {
     "caseD": dict(Nl=3, Nk=512, resum=True, ap=True, z=0.7),
     "caseE": dict(Nl=2, Nk=None, resum=True, ap=True, z=0.7, draw=3),
     "caseF": dict(Nl=3, Nk=2048, resum=True, ap=True, z=0.7, final_only=True),
+    # cfg 3 shape: Nk=512, window on, chained multipoles, cross-tracer bias contraction (final stages only)
+    "caseG": dict(Nl=3, Nk=512, resum=True, ap=True, APst=True, window=True, chained_only=True, z=0.7, final_only=True),
 }
 
 
@@ -104,9 +106,20 @@ def run_case(ref, name, spec):
         # spot values of the precomputed window matrix (full Waldk is too large to commit)
         out["window_Waldk_sum_p"] = win.Waldk.sum(axis=-1)
         out["window_Waldk_k10"] = win.Waldk[:, :, 10, :]
+        if spec.get("chained_only"):
+            chw = ref.chained.Chained()
         win.Window(bird)
         for n, v in stage(bird).items():
             out["window_" + n] = v
+        if spec.get("chained_only"):
+            ch = chw.transform(bird)
+            for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+                out["chained_" + n] = np.array(getattr(ch, n), copy=True)
+            cox = make_common(pb, Nl, Nk, kmB=0.6, krB=0.3, ndB=2.3e-4)
+            cox.No = Nl - 1
+            holder = ref.transformer.PlainBird(f=ch.f, co=cox, P11l=ch.P11l, Ploopl=ch.Ploopl, Pctl=ch.Pctl, Pstl=ch.Pstl,
+                                               Picc=ch.Picc, PctNNLOl=None)
+            out["plk_chained_cross"] = ref.parambasis.reduce_Plk(holder, BS_A, BS_B, es=ES).sum()
     last = bird
     out["plk_auto"] = ref.parambasis.reduce_Plk(bird, BS_A, es=ES).sum()
     if spec.get("binning"):
