@@ -114,3 +114,38 @@ def test_rccl_gather_single_rank(golden):
     assert out.shape == (1, 3, 2, 50)
     assert relerr(out[0, 0], g["plk_auto"]) < TOL and np.array_equal(out[0, 0], out[0, 2])
     eng.close()
+
+
+def test_cfg3_shape_nk512_window_chained_cross(golden):
+    """BASELINE cfg 3 shape: Nl=3, Nk=512, IR-resum + AP + window, chained multipoles, cross-tracer biases."""
+    from eftpipe_amd import pybird
+    from eftpipe_amd.chained import Chained
+    from eftpipe_amd.parambasis import reduce_Plk
+    from eftpipe_amd.window import Window
+
+    g = golden("caseG")
+    co = pybird.Common(Nl=3, No=2, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5, kmB=0.6, krB=0.3, ndB=2.3e-4)
+    co.k, co.Nk = g["k"], g["k"].size
+    co.kr = co.k[0.02 <= co.k]
+    co.Nkr = co.kr.size
+    co.Nklow = co.Nk - co.Nkr
+    nl, rs = pybird.NonLinear(co=co), pybird.Resum(co=co)
+    ap = pybird.APeffect(Om_AP=synth.OM_AP, z_AP=0.7, co=co, APst=True)
+    win = Window(window_configspace_file=WIN, co=co, load=False, save=False)
+    assert np.array_equal(win.p, g["window_p"])
+    assert relerr(win.Waldk[:, :, 10, :], g["window_Waldk_k10"]) < 1e-9
+    bird = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), 0.7, co=co)
+    nl.PsCf(bird)
+    bird.setPsCfl()
+    rs.Ps(bird)
+    ap.AP(bird)
+    for n in NAMES:
+        assert relerr(getattr(bird, n), g["ap_" + n]) < TOL, n
+    win.Window(bird)
+    for n in NAMES:
+        assert relerr(getattr(bird, n), g["window_" + n]) < TOL, n
+    ch = Chained().transform(bird)
+    for n in NAMES:
+        assert relerr(getattr(ch, n), g["chained_" + n]) < TOL, n
+    plk = reduce_Plk(ch, list(g["bsA"]), list(g["bsB"]), tuple(g["es"])).sum()
+    assert plk.shape == (2, 512) and relerr(plk, g["plk_chained_cross"]) < TOL
