@@ -82,6 +82,17 @@ __global__ __launch_bounds__(256) void uvec_kernel(int rows, const double* __res
     }
 }
 
+// Linear (single-sum) terms that share the u tile of a pair GEMM workgroup: out[v] = scale * (vec[v] . u[row]).
+//   k rows: P13[w][b][k] = k^3 P11[k] (m13r[b] . u)                      (reference pybird.py:1080-1086)
+//   s rows: C11[w][l][s] = c11r[l] . u ;  Cct[w][l][s] = s^-2 (cctr[l] . u)   (reference pybird.py:1088-1096)
+struct LinTerms {
+    int nA, nB;                  // vectors of the first / second family (nA + nB <= 16)
+    const double *vecA, *vecB;   // [nA][257], [nB][257]
+    const double *scaleA, *scaleB;  // per row-in-cosmology factors (may be null)
+    const double* rowdata;       // per global row factor of family A (P11; may be null)
+    double *outA, *outB;         // [w][nA][rows_per_w], [w][nB][rows_per_w]
+};
+
 // column tiles reduced per pass of the epilogue: the largest divisor of NT whose NW partial tiles fit 128 KB
 constexpr int pair_reduce_cols(int MT, int NT, int NW) {
     int best = 1;
@@ -104,7 +115,7 @@ template <int MT, int NT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
                                                            const int* __restrict__ plan, int rows_total, int rows_per_w,
                                                            int ncols_out, int ncols_ld, const double* __restrict__ rowscale,
-                                                           double* __restrict__ out) {
+                                                           double* __restrict__ out, double* __restrict__ part, LinTerms lin) {
     constexpr int ROWS = MT * 16;  // NW waves per workgroup = K slices; NW/4 waves per SIMD hide each other's LDS/L2 latency
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,12 +131,39 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
     if (tid < 16) sm[ROWS * ULDS + tid] = 0.0;  // slack read by the zero-weight pad pairs of the last row
     __syncthreads();
 
+    // ---- linear terms straight from the LDS tile: thread <-> (row, vector), 257 FMAs each (< 0.5 % of the workgroup)
+    if (blockIdx.y == 0 && lin.nA + lin.nB > 0) {
+        for (int e = tid; e < ROWS * (lin.nA + lin.nB); e += 64 * NW) {
+            const int rr = e % ROWS, v = e / ROWS, grow = row0 + rr;
+            if (grow >= rows_total) continue;
+            const bool famA = v < lin.nA;
+            const double* vec = famA ? lin.vecA + (size_t)v * NPOW : lin.vecB + (size_t)(v - lin.nA) * NPOW;
+            const double* ur = sm + rr * ULDS;
+            double a0 = 0.0, a1 = 0.0;
+            for (int nn = 0; nn < NPOW - 1; nn += 2) {
+                a0 = fma(vec[nn], ur[nn], a0);
+                a1 = fma(vec[nn + 1], ur[nn + 1], a1);
+            }
+            double d = (a0 + a1) + vec[NPOW - 1] * ur[NPOW - 1];
+            const int w = grow / rows_per_w, rw = grow % rows_per_w;
+            if (famA) {
+                if (lin.scaleA) d *= lin.scaleA[rw];
+                if (lin.rowdata) d *= lin.rowdata[grow];
+                lin.outA[((size_t)w * lin.nA + v) * rows_per_w + rw] = d;
+            } else {
+                if (lin.scaleB) d *= lin.scaleB[rw];
+                lin.outB[((size_t)w * lin.nB + (v - lin.nA)) * rows_per_w + rw] = d;
+            }
+        }
+    }
+
     const int r = lane & 15, g = lane >> 4;
     // the wave's K range: wave-uniform, kept in SGPRs so the loops below branch on SCC, not EXEC
-    int n = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 0]);
-    int m0 = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 1]);
-    const int t0 = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 2]);
-    int nsteps = __builtin_amdgcn_readfirstlane(plan[wave * 4 + 3]);
+    const int* pl = plan + (blockIdx.y * NW + wave) * 4;  // blockIdx.y = K split across workgroups (plan has gridDim.y * NW entries)
+    int n = __builtin_amdgcn_readfirstlane(pl[0]);
+    int m0 = __builtin_amdgcn_readfirstlane(pl[1]);
+    const int t0 = __builtin_amdgcn_readfirstlane(pl[2]);
+    int nsteps = __builtin_amdgcn_readfirstlane(pl[3]);
     const double* fp = frag + ((size_t)t0 * NT) * 64 + lane;
 
     v4d acc[MT][NT];
@@ -198,10 +236,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 #pragma unroll
             for (int w8 = 0; w8 < NW; ++w8) v += sm[w8 * PER_WAVE + off];
             const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
-            if (rowscale) v *= rowscale[rw];
-            out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
+            if (gridDim.y > 1) {  // K split over workgroups: unscaled partial, summed by pair_sum_kernel
+                part[((size_t)blockIdx.y * rows_total + grow) * ncols_out + col] = v;
+            } else {
+                if (rowscale) v *= rowscale[rw];
+                out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
+            }
         }
     }
+}
+
+// sum of the K-split partials of pair_gemm_kernel: out[w][col][r] = scale[r] * sum_s part[s][row][col]
+__global__ __launch_bounds__(256) void pair_sum_kernel(int nsplit, int rows_total, int rows_per_w, int ncols_out, int ncols_ld,
+                                                       const double* __restrict__ rowscale, const double* __restrict__ part,
+                                                       double* __restrict__ out) {
+    const int rw = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y, w = blockIdx.z;
+    if (rw >= rows_per_w) return;
+    const size_t grow = (size_t)w * rows_per_w + rw;
+    double v = 0.0;
+    for (int s = 0; s < nsplit; ++s) v += part[((size_t)s * rows_total + grow) * ncols_out + col];
+    if (rowscale) v *= rowscale[rw];
+    out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,55 +368,6 @@ __global__ __launch_bounds__(256) void c13_kernel(int Nl, int ldv, const double*
         if (lane == 0)
 #pragma unroll
             for (int b = 0; b < 10; ++b) CC[((size_t)w * Nl * 38 + Nl * 28 + l * 10 + b) * NS + s] = acc[b];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// rowdot: out[v] = sum_n u[row][n] * vec[v][n] for a handful of real-reduced vectors (P13: 10; C11 and
-// Cct: 2*Nl).  One wave per row, lanes along n, shuffle reduction (reference pybird.py:1080-1101).
-// mode 0: P13[w][b][k] = k^3 P11[k] dot_b ; mode 1: C11[w][l][s] = dot_l, Cct[w][l][s] = s^-2 dot_{Nl+l}
-// ------------------------------------------------------------------------------------------------
-template <int NV>
-__global__ __launch_bounds__(256) void rowdot_kernel(int mode, int rows, int Nl, const double* __restrict__ U,
-                                                     const double* __restrict__ vecA, const double* __restrict__ vecB,
-                                                     const double* __restrict__ absc, const double* __restrict__ P11,
-                                                     double* __restrict__ outA, double* __restrict__ outB) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave, w = blockIdx.y;
-    if (row >= rows) return;
-    const double* u = U + ((size_t)w * rows + row) * UPAD;
-    const int nv = (mode == 0) ? 10 : 2 * Nl;
-    double acc[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-    for (int n = lane; n < NPOW; n += 64) {
-        const double x = u[n];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            if (v < nv) {
-                const double* vec = (mode == 0 || v < Nl) ? vecA + (size_t)v * NPOW : vecB + (size_t)(v - Nl) * NPOW;
-                acc[v] = fma(vec[n], x, acc[v]);
-            }
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[v] += __shfl_down(acc[v], o, 64);
-    if (lane == 0) {
-        const double x = absc[row];
-        if (mode == 0) {
-            const double sc = x * x * x * P11[(size_t)w * rows + row];
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-                if (v < 10) outA[((size_t)w * 10 + v) * rows + row] = sc * acc[v];
-        } else {
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                if (v < Nl) outA[((size_t)w * Nl + v) * rows + row] = acc[v];
-                else if (v < 2 * Nl) outB[((size_t)w * Nl + (v - Nl)) * rows + row] = acc[v] / (x * x);
-            }
-        }
     }
 }
 

@@ -49,6 +49,7 @@ struct eftb_engine {
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
     double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
+    double *pairpartP = nullptr, *pairpartC = nullptr;  // K-split partials of the two pair GEMMs
     int ldtv = 0;  // padded column count of Tv / V (Nl*257 rounded up to 16)
     // linear post-AP operators (window / binning / chained), stored K-major for gemm_rows_kernel
     struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; };
@@ -57,7 +58,8 @@ struct eftb_engine {
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
     int Nn = 0;
-    double* k3 = nullptr;  // k^3 row scale of P22
+    double* k3 = nullptr;   // k^3 row scale of P22 / P13
+    double* sm2 = nullptr;  // s^-2 row scale of Cct
     // RCCL gather (multi-GPU batches)
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -120,8 +122,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
         case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + 1) * 2 * 64;
         case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + 1) * (c.ncolsC / 16) * 64 : 0;
-        case EFTB_T_PLAN: return sizeof(int32_t) * 4 * NW_P22;
-        case EFTB_T_PLANC: return c.with_resum ? sizeof(int32_t) * 4 * NW_C : 0;
+        case EFTB_T_PLAN: return sizeof(int32_t) * 4 * NW_P22 * 15;
+        case EFTB_T_PLANC: return c.with_resum ? sizeof(int32_t) * 4 * NW_C * 15 : 0;
         case EFTB_T_TVT: return c.with_resum ? D * (size_t)NPOW * ((c.Nl * NPOW + 15) / 16 * 16) : 0;
         case EFTB_T_M13R: return D * 10 * NPOW;
         case EFTB_T_C11R: return c.with_resum ? D * c.Nl * NPOW : 0;
@@ -178,6 +180,36 @@ static constexpr size_t pair_lds_bytes(int MT, int NT, int NW) {
 }
 
 
+// Pair GEMM launcher.  When the row tiles alone cannot fill the 256 CUs evenly (small batches, or the 1.25-round
+// tail of the xi-space contraction at batch 128) the K range is additionally split over `ks` workgroups; their
+// unscaled partials are summed in a fixed order by pair_sum_kernel (deterministic).
+static int pick_ksplit(int row_tiles) {
+    int best = 1;
+    double best_eff = 0.0;
+    for (int ks = 1; ks <= 8; ks *= 2) {
+        const int n = row_tiles * ks;
+        const double eff = (double)n / (((n + 255) / 256) * 256.0);
+        if (eff >= 0.85) return ks;
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
+    }
+    return best;
+}
+
+template <int MT, int NT, int NW>
+static void launch_pair(eftb_engine* e, hipStream_t st, const double* U, const double* frag, const int* plan, int rows, int rows_per_w,
+                        int ncols_out, int ncols_ld, const double* rowscale, double* out, double* part, const LinTerms& lin) {
+    const int tiles = (rows + MT * 16 - 1) / (MT * 16);
+    const int ks = pick_ksplit(tiles);
+    int level = 0;
+    while ((1 << level) < ks) ++level;
+    const int* pl = plan + 4 * NW * ((1 << level) - 1);  // plans for 1, 2, 4, 8 splits are stored back to back
+    hipLaunchKernelGGL((pair_gemm_kernel<MT, NT, NW>), dim3(tiles, ks), dim3(64 * NW), pair_lds_bytes(MT, NT, NW), st, U, frag, pl, rows, rows_per_w,
+                       ncols_out, ncols_ld, rowscale, out, part, lin);
+    if (ks > 1)
+        hipLaunchKernelGGL(pair_sum_kernel, dim3((rows_per_w + 255) / 256, ncols_out, rows / rows_per_w), dim3(256), 0, st, ks, rows, rows_per_w,
+                           ncols_out, ncols_ld, rowscale, part, out);
+}
+
 // out[w][a][r][x] = sum_{l,k} T[w][l][r][k] * opT[(l,k)][(a,x)] on the FP64 matrix cores; the block changes shape
 static int launch_operator(eftb_engine* e, int id, int B) {
     if (id < 0 || id >= (int)e->ops.size()) return fail("operator id %d out of range", id);
@@ -219,26 +251,28 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & EFTB_S_LOOPS)
         hipLaunchKernelGGL(uvec_kernel, dim3(Nk, B), dim3(256), 0, st, Nk, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), e->U);
     if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
-        const int rows = B * Nk;
-        const size_t lds = pair_lds_bytes(4, 2, NW_P22);
-        hipLaunchKernelGGL((pair_gemm_kernel<4, 2, NW_P22>), dim3((rows + 63) / 64), dim3(64 * NW_P22), lds, st, e->U, tb<double>(e, EFTB_T_PAIRS22),
-                           tb<int>(e, EFTB_T_PLAN), rows, Nk, 28, 28, e->k3, b[EFTB_B_P22]);
-    }
-    if (mask & EFTB_S_LOOPS) {
-        hipLaunchKernelGGL((rowdot_kernel<10>), dim3((Nk + 3) / 4, B), dim3(256), 0, st, 0, Nk, Nl, e->U, tb<double>(e, EFTB_T_M13R),
-                           (const double*)nullptr, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], b[EFTB_B_P13], (double*)nullptr);
+        LinTerms lin{};  // P13 rides on the P22 workgroups' u tile
+        if (mask & EFTB_S_LOOPS) {
+            lin.nA = 10; lin.vecA = tb<double>(e, EFTB_T_M13R); lin.scaleA = e->k3; lin.rowdata = b[EFTB_B_P11]; lin.outA = b[EFTB_B_P13];
+        }
+        launch_pair<4, 2, NW_P22>(e, st, e->U, tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, 28, 28, e->k3, b[EFTB_B_P22],
+                                  e->pairpartP, lin);
     }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
     if (mask & EFTB_S_CF)
         hipLaunchKernelGGL(uvec_kernel, dim3(NS, B), dim3(256), 0, stc, NS, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), e->Us);
     if (mask & (EFTB_S_CF | EFTB_K_C22)) {
-        const int rows = B * NS;
+        LinTerms lin{};  // C11 and Cct ride on the C22 workgroups' u tile
+        if (mask & EFTB_S_CF) {
+            lin.nA = Nl; lin.vecA = tb<double>(e, EFTB_T_C11R); lin.outA = b[EFTB_B_C11];
+            lin.nB = Nl; lin.vecB = tb<double>(e, EFTB_T_CCTR); lin.scaleB = e->sm2; lin.outB = b[EFTB_B_CCT];
+        }
         if (Nl == 3)
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 6, NW_C>), dim3((rows + 31) / 32), dim3(64 * NW_C), pair_lds_bytes(2, 6, NW_C), stc, e->Us,
-                               tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), rows, NS, Nl * 28, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
+            launch_pair<2, 6, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, Nl * 28, Nl * 38, nullptr,
+                                    b[EFTB_B_CC], e->pairpartC, lin);
         else
-            hipLaunchKernelGGL((pair_gemm_kernel<2, 4, NW_C>), dim3((rows + 31) / 32), dim3(64 * NW_C), pair_lds_bytes(2, 4, NW_C), stc, e->Us,
-                               tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), rows, NS, Nl * 28, Nl * 38, (const double*)nullptr, b[EFTB_B_CC]);
+            launch_pair<2, 4, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, Nl * 28, Nl * 38, nullptr,
+                                    b[EFTB_B_CC], e->pairpartC, lin);
     }
     if (mask & EFTB_S_CF) {
         // 13 term through its rank structure: V = us . Tv (FP64-MFMA GEMM), then one complex product + 10 dots per row
@@ -248,8 +282,6 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         g.C = e->V; g.c_group = 0; g.c_row = e->ldtv; g.c_colgroup = 0; g.cols_per_group = Nl * NPOW;
         hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, stc, g);
         hipLaunchKernelGGL(c13_kernel, dim3((NS + 3) / 4, B), dim3(256), 0, stc, Nl, e->ldtv, e->Us, e->V, tb<double>(e, EFTB_T_M13R), b[EFTB_B_CC]);
-        hipLaunchKernelGGL((rowdot_kernel<6>), dim3((NS + 3) / 4, B), dim3(256), 0, stc, 1, NS, Nl, e->Us, tb<double>(e, EFTB_T_C11R),
-                           tb<double>(e, EFTB_T_CCTR), tb<double>(e, EFTB_T_S), (const double*)nullptr, b[EFTB_B_C11], b[EFTB_B_CCT]);
     }
     if (fork) {
         if (hipEventRecord(e->evJoin, stc) != hipSuccess || hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess)
@@ -353,8 +385,11 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     const size_t B = c.max_batch;
     HIPCHK(hipMalloc(&e->U, B * c.Nk * UPAD * sizeof(double)));
     HIPCHK(hipMalloc(&e->k3, c.Nk * sizeof(double)));
+    HIPCHK(hipMalloc(&e->sm2, NS * sizeof(double)));
     e->ldtv = (c.Nl * NPOW + 15) / 16 * 16;
+    HIPCHK(hipMalloc(&e->pairpartP, (size_t)8 * B * c.Nk * 28 * sizeof(double)));
     if (c.with_resum) {
+        HIPCHK(hipMalloc(&e->pairpartC, (size_t)8 * B * NS * c.Nl * 28 * sizeof(double)));
         HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
         HIPCHK(hipMalloc(&e->V, B * NS * e->ldtv * sizeof(double)));
     }
@@ -374,6 +409,12 @@ int eftb_set_table(eftb_engine* e, int id, const void* host, size_t nbytes) {
     if (!e->tab[id]) HIPCHK(hipMalloc(&e->tab[id], nbytes));
     HIPCHK(hipMemcpy(e->tab[id], host, nbytes, hipMemcpyHostToDevice));
     e->tab_bytes[id] = nbytes;
+    if (id == EFTB_T_S) {
+        std::vector<double> v(NS);
+        const double* sv = static_cast<const double*>(host);
+        for (int i = 0; i < NS; ++i) v[i] = 1.0 / (sv[i] * sv[i]);
+        HIPCHK(hipMemcpy(e->sm2, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (id == EFTB_T_K) {
         std::vector<double> k3(e->c.Nk);
         const double* k = static_cast<const double*>(host);
@@ -465,7 +506,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V}) if (p) (void)hipFree(p);
+    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);

@@ -20,13 +20,19 @@ ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(
 
 
 def wave_plan(steps, nwaves=8):
-    """Split the K-steps of the pair contraction evenly over the waves of a workgroup."""
+    """Split the K-steps of the pair contraction evenly over `nwaves` K slices: (n, m0, first step, count) each."""
     T = len(steps)
     plan = np.zeros((nwaves, 4), dtype=np.int32)
     for q in range(nwaves):
         t0, t1 = (q * T) // nwaves, ((q + 1) * T) // nwaves
         plan[q] = (steps[t0, 0], steps[t0, 1], t0, t1 - t0)
     return plan
+
+
+def split_plans(steps, nwaves):
+    """Plans for 1, 2, 4 and 8 workgroup-level K splits, back to back ([15 * nwaves, 4]); the workgroup
+    with blockIdx.y = s of a ks-way split uses entries [(ks - 1 + s) * nwaves, (ks + s) * nwaves)."""
+    return np.concatenate([wave_plan(steps, nwaves * ks) for ks in (1, 2, 4, 8)])
 
 
 def _padded_fragments(frag):
@@ -81,7 +87,7 @@ class Engine:
         self._set("LNXTAIL", t["lnx_tail"])
         self._set("KPOW", t["kpow"])
         self._set("PAIRS22", _padded_fragments(t["pairs22"]))
-        self._set("PLAN", wave_plan(t["steps"], NW_P22), np.int32)
+        self._set("PLAN", split_plans(t["steps"], NW_P22), np.int32)
         self._set("M13R", t["m13r"])
         for n in ("L11", "LCT", "L22", "L13"):
             self._set(n, t[n.lower()])
@@ -89,7 +95,7 @@ class Engine:
         if cfg.with_resum:
             self._set("SPOW", t["spow"])
             self._set("PAIRSC", _padded_fragments(t["pairsC"]))
-            self._set("PLANC", wave_plan(t["steps"], NW_C), np.int32)
+            self._set("PLANC", split_plans(t["steps"], NW_C), np.int32)
             ld = (cfg.Nl * 257 + 15) // 16 * 16
             tvt = np.zeros((257, ld))
             tvt[:, : cfg.Nl * 257] = t["Tv"].transpose(2, 0, 1).reshape(257, cfg.Nl * 257)
