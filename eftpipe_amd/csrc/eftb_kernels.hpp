@@ -100,6 +100,7 @@ constexpr int pair_reduce_cols(int MT, int NT, int NW) {
         if (NT % jc == 0 && (size_t)NW * MT * jc * 4 * 64 * 8 <= 128 * 1024) best = jc;
     return best;
 }
+// (NW * MT * JC * 4 * 64 partial doubles + MT*16 x NT*16 basis values must fit the 160 KB LDS)
 
 // ------------------------------------------------------------------------------------------------
 // pair GEMM on the FP64 matrix cores.
@@ -114,8 +115,9 @@ constexpr int pair_reduce_cols(int MT, int NT, int NW) {
 template <int MT, int NT, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
                                                            const int* __restrict__ plan, int rows_total, int rows_per_w,
-                                                           int ncols_out, int ncols_ld, const double* __restrict__ rowscale,
-                                                           double* __restrict__ out, double* __restrict__ part, LinTerms lin) {
+                                                           int nbasis, const double* __restrict__ comb, int ncols_out, int ncols_ld,
+                                                           const double* __restrict__ rowscale, double* __restrict__ out,
+                                                           double* __restrict__ part, LinTerms lin) {
     constexpr int ROWS = MT * 16;  // NW waves per workgroup = K slices; NW/4 waves per SIMD hide each other's LDS/L2 latency
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -213,10 +215,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
         m0 = n;
     }
 
-    // ---- reduce the 8 K-slices through LDS (the u tile is dead now) and write out, JC column tiles per pass
+    // ---- reduce the NW K-slices through LDS (the u tile is dead now) into the basis values bas[row][col], JC column
+    // tiles per pass; then expand to the requested outputs  out[col] = sum_c comb[col][c] bas[c]  (the loop matrices
+    // span a low-dimensional space: tables.py loop_basis) -- or hand the unscaled basis partial to pair_sum_kernel
     constexpr int JC = pair_reduce_cols(MT, NT, NW);
     constexpr int PER_WAVE = MT * JC * 4 * 64;
-    static_assert((size_t)NW * PER_WAVE * 8 <= 160 * 1024, "reduction buffer exceeds LDS");
+    constexpr int NBC = NT * 16;
+    static_assert((size_t)(NW * PER_WAVE + ROWS * NBC) * 8 <= 160 * 1024, "reduction buffer exceeds LDS");
+    double* bas = sm + NW * PER_WAVE;
     for (int jc = 0; jc < NT; jc += JC) {
         __syncthreads();
 #pragma unroll
@@ -228,33 +234,55 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
         __syncthreads();
         for (int e = tid; e < ROWS * JC * 16; e += 64 * NW) {
             const int row = e % ROWS, col = jc * 16 + e / ROWS;
-            if (col >= ncols_out || row0 + row >= rows_total) continue;
             const int i = row >> 4, rr = row & 15, q = rr >> 2, gg = rr & 3;
             const int j = (e / ROWS) >> 4, ln = gg * 16 + (col & 15);
             const int off = ((i * JC + j) * 4 + q) * 64 + ln;
             double v = 0.0;
 #pragma unroll
             for (int w8 = 0; w8 < NW; ++w8) v += sm[w8 * PER_WAVE + off];
-            const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
-            if (gridDim.y > 1) {  // K split over workgroups: unscaled partial, summed by pair_sum_kernel
-                part[((size_t)blockIdx.y * rows_total + grow) * ncols_out + col] = v;
-            } else {
-                if (rowscale) v *= rowscale[rw];
-                out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
-            }
+            bas[row * NBC + col] = v;
         }
+    }
+    __syncthreads();
+    if (gridDim.y > 1) {  // K split over workgroups: unscaled basis partial, finished by pair_sum_kernel
+        for (int e = tid; e < ROWS * nbasis; e += 64 * NW) {
+            const int row = e / nbasis, c = e % nbasis;
+            if (row0 + row < rows_total) part[((size_t)blockIdx.y * rows_total + row0 + row) * nbasis + c] = bas[row * NBC + c];
+        }
+        return;
+    }
+    for (int e = tid; e < ROWS * ncols_out; e += 64 * NW) {
+        const int row = e % ROWS, col = e / ROWS;
+        if (row0 + row >= rows_total) continue;
+        double v;
+        if (comb) {
+            v = 0.0;
+            for (int c = 0; c < nbasis; ++c) v = fma(comb[col * nbasis + c], bas[row * NBC + c], v);
+        } else {
+            v = bas[row * NBC + col];
+        }
+        const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
+        if (rowscale) v *= rowscale[rw];
+        out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
     }
 }
 
-// sum of the K-split partials of pair_gemm_kernel: out[w][col][r] = scale[r] * sum_s part[s][row][col]
-__global__ __launch_bounds__(256) void pair_sum_kernel(int nsplit, int rows_total, int rows_per_w, int ncols_out, int ncols_ld,
-                                                       const double* __restrict__ rowscale, const double* __restrict__ part,
-                                                       double* __restrict__ out) {
+// sum of the K-split basis partials of pair_gemm_kernel, then the expansion to the outputs:
+//   out[w][col][r] = scale[r] * sum_c comb[col][c] * sum_s part[s][row][c]
+__global__ __launch_bounds__(256) void pair_sum_kernel(int nsplit, int rows_total, int rows_per_w, int nbasis, const double* __restrict__ comb,
+                                                       int ncols_out, int ncols_ld, const double* __restrict__ rowscale,
+                                                       const double* __restrict__ part, double* __restrict__ out) {
     const int rw = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y, w = blockIdx.z;
     if (rw >= rows_per_w) return;
     const size_t grow = (size_t)w * rows_per_w + rw;
     double v = 0.0;
-    for (int s = 0; s < nsplit; ++s) v += part[((size_t)s * rows_total + grow) * ncols_out + col];
+    for (int c = 0; c < nbasis; ++c) {
+        const double cc = comb ? comb[col * nbasis + c] : (c == col ? 1.0 : 0.0);
+        if (cc == 0.0) continue;
+        double b = 0.0;
+        for (int s = 0; s < nsplit; ++s) b += part[((size_t)s * rows_total + grow) * nbasis + c];
+        v = fma(cc, b, v);
+    }
     if (rowscale) v *= rowscale[rw];
     out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
 }
@@ -524,6 +552,16 @@ __global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int sc
 #pragma unroll
             for (int v = 0; v < NA; ++v) q[v][p] = qa[p * NA + v];
     }
+    // selection rules make ~40 % of the Q polynomials identically zero (e.g. alpha = 4 never feeds l = l' = 0):
+    // skip those Bessel orders for the whole s loop (wave-uniform branch)
+    bool nz[NA];
+#pragma unroll
+    for (int v = 0; v < NA; ++v) {
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < NIR; ++p) any = any || (q[v][p] != 0.0);
+        nz[v] = __builtin_amdgcn_readfirstlane(any ? 1 : 0) != 0;
+    }
     double acc[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) acc[i] = 0.0;
@@ -539,27 +577,54 @@ __global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int sc
     }
     __syncthreads();
     const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
+    // the H columns of the next s pair are fetched under the current pair's Horner chains (global latency ~1 us)
+    double hnA[NA], hnB[NA];
+    {
+        const int sb0 = (s0 + 1 < s1) ? s0 + 1 : s0;
+#pragma unroll
+        for (int v = 0; v < NA; ++v) {
+            hnA[v] = H[((size_t)v * NS + s0) * Nk + kc];
+            hnB[v] = H[((size_t)v * NS + sb0) * Nk + kc];
+        }
+    }
     for (int s = s0; s < s1; s += 2) {
         const int sb = (s + 1 < s1) ? s + 1 : s;        // second lane of the pair (weight 0 if past the end)
         const double wb = (s + 1 < s1) ? 1.0 : 0.0;
         double hA[NA], hB[NA];
 #pragma unroll
         for (int v = 0; v < NA; ++v) {
-            hA[v] = H[((size_t)v * NS + s) * Nk + kc];
-            hB[v] = H[((size_t)v * NS + sb) * Nk + kc];
+            hA[v] = hnA[v];
+            hB[v] = hnB[v];
+        }
+        {
+            const int sn = (s + 2 < s1) ? s + 2 : s, snb = (s + 3 < s1) ? s + 3 : sn;
+#pragma unroll
+            for (int v = 0; v < NA; ++v) {
+                hnA[v] = H[((size_t)v * NS + sn) * Nk + kc];
+                hnB[v] = H[((size_t)v * NS + snb) * Nk + kc];
+            }
         }
         const double zA = k2 * sh[s], zB = k2 * sh[sb];
         const double fA = half ? k2 * sh[NS + s] : zA, fB = (half ? k2 * sh[NS + sb] : zB) * wb;
         double pA[NA], pB[NA];
 #pragma unroll
-        for (int v = 0; v < NA; ++v) pA[v] = pB[v] = q[v][NIR - 1];
+        for (int v = 0; v < NA; ++v) {
+            pA[v] = pB[v] = 0.0;
+            if (nz[v]) {
+                // four interleaved Horner chains (even / odd powers of the two s values): v_fma_f64 latency is 32 cycles
+                const double zA2 = zA * zA, zB2 = zB * zB;
+                double eA = q[v][NIR - 2], oA = q[v][NIR - 1], eB = eA, oB = oA;
 #pragma unroll
-        for (int p = NIR - 2; p >= 0; --p)
-#pragma unroll
-            for (int v = 0; v < NA; ++v) {
-                pA[v] = fma(pA[v], zA, q[v][p]);
-                pB[v] = fma(pB[v], zB, q[v][p]);
+                for (int p = NIR - 4; p >= 0; p -= 2) {
+                    eA = fma(eA, zA2, q[v][p]);
+                    oA = fma(oA, zA2, q[v][p + 1]);
+                    eB = fma(eB, zB2, q[v][p]);
+                    oB = fma(oB, zB2, q[v][p + 1]);
+                }
+                pA[v] = fma(oA, zA, eA);
+                pB[v] = fma(oB, zB, eB);
             }
+        }
         double wA = 0.0, wB = 0.0;
 #pragma unroll
         for (int v = 0; v < NA; ++v) {

@@ -17,7 +17,7 @@
 using namespace eftb;
 
 constexpr int NW_P22 = 16;  // waves per workgroup (K slices) of the P22 pair GEMM
-constexpr int NW_C = 8;     // ... of the xi-space pair GEMM
+constexpr int NW_C = 16;    // ... of the xi-space pair GEMM
 constexpr size_t GEMM_LDS = (size_t)64 * 258 * sizeof(double);  // A tile of gemm_rows_kernel
 
 static thread_local std::string g_err;
@@ -120,7 +120,9 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_LNXTAIL: return D * c.ntail;
         case EFTB_T_KPOW: return D * c.Nk * 2 * NCH;
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
-        case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + 1) * 2 * 64;
+        case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + 1) * 1 * 64;
+        case EFTB_T_COMB22: return D * 28 * c.nbasis;
+        case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 28 * c.ncolsC : 0;
         case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + 1) * (c.ncolsC / 16) * 64 : 0;
         case EFTB_T_PLAN: return sizeof(int32_t) * 4 * NW_P22 * 15;
         case EFTB_T_PLANC: return c.with_resum ? sizeof(int32_t) * 4 * NW_C * 15 : 0;
@@ -175,7 +177,7 @@ static inline const T* tb(const eftb_engine* e, int id) { return static_cast<con
 // dynamic LDS of pair_gemm_kernel<MT, NT>: the u tile (+ slack) or the 4-way reduction buffer
 static constexpr size_t pair_lds_bytes(int MT, int NT, int NW) {
     const size_t tile = (size_t)(MT * 16 * ULDS + 16) * sizeof(double);
-    const size_t red = (size_t)NW * MT * pair_reduce_cols(MT, NT, NW) * 4 * 64 * sizeof(double);
+    const size_t red = ((size_t)NW * MT * pair_reduce_cols(MT, NT, NW) * 4 * 64 + (size_t)MT * 16 * NT * 16) * sizeof(double);
     return tile > red ? tile : red;
 }
 
@@ -197,17 +199,18 @@ static int pick_ksplit(int row_tiles) {
 
 template <int MT, int NT, int NW>
 static void launch_pair(eftb_engine* e, hipStream_t st, const double* U, const double* frag, const int* plan, int rows, int rows_per_w,
-                        int ncols_out, int ncols_ld, const double* rowscale, double* out, double* part, const LinTerms& lin) {
+                        int nbasis, const double* comb, int ncols_out, int ncols_ld, const double* rowscale, double* out, double* part,
+                        const LinTerms& lin) {
     const int tiles = (rows + MT * 16 - 1) / (MT * 16);
     const int ks = pick_ksplit(tiles);
     int level = 0;
     while ((1 << level) < ks) ++level;
     const int* pl = plan + 4 * NW * ((1 << level) - 1);  // plans for 1, 2, 4, 8 splits are stored back to back
     hipLaunchKernelGGL((pair_gemm_kernel<MT, NT, NW>), dim3(tiles, ks), dim3(64 * NW), pair_lds_bytes(MT, NT, NW), st, U, frag, pl, rows, rows_per_w,
-                       ncols_out, ncols_ld, rowscale, out, part, lin);
+                       nbasis, comb, ncols_out, ncols_ld, rowscale, out, part, lin);
     if (ks > 1)
         hipLaunchKernelGGL(pair_sum_kernel, dim3((rows_per_w + 255) / 256, ncols_out, rows / rows_per_w), dim3(256), 0, st, ks, rows, rows_per_w,
-                           ncols_out, ncols_ld, rowscale, part, out);
+                           nbasis, comb, ncols_out, ncols_ld, rowscale, part, out);
 }
 
 // out[w][a][r][x] = sum_{l,k} T[w][l][r][k] * opT[(l,k)][(a,x)] on the FP64 matrix cores; the block changes shape
@@ -255,8 +258,8 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (mask & EFTB_S_LOOPS) {
             lin.nA = 10; lin.vecA = tb<double>(e, EFTB_T_M13R); lin.scaleA = e->k3; lin.rowdata = b[EFTB_B_P11]; lin.outA = b[EFTB_B_P13];
         }
-        launch_pair<4, 2, NW_P22>(e, st, e->U, tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, 28, 28, e->k3, b[EFTB_B_P22],
-                                  e->pairpartP, lin);
+        launch_pair<4, 1, NW_P22>(e, st, e->U, tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, c.nbasis,
+                                  tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22], e->pairpartP, lin);
     }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
     if (mask & EFTB_S_CF)
@@ -267,12 +270,12 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             lin.nA = Nl; lin.vecA = tb<double>(e, EFTB_T_C11R); lin.outA = b[EFTB_B_C11];
             lin.nB = Nl; lin.vecB = tb<double>(e, EFTB_T_CCTR); lin.scaleB = e->sm2; lin.outB = b[EFTB_B_CCT];
         }
-        if (Nl == 3)
-            launch_pair<2, 6, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, Nl * 28, Nl * 38, nullptr,
-                                    b[EFTB_B_CC], e->pairpartC, lin);
+        if (c.ncolsC == 32)
+            launch_pair<4, 2, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
+                                    tb<double>(e, EFTB_T_COMBC), Nl * 28, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
         else
-            launch_pair<2, 4, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, Nl * 28, Nl * 38, nullptr,
-                                    b[EFTB_B_CC], e->pairpartC, lin);
+            launch_pair<4, 1, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
+                                    tb<double>(e, EFTB_T_COMBC), Nl * 28, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
     }
     if (mask & EFTB_S_CF) {
         // 13 term through its rank structure: V = us . Tv (FP64-MFMA GEMM), then one complex product + 10 dots per row
@@ -355,7 +358,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     const eftb_config& c = *cfg;
     if (c.Nl != 2 && c.Nl != 3) return fail("eftb_create: Nl must be 2 or 3 (got %d)", c.Nl);
     if (c.Nk < 8 || c.Nkin < 4 || c.max_batch < 1) return fail("eftb_create: bad dimensions Nk=%d Nkin=%d max_batch=%d", c.Nk, c.Nkin, c.max_batch);
-    if (c.with_resum && (c.ncolsC % 16 || c.ncolsC < c.Nl * 28)) return fail("eftb_create: bad ncolsC=%d", c.ncolsC);
+    if (c.nbasis < 1 || c.nbasis > 16) return fail("eftb_create: nbasis=%d outside [1, 16]", c.nbasis);
+    if (c.with_resum && (c.ncolsC % 16 || c.ncolsC < c.Nl * c.nbasis || c.ncolsC > 32)) return fail("eftb_create: bad ncolsC=%d", c.ncolsC);
     if (c.with_resum && !((c.Nl == 3 && c.NIR == 16 && c.Na == 3) || (c.Nl == 2 && c.NIR == 8 && c.Na == 2)))
         return fail("eftb_create: (Nl, NIR, Na) = (%d, %d, %d) unsupported", c.Nl, c.NIR, c.Na);
     int ndev = 0;
@@ -387,9 +391,9 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipMalloc(&e->k3, c.Nk * sizeof(double)));
     HIPCHK(hipMalloc(&e->sm2, NS * sizeof(double)));
     e->ldtv = (c.Nl * NPOW + 15) / 16 * 16;
-    HIPCHK(hipMalloc(&e->pairpartP, (size_t)8 * B * c.Nk * 28 * sizeof(double)));
+    HIPCHK(hipMalloc(&e->pairpartP, (size_t)8 * B * c.Nk * 16 * sizeof(double)));
     if (c.with_resum) {
-        HIPCHK(hipMalloc(&e->pairpartC, (size_t)8 * B * NS * c.Nl * 28 * sizeof(double)));
+        HIPCHK(hipMalloc(&e->pairpartC, (size_t)8 * B * NS * 32 * sizeof(double)));
         HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
         HIPCHK(hipMalloc(&e->V, B * NS * e->ldtv * sizeof(double)));
     }
@@ -436,9 +440,8 @@ int eftb_finalize(eftb_engine* e) {
         HIPCHK(hipMalloc(&e->part, (size_t)c.max_batch * e->resum_splits * 2 * c.Nl * c.Nl * 21 * c.Nk * sizeof(double)));
     }
     // opt in to the large dynamic LDS tiles of the pair GEMM
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, NW_P22>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 6, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<2, 4, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     e->finalized = true;
     return 0;

@@ -15,7 +15,7 @@ from . import _lib as L
 from .tables import EngineConfig, build_tables
 
 NROW = 24
-NW_P22, NW_C = 16, 8  # waves per workgroup (K slices) of the two pair GEMMs; must match csrc/eftbird.hip
+NW_P22, NW_C = 16, 16 # waves per workgroup (K slices) of the two pair GEMMs; must match csrc/eftbird.hip
 ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
 
 
@@ -60,6 +60,7 @@ class Engine:
         c.nmu = cfg.nbinsmu
         c.ntail = t["lnx_tail"].size
         c.nsteps = len(t["steps"])
+        c.nbasis = t["comb22"].shape[1]
         if cfg.with_resum:
             c.nxtail = t["lnx_xtail"].size
             c.ncolsC = t["pairsC"].shape[1] * 16
@@ -89,6 +90,7 @@ class Engine:
         self._set("PAIRS22", _padded_fragments(t["pairs22"]))
         self._set("PLAN", split_plans(t["steps"], NW_P22), np.int32)
         self._set("M13R", t["m13r"])
+        self._set("COMB22", t["comb22"])
         for n in ("L11", "LCT", "L22", "L13"):
             self._set(n, t[n.lower()])
         self._set("GRP", np.concatenate([t["grp22"], t["grp13"]]), np.int32)
@@ -96,6 +98,7 @@ class Engine:
             self._set("SPOW", t["spow"])
             self._set("PAIRSC", _padded_fragments(t["pairsC"]))
             self._set("PLANC", split_plans(t["steps"], NW_C), np.int32)
+            self._set("COMBC", t["combC"])
             ld = (cfg.Nl * 257 + 15) // 16 * 16
             tvt = np.zeros((257, ld))
             tvt[:, : cfg.Nl * 257] = t["Tv"].transpose(2, 0, 1).reshape(257, cfg.Nl * 257)

@@ -133,6 +133,24 @@ def reduce_quadratic(M):
     return np.ascontiguousarray(R.real), float(np.max(np.abs(R.imag)) / scale)
 
 
+def loop_basis(M22, tol=1e-11):
+    """The 28 loop matrices M22[b] span a space of dimension 7 only (they are built from a handful of F2/G2
+    angular structures): pick a well-conditioned subset by column-pivoted QR and express every M22[b] as a real
+    combination of it.  -> (basis indices [nb], comb [28, nb]);  max |comb| ~ 1, residual ~ 1e-15 (asserted)."""
+    from scipy.linalg import qr
+
+    A = M22.reshape(M22.shape[0], -1)
+    _, Rq, piv = qr(A.T, mode="economic", pivoting=True)
+    d = np.abs(np.diag(Rq))
+    rank = int(np.sum(d > tol * d[0]))
+    basis = np.sort(piv[:rank])
+    X = np.linalg.lstsq(A[basis].T, A.T, rcond=None)[0].T
+    resid = np.max(np.abs(X @ A[basis] - A)) / np.max(np.abs(A))
+    if resid > 1e-13 or np.max(np.abs(X.imag)) > 1e-12 or rank > 16:
+        raise ValueError(f"loop-matrix basis reduction failed: rank {rank}, residual {resid:.2e}")
+    return basis, np.ascontiguousarray(X.real)
+
+
 def pair_steps():
     """K-steps of the pair contraction: step t covers pairs (n, m0..m0+3), n <= m0 <= 256."""
     return np.array([(n, m0) for n in range(NPOW) for m0 in range(n, NPOW, 4)], dtype=np.int32)
@@ -277,17 +295,25 @@ def build_tables(cfg: EngineConfig) -> dict:
     Mcf11 = lm.bessel_weight(ells[:, None], nu[None, :])
     Mcfct = lm.bessel_weight(ells[:, None], nu[None, :] - 1.0)
     Ml = lm.bessel_weight(ells[:, None, None], nu[None, :, None] + nu[None, None, :] - 1.5)
-    R22, im22 = reduce_quadratic(M22)
+    basis, comb = loop_basis(M22)
+    nb = len(basis)
+    t["basis22"], t["comb22"] = basis.astype(np.int32), comb                 # M22[b] = sum_c comb[b, c] M22[basis[c]]
+    R22, im22 = reduce_quadratic(M22[basis])
     t["steps"] = pair_steps()
-    t["pairs22"] = pair_fragments(R22, 32)
+    t["pairs22"] = pair_fragments(R22, 16)
     t["m13r"] = np.ascontiguousarray(reduce_linear(M13))                 # [10,257]
     resid = [im22]
     if cfg.with_resum:
-        # columns of the configuration-space pair contraction: [l*28+b] (C22 only)
-        Rc22, imc = reduce_quadratic((Ml[:, None] * M22[None]).reshape(Nl * 28, NPOW, NPOW))
+        # columns of the configuration-space pair contraction: [l*nb + c] = Ml[l] (.) M22[basis[c]]  (C22 only);
+        # C22[l, b] = sum_c comb[b, c] * column[l*nb + c]
+        Rc22, imc = reduce_quadratic((Ml[:, None] * M22[basis][None]).reshape(Nl * nb, NPOW, NPOW))
         resid += [imc]
-        ncol = Nl * 28
+        ncol = Nl * nb
         t["pairsC"] = pair_fragments(Rc22, 16 * ((ncol + 15) // 16))
+        combC = np.zeros((Nl * 28, 16 * ((ncol + 15) // 16)))
+        for l in range(Nl):
+            combC[l * 28 : (l + 1) * 28, l * nb : (l + 1) * nb] = comb
+        t["combC"] = combC
         # C13 through its rank structure: v_l = Ml[l] x  as a real operator on u (then y = x*v, dotted with m13r)
         Tm = realify_matrix()
         W = np.einsum("lnm,ma->lna", Ml[:, :NHALF + 1, :], Tm)           # [Nl,129,257] complex

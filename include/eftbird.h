@@ -40,7 +40,8 @@ typedef struct eftb_config {
     int32_t ntail;         /* high-k power-law tail length of the loop FFTLog           fftlog.py:146-151 */
     int32_t nxtail;        /* same for the 32-point IR-filter FFTLog                    pybird.py:1293 */
     int32_t nsteps;        /* K-steps of the pair contraction (eftpipe_amd/tables.py pair_steps) */
-    int32_t ncolsC;        /* padded columns of the xi contraction (multiple of 16)     */
+    int32_t ncolsC;        /* padded basis columns of the xi contraction (16 or 32)     */
+    int32_t nbasis;        /* dimension of the span of the 28 loop matrices (7)         tables.py loop_basis */
     int32_t NIR, Na, Nklow;/* Resum.NIR, Resum.Na, Common.Nklow                         pybird.py:1247-1259, 560 */
 } eftb_config;
 
@@ -51,7 +52,7 @@ enum eftb_table {
     EFTB_T_CCTR, EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
     EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
     EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
-    EFTB_T_PLANC, EFTB_T_TVT, EFTB_T_COUNT
+    EFTB_T_PLANC, EFTB_T_TVT, EFTB_T_COMB22, EFTB_T_COMBC, EFTB_T_COUNT
 };
 
 /* Device-resident state (per engine, [max_batch] leading axis unless noted). */

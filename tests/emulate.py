@@ -48,13 +48,14 @@ def pscf(t, Pin, with_cf):
     c = coef_half(t, Pin)
     U = reduced_vectors(c, t["kpow"])
     out = dict(P11=P11)
-    out["P22"] = (k[:, None] ** 3 * pair_contract(U, t["pairs22"], t["steps"])[:, :28]).T
+    nb = t["comb22"].shape[1]
+    out["P22"] = t["comb22"] @ (k[:, None] ** 3 * pair_contract(U, t["pairs22"], t["steps"])[:, :nb]).T
     out["P13"] = (k**3 * P11)[None, :] * (t["m13r"] @ U.T)
     if with_cf:
         Nl = t["l11"].shape[0]
         Us = reduced_vectors(c, t["spow"])
         cc = pair_contract(Us, t["pairsC"], t["steps"])  # [80, cols]
-        out["C22"] = cc[:, : Nl * 28].T.reshape(Nl, 28, -1)
+        out["C22"] = (t["combC"] @ cc.T).reshape(Nl, 28, -1)
         V = np.einsum("loi,si->slo", t["Tv"], Us)  # [80,Nl,257]
         a, b, c, d = Us[:, None, :NH], Us[:, None, NH + 1 :], V[:, :, :NH], V[:, :, NH + 1 :]
         y = np.concatenate([a * c - b * d, Us[:, None, NH : NH + 1] * V[:, :, NH : NH + 1], a * d + b * c], axis=-1)
