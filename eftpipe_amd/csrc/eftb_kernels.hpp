@@ -17,6 +17,7 @@ constexpr int NPOW = 257;    // FFTLog powers (NFFT + 1)         reference pybir
 constexpr int NHALF = 128;
 constexpr int NCH = 129;     // independent complex coefficients
 constexpr int UPAD = 260;    // HBM row stride of u (doubles), 16-byte aligned rows
+constexpr int PAIR_KU = 2;  // K-steps per inner-loop iteration of the pair GEMM (tables.py KU)
 constexpr int ULDS = 258;    // LDS row stride of u: 258 = 2 (mod 32) -> conflict-free ds_read_b64
 constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl) + 12 (Ploopl) + 3 (Pstl)
 
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
         if (row0 + r < rows_total) v = *reinterpret_cast<const double2*>(U + (size_t)(row0 + r) * UPAD + 2 * c);
         if (c < 129) *reinterpret_cast<double2*>(sm + r * ULDS + 2 * c) = v;
     }
-    if (tid < 16) sm[ROWS * ULDS + tid] = 0.0;  // slack read by the zero-weight pad pairs of the last row
+    if (tid < 32) sm[ROWS * ULDS + tid] = 0.0;  // slack read by the zero-weight pad pairs of the last row
     __syncthreads();
 
     // ---- linear terms straight from the LDS tile: thread <-> (row, vector), 257 FMAs each (< 0.5 % of the workgroup)
@@ -174,43 +175,62 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    double bcur[NT];
+    // B fragments of one iteration (PAIR_KU consecutive K-steps), prefetched one iteration ahead
+    double bcur[PAIR_KU][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) bcur[j] = fp[j * 64];
-    fp += NT * 64;
+    for (int u = 0; u < PAIR_KU; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bcur[u][j] = fp[(u * NT + j) * 64];
+    fp += PAIR_KU * NT * 64;
 
     const double* urow = sm + r * ULDS;
     while (nsteps > 0) {
-        // one n-run: pairs (n, m0) ... (n, 256) in steps of 4; the inner loop is branch-free and software
-        // pipelined: B fragments (global) and u_m values (LDS) of step t+1 are in flight under step t's MFMAs
-        const int left = ((2 * NHALF - m0) >> 2) + 1;
-        const int cnt = left < nsteps ? left : nsteps;
-        double un[MT], um[MT];
+        // one n-run: pairs (n, m0) ... in steps of 4, padded with zero-weight steps to a multiple of PAIR_KU; the
+        // inner loop is branch-free and software pipelined: the B fragments (global) and u_m values (LDS) of
+        // iteration t+1 are in flight under iteration t's PAIR_KU * MT * NT MFMAs
+        const int run = (((2 * NHALF - n) >> 2) + PAIR_KU) / PAIR_KU * PAIR_KU;
+        const int left = run - ((m0 - n) >> 2);
+        const int cnt = (left < nsteps ? left : nsteps) / PAIR_KU;
+        double un[MT], um[PAIR_KU][MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) un[i] = urow[i * 16 * ULDS + n];
         const double* up = urow + m0 + g;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) um[i] = up[i * 16 * ULDS];
+        for (int u = 0; u < PAIR_KU; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) um[u][i] = up[i * 16 * ULDS + 4 * u];
         for (int it = 0; it < cnt; ++it) {
-            double bnxt[NT], umn[MT], a[MT];
+            double bnxt[PAIR_KU][NT], umn[PAIR_KU][MT], a[PAIR_KU][MT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bnxt[j] = fp[j * 64];  // table carries one zero step of padding at the end
-            fp += NT * 64;
-            up += 4;
+            for (int u = 0; u < PAIR_KU; ++u)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) umn[i] = up[i * 16 * ULDS];  // at most 8 doubles past the run: inside the slack
+                for (int j = 0; j < NT; ++j) bnxt[u][j] = fp[(u * NT + j) * 64];  // the table ends with one zero iteration
+            fp += PAIR_KU * NT * 64;
+            up += 4 * PAIR_KU;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = un[i] * um[i];
+            for (int u = 0; u < PAIR_KU; ++u)
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i) umn[u][i] = up[i * 16 * ULDS + 4 * u];  // <= 16 doubles past the run: inside the slack
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bcur[j], acc[i][j], 0, 0, 0);
+            for (int u = 0; u < PAIR_KU; ++u)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bcur[j] = bnxt[j];
+                for (int i = 0; i < MT; ++i) a[u][i] = un[i] * um[u][i];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) um[i] = umn[i];
+            for (int u = 0; u < PAIR_KU; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], bcur[u][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < PAIR_KU; ++u) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bcur[u][j] = bnxt[u][j];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) um[u][i] = umn[u][i];
+            }
         }
-        nsteps -= cnt;
+        nsteps -= cnt * PAIR_KU;
         ++n;
         m0 = n;
     }

@@ -120,10 +120,10 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_LNXTAIL: return D * c.ntail;
         case EFTB_T_KPOW: return D * c.Nk * 2 * NCH;
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
-        case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + 1) * 1 * 64;
+        case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + PAIR_KU) * 1 * 64;
         case EFTB_T_COMB22: return D * 28 * c.nbasis;
         case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 28 * c.ncolsC : 0;
-        case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + 1) * (c.ncolsC / 16) * 64 : 0;
+        case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + PAIR_KU) * (c.ncolsC / 16) * 64 : 0;
         case EFTB_T_PLAN: return sizeof(int32_t) * 4 * NW_P22 * 15;
         case EFTB_T_PLANC: return c.with_resum ? sizeof(int32_t) * 4 * NW_C * 15 : 0;
         case EFTB_T_TVT: return c.with_resum ? D * (size_t)NPOW * ((c.Nl * NPOW + 15) / 16 * 16) : 0;
@@ -176,7 +176,7 @@ static inline const T* tb(const eftb_engine* e, int id) { return static_cast<con
 
 // dynamic LDS of pair_gemm_kernel<MT, NT>: the u tile (+ slack) or the 4-way reduction buffer
 static constexpr size_t pair_lds_bytes(int MT, int NT, int NW) {
-    const size_t tile = (size_t)(MT * 16 * ULDS + 16) * sizeof(double);
+    const size_t tile = (size_t)(MT * 16 * ULDS + 32) * sizeof(double);
     const size_t red = ((size_t)NW * MT * pair_reduce_cols(MT, NT, NW) * 4 * 64 + (size_t)MT * 16 * NT * 16) * sizeof(double);
     return tile > red ? tile : red;
 }

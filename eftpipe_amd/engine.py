@@ -21,10 +21,12 @@ ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(
 
 def wave_plan(steps, nwaves=8):
     """Split the K-steps of the pair contraction evenly over `nwaves` K slices: (n, m0, first step, count) each."""
-    T = len(steps)
+    from .tables import KU
+
+    T = len(steps) // KU  # slices start and end on KU-step boundaries (every n-run is a multiple of KU steps)
     plan = np.zeros((nwaves, 4), dtype=np.int32)
     for q in range(nwaves):
-        t0, t1 = (q * T) // nwaves, ((q + 1) * T) // nwaves
+        t0, t1 = KU * ((q * T) // nwaves), KU * (((q + 1) * T) // nwaves)
         plan[q] = (steps[t0, 0], steps[t0, 1], t0, t1 - t0)
     return plan
 
@@ -36,9 +38,11 @@ def split_plans(steps, nwaves):
 
 
 def _padded_fragments(frag):
-    """[T, J, 4, 16] -> [(T + 1), J, 64] with one zero step (the kernel prefetches one step ahead)."""
+    """[T, J, 4, 16] -> [(T + KU), J, 64] with one zero iteration (the kernel prefetches one iteration ahead)."""
+    from .tables import KU
+
     T, J = frag.shape[:2]
-    out = np.zeros((T + 1, J, 64))
+    out = np.zeros((T + KU, J, 64))
     out[:T] = frag.reshape(T, J, 64)
     return out
 

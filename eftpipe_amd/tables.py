@@ -151,9 +151,18 @@ def loop_basis(M22, tol=1e-11):
     return basis, np.ascontiguousarray(X.real)
 
 
+KU = 2  # K-steps per inner-loop iteration of the pair GEMM (must match csrc/eftb_kernels.hpp PAIR_KU)
+
+
 def pair_steps():
-    """K-steps of the pair contraction: step t covers pairs (n, m0..m0+3), n <= m0 <= 256."""
-    return np.array([(n, m0) for n in range(NPOW) for m0 in range(n, NPOW, 4)], dtype=np.int32)
+    """K-steps of the pair contraction: step t covers pairs (n, m0..m0+3), n <= m0; every n-run is padded with
+    zero-weight steps to a multiple of KU steps so that the kernel's inner loop can take KU steps per iteration."""
+    out = []
+    for n in range(NPOW):
+        cnt = (NPOW - n + 3) // 4
+        cnt = (cnt + KU - 1) // KU * KU
+        out += [(n, n + 4 * j) for j in range(cnt)]
+    return np.array(out, dtype=np.int32)
 
 
 def pair_fragments(R, ncols_pad):
@@ -172,7 +181,7 @@ def pair_fragments(R, ncols_pad):
     for g in range(4):
         m = st[:, 1] + g
         ok = m < NPOW
-        frag[ok, :ncols, g] = Rs[:, st[ok, 0], m[ok]].T
+        frag[ok, :ncols, g] = Rs[:, st[ok, 0], m[ok]].T   # padded steps (m0 > 256) keep zero weights
     return np.ascontiguousarray(frag.reshape(len(st), ncols_pad // 16, 16, 4).transpose(0, 1, 3, 2))
 
 

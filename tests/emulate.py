@@ -33,7 +33,7 @@ def reduced_vectors(c, pw):
 
 def pair_contract(u, frag, steps):
     """u [rows,257], frag [T,J,4,16] -> [rows, 16J]"""
-    up = np.concatenate([u, np.zeros((u.shape[0], 4))], axis=1)
+    up = np.concatenate([u, np.zeros((u.shape[0], 16))], axis=1)
     un = u[:, steps[:, 0]]  # [rows,T]
     out = np.zeros((u.shape[0], frag.shape[1] * 16))
     for g in range(4):

@@ -46,8 +46,10 @@ def test_wave_plan_covers_all_steps():
     from eftpipe_amd.engine import wave_plan
     from eftpipe_amd.tables import pair_steps
 
+    from eftpipe_amd.tables import KU
+
     st = pair_steps()
-    assert len(st) == sum((257 - n + 3) // 4 for n in range(257))
+    assert len(st) == sum(((257 - n + 3) // 4 + KU - 1) // KU * KU for n in range(257))
     plan = wave_plan(st)
     assert plan[:, 3].sum() == len(st) and plan[0, 2] == 0
     for q in range(len(plan)):
