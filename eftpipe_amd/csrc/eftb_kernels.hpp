@@ -309,8 +309,6 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(int nsplit, int rows_tota
 
 // ------------------------------------------------------------------------------------------------
 // General FP64-MFMA GEMM for the smaller dense stages:  C[row][col] = sum_seg sum_k A_seg[row][k] B_seg[k][col].
-//   * xi-space 13 term: V = us . Tv  (rows = (cosmology, s), K = 257, N = Nl*257; reference pybird.py:1115-1125
-//     evaluated through its rank structure  C13 = Re sum_n x_n M13[b,n] (Ml[l] x)_n)
 //   * post-AP projection: out[(w,r)][(a,x)] = sum_{l,k} T[w][l][r][k] ProjT[(l,k)][(a,x)]  (window / binning / chained)
 // Workgroup = 4 waves = 64 rows x 256 columns; wave q owns column tiles 4q..4q+3 (16 accumulator tiles); the A
 // tile (64 rows x <= 256 k) is staged in LDS per K chunk (stride KC+2 -> conflict-free ds_read_b64), B is read
@@ -386,37 +384,6 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmDesc d) {
                     d.C[(long long)(grow / d.rows_per_group) * d.c_group + (long long)(grow % d.rows_per_group) * d.c_row +
                         (long long)(col / d.cols_per_group) * d.c_colgroup + (col % d.cols_per_group)] = acc[i][j][q];
             }
-}
-
-// C13[w][l][b][s] = y_red(l) . m13r[b],  y = x * v_l (complex, per n),  x from us, v_l from V (reference pybird.py:1115-1125)
-__global__ __launch_bounds__(256) void c13_kernel(int Nl, int ldv, const double* __restrict__ Us, const double* __restrict__ V,
-                                                  const double* __restrict__ m13r, double* __restrict__ CC) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = blockIdx.x * 4 + wave, w = blockIdx.y;
-    if (s >= NS) return;
-    const size_t row = (size_t)w * NS + s;
-    const double* u = Us + row * UPAD;
-    for (int l = 0; l < Nl; ++l) {
-        const double* v = V + row * ldv + (size_t)l * NPOW;
-        double acc[10];
-#pragma unroll
-        for (int b = 0; b < 10; ++b) acc[b] = 0.0;
-        for (int n = lane; n < NPOW; n += 64) {
-            double y;
-            if (n < NHALF) y = u[n] * v[n] - u[NCH + n] * v[NCH + n];
-            else if (n == NHALF) y = u[NHALF] * v[NHALF];
-            else y = u[n - NCH] * v[n] + u[n] * v[n - NCH];
-#pragma unroll
-            for (int b = 0; b < 10; ++b) acc[b] = fma(m13r[b * NPOW + n], y, acc[b]);
-        }
-#pragma unroll
-        for (int b = 0; b < 10; ++b)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc[b] += __shfl_down(acc[b], o, 64);
-        if (lane == 0)
-#pragma unroll
-            for (int b = 0; b < 10; ++b) CC[((size_t)w * Nl * 38 + Nl * 28 + l * 10 + b) * NS + s] = acc[b];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,11 +122,10 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
         case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + PAIR_KU) * 1 * 64;
         case EFTB_T_COMB22: return D * 28 * c.nbasis;
-        case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 28 * c.ncolsC : 0;
+        case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 38 * c.ncolsC : 0;
         case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + PAIR_KU) * (c.ncolsC / 16) * 64 : 0;
         case EFTB_T_PLAN: return sizeof(int32_t) * 4 * NW_P22 * 15;
         case EFTB_T_PLANC: return c.with_resum ? sizeof(int32_t) * 4 * NW_C * 15 : 0;
-        case EFTB_T_TVT: return c.with_resum ? D * (size_t)NPOW * ((c.Nl * NPOW + 15) / 16 * 16) : 0;
         case EFTB_T_M13R: return D * 10 * NPOW;
         case EFTB_T_C11R: return c.with_resum ? D * c.Nl * NPOW : 0;
         case EFTB_T_CCTR: return c.with_resum ? D * c.Nl * NPOW : 0;
@@ -272,19 +271,10 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         }
         if (c.ncolsC == 32)
             launch_pair<4, 2, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
-                                    tb<double>(e, EFTB_T_COMBC), Nl * 28, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
+                                    tb<double>(e, EFTB_T_COMBC), Nl * 38, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
         else
             launch_pair<4, 1, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
-                                    tb<double>(e, EFTB_T_COMBC), Nl * 28, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
-    }
-    if (mask & EFTB_S_CF) {
-        // 13 term through its rank structure: V = us . Tv (FP64-MFMA GEMM), then one complex product + 10 dots per row
-        GemmDesc g{};
-        g.A = e->Us; g.a_group = 0; g.a_row = UPAD; g.a_seg = 0; g.rows = B * NS; g.rows_per_group = B * NS; g.nseg = 1; g.kseg = NPOW;
-        g.B = tb<double>(e, EFTB_T_TVT); g.ldb = e->ldtv; g.ncols = Nl * NPOW;
-        g.C = e->V; g.c_group = 0; g.c_row = e->ldtv; g.c_colgroup = 0; g.cols_per_group = Nl * NPOW;
-        hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, stc, g);
-        hipLaunchKernelGGL(c13_kernel, dim3((NS + 3) / 4, B), dim3(256), 0, stc, Nl, e->ldtv, e->Us, e->V, tb<double>(e, EFTB_T_M13R), b[EFTB_B_CC]);
+                                    tb<double>(e, EFTB_T_COMBC), Nl * 38, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
     }
     if (fork) {
         if (hipEventRecord(e->evJoin, stc) != hipSuccess || hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess)
@@ -395,7 +385,6 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (c.with_resum) {
         HIPCHK(hipMalloc(&e->pairpartC, (size_t)8 * B * NS * 32 * sizeof(double)));
         HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
-        HIPCHK(hipMalloc(&e->V, B * NS * e->ldtv * sizeof(double)));
     }
     HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
     if (c.with_ap) HIPCHK(hipMalloc(&e->SD, 4 * e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // power-form cubics

@@ -103,10 +103,6 @@ class Engine:
             self._set("PAIRSC", _padded_fragments(t["pairsC"]))
             self._set("PLANC", split_plans(t["steps"], NW_C), np.int32)
             self._set("COMBC", t["combC"])
-            ld = (cfg.Nl * 257 + 15) // 16 * 16
-            tvt = np.zeros((257, ld))
-            tvt[:, : cfg.Nl * 257] = t["Tv"].transpose(2, 0, 1).reshape(257, cfg.Nl * 257)
-            self._set("TVT", tvt)
             self._set("C11R", t["c11r"])
             self._set("CCTR", t["cctr"])
             self._set("BXT", t["BX"].T)

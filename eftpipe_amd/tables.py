@@ -313,20 +313,23 @@ def build_tables(cfg: EngineConfig) -> dict:
     t["m13r"] = np.ascontiguousarray(reduce_linear(M13))                 # [10,257]
     resid = [im22]
     if cfg.with_resum:
-        # columns of the configuration-space pair contraction: [l*nb + c] = Ml[l] (.) M22[basis[c]]  (C22 only);
-        # C22[l, b] = sum_c comb[b, c] * column[l*nb + c]
+        # columns of the configuration-space pair contraction:
+        #   [l*nb + c]            = Ml[l] (.) M22[basis[c]]                      ->  C22[l, b] = sum_c comb[b, c] col
+        #   [Nl*nb + l*nb13 + c]  = Ml[l] (.) M13[basis13[c]] (row-broadcast)    ->  C13[l, b] = sum_c comb13[b, c] col
+        # (the 10 M13 vectors span 2 dimensions; their 2*Nl columns fit the padding of the second MFMA column tile)
+        basis13, comb13 = loop_basis(M13)
+        nb13 = len(basis13)
         Rc22, imc = reduce_quadratic((Ml[:, None] * M22[basis][None]).reshape(Nl * nb, NPOW, NPOW))
-        resid += [imc]
-        ncol = Nl * nb
-        t["pairsC"] = pair_fragments(Rc22, 16 * ((ncol + 15) // 16))
-        combC = np.zeros((Nl * 28, 16 * ((ncol + 15) // 16)))
+        Rc13, imd = reduce_quadratic((Ml[:, None] * M13[basis13][None, :, :, None]).reshape(Nl * nb13, NPOW, NPOW))
+        resid += [imc, imd]
+        ncol = Nl * (nb + nb13)
+        ncp = 16 * ((ncol + 15) // 16)
+        t["pairsC"] = pair_fragments(np.concatenate([Rc22, Rc13]), ncp)
+        combC = np.zeros((Nl * 38, ncp))
         for l in range(Nl):
             combC[l * 28 : (l + 1) * 28, l * nb : (l + 1) * nb] = comb
+            combC[Nl * 28 + l * 10 : Nl * 28 + (l + 1) * 10, Nl * nb + l * nb13 : Nl * nb + (l + 1) * nb13] = comb13
         t["combC"] = combC
-        # C13 through its rank structure: v_l = Ml[l] x  as a real operator on u (then y = x*v, dotted with m13r)
-        Tm = realify_matrix()
-        W = np.einsum("lnm,ma->lna", Ml[:, :NHALF + 1, :], Tm)           # [Nl,129,257] complex
-        t["Tv"] = np.ascontiguousarray(np.concatenate([W.real, W.imag[:, :NHALF, :]], axis=1))  # [Nl,257(out),257(in)]
         t["c11r"] = np.ascontiguousarray(reduce_linear(Mcf11))           # [Nl,257]
         t["cctr"] = np.ascontiguousarray(reduce_linear(Mcfct))           # [Nl,257]
     t["reduction_residue"] = np.array(resid)

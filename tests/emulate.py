@@ -55,11 +55,9 @@ def pscf(t, Pin, with_cf):
         Nl = t["l11"].shape[0]
         Us = reduced_vectors(c, t["spow"])
         cc = pair_contract(Us, t["pairsC"], t["steps"])  # [80, cols]
-        out["C22"] = (t["combC"] @ cc.T).reshape(Nl, 28, -1)
-        V = np.einsum("loi,si->slo", t["Tv"], Us)  # [80,Nl,257]
-        a, b, c, d = Us[:, None, :NH], Us[:, None, NH + 1 :], V[:, :, :NH], V[:, :, NH + 1 :]
-        y = np.concatenate([a * c - b * d, Us[:, None, NH : NH + 1] * V[:, :, NH : NH + 1], a * d + b * c], axis=-1)
-        out["C13"] = np.einsum("bn,sln->lbs", t["m13r"], y)
+        full = t["combC"] @ cc.T  # [Nl*38, 80]
+        out["C22"] = full[: Nl * 28].reshape(Nl, 28, -1)
+        out["C13"] = full[Nl * 28 :].reshape(Nl, 10, -1)
         out["C11"] = t["c11r"] @ Us.T
         out["Cct"] = s[None, :] ** -2 * (t["cctr"] @ Us.T)
     return out
