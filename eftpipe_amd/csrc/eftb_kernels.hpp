@@ -289,22 +289,35 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 
 // sum of the K-split basis partials of pair_gemm_kernel, then the expansion to the outputs:
 //   out[w][col][r] = scale[r] * sum_c comb[col][c] * sum_s part[s][row][c]
+// One workgroup = 8 rows: 256 threads first reduce the (row, basis) partials (coalesced along the basis index) into
+// LDS, then share the 8 * ncols_out outputs.
 __global__ __launch_bounds__(256) void pair_sum_kernel(int nsplit, int rows_total, int rows_per_w, int nbasis, const double* __restrict__ comb,
                                                        int ncols_out, int ncols_ld, const double* __restrict__ rowscale,
                                                        const double* __restrict__ part, double* __restrict__ out) {
-    const int rw = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y, w = blockIdx.z;
-    if (rw >= rows_per_w) return;
-    const size_t grow = (size_t)w * rows_per_w + rw;
-    double v = 0.0;
-    for (int c = 0; c < nbasis; ++c) {
-        const double cc = comb ? comb[col * nbasis + c] : (c == col ? 1.0 : 0.0);
-        if (cc == 0.0) continue;
+    __shared__ double bas[8][32];
+    const int row0 = blockIdx.x * 8;
+    {
+        const int rr = threadIdx.x >> 5, c = threadIdx.x & 31, grow = row0 + rr;
         double b = 0.0;
-        for (int s = 0; s < nsplit; ++s) b += part[((size_t)s * rows_total + grow) * nbasis + c];
-        v = fma(cc, b, v);
+        if (c < nbasis && grow < rows_total)
+            for (int s = 0; s < nsplit; ++s) b += part[((size_t)s * rows_total + grow) * nbasis + c];
+        bas[rr][c] = b;
     }
-    if (rowscale) v *= rowscale[rw];
-    out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 8 * ncols_out; e += 256) {
+        const int rr = e & 7, col = e >> 3, grow = row0 + rr;
+        if (grow >= rows_total) continue;
+        double v;
+        if (comb) {
+            v = 0.0;
+            for (int c = 0; c < nbasis; ++c) v = fma(comb[col * nbasis + c], bas[rr][c], v);
+        } else {
+            v = bas[rr][col];
+        }
+        const int w = grow / rows_per_w, rw = grow % rows_per_w;
+        if (rowscale) v *= rowscale[rw];
+        out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -55,6 +56,7 @@ struct eftb_engine {
     struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; };
     std::vector<Op> ops;
     int pipeline_op = -1;
+    bool use_fork = false;  // run the k-space and xi-space contractions on two streams (EFTB_FORK=1); off: one stream
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
     int Nn = 0;
@@ -208,8 +210,8 @@ static void launch_pair(eftb_engine* e, hipStream_t st, const double* U, const d
     hipLaunchKernelGGL((pair_gemm_kernel<MT, NT, NW>), dim3(tiles, ks), dim3(64 * NW), pair_lds_bytes(MT, NT, NW), st, U, frag, pl, rows, rows_per_w,
                        nbasis, comb, ncols_out, ncols_ld, rowscale, out, part, lin);
     if (ks > 1)
-        hipLaunchKernelGGL(pair_sum_kernel, dim3((rows_per_w + 255) / 256, ncols_out, rows / rows_per_w), dim3(256), 0, st, ks, rows, rows_per_w,
-                           nbasis, comb, ncols_out, ncols_ld, rowscale, part, out);
+        hipLaunchKernelGGL(pair_sum_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, ks, rows, rows_per_w, nbasis, comb, ncols_out, ncols_ld,
+                           rowscale, part, out);
 }
 
 // out[w][a][r][x] = sum_{l,k} T[w][l][r][k] * opT[(l,k)][(a,x)] on the FP64 matrix cores; the block changes shape
@@ -238,7 +240,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     double** b = e->buf;
     // the k-space (LOOPS) and xi-space (CF) contractions are independent: when both are requested the CF
     // kernels go to a second stream so their workgroups back-fill the CUs the P22 grid leaves idle
-    const bool fork = (mask & EFTB_S_LOOPS) && (mask & EFTB_S_CF);
+    const bool fork = e->use_fork && (mask & EFTB_S_LOOPS) && (mask & EFTB_S_CF);
     hipStream_t stc = fork ? e->stream2 : st;
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
@@ -362,6 +364,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->Nn = 2 * c.NIR * c.Na;
     e->cur_nl = c.Nl;
     e->cur_nx = c.Nk;
+    if (const char* f = getenv("EFTB_FORK")) e->use_fork = (f[0] == '1');
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&e->ev0));
