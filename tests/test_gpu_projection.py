@@ -149,3 +149,33 @@ def test_cfg3_shape_nk512_window_chained_cross(golden):
         assert relerr(getattr(ch, n), g["chained_" + n]) < TOL, n
     plk = reduce_Plk(ch, list(g["bsA"]), list(g["bsB"]), tuple(g["es"])).sum()
     assert plk.shape == (2, 512) and relerr(plk, g["plk_chained_cross"]) < TOL
+
+
+def test_cfg5_shape_nk2048_window_binning(golden):
+    """BASELINE cfg 5 shape: Nk=2048, IR-resum + AP + window + binning folded into one device operator.
+    Templates before the projection are pinned by the reference (caseF); the projection itself is checked
+    against a NumPy application of the same host-built operator (the reference's window at Nk=2048 is too
+    heavy to run in the build container)."""
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseF")
+    k = g["k"]
+    tab = np.load(WIN)
+    Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+    Wfold, _ = TB.window_fold(k, Wal, p)
+    kout = np.arange(0.025, 0.2, 0.01)
+    Bm, keff, _, _ = TB.binning_operator(k, kout)
+    op = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm)
+    eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=2)
+    templ = eng.eval_batch(np.stack([g["Pin"], g["Pin"]]), float(g["f"]), float(g["DA"]), float(g["H"]))
+    for n, sl in dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24)).items():
+        assert relerr(templ[0][:, sl], g["ap_" + n]) < TOL, n
+    oid = eng.add_operator(op)
+    eng.set_pipeline_operator(oid)
+    proj = eng.eval_batch(np.stack([g["Pin"], g["Pin"]]), float(g["f"]), float(g["DA"]), float(g["H"]))
+    assert proj.shape == (2, 3, 24, len(kout))
+    want = np.einsum("alxk,lrk->arx", op, templ[0])
+    assert relerr(proj[0], want) < 1e-10 and np.array_equal(proj[0], proj[1])
+    eng.close()
