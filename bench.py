@@ -147,7 +147,7 @@ def main():
                                                         ("regroup", L.S_REGROUP), ("resum", L.S_RESUM), ("ap", L.S_AP), ("reduce", L.S_REDUCE))}
         # AP ping-pongs the template block; leave the state consistent
         alg_flops = 8.0 * 28 * NK * NPOW**2 * B          # F_P22 per evaluation x B
-        exe_flops = 2.0 * 16 * 4 * eng.tables["steps"].shape[0] * NK * B   # MFMA flops actually issued (real-reduced pairs, 7-matrix basis in one 16-column tile)
+        exe_flops = 2.0 * 8 * 4 * eng.tables["steps"].shape[0] * NK * B   # MFMA flops actually issued: v_mfma_f64_4x4x4 blocks, 8 columns (7 basis matrices), real-reduced pairs
         achieved = alg_flops / (ms_p22 * 1e-3) / 1e12
         try:
             measured_peak = mfma_f64_peak(cp.local_rank)
@@ -159,7 +159,7 @@ def main():
             with open(pmc) as fh:
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         roofline = {
-            "bound": "mfma", "kernel": "pair_gemm_kernel<4,1,16> (makeP22)", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "bound": "mfma", "kernel": "pair_gemm4_kernel<16> (makeP22, v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "ms_per_launch": ms_p22, "algorithmic_flops_per_launch": alg_flops,
             "executed_mfma_flops_per_launch": exe_flops, "executed_tflops": exe_flops / (ms_p22 * 1e-3) / 1e12,

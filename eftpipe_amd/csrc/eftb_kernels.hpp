@@ -287,6 +287,153 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pair GEMM for <= 8 basis columns on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction,
+// issued every ~16 cycles).  With only 7 useful columns the 16x16x4 form wastes 9 of its 16 columns; here the four
+// blocks are (rows 0-3 | 4-7) x (columns 0-3 | 4-7) of an 8-row group, so 7 of 8 columns are useful and the same
+// pairs cost half the matrix-pipe time.  Measured lane maps (tools/probe/mfma4_probe.hip):
+//   A[blk][i][k] at lane 16 k + 4 blk + i,  B[blk][k][j] at lane 16 k + 4 blk + j,  D[blk][i][j] at lane 16 i + 4 blk + j.
+// Workgroup = NW waves = 64 rows (8 row groups per wave), K split NW ways; same n-run walk, LDS u tile, plans, linear
+// terms, workgroup-level K split and epilogue expansion as pair_gemm_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const double* __restrict__ U, const double* __restrict__ frag,
+                                                                     const int* __restrict__ plan, int rows_total, int rows_per_w,
+                                                                     int nbasis, const double* __restrict__ comb, int ncols_out, int ncols_ld,
+                                                                     const double* __restrict__ rowscale, double* __restrict__ out,
+                                                                     double* __restrict__ part, LinTerms lin) {
+    constexpr int ROWS = 64, RG = 8;  // 8 row groups of 8 rows
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS;
+    for (int idx = tid; idx < ROWS * 130; idx += 64 * NW) {
+        const int r = idx / 130, c = idx % 130;
+        double2 v = make_double2(0.0, 0.0);
+        if (row0 + r < rows_total) v = *reinterpret_cast<const double2*>(U + (size_t)(row0 + r) * UPAD + 2 * c);
+        if (c < 129) *reinterpret_cast<double2*>(sm + r * ULDS + 2 * c) = v;
+    }
+    if (tid < 32) sm[ROWS * ULDS + tid] = 0.0;
+    __syncthreads();
+
+    if (blockIdx.y == 0 && lin.nA + lin.nB > 0) {
+        for (int e = tid; e < ROWS * (lin.nA + lin.nB); e += 64 * NW) {
+            const int rr = e % ROWS, v = e / ROWS, grow = row0 + rr;
+            if (grow >= rows_total) continue;
+            const bool famA = v < lin.nA;
+            const double* vec = famA ? lin.vecA + (size_t)v * NPOW : lin.vecB + (size_t)(v - lin.nA) * NPOW;
+            const double* ur = sm + rr * ULDS;
+            double a0 = 0.0, a1 = 0.0;
+            for (int nn = 0; nn < NPOW - 1; nn += 2) {
+                a0 = fma(vec[nn], ur[nn], a0);
+                a1 = fma(vec[nn + 1], ur[nn + 1], a1);
+            }
+            double d = (a0 + a1) + vec[NPOW - 1] * ur[NPOW - 1];
+            const int w = grow / rows_per_w, rw = grow % rows_per_w;
+            if (famA) {
+                if (lin.scaleA) d *= lin.scaleA[rw];
+                if (lin.rowdata) d *= lin.rowdata[grow];
+                lin.outA[((size_t)w * lin.nA + v) * rows_per_w + rw] = d;
+            } else {
+                if (lin.scaleB) d *= lin.scaleB[rw];
+                lin.outB[((size_t)w * lin.nB + (v - lin.nA)) * rows_per_w + rw] = d;
+            }
+        }
+    }
+
+    const int kq = lane >> 4, blk = (lane >> 2) & 3, rowl = 4 * (blk >> 1) + (lane & 3);
+    const int* pl = plan + (blockIdx.y * NW + wave) * 4;
+    int n = __builtin_amdgcn_readfirstlane(pl[0]);
+    int m0 = __builtin_amdgcn_readfirstlane(pl[1]);
+    const int t0 = __builtin_amdgcn_readfirstlane(pl[2]);
+    int nsteps = __builtin_amdgcn_readfirstlane(pl[3]);
+    const double* fp = frag + (size_t)t0 * 64 + lane;
+
+    double acc[RG];
+#pragma unroll
+    for (int t = 0; t < RG; ++t) acc[t] = 0.0;
+    double bcur[PAIR_KU];
+#pragma unroll
+    for (int u = 0; u < PAIR_KU; ++u) bcur[u] = fp[u * 64];
+    fp += PAIR_KU * 64;
+
+    const double* urow = sm + rowl * ULDS;  // row group t adds 8 t rows
+    while (nsteps > 0) {
+        const int run = (((2 * NHALF - n) >> 2) + PAIR_KU) / PAIR_KU * PAIR_KU;
+        const int left = run - ((m0 - n) >> 2);
+        const int cnt = (left < nsteps ? left : nsteps) / PAIR_KU;
+        double un[RG], um[PAIR_KU][RG];
+#pragma unroll
+        for (int t = 0; t < RG; ++t) un[t] = urow[t * 8 * ULDS + n];
+        const double* up = urow + m0 + kq;
+#pragma unroll
+        for (int u = 0; u < PAIR_KU; ++u)
+#pragma unroll
+            for (int t = 0; t < RG; ++t) um[u][t] = up[t * 8 * ULDS + 4 * u];
+        for (int it = 0; it < cnt; ++it) {
+            double bnxt[PAIR_KU], umn[PAIR_KU][RG];
+#pragma unroll
+            for (int u = 0; u < PAIR_KU; ++u) bnxt[u] = fp[u * 64];
+            fp += PAIR_KU * 64;
+            up += 4 * PAIR_KU;
+#pragma unroll
+            for (int u = 0; u < PAIR_KU; ++u)
+#pragma unroll
+                for (int t = 0; t < RG; ++t) umn[u][t] = up[t * 8 * ULDS + 4 * u];
+#pragma unroll
+            for (int u = 0; u < PAIR_KU; ++u)
+#pragma unroll
+                for (int t = 0; t < RG; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(un[t] * um[u][t], bcur[u], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < PAIR_KU; ++u) {
+                bcur[u] = bnxt[u];
+#pragma unroll
+                for (int t = 0; t < RG; ++t) um[u][t] = umn[u][t];
+            }
+        }
+        nsteps -= cnt * PAIR_KU;
+        ++n;
+        m0 = n;
+    }
+
+    // ---- reduce the NW K slices: red[wave][t][lane] -> bas[row][col] (8 columns), then expand / hand over
+    __syncthreads();
+    double* bas = sm + NW * RG * 64;
+#pragma unroll
+    for (int t = 0; t < RG; ++t) sm[(wave * RG + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    for (int e = tid; e < ROWS * 8; e += 64 * NW) {
+        const int row = e >> 3, col = e & 7;
+        const int t = row >> 3, rl = row & 7;
+        const int lo = 16 * (rl & 3) + 4 * (2 * (rl >> 2) + (col >> 2)) + (col & 3);
+        double v = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) v += sm[(w8 * RG + t) * 64 + lo];
+        bas[row * 8 + col] = v;
+    }
+    __syncthreads();
+    if (gridDim.y > 1) {
+        for (int e = tid; e < ROWS * nbasis; e += 64 * NW) {
+            const int row = e / nbasis, c = e % nbasis;
+            if (row0 + row < rows_total) part[((size_t)blockIdx.y * rows_total + row0 + row) * nbasis + c] = bas[row * 8 + c];
+        }
+        return;
+    }
+    for (int e = tid; e < ROWS * ncols_out; e += 64 * NW) {
+        const int row = e % ROWS, col = e / ROWS;
+        if (row0 + row >= rows_total) continue;
+        double v;
+        if (comb) {
+            v = 0.0;
+            for (int c = 0; c < nbasis; ++c) v = fma(comb[col * nbasis + c], bas[row * 8 + c], v);
+        } else {
+            v = bas[row * 8 + col];
+        }
+        const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
+        if (rowscale) v *= rowscale[rw];
+        out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
+    }
+}
+
 // sum of the K-split basis partials of pair_gemm_kernel, then the expansion to the outputs:
 //   out[w][col][r] = scale[r] * sum_c comb[col][c] * sum_s part[s][row][c]
 // One workgroup = 8 rows: 256 threads first reduce the (row, basis) partials (coalesced along the basis index) into

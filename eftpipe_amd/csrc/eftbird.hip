@@ -123,6 +123,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_KPOW: return D * c.Nk * 2 * NCH;
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
         case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + PAIR_KU) * 1 * 64;
+        case EFTB_T_PAIRS22Q: return c.nbasis <= 8 ? D * (size_t)(c.nsteps + PAIR_KU) * 64 : 0;
         case EFTB_T_COMB22: return D * 28 * c.nbasis;
         case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 38 * c.ncolsC : 0;
         case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + PAIR_KU) * (c.ncolsC / 16) * 64 : 0;
@@ -259,8 +260,21 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (mask & EFTB_S_LOOPS) {
             lin.nA = 10; lin.vecA = tb<double>(e, EFTB_T_M13R); lin.scaleA = e->k3; lin.rowdata = b[EFTB_B_P11]; lin.outA = b[EFTB_B_P13];
         }
-        launch_pair<4, 1, NW_P22>(e, st, e->U, tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, c.nbasis,
-                                  tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22], e->pairpartP, lin);
+        if (c.nbasis <= 8) {  // 4x4x4 matrix-core form: 7 of 8 columns useful instead of 7 of 16
+            const int rows = B * Nk, tiles = (rows + 63) / 64, ks = pick_ksplit(tiles);
+            int level = 0;
+            while ((1 << level) < ks) ++level;
+            const int* pl = tb<int>(e, EFTB_T_PLAN) + 4 * NW_P22 * ((1 << level) - 1);
+            hipLaunchKernelGGL((pair_gemm4_kernel<NW_P22>), dim3(tiles, ks), dim3(64 * NW_P22), pair_lds_bytes(4, 1, NW_P22), st, e->U,
+                               tb<double>(e, EFTB_T_PAIRS22Q), pl, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22],
+                               e->pairpartP, lin);
+            if (ks > 1)
+                hipLaunchKernelGGL(pair_sum_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, ks, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28,
+                                   28, e->k3, e->pairpartP, b[EFTB_B_P22]);
+        } else {
+            launch_pair<4, 1, NW_P22>(e, st, e->U, tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, c.nbasis,
+                                      tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22], e->pairpartP, lin);
+        }
     }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
     if (mask & EFTB_S_CF)
@@ -433,6 +447,7 @@ int eftb_finalize(eftb_engine* e) {
     }
     // opt in to the large dynamic LDS tiles of the pair GEMM
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     e->finalized = true;

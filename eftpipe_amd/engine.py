@@ -92,6 +92,9 @@ class Engine:
         self._set("LNXTAIL", t["lnx_tail"])
         self._set("KPOW", t["kpow"])
         self._set("PAIRS22", _padded_fragments(t["pairs22"]))
+        if "pairs22q" in t:
+            from .tables import KU
+            self._set("PAIRS22Q", np.concatenate([t["pairs22q"], np.zeros((KU, 64))]))
         self._set("PLAN", split_plans(t["steps"], NW_P22), np.int32)
         self._set("M13R", t["m13r"])
         self._set("COMB22", t["comb22"])

@@ -185,6 +185,25 @@ def pair_fragments(R, ncols_pad):
     return np.ascontiguousarray(frag.reshape(len(st), ncols_pad // 16, 16, 4).transpose(0, 1, 3, 2))
 
 
+def pair_fragments_4x4(R):
+    """R[cols <= 8, 257, 257] -> B fragments of v_mfma_f64_4x4x4_4b_f64, [T, 64] (f64): lane 16 k + 4 blk + j holds the weight of
+    pair (n_t, m0_t + k) for column 4 (blk & 1) + j (the two row-half blocks blk >> 1 carry the same values)."""
+    ncols = R.shape[0]
+    assert ncols <= 8
+    st = pair_steps()
+    Rs = R + np.swapaxes(R, 1, 2)
+    idx = np.arange(NPOW)
+    Rs[:, idx, idx] = R[:, idx, idx]
+    w = np.zeros((len(st), 4, 8))                       # [t, k, col]
+    for k in range(4):
+        m = st[:, 1] + k
+        ok = m < NPOW
+        w[ok, k, :ncols] = Rs[:, st[ok, 0], m[ok]].T
+    lane = np.arange(64)
+    kq, blk, j = lane >> 4, (lane >> 2) & 3, lane & 3
+    return np.ascontiguousarray(w[:, kq, 4 * (blk & 1) + j])
+
+
 # ----------------------------------------------------------------------------- cubic spline (not-a-knot)
 def spline_factors(x):
     """Tridiagonal system of scipy's not-a-knot CubicSpline for knot derivatives, pre-factored.
@@ -310,6 +329,8 @@ def build_tables(cfg: EngineConfig) -> dict:
     R22, im22 = reduce_quadratic(M22[basis])
     t["steps"] = pair_steps()
     t["pairs22"] = pair_fragments(R22, 16)
+    if nb <= 8:
+        t["pairs22q"] = pair_fragments_4x4(R22)
     t["m13r"] = np.ascontiguousarray(reduce_linear(M13))                 # [10,257]
     resid = [im22]
     if cfg.with_resum:
