@@ -15,6 +15,7 @@ CASE_FLAGS = {
     "caseD": dict(resum=True, ap=True),
     "caseE": dict(resum=True, ap=True),
     "caseF": dict(resum=True, ap=True),
+    "caseG": dict(resum=True, ap=True, APst=True, window=True),
 }
 
 

@@ -108,3 +108,19 @@ def test_final_nk2048(golden):
     for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
         assert relerr(st[n], g["ap_" + n]) < 1e-9, n
     assert relerr(eng.reduce_plk(f, st, list(g["bsA"]), es=tuple(g["es"])), g["plk_auto"]) < 1e-9
+
+
+def test_cfg3_shape_window_chained_cross(golden):
+    """Oracle == reference for the cfg-3 shape (Nk=512, window, chained, cross-tracer biases; final stages)."""
+    g = golden("caseG")
+    eng = oracle_engine(g, "caseG")
+    f = float(g["f"])
+    st = eng.evaluate(g["kin"], g["Pin"], f, float(g["DA"]), float(g["H"]), pairwise=True)
+    assert relerr(eng.Waldk[:, :, 10, :], g["window_Waldk_k10"]) < 1e-9
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        assert relerr(st[n], g["window_" + n]) < 1e-9, n
+    ch = eng.chained(st)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        assert relerr(ch[n], g["chained_" + n]) < 1e-9, n
+    eng.kmB, eng.krB, eng.ndB, eng.No = 0.6, 0.3, 2.3e-4, 2
+    assert relerr(eng.reduce_plk(f, ch, list(g["bsA"]), list(g["bsB"]), tuple(g["es"])), g["plk_chained_cross"]) < 1e-9
