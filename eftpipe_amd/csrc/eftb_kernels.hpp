@@ -185,22 +185,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 
     const double* urow = sm + r * ULDS;
     while (nsteps > 0) {
-        // one n-run: pairs (n, m0) ... in steps of 4, padded with zero-weight steps to a multiple of PAIR_KU; the
-        // inner loop is branch-free and software pipelined: the B fragments (global) and u_m values (LDS) of
-        // iteration t+1 are in flight under iteration t's PAIR_KU * MT * NT MFMAs
+        // one n-run: sum_m u_m R[(n, m)] is a plain GEMM whose A operand is the raw u tile (no per-MFMA multiply);
+        // the common factor u_n is applied once per run to the run's accumulator, in the D layout
+        // (rows (lane >> 4) + 4 q).  Runs are padded with zero-weight steps to a multiple of PAIR_KU; the inner loop is
+        // branch-free and software pipelined (B fragments and u_m values of iteration t+1 in flight under iteration t)
         const int run = (((2 * NHALF - n) >> 2) + PAIR_KU) / PAIR_KU * PAIR_KU;
         const int left = run - ((m0 - n) >> 2);
         const int cnt = (left < nsteps ? left : nsteps) / PAIR_KU;
-        double un[MT], um[PAIR_KU][MT];
+        v4d racc[MT][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) un[i] = urow[i * 16 * ULDS + n];
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) racc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        double um[PAIR_KU][MT];
         const double* up = urow + m0 + g;
 #pragma unroll
         for (int u = 0; u < PAIR_KU; ++u)
 #pragma unroll
             for (int i = 0; i < MT; ++i) um[u][i] = up[i * 16 * ULDS + 4 * u];
         for (int it = 0; it < cnt; ++it) {
-            double bnxt[PAIR_KU][NT], umn[PAIR_KU][MT], a[PAIR_KU][MT];
+            double bnxt[PAIR_KU][NT], umn[PAIR_KU][MT];
 #pragma unroll
             for (int u = 0; u < PAIR_KU; ++u)
 #pragma unroll
@@ -214,14 +218,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 #pragma unroll
             for (int u = 0; u < PAIR_KU; ++u)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[u][i] = un[i] * um[u][i];
-#pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], bcur[u][j], acc[i][j], 0, 0, 0);
+                        racc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(um[u][i], bcur[u][j], racc[i][j], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < PAIR_KU; ++u) {
 #pragma unroll
@@ -230,6 +230,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
                 for (int i = 0; i < MT; ++i) um[u][i] = umn[u][i];
             }
         }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double un = sm[(16 * i + g + 4 * q) * ULDS + n];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j][q] = fma(un, racc[i][j][q], acc[i][j][q]);
+            }
         nsteps -= cnt * PAIR_KU;
         ++n;
         m0 = n;
@@ -356,14 +364,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const doubl
     for (int u = 0; u < PAIR_KU; ++u) bcur[u] = fp[u * 64];
     fp += PAIR_KU * 64;
 
-    const double* urow = sm + rowl * ULDS;  // row group t adds 8 t rows
+    const double* urow = sm + rowl * ULDS;                                // A side: row group t adds 8 t rows
+    const double* drow = sm + (4 * (blk >> 1) + (lane >> 4)) * ULDS;      // D side: this lane's output row within a group
     while (nsteps > 0) {
+        // one n-run as a plain GEMM on the raw u tile; the factor u_n multiplies the run's accumulator once (D layout)
         const int run = (((2 * NHALF - n) >> 2) + PAIR_KU) / PAIR_KU * PAIR_KU;
         const int left = run - ((m0 - n) >> 2);
         const int cnt = (left < nsteps ? left : nsteps) / PAIR_KU;
-        double un[RG], um[PAIR_KU][RG];
+        double racc[RG], um[PAIR_KU][RG];
 #pragma unroll
-        for (int t = 0; t < RG; ++t) un[t] = urow[t * 8 * ULDS + n];
+        for (int t = 0; t < RG; ++t) racc[t] = 0.0;
         const double* up = urow + m0 + kq;
 #pragma unroll
         for (int u = 0; u < PAIR_KU; ++u)
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const doubl
 #pragma unroll
             for (int u = 0; u < PAIR_KU; ++u)
 #pragma unroll
-                for (int t = 0; t < RG; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(un[t] * um[u][t], bcur[u], acc[t], 0, 0, 0);
+                for (int t = 0; t < RG; ++t) racc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(um[u][t], bcur[u], racc[t], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < PAIR_KU; ++u) {
                 bcur[u] = bnxt[u];
@@ -390,6 +400,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const doubl
                 for (int t = 0; t < RG; ++t) um[u][t] = umn[u][t];
             }
         }
+#pragma unroll
+        for (int t = 0; t < RG; ++t) acc[t] = fma(drow[t * 8 * ULDS + n], racc[t], acc[t]);
         nsteps -= cnt * PAIR_KU;
         ++n;
         m0 = n;

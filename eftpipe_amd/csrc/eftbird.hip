@@ -18,7 +18,7 @@
 using namespace eftb;
 
 constexpr int NW_P22 = 16;  // waves per workgroup (K slices) of the P22 pair GEMM
-constexpr int NW_C = 16;    // ... of the xi-space pair GEMM
+constexpr int NW_C = 8;     // ... of the xi-space pair GEMM (two accumulator sets: 2 waves per SIMD)
 constexpr size_t GEMM_LDS = (size_t)64 * 258 * sizeof(double);  // A tile of gemm_rows_kernel
 
 static thread_local std::string g_err;
@@ -448,7 +448,8 @@ int eftb_finalize(eftb_engine* e) {
     // opt in to the large dynamic LDS tiles of the pair GEMM
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     e->finalized = true;
     return 0;

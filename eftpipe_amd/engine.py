@@ -15,7 +15,7 @@ from . import _lib as L
 from .tables import EngineConfig, build_tables
 
 NROW = 24
-NW_P22, NW_C = 16, 16 # waves per workgroup (K slices) of the two pair GEMMs; must match csrc/eftbird.hip
+NW_P22, NW_C = 16, 8  # waves per workgroup (K slices) of the two pair GEMMs; must match csrc/eftbird.hip
 ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
 
 
