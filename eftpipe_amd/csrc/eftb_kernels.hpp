@@ -969,6 +969,137 @@ __global__ __launch_bounds__(256) void ap_kernel(int Nk, int nmu, int nrows_ap, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// ap_moment_kernel: the AP integral as (moments of the quadrature on each knot interval) x (cubic coefficients).
+// For a fixed (cosmology, k) the map  k'(mu), t = k' - k_i, L_l'(mu'), w_mu (2l+1)/2 L_l(mu)  does not depend on the
+// template row, so on every knot interval i that k'(mu) visits
+//     M_i[l][l'][p] = sum_{mu_j in i} wl[l][j] lp[l'][j] t_j^p            (NL*NL*4 numbers, row-independent)
+// and   out[l][row][k] = sum_i sum_{l',p} M_i[l][l'][p] * CO[l'][row][i][p].
+// One lane = one k and one quarter of the mu nodes (wave <-> quarter); it walks its nodes monotonically through the
+// knots, and whenever it leaves an interval applies that interval's moments to all NR rows (coalesced double4 reads of
+// the cubics: neighbouring lanes sit on neighbouring intervals).  The per-row work drops from nmu cubic evaluations
+// to (intervals crossed) x 4 NL FMAs per output multipole.  The four quarters are summed through LDS in a fixed order.
+// ------------------------------------------------------------------------------------------------
+template <int NL, int NR, int RS>
+__global__ __launch_bounds__(256, RS == 1 ? 1 : 2) void ap_moment_kernel(int Nk, int nmu, const double* __restrict__ kk,
+                                                           const double* __restrict__ DAw, const double* __restrict__ Hw,
+                                                           const double* __restrict__ fid, const double* __restrict__ mu,
+                                                           const double* __restrict__ wmu, const double* __restrict__ legmu,
+                                                           const double* __restrict__ T, const double* __restrict__ CO,
+                                                           double* __restrict__ Tout) {
+    extern __shared__ double sm[];
+    double* s_root = sm;                   // [nmu]      k'/k * qperp
+    double* s_lp = sm + nmu;               // [NL][nmu]  L_l'(mu')
+    double* s_wl = sm + (1 + NL) * nmu;    // [NL][nmu]  wmu * (2l+1)/2 L_l(mu)
+    double* red = sm + (1 + 2 * NL) * nmu; // [4][NRT][64]
+    constexpr int NRT = (NR + RS - 1) / RS;  // rows per lane: the NR rows are split over RS workgroups (blockIdx.z)
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, w = blockIdx.y, rbase = blockIdx.z * NRT;
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
+    for (int j = threadIdx.x; j < nmu; j += 256) {
+        const double m = mu[j];
+        const double root = sqrt(1.0 + m * m * g);
+        const double mp = m / (F * root), x2 = mp * mp;
+        s_root[j] = root;
+        s_lp[j] = 1.0;
+        s_lp[nmu + j] = 0.5 * (3.0 * x2 - 1.0);
+        if (NL > 2) s_lp[2 * nmu + j] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) s_wl[l * nmu + j] = wmu[j] * legmu[l * nmu + j];
+    }
+    __syncthreads();
+    double acc[NL][NRT];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[l][r] = 0.0;
+    const bool live = k < Nk;
+    const int j1 = live ? ((seg + 1) * nmu) / 4 : 0;
+    int j = live ? (seg * nmu) / 4 : 0;
+    const double kq = live ? kk[k] / qperp : 0.0;
+    int i0 = 0;
+    if (j < j1) i0 = knot_interval(kk, Nk, kq * s_root[j]);
+    while (j < j1) {
+        const double k0 = kk[i0], k1 = kk[i0 + 1];
+        const bool first = i0 == 0, last = i0 == Nk - 2;
+        double M[NL][NL][4];
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) M[l][lp][p] = 0.0;
+        double kp = kq * s_root[j];
+        do {  // the nodes of this lane that fall in [k0, k1) (end intervals extrapolate)
+            const double t = kp - k0, t2 = t * t, t3 = t2 * t;
+            double wl[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) wl[l] = s_wl[l * nmu + j];
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                const double a = s_lp[lp * nmu + j];
+                const double a1 = a * t, a2 = a * t2, a3 = a * t3;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    M[l][lp][0] = fma(wl[l], a, M[l][lp][0]);
+                    M[l][lp][1] = fma(wl[l], a1, M[l][lp][1]);
+                    M[l][lp][2] = fma(wl[l], a2, M[l][lp][2]);
+                    M[l][lp][3] = fma(wl[l], a3, M[l][lp][3]);
+                }
+            }
+            ++j;
+            if (j >= j1) break;
+            kp = kq * s_root[j];
+        } while ((kp >= k0 || first) && (kp < k1 || last));
+        // apply the interval's moments to every row.  l' is a real (not unrolled) loop: hipcc otherwise hoists all NL*NRT
+        // 32-byte loads to the top and sinks the FMAs below the interval search, which costs 170+ VGPRs of spills.
+        {
+            const double* cw = CO + ((size_t)w * NL * NROW * Nk + i0) * 4;
+#pragma unroll 1
+            for (int lp = 0; lp < NL; ++lp) {
+                double ms[NL][4];
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) ms[l][p] = lp == 0 ? M[l][0][p] : (lp == 1 ? M[l][1][p] : M[l][NL - 1][p]);
+                const double* cl = cw + (size_t)lp * NROW * Nk * 4;
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const double4 c = *reinterpret_cast<const double4*>(cl + (size_t)min(rbase + r, NR - 1) * Nk * 4);
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        acc[l][r] = fma(ms[l][0], c.x, fma(ms[l][1], c.y, fma(ms[l][2], c.z, fma(ms[l][3], c.w, acc[l][r]))));
+                }
+            }
+        }
+        if (j < j1) {  // move to the interval of the next node (intervals without nodes are skipped)
+            while (i0 < Nk - 2 && kp >= kk[i0 + 1]) ++i0;
+            while (i0 > 0 && kp < kk[i0]) --i0;
+        }
+    }
+    // sum the four mu quarters in a fixed order and write
+    const double c = 2.0 / (qperp * qperp * qpar);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) red[(seg * NRT + r) * 64 + lane] = acc[l][r];
+        __syncthreads();
+        for (int r = seg; r < NRT; r += 4) {
+            const double v = (red[(0 * NRT + r) * 64 + lane] + red[(1 * NRT + r) * 64 + lane]) + (red[(2 * NRT + r) * 64 + lane] + red[(3 * NRT + r) * 64 + lane]);
+            if (live && rbase + r < NR) Tout[(((size_t)w * NL + l) * NROW + rbase + r) * Nk + k] = c * v;
+        }
+    }
+    constexpr int NCP = NROW - NR > 0 ? NROW - NR : 1;  // rows that APeffect leaves alone (Pstl unless APst)
+    if (live && NR < NROW && blockIdx.z == 0)
+        for (int e = seg; e < NCP * NL; e += 4) {
+            const int l = e / NCP, r = NR + e % NCP;
+            const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
+            Tout[o] = T[o];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // reduce: P_l(k) = sum_row bias[row] * T[l][row][k]  (reference parambasis.py:128-136)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const double* __restrict__ bias, const double* __restrict__ T,

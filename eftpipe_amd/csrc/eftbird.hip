@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "eftb_kernels.hpp"
@@ -57,6 +58,7 @@ struct eftb_engine {
     std::vector<Op> ops;
     int pipeline_op = -1;
     bool use_fork = false;  // run the k-space and xi-space contractions on two streams (EFTB_FORK=1); off: one stream
+    int ap_rowsplit = 2;  // template rows of one k are split over this many workgroups in ap_moment_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
     int Nn = 0;
@@ -328,13 +330,26 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         const int nseries = B * Nl * NROW;
         hipLaunchKernelGGL(spline_kernel, dim3((Nk + 255) / 256, nseries), dim3(256), 0, st, Nk, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_K),
                            tb<double>(e, EFTB_T_SPBAND), e->SD);
-        const int nrows_ap = c.ap_stochastic ? NROW : 21;
-#define AP_ARGS Nk, c.nmu, nrows_ap, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), \
-                tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), b[EFTB_B_TEMPL], e->SD, e->Talt
-        const size_t aplds = (size_t)(1 + 2 * Nl) * c.nmu * sizeof(double);
-        const dim3 apgrid((Nk + 63) / 64, (NROW + 4 * AP_R - 1) / (4 * AP_R), B);
-        if (Nl == 3) hipLaunchKernelGGL((ap_kernel<3>), apgrid, dim3(256), aplds, st, AP_ARGS);
-        else hipLaunchKernelGGL((ap_kernel<2>), apgrid, dim3(256), aplds, st, AP_ARGS);
+        // interval moments x cubic coefficients (ap_moment_kernel); 21 rows unless the stochastic terms are distorted too
+#define AP_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), \
+                tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), b[EFTB_B_TEMPL], e->SD, e->Talt
+        const int nr = c.ap_stochastic ? NROW : 21;
+        const int rs = e->ap_rowsplit;
+        const size_t aplds = ((size_t)(1 + 2 * Nl) * c.nmu + (size_t)4 * ((nr + rs - 1) / rs) * 64) * sizeof(double);
+        const dim3 apgrid((Nk + 63) / 64, B, rs);
+#define AP_LAUNCH(NLV, NRV, RSV) hipLaunchKernelGGL((ap_moment_kernel<NLV, NRV, RSV>), apgrid, dim3(256), aplds, st, AP_ARGS)
+#define AP_PICK(RSV)                                 \
+    do {                                             \
+        if (Nl == 3 && nr == 21) AP_LAUNCH(3, 21, RSV);   \
+        else if (Nl == 3) AP_LAUNCH(3, NROW, RSV);        \
+        else if (nr == 21) AP_LAUNCH(2, 21, RSV);         \
+        else AP_LAUNCH(2, NROW, RSV);                     \
+    } while (0)
+        if (rs == 1) AP_PICK(1);
+        else if (rs == 2) AP_PICK(2);
+        else AP_PICK(3);
+#undef AP_PICK
+#undef AP_LAUNCH
 #undef AP_ARGS
         std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     }
@@ -379,6 +394,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->cur_nl = c.Nl;
     e->cur_nx = c.Nk;
     if (const char* f = getenv("EFTB_FORK")) e->use_fork = (f[0] == '1');
+    if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(3, std::max(1, atoi(f)));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&e->ev0));
