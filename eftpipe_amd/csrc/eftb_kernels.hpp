@@ -832,37 +832,39 @@ __global__ __launch_bounds__(256) void resum_sum_kernel(int Nk, int Nl, int nchu
 //
 // spline_kernel: the knot derivatives are  s = A^-1 R y  with A the (constant) not-a-knot tridiagonal matrix;
 // A^-1 R decays like 0.27^|i-j|, so the host ships it as a band of half-width SPL_HB (truncation < 1e-18,
-// checked in tests) and the solve becomes a fully parallel, coalesced banded mat-vec.  Output: the piecewise
-// cubic in power form, CO[series][i][4] = (y_i, s_i, c2_i, c3_i) on [k_i, k_i+1].
+// checked in tests) and the solve becomes a fully parallel, coalesced banded mat-vec.  Output: YS[series][i] = (y_i, s_i),
+// the Hermite data of the piecewise cubic on [k_i, k_i+1] (half the bytes of power-form coefficients).
 // ------------------------------------------------------------------------------------------------
 constexpr int SPL_HB = 32;
 
-__global__ __launch_bounds__(256) void spline_kernel(int Nk, const double* __restrict__ T, const double* __restrict__ kk,
-                                                     const double* __restrict__ band, double* __restrict__ CO) {
-    __shared__ double ys[256 + 2 * SPL_HB + 1];
+__global__ __launch_bounds__(256) void spline_kernel(int Nk, int nseries, const double* __restrict__ T, const double* __restrict__ band,
+                                                     double* __restrict__ YS) {
+    // lane <-> knot: its band row stays in registers while the workgroup sweeps its share of the series; the y window of
+    // each series goes through LDS (double-buffered, one barrier per series).  Output: (y_i, s_i) pairs.
+    __shared__ double ys[2][256 + 2 * SPL_HB];
     const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
-    const size_t series = blockIdx.y;
-    const double* y = T + series * Nk;
-    for (int e = threadIdx.x; e < 256 + 2 * SPL_HB + 1; e += 256) {
-        const int jj = i0 - SPL_HB + e;
-        ys[e] = (jj >= 0 && jj < Nk) ? y[jj] : 0.0;
+    double bnd[2 * SPL_HB + 1];
+#pragma unroll
+    for (int d = 0; d <= 2 * SPL_HB; ++d) bnd[d] = i < Nk ? band[(size_t)d * Nk + i] : 0.0;
+    const int per = (nseries + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(nseries, s0 + per);
+    for (int s = s0; s < s1; ++s) {
+        double* buf = ys[(s - s0) & 1];
+        const double* y = T + (size_t)s * Nk;
+        for (int e = threadIdx.x; e < 256 + 2 * SPL_HB; e += 256) {
+            const int jj = i0 - SPL_HB + e;
+            buf[e] = (jj >= 0 && jj < Nk) ? y[jj] : 0.0;
+        }
+        __syncthreads();
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int d = 0; d + 1 <= 2 * SPL_HB; d += 2) {
+            a0 = fma(bnd[d], buf[threadIdx.x + d], a0);
+            a1 = fma(bnd[d + 1], buf[threadIdx.x + d + 1], a1);
+        }
+        a0 = fma(bnd[2 * SPL_HB], buf[threadIdx.x + 2 * SPL_HB], a0);
+        if (i < Nk) *reinterpret_cast<double2*>(YS + ((size_t)s * Nk + i) * 2) = make_double2(buf[threadIdx.x + SPL_HB], a0 + a1);
     }
-    __syncthreads();
-    if (i >= Nk - 1) return;
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll 5
-    for (int d = 0; d <= 2 * SPL_HB; ++d) {
-        s0 = fma(band[(size_t)d * Nk + i], ys[threadIdx.x + d], s0);
-        s1 = fma(band[(size_t)d * Nk + i + 1], ys[threadIdx.x + 1 + d], s1);
-    }
-    const double y0 = ys[threadIdx.x + SPL_HB], y1 = ys[threadIdx.x + SPL_HB + 1];
-    const double h = kk[i + 1] - kk[i], ih = 1.0 / h;
-    const double sl = (y1 - y0) * ih;
-    const double c3 = (s0 + s1 - 2.0 * sl) * ih * ih;
-    const double c2 = (sl - s0) * ih - c3 * h;
-    double4 o;
-    o.x = y0; o.y = s0; o.z = c2; o.w = c3;
-    *reinterpret_cast<double4*>(CO + (series * Nk + i) * 4) = o;
 }
 
 __device__ inline int knot_interval(const double* __restrict__ kk, int Nk, double x) {
@@ -874,32 +876,39 @@ __device__ inline int knot_interval(const double* __restrict__ kk, int Nk, doubl
     return lo;
 }
 
-// ap_kernel: one lane = one k and AP_R template rows (the interval search, t = k' - k_i, Legendre(mu') and the
-// quadrature weights are shared by the AP_R * NL cubics).  (cosmology, mu)-only quantities are computed once
-// per workgroup into LDS; each lane walks k'(mu) monotonically through the knots and keeps the current
-// interval's cubics in registers, re-read (two 16-byte loads each) only when the interval changes.
-constexpr int AP_R = 2;
-
+// ------------------------------------------------------------------------------------------------
+// AP as prefix sums over mu (ap_prefix_kernel) + interval moments by differences (ap_apply_kernel).
+// With k' = kq (1 + rho_j), kq = k / qperp, rho_j = sqrt(1 + g mu_j^2) - 1, the offset inside knot interval i is
+//     t_j = k' - k_i = kq rho_j + delta,   delta = kq - k_i,
+// so the moments of the quadrature on the nodes [ja, jb) that fall into interval i,
+//     M_i[l][l'][p] = sum_{j in [ja, jb)} wl[l][j] lp[l'][j] t_j^p = sum_{q <= p} C(p,q) kq^q delta^(p-q) (PS[jb] - PS[ja])[l'][l][q],
+// need only the k-independent prefix sums  PS[w][j][l'][l][q] = sum_{j' < j} wl[l][j'] lp[l'][j'] rho_j'^q  (one small
+// table per cosmology) and the node indices where k'(mu) crosses the knots (closed form + a one-step fix-up against the
+// stored roots, so every node lands in the interval the comparison k_i <= k' < k_i+1 selects).  Then
+//     out[l][row][k] = sum_i sum_{l',p} M_i[l][l'][p] CO[l'][row][i][p],
+// i.e. per (k, row, l) the nmu cubic evaluations of the direct form (reference pybird.py:1581-1621) collapse to
+// (intervals crossed, ~3) x 4 NL FMAs.  No mu loop, no LDS, no divergence beyond the number of intervals crossed.
+// ------------------------------------------------------------------------------------------------
 template <int NL>
-__global__ __launch_bounds__(256) void ap_kernel(int Nk, int nmu, int nrows_ap, const double* __restrict__ kk,
-                                                 const double* __restrict__ DAw, const double* __restrict__ Hw,
-                                                 const double* __restrict__ fid, const double* __restrict__ mu,
-                                                 const double* __restrict__ wmu, const double* __restrict__ legmu,
-                                                 const double* __restrict__ T, const double* __restrict__ CO,
-                                                 double* __restrict__ Tout) {
+__global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* __restrict__ DAw, const double* __restrict__ Hw,
+                                                        const double* __restrict__ fid, const double* __restrict__ mu,
+                                                        const double* __restrict__ wmu, const double* __restrict__ legmu,
+                                                        double* __restrict__ PS, double* __restrict__ ROOT) {
+    constexpr int NS = NL * NL * 4, NCH = 8;  // sequences (l', l, q), chunks of the mu range per sequence
     extern __shared__ double sm[];
-    double* s_root = sm;                  // [nmu]      k'/k * qperp
-    double* s_lp = sm + nmu;              // [NL][nmu]  L_l'(mu')
-    double* s_wl = sm + (1 + NL) * nmu;   // [NL][nmu]  wmu * (2l+1)/2 L_l(mu)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + lane, row0 = (blockIdx.y * 4 + wave) * AP_R, w = blockIdx.z;
+    double* s_rho = sm;                    // [nmu]
+    double* s_lp = sm + nmu;               // [NL][nmu]  L_l'(mu')
+    double* s_wl = sm + (1 + NL) * nmu;    // [NL][nmu]  wmu (2l+1)/2 L_l(mu)
+    double* s_tot = sm + (1 + 2 * NL) * nmu;  // [NS][NCH] chunk totals -> chunk offsets
+    const int w = blockIdx.x;
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
     const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
     for (int j = threadIdx.x; j < nmu; j += blockDim.x) {
         const double m = mu[j];
         const double root = sqrt(1.0 + m * m * g);
         const double mp = m / (F * root), x2 = mp * mp;
-        s_root[j] = root;
+        ROOT[(size_t)w * nmu + j] = root;
+        s_rho[j] = g * m * m / (1.0 + root);
         s_lp[j] = 1.0;
         s_lp[nmu + j] = 0.5 * (3.0 * x2 - 1.0);
         if (NL > 2) s_lp[2 * nmu + j] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
@@ -907,192 +916,142 @@ __global__ __launch_bounds__(256) void ap_kernel(int Nk, int nmu, int nrows_ap, 
         for (int l = 0; l < NL; ++l) s_wl[l * nmu + j] = wmu[j] * legmu[l * nmu + j];
     }
     __syncthreads();
-    if (k >= Nk || row0 >= NROW) return;
-    if (row0 >= nrows_ap) {  // rows that APeffect leaves alone (Pstl unless APst); nrows_ap is a multiple of AP_R... 21 is not:
-        // handled below row by row
+    const int seq = threadIdx.x % NS, ch = threadIdx.x / NS;
+    const int q = seq & 3, l = (seq >> 2) % NL, lp = seq / (4 * NL);
+    const int clen = (nmu + NCH - 1) / NCH, j0 = ch * clen, j1 = min(nmu, j0 + clen);
+    double* ps = PS + (size_t)w * (nmu + 1) * NS + seq;
+    double s = 0.0;
+    if (ch < NCH) {
+        for (int j = j0; j < j1; ++j) {
+            const double r = s_rho[j];
+            const double rq = q == 0 ? 1.0 : (q == 1 ? r : (q == 2 ? r * r : r * r * r));
+            s = fma(s_wl[l * nmu + j] * s_lp[lp * nmu + j], rq, s);
+            ps[(size_t)(j + 1) * NS] = s;  // chunk-local prefix
+        }
+        s_tot[seq * NCH + ch] = s;
     }
-    const double kq = kk[k] / qperp;
-    int i0 = knot_interval(kk, Nk, kq * s_root[0]);
-    int icur = -1;
-    double k0 = 0.0, k1 = 0.0;
-    double4 cf[AP_R][NL];
-    double acc[AP_R][NL];
-#pragma unroll
-    for (int r = 0; r < AP_R; ++r)
-#pragma unroll
-        for (int l = 0; l < NL; ++l) acc[r][l] = 0.0;
-    for (int j = 0; j < nmu; ++j) {
-        const double kp = kq * s_root[j];
-        if (icur >= 0) {
-            while (i0 < Nk - 2 && kp >= k1) { ++i0; k1 = kk[i0 + 1]; }
-            while (i0 > 0 && kp < k0) { --i0; k0 = kk[i0]; }
+    __syncthreads();
+    if (threadIdx.x < NS) {  // exclusive scan of the chunk totals
+        double run = 0.0;
+        for (int c = 0; c < NCH; ++c) {
+            const double t = s_tot[threadIdx.x * NCH + c];
+            s_tot[threadIdx.x * NCH + c] = run;
+            run += t;
         }
-        if (i0 != icur) {
-            icur = i0;
-            k0 = kk[i0];
-            k1 = kk[i0 + 1];
-#pragma unroll
-            for (int r = 0; r < AP_R; ++r)
-#pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const int row = min(row0 + r, NROW - 1);
-                    cf[r][l] = *reinterpret_cast<const double4*>(CO + ((((size_t)w * NL + l) * NROW + row) * Nk + i0) * 4);
-                }
-        }
-        const double t = kp - k0;
-        double lp[NL], wl[NL];
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            lp[l] = s_lp[l * nmu + j];
-            wl[l] = s_wl[l * nmu + j];
-        }
-#pragma unroll
-        for (int r = 0; r < AP_R; ++r) {
-            double pk = 0.0;
-#pragma unroll
-            for (int l = 0; l < NL; ++l) pk = fma(lp[l], cf[r][l].x + t * (cf[r][l].y + t * (cf[r][l].z + t * cf[r][l].w)), pk);
-#pragma unroll
-            for (int l = 0; l < NL; ++l) acc[r][l] = fma(wl[l], pk, acc[r][l]);
-        }
+        PS[(size_t)w * (nmu + 1) * NS + threadIdx.x] = 0.0;
     }
-    const double c = 2.0 / (qperp * qperp * qpar);
-#pragma unroll
-    for (int r = 0; r < AP_R; ++r) {
-        const int row = row0 + r;
-        if (row >= NROW) break;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const size_t o = (((size_t)w * NL + l) * NROW + row) * Nk + k;
-            Tout[o] = (row < nrows_ap) ? c * acc[r][l] : T[o];
-        }
+    __syncthreads();
+    if (ch < NCH && ch > 0) {
+        const double off = s_tot[seq * NCH + ch];
+        for (int j = j0; j < j1; ++j) ps[(size_t)(j + 1) * NS] += off;
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// ap_moment_kernel: the AP integral as (moments of the quadrature on each knot interval) x (cubic coefficients).
-// For a fixed (cosmology, k) the map  k'(mu), t = k' - k_i, L_l'(mu'), w_mu (2l+1)/2 L_l(mu)  does not depend on the
-// template row, so on every knot interval i that k'(mu) visits
-//     M_i[l][l'][p] = sum_{mu_j in i} wl[l][j] lp[l'][j] t_j^p            (NL*NL*4 numbers, row-independent)
-// and   out[l][row][k] = sum_i sum_{l',p} M_i[l][l'][p] * CO[l'][row][i][p].
-// One lane = one k and one quarter of the mu nodes (wave <-> quarter); it walks its nodes monotonically through the
-// knots, and whenever it leaves an interval applies that interval's moments to all NR rows (coalesced double4 reads of
-// the cubics: neighbouring lanes sit on neighbouring intervals).  The per-row work drops from nmu cubic evaluations
-// to (intervals crossed) x 4 NL FMAs per output multipole.  The four quarters are summed through LDS in a fixed order.
-// ------------------------------------------------------------------------------------------------
+// ap_apply_kernel: workgroup = 64 k x 4 waves of one cosmology; wave <-> interval slot (s = wave, wave + 4, ...), so
+// the intervals that k'(mu) crosses are handled in parallel: slot s of a k is interval i = i_first + s dir, and its
+// node range [ja, jb) comes from the closed-form crossings of its two knots (the same function of (kq, knot) in both
+// neighbouring slots, so the ranges tile [0, nmu) exactly).  Knots and roots sit in LDS; the four waves' partial sums
+// are added through LDS in a fixed order.
 template <int NL, int NR, int RS>
-__global__ __launch_bounds__(256, RS == 1 ? 1 : 2) void ap_moment_kernel(int Nk, int nmu, const double* __restrict__ kk,
-                                                           const double* __restrict__ DAw, const double* __restrict__ Hw,
-                                                           const double* __restrict__ fid, const double* __restrict__ mu,
-                                                           const double* __restrict__ wmu, const double* __restrict__ legmu,
-                                                           const double* __restrict__ T, const double* __restrict__ CO,
-                                                           double* __restrict__ Tout) {
-    extern __shared__ double sm[];
-    double* s_root = sm;                   // [nmu]      k'/k * qperp
-    double* s_lp = sm + nmu;               // [NL][nmu]  L_l'(mu')
-    double* s_wl = sm + (1 + NL) * nmu;    // [NL][nmu]  wmu * (2l+1)/2 L_l(mu)
-    double* red = sm + (1 + 2 * NL) * nmu; // [4][NRT][64]
+__global__ __launch_bounds__(256) void ap_apply_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+                                                       const double* __restrict__ Hw, const double* __restrict__ fid,
+                                                       const double* __restrict__ mu, const double* __restrict__ PS,
+                                                       const double* __restrict__ ROOT, const double* __restrict__ T,
+                                                       const double* __restrict__ YS, double* __restrict__ Tout) {
+    constexpr int NS = NL * NL * 4;
     constexpr int NRT = (NR + RS - 1) / RS;  // rows per lane: the NR rows are split over RS workgroups (blockIdx.z)
-    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    constexpr int NACC = NL * NRT;
+    extern __shared__ double sm[];
+    double* s_k = sm;               // [Nk]
+    double* s_root = sm + Nk;       // [nmu]
+    double* red = sm + Nk + nmu;    // [4][NACC][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + lane, w = blockIdx.y, rbase = blockIdx.z * NRT;
+    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
+    for (int e = threadIdx.x; e < nmu; e += 256) s_root[e] = ROOT[(size_t)w * nmu + e];
+    __syncthreads();
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
     const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
-    for (int j = threadIdx.x; j < nmu; j += 256) {
-        const double m = mu[j];
-        const double root = sqrt(1.0 + m * m * g);
-        const double mp = m / (F * root), x2 = mp * mp;
-        s_root[j] = root;
-        s_lp[j] = 1.0;
-        s_lp[nmu + j] = 0.5 * (3.0 * x2 - 1.0);
-        if (NL > 2) s_lp[2 * nmu + j] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) s_wl[l * nmu + j] = wmu[j] * legmu[l * nmu + j];
-    }
-    __syncthreads();
+    const bool live = k < Nk;
+    const double kq = s_k[live ? k : Nk - 1] / qperp;
+    const double* ps = PS + (size_t)w * (nmu + 1) * NS;
+    const bool up = g > 0.0;  // k'(mu) rises or falls with mu
+    const int dir = up ? 1 : -1;
+    const double jscale = (nmu - 1) / mu[nmu - 1];  // node index per unit mu (uniform grid: only a first guess, see the fix-up)
     double acc[NL][NRT];
 #pragma unroll
     for (int l = 0; l < NL; ++l)
 #pragma unroll
         for (int r = 0; r < NRT; ++r) acc[l][r] = 0.0;
-    const bool live = k < Nk;
-    const int j1 = live ? ((seg + 1) * nmu) / 4 : 0;
-    int j = live ? (seg * nmu) / 4 : 0;
-    const double kq = live ? kk[k] / qperp : 0.0;
-    int i0 = 0;
-    if (j < j1) i0 = knot_interval(kk, Nk, kq * s_root[j]);
-    while (j < j1) {
-        const double k0 = kk[i0], k1 = kk[i0 + 1];
-        const bool first = i0 == 0, last = i0 == Nk - 2;
-        double M[NL][NL][4];
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) M[l][lp][p] = 0.0;
-        double kp = kq * s_root[j];
-        do {  // the nodes of this lane that fall in [k0, k1) (end intervals extrapolate)
-            const double t = kp - k0, t2 = t * t, t3 = t2 * t;
-            double wl[NL];
-#pragma unroll
-            for (int l = 0; l < NL; ++l) wl[l] = s_wl[l * nmu + j];
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                const double a = s_lp[lp * nmu + j];
-                const double a1 = a * t, a2 = a * t2, a3 = a * t3;
-#pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    M[l][lp][0] = fma(wl[l], a, M[l][lp][0]);
-                    M[l][lp][1] = fma(wl[l], a1, M[l][lp][1]);
-                    M[l][lp][2] = fma(wl[l], a2, M[l][lp][2]);
-                    M[l][lp][3] = fma(wl[l], a3, M[l][lp][3]);
-                }
-            }
-            ++j;
-            if (j >= j1) break;
-            kp = kq * s_root[j];
-        } while ((kp >= k0 || first) && (kp < k1 || last));
-        // apply the interval's moments to every row.  l' is a real (not unrolled) loop: hipcc otherwise hoists all NL*NRT
-        // 32-byte loads to the top and sinks the FMAs below the interval search, which costs 170+ VGPRs of spills.
-        {
-            const double* cw = CO + ((size_t)w * NL * NROW * Nk + i0) * 4;
+    // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling)
+    auto cross = [&](double kb) -> int {
+        const double rc = kb / kq, x = (rc * rc - 1.0) / g;  // mu^2 at the crossing
+        int j = nmu;
+        if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
+        j = max(0, min(j, nmu));
+        while (j > 0 && (up ? kq * s_root[j - 1] >= kb : kq * s_root[j - 1] < kb)) --j;
+        while (j < nmu && !(up ? kq * s_root[j] >= kb : kq * s_root[j] < kb)) ++j;
+        return j;
+    };
+    const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
+    const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
+    const int nslot = live ? (up ? i_last - i_first : i_first - i_last) + 1 : 0;
+    for (int s = wave; s < nslot; s += 4) {
+        const int i = i_first + s * dir;
+        const double klo = s_k[i], khi = s_k[i + 1];
+        const int ja = s == 0 ? 0 : cross(up ? klo : khi);
+        const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
+        if (jb <= ja) continue;
+        const double ih = 1.0 / (khi - klo);
+        const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
+        const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
+        const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
+        const double* pa = ps + (size_t)ja * NS;
+        const double* pb = ps + (size_t)jb * NS;
+        const double* cw = YS + ((size_t)w * NL * NROW * Nk + i) * 2;
 #pragma unroll 1
-            for (int lp = 0; lp < NL; ++lp) {
-                double ms[NL][4];
+        for (int lp = 0; lp < NL; ++lp) {  // a real loop: keeps hipcc from hoisting all NL*NRT row loads (spills)
+            double ms[NL][4];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const double4 b4 = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
+                const double4 a4 = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
+                const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
+                const double m0 = d0, m1 = fma(c10, d0, c11 * d1), m2 = fma(c20, d0, fma(c21, d1, c22 * d2));
+                const double m3 = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+                // power moments -> weights of the Hermite data (y_i, s_i, y_i+1, s_i+1)
+                const double hy1 = (3.0 * m2 - 2.0 * m3 * ih) * ih * ih;
+                ms[l][0] = m0 - hy1;
+                ms[l][1] = m1 - (2.0 * m2 - m3 * ih) * ih;
+                ms[l][2] = hy1;
+                ms[l][3] = (m3 * ih - m2) * ih;
+            }
+            const double* cl = cw + (size_t)lp * NROW * Nk * 2;
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const double2* cp = reinterpret_cast<const double2*>(cl + (size_t)min(rbase + r, NR - 1) * Nk * 2);
+                const double2 ca = cp[0], cb = cp[1];
 #pragma unroll
                 for (int l = 0; l < NL; ++l)
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) ms[l][p] = lp == 0 ? M[l][0][p] : (lp == 1 ? M[l][1][p] : M[l][NL - 1][p]);
-                const double* cl = cw + (size_t)lp * NROW * Nk * 4;
-#pragma unroll
-                for (int r = 0; r < NRT; ++r) {
-                    const double4 c = *reinterpret_cast<const double4*>(cl + (size_t)min(rbase + r, NR - 1) * Nk * 4);
-#pragma unroll
-                    for (int l = 0; l < NL; ++l)
-                        acc[l][r] = fma(ms[l][0], c.x, fma(ms[l][1], c.y, fma(ms[l][2], c.z, fma(ms[l][3], c.w, acc[l][r]))));
-                }
+                    acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], cb.x, fma(ms[l][3], cb.y, acc[l][r]))));
             }
         }
-        if (j < j1) {  // move to the interval of the next node (intervals without nodes are skipped)
-            while (i0 < Nk - 2 && kp >= kk[i0 + 1]) ++i0;
-            while (i0 > 0 && kp < kk[i0]) --i0;
-        }
     }
-    // sum the four mu quarters in a fixed order and write
+    // sum the four waves in a fixed order and write
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) red[(wave * NACC + l * NRT + r) * 64 + lane] = acc[l][r];
+    __syncthreads();
     const double c = 2.0 / (qperp * qperp * qpar);
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < NRT; ++r) red[(seg * NRT + r) * 64 + lane] = acc[l][r];
-        __syncthreads();
-        for (int r = seg; r < NRT; r += 4) {
-            const double v = (red[(0 * NRT + r) * 64 + lane] + red[(1 * NRT + r) * 64 + lane]) + (red[(2 * NRT + r) * 64 + lane] + red[(3 * NRT + r) * 64 + lane]);
-            if (live && rbase + r < NR) Tout[(((size_t)w * NL + l) * NROW + rbase + r) * Nk + k] = c * v;
-        }
+    for (int e = wave; e < NACC; e += 4) {
+        const int l = e / NRT, r = e % NRT;
+        const double v = (red[(0 * NACC + e) * 64 + lane] + red[(1 * NACC + e) * 64 + lane]) + (red[(2 * NACC + e) * 64 + lane] + red[(3 * NACC + e) * 64 + lane]);
+        if (live && rbase + r < NR) Tout[(((size_t)w * NL + l) * NROW + rbase + r) * Nk + k] = c * v;
     }
     constexpr int NCP = NROW - NR > 0 ? NROW - NR : 1;  // rows that APeffect leaves alone (Pstl unless APst)
     if (live && NR < NROW && blockIdx.z == 0)
-        for (int e = seg; e < NCP * NL; e += 4) {
+        for (int e = wave; e < NCP * NL; e += 4) {
             const int l = e / NCP, r = NR + e % NCP;
             const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
             Tout[o] = T[o];

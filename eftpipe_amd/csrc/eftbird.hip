@@ -51,6 +51,7 @@ struct eftb_engine {
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
     double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
+    double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     double *pairpartP = nullptr, *pairpartC = nullptr;  // K-split partials of the two pair GEMMs
     int ldtv = 0;  // padded column count of Tv / V (Nl*257 rounded up to 16)
     // linear post-AP operators (window / binning / chained), stored K-major for gemm_rows_kernel
@@ -58,7 +59,7 @@ struct eftb_engine {
     std::vector<Op> ops;
     int pipeline_op = -1;
     bool use_fork = false;  // run the k-space and xi-space contractions on two streams (EFTB_FORK=1); off: one stream
-    int ap_rowsplit = 2;  // template rows of one k are split over this many workgroups in ap_moment_kernel (EFTB_AP_ROWSPLIT=1|2|3)
+    int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
     int Nn = 0;
@@ -328,16 +329,25 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & EFTB_S_AP) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
         const int nseries = B * Nl * NROW;
-        hipLaunchKernelGGL(spline_kernel, dim3((Nk + 255) / 256, nseries), dim3(256), 0, st, Nk, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_K),
-                           tb<double>(e, EFTB_T_SPBAND), e->SD);
-        // interval moments x cubic coefficients (ap_moment_kernel); 21 rows unless the stochastic terms are distorted too
-#define AP_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), \
-                tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), b[EFTB_B_TEMPL], e->SD, e->Talt
+        {
+            const int kt = (Nk + 255) / 256;
+            const int ysplit = std::max(1, std::min(nseries, 2048 / kt));  // ~8 workgroups per CU, each sweeping nseries/ysplit series
+            hipLaunchKernelGGL(spline_kernel, dim3(kt, ysplit), dim3(256), 0, st, Nk, nseries, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPBAND), e->SD);
+        }
+        // prefix sums over mu per cosmology, then interval moments by differences x cubic coefficients
         const int nr = c.ap_stochastic ? NROW : 21;
         const int rs = e->ap_rowsplit;
-        const size_t aplds = ((size_t)(1 + 2 * Nl) * c.nmu + (size_t)4 * ((nr + rs - 1) / rs) * 64) * sizeof(double);
+        const size_t pflds = ((size_t)(1 + 2 * Nl) * c.nmu + (size_t)Nl * Nl * 4 * 8) * sizeof(double);
+#define PF_ARGS c.nmu, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
+                tb<double>(e, EFTB_T_LEGMU), e->APP, e->APR
+        if (Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(320), pflds, st, PF_ARGS);
+        else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(320), pflds, st, PF_ARGS);
+#undef PF_ARGS
+#define AP_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), \
+                e->APP, e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt
         const dim3 apgrid((Nk + 63) / 64, B, rs);
-#define AP_LAUNCH(NLV, NRV, RSV) hipLaunchKernelGGL((ap_moment_kernel<NLV, NRV, RSV>), apgrid, dim3(256), aplds, st, AP_ARGS)
+        const size_t aplds = ((size_t)Nk + c.nmu + (size_t)4 * Nl * ((nr + rs - 1) / rs) * 64) * sizeof(double);
+#define AP_LAUNCH(NLV, NRV, RSV) hipLaunchKernelGGL((ap_apply_kernel<NLV, NRV, RSV>), apgrid, dim3(256), aplds, st, AP_ARGS)
 #define AP_PICK(RSV)                                 \
     do {                                             \
         if (Nl == 3 && nr == 21) AP_LAUNCH(3, 21, RSV);   \
@@ -420,7 +430,11 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
     }
     HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
-    if (c.with_ap) HIPCHK(hipMalloc(&e->SD, 4 * e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // power-form cubics
+    if (c.with_ap) {
+        HIPCHK(hipMalloc(&e->SD, 2 * e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // (y, s) pairs of the splines
+        HIPCHK(hipMalloc(&e->APP, (size_t)c.max_batch * (c.nmu + 1) * c.Nl * c.Nl * 4 * sizeof(double)));
+        HIPCHK(hipMalloc(&e->APR, (size_t)c.max_batch * c.nmu * sizeof(double)));
+    }
     *out = e;
     return 0;
 }
@@ -467,6 +481,10 @@ int eftb_finalize(eftb_engine* e) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define AP_LDS(NLV, NRV, RSV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_apply_kernel<NLV, NRV, RSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3);
+    AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3);
+#undef AP_LDS
     e->finalized = true;
     return 0;
 }
@@ -533,7 +551,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
+    for (double* p : {e->APP, e->APR, e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);
