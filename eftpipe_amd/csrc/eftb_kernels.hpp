@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void ap_apply_kernel(int Nk, int nmu, const do
         const int ja = s == 0 ? 0 : cross(up ? klo : khi);
         const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
         if (jb <= ja) continue;
-        const double ih = 1.0 / (khi - klo);
+        const double h = khi - klo, ih = 1.0 / h;
         const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
         const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
         const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
@@ -1017,23 +1017,22 @@ __global__ __launch_bounds__(256) void ap_apply_kernel(int Nk, int nmu, const do
                 const double4 b4 = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
                 const double4 a4 = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
                 const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
-                const double m0 = d0, m1 = fma(c10, d0, c11 * d1), m2 = fma(c20, d0, fma(c21, d1, c22 * d2));
-                const double m3 = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
-                // power moments -> weights of the Hermite data (y_i, s_i, y_i+1, s_i+1)
-                const double hy1 = (3.0 * m2 - 2.0 * m3 * ih) * ih * ih;
-                ms[l][0] = m0 - hy1;
-                ms[l][1] = m1 - (2.0 * m2 - m3 * ih) * ih;
-                ms[l][2] = hy1;
-                ms[l][3] = (m3 * ih - m2) * ih;
+                ms[l][0] = d0;
+                ms[l][1] = fma(c10, d0, c11 * d1);
+                ms[l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
+                ms[l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
             }
             const double* cl = cw + (size_t)lp * NROW * Nk * 2;
 #pragma unroll
             for (int r = 0; r < NRT; ++r) {
                 const double2* cp = reinterpret_cast<const double2*>(cl + (size_t)min(rbase + r, NR - 1) * Nk * 2);
-                const double2 ca = cp[0], cb = cp[1];
+                const double2 ca = cp[0], cb = cp[1];  // (y_i, s_i), (y_i+1, s_i+1) -> power form on [k_i, k_i+1]
+                const double sl = (cb.x - ca.x) * ih;
+                const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
+                const double c2 = (sl - ca.y) * ih - c3 * h;
 #pragma unroll
                 for (int l = 0; l < NL; ++l)
-                    acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], cb.x, fma(ms[l][3], cb.y, acc[l][r]))));
+                    acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], c2, fma(ms[l][3], c3, acc[l][r]))));
             }
         }
     }
