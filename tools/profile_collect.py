@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof (written by tools/profile_round.sh on the GPU box) into profiles/rNN_*.
+
+    python tools/profile_collect.py r01
+
+Writes: rNN_bench.json, rNN_bench_under_rocprof.json, rNN_kernel_stats.csv (rocprofv3 --stats, verbatim),
+rNN_pmc_per_kernel.json (average counter values per kernel) and rNN_pmc_p22.json (the dominant kernel: HBM bytes
+per launch corrected as MI355X_MICROARCH.md prescribes, MFMA busy fraction, L2 hit rate, rocprof vs HIP-event time).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", "prof"), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def find(pat):
+    hits = glob.glob(os.path.join(src, "**", pat), recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {pat} under {src}")
+    return hits[0]
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+for n in ("bench.json", "bench_under_rocprof.json"):
+    shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
+shutil.copy(find("stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in ("pmc_fetch_counter_collection.csv", "pmc_write_counter_collection.csv", "pmc_sq_counter_collection.csv",
+          "pmc_l2hit_counter_collection.csv", "pmc_l2miss_counter_collection.csv"):
+    for r in csv.DictReader(open(find(f))):
+        per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per.items() if k.startswith("eftb::")}
+json.dump(avg, open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
+
+bench = json.load(open(os.path.join(src, "bench.json")))
+stats = {short(r["Name"]): r for r in csv.DictReader(open(find("stats_kernel_stats.csv")))}
+dom = next(k for k in avg if k.startswith("eftb::pair_gemm4_kernel"))
+c = avg[dom]
+B, NK = bench["config"]["batch_per_gpu"], 512
+out = {
+    "kernel": f"{dom} (makeP22), batch {B}, Nk {NK}",
+    "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+    "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+    "note": "(2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
+            "128-B requests of wide streams as 64 B; the 8-B/lane B-fragment loads are uncalibrated, so this is an upper bound). "
+            f"Algorithmic bytes per launch: u rows {B}*{NK}*260*8 = {B * NK * 260 * 8 / 1e6:.0f} MB + pair table + P22 basis out "
+            f"{B * NK * 7 * 8 / 1e6:.1f} MB.",
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    "kernel_cycles_est": c["GRBM_GUI_ACTIVE"] / 8.0,
+    "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+    "effective_clock_GHz": c["GRBM_GUI_ACTIVE"] / 8.0 / float(stats[dom]["AverageNs"]),
+    "L2_hit": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+    "rocprof_avg_us": float(stats[dom]["AverageNs"]) / 1e3,
+    "bench_hip_event_us": bench["roofline"]["ms_per_launch"] * 1e3,
+}
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_p22.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+print("evaluations/s", bench["value"], "ms/step", bench["ms_per_step"], "stage_ms", bench["roofline"]["stage_ms"])
