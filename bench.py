@@ -147,7 +147,8 @@ def main():
                                                         ("regroup", L.S_REGROUP), ("resum", L.S_RESUM), ("ap", L.S_AP), ("reduce", L.S_REDUCE))}
         # AP ping-pongs the template block; leave the state consistent
         alg_flops = 8.0 * 28 * NK * NPOW**2 * B          # F_P22 per evaluation x B
-        exe_flops = 2.0 * 8 * 4 * eng.tables["steps"].shape[0] * NK * B   # MFMA flops actually issued: v_mfma_f64_4x4x4 blocks, 8 columns (7 basis matrices), real-reduced pairs
+        # MFMA flops actually issued: two v_mfma_f64_4x4x4_4b (512 flops, 8 rows x 8 columns x 4 pairs) per double step and 8-row group
+        exe_flops = 512.0 * 2 * eng.tables["steps4"].shape[0] * (NK * B / 8)
         achieved = alg_flops / (ms_p22 * 1e-3) / 1e12
         try:
             measured_peak = mfma_f64_peak(cp.local_rank)

@@ -18,6 +18,7 @@ constexpr int NHALF = 128;
 constexpr int NCH = 129;     // independent complex coefficients
 constexpr int UPAD = 260;    // HBM row stride of u (doubles), 16-byte aligned rows
 constexpr int PAIR_KU = 2;  // K-steps per inner-loop iteration of the pair GEMM (tables.py KU)
+constexpr int PAIR4_STEPS = []() { int t = 0; for (int n = 0; n < 2 * NHALF + 1; n += 2) t += ((2 * NHALF - n) >> 2) + 1; return t; }();  // double steps of the 4x4x4 form
 constexpr int ULDS = 258;    // LDS row stride of u: 258 = 2 (mod 32) -> conflict-free ds_read_b64
 constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl) + 12 (Ploopl) + 3 (Pstl)
 
@@ -301,8 +302,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 // blocks are (rows 0-3 | 4-7) x (columns 0-3 | 4-7) of an 8-row group, so 7 of 8 columns are useful and the same
 // pairs cost half the matrix-pipe time.  Measured lane maps (tools/probe/mfma4_probe.hip):
 //   A[blk][i][k] at lane 16 k + 4 blk + i,  B[blk][k][j] at lane 16 k + 4 blk + j,  D[blk][i][j] at lane 16 i + 4 blk + j.
-// Workgroup = NW waves = 64 rows (8 row groups per wave), K split NW ways; same n-run walk, LDS u tile, plans, linear
-// terms, workgroup-level K split and epilogue expansion as pair_gemm_kernel.
+// Workgroup = NW waves = 64 rows (8 row groups per wave), K split NW ways; same LDS u tile, plans, linear terms,
+// workgroup-level K split and epilogue expansion as pair_gemm_kernel; the n-runs are walked two at a time (tables.py
+// pair_steps_4x4).
 // ------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const double* __restrict__ U, const double* __restrict__ frag,
@@ -350,60 +352,54 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const doubl
 
     const int kq = lane >> 4, blk = (lane >> 2) & 3, rowl = 4 * (blk >> 1) + (lane & 3);
     const int* pl = plan + (blockIdx.y * NW + wave) * 4;
-    int n = __builtin_amdgcn_readfirstlane(pl[0]);
+    int n = __builtin_amdgcn_readfirstlane(pl[0]);   // even: the double run (n, n + 1)
     int m0 = __builtin_amdgcn_readfirstlane(pl[1]);
     const int t0 = __builtin_amdgcn_readfirstlane(pl[2]);
     int nsteps = __builtin_amdgcn_readfirstlane(pl[3]);
-    const double* fp = frag + (size_t)t0 * 64 + lane;
+    const double* fp = frag + (size_t)t0 * 128 + lane;
 
     double acc[RG];
 #pragma unroll
     for (int t = 0; t < RG; ++t) acc[t] = 0.0;
-    double bcur[PAIR_KU];
-#pragma unroll
-    for (int u = 0; u < PAIR_KU; ++u) bcur[u] = fp[u * 64];
-    fp += PAIR_KU * 64;
+    double b0 = fp[0], b1 = fp[64];  // B fragments of runs n and n + 1, prefetched one double step ahead
+    fp += 128;
 
     const double* urow = sm + rowl * ULDS;                                // A side: row group t adds 8 t rows
     const double* drow = sm + (4 * (blk >> 1) + (lane >> 4)) * ULDS;      // D side: this lane's output row within a group
     while (nsteps > 0) {
-        // one n-run as a plain GEMM on the raw u tile; the factor u_n multiplies the run's accumulator once (D layout)
-        const int run = (((2 * NHALF - n) >> 2) + PAIR_KU) / PAIR_KU * PAIR_KU;
+        // one double run as two plain GEMMs that share the raw u operand (one LDS read feeds two MFMAs: the A operand of
+        // the 4x4x4 form costs 1 B/flop, exactly the LDS bandwidth at the MFMA peak, so unshared reads cap it near 60 %);
+        // the factors u_n, u_n+1 multiply the runs' accumulators once (D layout)
+        const int run = ((2 * NHALF - n) >> 2) + 1;
         const int left = run - ((m0 - n) >> 2);
-        const int cnt = (left < nsteps ? left : nsteps) / PAIR_KU;
-        double racc[RG], um[PAIR_KU][RG];
+        const int cnt = left < nsteps ? left : nsteps;
+        double ra[RG], rb[RG], um[RG];
 #pragma unroll
-        for (int t = 0; t < RG; ++t) racc[t] = 0.0;
+        for (int t = 0; t < RG; ++t) ra[t] = rb[t] = 0.0;
         const double* up = urow + m0 + kq;
 #pragma unroll
-        for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
-            for (int t = 0; t < RG; ++t) um[u][t] = up[t * 8 * ULDS + 4 * u];
+        for (int t = 0; t < RG; ++t) um[t] = up[t * 8 * ULDS];
         for (int it = 0; it < cnt; ++it) {
-            double bnxt[PAIR_KU], umn[PAIR_KU][RG];
+            double umn[RG];
+            const double bn0 = fp[0], bn1 = fp[64];
+            fp += 128;
+            up += 4;
 #pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u) bnxt[u] = fp[u * 64];
-            fp += PAIR_KU * 64;
-            up += 4 * PAIR_KU;
+            for (int t = 0; t < RG; ++t) umn[t] = up[t * 8 * ULDS];
 #pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
-                for (int t = 0; t < RG; ++t) umn[u][t] = up[t * 8 * ULDS + 4 * u];
-#pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
-                for (int t = 0; t < RG; ++t) racc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(um[u][t], bcur[u], racc[t], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u) {
-                bcur[u] = bnxt[u];
-#pragma unroll
-                for (int t = 0; t < RG; ++t) um[u][t] = umn[u][t];
+            for (int t = 0; t < RG; ++t) {
+                ra[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(um[t], b0, ra[t], 0, 0, 0);
+                rb[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(um[t], b1, rb[t], 0, 0, 0);
             }
+            b0 = bn0;
+            b1 = bn1;
+#pragma unroll
+            for (int t = 0; t < RG; ++t) um[t] = umn[t];
         }
 #pragma unroll
-        for (int t = 0; t < RG; ++t) acc[t] = fma(drow[t * 8 * ULDS + n], racc[t], acc[t]);
-        nsteps -= cnt * PAIR_KU;
-        ++n;
+        for (int t = 0; t < RG; ++t) acc[t] = fma(drow[t * 8 * ULDS + n], ra[t], fma(drow[t * 8 * ULDS + n + 1], rb[t], acc[t]));
+        nsteps -= cnt;
+        n += 2;
         m0 = n;
     }
 

@@ -126,7 +126,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_KPOW: return D * c.Nk * 2 * NCH;
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
         case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + PAIR_KU) * 1 * 64;
-        case EFTB_T_PAIRS22Q: return c.nbasis <= 8 ? D * (size_t)(c.nsteps + PAIR_KU) * 64 : 0;
+        case EFTB_T_PAIRS22Q: return c.nbasis <= 8 ? D * (size_t)(PAIR4_STEPS + 1) * 128 : 0;
+        case EFTB_T_PLANQ: return c.nbasis <= 8 ? sizeof(int32_t) * 4 * NW_P22 * 15 : 0;
         case EFTB_T_COMB22: return D * 28 * c.nbasis;
         case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 38 * c.ncolsC : 0;
         case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + PAIR_KU) * (c.ncolsC / 16) * 64 : 0;
@@ -267,7 +268,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             const int rows = B * Nk, tiles = (rows + 63) / 64, ks = pick_ksplit(tiles);
             int level = 0;
             while ((1 << level) < ks) ++level;
-            const int* pl = tb<int>(e, EFTB_T_PLAN) + 4 * NW_P22 * ((1 << level) - 1);
+            const int* pl = tb<int>(e, EFTB_T_PLANQ) + 4 * NW_P22 * ((1 << level) - 1);
             hipLaunchKernelGGL((pair_gemm4_kernel<NW_P22>), dim3(tiles, ks), dim3(64 * NW_P22), pair_lds_bytes(4, 1, NW_P22), st, e->U,
                                tb<double>(e, EFTB_T_PAIRS22Q), pl, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22],
                                e->pairpartP, lin);

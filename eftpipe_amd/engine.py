@@ -8,6 +8,7 @@ the stage-by-stage methods back the PyBird-compatible classes in ``eftpipe_amd.p
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -31,10 +32,31 @@ def wave_plan(steps, nwaves=8):
     return plan
 
 
-def split_plans(steps, nwaves):
+RUN_COST = float(os.environ.get("EFTB_PLAN_RUNCOST", "3"))  # cost of starting / closing a run, in double steps
+
+
+def wave_plan_4x4(steps4, nwaves):
+    """Same for the double-run steps of the 4x4x4 kernel (no KU padding there).  Slices are balanced on
+    steps + RUN_COST * (runs touched): the tail of the table is made of many short runs whose per-run epilogue
+    (accumulator scaling by u_n) would otherwise make the last waves the slowest."""
+    T = len(steps4)
+    first = np.concatenate([[True], steps4[1:, 0] != steps4[:-1, 0]])
+    cost = np.cumsum(1.0 + RUN_COST * first)
+    cuts = [0] + [int(np.searchsorted(cost, cost[-1] * q / nwaves)) for q in range(1, nwaves)] + [T]
+    cuts = np.maximum.accumulate(np.array(cuts))
+    for q in range(1, nwaves):  # every slice keeps at least one step
+        cuts[q] = min(max(cuts[q], cuts[q - 1] + 1), T - (nwaves - q))
+    plan = np.zeros((nwaves, 4), dtype=np.int32)
+    for q in range(nwaves):
+        t0, t1 = cuts[q], cuts[q + 1]
+        plan[q] = (steps4[t0, 0], steps4[t0, 1], t0, t1 - t0)
+    return plan
+
+
+def split_plans(steps, nwaves, plan=wave_plan):
     """Plans for 1, 2, 4 and 8 workgroup-level K splits, back to back ([15 * nwaves, 4]); the workgroup
     with blockIdx.y = s of a ks-way split uses entries [(ks - 1 + s) * nwaves, (ks + s) * nwaves)."""
-    return np.concatenate([wave_plan(steps, nwaves * ks) for ks in (1, 2, 4, 8)])
+    return np.concatenate([plan(steps, nwaves * ks) for ks in (1, 2, 4, 8)])
 
 
 def _padded_fragments(frag):
@@ -92,9 +114,9 @@ class Engine:
         self._set("LNXTAIL", t["lnx_tail"])
         self._set("KPOW", t["kpow"])
         self._set("PAIRS22", _padded_fragments(t["pairs22"]))
-        if "pairs22q" in t:
-            from .tables import KU
-            self._set("PAIRS22Q", np.concatenate([t["pairs22q"], np.zeros((KU, 64))]))
+        if "pairs22q" in t:  # one zero double step: the kernel prefetches one iteration ahead
+            self._set("PAIRS22Q", np.concatenate([t["pairs22q"], np.zeros((1, 2, 64))]))
+            self._set("PLANQ", split_plans(t["steps4"], NW_P22, wave_plan_4x4), np.int32)
         self._set("PLAN", split_plans(t["steps"], NW_P22), np.int32)
         self._set("M13R", t["m13r"])
         self._set("COMB22", t["comb22"])

@@ -42,6 +42,22 @@ def pair_contract(u, frag, steps):
     return out
 
 
+def pair_contract_4x4(u, frag, steps4):
+    """u [rows,257], frag [T,2,64] (v_mfma_f64_4x4x4 B fragments of the double runs) -> [rows, 8]"""
+    up = np.concatenate([u, np.zeros((u.shape[0], 16))], axis=1)
+    lane = np.arange(64)
+    kq, blk, j = lane >> 4, (lane >> 2) & 3, lane & 3
+    out = np.zeros((u.shape[0], 8))
+    for r in range(2):
+        un = up[:, steps4[:, 0] + r]  # [rows,T]
+        for k in range(4):
+            v = un * up[:, steps4[:, 1] + k]
+            for b in range(2):  # column halves; the row-half blocks blk >> 1 hold copies
+                sel = (kq == k) & (blk == b)
+                out[:, 4 * b : 4 * b + 4] += v @ frag[:, r, sel]
+    return out
+
+
 def pscf(t, Pin, with_cf):
     k, s = t["k"], t["s"]
     P11 = t["Sk"] @ Pin

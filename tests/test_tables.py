@@ -47,6 +47,26 @@ def test_device_algebra_matches_oracle(golden, name, resum, ap):
             assert relerr(st[n], g["ap_" + n]) < 1e-9, n
 
 
+def test_4x4_double_run_fragments_match_16x16(golden):
+    """The v_mfma_f64_4x4x4 double-run table contracts to the same basis columns as the 16x16x4 table."""
+    g = golden("caseA")
+    t = _tables(g, False, False)
+    c = E.coef_half(t, g["Pin"])
+    U = E.reduced_vectors(c, t["kpow"])
+    nb = t["comb22"].shape[1]
+    a = E.pair_contract(U, t["pairs22"], t["steps"])[:, :nb]
+    b = E.pair_contract_4x4(U, t["pairs22q"], t["steps4"])[:, :nb]
+    assert relerr(b.T, a.T) < 1e-8  # different summation order of a cancelling sum
+    # every wave slice of every K split starts on a step of its (even) run
+    from eftpipe_amd.engine import NW_P22, split_plans, wave_plan_4x4
+
+    pl = split_plans(t["steps4"], NW_P22, wave_plan_4x4)
+    assert np.all(pl[:, 0] % 2 == 0) and np.all((pl[:, 1] - pl[:, 0]) % 4 == 0) and np.all(pl[:, 3] > 0)
+    for ks, off in ((1, 0), (2, 1), (4, 3), (8, 7)):
+        q = pl[off * NW_P22 : (off + ks) * NW_P22]
+        assert q[0, 2] == 0 and np.all(q[1:, 2] == q[:-1, 2] + q[:-1, 3]) and q[-1, 2] + q[-1, 3] == len(t["steps4"])
+
+
 def test_banded_spline_operator_matches_scipy():
     from scipy.interpolate import CubicSpline
 
