@@ -811,6 +811,172 @@ __global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int sc
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// IR-resummation on the FP64 matrix cores (Nl = 3; tables.py resum_mfma_tables).
+// All 108 polynomials  sum_p Q_a[l,l',(half,p,v)](f) z^p  of one cosmology lie in a fixed 8-dimensional space, so with
+// an orthonormal basis beta_r(t), t = z / RS_ZS, of that space their values at 16 (k, s) points are one
+// [96 x 8] x [8 x 16] product:  rows = (tile tau, chunk, slot) as laid out by the host so that the four numbers a lane
+// receives from one v_mfma_f64_16x16x4 (rows (lane >> 4) + 4 q, column lane & 15) are the four (v, half) slots of ONE
+// (a, l, l') block at ONE k.  The lane then forms
+//     W_a[l,l'](k,s) = z H_l'(k,s) D0 + y (H_0 D1 + H_1 D2 + H_2 D3),   z = k^2 X(s), y = k^2 Y(s),
+// and contracts it with the s-dependent (wave-uniform, scalar-loaded) C11 / Cct / Cloopl columns into its own output
+// rows, accumulated over s in registers:  lanes (jg = lane >> 4, n = lane & 15) own k = k0 + n and
+//     tiles 0-2 (l' = tau):      jg < 3 -> (a = 1, l = jg): Pctl[6] + Ploopl[12];   jg = 3 -> (a = 0, l = 0): P11l[3]
+//     tiles 3-5 (l' = tau - 3):  jg < 2 -> (a = 0, l = jg + 1): P11l[3]             (jg >= 2: zero rows)
+// so every (l, row, k) is written by exactly one lane and no cross-lane reduction is needed.  The loop has no branches
+// (lane roles are applied through zeroed weights), which keeps hipcc from shuffling MFMA results through AGPRs.
+// resum_prep_kernel builds, per cosmology, A = Q(f) diag(RS_ZS^p) V8^T and the per-s records
+//   RSC[w][s] = { [l'][24]: l11[l',0..2] C11[l'], lct[l',0..5] Cct[l'], Cloopl[l',0..11], 0 0 0 } , X, Y, pad  (80 doubles).
+// ------------------------------------------------------------------------------------------------
+constexpr double RS_ZS = 8.0;  // tables.py RS_ZS
+constexpr int RS_NB = 8, RS_ROWS = 96, RS_REC = 80;
+
+__global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na, const double* __restrict__ Q,
+                                                         const double* __restrict__ V8S, const int* __restrict__ rows,
+                                                         const double* __restrict__ XY, const double* __restrict__ C11,
+                                                         const double* __restrict__ Cct, const double* __restrict__ Cloopl,
+                                                         const double* __restrict__ l11, const double* __restrict__ lct,
+                                                         double* __restrict__ RSA, double* __restrict__ RSC) {
+    constexpr int NL = 3;
+    const int w = blockIdx.x;
+    const double* q = Q + (size_t)w * 2 * NL * NL * NN;
+    for (int idx = threadIdx.x; idx < RS_ROWS * RS_NB; idx += blockDim.x) {
+        const int row = idx / RS_NB, r = idx % RS_NB, off = rows[row];
+        double a = 0.0;
+        if (off >= 0)
+            for (int p = 0; p < NIR; ++p) a = fma(q[off + p * Na], V8S[r * 16 + p], a);
+        RSA[((size_t)w * RS_ROWS + row) * RS_NB + r] = a;
+    }
+    for (int idx = threadIdx.x; idx < NS * RS_REC; idx += blockDim.x) {
+        const int s = idx / RS_REC, c = idx % RS_REC;
+        double v = 0.0;
+        if (c < 72) {
+            const int lp = c / 24, j = c % 24;
+            if (j < 3) v = l11[lp * 3 + j] * C11[((size_t)w * NL + lp) * NS + s];
+            else if (j < 9) v = lct[lp * 6 + (j - 3)] * Cct[((size_t)w * NL + lp) * NS + s];
+            else if (j < 21) v = Cloopl[(((size_t)w * NL + lp) * 12 + (j - 9)) * NS + s];
+        } else if (c < 74) {
+            v = XY[(size_t)w * 2 * NS + (c - 72) * NS + s];
+        }
+        RSC[((size_t)w * NS + s) * RS_REC + c] = v;
+    }
+}
+
+__device__ inline double estrin16(const double* __restrict__ c, double t, double t2, double t4, double t8) {
+    const double e0 = fma(c[1], t, c[0]), e1 = fma(c[3], t, c[2]), e2 = fma(c[5], t, c[4]), e3 = fma(c[7], t, c[6]);
+    const double e4 = fma(c[9], t, c[8]), e5 = fma(c[11], t, c[10]), e6 = fma(c[13], t, c[12]), e7 = fma(c[15], t, c[14]);
+    const double f0 = fma(e1, t2, e0), f1 = fma(e3, t2, e2), f2 = fma(e5, t2, e4), f3 = fma(e7, t2, e6);
+    const double g0 = fma(f1, t4, f0), g1 = fma(f3, t4, f2);
+    return fma(g1, t8, g0);
+}
+
+__global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
+                                                            const double* __restrict__ H, const double* __restrict__ V8,
+                                                            const double* __restrict__ RSA, const double* __restrict__ RSC,
+                                                            double* __restrict__ T, double* __restrict__ part, int nsplit) {
+    constexpr int NL = 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jg = lane >> 4, n = lane & 15;
+    const int k = Nklow + (blockIdx.x * 4 + wave) * 16 + n, w = blockIdx.y, split = blockIdx.z;
+    const bool live = k < Nk;
+    const int kc = live ? k : Nk - 1;
+    const double k2 = kk[kc] * kk[kc];
+    // B operand: this lane evaluates basis polynomials jg and jg + 4 at its point; A operand: rows (16 tau + n), columns jg + 4 t
+    double vb[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
+    double aop[6][2];
+#pragma unroll
+    for (int tau = 0; tau < 6; ++tau)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) aop[tau][t] = RSA[((size_t)w * RS_ROWS + 16 * tau + n) * RS_NB + jg + 4 * t];
+    // lane roles as weights (no branches in the s loop)
+    const double r1 = jg < 3 ? 1.0 : 0.0, r0 = jg < 3 ? 0.0 : 1.0;
+    double accL[18], accA0[3], accB[3];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) accL[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) accA0[i] = accB[i] = 0.0;
+    const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
+    double hn[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) hn[v] = H[((size_t)v * NS + s0) * Nk + kc];
+    for (int s = s0; s < s1; ++s) {
+        const double* ct = RSC + ((size_t)w * NS + s) * RS_REC;  // wave-uniform record
+        double h[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) h[v] = hn[v];
+        const int sn = s + 1 < s1 ? s + 1 : s;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) hn[v] = H[((size_t)v * NS + sn) * Nk + kc];
+        const double z = k2 * ct[72], y = k2 * ct[73];
+        const double t = z * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
+        const double b0 = estrin16(vb[0], t, t2, t4, t8), b1 = estrin16(vb[1], t, t2, t4, t8);
+        v4d D[6];
+#pragma unroll
+        for (int tau = 0; tau < 6; ++tau) {
+            D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+            D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
+        }
+        double zh[3], yh[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            zh[v] = z * h[v];
+            yh[v] = y * h[v];
+        }
+#pragma unroll
+        for (int tau = 0; tau < 3; ++tau) {
+            const double W = fma(zh[tau], D[tau][0], fma(yh[0], D[tau][1], fma(yh[1], D[tau][2], yh[2] * D[tau][3])));
+            const double W1 = W * r1, W0 = W * r0;
+            const double* c = ct + tau * 24;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) accL[i] = fma(W1, c[3 + i], accL[i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) accA0[i] = fma(W0, c[i], accA0[i]);
+        }
+#pragma unroll
+        for (int tau = 3; tau < 6; ++tau) {
+            const double W = fma(zh[tau - 3], D[tau][0], fma(yh[0], D[tau][1], fma(yh[1], D[tau][2], yh[2] * D[tau][3])));
+            const double* c = ct + (tau - 3) * 24;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) accB[i] = fma(W, c[i], accB[i]);
+        }
+    }
+    if (!live) return;
+    // (a, l) blocks of this lane -> output rows
+    if (nsplit == 1) {
+        if (jg < 3) {
+            double* dst = T + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) dst[(size_t)i * Nk] += accL[i];
+        } else {
+            double* dst = T + (((size_t)w * NL + 0) * NROW) * Nk + k;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += accA0[i];
+        }
+        if (jg < 2) {
+            double* dst = T + (((size_t)w * NL + jg + 1) * NROW) * Nk + k;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += accB[i];
+        }
+    } else {  // partial sums over the s slices, added in a fixed order by resum_sum_kernel
+        double* pw = part + ((size_t)w * nsplit + split) * NL * 21 * Nk + k;
+        if (jg < 3) {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) pw[((size_t)jg * 21 + 3 + i) * Nk] = accL[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pw[(size_t)i * Nk] = accA0[i];
+        }
+        if (jg < 2) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pw[((size_t)(jg + 1) * 21 + i) * Nk] = accB[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void resum_sum_kernel(int Nk, int Nl, int nchunk, const double* __restrict__ part,
                                                         double* __restrict__ T) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -51,6 +51,7 @@ struct eftb_engine {
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
     double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
+    double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][96][8], per-s records [B][NS][80]
     double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     double *pairpartP = nullptr, *pairpartC = nullptr;  // K-split partials of the two pair GEMMs
     int ldtv = 0;  // padded column count of Tv / V (Nl*257 rounded up to 16)
@@ -147,6 +148,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_WQLAST2: return c.with_resum ? D * 2 : 0;
         case EFTB_T_QPOLY: return c.with_resum ? D * 2 * c.Nl * c.Nl * Nn * 15 : 0;
         case EFTB_T_H: return c.with_resum ? D * c.Na * NS * c.Nk : 0;
+        case EFTB_T_RSBASIS: case EFTB_T_RSBASISS: return c.with_resum && c.Nl == 3 ? D * RS_NB * 16 : 0;
+        case EFTB_T_RSROWS: return c.with_resum && c.Nl == 3 ? sizeof(int32_t) * RS_ROWS : 0;
         case EFTB_T_MU: case EFTB_T_WMU: return c.with_ap ? D * c.nmu : 0;
         case EFTB_T_LEGMU: return c.with_ap ? D * c.Nl * c.nmu : 0;
         case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
@@ -315,17 +318,31 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
                            tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
                            tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
                            b[EFTB_B_XY], b[EFTB_B_Q]);
-        const int kblocks = (Nk + 255) / 256;
-        // waves = kblocks*4 x (2*Nl) x (B*Nl*nsplit): split the s sum further only for small batches
-        int nsplit = 1;
-        while (nsplit < e->resum_splits && (size_t)kblocks * 4 * 4 * Nl * Nl * B * nsplit < 8192) nsplit *= 2;
-        const int schunk = (NS + nsplit - 1) / nsplit;
-#define RESUM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), b[EFTB_B_C11], \
-                   b[EFTB_B_CCT], b[EFTB_B_CLOOPL], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), e->part, nsplit
-        if (Nl == 3) hipLaunchKernelGGL((resum_kernel<3>), dim3(kblocks, 4 * Nl, B * Nl * nsplit), dim3(256), 0, st, RESUM_ARGS);
-        else hipLaunchKernelGGL((resum_kernel<2>), dim3(kblocks, 4 * Nl, B * Nl * nsplit), dim3(256), 0, st, RESUM_ARGS);
-#undef RESUM_ARGS
-        hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, 2 * Nl * nsplit, e->part, b[EFTB_B_TEMPL]);
+        if (Nl == 3) {
+            // matrix-core form: polynomials as [96 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
+            hipLaunchKernelGGL(resum_prep_kernel, dim3(B), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
+                               tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL], tb<double>(e, EFTB_T_L11),
+                               tb<double>(e, EFTB_T_LCT), e->RSA, e->RSC);
+            const int kblocks = (Nk - c.Nklow + 63) / 64;
+            int nsplit = 1;
+            while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
+            const int schunk = (NS + nsplit - 1) / nsplit;
+            if (kblocks > 0)
+                hipLaunchKernelGGL(resum_mfma_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K),
+                                   tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, b[EFTB_B_TEMPL], e->part, nsplit);
+            if (nsplit > 1)
+                hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nsplit, e->part, b[EFTB_B_TEMPL]);
+        } else {
+            const int kblocks = (Nk + 255) / 256;
+            // waves = kblocks*4 x (2*Nl) x (B*Nl*nsplit): split the s sum further only for small batches
+            int nsplit = 1;
+            while (nsplit < e->resum_splits && (size_t)kblocks * 4 * 4 * Nl * Nl * B * nsplit < 8192) nsplit *= 2;
+            const int schunk = (NS + nsplit - 1) / nsplit;
+            hipLaunchKernelGGL((resum_kernel<2>), dim3(kblocks, 4 * Nl, B * Nl * nsplit), dim3(256), 0, st, Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K),
+                               b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL],
+                               tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), e->part, nsplit);
+            hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, 2 * Nl * nsplit, e->part, b[EFTB_B_TEMPL]);
+        }
     }
     if (mask & EFTB_S_AP) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
@@ -474,7 +491,15 @@ int eftb_finalize(eftb_engine* e) {
     if (c.with_resum) {
         // split the s sum when the batch alone cannot fill the chip (deterministic two-pass reduction)
         e->resum_splits = c.max_batch >= 16 ? 1 : 8;
-        HIPCHK(hipMalloc(&e->part, (size_t)c.max_batch * e->resum_splits * 2 * c.Nl * c.Nl * 21 * c.Nk * sizeof(double)));
+        {
+            const size_t pbytes = (size_t)c.max_batch * e->resum_splits * 2 * c.Nl * c.Nl * 21 * c.Nk * sizeof(double);
+            HIPCHK(hipMalloc(&e->part, pbytes));
+            HIPCHK(hipMemset(e->part, 0, pbytes));  // the matrix-core kernel never touches k < Nklow
+        }
+        if (c.Nl == 3) {
+            HIPCHK(hipMalloc(&e->RSA, (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double)));
+            HIPCHK(hipMalloc(&e->RSC, (size_t)c.max_batch * NS * RS_REC * sizeof(double)));
+        }
     }
     // opt in to the large dynamic LDS tiles of the pair GEMM
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -552,7 +577,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->APP, e->APR, e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);

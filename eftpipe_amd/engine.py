@@ -138,6 +138,10 @@ class Engine:
             self._set("WQLAST2", t["wq_last2"])
             self._set("QPOLY", t["Qpoly"])
             self._set("H", t["H"].transpose(0, 2, 1))
+            if "rs_rows" in t:
+                self._set("RSBASIS", t["rs_basis"])
+                self._set("RSBASISS", t["rs_basis_scaled"])
+                self._set("RSROWS", t["rs_rows"], np.int32)
         if cfg.with_ap:
             self._set("MU", t["mu"])
             self._set("WMU", t["wmu"])

@@ -400,6 +400,8 @@ def build_tables(cfg: EngineConfig) -> dict:
         t["wq_last2"] = wq[-2:].copy()
         t["Qpoly"] = lm.q_polynomials(Nl)
         t["resum_dims"] = np.array([NIR, Na, int(np.sum(~kr_mask))], dtype=np.int32)
+        if Nl == 3:
+            t.update(resum_mfma_tables(t["Qpoly"], NIR, Na))
 
     # ---- AP
     if cfg.with_ap:
@@ -411,6 +413,59 @@ def build_tables(cfg: EngineConfig) -> dict:
         t["sp_band"] = spline_derivative_band(k)
         t["ap_fid"] = np.array([cfg.DA_AP, cfg.H_AP], dtype=np.float64)
     return t
+
+
+# ----------------------------------------------------------------------------- IR-resummation on the matrix cores
+RS_ZS = 8.0     # the polynomials are evaluated in t = k^2 X / RS_ZS (must match csrc/eftb_kernels.hpp RS_ZS)
+RS_NB = 8       # dimension of the span of all resummation polynomials
+RS_ROWS = 96    # 6 MFMA row tiles x 16
+
+
+def resum_mfma_tables(Qpoly, NIR, Na):
+    """Tables of resum_mfma_kernel (Nl = 3).
+
+    Every polynomial  sum_p Q_a[l,l',(half,p,v)](f) z^p  of the IR-resummation (there are 108 per cosmology, degree 15)
+    lies, for every f, in one fixed 8-dimensional space: q_p (p+1)! (-2)^(p+1) is a degree-7 polynomial in p.  With an
+    orthonormal basis V8 of that space (in the scaled variable t = z / RS_ZS) the polynomials of all rows at 16 (k, s) points
+    become one [96 x 8] x [8 x 16] matrix product on the FP64 matrix cores, A = Q . diag(RS_ZS^p) . V8^T.
+
+    Row layout (tile tau, row i):  chunk = (tau, i % 4), slot = i // 4  -- exactly the 4 values a lane holds of one
+    v_mfma_f64_16x16x4 result (rows (lane >> 4) + 4 q).  Chunks:  tau < 3: l' = tau and i % 4 = 0, 1, 2 -> (a = 1, l = i % 4),
+    3 -> (a = 0, l = 0);  tau >= 3: l' = tau - 3 and i % 4 = 0, 1 -> (a = 0, l = 1), (a = 0, l = 2), 2, 3 -> unused.
+    Slots: 0 -> (v = l', half 0) [the X^(p+1) series only couples v = l'],  1..3 -> (v = slot - 1, half 1).
+
+    -> rs_basis [8,16] (V8), rs_basis_scaled [8,16] (V8 diag(RS_ZS^p)), rs_rows int32[96] (offset of the row's p = 0
+       coefficient inside one cosmology's Q block [2,Nl,Nl,Nn], stride Na per p; -1 = zero row)."""
+    Nl = 3
+    NN = 2 * NIR * Na
+    Qr = Qpoly.reshape(2, Nl, Nl, 2, NIR, Na, Qpoly.shape[-1])          # table, l, l', half, p, v, f-power
+    scale = RS_ZS ** np.arange(NIR)
+    M = Qr.transpose(0, 1, 2, 3, 5, 6, 4).reshape(-1, NIR) * scale[None, :]
+    M = M[np.abs(M).max(axis=1) > 0]
+    _, sv, Vt = np.linalg.svd(M, full_matrices=False)
+    if sv[RS_NB] > 1e-13 * sv[0]:
+        raise ValueError(f"resummation polynomials do not span {RS_NB} dimensions (sv ratio {sv[RS_NB] / sv[0]:.2e})")
+    V8 = np.ascontiguousarray(Vt[:RS_NB])
+    rows = np.full(RS_ROWS, -1, dtype=np.int32)
+    used = np.zeros((2, Nl, Nl, 2, Na), dtype=bool)                     # a (device convention), l, l', half, v
+    for tau in range(6):
+        lp = tau % 3
+        for i in range(16):
+            jg, slot = i % 4, i // 4
+            if tau < 3:
+                a, l = (1, jg) if jg < 3 else (0, 0)
+            elif jg < 2:
+                a, l = 0, jg + 1
+            else:
+                continue
+            v, half = (lp, 0) if slot == 0 else (slot - 1, 1)
+            rows[16 * tau + i] = ((a * Nl + l) * Nl + lp) * NN + half * NIR * Na + v
+            used[a, l, lp, half, v] = True
+    # device Q[a] = table[1 - a] (reference pybird.py:1374-1376): every nonzero polynomial must have a row
+    nz = np.abs(Qr).max(axis=(4, 6)) > 0                                 # table, l, l', half, v
+    if np.any(nz[::-1] & ~used):
+        raise ValueError("resummation table has entries outside the (v = l' | half 1) slot pattern")
+    return dict(rs_basis=V8, rs_basis_scaled=np.ascontiguousarray(V8 * scale[None, :]), rs_rows=rows)
 
 
 # ----------------------------------------------------------------------------- projections after AP

@@ -135,6 +135,48 @@ def resum(t, f, Pin, st):
     return out
 
 
+def resum_mfma(t, f, Pin, st):
+    """The matrix-core form of the same stage (device: resum_prep_kernel + resum_mfma_kernel, Nl = 3): polynomials as
+    A[96 rows, 8] x beta[8, points] in t = z / RS_ZS, rows laid out as (tile, chunk, slot) -- see tables.resum_mfma_tables."""
+    from eftpipe_amd.tables import RS_ZS
+
+    NIR, Na, Nklow = t["resum_dims"]
+    Nl = 3
+    k = t["k"]
+    Q = (t["Qpoly"] @ f ** np.arange(15))[::-1].reshape(-1)
+    X, Y = ir_filters(t, Pin)
+    z = k[:, None] ** 2 * X[None, :]
+    yk = k[:, None] ** 2 * Y[None, :]
+    rows = t["rs_rows"]
+    A = np.zeros((96, 8))
+    for r in np.nonzero(rows >= 0)[0]:
+        A[r] = t["rs_basis_scaled"] @ Q[rows[r] + np.arange(NIR) * Na]
+    tt = z / RS_ZS
+    beta = np.einsum("rp,pks->rks", t["rs_basis"], np.stack([tt**p for p in range(NIR)]))  # [8,Nk,Ns]
+    D = np.einsum("ir,rks->iks", A, beta).reshape(6, 4, 4, *z.shape)  # [tau, slot, jg, k, s]
+    H = t["H"]
+    out = {n: st[n].copy() for n in ("P11l", "Pctl", "Ploopl")}
+    for tau in range(6):
+        lp = tau % 3
+        for jg in range(4):
+            if tau < 3:
+                a, l = (1, jg) if jg < 3 else (0, 0)
+            elif jg < 2:
+                a, l = 0, jg + 1
+            else:
+                continue
+            d = D[tau, :, jg]
+            W = z * H[lp] * d[0] + yk * (H[0] * d[1] + H[1] * d[2] + H[2] * d[3])  # [Nk,Ns]
+            if a == 0:
+                out["P11l"][l] += np.einsum("ks,s,i->ik", W, st["C11"][lp], t["l11"][lp])
+            else:
+                out["Pctl"][l] += np.einsum("ks,s,i->ik", W, st["Cct"][lp], t["lct"][lp])
+                out["Ploopl"][l] += np.einsum("ks,is->ik", W, st["Cloopl"][lp])
+    out = dict(st, **out)
+    out["X"], out["Y"] = X, Y
+    return out
+
+
 def spline_derivs(t, y):
     """y [..., Nk] -> knot derivatives via the banded operator (device: spline_kernel)."""
     band = t["sp_band"]

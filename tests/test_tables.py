@@ -39,6 +39,14 @@ def test_device_algebra_matches_oracle(golden, name, resum, ap):
         assert relerr(st["Y"], taps["resum"]["Y"]) < 1e-10
         for n in ("P11l", "Pctl", "Ploopl"):
             assert relerr(st[n], taps["resum"][n]) < 1e-9, n
+        if "rs_rows" in t:  # matrix-core form of the stage (Nl = 3)
+            pre = {n: taps["setpscfl"][n] for n in ("P11l", "Pctl", "Ploopl", "Cloopl")}
+            pre.update(C11=taps["pscf"]["C11"], Cct=taps["pscf"]["Cct"])
+            alt = E.resum_mfma(t, f, g["Pin"], pre)
+            for n in ("P11l", "Pctl", "Ploopl"):
+                assert relerr(alt[n], taps["resum"][n]) < 1e-9, n
+            z = t["k"][:, None] ** 2 * alt["X"][None, :]
+            assert z.max() < 2 * 8.0  # the scaled variable of the polynomial basis stays O(1)
     if ap:
         names = ("P11l", "Pctl", "Ploopl") + (("Pstl",) if name == "caseC" else ())
         st = E.ap(t, float(g["DA"]), float(g["H"]), st, names)
