@@ -29,6 +29,24 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // operators on Pin, plus the high-k power-law tail (reference pybird.py:694-695, fftlog.py:84-166).
 // One workgroup per cosmology.
 // ------------------------------------------------------------------------------------------------
+// sum_j a[j * stride] * b[j] with eight independent chains (v_fma_f64 has a 32-cycle dependent latency; a single chain of a
+// few hundred terms is what made the small per-cosmology kernels latency-bound) and the strided loads issued in batches
+__device__ inline double dot8(const double* __restrict__ a, size_t stride, const double* b, int n) {
+    double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        double av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = a[(size_t)(j + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = fma(av[u], b[j + u], acc[u]);
+    }
+    for (; j < n; ++j) acc[0] = fma(a[(size_t)j * stride], b[j], acc[0]);
+    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+}
+
 __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, const double* __restrict__ Pin,
                                                    const double* __restrict__ lnkin, const double* __restrict__ SkT,
                                                    const double* __restrict__ GcT, const double* __restrict__ EcT,
@@ -45,19 +63,13 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
     const double amp = pin[Nkin - 1] * exp(-slope * lnkin[Nkin - 1]);
     for (int i = tid; i < ntail; i += blockDim.x) tail[i] = amp * exp(slope * lnxtail[i]);
     __syncthreads();
-    for (int k = tid; k < Nk; k += blockDim.x) {
-        double acc = 0.0;
-        for (int j = 0; j < Nkin; ++j) acc = fma(SkT[(size_t)j * Nk + k], pin[j], acc);
-        P11[(size_t)w * Nk + k] = acc;
-    }
-    for (int idx = tid; idx < 2 * NCH; idx += blockDim.x) {
-        const int c = idx / NCH, n = idx % NCH;
-        const double* g = GcT + (size_t)c * Nkin * NCH + n;
-        double acc = 0.0;
-        for (int j = 0; j < Nkin; ++j) acc = fma(g[(size_t)j * NCH], pin[j], acc);
-        const double* e = EcT + (size_t)c * ntail * NCH + n;
-        for (int i = 0; i < ntail; ++i) acc = fma(e[(size_t)i * NCH], tail[i], acc);
-        coef[(size_t)w * 2 * NCH + idx] = acc;
+    // outputs of this cosmology: Nk values of P11 then 2 * 129 FFTLog coefficients, one per thread, blockIdx.y-th slab of 256
+    const int o = blockIdx.y * blockDim.x + tid;
+    if (o < Nk) {
+        P11[(size_t)w * Nk + o] = dot8(SkT + o, Nk, pin, Nkin);
+    } else if (o < Nk + 2 * NCH) {
+        const int idx = o - Nk, c = idx / NCH, n = idx % NCH;
+        coef[(size_t)w * 2 * NCH + idx] = dot8(GcT + (size_t)c * Nkin * NCH + n, NCH, pin, Nkin) + dot8(EcT + (size_t)c * ntail * NCH + n, NCH, tail, ntail);
     }
 }
 
@@ -636,7 +648,7 @@ __global__ __launch_bounds__(256) void irfilter_kernel(int Nkin, int nxtail, int
     extern __shared__ double sm[];
     double* pin = sm;
     double* tail = sm + Nkin;
-    const int w = blockIdx.x, tid = threadIdx.x;
+    const int w = blockIdx.x, tid = threadIdx.x;  // blockIdx.y: 0 -> X, Y filters, 1 -> Q(f) (both workgroup-uniform roles)
     for (int j = tid; j < Nkin; j += blockDim.x) pin[j] = Pin[(size_t)w * Nkin + j];
     __syncthreads();
     const double q1 = pin[Nkin - 1] * wq2[1], q0 = pin[Nkin - 2] * wq2[0];
@@ -644,24 +656,31 @@ __global__ __launch_bounds__(256) void irfilter_kernel(int Nkin, int nxtail, int
     const double amp = q1 * exp(-slope * lnkin[Nkin - 1]);
     for (int i = tid; i < nxtail; i += blockDim.x) tail[i] = amp * exp(slope * lnxxtail[i]);
     __syncthreads();
-    for (int idx = tid; idx < 2 * NS; idx += blockDim.x) {
-        const int c = idx / NS, s = idx % NS;
-        const double* B = c ? BYT : BXT;
-        const double* Tt = c ? TYT : TXT;
-        double acc = 0.0;
-        for (int j = 0; j < Nkin; ++j) acc = fma(B[(size_t)j * NS + s], pin[j], acc);
-        for (int i = 0; i < nxtail; ++i) acc = fma(Tt[(size_t)i * NS + s], tail[i], acc);
-        XY[(size_t)w * 2 * NS + idx] = acc;
+    if (blockIdx.y == 0) {
+        for (int idx = tid; idx < 2 * NS; idx += blockDim.x) {
+            const int c = idx / NS, s = idx % NS;
+            const double* B = c ? BYT : BXT;
+            const double* Tt = c ? TYT : TXT;
+            XY[(size_t)w * 2 * NS + idx] = dot8(B + s, NS, pin, Nkin) + dot8(Tt + s, NS, tail, nxtail);
+        }
+        return;
     }
     // Q[a] = table[1 - a] (reference pybird.py:1374-1376); nq = Nl*Nl*Nn entries per table
     const double f = fgrow[w];
     for (int idx = tid; idx < 2 * nq; idx += blockDim.x) {
         const int a = idx / nq, rest = idx % nq;
         const double* c = Qpoly + ((size_t)(1 - a) * nq + rest) * 15;
-        double acc = c[14];
+        double cv[15];
 #pragma unroll
-        for (int p = 13; p >= 0; --p) acc = fma(acc, f, c[p]);
-        Q[(size_t)w * 2 * nq + idx] = acc;
+        for (int p = 0; p < 15; ++p) cv[p] = c[p];
+        const double f2 = f * f;
+        double ev = cv[14], od = cv[13];  // even / odd powers: two chains
+#pragma unroll
+        for (int p = 12; p >= 0; p -= 2) {
+            ev = fma(ev, f2, cv[p]);
+            if (p >= 1) od = fma(od, f2, cv[p - 1]);
+        }
+        Q[(size_t)w * 2 * nq + idx] = fma(od, f, ev);
     }
 }
 
@@ -842,13 +861,16 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
     const double* q = Q + (size_t)w * 2 * NL * NL * NN;
     for (int idx = threadIdx.x; idx < RS_ROWS * RS_NB; idx += blockDim.x) {
         const int row = idx / RS_NB, r = idx % RS_NB, off = rows[row];
-        double a = 0.0;
+        double a0 = 0.0, a1 = 0.0;
         if (off >= 0)
-            for (int p = 0; p < NIR; ++p) a = fma(q[off + p * Na], V8S[r * 16 + p], a);
-        RSA[((size_t)w * RS_ROWS + row) * RS_NB + r] = a;
+            for (int p = 0; p < NIR; p += 2) {
+                a0 = fma(q[off + p * Na], V8S[r * 16 + p], a0);
+                a1 = fma(q[off + (p + 1) * Na], V8S[r * 16 + p + 1], a1);
+            }
+        RSA[((size_t)w * RS_ROWS + row) * RS_NB + r] = a0 + a1;
     }
     for (int idx = threadIdx.x; idx < NS * RS_REC; idx += blockDim.x) {
-        const int s = idx / RS_REC, c = idx % RS_REC;
+        const int c = idx / NS, s = idx % NS;  // s fastest: coalesced reads of the s-major inputs
         double v = 0.0;
         if (c < 72) {
             const int lp = c / 24, j = c % 24;

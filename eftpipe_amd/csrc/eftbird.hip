@@ -252,7 +252,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     hipStream_t stc = fork ? e->stream2 : st;
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
-        hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
+        hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
                            b[EFTB_B_P11], b[EFTB_B_COEF]);
     }
@@ -314,7 +314,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & EFTB_S_RESUM) {
         if (!c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
         const size_t lds = (size_t)(c.Nkin + c.nxtail) * sizeof(double);
-        hipLaunchKernelGGL(irfilter_kernel, dim3(B), dim3(256), lds, st, c.Nkin, c.nxtail, Nl * Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
+        hipLaunchKernelGGL(irfilter_kernel, dim3(B, 2), dim3(256), lds, st, c.Nkin, c.nxtail, Nl * Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
                            tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
                            tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
                            b[EFTB_B_XY], b[EFTB_B_Q]);
