@@ -16,7 +16,7 @@ constexpr int NS = 80;       // |sbird|                         reference pybird
 constexpr int NPOW = 257;    // FFTLog powers (NFFT + 1)         reference pybird.py:919
 constexpr int NHALF = 128;
 constexpr int NCH = 129;     // independent complex coefficients
-constexpr int UPAD = 260;    // HBM row stride of u (doubles), 16-byte aligned rows
+
 constexpr int PAIR_KU = 2;  // K-steps per inner-loop iteration of the pair GEMM (tables.py KU)
 constexpr int PAIR4_STEPS = []() { int t = 0; for (int n = 0; n < 2 * NHALF + 1; n += 2) t += ((2 * NHALF - n) >> 2) + 1; return t; }();  // double steps of the 4x4x4 form
 constexpr int ULDS = 258;    // LDS row stride of u: 258 = 2 (mod 32) -> conflict-free ds_read_b64
@@ -73,27 +73,29 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// uvec: u[row] = (Re x_0..Re x_127, x_128, Im x_0..Im x_127), x_n = Coef_n * r^{p_n} with r^{p_n} from
-// the pow table of the row's abscissa (k^Pow or s^(-Pow-3); reference pybird.py:1066-1072).
-// grid (rows, B), lanes along n -> coalesced.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void uvec_kernel(int rows, const double* __restrict__ coef, const double* __restrict__ pw,
-                                                   double* __restrict__ U) {
-    const int row = blockIdx.x, w = blockIdx.y;
-    const double* c = coef + (size_t)w * 2 * NCH;
-    const double* p = pw + (size_t)row * 2 * NCH;
-    double* u = U + ((size_t)w * rows + row) * UPAD;
-    for (int n = threadIdx.x; n < UPAD; n += blockDim.x) {
-        double v = 0.0;
-        if (n < NHALF) v = c[n] * p[n] - c[NCH + n] * p[NCH + n];
-        else if (n == NHALF) v = c[NHALF] * p[NHALF];
-        else if (n < NPOW) {
-            const int q = n - NCH;
-            v = c[q] * p[NCH + q] + c[NCH + q] * p[q];
+// Stage the u tile of a pair-GEMM workgroup straight from the FFTLog coefficients (what used to be a separate uvec kernel
+// and a [rows][260] HBM round trip): u[row] = (Re x_0..Re x_127, x_128, Im x_0..Im x_127), x_n = Coef_n * r^{p_n} with
+// r^{p_n} from the pow table of the row's abscissa (k^Pow or s^(-Pow-3); reference pybird.py:1066-1072).  Lanes run along n
+// (coalesced reads of the 1 MB, L2-resident pow table); LDS row stride ULDS, column 257 and the slack after the last row are
+// zero (read by zero-weight pad pairs only).
+template <int ROWS, int NTHREADS>
+__device__ inline void stage_u_tile(double* sm, int row0, int rows_total, int rows_per_w, const double* __restrict__ coef,
+                                    const double* __restrict__ pw) {
+    for (int idx = threadIdx.x; idx < ROWS * NCH; idx += NTHREADS) {
+        const int r = idx / NCH, n = idx % NCH, grow = row0 + r;
+        double a = 0.0, b = 0.0;
+        if (grow < rows_total) {
+            const double* c = coef + (size_t)(grow / rows_per_w) * 2 * NCH;
+            const double* p = pw + (size_t)(grow % rows_per_w) * 2 * NCH;
+            const double cr = c[n], ci = c[NCH + n], pr = p[n], pi = p[NCH + n];
+            a = n < NHALF ? cr * pr - ci * pi : cr * pr;
+            b = cr * pi + ci * pr;
         }
-        u[n] = v;
+        sm[r * ULDS + n] = a;
+        if (n < NHALF) sm[r * ULDS + NCH + n] = b;
+        else sm[r * ULDS + NPOW] = 0.0;
     }
+    if (threadIdx.x < 32) sm[ROWS * ULDS + threadIdx.x] = 0.0;
 }
 
 // Linear (single-sum) terms that share the u tile of a pair GEMM workgroup: out[v] = scale * (vec[v] . u[row]).
@@ -127,7 +129,8 @@ constexpr int pair_reduce_cols(int MT, int NT, int NW) {
 // Output element (row, col) is written to out[w][col][r] (w = row / rows_per_w, r = row % rows_per_w; ncols_ld columns per w).
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NT, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double* __restrict__ U, const double* __restrict__ frag,
+__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double* __restrict__ coef, const double* __restrict__ pw,
+                                                           const double* __restrict__ frag,
                                                            const int* __restrict__ plan, int rows_total, int rows_per_w,
                                                            int nbasis, const double* __restrict__ comb, int ncols_out, int ncols_ld,
                                                            const double* __restrict__ rowscale, double* __restrict__ out,
@@ -137,14 +140,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS;
 
-    // ---- stage the u tile: 130 x 16-byte pieces per row (cols 0..259), LDS stride 258
-    for (int idx = tid; idx < ROWS * 130; idx += 64 * NW) {
-        const int r = idx / 130, c = idx % 130;
-        double2 v = make_double2(0.0, 0.0);
-        if (row0 + r < rows_total) v = *reinterpret_cast<const double2*>(U + (size_t)(row0 + r) * UPAD + 2 * c);
-        if (c < 129) *reinterpret_cast<double2*>(sm + r * ULDS + 2 * c) = v;
-    }
-    if (tid < 32) sm[ROWS * ULDS + tid] = 0.0;  // slack read by the zero-weight pad pairs of the last row
+    stage_u_tile<ROWS, 64 * NW>(sm, row0, rows_total, rows_per_w, coef, pw);
     __syncthreads();
 
     // ---- linear terms straight from the LDS tile: thread <-> (row, vector), 257 FMAs each (< 0.5 % of the workgroup)
@@ -319,7 +315,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 // pair_steps_4x4).
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const double* __restrict__ U, const double* __restrict__ frag,
+__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const double* __restrict__ coef, const double* __restrict__ pw,
+                                                                     const double* __restrict__ frag,
                                                                      const int* __restrict__ plan, int rows_total, int rows_per_w,
                                                                      int nbasis, const double* __restrict__ comb, int ncols_out, int ncols_ld,
                                                                      const double* __restrict__ rowscale, double* __restrict__ out,
@@ -328,13 +325,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const doubl
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS;
-    for (int idx = tid; idx < ROWS * 130; idx += 64 * NW) {
-        const int r = idx / 130, c = idx % 130;
-        double2 v = make_double2(0.0, 0.0);
-        if (row0 + r < rows_total) v = *reinterpret_cast<const double2*>(U + (size_t)(row0 + r) * UPAD + 2 * c);
-        if (c < 129) *reinterpret_cast<double2*>(sm + r * ULDS + 2 * c) = v;
-    }
-    if (tid < 32) sm[ROWS * ULDS + tid] = 0.0;
+    stage_u_tile<ROWS, 64 * NW>(sm, row0, rows_total, rows_per_w, coef, pw);
     __syncthreads();
 
     if (blockIdx.y == 0 && lin.nA + lin.nB > 0) {
@@ -583,38 +574,51 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
                                                       const double* __restrict__ lct, const double* __restrict__ l22,
                                                       const double* __restrict__ l13, const int* __restrict__ grp,
                                                       double* __restrict__ T) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = blockIdx.y % NROW, l = blockIdx.y / NROW, w = blockIdx.z;
+    // one lane = one k of one cosmology: reads the 28 + 10 loop pieces once and writes all Nl x 24 template rows
+    __shared__ double cf[3 * 38];  // f^power * mu-weight per (l, piece)
+    __shared__ double p0[38];      // the pieces at the first k (shot-noise subtraction, reference pybird.py:799-800)
+    __shared__ int gi[38];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    const double f = fgrow[w];
+    for (int e = threadIdx.x; e < Nl * 38; e += blockDim.x) {
+        const int l = e / 38, b = e % 38;
+        cf[e] = ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
+    }
+    for (int b = threadIdx.x; b < 38; b += blockDim.x) {
+        p0[b] = b < 28 ? P22[((size_t)w * 28 + b) * Nk] : P13[((size_t)w * 10 + (b - 28)) * Nk];
+        gi[b] = grp[2 * b];
+    }
+    __syncthreads();
     if (k >= Nk) return;
     const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
-    double v = 0.0;
-    if (row < 3) v = l11[l * 3 + row] * p11;
-    else if (row < 9) v = lct[l * 6 + (row - 3)] * kv * kv * p11;
-    else if (row < 21) {
-        const int i = row - 9;
-        const double f = fgrow[w];
-        double a = 0.0, a0 = 0.0;
-        for (int b = 0; b < 28; ++b)
-            if (grp[2 * b] == i) {
-                const double c = ipow(f, grp[2 * b + 1]) * l22[l * 28 + b];
-                const double* p = P22 + ((size_t)w * 28 + b) * Nk;
-                a += c * p[k];
-                a0 += c * p[0];
+    double acc[3][12];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[l][i] = 0.0;
+    for (int b = 0; b < 38; ++b) {
+        const double d = (b < 28 ? P22[((size_t)w * 28 + b) * Nk + k] : P13[((size_t)w * 10 + (b - 28)) * Nk + k]) - p0[b];
+        const int g = gi[b];  // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (g == i) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l)
+                    if (l < Nl) acc[l][i] = fma(cf[l * 38 + b], d, acc[l][i]);
             }
-        for (int b = 0; b < 10; ++b)
-            if (grp[2 * (28 + b)] == i) {
-                const double c = ipow(f, grp[2 * (28 + b) + 1]) * l13[l * 10 + b];
-                const double* p = P13 + ((size_t)w * 10 + b) * Nk;
-                a += c * p[k];
-                a0 += c * p[0];
-            }
-        v = a - a0;
-    } else {
-        const int j = row - 21;
-        if (l == 0 && j == 0) v = 1.0;
-        else if ((l == 0 && j == 1) || (l == 1 && j == 2)) v = kv * kv;
     }
-    T[(((size_t)w * Nl + l) * NROW + row) * Nk + k] = v;
+    for (int l = 0; l < Nl; ++l) {
+        double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[(size_t)r * Nk] = l11[l * 3 + r] * p11;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t[(size_t)(3 + r) * Nk] = lct[l * 6 + r] * kv * kv * p11;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) t[(size_t)(9 + i) * Nk] = l == 0 ? acc[0][i] : (l == 1 ? acc[1][i] : acc[2][i]);
+        t[(size_t)21 * Nk] = l == 0 ? 1.0 : 0.0;
+        t[(size_t)22 * Nk] = l == 0 ? kv * kv : 0.0;
+        t[(size_t)23 * Nk] = l == 1 ? kv * kv : 0.0;
+    }
 }
 
 // Cloopl[w][l][12][80] from CC[w][Nl*38][80] (C22 then C13; reference pybird.py:752-753, 805-846)

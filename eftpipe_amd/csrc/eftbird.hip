@@ -50,7 +50,7 @@ struct eftb_engine {
     double* buf[EFTB_B_COUNT] = {nullptr};
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
-    double *U = nullptr, *Us = nullptr, *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
+    double *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
     double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][96][8], per-s records [B][NS][80]
     double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     double *pairpartP = nullptr, *pairpartC = nullptr;  // K-split partials of the two pair GEMMs
@@ -207,7 +207,7 @@ static int pick_ksplit(int row_tiles) {
 }
 
 template <int MT, int NT, int NW>
-static void launch_pair(eftb_engine* e, hipStream_t st, const double* U, const double* frag, const int* plan, int rows, int rows_per_w,
+static void launch_pair(eftb_engine* e, hipStream_t st, const double* coef, const double* pw, const double* frag, const int* plan, int rows, int rows_per_w,
                         int nbasis, const double* comb, int ncols_out, int ncols_ld, const double* rowscale, double* out, double* part,
                         const LinTerms& lin) {
     const int tiles = (rows + MT * 16 - 1) / (MT * 16);
@@ -215,7 +215,7 @@ static void launch_pair(eftb_engine* e, hipStream_t st, const double* U, const d
     int level = 0;
     while ((1 << level) < ks) ++level;
     const int* pl = plan + 4 * NW * ((1 << level) - 1);  // plans for 1, 2, 4, 8 splits are stored back to back
-    hipLaunchKernelGGL((pair_gemm_kernel<MT, NT, NW>), dim3(tiles, ks), dim3(64 * NW), pair_lds_bytes(MT, NT, NW), st, U, frag, pl, rows, rows_per_w,
+    hipLaunchKernelGGL((pair_gemm_kernel<MT, NT, NW>), dim3(tiles, ks), dim3(64 * NW), pair_lds_bytes(MT, NT, NW), st, coef, pw, frag, pl, rows, rows_per_w,
                        nbasis, comb, ncols_out, ncols_ld, rowscale, out, part, lin);
     if (ks > 1)
         hipLaunchKernelGGL(pair_sum_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, ks, rows, rows_per_w, nbasis, comb, ncols_out, ncols_ld,
@@ -260,8 +260,6 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(stc, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
     }
-    if (mask & EFTB_S_LOOPS)
-        hipLaunchKernelGGL(uvec_kernel, dim3(Nk, B), dim3(256), 0, st, Nk, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), e->U);
     if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
         LinTerms lin{};  // P13 rides on the P22 workgroups' u tile
         if (mask & EFTB_S_LOOPS) {
@@ -272,20 +270,18 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             int level = 0;
             while ((1 << level) < ks) ++level;
             const int* pl = tb<int>(e, EFTB_T_PLANQ) + 4 * NW_P22 * ((1 << level) - 1);
-            hipLaunchKernelGGL((pair_gemm4_kernel<NW_P22>), dim3(tiles, ks), dim3(64 * NW_P22), pair_lds_bytes(4, 1, NW_P22), st, e->U,
+            hipLaunchKernelGGL((pair_gemm4_kernel<NW_P22>), dim3(tiles, ks), dim3(64 * NW_P22), pair_lds_bytes(4, 1, NW_P22), st, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW),
                                tb<double>(e, EFTB_T_PAIRS22Q), pl, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22],
                                e->pairpartP, lin);
             if (ks > 1)
                 hipLaunchKernelGGL(pair_sum_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, ks, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28,
                                    28, e->k3, e->pairpartP, b[EFTB_B_P22]);
         } else {
-            launch_pair<4, 1, NW_P22>(e, st, e->U, tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, c.nbasis,
+            launch_pair<4, 1, NW_P22>(e, st, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, c.nbasis,
                                       tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22], e->pairpartP, lin);
         }
     }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
-    if (mask & EFTB_S_CF)
-        hipLaunchKernelGGL(uvec_kernel, dim3(NS, B), dim3(256), 0, stc, NS, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), e->Us);
     if (mask & (EFTB_S_CF | EFTB_K_C22)) {
         LinTerms lin{};  // C11 and Cct ride on the C22 workgroups' u tile
         if (mask & EFTB_S_CF) {
@@ -293,10 +289,10 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             lin.nB = Nl; lin.vecB = tb<double>(e, EFTB_T_CCTR); lin.scaleB = e->sm2; lin.outB = b[EFTB_B_CCT];
         }
         if (c.ncolsC == 32)
-            launch_pair<4, 2, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
+            launch_pair<4, 2, NW_C>(e, stc, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
                                     tb<double>(e, EFTB_T_COMBC), Nl * 38, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
         else
-            launch_pair<4, 1, NW_C>(e, stc, e->Us, tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
+            launch_pair<4, 1, NW_C>(e, stc, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
                                     tb<double>(e, EFTB_T_COMBC), Nl * 38, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
     }
     if (fork) {
@@ -304,7 +300,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             return fail("eftb_run: stream join failed");
     }
     if (mask & EFTB_S_REGROUP) {
-        hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, NROW * Nl, B), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
+        hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
                            b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
                            tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_TEMPL]);
         if (c.with_resum)
@@ -438,14 +434,12 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         }
     }
     const size_t B = c.max_batch;
-    HIPCHK(hipMalloc(&e->U, B * c.Nk * UPAD * sizeof(double)));
     HIPCHK(hipMalloc(&e->k3, c.Nk * sizeof(double)));
     HIPCHK(hipMalloc(&e->sm2, NS * sizeof(double)));
     e->ldtv = (c.Nl * NPOW + 15) / 16 * 16;
     HIPCHK(hipMalloc(&e->pairpartP, (size_t)8 * B * c.Nk * 16 * sizeof(double)));
     if (c.with_resum) {
         HIPCHK(hipMalloc(&e->pairpartC, (size_t)8 * B * NS * 32 * sizeof(double)));
-        HIPCHK(hipMalloc(&e->Us, B * NS * UPAD * sizeof(double)));
     }
     HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
     if (c.with_ap) {
@@ -577,7 +571,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->U, e->Us, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);
