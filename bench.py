@@ -147,8 +147,8 @@ def main():
                                                         ("regroup", L.S_REGROUP), ("resum", L.S_RESUM), ("ap", L.S_AP), ("reduce", L.S_REDUCE))}
         # AP ping-pongs the template block; leave the state consistent
         alg_flops = 8.0 * 28 * NK * NPOW**2 * B          # F_P22 per evaluation x B
-        # MFMA flops actually issued: two v_mfma_f64_4x4x4_4b (512 flops, 8 rows x 8 columns x 4 pairs) per double step and 8-row group
-        exe_flops = 512.0 * 2 * eng.tables["steps4"].shape[0] * (NK * B / 8)
+        # MFMA flops actually issued: one v_mfma_f64_16x16x4 (2048 flops: 16 rows x (2 runs x 8 columns) x 4 pairs) per double step and 16-row tile
+        exe_flops = 2048.0 * eng.tables["steps4"].shape[0] * (NK * B / 16)
         achieved = alg_flops / (ms_p22 * 1e-3) / 1e12
         try:
             measured_peak = mfma_f64_peak(cp.local_rank)
@@ -160,7 +160,7 @@ def main():
             with open(pmc) as fh:
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         roofline = {
-            "bound": "mfma", "kernel": "pair_gemm4_kernel<16> (makeP22, v_mfma_f64_4x4x4_4b_f64)", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "bound": "mfma", "kernel": "pair_gemm2r_kernel<16> (makeP22, v_mfma_f64_16x16x4_f64, two runs per MFMA)", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
             "ms_per_launch": ms_p22, "algorithmic_flops_per_launch": alg_flops,
             "executed_mfma_flops_per_launch": exe_flops, "executed_tflops": exe_flops / (ms_p22 * 1e-3) / 1e12,

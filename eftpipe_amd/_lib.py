@@ -29,7 +29,7 @@ class Config(C.Structure):
 
 # enum eftb_table / eftb_buffer / eftb_stage (same order as the header)
 TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL KPOW SPOW PAIRS22 PAIRSC PLAN M13R C11R CCTR L11 LCT L22 L13 GRP "
-          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H MU WMU LEGMU SPBAND APFID PLANC COMB22 COMBC PAIRS22Q PLANQ RSBASIS RSBASISS RSROWS").split()
+          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H MU WMU LEGMU SPBAND APFID PLANC COMB22 COMBC PLANQ RSBASIS RSBASISS RSROWS PAIRS22D").split()
 T = {n: i for i, n in enumerate(TABLES)}
 BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF".split()
 B = {n: i for i, n in enumerate(BUFFERS)}

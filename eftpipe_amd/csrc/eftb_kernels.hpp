@@ -18,7 +18,8 @@ constexpr int NHALF = 128;
 constexpr int NCH = 129;     // independent complex coefficients
 
 constexpr int PAIR_KU = 2;  // K-steps per inner-loop iteration of the pair GEMM (tables.py KU)
-constexpr int PAIR4_STEPS = []() { int t = 0; for (int n = 0; n < 2 * NHALF + 1; n += 2) t += ((2 * NHALF - n) >> 2) + 1; return t; }();  // double steps of the 4x4x4 form
+constexpr int PAIR4_STEPS = []() { int t = 0; for (int n = 0; n < 2 * NHALF + 1; n += 2) t += ((2 * NHALF - n) >> 2) + 1; return t; }();  // double steps of the two-run form (tables.py pair_steps_2run)
+constexpr int PAIR4_PF = 4;     // prefetch depth (double steps) of the two-run fragment stream; the host pads the table with as many zero steps
 constexpr int ULDS = 258;    // LDS row stride of u: 258 = 2 (mod 32) -> conflict-free ds_read_b64
 constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl) + 12 (Ploopl) + 3 (Pstl)
 
@@ -151,12 +152,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
             const bool famA = v < lin.nA;
             const double* vec = famA ? lin.vecA + (size_t)v * NPOW : lin.vecB + (size_t)(v - lin.nA) * NPOW;
             const double* ur = sm + rr * ULDS;
-            double a0 = 0.0, a1 = 0.0;
-            for (int nn = 0; nn < NPOW - 1; nn += 2) {
-                a0 = fma(vec[nn], ur[nn], a0);
-                a1 = fma(vec[nn + 1], ur[nn + 1], a1);
+            // 8 independent chains, operands fetched in batches (v_fma_f64: 32-cycle dependent latency)
+            double ac[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ac[q] = 0.0;
+            for (int nn = 0; nn < NPOW - 1; nn += 8) {
+                double vv[8], uu[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    vv[q] = vec[nn + q];
+                    uu[q] = ur[nn + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ac[q] = fma(vv[q], uu[q], ac[q]);
             }
-            double d = (a0 + a1) + vec[NPOW - 1] * ur[NPOW - 1];
+            double d = (((ac[0] + ac[1]) + (ac[2] + ac[3])) + ((ac[4] + ac[5]) + (ac[6] + ac[7]))) + vec[NPOW - 1] * ur[NPOW - 1];
             const int w = grow / rows_per_w, rw = grow % rows_per_w;
             if (famA) {
                 if (lin.scaleA) d *= lin.scaleA[rw];
@@ -305,23 +315,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double
 }
 
 // ------------------------------------------------------------------------------------------------
-// pair GEMM for <= 8 basis columns on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction,
-// issued every ~16 cycles).  With only 7 useful columns the 16x16x4 form wastes 9 of its 16 columns; here the four
-// blocks are (rows 0-3 | 4-7) x (columns 0-3 | 4-7) of an 8-row group, so 7 of 8 columns are useful and the same
-// pairs cost half the matrix-pipe time.  Measured lane maps (tools/probe/mfma4_probe.hip):
-//   A[blk][i][k] at lane 16 k + 4 blk + i,  B[blk][k][j] at lane 16 k + 4 blk + j,  D[blk][i][j] at lane 16 i + 4 blk + j.
-// Workgroup = NW waves = 64 rows (8 row groups per wave), K split NW ways; same LDS u tile, plans, linear terms,
-// workgroup-level K split and epilogue expansion as pair_gemm_kernel; the n-runs are walked two at a time (tables.py
-// pair_steps_4x4).
+// pair GEMM for <= 8 basis columns on v_mfma_f64_16x16x4_f64 with the 16 MFMA columns shared by TWO runs: columns
+// 0-7 carry the basis weights of pairs (n, m), columns 8-15 those of (n + 1, m), both against the same raw u operand
+// (double steps of tables.py pair_steps_2run).  14 of 16 columns do useful work (7 of 16 in the single-run form), and
+// unlike v_mfma_f64_4x4x4_4b -- which in this loop sustains only ~19-20 cycles per 512 flops, measured with operand
+// fetches removed -- the 16x16x4 form runs at its nominal 64 cycles per 2048 flops.  Per double step and wave: four
+// MFMAs, four LDS operand reads, one 512-byte fragment.  The run factors u_n (columns 0-7) and u_n+1 (columns 8-15)
+// multiply the run accumulator once, in the D layout; the two column halves are added in the epilogue reduction.
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const double* __restrict__ coef, const double* __restrict__ pw,
+__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm2r_kernel(const double* __restrict__ coef, const double* __restrict__ pw,
                                                                      const double* __restrict__ frag,
                                                                      const int* __restrict__ plan, int rows_total, int rows_per_w,
                                                                      int nbasis, const double* __restrict__ comb, int ncols_out, int ncols_ld,
                                                                      const double* __restrict__ rowscale, double* __restrict__ out,
                                                                      double* __restrict__ part, LinTerms lin) {
-    constexpr int ROWS = 64, RG = 8;  // 8 row groups of 8 rows
+    constexpr int ROWS = 64, MT = 4;  // four 16-row MFMA tiles
     extern __shared__ double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS;
@@ -335,12 +344,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const doubl
             const bool famA = v < lin.nA;
             const double* vec = famA ? lin.vecA + (size_t)v * NPOW : lin.vecB + (size_t)(v - lin.nA) * NPOW;
             const double* ur = sm + rr * ULDS;
-            double a0 = 0.0, a1 = 0.0;
-            for (int nn = 0; nn < NPOW - 1; nn += 2) {
-                a0 = fma(vec[nn], ur[nn], a0);
-                a1 = fma(vec[nn + 1], ur[nn + 1], a1);
+            // 8 independent chains, operands fetched in batches (v_fma_f64: 32-cycle dependent latency)
+            double ac[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ac[q] = 0.0;
+            for (int nn = 0; nn < NPOW - 1; nn += 8) {
+                double vv[8], uu[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    vv[q] = vec[nn + q];
+                    uu[q] = ur[nn + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ac[q] = fma(vv[q], uu[q], ac[q]);
             }
-            double d = (a0 + a1) + vec[NPOW - 1] * ur[NPOW - 1];
+            double d = (((ac[0] + ac[1]) + (ac[2] + ac[3])) + ((ac[4] + ac[5]) + (ac[6] + ac[7]))) + vec[NPOW - 1] * ur[NPOW - 1];
             const int w = grow / rows_per_w, rw = grow % rows_per_w;
             if (famA) {
                 if (lin.scaleA) d *= lin.scaleA[rw];
@@ -353,72 +371,85 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm4_kernel(const doubl
         }
     }
 
-    const int kq = lane >> 4, blk = (lane >> 2) & 3, rowl = 4 * (blk >> 1) + (lane & 3);
+    const int r = lane & 15, g = lane >> 4;
     const int* pl = plan + (blockIdx.y * NW + wave) * 4;
     int n = __builtin_amdgcn_readfirstlane(pl[0]);   // even: the double run (n, n + 1)
-    int m0 = __builtin_amdgcn_readfirstlane(pl[1]);
+    const int m0 = __builtin_amdgcn_readfirstlane(pl[1]);
     const int t0 = __builtin_amdgcn_readfirstlane(pl[2]);
-    int nsteps = __builtin_amdgcn_readfirstlane(pl[3]);
-    const double* fp = frag + (size_t)t0 * 128 + lane;
+    const int nsteps = __builtin_amdgcn_readfirstlane(pl[3]);
+    const double* fp = frag + (size_t)t0 * 64 + lane;
 
-    double acc[RG];
+    v4d acc[MT], racc[MT];
 #pragma unroll
-    for (int t = 0; t < RG; ++t) acc[t] = 0.0;
-    double b0 = fp[0], b1 = fp[64];  // B fragments of runs n and n + 1, prefetched one double step ahead
-    fp += 128;
+    for (int i = 0; i < MT; ++i) acc[i] = racc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    // fragment stream prefetched PAIR4_PF double steps ahead through a register ring (fixed slots: the step loop is
+    // unrolled PAIR4_PF times; the stream is continuous across run boundaries, which are wave-uniform scalar branches)
+    double bq[PAIR4_PF];
+#pragma unroll
+    for (int q = 0; q < PAIR4_PF; ++q) bq[q] = fp[q * 64];
+    fp += PAIR4_PF * 64;
 
-    const double* urow = sm + rowl * ULDS;                                // A side: row group t adds 8 t rows
-    const double* drow = sm + (4 * (blk >> 1) + (lane >> 4)) * ULDS;      // D side: this lane's output row within a group
-    while (nsteps > 0) {
-        // one double run as two plain GEMMs that share the raw u operand (one LDS read feeds two MFMAs: the A operand of
-        // the 4x4x4 form costs 1 B/flop, exactly the LDS bandwidth at the MFMA peak, so unshared reads cap it near 60 %);
-        // the factors u_n, u_n+1 multiply the runs' accumulators once (D layout)
-        const int run = ((2 * NHALF - n) >> 2) + 1;
-        const int left = run - ((m0 - n) >> 2);
-        const int cnt = left < nsteps ? left : nsteps;
-        double ra[RG], rb[RG], um[RG];
+    const double* urow = sm + r * ULDS + g;                 // A side: tile i adds 16 i rows; K index g
+    const double* drow = sm + g * ULDS + (r >> 3);          // D side: rows g + 4 q (+ 16 i), run n + (column >> 3)
+    int left = (((2 * NHALF - n) >> 2) + 1) - ((m0 - n) >> 2);  // steps left in the current double run
+    const double* up = urow + m0;
+    double um[MT];
 #pragma unroll
-        for (int t = 0; t < RG; ++t) ra[t] = rb[t] = 0.0;
-        const double* up = urow + m0 + kq;
+    for (int i = 0; i < MT; ++i) um[i] = up[i * 16 * ULDS];
+    for (int base = 0; base < nsteps; base += PAIR4_PF) {
 #pragma unroll
-        for (int t = 0; t < RG; ++t) um[t] = up[t * 8 * ULDS];
-        for (int it = 0; it < cnt; ++it) {
-            double umn[RG];
-            const double bn0 = fp[0], bn1 = fp[64];
-            fp += 128;
-            up += 4;
+        for (int q = 0; q < PAIR4_PF; ++q) {
+            if (base + q < nsteps) {
+                const bool last = left == 1;
+                const double* upn = last ? urow + (n + 2) : up + 4;  // next step: same run, or the start of the next one
+                double umn[MT];
 #pragma unroll
-            for (int t = 0; t < RG; ++t) umn[t] = up[t * 8 * ULDS];
+                for (int i = 0; i < MT; ++i) umn[i] = upn[i * 16 * ULDS];
 #pragma unroll
-            for (int t = 0; t < RG; ++t) {
-                ra[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(um[t], b0, ra[t], 0, 0, 0);
-                rb[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(um[t], b1, rb[t], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) racc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(um[i], bq[q], racc[i], 0, 0, 0);
+                bq[q] = fp[0];  // this slot's next use is PAIR4_PF steps away
+                fp += 64;
+                if (last) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            acc[i][qq] = fma(drow[(16 * i + 4 * qq) * ULDS + n], racc[i][qq], acc[i][qq]);
+                            racc[i][qq] = 0.0;
+                        }
+                    n += 2;
+                    left = ((2 * NHALF - n) >> 2) + 1;
+                } else {
+                    --left;
+                }
+                up = upn;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) um[i] = umn[i];
             }
-            b0 = bn0;
-            b1 = bn1;
-#pragma unroll
-            for (int t = 0; t < RG; ++t) um[t] = umn[t];
         }
-#pragma unroll
-        for (int t = 0; t < RG; ++t) acc[t] = fma(drow[t * 8 * ULDS + n], ra[t], fma(drow[t * 8 * ULDS + n + 1], rb[t], acc[t]));
-        nsteps -= cnt;
-        n += 2;
-        m0 = n;
     }
-
-    // ---- reduce the NW K slices: red[wave][t][lane] -> bas[row][col] (8 columns), then expand / hand over
-    __syncthreads();
-    double* bas = sm + NW * RG * 64;
+    // the slice may end inside a run: fold the open accumulators (zero if the run was just closed; n <= 258 stays inside the
+    // zero-padded tile)
 #pragma unroll
-    for (int t = 0; t < RG; ++t) sm[(wave * RG + t) * 64 + lane] = acc[t];
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[i][qq] = fma(drow[(16 * i + 4 * qq) * ULDS + n], racc[i][qq], acc[i][qq]);
+
+    // ---- reduce the NW K slices and the two column halves: red[wave][i][q][lane] -> bas[row][col] (8 columns)
+    __syncthreads();
+    double* bas = sm + NW * MT * 4 * 64;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) sm[((wave * MT + i) * 4 + qq) * 64 + lane] = acc[i][qq];
     __syncthreads();
     for (int e = tid; e < ROWS * 8; e += 64 * NW) {
         const int row = e >> 3, col = e & 7;
-        const int t = row >> 3, rl = row & 7;
-        const int lo = 16 * (rl & 3) + 4 * (2 * (rl >> 2) + (col >> 2)) + (col & 3);
+        const int i = row >> 4, rr = row & 15, qq = rr >> 2, gg = rr & 3;
+        const int lo = (i * 4 + qq) * 64 + gg * 16 + col;
         double v = 0.0;
 #pragma unroll
-        for (int w8 = 0; w8 < NW; ++w8) v += sm[(w8 * RG + t) * 64 + lo];
+        for (int w8 = 0; w8 < NW; ++w8) v += sm[w8 * MT * 4 * 64 + lo] + sm[w8 * MT * 4 * 64 + lo + 8];
         bas[row * 8 + col] = v;
     }
     __syncthreads();

@@ -127,7 +127,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_KPOW: return D * c.Nk * 2 * NCH;
         case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
         case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + PAIR_KU) * 1 * 64;
-        case EFTB_T_PAIRS22Q: return c.nbasis <= 8 ? D * (size_t)(PAIR4_STEPS + 1) * 128 : 0;
+        case EFTB_T_PAIRS22D: return c.nbasis <= 8 ? D * (size_t)(PAIR4_STEPS + PAIR4_PF) * 64 : 0;
         case EFTB_T_PLANQ: return c.nbasis <= 8 ? sizeof(int32_t) * 4 * NW_P22 * 15 : 0;
         case EFTB_T_COMB22: return D * 28 * c.nbasis;
         case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 38 * c.ncolsC : 0;
@@ -184,6 +184,11 @@ template <typename T>
 static inline const T* tb(const eftb_engine* e, int id) { return static_cast<const T*>(e->tab[id]); }
 
 // dynamic LDS of pair_gemm_kernel<MT, NT>: the u tile (+ slack) or the 4-way reduction buffer
+static constexpr size_t pair2r_lds_bytes(int NW) {
+    const size_t tile = (size_t)(64 * ULDS + 32) * sizeof(double), red = ((size_t)NW * 4 * 4 * 64 + 64 * 8) * sizeof(double);
+    return tile > red ? tile : red;
+}
+
 static constexpr size_t pair_lds_bytes(int MT, int NT, int NW) {
     const size_t tile = (size_t)(MT * 16 * ULDS + 32) * sizeof(double);
     const size_t red = ((size_t)NW * MT * pair_reduce_cols(MT, NT, NW) * 4 * 64 + (size_t)MT * 16 * NT * 16) * sizeof(double);
@@ -265,14 +270,14 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (mask & EFTB_S_LOOPS) {
             lin.nA = 10; lin.vecA = tb<double>(e, EFTB_T_M13R); lin.scaleA = e->k3; lin.rowdata = b[EFTB_B_P11]; lin.outA = b[EFTB_B_P13];
         }
-        if (c.nbasis <= 8) {  // 4x4x4 matrix-core form: 7 of 8 columns useful instead of 7 of 16
+        if (c.nbasis <= 8) {  // two runs share the 16 MFMA columns: 14 of 16 useful instead of 7 of 16
             const int rows = B * Nk, tiles = (rows + 63) / 64, ks = pick_ksplit(tiles);
             int level = 0;
             while ((1 << level) < ks) ++level;
             const int* pl = tb<int>(e, EFTB_T_PLANQ) + 4 * NW_P22 * ((1 << level) - 1);
-            hipLaunchKernelGGL((pair_gemm4_kernel<NW_P22>), dim3(tiles, ks), dim3(64 * NW_P22), pair_lds_bytes(4, 1, NW_P22), st, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW),
-                               tb<double>(e, EFTB_T_PAIRS22Q), pl, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22],
-                               e->pairpartP, lin);
+                hipLaunchKernelGGL((pair_gemm2r_kernel<NW_P22>), dim3(tiles, ks), dim3(64 * NW_P22), pair2r_lds_bytes(NW_P22), st, b[EFTB_B_COEF],
+                                   tb<double>(e, EFTB_T_KPOW), tb<double>(e, EFTB_T_PAIRS22D), pl, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28,
+                                   28, e->k3, b[EFTB_B_P22], e->pairpartP, lin);
             if (ks > 1)
                 hipLaunchKernelGGL(pair_sum_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, ks, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28,
                                    28, e->k3, e->pairpartP, b[EFTB_B_P22]);
@@ -497,7 +502,7 @@ int eftb_finalize(eftb_engine* e) {
     }
     // opt in to the large dynamic LDS tiles of the pair GEMM
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm2r_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -35,8 +35,8 @@ def wave_plan(steps, nwaves=8):
 RUN_COST = float(os.environ.get("EFTB_PLAN_RUNCOST", "3"))  # cost of starting / closing a run, in double steps
 
 
-def wave_plan_4x4(steps4, nwaves):
-    """Same for the double-run steps of the 4x4x4 kernel (no KU padding there).  Slices are balanced on
+def wave_plan_2run(steps4, nwaves):
+    """Same for the double-run steps of pair_gemm2r_kernel (no KU padding there).  Slices are balanced on
     steps + RUN_COST * (runs touched): the tail of the table is made of many short runs whose per-run epilogue
     (accumulator scaling by u_n) would otherwise make the last waves the slowest."""
     T = len(steps4)
@@ -114,9 +114,9 @@ class Engine:
         self._set("LNXTAIL", t["lnx_tail"])
         self._set("KPOW", t["kpow"])
         self._set("PAIRS22", _padded_fragments(t["pairs22"]))
-        if "pairs22q" in t:  # one zero double step: the kernel prefetches one iteration ahead
-            self._set("PAIRS22Q", np.concatenate([t["pairs22q"], np.zeros((1, 2, 64))]))
-            self._set("PLANQ", split_plans(t["steps4"], NW_P22, wave_plan_4x4), np.int32)
+        if "pairs22d" in t:  # zero double steps at the end: the kernel prefetches PAIR4_PF = 4 steps ahead
+            self._set("PAIRS22D", np.concatenate([t["pairs22d"], np.zeros((4, 64))]))
+            self._set("PLANQ", split_plans(t["steps4"], NW_P22, wave_plan_2run), np.int32)
         self._set("PLAN", split_plans(t["steps"], NW_P22), np.int32)
         self._set("M13R", t["m13r"])
         self._set("COMB22", t["comb22"])

@@ -185,35 +185,33 @@ def pair_fragments(R, ncols_pad):
     return np.ascontiguousarray(frag.reshape(len(st), ncols_pad // 16, 16, 4).transpose(0, 1, 3, 2))
 
 
-def pair_steps_4x4():
-    """K-steps of the 4x4x4 form of the pair contraction: step t covers pairs (n, m0..m0+3) AND (n+1, m0..m0+3) for an even
-    n (a "double run": both runs read the same u[m0..m0+3] operand, which halves the LDS traffic per MFMA)."""
+def pair_steps_2run():
+    """K-steps of the two-run form of the pair contraction: step t covers pairs (n, m0..m0+3) AND (n+1, m0..m0+3) for an
+    even n (a "double run": both runs read the same u[m0..m0+3] operand and share the 16 columns of one MFMA)."""
     out = []
     for n in range(0, NPOW, 2):
         out += [(n, n + 4 * j) for j in range(((NPOW - 1 - n) >> 2) + 1)]
     return np.array(out, dtype=np.int32)
 
 
-def pair_fragments_4x4(R):
-    """R[cols <= 8, 257, 257] -> B fragments of v_mfma_f64_4x4x4_4b_f64, [T, 2, 64] (f64): for run r of double step t, lane
-    16 k + 4 blk + j holds the weight of pair (n_t + r, m0_t + k) for column 4 (blk & 1) + j (the two row-half blocks blk >> 1
-    carry the same values); pairs with m < n + r or beyond the table are zero."""
+def pair_fragments_2run(R):
+    """R[cols <= 8, 257, 257] -> B fragments of v_mfma_f64_16x16x4_f64 for the double steps of pair_steps_2run, [T, 64] (f64):
+    lane 16 g + c holds the weight of pair (n_t + (c >> 3), m0_t + g) for basis column c & 7 (two runs share the 16 MFMA
+    columns); pairs with m < n + (c >> 3) or beyond the table are zero."""
     ncols = R.shape[0]
     assert ncols <= 8
-    st = pair_steps_4x4()
+    st = pair_steps_2run()
     Rs = R + np.swapaxes(R, 1, 2)
     idx = np.arange(NPOW)
     Rs[:, idx, idx] = R[:, idx, idx]
-    w = np.zeros((len(st), 2, 4, 8))                    # [t, run, k, col]
+    w = np.zeros((len(st), 4, 16))                      # [t, g, c]
     for r in range(2):
         n = st[:, 0] + r
-        for k in range(4):
-            m = st[:, 1] + k
+        for g in range(4):
+            m = st[:, 1] + g
             ok = (m < NPOW) & (n < NPOW) & (m >= n)
-            w[ok, r, k, :ncols] = Rs[:, n[ok], m[ok]].T
-    lane = np.arange(64)
-    kq, blk, j = lane >> 4, (lane >> 2) & 3, lane & 3
-    return np.ascontiguousarray(w[:, :, kq, 4 * (blk & 1) + j])
+            w[ok, g, 8 * r : 8 * r + ncols] = Rs[:, n[ok], m[ok]].T
+    return np.ascontiguousarray(w.reshape(len(st), 64))
 
 
 # ----------------------------------------------------------------------------- cubic spline (not-a-knot)
@@ -342,8 +340,8 @@ def build_tables(cfg: EngineConfig) -> dict:
     t["steps"] = pair_steps()
     t["pairs22"] = pair_fragments(R22, 16)
     if nb <= 8:
-        t["steps4"] = pair_steps_4x4()
-        t["pairs22q"] = pair_fragments_4x4(R22)
+        t["steps4"] = pair_steps_2run()
+        t["pairs22d"] = pair_fragments_2run(R22)
     t["m13r"] = np.ascontiguousarray(reduce_linear(M13))                 # [10,257]
     resid = [im22]
     if cfg.with_resum:

@@ -52,8 +52,9 @@ enum eftb_table {
     EFTB_T_CCTR, EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
     EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
     EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
-    EFTB_T_PLANC, EFTB_T_COMB22, EFTB_T_COMBC, EFTB_T_PAIRS22Q, EFTB_T_PLANQ,
+    EFTB_T_PLANC, EFTB_T_COMB22, EFTB_T_COMBC, EFTB_T_PLANQ,
     EFTB_T_RSBASIS, EFTB_T_RSBASISS, EFTB_T_RSROWS,   /* matrix-core IR-resummation (Nl = 3): tables.py resum_mfma_tables */
+    EFTB_T_PAIRS22D,                                   /* two-run 16x16x4 fragments of P22: tables.py pair_fragments_2run */
     EFTB_T_COUNT
 };
 

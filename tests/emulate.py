@@ -42,19 +42,15 @@ def pair_contract(u, frag, steps):
     return out
 
 
-def pair_contract_4x4(u, frag, steps4):
-    """u [rows,257], frag [T,2,64] (v_mfma_f64_4x4x4 B fragments of the double runs) -> [rows, 8]"""
+def pair_contract_2run(u, frag, steps4):
+    """u [rows,257], frag [T,64] (16x16x4 fragments, lane 16 g + c: run c >> 3, column c & 7) -> [rows, 8]"""
     up = np.concatenate([u, np.zeros((u.shape[0], 16))], axis=1)
-    lane = np.arange(64)
-    kq, blk, j = lane >> 4, (lane >> 2) & 3, lane & 3
+    f = frag.reshape(-1, 4, 2, 8)  # [t, g, run, col]
     out = np.zeros((u.shape[0], 8))
     for r in range(2):
-        un = up[:, steps4[:, 0] + r]  # [rows,T]
-        for k in range(4):
-            v = un * up[:, steps4[:, 1] + k]
-            for b in range(2):  # column halves; the row-half blocks blk >> 1 hold copies
-                sel = (kq == k) & (blk == b)
-                out[:, 4 * b : 4 * b + 4] += v @ frag[:, r, sel]
+        un = up[:, steps4[:, 0] + r]
+        for g in range(4):
+            out += (un * up[:, steps4[:, 1] + g]) @ f[:, g, r, :]
     return out
 
 

@@ -55,20 +55,20 @@ def test_device_algebra_matches_oracle(golden, name, resum, ap):
             assert relerr(st[n], g["ap_" + n]) < 1e-9, n
 
 
-def test_4x4_double_run_fragments_match_16x16(golden):
-    """The v_mfma_f64_4x4x4 double-run table contracts to the same basis columns as the 16x16x4 table."""
+def test_two_run_fragments_match_single_run(golden):
+    """The two-run (double step) fragment table contracts to the same basis columns as the single-run table."""
     g = golden("caseA")
     t = _tables(g, False, False)
     c = E.coef_half(t, g["Pin"])
     U = E.reduced_vectors(c, t["kpow"])
     nb = t["comb22"].shape[1]
     a = E.pair_contract(U, t["pairs22"], t["steps"])[:, :nb]
-    b = E.pair_contract_4x4(U, t["pairs22q"], t["steps4"])[:, :nb]
+    b = E.pair_contract_2run(U, t["pairs22d"], t["steps4"])[:, :nb]
     assert relerr(b.T, a.T) < 1e-8  # different summation order of a cancelling sum
     # every wave slice of every K split starts on a step of its (even) run
-    from eftpipe_amd.engine import NW_P22, split_plans, wave_plan_4x4
+    from eftpipe_amd.engine import NW_P22, split_plans, wave_plan_2run
 
-    pl = split_plans(t["steps4"], NW_P22, wave_plan_4x4)
+    pl = split_plans(t["steps4"], NW_P22, wave_plan_2run)
     assert np.all(pl[:, 0] % 2 == 0) and np.all((pl[:, 1] - pl[:, 0]) % 4 == 0) and np.all(pl[:, 3] > 0)
     for ks, off in ((1, 0), (2, 1), (4, 3), (8, 7)):
         q = pl[off * NW_P22 : (off + ks) * NW_P22]

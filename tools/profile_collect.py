@@ -47,7 +47,7 @@ json.dump(avg, open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w"), inden
 
 bench = json.load(open(os.path.join(src, "bench.json")))
 stats = {short(r["Name"]): r for r in csv.DictReader(open(find("stats_kernel_stats.csv")))}
-dom = next(k for k in avg if k.startswith("eftb::pair_gemm4_kernel"))
+dom = next(k for k in avg if k.startswith("eftb::pair_gemm2r_kernel"))
 c = avg[dom]
 B, NK = bench["config"]["batch_per_gpu"], 512
 out = {
