@@ -880,16 +880,16 @@ __global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int sc
 // so every (l, row, k) is written by exactly one lane and no cross-lane reduction is needed.  The loop has no branches
 // (lane roles are applied through zeroed weights), which keeps hipcc from shuffling MFMA results through AGPRs.
 // resum_prep_kernel builds, per cosmology, A = Q(f) diag(RS_ZS^p) V8^T and the per-s records
-//   RSC[w][s] = { [l'][24]: l11[l',0..2] C11[l'], lct[l',0..5] Cct[l'], Cloopl[l',0..11], 0 0 0 } , X, Y, pad  (80 doubles).
+//   RSC[w][s] = { [l'][14]: C11[l'], Cct[l'], Cloopl[l',0..11] } , X, Y, pad  (48 doubles);
+// the mu weights l11 / lct multiply the s-sums once, at the end.
 // ------------------------------------------------------------------------------------------------
 constexpr double RS_ZS = 8.0;  // tables.py RS_ZS
-constexpr int RS_NB = 8, RS_ROWS = 96, RS_REC = 80;
+constexpr int RS_NB = 8, RS_ROWS = 96, RS_REC = 48;
 
 __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na, const double* __restrict__ Q,
                                                          const double* __restrict__ V8S, const int* __restrict__ rows,
                                                          const double* __restrict__ XY, const double* __restrict__ C11,
                                                          const double* __restrict__ Cct, const double* __restrict__ Cloopl,
-                                                         const double* __restrict__ l11, const double* __restrict__ lct,
                                                          double* __restrict__ RSA, double* __restrict__ RSC) {
     constexpr int NL = 3;
     const int w = blockIdx.x;
@@ -907,13 +907,13 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
     for (int idx = threadIdx.x; idx < NS * RS_REC; idx += blockDim.x) {
         const int c = idx / NS, s = idx % NS;  // s fastest: coalesced reads of the s-major inputs
         double v = 0.0;
-        if (c < 72) {
-            const int lp = c / 24, j = c % 24;
-            if (j < 3) v = l11[lp * 3 + j] * C11[((size_t)w * NL + lp) * NS + s];
-            else if (j < 9) v = lct[lp * 6 + (j - 3)] * Cct[((size_t)w * NL + lp) * NS + s];
-            else if (j < 21) v = Cloopl[(((size_t)w * NL + lp) * 12 + (j - 9)) * NS + s];
-        } else if (c < 74) {
-            v = XY[(size_t)w * 2 * NS + (c - 72) * NS + s];
+        if (c < 42) {
+            const int lp = c / 14, j = c % 14;
+            if (j == 0) v = C11[((size_t)w * NL + lp) * NS + s];
+            else if (j == 1) v = Cct[((size_t)w * NL + lp) * NS + s];
+            else v = Cloopl[(((size_t)w * NL + lp) * 12 + (j - 2)) * NS + s];
+        } else if (c < 44) {
+            v = XY[(size_t)w * 2 * NS + (c - 42) * NS + s];
         }
         RSC[((size_t)w * NS + s) * RS_REC + c] = v;
     }
@@ -930,6 +930,7 @@ __device__ inline double estrin16(const double* __restrict__ c, double t, double
 __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
                                                             const double* __restrict__ H, const double* __restrict__ V8,
                                                             const double* __restrict__ RSA, const double* __restrict__ RSC,
+                                                            const double* __restrict__ l11, const double* __restrict__ lct,
                                                             double* __restrict__ T, double* __restrict__ part, int nsplit) {
     constexpr int NL = 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -951,32 +952,56 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
         for (int t = 0; t < 2; ++t) aop[tau][t] = RSA[((size_t)w * RS_ROWS + 16 * tau + n) * RS_NB + jg + 4 * t];
     // lane roles as weights (no branches in the s loop)
     const double r1 = jg < 3 ? 1.0 : 0.0, r0 = jg < 3 ? 0.0 : 1.0;
-    double accL[18], accA0[3], accB[3];
+    double accL[12], accCt[3], acc11A[3], acc11B[3];  // s-sums: W Cloopl[l',i] (summed over l'), W Cct[l'], W C11[l'] (tiles 0-2 / 3-5)
 #pragma unroll
-    for (int i = 0; i < 18; ++i) accL[i] = 0.0;
+    for (int i = 0; i < 12; ++i) accL[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) accA0[i] = accB[i] = 0.0;
+    for (int i = 0; i < 3; ++i) accCt[i] = acc11A[i] = acc11B[i] = 0.0;
     const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
-    double hn[3];
+    const double* ct = RSC + ((size_t)w * NS + s0) * RS_REC;  // wave-uniform record of the current s
+    double h[3];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) hn[v] = H[((size_t)v * NS + s0) * Nk + kc];
+    for (int v = 0; v < 3; ++v) h[v] = H[((size_t)v * NS + s0) * Nk + kc];
+    double z = k2 * ct[42], y = k2 * ct[43];
+    double b0, b1;
+    {
+        const double t = z * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
+        b0 = estrin16(vb[0], t, t2, t4, t8);
+        b1 = estrin16(vb[1], t, t2, t4, t8);
+    }
+    // keep the A operand in registers (hipcc would otherwise re-load it from memory every step)
+#pragma unroll
+    for (int tau = 0; tau < 6; ++tau)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(aop[tau][t]));
     for (int s = s0; s < s1; ++s) {
-        const double* ct = RSC + ((size_t)w * NS + s) * RS_REC;  // wave-uniform record
-        double h[3];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) h[v] = hn[v];
+        // memory first: this step's C columns (scalar loads, consumed after the MFMAs) and the next step's X, Y, H
         const int sn = s + 1 < s1 ? s + 1 : s;
+        const double* ctn = RSC + ((size_t)w * NS + sn) * RS_REC;
+        double cv[42];
+#pragma unroll
+        for (int i = 0; i < 42; ++i) cv[i] = ct[i];
+        const double xn = ctn[42], yn0 = ctn[43];
+        double hn[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) hn[v] = H[((size_t)v * NS + sn) * Nk + kc];
-        const double z = k2 * ct[72], y = k2 * ct[73];
-        const double t = z * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
-        const double b0 = estrin16(vb[0], t, t2, t4, t8), b1 = estrin16(vb[1], t, t2, t4, t8);
+        __builtin_amdgcn_sched_barrier(0);
+        // all twelve MFMAs of this step (six independent accumulators) ...
         v4d D[6];
 #pragma unroll
-        for (int tau = 0; tau < 6; ++tau) {
-            D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-            D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
+        for (int tau = 0; tau < 6; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+        for (int tau = 0; tau < 6; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ... under them the basis polynomials of the next step ...
+        const double zn = k2 * xn, yn = k2 * yn0;
+        double bn0, bn1;
+        {
+            const double t = zn * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
+            bn0 = estrin16(vb[0], t, t2, t4, t8);
+            bn1 = estrin16(vb[1], t, t2, t4, t8);
         }
+        // ... and the contraction of this step
         double zh[3], yh[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
@@ -987,49 +1012,64 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
         for (int tau = 0; tau < 3; ++tau) {
             const double W = fma(zh[tau], D[tau][0], fma(yh[0], D[tau][1], fma(yh[1], D[tau][2], yh[2] * D[tau][3])));
             const double W1 = W * r1, W0 = W * r0;
-            const double* c = ct + tau * 24;
+            acc11A[tau] = fma(W0, cv[tau * 14], acc11A[tau]);
+            accCt[tau] = fma(W1, cv[tau * 14 + 1], accCt[tau]);
 #pragma unroll
-            for (int i = 0; i < 18; ++i) accL[i] = fma(W1, c[3 + i], accL[i]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) accA0[i] = fma(W0, c[i], accA0[i]);
+            for (int i = 0; i < 12; ++i) accL[i] = fma(W1, cv[tau * 14 + 2 + i], accL[i]);
         }
 #pragma unroll
         for (int tau = 3; tau < 6; ++tau) {
             const double W = fma(zh[tau - 3], D[tau][0], fma(yh[0], D[tau][1], fma(yh[1], D[tau][2], yh[2] * D[tau][3])));
-            const double* c = ct + (tau - 3) * 24;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) accB[i] = fma(W, c[i], accB[i]);
+            acc11B[tau - 3] = fma(W, cv[(tau - 3) * 14], acc11B[tau - 3]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        ct = ctn;
+        z = zn;
+        y = yn;
+        b0 = bn0;
+        b1 = bn1;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) h[v] = hn[v];
     }
     if (!live) return;
-    // (a, l) blocks of this lane -> output rows
+    // (a, l) blocks of this lane -> output rows, mu weights applied to the s-sums
+    double o18[18], oA[3], oB[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o18[i] = lct[i] * accCt[0] + lct[6 + i] * accCt[1] + lct[12 + i] * accCt[2];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o18[6 + i] = accL[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        oA[i] = l11[i] * acc11A[0] + l11[3 + i] * acc11A[1] + l11[6 + i] * acc11A[2];
+        oB[i] = l11[i] * acc11B[0] + l11[3 + i] * acc11B[1] + l11[6 + i] * acc11B[2];
+    }
     if (nsplit == 1) {
         if (jg < 3) {
             double* dst = T + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
 #pragma unroll
-            for (int i = 0; i < 18; ++i) dst[(size_t)i * Nk] += accL[i];
+            for (int i = 0; i < 18; ++i) dst[(size_t)i * Nk] += o18[i];
         } else {
             double* dst = T + (((size_t)w * NL + 0) * NROW) * Nk + k;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += accA0[i];
+            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += oA[i];
         }
         if (jg < 2) {
             double* dst = T + (((size_t)w * NL + jg + 1) * NROW) * Nk + k;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += accB[i];
+            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += oB[i];
         }
     } else {  // partial sums over the s slices, added in a fixed order by resum_sum_kernel
         double* pw = part + ((size_t)w * nsplit + split) * NL * 21 * Nk + k;
         if (jg < 3) {
 #pragma unroll
-            for (int i = 0; i < 18; ++i) pw[((size_t)jg * 21 + 3 + i) * Nk] = accL[i];
+            for (int i = 0; i < 18; ++i) pw[((size_t)jg * 21 + 3 + i) * Nk] = o18[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pw[(size_t)i * Nk] = accA0[i];
+            for (int i = 0; i < 3; ++i) pw[(size_t)i * Nk] = oA[i];
         }
         if (jg < 2) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pw[((size_t)(jg + 1) * 21 + i) * Nk] = accB[i];
+            for (int i = 0; i < 3; ++i) pw[((size_t)(jg + 1) * 21 + i) * Nk] = oB[i];
         }
     }
 }

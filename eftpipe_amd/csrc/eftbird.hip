@@ -322,15 +322,15 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (Nl == 3) {
             // matrix-core form: polynomials as [96 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
             hipLaunchKernelGGL(resum_prep_kernel, dim3(B), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
-                               tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL], tb<double>(e, EFTB_T_L11),
-                               tb<double>(e, EFTB_T_LCT), e->RSA, e->RSC);
+                               tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL], e->RSA, e->RSC);
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
             const int schunk = (NS + nsplit - 1) / nsplit;
             if (kblocks > 0)
                 hipLaunchKernelGGL(resum_mfma_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K),
-                                   tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, b[EFTB_B_TEMPL], e->part, nsplit);
+                                   tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
+                                   b[EFTB_B_TEMPL], e->part, nsplit);
             if (nsplit > 1)
                 hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nsplit, e->part, b[EFTB_B_TEMPL]);
         } else {
