@@ -147,8 +147,9 @@ def main():
                                                         ("regroup", L.S_REGROUP), ("resum", L.S_RESUM), ("ap", L.S_AP), ("reduce", L.S_REDUCE))}
         # AP ping-pongs the template block; leave the state consistent
         alg_flops = 8.0 * 28 * NK * NPOW**2 * B          # F_P22 per evaluation x B
-        # MFMA flops actually issued: one v_mfma_f64_16x16x4 (2048 flops: 16 rows x (2 runs x 8 columns) x 4 pairs) per double step and 16-row tile
-        exe_flops = 2048.0 * eng.tables["steps4"].shape[0] * (NK * B / 16)
+        # flops actually executed by the makeP22 path: anti-diagonal sums (9 matrices x 33 153 pairs x 2 complex products) + the
+        # 528-term synthesis of 32 (28 used) rows x Nk points on the matrix cores
+        exe_flops = B * (9 * 33153 * 16.0 + 2.0 * 32 * 528 * NK)
         achieved = alg_flops / (ms_p22 * 1e-3) / 1e12
         try:
             measured_peak = mfma_f64_peak(cp.local_rank)

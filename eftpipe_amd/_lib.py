@@ -24,12 +24,12 @@ class Config(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "device", "Nl", "Nk", "Nkin", "max_batch", "with_resum", "with_ap", "ap_stochastic", "nmu",
-        "ntail", "nxtail", "nsteps", "ncolsC", "nbasis", "NIR", "Na", "Nklow")]
+        "ntail", "nxtail", "nbasis", "nbasis13", "NIR", "Na", "Nklow")]
 
 
 # enum eftb_table / eftb_buffer / eftb_stage (same order as the header)
-TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL KPOW SPOW PAIRS22 PAIRSC PLAN M13R C11R CCTR L11 LCT L22 L13 GRP "
-          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H MU WMU LEGMU SPBAND APFID PLANC COMB22 COMBC PLANQ RSBASIS RSBASISS RSROWS PAIRS22D").split()
+TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD COMB22 COMB13 MLJ LINVEC SYNK SYNS LINK LINS L11 LCT L22 L13 GRP "
+          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID").split()
 T = {n: i for i, n in enumerate(TABLES)}
 BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF".split()
 B = {n: i for i, n in enumerate(BUFFERS)}

@@ -1,11 +1,9 @@
 // eftb_kernels.hpp -- HIP kernels of the one-loop engine, written for gfx950 (MI355X, CDNA4) only.
 //
-// Everything is FP64.  The two dense contractions (P22 and the xi-space C22/C13) run on the FP64
-// matrix cores (v_mfma_f64_16x16x4_f64) as a "pair GEMM": rows = (cosmology, k) points, K = the
-// 33 153 unordered index pairs (n <= m) of the real-reduced FFTLog vector u[257], N = loop matrices.
-// The A operand u_n*u_m is formed in registers from an LDS-resident tile of u; the B operand streams
-// from HBM/L2 in a layout that is exactly one MFMA fragment per 512 contiguous bytes.
-// The remaining stages are small streaming kernels (wave reductions, Horner sums, spline sweeps).
+// Everything is FP64.  The one-loop double sums (P22, C22, C13) are regrouped by anti-diagonals into one k-independent
+// pass per cosmology plus a 513-term synthesis per output point; the syntheses, the IR-resummation polynomials and the
+// post-AP projection operators run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).  The remaining stages are small
+// streaming kernels (spline sweeps, prefix sums, wave reductions).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,10 +15,6 @@ constexpr int NPOW = 257;    // FFTLog powers (NFFT + 1)         reference pybir
 constexpr int NHALF = 128;
 constexpr int NCH = 129;     // independent complex coefficients
 
-constexpr int PAIR_KU = 2;  // K-steps per inner-loop iteration of the pair GEMM (tables.py KU)
-constexpr int PAIR4_STEPS = []() { int t = 0; for (int n = 0; n < 2 * NHALF + 1; n += 2) t += ((2 * NHALF - n) >> 2) + 1; return t; }();  // double steps of the two-run form (tables.py pair_steps_2run)
-constexpr int PAIR4_PF = 4;     // prefetch depth (double steps) of the two-run fragment stream; the host pads the table with as many zero steps
-constexpr int ULDS = 258;    // LDS row stride of u: 258 = 2 (mod 32) -> conflict-free ds_read_b64
 constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl) + 12 (Ploopl) + 3 (Pstl)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -74,439 +68,195 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
     }
 }
 
-// Stage the u tile of a pair-GEMM workgroup straight from the FFTLog coefficients (what used to be a separate uvec kernel
-// and a [rows][260] HBM round trip): u[row] = (Re x_0..Re x_127, x_128, Im x_0..Im x_127), x_n = Coef_n * r^{p_n} with
-// r^{p_n} from the pow table of the row's abscissa (k^Pow or s^(-Pow-3); reference pybird.py:1066-1072).  Lanes run along n
-// (coalesced reads of the 1 MB, L2-resident pow table); LDS row stride ULDS, column 257 and the slack after the last row are
-// zero (read by zero-weight pad pairs only).
-template <int ROWS, int NTHREADS>
-__device__ inline void stage_u_tile(double* sm, int row0, int rows_total, int rows_per_w, const double* __restrict__ coef,
-                                    const double* __restrict__ pw) {
-    for (int idx = threadIdx.x; idx < ROWS * NCH; idx += NTHREADS) {
-        const int r = idx / NCH, n = idx % NCH, grow = row0 + r;
-        double a = 0.0, b = 0.0;
-        if (grow < rows_total) {
-            const double* c = coef + (size_t)(grow / rows_per_w) * 2 * NCH;
-            const double* p = pw + (size_t)(grow % rows_per_w) * 2 * NCH;
-            const double cr = c[n], ci = c[NCH + n], pr = p[n], pi = p[NCH + n];
-            a = n < NHALF ? cr * pr - ci * pi : cr * pr;
-            b = cr * pi + ci * pr;
-        }
-        sm[r * ULDS + n] = a;
-        if (n < NHALF) sm[r * ULDS + NCH + n] = b;
-        else sm[r * ULDS + NPOW] = 0.0;
+// ------------------------------------------------------------------------------------------------
+// One-loop pieces in anti-diagonal form (tables.py antidiagonal_tables).  With x_n(k) = c_n k^{Pow_n} and
+// Pow_n = bias + i dpow (n - 128), the k dependence of a pair (n, m) is k^{2 bias + i dpow (n + m - 256)}: it depends on
+// n + m only.  So for every loop matrix M
+//     sum_{n,m} x_n M[n,m] x_m = sum_{j'} k^{2 bias + i dpow j'} S[j'],     S[j'] = sum_{n+m=256+j'} c_n c_m M[n,m]
+// -- one k-INDEPENDENT pass over the matrix per cosmology (antidiag_kernel: 9 x 33 153 complex MACs) and a 513-term real
+// synthesis per output point (synth_kernel on the FP64 matrix cores), instead of 257^2 terms per point
+// (reference pybird.py:1074-1078 makeP22, :1103-1125 makeC22 / makeC13).  The same S serve P22 at all k and, multiplied
+// by the Bessel weights Ml(n + m), C22 / C13 at all s and l.  The single sums (P13, C11, Cct) are 257-term syntheses.
+//   antidiag_kernel    S[w][c][j'], j' = 0..256 (S[-j'] = conj S[j']): wave <-> j', lanes along the anti-diagonal
+//   build_rows_kernel  real coefficient rows (Re Z_0, Re Z_1, Im Z_1, ...) of every output row: comb (basis -> 28 / 10
+//                      matrices), Ml weights, or c_n V_n for the single sums
+//   synth_kernel       out[w][row][x] = sum_q rows[w][row][q] Tab[q][x]   (Tab = k^{..}{1, 2cos, -/+2sin}: tables.py)
+// ------------------------------------------------------------------------------------------------
+constexpr int AD_T = NHALF + 2;   // anti-diagonal length (129) rounded up to even
+constexpr int KSYN = 528;         // 1 + 2*256 synthesis coefficients, zero padded to a multiple of 16 (4 MFMA K-steps)
+constexpr int KLIN = 272;         // 1 + 2*128, likewise
+
+template <int NC>
+__global__ __launch_bounds__(256) void antidiag_kernel(const double* __restrict__ coef, const double2* __restrict__ AD,
+                                                       double2* __restrict__ S) {
+    __shared__ double2 cs[NPOW];
+    const int w = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* c = coef + (size_t)w * 2 * NCH;
+    for (int n = threadIdx.x; n < NPOW; n += 256) {  // c_{256-n} = conj(c_n)
+        const int q = n <= NHALF ? n : 2 * NHALF - n;
+        cs[n] = make_double2(c[q], n <= NHALF ? c[NCH + q] : -c[NCH + q]);
     }
-    if (threadIdx.x < 32) sm[ROWS * ULDS + threadIdx.x] = 0.0;
+    __syncthreads();
+    const int jp = blockIdx.x * 4 + wave;
+    if (jp >= NPOW) return;
+    const int cnt = ((2 * NHALF + jp) >> 1) - jp + 1;  // pairs (n, m) = (jp + t, 256 - t), n <= m
+    double ar[NC], ai[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) ar[q] = ai[q] = 0.0;
+    for (int t = lane; t < cnt; t += 64) {
+        const double2 a = cs[jp + t], b = cs[2 * NHALF - t];
+        const double pr = a.x * b.x - a.y * b.y, pi = a.x * b.y + a.y * b.x;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const double2 m = AD[((size_t)q * NPOW + jp) * AD_T + t];
+            ar[q] = fma(m.x, pr, fma(-m.y, pi, ar[q]));
+            ai[q] = fma(m.x, pi, fma(m.y, pr, ai[q]));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            ar[q] += __shfl_xor(ar[q], off);
+            ai[q] += __shfl_xor(ai[q], off);
+        }
+        if (lane == 0) S[((size_t)w * NC + q) * NPOW + jp] = make_double2(ar[q], ai[q]);
+    }
 }
 
-// Linear (single-sum) terms that share the u tile of a pair GEMM workgroup: out[v] = scale * (vec[v] . u[row]).
-//   k rows: P13[w][b][k] = k^3 P11[k] (m13r[b] . u)                      (reference pybird.py:1080-1086)
-//   s rows: C11[w][l][s] = c11r[l] . u ;  Cct[w][l][s] = s^-2 (cctr[l] . u)   (reference pybird.py:1088-1096)
-struct LinTerms {
-    int nA, nB;                  // vectors of the first / second family (nA + nB <= 16)
-    const double *vecA, *vecB;   // [nA][257], [nB][257]
-    const double *scaleA, *scaleB;  // per row-in-cosmology factors (may be null)
-    const double* rowdata;       // per global row factor of family A (P11; may be null)
-    double *outA, *outB;         // [w][nA][rows_per_w], [w][nB][rows_per_w]
+// Row sets (blockIdx.y): 0 -> P22 rows [28][KSYN]; 1 -> P13 rows [10][KLIN]; 2 -> C22 / C13 rows [Nl*38][KSYN];
+// 3 -> C11 / Cct rows [2*Nl][KLIN].  `sets` is a bit mask of the sets to build.
+__global__ __launch_bounds__(256) void build_rows_kernel(int sets, int Nl, int nb, int nb13, const double* __restrict__ coef,
+                                                         const double2* __restrict__ S, const double* __restrict__ comb22,
+                                                         const double* __restrict__ comb13, const double2* __restrict__ mlj,
+                                                         const double2* __restrict__ linvec, double* __restrict__ A22,
+                                                         double* __restrict__ A13, double* __restrict__ ACF, double* __restrict__ ALC) {
+    const int w = blockIdx.x, set = blockIdx.y;
+    if (!((sets >> set) & 1)) return;
+    const int nc = nb + nb13;
+    const double2* sw = S + (size_t)w * nc * NPOW;
+    if (set == 0 || set == 2) {
+        const int nrows = set == 0 ? 28 : Nl * 38;
+        double* out = set == 0 ? A22 + (size_t)w * 28 * KSYN : ACF + (size_t)w * Nl * 38 * KSYN;
+        for (int e = threadIdx.x; e < nrows * NPOW; e += blockDim.x) {
+            const int row = e / NPOW, jp = e % NPOW;
+            double zr = 0.0, zi = 0.0;
+            int l = 0;
+            if (set == 0 || row < Nl * 28) {
+                const int b = set == 0 ? row : row % 28;
+                l = set == 0 ? 0 : row / 28;
+                for (int q = 0; q < nb; ++q) {
+                    const double cq = comb22[b * nb + q];
+                    zr = fma(cq, sw[q * NPOW + jp].x, zr);
+                    zi = fma(cq, sw[q * NPOW + jp].y, zi);
+                }
+            } else {
+                const int rr = row - Nl * 28, b = rr % 10;
+                l = rr / 10;
+                for (int q = 0; q < nb13; ++q) {
+                    const double cq = comb13[b * nb13 + q];
+                    zr = fma(cq, sw[(nb + q) * NPOW + jp].x, zr);
+                    zi = fma(cq, sw[(nb + q) * NPOW + jp].y, zi);
+                }
+            }
+            if (set == 2) {  // Bessel weight Ml[l](n + m) (reference pybird.py:1040-1046)
+                const double2 m = mlj[l * NPOW + jp];
+                const double tr = m.x * zr - m.y * zi;
+                zi = m.x * zi + m.y * zr;
+                zr = tr;
+            }
+            double* o = out + (size_t)row * KSYN;
+            if (jp == 0) o[0] = zr;
+            else {
+                o[2 * jp - 1] = zr;
+                o[2 * jp] = zi;
+            }
+        }
+    } else {
+        const int nrows = set == 1 ? 10 : 2 * Nl, v0 = set == 1 ? 0 : 10;
+        double* out = set == 1 ? A13 + (size_t)w * 10 * KLIN : ALC + (size_t)w * 2 * Nl * KLIN;
+        const double* c = coef + (size_t)w * 2 * NCH;
+        for (int e = threadIdx.x; e < nrows * NCH; e += blockDim.x) {
+            const int row = e / NCH, mp = e % NCH, n = NHALF - mp;  // harmonic mp <-> coefficient n = 128 - mp
+            const double2 v = linvec[(size_t)(v0 + row) * NCH + n];
+            const double cr = c[n], ci = n == NHALF ? 0.0 : c[NCH + n];
+            double* o = out + (size_t)row * KLIN;
+            if (mp == 0) o[0] = cr * v.x - ci * v.y;
+            else {
+                o[2 * mp - 1] = cr * v.x - ci * v.y;
+                o[2 * mp] = cr * v.y + ci * v.x;
+            }
+        }
+    }
+}
+
+// out[g][row][x] = sum_q A[g][row][q] Tab[q][x]  (* gscale[g][x]) (* xscale[x] for rows >= xscale_row0): one wave per
+// (32 x, 16 MT rows, group); A operand lane (row = lane & 15, q = lane >> 4), B operand lane (q = lane >> 4, x = lane & 15).
+struct SynthDesc {
+    const double* A;      // [G][.][K]: rows of group g start at A + g * a_group
+    long long a_group;
+    const double* Tab;    // [K][X]
+    double* out;          // [G][R][X]
+    const double* gscale; // [G][X] or null   (P13: P11)
+    const double* xscale; // [X] or null      (Cct: s^-2)
+    int R, K, X, xscale_row0;
 };
 
-// column tiles reduced per pass of the epilogue: the largest divisor of NT whose NW partial tiles fit 128 KB
-constexpr int pair_reduce_cols(int MT, int NT, int NW) {
-    int best = 1;
-    for (int jc = 1; jc <= NT; ++jc)
-        if (NT % jc == 0 && (size_t)NW * MT * jc * 4 * 64 * 8 <= 128 * 1024) best = jc;
-    return best;
-}
-// (NW * MT * JC * 4 * 64 partial doubles + MT*16 x NT*16 basis values must fit the 160 KB LDS)
-
-// ------------------------------------------------------------------------------------------------
-// pair GEMM on the FP64 matrix cores.
-//   out[row, col] = scale[row] * sum_{t, g} u[row, n_t] u[row, m_t + g] * frag[t][col/16][g][col%16]
-// Workgroup = NW waves = MT*16 rows, the whole K range split NW ways over the waves (NW/4 waves per SIMD,
-// each with MT*NT independent accumulator tiles); the u tile lives in LDS (stride 258 doubles), the B
-// fragments are read once per workgroup straight into registers (8 B/lane, 512 B per instruction).
-// MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = lane >> 4],
-// B[k = lane >> 4][j = lane & 15], D reg q -> row (lane >> 4) + 4 q, col lane & 15.
-// Output element (row, col) is written to out[w][col][r] (w = row / rows_per_w, r = row % rows_per_w; ncols_ld columns per w).
-// ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm_kernel(const double* __restrict__ coef, const double* __restrict__ pw,
-                                                           const double* __restrict__ frag,
-                                                           const int* __restrict__ plan, int rows_total, int rows_per_w,
-                                                           int nbasis, const double* __restrict__ comb, int ncols_out, int ncols_ld,
-                                                           const double* __restrict__ rowscale, double* __restrict__ out,
-                                                           double* __restrict__ part, LinTerms lin) {
-    constexpr int ROWS = MT * 16;  // NW waves per workgroup = K slices; NW/4 waves per SIMD hide each other's LDS/L2 latency
-    extern __shared__ double sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS;
-
-    stage_u_tile<ROWS, 64 * NW>(sm, row0, rows_total, rows_per_w, coef, pw);
-    __syncthreads();
-
-    // ---- linear terms straight from the LDS tile: thread <-> (row, vector), 257 FMAs each (< 0.5 % of the workgroup)
-    if (blockIdx.y == 0 && lin.nA + lin.nB > 0) {
-        for (int e = tid; e < ROWS * (lin.nA + lin.nB); e += 64 * NW) {
-            const int rr = e % ROWS, v = e / ROWS, grow = row0 + rr;
-            if (grow >= rows_total) continue;
-            const bool famA = v < lin.nA;
-            const double* vec = famA ? lin.vecA + (size_t)v * NPOW : lin.vecB + (size_t)(v - lin.nA) * NPOW;
-            const double* ur = sm + rr * ULDS;
-            // 8 independent chains, operands fetched in batches (v_fma_f64: 32-cycle dependent latency)
-            double ac[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ac[q] = 0.0;
-            for (int nn = 0; nn < NPOW - 1; nn += 8) {
-                double vv[8], uu[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    vv[q] = vec[nn + q];
-                    uu[q] = ur[nn + q];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) ac[q] = fma(vv[q], uu[q], ac[q]);
-            }
-            double d = (((ac[0] + ac[1]) + (ac[2] + ac[3])) + ((ac[4] + ac[5]) + (ac[6] + ac[7]))) + vec[NPOW - 1] * ur[NPOW - 1];
-            const int w = grow / rows_per_w, rw = grow % rows_per_w;
-            if (famA) {
-                if (lin.scaleA) d *= lin.scaleA[rw];
-                if (lin.rowdata) d *= lin.rowdata[grow];
-                lin.outA[((size_t)w * lin.nA + v) * rows_per_w + rw] = d;
-            } else {
-                if (lin.scaleB) d *= lin.scaleB[rw];
-                lin.outB[((size_t)w * lin.nB + (v - lin.nA)) * rows_per_w + rw] = d;
-            }
-        }
-    }
-
-    const int r = lane & 15, g = lane >> 4;
-    // the wave's K range: wave-uniform, kept in SGPRs so the loops below branch on SCC, not EXEC
-    const int* pl = plan + (blockIdx.y * NW + wave) * 4;  // blockIdx.y = K split across workgroups (plan has gridDim.y * NW entries)
-    int n = __builtin_amdgcn_readfirstlane(pl[0]);
-    int m0 = __builtin_amdgcn_readfirstlane(pl[1]);
-    const int t0 = __builtin_amdgcn_readfirstlane(pl[2]);
-    int nsteps = __builtin_amdgcn_readfirstlane(pl[3]);
-    const double* fp = frag + ((size_t)t0 * NT) * 64 + lane;
-
-    v4d acc[MT][NT];
+template <int MT>
+__global__ __launch_bounds__(64) void synth_kernel(SynthDesc d) {
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const int x0 = blockIdx.x * 32, row0 = blockIdx.y * 16 * MT, grp = blockIdx.z;
+    v4d acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-    // B fragments of one iteration (PAIR_KU consecutive K-steps), prefetched one iteration ahead
-    double bcur[PAIR_KU][NT];
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* ap[MT];
+    double am[MT];
 #pragma unroll
-    for (int u = 0; u < PAIR_KU; ++u)
+    for (int i = 0; i < MT; ++i) {
+        const int row = row0 + 16 * i + r;
+        am[i] = row < d.R ? 1.0 : 0.0;
+        ap[i] = d.A + (size_t)grp * d.a_group + (size_t)(row < d.R ? row : d.R - 1) * d.K + g;
+    }
+    const double* bp[2];
+    double bm[2];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bcur[u][j] = fp[(u * NT + j) * 64];
-    fp += PAIR_KU * NT * 64;
-
-    const double* urow = sm + r * ULDS;
-    while (nsteps > 0) {
-        // one n-run: sum_m u_m R[(n, m)] is a plain GEMM whose A operand is the raw u tile (no per-MFMA multiply);
-        // the common factor u_n is applied once per run to the run's accumulator, in the D layout
-        // (rows (lane >> 4) + 4 q).  Runs are padded with zero-weight steps to a multiple of PAIR_KU; the inner loop is
-        // branch-free and software pipelined (B fragments and u_m values of iteration t+1 in flight under iteration t)
-        const int run = (((2 * NHALF - n) >> 2) + PAIR_KU) / PAIR_KU * PAIR_KU;
-        const int left = run - ((m0 - n) >> 2);
-        const int cnt = (left < nsteps ? left : nsteps) / PAIR_KU;
-        v4d racc[MT][NT];
+    for (int j = 0; j < 2; ++j) {
+        const int x = x0 + 16 * j + r;
+        bm[j] = x < d.X ? 1.0 : 0.0;
+        bp[j] = d.Tab + (size_t)g * d.X + (x < d.X ? x : d.X - 1);
+    }
+    for (int t0 = 0; t0 < (d.K >> 2); t0 += 4) {  // K is a multiple of 16: four K-steps of operands in flight
+        double a[4][MT], b[4][2];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) racc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-        double um[PAIR_KU][MT];
-        const double* up = urow + m0 + g;
+            for (int i = 0; i < MT; ++i) a[u][i] = ap[i][4 * (t0 + u)] * am[i];
 #pragma unroll
-        for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) um[u][i] = up[i * 16 * ULDS + 4 * u];
-        for (int it = 0; it < cnt; ++it) {
-            double bnxt[PAIR_KU][NT], umn[PAIR_KU][MT];
-#pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bnxt[u][j] = fp[(u * NT + j) * 64];  // the table ends with one zero iteration
-            fp += PAIR_KU * NT * 64;
-            up += 4 * PAIR_KU;
-#pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) umn[u][i] = up[i * 16 * ULDS + 4 * u];  // <= 16 doubles past the run: inside the slack
-#pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        racc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(um[u][i], bcur[u][j], racc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < PAIR_KU; ++u) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bcur[u][j] = bnxt[u][j];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) um[u][i] = umn[u][i];
-            }
+            for (int j = 0; j < 2; ++j) b[u][j] = bp[j][(size_t)4 * (t0 + u) * d.X] * bm[j];
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double un = sm[(16 * i + g + 4 * q) * ULDS + n];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j][q] = fma(un, racc[i][j][q], acc[i][j][q]);
-            }
-        nsteps -= cnt * PAIR_KU;
-        ++n;
-        m0 = n;
-    }
-
-    // ---- reduce the NW K-slices through LDS (the u tile is dead now) into the basis values bas[row][col], JC column
-    // tiles per pass; then expand to the requested outputs  out[col] = sum_c comb[col][c] bas[c]  (the loop matrices
-    // span a low-dimensional space: tables.py loop_basis) -- or hand the unscaled basis partial to pair_sum_kernel
-    constexpr int JC = pair_reduce_cols(MT, NT, NW);
-    constexpr int PER_WAVE = MT * JC * 4 * 64;
-    constexpr int NBC = NT * 16;
-    static_assert((size_t)(NW * PER_WAVE + ROWS * NBC) * 8 <= 160 * 1024, "reduction buffer exceeds LDS");
-    double* bas = sm + NW * PER_WAVE;
-    for (int jc = 0; jc < NT; jc += JC) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < JC; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sm[wave * PER_WAVE + ((i * JC + j) * 4 + q) * 64 + lane] = acc[i][jc + j][q];
-        __syncthreads();
-        for (int e = tid; e < ROWS * JC * 16; e += 64 * NW) {
-            const int row = e % ROWS, col = jc * 16 + e / ROWS;
-            const int i = row >> 4, rr = row & 15, q = rr >> 2, gg = rr & 3;
-            const int j = (e / ROWS) >> 4, ln = gg * 16 + (col & 15);
-            const int off = ((i * JC + j) * 4 + q) * 64 + ln;
-            double v = 0.0;
-#pragma unroll
-            for (int w8 = 0; w8 < NW; ++w8) v += sm[w8 * PER_WAVE + off];
-            bas[row * NBC + col] = v;
-        }
-    }
-    __syncthreads();
-    if (gridDim.y > 1) {  // K split over workgroups: unscaled basis partial, finished by pair_sum_kernel
-        for (int e = tid; e < ROWS * nbasis; e += 64 * NW) {
-            const int row = e / nbasis, c = e % nbasis;
-            if (row0 + row < rows_total) part[((size_t)blockIdx.y * rows_total + row0 + row) * nbasis + c] = bas[row * NBC + c];
-        }
-        return;
-    }
-    for (int e = tid; e < ROWS * ncols_out; e += 64 * NW) {
-        const int row = e % ROWS, col = e / ROWS;
-        if (row0 + row >= rows_total) continue;
-        double v;
-        if (comb) {
-            v = 0.0;
-            for (int c = 0; c < nbasis; ++c) v = fma(comb[col * nbasis + c], bas[row * NBC + c], v);
-        } else {
-            v = bas[row * NBC + col];
-        }
-        const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
-        if (rowscale) v *= rowscale[rw];
-        out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// pair GEMM for <= 8 basis columns on v_mfma_f64_16x16x4_f64 with the 16 MFMA columns shared by TWO runs: columns
-// 0-7 carry the basis weights of pairs (n, m), columns 8-15 those of (n + 1, m), both against the same raw u operand
-// (double steps of tables.py pair_steps_2run).  14 of 16 columns do useful work (7 of 16 in the single-run form), and
-// unlike v_mfma_f64_4x4x4_4b -- which in this loop sustains only ~19-20 cycles per 512 flops, measured with operand
-// fetches removed -- the 16x16x4 form runs at its nominal 64 cycles per 2048 flops.  Per double step and wave: four
-// MFMAs, four LDS operand reads, one 512-byte fragment.  The run factors u_n (columns 0-7) and u_n+1 (columns 8-15)
-// multiply the run accumulator once, in the D layout; the two column halves are added in the epilogue reduction.
-// ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW / 4) void pair_gemm2r_kernel(const double* __restrict__ coef, const double* __restrict__ pw,
-                                                                     const double* __restrict__ frag,
-                                                                     const int* __restrict__ plan, int rows_total, int rows_per_w,
-                                                                     int nbasis, const double* __restrict__ comb, int ncols_out, int ncols_ld,
-                                                                     const double* __restrict__ rowscale, double* __restrict__ out,
-                                                                     double* __restrict__ part, LinTerms lin) {
-    constexpr int ROWS = 64, MT = 4;  // four 16-row MFMA tiles
-    extern __shared__ double sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS;
-    stage_u_tile<ROWS, 64 * NW>(sm, row0, rows_total, rows_per_w, coef, pw);
-    __syncthreads();
-
-    if (blockIdx.y == 0 && lin.nA + lin.nB > 0) {
-        for (int e = tid; e < ROWS * (lin.nA + lin.nB); e += 64 * NW) {
-            const int rr = e % ROWS, v = e / ROWS, grow = row0 + rr;
-            if (grow >= rows_total) continue;
-            const bool famA = v < lin.nA;
-            const double* vec = famA ? lin.vecA + (size_t)v * NPOW : lin.vecB + (size_t)(v - lin.nA) * NPOW;
-            const double* ur = sm + rr * ULDS;
-            // 8 independent chains, operands fetched in batches (v_fma_f64: 32-cycle dependent latency)
-            double ac[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ac[q] = 0.0;
-            for (int nn = 0; nn < NPOW - 1; nn += 8) {
-                double vv[8], uu[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    vv[q] = vec[nn + q];
-                    uu[q] = ur[nn + q];
+                const int row = row0 + 16 * i + g + 4 * q, x = x0 + 16 * j + r;
+                if (row < d.R && x < d.X) {
+                    double v = acc[i][j][q];
+                    if (d.gscale) v *= d.gscale[(size_t)grp * d.X + x];
+                    if (d.xscale && row >= d.xscale_row0) v *= d.xscale[x];
+                    d.out[((size_t)grp * d.R + row) * d.X + x] = v;
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) ac[q] = fma(vv[q], uu[q], ac[q]);
             }
-            double d = (((ac[0] + ac[1]) + (ac[2] + ac[3])) + ((ac[4] + ac[5]) + (ac[6] + ac[7]))) + vec[NPOW - 1] * ur[NPOW - 1];
-            const int w = grow / rows_per_w, rw = grow % rows_per_w;
-            if (famA) {
-                if (lin.scaleA) d *= lin.scaleA[rw];
-                if (lin.rowdata) d *= lin.rowdata[grow];
-                lin.outA[((size_t)w * lin.nA + v) * rows_per_w + rw] = d;
-            } else {
-                if (lin.scaleB) d *= lin.scaleB[rw];
-                lin.outB[((size_t)w * lin.nB + (v - lin.nA)) * rows_per_w + rw] = d;
-            }
-        }
-    }
-
-    const int r = lane & 15, g = lane >> 4;
-    const int* pl = plan + (blockIdx.y * NW + wave) * 4;
-    int n = __builtin_amdgcn_readfirstlane(pl[0]);   // even: the double run (n, n + 1)
-    const int m0 = __builtin_amdgcn_readfirstlane(pl[1]);
-    const int t0 = __builtin_amdgcn_readfirstlane(pl[2]);
-    const int nsteps = __builtin_amdgcn_readfirstlane(pl[3]);
-    const double* fp = frag + (size_t)t0 * 64 + lane;
-
-    v4d acc[MT], racc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] = racc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-    // fragment stream prefetched PAIR4_PF double steps ahead through a register ring (fixed slots: the step loop is
-    // unrolled PAIR4_PF times; the stream is continuous across run boundaries, which are wave-uniform scalar branches)
-    double bq[PAIR4_PF];
-#pragma unroll
-    for (int q = 0; q < PAIR4_PF; ++q) bq[q] = fp[q * 64];
-    fp += PAIR4_PF * 64;
-
-    const double* urow = sm + r * ULDS + g;                 // A side: tile i adds 16 i rows; K index g
-    const double* drow = sm + g * ULDS + (r >> 3);          // D side: rows g + 4 q (+ 16 i), run n + (column >> 3)
-    int left = (((2 * NHALF - n) >> 2) + 1) - ((m0 - n) >> 2);  // steps left in the current double run
-    const double* up = urow + m0;
-    double um[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) um[i] = up[i * 16 * ULDS];
-    for (int base = 0; base < nsteps; base += PAIR4_PF) {
-#pragma unroll
-        for (int q = 0; q < PAIR4_PF; ++q) {
-            if (base + q < nsteps) {
-                const bool last = left == 1;
-                const double* upn = last ? urow + (n + 2) : up + 4;  // next step: same run, or the start of the next one
-                double umn[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) umn[i] = upn[i * 16 * ULDS];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) racc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(um[i], bq[q], racc[i], 0, 0, 0);
-                bq[q] = fp[0];  // this slot's next use is PAIR4_PF steps away
-                fp += 64;
-                if (last) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int qq = 0; qq < 4; ++qq) {
-                            acc[i][qq] = fma(drow[(16 * i + 4 * qq) * ULDS + n], racc[i][qq], acc[i][qq]);
-                            racc[i][qq] = 0.0;
-                        }
-                    n += 2;
-                    left = ((2 * NHALF - n) >> 2) + 1;
-                } else {
-                    --left;
-                }
-                up = upn;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) um[i] = umn[i];
-            }
-        }
-    }
-    // the slice may end inside a run: fold the open accumulators (zero if the run was just closed; n <= 258 stays inside the
-    // zero-padded tile)
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) acc[i][qq] = fma(drow[(16 * i + 4 * qq) * ULDS + n], racc[i][qq], acc[i][qq]);
-
-    // ---- reduce the NW K slices and the two column halves: red[wave][i][q][lane] -> bas[row][col] (8 columns)
-    __syncthreads();
-    double* bas = sm + NW * MT * 4 * 64;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) sm[((wave * MT + i) * 4 + qq) * 64 + lane] = acc[i][qq];
-    __syncthreads();
-    for (int e = tid; e < ROWS * 8; e += 64 * NW) {
-        const int row = e >> 3, col = e & 7;
-        const int i = row >> 4, rr = row & 15, qq = rr >> 2, gg = rr & 3;
-        const int lo = (i * 4 + qq) * 64 + gg * 16 + col;
-        double v = 0.0;
-#pragma unroll
-        for (int w8 = 0; w8 < NW; ++w8) v += sm[w8 * MT * 4 * 64 + lo] + sm[w8 * MT * 4 * 64 + lo + 8];
-        bas[row * 8 + col] = v;
-    }
-    __syncthreads();
-    if (gridDim.y > 1) {
-        for (int e = tid; e < ROWS * nbasis; e += 64 * NW) {
-            const int row = e / nbasis, c = e % nbasis;
-            if (row0 + row < rows_total) part[((size_t)blockIdx.y * rows_total + row0 + row) * nbasis + c] = bas[row * 8 + c];
-        }
-        return;
-    }
-    for (int e = tid; e < ROWS * ncols_out; e += 64 * NW) {
-        const int row = e % ROWS, col = e / ROWS;
-        if (row0 + row >= rows_total) continue;
-        double v;
-        if (comb) {
-            v = 0.0;
-            for (int c = 0; c < nbasis; ++c) v = fma(comb[col * nbasis + c], bas[row * 8 + c], v);
-        } else {
-            v = bas[row * 8 + col];
-        }
-        const int grow = row0 + row, w = grow / rows_per_w, rw = grow % rows_per_w;
-        if (rowscale) v *= rowscale[rw];
-        out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
-    }
-}
-
-// sum of the K-split basis partials of pair_gemm_kernel, then the expansion to the outputs:
-//   out[w][col][r] = scale[r] * sum_c comb[col][c] * sum_s part[s][row][c]
-// One workgroup = 8 rows: 256 threads first reduce the (row, basis) partials (coalesced along the basis index) into
-// LDS, then share the 8 * ncols_out outputs.
-__global__ __launch_bounds__(256) void pair_sum_kernel(int nsplit, int rows_total, int rows_per_w, int nbasis, const double* __restrict__ comb,
-                                                       int ncols_out, int ncols_ld, const double* __restrict__ rowscale,
-                                                       const double* __restrict__ part, double* __restrict__ out) {
-    __shared__ double bas[8][32];
-    const int row0 = blockIdx.x * 8;
-    {
-        const int rr = threadIdx.x >> 5, c = threadIdx.x & 31, grow = row0 + rr;
-        double b = 0.0;
-        if (c < nbasis && grow < rows_total)
-            for (int s = 0; s < nsplit; ++s) b += part[((size_t)s * rows_total + grow) * nbasis + c];
-        bas[rr][c] = b;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 8 * ncols_out; e += 256) {
-        const int rr = e & 7, col = e >> 3, grow = row0 + rr;
-        if (grow >= rows_total) continue;
-        double v;
-        if (comb) {
-            v = 0.0;
-            for (int c = 0; c < nbasis; ++c) v = fma(comb[col * nbasis + c], bas[rr][c], v);
-        } else {
-            v = bas[rr][col];
-        }
-        const int w = grow / rows_per_w, rw = grow % rows_per_w;
-        if (rowscale) v *= rowscale[rw];
-        out[((size_t)w * ncols_ld + col) * rows_per_w + rw] = v;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,8 +18,6 @@
 
 using namespace eftb;
 
-constexpr int NW_P22 = 16;  // waves per workgroup (K slices) of the P22 pair GEMM
-constexpr int NW_C = 8;     // ... of the xi-space pair GEMM (two accumulator sets: 2 waves per SIMD)
 constexpr size_t GEMM_LDS = (size_t)64 * 258 * sizeof(double);  // A tile of gemm_rows_kernel
 
 static thread_local std::string g_err;
@@ -42,8 +40,8 @@ static int fail(const char* fmt, ...) {
 
 struct eftb_engine {
     eftb_config c;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJoin = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool finalized = false;
     void* tab[EFTB_T_COUNT] = {nullptr};
     size_t tab_bytes[EFTB_T_COUNT] = {0};
@@ -53,18 +51,17 @@ struct eftb_engine {
     double *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
     double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][96][8], per-s records [B][NS][80]
     double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
-    double *pairpartP = nullptr, *pairpartC = nullptr;  // K-split partials of the two pair GEMMs
-    int ldtv = 0;  // padded column count of Tv / V (Nl*257 rounded up to 16)
+    double2* SAD = nullptr;                  // anti-diagonal sums S[B][nbasis + nbasis13][257]
+    double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of P22 [B][28][516] and P13 [B][10][260]
+    double *ACF = nullptr, *ALC = nullptr;   // ... of C22 / C13 [B][Nl*38][516] and C11 / Cct [B][2 Nl][260]
     // linear post-AP operators (window / binning / chained), stored K-major for gemm_rows_kernel
     struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; };
     std::vector<Op> ops;
     int pipeline_op = -1;
-    bool use_fork = false;  // run the k-space and xi-space contractions on two streams (EFTB_FORK=1); off: one stream
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
     int Nn = 0;
-    double* k3 = nullptr;   // k^3 row scale of P22 / P13
     double* sm2 = nullptr;  // s^-2 row scale of Cct
     // RCCL gather (multi-GPU batches)
     ncclComm_t comm = nullptr;
@@ -124,19 +121,15 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_GCT: return D * 2 * c.Nkin * NCH;
         case EFTB_T_ECT: return D * 2 * c.ntail * NCH;
         case EFTB_T_LNXTAIL: return D * c.ntail;
-        case EFTB_T_KPOW: return D * c.Nk * 2 * NCH;
-        case EFTB_T_SPOW: return c.with_resum ? D * NS * 2 * NCH : 0;
-        case EFTB_T_PAIRS22: return D * (size_t)(c.nsteps + PAIR_KU) * 1 * 64;
-        case EFTB_T_PAIRS22D: return c.nbasis <= 8 ? D * (size_t)(PAIR4_STEPS + PAIR4_PF) * 64 : 0;
-        case EFTB_T_PLANQ: return c.nbasis <= 8 ? sizeof(int32_t) * 4 * NW_P22 * 15 : 0;
+        case EFTB_T_AD: return 2 * D * (size_t)(c.nbasis + (c.with_resum ? c.nbasis13 : 0)) * NPOW * AD_T;
         case EFTB_T_COMB22: return D * 28 * c.nbasis;
-        case EFTB_T_COMBC: return c.with_resum ? D * (size_t)c.Nl * 38 * c.ncolsC : 0;
-        case EFTB_T_PAIRSC: return c.with_resum ? D * (size_t)(c.nsteps + PAIR_KU) * (c.ncolsC / 16) * 64 : 0;
-        case EFTB_T_PLAN: return sizeof(int32_t) * 4 * NW_P22 * 15;
-        case EFTB_T_PLANC: return c.with_resum ? sizeof(int32_t) * 4 * NW_C * 15 : 0;
-        case EFTB_T_M13R: return D * 10 * NPOW;
-        case EFTB_T_C11R: return c.with_resum ? D * c.Nl * NPOW : 0;
-        case EFTB_T_CCTR: return c.with_resum ? D * c.Nl * NPOW : 0;
+        case EFTB_T_COMB13: return c.with_resum ? D * 10 * c.nbasis13 : 0;
+        case EFTB_T_MLJ: return c.with_resum ? 2 * D * c.Nl * NPOW : 0;
+        case EFTB_T_LINVEC: return 2 * D * (size_t)(10 + (c.with_resum ? 2 * c.Nl : 0)) * NCH;
+        case EFTB_T_SYNK: return D * (size_t)KSYN * c.Nk;
+        case EFTB_T_LINK: return D * (size_t)KLIN * c.Nk;
+        case EFTB_T_SYNS: return c.with_resum ? D * (size_t)KSYN * NS : 0;
+        case EFTB_T_LINS: return c.with_resum ? D * (size_t)KLIN * NS : 0;
         case EFTB_T_L11: return D * c.Nl * 3;
         case EFTB_T_LCT: return D * c.Nl * 6;
         case EFTB_T_L22: return D * c.Nl * 28;
@@ -183,48 +176,32 @@ static size_t need_buffer_elems(const eftb_config& c, int id) {
 template <typename T>
 static inline const T* tb(const eftb_engine* e, int id) { return static_cast<const T*>(e->tab[id]); }
 
-// dynamic LDS of pair_gemm_kernel<MT, NT>: the u tile (+ slack) or the 4-way reduction buffer
-static constexpr size_t pair2r_lds_bytes(int NW) {
-    const size_t tile = (size_t)(64 * ULDS + 32) * sizeof(double), red = ((size_t)NW * 4 * 4 * 64 + 64 * 8) * sizeof(double);
-    return tile > red ? tile : red;
+// out[g][row][x] = sum_q A[g][row][q] Tab[q][x] on the FP64 matrix cores (synth_kernel): one wave per (32 x, 16 or 32 rows, g)
+static void launch_synth(hipStream_t st, int G, const double* A, long long a_group, int R, int K, const double* Tab, int X, double* out, const double* gscale,
+                         const double* xscale, int xscale_row0) {
+    SynthDesc d{};
+    d.A = A; d.a_group = a_group; d.Tab = Tab; d.out = out; d.gscale = gscale; d.xscale = xscale;
+    d.R = R; d.K = K; d.X = X; d.xscale_row0 = xscale_row0;
+    if (R > 16) hipLaunchKernelGGL((synth_kernel<2>), dim3((X + 31) / 32, (R + 31) / 32, G), dim3(64), 0, st, d);
+    else hipLaunchKernelGGL((synth_kernel<1>), dim3((X + 31) / 32, 1, G), dim3(64), 0, st, d);
 }
 
-static constexpr size_t pair_lds_bytes(int MT, int NT, int NW) {
-    const size_t tile = (size_t)(MT * 16 * ULDS + 32) * sizeof(double);
-    const size_t red = ((size_t)NW * MT * pair_reduce_cols(MT, NT, NW) * 4 * 64 + (size_t)MT * 16 * NT * 16) * sizeof(double);
-    return tile > red ? tile : red;
+// anti-diagonal sums of every loop matrix for the batch (shared by the k-space and the xi-space pieces)
+static int launch_antidiag(eftb_engine* e, hipStream_t st, int B) {
+    const eftb_config& c = e->c;
+    const int nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
+    const dim3 grid((NPOW + 3) / 4, B);
+    if (nc == 9) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(256), 0, st, e->buf[EFTB_B_COEF], tb<double2>(e, EFTB_T_AD), e->SAD);
+    else if (nc == 7) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(256), 0, st, e->buf[EFTB_B_COEF], tb<double2>(e, EFTB_T_AD), e->SAD);
+    else return fail("loop-matrix basis of dimension %d + %d is not instantiated (expected 7 + 2)", c.nbasis, c.with_resum ? c.nbasis13 : 0);
+    return 0;
 }
 
-
-// Pair GEMM launcher.  When the row tiles alone cannot fill the 256 CUs evenly (small batches, or the 1.25-round
-// tail of the xi-space contraction at batch 128) the K range is additionally split over `ks` workgroups; their
-// unscaled partials are summed in a fixed order by pair_sum_kernel (deterministic).
-static int pick_ksplit(int row_tiles) {
-    int best = 1;
-    double best_eff = 0.0;
-    for (int ks = 1; ks <= 8; ks *= 2) {
-        const int n = row_tiles * ks;
-        const double eff = (double)n / (((n + 255) / 256) * 256.0);
-        if (eff >= 0.85) return ks;
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = ks; }
-    }
-    return best;
-}
-
-template <int MT, int NT, int NW>
-static void launch_pair(eftb_engine* e, hipStream_t st, const double* coef, const double* pw, const double* frag, const int* plan, int rows, int rows_per_w,
-                        int nbasis, const double* comb, int ncols_out, int ncols_ld, const double* rowscale, double* out, double* part,
-                        const LinTerms& lin) {
-    const int tiles = (rows + MT * 16 - 1) / (MT * 16);
-    const int ks = pick_ksplit(tiles);
-    int level = 0;
-    while ((1 << level) < ks) ++level;
-    const int* pl = plan + 4 * NW * ((1 << level) - 1);  // plans for 1, 2, 4, 8 splits are stored back to back
-    hipLaunchKernelGGL((pair_gemm_kernel<MT, NT, NW>), dim3(tiles, ks), dim3(64 * NW), pair_lds_bytes(MT, NT, NW), st, coef, pw, frag, pl, rows, rows_per_w,
-                       nbasis, comb, ncols_out, ncols_ld, rowscale, out, part, lin);
-    if (ks > 1)
-        hipLaunchKernelGGL(pair_sum_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, ks, rows, rows_per_w, nbasis, comb, ncols_out, ncols_ld,
-                           rowscale, part, out);
+static void launch_rows(eftb_engine* e, hipStream_t st, int B, int sets) {
+    const eftb_config& c = e->c;
+    hipLaunchKernelGGL(build_rows_kernel, dim3(B, 4), dim3(256), 0, st, sets, c.Nl, c.nbasis, c.with_resum ? c.nbasis13 : 0, e->buf[EFTB_B_COEF], e->SAD,
+                       tb<double>(e, EFTB_T_COMB22), tb<double>(e, EFTB_T_COMB13), tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22,
+                       e->A13, e->ACF, e->ALC);
 }
 
 // out[w][a][r][x] = sum_{l,k} T[w][l][r][k] * opT[(l,k)][(a,x)] on the FP64 matrix cores; the block changes shape
@@ -251,58 +228,29 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     hipStream_t st = e->stream;
     const int Nk = c.Nk, Nl = c.Nl;
     double** b = e->buf;
-    // the k-space (LOOPS) and xi-space (CF) contractions are independent: when both are requested the CF
-    // kernels go to a second stream so their workgroups back-fill the CUs the P22 grid leaves idle
-    const bool fork = e->use_fork && (mask & EFTB_S_LOOPS) && (mask & EFTB_S_CF);
-    hipStream_t stc = fork ? e->stream2 : st;
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
         hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
                            b[EFTB_B_P11], b[EFTB_B_COEF]);
     }
-    if (fork) {
-        if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(stc, e->evFork, 0) != hipSuccess)
-            return fail("eftb_run: stream fork failed");
-    }
-    if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
-        LinTerms lin{};  // P13 rides on the P22 workgroups' u tile
-        if (mask & EFTB_S_LOOPS) {
-            lin.nA = 10; lin.vecA = tb<double>(e, EFTB_T_M13R); lin.scaleA = e->k3; lin.rowdata = b[EFTB_B_P11]; lin.outA = b[EFTB_B_P13];
-        }
-        if (c.nbasis <= 8) {  // two runs share the 16 MFMA columns: 14 of 16 useful instead of 7 of 16
-            const int rows = B * Nk, tiles = (rows + 63) / 64, ks = pick_ksplit(tiles);
-            int level = 0;
-            while ((1 << level) < ks) ++level;
-            const int* pl = tb<int>(e, EFTB_T_PLANQ) + 4 * NW_P22 * ((1 << level) - 1);
-                hipLaunchKernelGGL((pair_gemm2r_kernel<NW_P22>), dim3(tiles, ks), dim3(64 * NW_P22), pair2r_lds_bytes(NW_P22), st, b[EFTB_B_COEF],
-                                   tb<double>(e, EFTB_T_KPOW), tb<double>(e, EFTB_T_PAIRS22D), pl, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28,
-                                   28, e->k3, b[EFTB_B_P22], e->pairpartP, lin);
-            if (ks > 1)
-                hipLaunchKernelGGL(pair_sum_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, ks, rows, Nk, c.nbasis, tb<double>(e, EFTB_T_COMB22), 28,
-                                   28, e->k3, e->pairpartP, b[EFTB_B_P22]);
-        } else {
-            launch_pair<4, 1, NW_P22>(e, st, b[EFTB_B_COEF], tb<double>(e, EFTB_T_KPOW), tb<double>(e, EFTB_T_PAIRS22), tb<int>(e, EFTB_T_PLAN), B * Nk, Nk, c.nbasis,
-                                      tb<double>(e, EFTB_T_COMB22), 28, 28, e->k3, b[EFTB_B_P22], e->pairpartP, lin);
-        }
-    }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
-    if (mask & (EFTB_S_CF | EFTB_K_C22)) {
-        LinTerms lin{};  // C11 and Cct ride on the C22 workgroups' u tile
-        if (mask & EFTB_S_CF) {
-            lin.nA = Nl; lin.vecA = tb<double>(e, EFTB_T_C11R); lin.outA = b[EFTB_B_C11];
-            lin.nB = Nl; lin.vecB = tb<double>(e, EFTB_T_CCTR); lin.scaleB = e->sm2; lin.outB = b[EFTB_B_CCT];
-        }
-        if (c.ncolsC == 32)
-            launch_pair<4, 2, NW_C>(e, stc, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
-                                    tb<double>(e, EFTB_T_COMBC), Nl * 38, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
-        else
-            launch_pair<4, 1, NW_C>(e, stc, b[EFTB_B_COEF], tb<double>(e, EFTB_T_SPOW), tb<double>(e, EFTB_T_PAIRSC), tb<int>(e, EFTB_T_PLANC), B * NS, NS, c.ncolsC,
-                                    tb<double>(e, EFTB_T_COMBC), Nl * 38, Nl * 38, nullptr, b[EFTB_B_CC], e->pairpartC, lin);
+    // the anti-diagonal sums serve both the k-space and the xi-space pieces
+    if (mask & (EFTB_S_LOOPS | EFTB_S_CF | EFTB_K_P22 | EFTB_K_C22))
+        if (int rc = launch_antidiag(e, st, B)) return rc;
+    if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
+        launch_rows(e, st, B, (mask & EFTB_S_LOOPS) ? 0x3 : 0x1);
+        launch_synth(st, B, e->A22, 28LL * KSYN, 28, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, b[EFTB_B_P22], nullptr, nullptr, 0);
+        if (mask & EFTB_S_LOOPS)
+            launch_synth(st, B, e->A13, 10LL * KLIN, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], b[EFTB_B_P11], nullptr, 0);
     }
-    if (fork) {
-        if (hipEventRecord(e->evJoin, stc) != hipSuccess || hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess)
-            return fail("eftb_run: stream join failed");
+    if (mask & (EFTB_S_CF | EFTB_K_C22)) {
+        launch_rows(e, st, B, (mask & EFTB_S_CF) ? 0xc : 0x4);
+        launch_synth(st, B, e->ACF, (long long)Nl * 38 * KSYN, Nl * 38, KSYN, tb<double>(e, EFTB_T_SYNS), NS, b[EFTB_B_CC], nullptr, nullptr, 0);
+        if (mask & EFTB_S_CF) {
+            launch_synth(st, B, e->ALC, 2LL * Nl * KLIN, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], nullptr, nullptr, 0);
+            launch_synth(st, B, e->ALC + (size_t)Nl * KLIN, 2LL * Nl * KLIN, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCT], nullptr, e->sm2, 0);
+        }
     }
     if (mask & EFTB_S_REGROUP) {
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
@@ -401,7 +349,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
 extern "C" {
 
 const char* eftb_last_error(void) { return g_err.c_str(); }
-const char* eftb_version(void) { return "eftbird 0.1 (gfx950, fp64 mfma pair-gemm)"; }
+const char* eftb_version(void) { return "eftbird 0.2 (gfx950, fp64: anti-diagonal loops + mfma synthesis)"; }
 
 int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (!cfg || !out) return fail("eftb_create: null argument");
@@ -409,7 +357,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (c.Nl != 2 && c.Nl != 3) return fail("eftb_create: Nl must be 2 or 3 (got %d)", c.Nl);
     if (c.Nk < 8 || c.Nkin < 4 || c.max_batch < 1) return fail("eftb_create: bad dimensions Nk=%d Nkin=%d max_batch=%d", c.Nk, c.Nkin, c.max_batch);
     if (c.nbasis < 1 || c.nbasis > 16) return fail("eftb_create: nbasis=%d outside [1, 16]", c.nbasis);
-    if (c.with_resum && (c.ncolsC % 16 || c.ncolsC < c.Nl * c.nbasis || c.ncolsC > 32)) return fail("eftb_create: bad ncolsC=%d", c.ncolsC);
+    if (c.with_resum && (c.nbasis13 < 1 || c.nbasis13 > 4)) return fail("eftb_create: nbasis13=%d outside [1, 4]", c.nbasis13);
     if (c.with_resum && !((c.Nl == 3 && c.NIR == 16 && c.Na == 3) || (c.Nl == 2 && c.NIR == 8 && c.Na == 2)))
         return fail("eftb_create: (Nl, NIR, Na) = (%d, %d, %d) unsupported", c.Nl, c.NIR, c.Na);
     int ndev = 0;
@@ -422,14 +370,10 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->Nn = 2 * c.NIR * c.Na;
     e->cur_nl = c.Nl;
     e->cur_nx = c.Nk;
-    if (const char* f = getenv("EFTB_FORK")) e->use_fork = (f[0] == '1');
     if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(3, std::max(1, atoi(f)));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
-    HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming));
     for (int id = 0; id < EFTB_B_COUNT; ++id) {
         const size_t n = need_buffer_elems(c, id);
         e->buf_elems[id] = n;
@@ -439,12 +383,18 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         }
     }
     const size_t B = c.max_batch;
-    HIPCHK(hipMalloc(&e->k3, c.Nk * sizeof(double)));
     HIPCHK(hipMalloc(&e->sm2, NS * sizeof(double)));
-    e->ldtv = (c.Nl * NPOW + 15) / 16 * 16;
-    HIPCHK(hipMalloc(&e->pairpartP, (size_t)8 * B * c.Nk * 16 * sizeof(double)));
+    // scratch of the anti-diagonal pipeline; the synthesis rows are zero beyond their last coefficient (K padded to 4)
+    HIPCHK(hipMalloc(&e->SAD, B * (c.nbasis + (c.with_resum ? c.nbasis13 : 0)) * NPOW * sizeof(double2)));
+    HIPCHK(hipMalloc(&e->A22, B * 28 * KSYN * sizeof(double)));
+    HIPCHK(hipMemset(e->A22, 0, B * 28 * KSYN * sizeof(double)));
+    HIPCHK(hipMalloc(&e->A13, B * 10 * KLIN * sizeof(double)));
+    HIPCHK(hipMemset(e->A13, 0, B * 10 * KLIN * sizeof(double)));
     if (c.with_resum) {
-        HIPCHK(hipMalloc(&e->pairpartC, (size_t)8 * B * NS * 32 * sizeof(double)));
+        HIPCHK(hipMalloc(&e->ACF, B * c.Nl * 38 * KSYN * sizeof(double)));
+        HIPCHK(hipMemset(e->ACF, 0, B * c.Nl * 38 * KSYN * sizeof(double)));
+        HIPCHK(hipMalloc(&e->ALC, B * 2 * c.Nl * KLIN * sizeof(double)));
+        HIPCHK(hipMemset(e->ALC, 0, B * 2 * c.Nl * KLIN * sizeof(double)));
     }
     HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
     if (c.with_ap) {
@@ -472,12 +422,6 @@ int eftb_set_table(eftb_engine* e, int id, const void* host, size_t nbytes) {
         for (int i = 0; i < NS; ++i) v[i] = 1.0 / (sv[i] * sv[i]);
         HIPCHK(hipMemcpy(e->sm2, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     }
-    if (id == EFTB_T_K) {
-        std::vector<double> k3(e->c.Nk);
-        const double* k = static_cast<const double*>(host);
-        for (int i = 0; i < e->c.Nk; ++i) k3[i] = k[i] * k[i] * k[i];
-        HIPCHK(hipMemcpy(e->k3, k3.data(), k3.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
     return 0;
 }
 
@@ -500,11 +444,7 @@ int eftb_finalize(eftb_engine* e) {
             HIPCHK(hipMalloc(&e->RSC, (size_t)c.max_batch * NS * RS_REC * sizeof(double)));
         }
     }
-    // opt in to the large dynamic LDS tiles of the pair GEMM
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm2r_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 2, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_gemm_kernel<4, 1, NW_C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // opt in to the large dynamic LDS tiles
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define AP_LDS(NLV, NRV, RSV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_apply_kernel<NLV, NRV, RSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3);
@@ -576,11 +516,10 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->k3, e->gathered, e->V, e->pairpartP, e->pairpartC, e->sm2}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->V, e->A22, e->A13, e->ACF, e->ALC, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin}) if (ev) (void)hipEventDestroy(ev);
-    if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    for (hipEvent_t ev : {e->ev0, e->ev1}) if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

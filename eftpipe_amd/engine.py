@@ -16,57 +16,7 @@ from . import _lib as L
 from .tables import EngineConfig, build_tables
 
 NROW = 24
-NW_P22, NW_C = 16, 8  # waves per workgroup (K slices) of the two pair GEMMs; must match csrc/eftbird.hip
 ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
-
-
-def wave_plan(steps, nwaves=8):
-    """Split the K-steps of the pair contraction evenly over `nwaves` K slices: (n, m0, first step, count) each."""
-    from .tables import KU
-
-    T = len(steps) // KU  # slices start and end on KU-step boundaries (every n-run is a multiple of KU steps)
-    plan = np.zeros((nwaves, 4), dtype=np.int32)
-    for q in range(nwaves):
-        t0, t1 = KU * ((q * T) // nwaves), KU * (((q + 1) * T) // nwaves)
-        plan[q] = (steps[t0, 0], steps[t0, 1], t0, t1 - t0)
-    return plan
-
-
-RUN_COST = float(os.environ.get("EFTB_PLAN_RUNCOST", "3"))  # cost of starting / closing a run, in double steps
-
-
-def wave_plan_2run(steps4, nwaves):
-    """Same for the double-run steps of pair_gemm2r_kernel (no KU padding there).  Slices are balanced on
-    steps + RUN_COST * (runs touched): the tail of the table is made of many short runs whose per-run epilogue
-    (accumulator scaling by u_n) would otherwise make the last waves the slowest."""
-    T = len(steps4)
-    first = np.concatenate([[True], steps4[1:, 0] != steps4[:-1, 0]])
-    cost = np.cumsum(1.0 + RUN_COST * first)
-    cuts = [0] + [int(np.searchsorted(cost, cost[-1] * q / nwaves)) for q in range(1, nwaves)] + [T]
-    cuts = np.maximum.accumulate(np.array(cuts))
-    for q in range(1, nwaves):  # every slice keeps at least one step
-        cuts[q] = min(max(cuts[q], cuts[q - 1] + 1), T - (nwaves - q))
-    plan = np.zeros((nwaves, 4), dtype=np.int32)
-    for q in range(nwaves):
-        t0, t1 = cuts[q], cuts[q + 1]
-        plan[q] = (steps4[t0, 0], steps4[t0, 1], t0, t1 - t0)
-    return plan
-
-
-def split_plans(steps, nwaves, plan=wave_plan):
-    """Plans for 1, 2, 4 and 8 workgroup-level K splits, back to back ([15 * nwaves, 4]); the workgroup
-    with blockIdx.y = s of a ks-way split uses entries [(ks - 1 + s) * nwaves, (ks + s) * nwaves)."""
-    return np.concatenate([plan(steps, nwaves * ks) for ks in (1, 2, 4, 8)])
-
-
-def _padded_fragments(frag):
-    """[T, J, 4, 16] -> [(T + KU), J, 64] with one zero iteration (the kernel prefetches one iteration ahead)."""
-    from .tables import KU
-
-    T, J = frag.shape[:2]
-    out = np.zeros((T + KU, J, 64))
-    out[:T] = frag.reshape(T, J, 64)
-    return out
 
 
 class Engine:
@@ -85,11 +35,10 @@ class Engine:
         c.with_resum, c.with_ap, c.ap_stochastic = int(cfg.with_resum), int(cfg.with_ap), int(cfg.APst)
         c.nmu = cfg.nbinsmu
         c.ntail = t["lnx_tail"].size
-        c.nsteps = len(t["steps"])
         c.nbasis = t["comb22"].shape[1]
+        c.nbasis13 = t["comb13"].shape[1] if cfg.with_resum else 0
         if cfg.with_resum:
             c.nxtail = t["lnx_xtail"].size
-            c.ncolsC = t["pairsC"].shape[1] * 16
             c.NIR, c.Na, c.Nklow = (int(x) for x in t["resum_dims"])
         self._cconf = c
         h = C.c_void_p()
@@ -112,24 +61,20 @@ class Engine:
         self._set("GCT", t["Gc"].transpose(0, 2, 1))
         self._set("ECT", t["Ec"].transpose(0, 2, 1))
         self._set("LNXTAIL", t["lnx_tail"])
-        self._set("KPOW", t["kpow"])
-        self._set("PAIRS22", _padded_fragments(t["pairs22"]))
-        if "pairs22d" in t:  # zero double steps at the end: the kernel prefetches PAIR4_PF = 4 steps ahead
-            self._set("PAIRS22D", np.concatenate([t["pairs22d"], np.zeros((4, 64))]))
-            self._set("PLANQ", split_plans(t["steps4"], NW_P22, wave_plan_2run), np.int32)
-        self._set("PLAN", split_plans(t["steps"], NW_P22), np.int32)
-        self._set("M13R", t["m13r"])
+        cplx = lambda z: np.stack([z.real, z.imag], axis=-1)  # complex -> (re, im) pairs (device double2)
+        self._set("AD", cplx(t["ad"]))
         self._set("COMB22", t["comb22"])
+        self._set("LINVEC", cplx(t["linvec"]))
+        self._set("SYNK", t["syn_k"])
+        self._set("LINK", t["lin_k"])
         for n in ("L11", "LCT", "L22", "L13"):
             self._set(n, t[n.lower()])
         self._set("GRP", np.concatenate([t["grp22"], t["grp13"]]), np.int32)
         if cfg.with_resum:
-            self._set("SPOW", t["spow"])
-            self._set("PAIRSC", _padded_fragments(t["pairsC"]))
-            self._set("PLANC", split_plans(t["steps"], NW_C), np.int32)
-            self._set("COMBC", t["combC"])
-            self._set("C11R", t["c11r"])
-            self._set("CCTR", t["cctr"])
+            self._set("COMB13", t["comb13"])
+            self._set("MLJ", cplx(t["mlj"]))
+            self._set("SYNS", t["syn_s"])
+            self._set("LINS", t["lin_s"])
             self._set("BXT", t["BX"].T)
             self._set("BYT", t["BY"].T)
             self._set("TXT", t["TX"].T)

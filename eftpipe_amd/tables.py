@@ -7,9 +7,9 @@ operators and real-reduced pair tables; the device then only runs real FP64 cont
 
   * ``Sk``        cubic not-a-knot spline  kin -> k          (Bird.__init__, pybird.py:694-695)
   * ``G*``/``E*`` FFTLog.Coef as a matrix + power-law tails  (fftlog.py:84-166)
-  * ``kpow/spow`` k^Pow, s^(-Pow-3)                          (pybird.py:1058-1064)
-  * ``pairs22``   sum_{nm} x_n M22[b,n,m] x_m  as  sum_{n<=m} (u_n u_m) R[b,(n,m)]  with u the
-                  real/imag parts of the 129 independent x_n  (pybird.py:1074-1078, 1103-1125)
+  * ``ad``        the loop matrices in anti-diagonal form: sum_{nm} x_n M[n,m] x_m = sum_j k^{..j} S[j] with the
+                  k-independent S[j] = sum_{n+m=j} c_n c_m M[n,m]           (pybird.py:1074-1078, 1103-1125)
+  * ``syn_*``     the 513-term (257 for the single sums) real synthesis bases k^{..}{1, cos, sin}  (pybird.py:1058-1064)
   * ``H``         resum FFTLog(192) + Bessel sum as a real [Na, Nk, Ns] operator (pybird.py:1361-1365,1409-1411)
   * ``BX/BY``     IR filters X(s), Y(s) as real [Ns, Nkin] operators + tails (pybird.py:1316-1353)
   * spline LU     tridiagonal factors of the not-a-knot system on the k grid (AP, pybird.py:1586-1593)
@@ -32,7 +32,6 @@ from . import loopmath as lm
 NS = 80          # |sbird|
 NPOW = 257       # NFFT + 1 for the loop FFTLog
 NHALF = 128
-UPAD = 260       # row stride of the real-reduced coefficient vectors in HBM (doubles)
 
 
 # ----------------------------------------------------------------------------- FFTLog as an operator
@@ -70,7 +69,8 @@ class FFTLogOperator:
         i = np.arange(N)
         self.x = xmin * np.exp(i * self.dx)
         m = np.arange(N + 1)
-        self.Pow = bias + 1j * 2.0 * np.pi / (N * self.dx) * (m - N / 2.0)
+        self.dpow = 2.0 * np.pi / (N * self.dx)
+        self.Pow = bias + 1j * self.dpow * (m - N / 2.0)
         coef_factor = xmin ** (-self.Pow) / float(N)
         lo = int(np.searchsorted(self.x, xin[0]))
         hi = int(np.searchsorted(self.x, xin[-1], side="right"))
@@ -93,46 +93,6 @@ class FFTLogOperator:
 
 
 # ----------------------------------------------------------------------------- real reduction
-def realify_matrix():
-    """T with x = T u, u = (Re x_0..Re x_127, x_128, Im x_0..Im x_127), x_{256-n} = conj(x_n)."""
-    T = np.zeros((NPOW, NPOW), dtype=complex)
-    n = np.arange(NHALF)
-    T[n, n] = 1.0
-    T[n, NHALF + 1 + n] = 1j
-    T[NHALF, NHALF] = 1.0
-    T[2 * NHALF - n, n] = 1.0
-    T[2 * NHALF - n, NHALF + 1 + n] = -1j
-    return T
-
-
-def reduce_linear(vec):
-    """Re sum_n x_n v_n = u . r  for conjugate-symmetric v  ->  r[..., 257]."""
-    v = np.asarray(vec)
-    return np.concatenate([2.0 * v[..., :NHALF].real, v[..., NHALF:NHALF + 1].real, -2.0 * v[..., :NHALF].imag], axis=-1)
-
-
-def reduce_quadratic(M):
-    """Re sum_nm x_n M_nm x_m = u^T R u  ->  R[..., 257, 257] (real; imaginary residue returned too).
-
-    R = T^T M T written out block by block (x_n = a_n + i b_n, x_{256-n} = a_n - i b_n, x_128 = c)."""
-    M = np.asarray(M)
-    h, c = NHALF, NHALF
-    lo, hi = slice(0, h), slice(2 * h, h, -1)          # n and its mirror 256 - n
-    A, B, Cm, D = M[..., lo, lo], M[..., lo, hi], M[..., hi, lo], M[..., hi, hi]
-    R = np.empty(M.shape, dtype=complex)
-    R[..., :h, :h] = A + B + Cm + D
-    R[..., :h, h + 1:] = 1j * (A - B + Cm - D)
-    R[..., h + 1:, :h] = 1j * (A + B - Cm - D)
-    R[..., h + 1:, h + 1:] = -(A - B - Cm + D)
-    R[..., :h, c] = M[..., lo, c] + M[..., hi, c]
-    R[..., c, :h] = M[..., c, lo] + M[..., c, hi]
-    R[..., h + 1:, c] = 1j * (M[..., lo, c] - M[..., hi, c])
-    R[..., c, h + 1:] = 1j * (M[..., c, lo] - M[..., c, hi])
-    R[..., c, c] = M[..., c, c]
-    scale = np.max(np.abs(R.real)) or 1.0
-    return np.ascontiguousarray(R.real), float(np.max(np.abs(R.imag)) / scale)
-
-
 def loop_basis(M22, tol=1e-11):
     """The 28 loop matrices M22[b] span a space of dimension 7 only (they are built from a handful of F2/G2
     angular structures): pick a well-conditioned subset by column-pivoted QR and express every M22[b] as a real
@@ -151,67 +111,51 @@ def loop_basis(M22, tol=1e-11):
     return basis, np.ascontiguousarray(X.real)
 
 
-KU = 2  # K-steps per inner-loop iteration of the pair GEMM (must match csrc/eftb_kernels.hpp PAIR_KU)
+def antidiagonal_tables(M22b, M13b):
+    """The one-loop double sums in anti-diagonal form.
 
+    With x_n(k) = c_n k^{Pow_n} and Pow_n = bias + i dpow (n - N/2) the k dependence of a pair (n, m) is
+    k^{2 bias + i dpow (n + m - N)}: it depends on n + m only.  Hence for any loop matrix M
 
-def pair_steps():
-    """K-steps of the pair contraction: step t covers pairs (n, m0..m0+3), n <= m0; every n-run is padded with
-    zero-weight steps to a multiple of KU steps so that the kernel's inner loop can take KU steps per iteration."""
-    out = []
-    for n in range(NPOW):
-        cnt = (NPOW - n + 3) // 4
-        cnt = (cnt + KU - 1) // KU * KU
-        out += [(n, n + 4 * j) for j in range(cnt)]
-    return np.array(out, dtype=np.int32)
+        sum_{n,m} x_n M[n,m] x_m  =  sum_{j'=-N..N}  k^{2 bias + i dpow j'}  S[j'],     S[j'] = sum_{n+m=N+j'} c_n c_m M[n,m],
 
+    i.e. ONE k-independent pass over the 257^2 matrix entries per cosmology (the anti-diagonal sums S) followed by a
+    513-term synthesis per k -- instead of 257^2 terms per k (reference pybird.py:1074-1078, 1103-1125).  The same S
+    serve P22 at every k and, multiplied by Ml(n + m), C22 / C13 at every s and l.  S[-j'] = conj S[j'], so only
+    j' = 0..N is kept.  Exact regrouping of the same sum (verified to 1e-15 against the reference in tests).
 
-def pair_fragments(R, ncols_pad):
-    """R[cols, 257, 257] -> MFMA-B-operand fragments [T, ncols_pad/16, 4, 16] (f64).
-
-    Element [t, j, g, c] multiplies u[n]*u[m0+g] for column 16j+c; symmetric partner folded in.
-    The layout is exactly one ``v_mfma_f64_16x16x4_f64`` B fragment (lane = 16 g + c) per (t, j),
-    512 contiguous bytes, so a wave loads it with one coalesced 8-byte-per-lane instruction.
-    """
-    ncols = R.shape[0]
-    st = pair_steps()
-    frag = np.zeros((len(st), ncols_pad, 4))
-    Rs = R + np.swapaxes(R, 1, 2)
+    -> AD[c, j', t] complex, t = 0..128: the symmetrised weight of the pair (n, m) = (j' + t, N - t), n <= m, of matrix c
+       (M22 basis first: M[n,m] + M[m,n], or M[n,n]; then the row-broadcast M13 basis: V[n] + V[m], or V[n]); zero
+       beyond the end of the anti-diagonal."""
+    N = NPOW - 1
+    mats = [np.asarray(M22b)]
+    if M13b is not None:
+        mats.append(np.asarray(M13b)[:, :, None] * np.ones((1, 1, NPOW)))
+    M = np.concatenate(mats)
+    Ms = M + np.swapaxes(M, 1, 2)
     idx = np.arange(NPOW)
-    Rs[:, idx, idx] = R[:, idx, idx]
-    for g in range(4):
-        m = st[:, 1] + g
-        ok = m < NPOW
-        frag[ok, :ncols, g] = Rs[:, st[ok, 0], m[ok]].T   # padded steps (m0 > 256) keep zero weights
-    return np.ascontiguousarray(frag.reshape(len(st), ncols_pad // 16, 16, 4).transpose(0, 1, 3, 2))
+    Ms[:, idx, idx] = M[:, idx, idx]
+    AD = np.zeros((M.shape[0], NPOW, NHALF + 2), dtype=complex)
+    for jp in range(NPOW):
+        cnt = ((N + jp) >> 1) - jp + 1
+        tt = np.arange(cnt)
+        AD[:, jp, :cnt] = Ms[:, jp + tt, N - tt]
+    return AD
 
 
-def pair_steps_2run():
-    """K-steps of the two-run form of the pair contraction: step t covers pairs (n, m0..m0+3) AND (n+1, m0..m0+3) for an
-    even n (a "double run": both runs read the same u[m0..m0+3] operand and share the 16 columns of one MFMA)."""
-    out = []
-    for n in range(0, NPOW, 2):
-        out += [(n, n + 4 * j) for j in range(((NPOW - 1 - n) >> 2) + 1)]
-    return np.array(out, dtype=np.int32)
-
-
-def pair_fragments_2run(R):
-    """R[cols <= 8, 257, 257] -> B fragments of v_mfma_f64_16x16x4_f64 for the double steps of pair_steps_2run, [T, 64] (f64):
-    lane 16 g + c holds the weight of pair (n_t + (c >> 3), m0_t + g) for basis column c & 7 (two runs share the 16 MFMA
-    columns); pairs with m < n + (c >> 3) or beyond the table are zero."""
-    ncols = R.shape[0]
-    assert ncols <= 8
-    st = pair_steps_2run()
-    Rs = R + np.swapaxes(R, 1, 2)
-    idx = np.arange(NPOW)
-    Rs[:, idx, idx] = R[:, idx, idx]
-    w = np.zeros((len(st), 4, 16))                      # [t, g, c]
-    for r in range(2):
-        n = st[:, 0] + r
-        for g in range(4):
-            m = st[:, 1] + g
-            ok = (m < NPOW) & (n < NPOW) & (m >= n)
-            w[ok, g, 8 * r : 8 * r + ncols] = Rs[:, n[ok], m[ok]].T
-    return np.ascontiguousarray(w.reshape(len(st), 64))
+def synthesis_table(lnx, power, dpow, nharm, sign):
+    """Real basis of  x^power [ Z_0 + 2 Re sum_{j=1..nharm} Z_j e^{sign i dpow j ln x} ]  for coefficient rows stored as
+    (Re Z_0, Re Z_1, Im Z_1, Re Z_2, Im Z_2, ...):  -> [Kpad, len(x)], Kpad = 1 + 2 nharm rounded up to 16 (zero rows; four
+    MFMA K-steps per loop iteration of synth_kernel)."""
+    K = 1 + 2 * nharm
+    out = np.zeros(((K + 15) // 16 * 16, lnx.size))
+    amp = np.exp(power * lnx)
+    out[0] = amp
+    j = np.arange(1, nharm + 1)
+    th = dpow * np.outer(j, lnx)
+    out[1:K:2] = 2.0 * amp * np.cos(th)
+    out[2:K:2] = -sign * 2.0 * amp * np.sin(th)
+    return out
 
 
 # ----------------------------------------------------------------------------- cubic spline (not-a-knot)
@@ -321,50 +265,27 @@ def build_tables(cfg: EngineConfig) -> dict:
     t["lnx_tail"] = op.lnx_hi
     Pow = op.Pow
     nu = -0.5 * Pow
-    kp = np.exp(np.outer(np.log(k), Pow[:nh]))            # [Nk,129]
-    sp = np.exp(np.outer(np.log(s), -Pow[:nh] - 3.0))     # [Ns,129]
-    t["kpow"] = np.ascontiguousarray(np.stack([kp.real, kp.imag], axis=1))   # [Nk,2,129]
-    t["spow"] = np.ascontiguousarray(np.stack([sp.real, sp.imag], axis=1))   # [Ns,2,129]
-
-    # ---- loop matrices, real-reduced
+    # ---- one-loop pieces through the anti-diagonal form (see antidiagonal_tables)
     M22 = lm.matrices_22(nu)
     M13 = lm.vectors_13(nu)
     ells = 2 * np.arange(Nl)
-    Mcf11 = lm.bessel_weight(ells[:, None], nu[None, :])
-    Mcfct = lm.bessel_weight(ells[:, None], nu[None, :] - 1.0)
-    Ml = lm.bessel_weight(ells[:, None, None], nu[None, :, None] + nu[None, None, :] - 1.5)
     basis, comb = loop_basis(M22)
-    nb = len(basis)
     t["basis22"], t["comb22"] = basis.astype(np.int32), comb                 # M22[b] = sum_c comb[b, c] M22[basis[c]]
-    R22, im22 = reduce_quadratic(M22[basis])
-    t["steps"] = pair_steps()
-    t["pairs22"] = pair_fragments(R22, 16)
-    if nb <= 8:
-        t["steps4"] = pair_steps_2run()
-        t["pairs22d"] = pair_fragments_2run(R22)
-    t["m13r"] = np.ascontiguousarray(reduce_linear(M13))                 # [10,257]
-    resid = [im22]
+    vecs = [M13]
     if cfg.with_resum:
-        # columns of the configuration-space pair contraction:
-        #   [l*nb + c]            = Ml[l] (.) M22[basis[c]]                      ->  C22[l, b] = sum_c comb[b, c] col
-        #   [Nl*nb + l*nb13 + c]  = Ml[l] (.) M13[basis13[c]] (row-broadcast)    ->  C13[l, b] = sum_c comb13[b, c] col
-        # (the 10 M13 vectors span 2 dimensions; their 2*Nl columns fit the padding of the second MFMA column tile)
         basis13, comb13 = loop_basis(M13)
-        nb13 = len(basis13)
-        Rc22, imc = reduce_quadratic((Ml[:, None] * M22[basis][None]).reshape(Nl * nb, NPOW, NPOW))
-        Rc13, imd = reduce_quadratic((Ml[:, None] * M13[basis13][None, :, :, None]).reshape(Nl * nb13, NPOW, NPOW))
-        resid += [imc, imd]
-        ncol = Nl * (nb + nb13)
-        ncp = 16 * ((ncol + 15) // 16)
-        t["pairsC"] = pair_fragments(np.concatenate([Rc22, Rc13]), ncp)
-        combC = np.zeros((Nl * 38, ncp))
-        for l in range(Nl):
-            combC[l * 28 : (l + 1) * 28, l * nb : (l + 1) * nb] = comb
-            combC[Nl * 28 + l * 10 : Nl * 28 + (l + 1) * 10, Nl * nb + l * nb13 : Nl * nb + (l + 1) * nb13] = comb13
-        t["combC"] = combC
-        t["c11r"] = np.ascontiguousarray(reduce_linear(Mcf11))           # [Nl,257]
-        t["cctr"] = np.ascontiguousarray(reduce_linear(Mcfct))           # [Nl,257]
-    t["reduction_residue"] = np.array(resid)
+        t["comb13"] = comb13                                                  # M13[b] = sum_c comb13[b, c] M13[basis13[c]]
+        t["ad"] = antidiagonal_tables(M22[basis], M13[basis13])
+        jp = np.arange(NPOW)
+        t["mlj"] = lm.bessel_weight(ells[:, None], -op.bias - 0.5j * op.dpow * jp[None, :] - 1.5)   # Ml depends on n + m only
+        vecs += [lm.bessel_weight(ells[:, None], nu[None, :]), lm.bessel_weight(ells[:, None], nu[None, :] - 1.0)]
+        t["syn_s"] = synthesis_table(np.log(s), -2.0 * op.bias - 6.0, op.dpow, NPOW - 1, sign=-1.0)
+        t["lin_s"] = synthesis_table(np.log(s), -op.bias - 3.0, op.dpow, NHALF, sign=+1.0)
+    else:
+        t["ad"] = antidiagonal_tables(M22[basis], None)
+    t["linvec"] = np.ascontiguousarray(np.concatenate(vecs)[:, :nh])          # [10 (+ 2 Nl), 129] complex: M13, Mcf11, Mcfct
+    t["syn_k"] = synthesis_table(np.log(k), 3.0 + 2.0 * op.bias, op.dpow, NPOW - 1, sign=+1.0)
+    t["lin_k"] = synthesis_table(np.log(k), 3.0 + op.bias, op.dpow, NHALF, sign=-1.0)
 
     # ---- IR-resummation
     if cfg.with_resum:

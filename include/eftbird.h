@@ -39,24 +39,23 @@ typedef struct eftb_config {
     int32_t nmu;           /* AP mu nodes (nbinsmu*accboost)                            pybird.py:1538 */
     int32_t ntail;         /* high-k power-law tail length of the loop FFTLog           fftlog.py:146-151 */
     int32_t nxtail;        /* same for the 32-point IR-filter FFTLog                    pybird.py:1293 */
-    int32_t nsteps;        /* K-steps of the pair contraction (eftpipe_amd/tables.py pair_steps) */
-    int32_t ncolsC;        /* padded basis columns of the xi contraction (16 or 32)     */
-    int32_t nbasis;        /* dimension of the span of the 28 loop matrices (7)         tables.py loop_basis */
+    int32_t nbasis;        /* dimension of the span of the 28 M22 loop matrices (7)     tables.py loop_basis */
+    int32_t nbasis13;      /* dimension of the span of the 10 M13 vectors (2)           tables.py loop_basis */
     int32_t NIR, Na, Nklow;/* Resum.NIR, Resum.Na, Common.Nklow                         pybird.py:1247-1259, 560 */
 } eftb_config;
 
 /* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file). */
 enum eftb_table {
     EFTB_T_K = 0, EFTB_T_S, EFTB_T_LNKIN, EFTB_T_SKT, EFTB_T_GCT, EFTB_T_ECT, EFTB_T_LNXTAIL,
-    EFTB_T_KPOW, EFTB_T_SPOW, EFTB_T_PAIRS22, EFTB_T_PAIRSC, EFTB_T_PLAN, EFTB_T_M13R, EFTB_T_C11R,
-    EFTB_T_CCTR, EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
+    /* one-loop pieces in anti-diagonal form (tables.py antidiagonal_tables, synthesis_table) */
+    EFTB_T_AD, EFTB_T_COMB22, EFTB_T_COMB13, EFTB_T_MLJ, EFTB_T_LINVEC, EFTB_T_SYNK, EFTB_T_SYNS, EFTB_T_LINK, EFTB_T_LINS,
+    EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
     EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
-    EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
-    EFTB_T_PLANC, EFTB_T_COMB22, EFTB_T_COMBC, EFTB_T_PLANQ,
     EFTB_T_RSBASIS, EFTB_T_RSBASISS, EFTB_T_RSROWS,   /* matrix-core IR-resummation (Nl = 3): tables.py resum_mfma_tables */
-    EFTB_T_PAIRS22D,                                   /* two-run 16x16x4 fragments of P22: tables.py pair_fragments_2run */
+    EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
     EFTB_T_COUNT
 };
+
 
 /* Device-resident state (per engine, [max_batch] leading axis unless noted). */
 enum eftb_buffer {
@@ -94,8 +93,8 @@ enum eftb_stage {
     EFTB_S_REDUCE  = 1 << 7,  /* reduce_Plk                                   parambasis.py:42-136 */
     EFTB_S_ALL     = 0xff,
     /* single-kernel selectors (profiling / roofline measurement only; need the stage's inputs in place) */
-    EFTB_K_P22     = 1 << 8,  /* the FP64-MFMA pair GEMM of makeP22 alone */
-    EFTB_K_C22     = 1 << 9   /* the FP64-MFMA pair GEMM of makeC22 + makeC13 alone */
+    EFTB_K_P22     = 1 << 8,  /* makeP22 alone: anti-diagonal sums + rows + synthesis */
+    EFTB_K_C22     = 1 << 9   /* makeC22 + makeC13 alone */
 };
 
 int  eftb_create(const eftb_config* cfg, eftb_engine** out);

@@ -21,36 +21,35 @@ def coef_half(t, Pin):
     return t["Gc"] @ Pin + t["Ec"] @ tail  # [2,129]
 
 
-def reduced_vectors(c, pw):
-    """c [2,129], pw [rows,2,129] -> u [rows,257]"""
-    cre, cim = c
-    pr, pi = pw[:, 0], pw[:, 1]
-    a = cre[:NH] * pr[:, :NH] - cim[:NH] * pi[:, :NH]
-    b = cre[:NH] * pi[:, :NH] + cim[:NH] * pr[:, :NH]
-    mid = cre[NH] * pr[:, NH : NH + 1]
-    return np.concatenate([a, mid, b], axis=1)
+def antidiagonal_sums(t, c):
+    """c [2,129] -> S[nc, 257] complex: S[c, j'] = sum_{n+m=256+j'} c_n c_m M_c[n,m] (device: antidiag_kernel)."""
+    ch = c[0] + 1j * c[1]
+    full = np.concatenate([ch, np.conj(ch[:NH][::-1])])  # c_{256-n} = conj(c_n)
+    AD = t["ad"]
+    S = np.zeros(AD.shape[:2], dtype=complex)
+    for jp in range(AD.shape[1]):
+        cnt = ((256 + jp) >> 1) - jp + 1
+        tt = np.arange(cnt)
+        S[:, jp] = AD[:, jp, :cnt] @ (full[jp + tt] * full[256 - tt])
+    return S
 
 
-def pair_contract(u, frag, steps):
-    """u [rows,257], frag [T,J,4,16] -> [rows, 16J]"""
-    up = np.concatenate([u, np.zeros((u.shape[0], 16))], axis=1)
-    un = u[:, steps[:, 0]]  # [rows,T]
-    out = np.zeros((u.shape[0], frag.shape[1] * 16))
-    for g in range(4):
-        v = un * up[:, steps[:, 1] + g]  # [rows,T]
-        out += np.einsum("rt,tjc->rjc", v, frag[:, :, g, :]).reshape(u.shape[0], -1)
+def rows_from_sums(Z):
+    """complex [rows, 257] -> real synthesis rows [rows, 528]: (Re Z_0, Re Z_1, Im Z_1, ...) zero padded (build_rows_kernel)."""
+    out = np.zeros((Z.shape[0], 528))
+    out[:, 0] = Z[:, 0].real
+    out[:, 1:513:2] = Z[:, 1:].real
+    out[:, 2:513:2] = Z[:, 1:].imag
     return out
 
 
-def pair_contract_2run(u, frag, steps4):
-    """u [rows,257], frag [T,64] (16x16x4 fragments, lane 16 g + c: run c >> 3, column c & 7) -> [rows, 8]"""
-    up = np.concatenate([u, np.zeros((u.shape[0], 16))], axis=1)
-    f = frag.reshape(-1, 4, 2, 8)  # [t, g, run, col]
-    out = np.zeros((u.shape[0], 8))
-    for r in range(2):
-        un = up[:, steps4[:, 0] + r]
-        for g in range(4):
-            out += (un * up[:, steps4[:, 1] + g]) @ f[:, g, r, :]
+def rows_from_vectors(c, V):
+    """single sums: X_n = c_n V_n (n = 0..128) -> rows (Re X_128, Re X_127, Im X_127, ..., Re X_0, Im X_0, 0, 0, 0)"""
+    X = (c[0] + 1j * c[1])[None, :] * V
+    out = np.zeros((V.shape[0], 272))
+    out[:, 0] = X[:, NH].real
+    out[:, 1:257:2] = X[:, NH - 1 :: -1].real
+    out[:, 2:257:2] = X[:, NH - 1 :: -1].imag
     return out
 
 
@@ -58,20 +57,19 @@ def pscf(t, Pin, with_cf):
     k, s = t["k"], t["s"]
     P11 = t["Sk"] @ Pin
     c = coef_half(t, Pin)
-    U = reduced_vectors(c, t["kpow"])
-    out = dict(P11=P11)
+    S = antidiagonal_sums(t, c)
     nb = t["comb22"].shape[1]
-    out["P22"] = t["comb22"] @ (k[:, None] ** 3 * pair_contract(U, t["pairs22"], t["steps"])[:, :nb]).T
-    out["P13"] = (k**3 * P11)[None, :] * (t["m13r"] @ U.T)
+    out = dict(P11=P11)
+    out["P22"] = rows_from_sums(t["comb22"] @ S[:nb]) @ t["syn_k"]
+    L = t["linvec"]
+    out["P13"] = P11[None, :] * (rows_from_vectors(c, L[:10]) @ t["lin_k"])
     if with_cf:
         Nl = t["l11"].shape[0]
-        Us = reduced_vectors(c, t["spow"])
-        cc = pair_contract(Us, t["pairsC"], t["steps"])  # [80, cols]
-        full = t["combC"] @ cc.T  # [Nl*38, 80]
-        out["C22"] = full[: Nl * 28].reshape(Nl, 28, -1)
-        out["C13"] = full[Nl * 28 :].reshape(Nl, 10, -1)
-        out["C11"] = t["c11r"] @ Us.T
-        out["Cct"] = s[None, :] ** -2 * (t["cctr"] @ Us.T)
+        S22, S13 = t["comb22"] @ S[:nb], t["comb13"] @ S[nb:]
+        out["C22"] = np.stack([rows_from_sums(t["mlj"][l][None, :] * S22) @ t["syn_s"] for l in range(Nl)])
+        out["C13"] = np.stack([rows_from_sums(t["mlj"][l][None, :] * S13) @ t["syn_s"] for l in range(Nl)])
+        out["C11"] = rows_from_vectors(c, L[10 : 10 + Nl]) @ t["lin_s"]
+        out["Cct"] = s[None, :] ** -2 * (rows_from_vectors(c, L[10 + Nl :]) @ t["lin_s"])
     return out
 
 

@@ -42,25 +42,24 @@ def test_bias_vectors_match_oracle(golden):
     assert bias_row(f, list(g["bsA"])).shape == (24,)
 
 
-def test_wave_plan_covers_all_steps():
-    from eftpipe_amd.engine import wave_plan
-    from eftpipe_amd.tables import pair_steps
+def test_antidiagonal_table_covers_every_pair_once():
+    """AD[c, j', t] holds the symmetrised weight of pair (j' + t, 256 - t): every unordered pair with n + m >= 256 once."""
+    from eftpipe_amd.tables import antidiagonal_tables
 
-    from eftpipe_amd.tables import KU
-
-    st = pair_steps()
-    assert len(st) == sum(((257 - n + 3) // 4 + KU - 1) // KU * KU for n in range(257))
-    plan = wave_plan(st)
-    assert plan[:, 3].sum() == len(st) and plan[0, 2] == 0
-    for q in range(len(plan)):
-        assert tuple(st[plan[q, 2]]) == (plan[q, 0], plan[q, 1])
-    # every unordered pair appears exactly once
+    rng = np.random.default_rng(0)
+    M = rng.normal(size=(1, 257, 257)) + 1j * rng.normal(size=(1, 257, 257))
+    AD = antidiagonal_tables(M, None)
     seen = set()
-    for n, m0 in st:
-        for g in range(4):
-            if m0 + g <= 256:
-                seen.add((n, m0 + g))
-    assert len(seen) == 257 * 258 // 2
+    for jp in range(257):
+        cnt = ((256 + jp) >> 1) - jp + 1
+        assert np.all(AD[0, jp, cnt:] == 0)
+        for t in range(cnt):
+            n, m = jp + t, 256 - t
+            assert n <= m and n + m == 256 + jp
+            want = M[0, n, m] + M[0, m, n] if n < m else M[0, n, n]
+            assert AD[0, jp, t] == want
+            seen.add((n, m))
+    assert len(seen) == sum(1 for n in range(257) for m in range(n, 257) if n + m >= 256)
 
 
 def test_shard_bounds():
