@@ -28,7 +28,7 @@ class Config(C.Structure):
 
 
 # enum eftb_table / eftb_buffer / eftb_stage (same order as the header)
-TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD COMB22 COMB13 MLJ LINVEC SYNK SYNS LINK LINS L11 LCT L22 L13 GRP "
+TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD EXP22 EXPC MLJ LINVEC SYNK SYNS LINK LINS L11 LCT L22 L13 GRP "
           "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID").split()
 T = {n: i for i, n in enumerate(TABLES)}
 BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF".split()

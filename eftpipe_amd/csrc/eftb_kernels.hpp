@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
                                                    const double* __restrict__ lnkin, const double* __restrict__ SkT,
                                                    const double* __restrict__ GcT, const double* __restrict__ EcT,
                                                    const double* __restrict__ lnxtail, double* __restrict__ P11,
-                                                   double* __restrict__ coef) {
+                                                   double* __restrict__ coef, double* __restrict__ coefT, int Bmax) {
     extern __shared__ double sm[];
     double* pin = sm;
     double* tail = sm + Nkin;
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
         P11[(size_t)w * Nk + o] = dot8(SkT + o, Nk, pin, Nkin);
     } else if (o < Nk + 2 * NCH) {
         const int idx = o - Nk, c = idx / NCH, n = idx % NCH;
-        coef[(size_t)w * 2 * NCH + idx] = dot8(GcT + (size_t)c * Nkin * NCH + n, NCH, pin, Nkin) + dot8(EcT + (size_t)c * ntail * NCH + n, NCH, tail, ntail);
+        const double v = dot8(GcT + (size_t)c * Nkin * NCH + n, NCH, pin, Nkin) + dot8(EcT + (size_t)c * ntail * NCH + n, NCH, tail, ntail);
+        coef[(size_t)w * 2 * NCH + idx] = v;
+        coefT[(size_t)idx * Bmax + w] = v;  // [2][129][Bmax]: cosmology-contiguous copy for antidiag_kernel
     }
 }
 
@@ -77,104 +79,95 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
 // synthesis per output point (synth_kernel on the FP64 matrix cores), instead of 257^2 terms per point
 // (reference pybird.py:1074-1078 makeP22, :1103-1125 makeC22 / makeC13).  The same S serve P22 at all k and, multiplied
 // by the Bessel weights Ml(n + m), C22 / C13 at all s and l.  The single sums (P13, C11, Cct) are 257-term syntheses.
-//   antidiag_kernel    S[w][c][j'], j' = 0..256 (S[-j'] = conj S[j']): wave <-> j', lanes along the anti-diagonal
-//   build_rows_kernel  real coefficient rows (Re Z_0, Re Z_1, Im Z_1, ...) of every output row: comb (basis -> 28 / 10
-//                      matrices), Ml weights, or c_n V_n for the single sums
-//   synth_kernel       out[w][row][x] = sum_q rows[w][row][q] Tab[q][x]   (Tab = k^{..}{1, 2cos, -/+2sin}: tables.py)
+//   antidiag_kernel    S[w][c][j'], j' = 0..256 (S[-j'] = conj S[j']) for the 7 + 2 basis matrices: wave <-> (j', 64 cosmologies)
+//   build_rows_kernel  real coefficient rows (Re Z_0, Re Z_1, Im Z_1, ...): S_c (P22), Ml[l] S_c (C22 / C13), c_n V_n (single sums)
+//   synth_kernel       out[row][x] = sum_q rows[row][q] Tab[q][x]   (Tab = x^{..}{1, 2cos, -/+2sin}: tables.py synthesis_table)
+//   expand_kernel      the 28 / 10 loop matrices per l from the synthesised basis rows
 // ------------------------------------------------------------------------------------------------
 constexpr int AD_T = NHALF + 2;   // anti-diagonal length (129) rounded up to even
-constexpr int KSYN = 528;         // 1 + 2*256 synthesis coefficients, zero padded to a multiple of 16 (4 MFMA K-steps)
-constexpr int KLIN = 272;         // 1 + 2*128, likewise
+constexpr int AD_CH = 3, AD_TC = 44;  // the anti-diagonal is cut into AD_CH chunks of AD_TC pairs (partial sums, added by build_rows_kernel)
+constexpr int KSYN = 528;         // 1 + 2*256 synthesis coefficients, zero padded to a multiple of SYN_KC
+constexpr int KLIN = 288;         // 1 + 2*128, likewise
+constexpr int SYN_KC = 48;        // K chunk of synth_kernel staged in LDS
+constexpr int BAS22 = 8, BASC = 32;  // padded basis rows per cosmology: 7 M22 matrices; Nl * (7 + 2) weighted ones
 
+// Lanes <-> cosmologies (coefficients transposed by prep_kernel: coefT[2][129][Bmax]); the matrix weights are wave-uniform
+// (scalar loads), so the table is streamed once per 64 cosmologies and no cross-lane reduction is needed.
 template <int NC>
-__global__ __launch_bounds__(256) void antidiag_kernel(const double* __restrict__ coef, const double2* __restrict__ AD,
-                                                       double2* __restrict__ S) {
-    __shared__ double2 cs[NPOW];
-    const int w = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double* c = coef + (size_t)w * 2 * NCH;
-    for (int n = threadIdx.x; n < NPOW; n += 256) {  // c_{256-n} = conj(c_n)
-        const int q = n <= NHALF ? n : 2 * NHALF - n;
-        cs[n] = make_double2(c[q], n <= NHALF ? c[NCH + q] : -c[NCH + q]);
-    }
-    __syncthreads();
-    const int jp = blockIdx.x * 4 + wave;
-    if (jp >= NPOW) return;
+__global__ __launch_bounds__(64) void antidiag_kernel(int B, int Bmax, const double* __restrict__ coefT,
+                                                      const double2* __restrict__ AD, double2* __restrict__ S) {
+    const int jp = blockIdx.x, w = blockIdx.y * 64 + threadIdx.x, ch = blockIdx.z;
+    const int wl = w < B ? w : B - 1;
     const int cnt = ((2 * NHALF + jp) >> 1) - jp + 1;  // pairs (n, m) = (jp + t, 256 - t), n <= m
+    const int t0 = ch * AD_TC, t1 = min(cnt, t0 + AD_TC);
+    const double* cr = coefT + wl;
+    const double* ci = coefT + (size_t)NCH * Bmax + wl;
     double ar[NC], ai[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) ar[q] = ai[q] = 0.0;
-    for (int t = lane; t < cnt; t += 64) {
-        const double2 a = cs[jp + t], b = cs[2 * NHALF - t];
-        const double pr = a.x * b.x - a.y * b.y, pi = a.x * b.y + a.y * b.x;
+    for (int t = t0; t < t1; ++t) {
+        const int n = jp + t, qn = n <= NHALF ? n : 2 * NHALF - n;  // c_{256-n} = conj(c_n); c_m = conj(c_t) for m = 256 - t
+        const double xr = cr[(size_t)qn * Bmax], xi = n <= NHALF ? ci[(size_t)qn * Bmax] : -ci[(size_t)qn * Bmax];
+        const double yr = cr[(size_t)t * Bmax], yi = -ci[(size_t)t * Bmax];
+        const double pr = xr * yr - xi * yi, pi = xr * yi + xi * yr;
+        const double2* m = AD + ((size_t)jp * AD_T + t) * NC;  // wave-uniform
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            const double2 m = AD[((size_t)q * NPOW + jp) * AD_T + t];
-            ar[q] = fma(m.x, pr, fma(-m.y, pi, ar[q]));
-            ai[q] = fma(m.x, pi, fma(m.y, pr, ai[q]));
+            ar[q] = fma(m[q].x, pr, fma(-m[q].y, pi, ar[q]));
+            ai[q] = fma(m[q].x, pi, fma(m[q].y, pr, ai[q]));
         }
     }
+    if (w < B)
 #pragma unroll
-    for (int q = 0; q < NC; ++q) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            ar[q] += __shfl_xor(ar[q], off);
-            ai[q] += __shfl_xor(ai[q], off);
-        }
-        if (lane == 0) S[((size_t)w * NC + q) * NPOW + jp] = make_double2(ar[q], ai[q]);
-    }
+        for (int q = 0; q < NC; ++q) S[(((size_t)ch * Bmax + w) * NC + q) * NPOW + jp] = make_double2(ar[q], ai[q]);
 }
 
-// Row sets (blockIdx.y): 0 -> P22 rows [28][KSYN]; 1 -> P13 rows [10][KLIN]; 2 -> C22 / C13 rows [Nl*38][KSYN];
-// 3 -> C11 / Cct rows [2*Nl][KLIN].  `sets` is a bit mask of the sets to build.
-__global__ __launch_bounds__(256) void build_rows_kernel(int sets, int Nl, int nb, int nb13, const double* __restrict__ coef,
-                                                         const double2* __restrict__ S, const double* __restrict__ comb22,
-                                                         const double* __restrict__ comb13, const double2* __restrict__ mlj,
+// One lane = one j' of one cosmology: sums the AD_CH partials of the nc anti-diagonal sums once, then writes
+//   blockIdx.y = 0: the nb P22 basis rows  (A22[w][BAS22][KSYN])  and the 10 P13 rows (A13[w][10][KLIN])
+//   blockIdx.y = 1: the Nl*nc weighted rows Ml[l] S_c (ACF[w][BASC][KSYN]) and the 2 Nl C11 / Cct rows (ALC[w][2 Nl][KLIN])
+// as real synthesis coefficients (Re Z_0, Re Z_1, Im Z_1, ...).  `sets` bit 0/1: quadratic rows of y = 0/1, bit 2/3: linear rows.
+template <int NC>
+__global__ __launch_bounds__(320) void build_rows_kernel(int sets, int Bmax, int Nl, int nb, const double* __restrict__ coef,
+                                                         const double2* __restrict__ S, const double2* __restrict__ mlj,
                                                          const double2* __restrict__ linvec, double* __restrict__ A22,
                                                          double* __restrict__ A13, double* __restrict__ ACF, double* __restrict__ ALC) {
-    const int w = blockIdx.x, set = blockIdx.y;
-    if (!((sets >> set) & 1)) return;
-    const int nc = nb + nb13;
-    const double2* sw = S + (size_t)w * nc * NPOW;
-    if (set == 0 || set == 2) {
-        const int nrows = set == 0 ? 28 : Nl * 38;
-        double* out = set == 0 ? A22 + (size_t)w * 28 * KSYN : ACF + (size_t)w * Nl * 38 * KSYN;
-        for (int e = threadIdx.x; e < nrows * NPOW; e += blockDim.x) {
-            const int row = e / NPOW, jp = e % NPOW;
-            double zr = 0.0, zi = 0.0;
-            int l = 0;
-            if (set == 0 || row < Nl * 28) {
-                const int b = set == 0 ? row : row % 28;
-                l = set == 0 ? 0 : row / 28;
-                for (int q = 0; q < nb; ++q) {
-                    const double cq = comb22[b * nb + q];
-                    zr = fma(cq, sw[q * NPOW + jp].x, zr);
-                    zi = fma(cq, sw[q * NPOW + jp].y, zi);
-                }
-            } else {
-                const int rr = row - Nl * 28, b = rr % 10;
-                l = rr / 10;
-                for (int q = 0; q < nb13; ++q) {
-                    const double cq = comb13[b * nb13 + q];
-                    zr = fma(cq, sw[(nb + q) * NPOW + jp].x, zr);
-                    zi = fma(cq, sw[(nb + q) * NPOW + jp].y, zi);
-                }
-            }
-            if (set == 2) {  // Bessel weight Ml[l](n + m) (reference pybird.py:1040-1046)
-                const double2 m = mlj[l * NPOW + jp];
-                const double tr = m.x * zr - m.y * zi;
-                zi = m.x * zi + m.y * zr;
-                zr = tr;
-            }
-            double* o = out + (size_t)row * KSYN;
-            if (jp == 0) o[0] = zr;
-            else {
-                o[2 * jp - 1] = zr;
-                o[2 * jp] = zi;
+    const int w = blockIdx.x, cf = blockIdx.y, jp = threadIdx.x;
+    if (((sets >> cf) & 1) && jp < NPOW) {
+        double zr[NC], zi[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            zr[q] = zi[q] = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < AD_CH; ++ch) {
+                const double2 v = S[(((size_t)ch * Bmax + w) * NC + q) * NPOW + jp];
+                zr[q] += v.x;
+                zi[q] += v.y;
             }
         }
-    } else {
-        const int nrows = set == 1 ? 10 : 2 * Nl, v0 = set == 1 ? 0 : 10;
-        double* out = set == 1 ? A13 + (size_t)w * 10 * KLIN : ALC + (size_t)w * 2 * Nl * KLIN;
+        const int o0 = jp == 0 ? 0 : 2 * jp - 1;
+        if (cf == 0) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (q < nb) {
+                    double* o = A22 + ((size_t)w * BAS22 + q) * KSYN;
+                    o[o0] = zr[q];
+                    if (jp) o[o0 + 1] = zi[q];
+                }
+        } else {
+            for (int l = 0; l < Nl; ++l) {
+                const double2 m = mlj[l * NPOW + jp];  // Bessel weight Ml[l](n + m) (reference pybird.py:1040-1046)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    double* o = ACF + ((size_t)w * BASC + l * NC + q) * KSYN;
+                    o[o0] = m.x * zr[q] - m.y * zi[q];
+                    if (jp) o[o0 + 1] = m.x * zi[q] + m.y * zr[q];
+                }
+            }
+        }
+    }
+    if ((sets >> (2 + cf)) & 1) {
+        const int nrows = cf == 0 ? 10 : 2 * Nl, v0 = cf == 0 ? 0 : 10;
+        double* out = cf == 0 ? A13 + (size_t)w * 10 * KLIN : ALC + (size_t)w * 2 * Nl * KLIN;
         const double* c = coef + (size_t)w * 2 * NCH;
         for (int e = threadIdx.x; e < nrows * NCH; e += blockDim.x) {
             const int row = e / NCH, mp = e % NCH, n = NHALF - mp;  // harmonic mp <-> coefficient n = 128 - mp
@@ -190,73 +183,109 @@ __global__ __launch_bounds__(256) void build_rows_kernel(int sets, int Nl, int n
     }
 }
 
-// out[g][row][x] = sum_q A[g][row][q] Tab[q][x]  (* gscale[g][x]) (* xscale[x] for rows >= xscale_row0): one wave per
-// (32 x, 16 MT rows, group); A operand lane (row = lane & 15, q = lane >> 4), B operand lane (q = lane >> 4, x = lane & 15).
+// out[row][x] = sum_q A[row][q] Tab[q][x]  (* gscale[row / rpg][x]) (* xscale[x]) on the FP64 matrix cores.  Rows are
+// addressed as (group = row / rpg, member = row % rpg): A + group a_group + member K, out + group o_group + member X.
+// Workgroup = 4 waves = 32 rows x 64 x; A and Tab chunks of SYN_KC go through LDS (strides 50 / 80: conflict-free
+// ds_read_b64 for the MFMA operand layouts), each wave owns 16 rows x 32 x.
 struct SynthDesc {
-    const double* A;      // [G][.][K]: rows of group g start at A + g * a_group
-    long long a_group;
+    const double* A;
     const double* Tab;    // [K][X]
-    double* out;          // [G][R][X]
-    const double* gscale; // [G][X] or null   (P13: P11)
-    const double* xscale; // [X] or null      (Cct: s^-2)
-    int R, K, X, xscale_row0;
+    double* out;
+    const double* gscale; // [groups][X] or null   (P13: P11)
+    const double* xscale; // [X] or null           (Cct: s^-2)
+    long long a_group, o_group;
+    int M, rpg, K, X;
 };
 
-template <int MT>
-__global__ __launch_bounds__(64) void synth_kernel(SynthDesc d) {
-    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
-    const int x0 = blockIdx.x * 32, row0 = blockIdx.y * 16 * MT, grp = blockIdx.z;
-    v4d acc[MT][2];
+__global__ __launch_bounds__(256) void synth_kernel(SynthDesc d) {
+    constexpr int LDA = SYN_KC + 2, LDB = 80, NA = 32 * SYN_KC / 256, NB = SYN_KC * 64 / 256;
+    __shared__ double As[32 * LDA];
+    __shared__ double Bs[SYN_KC * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.y * 32, x0 = blockIdx.x * 64;
+    const int rh = wave >> 1, xh = wave & 1;
+    // this thread's share of every chunk: NA elements of the A tile, NB of the Tab tile (fixed positions, pointers hoisted)
+    const double* pa[NA];
+    const double* pb[NB];
+    double ma[NA], mb[NB], va[NA], vb[NB];
+    int la[NA], lb[NB];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* ap[MT];
-    double am[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int row = row0 + 16 * i + r;
-        am[i] = row < d.R ? 1.0 : 0.0;
-        ap[i] = d.A + (size_t)grp * d.a_group + (size_t)(row < d.R ? row : d.R - 1) * d.K + g;
+    for (int i = 0; i < NA; ++i) {
+        const int e = tid + 256 * i, rr = e / SYN_KC, kk = e % SYN_KC, row = row0 + rr, rc = row < d.M ? row : d.M - 1;
+        pa[i] = d.A + (size_t)(rc / d.rpg) * d.a_group + (size_t)(rc % d.rpg) * d.K + kk;
+        ma[i] = row < d.M ? 1.0 : 0.0;
+        la[i] = rr * LDA + kk;
     }
-    const double* bp[2];
-    double bm[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int x = x0 + 16 * j + r;
-        bm[j] = x < d.X ? 1.0 : 0.0;
-        bp[j] = d.Tab + (size_t)g * d.X + (x < d.X ? x : d.X - 1);
+    for (int i = 0; i < NB; ++i) {
+        const int e = tid + 256 * i, kk = e >> 6, xx = e & 63, x = x0 + xx;
+        pb[i] = d.Tab + (size_t)kk * d.X + (x < d.X ? x : d.X - 1);
+        mb[i] = x < d.X ? 1.0 : 0.0;
+        lb[i] = kk * LDB + xx;
     }
-    for (int t0 = 0; t0 < (d.K >> 2); t0 += 4) {  // K is a multiple of 16: four K-steps of operands in flight
-        double a[4][MT], b[4][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+    for (int i = 0; i < NA; ++i) va[i] = pa[i][0];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[u][i] = ap[i][4 * (t0 + u)] * am[i];
+    for (int i = 0; i < NB; ++i) vb[i] = pb[i][0];
+    v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+    for (int k0 = 0; k0 < d.K; k0 += SYN_KC) {
+        __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[u][j] = bp[j][(size_t)4 * (t0 + u) * d.X] * bm[j];
+        for (int i = 0; i < NA; ++i) As[la[i]] = va[i] * ma[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[lb[i]] = vb[i] * mb[i];
+        __syncthreads();
+        if (k0 + SYN_KC < d.K) {  // next chunk's global loads fly under this chunk's MFMAs
+#pragma unroll
+            for (int i = 0; i < NA; ++i) va[i] = pa[i][k0 + SYN_KC];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) vb[i] = pb[i][(size_t)(k0 + SYN_KC) * d.X];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int t = 0; t < SYN_KC / 4; ++t) {
+            const double a = As[(rh * 16 + r) * LDA + 4 * t + g];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(4 * t + g) * LDB + xh * 32 + 16 * j + r], acc[j], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = row0 + 16 * i + g + 4 * q, x = x0 + 16 * j + r;
-                if (row < d.R && x < d.X) {
-                    double v = acc[i][j][q];
-                    if (d.gscale) v *= d.gscale[(size_t)grp * d.X + x];
-                    if (d.xscale && row >= d.xscale_row0) v *= d.xscale[x];
-                    d.out[((size_t)grp * d.R + row) * d.X + x] = v;
-                }
+        for (int q = 0; q < 4; ++q) {
+            const int row = row0 + rh * 16 + g + 4 * q, x = x0 + xh * 32 + 16 * j + r;
+            if (row < d.M && x < d.X) {
+                const int grp = row / d.rpg, mem = row % d.rpg;
+                double v = acc[j][q];
+                if (d.gscale) v *= d.gscale[(size_t)grp * d.X + x];
+                if (d.xscale) v *= d.xscale[x];
+                d.out[(size_t)grp * d.o_group + (size_t)mem * d.X + x] = v;
             }
+        }
+}
+
+// out[g][r][x] = sum_c comb[r][c] basis[g][c][x]: the 28 (10) loop matrices from their 7 (2) basis matrices
+// (tables.py loop_basis); one lane = one x of one cosmology and EXP_RPB output rows, the basis values stay in registers.
+constexpr int EXP_RPB = 8;
+
+template <int RIN>
+__global__ __launch_bounds__(64) void expand_kernel(int Rout, int X, const double* __restrict__ basis, const double* __restrict__ comb,
+                                                    double* __restrict__ out) {
+    const int x = blockIdx.x * 64 + threadIdx.x, grp = blockIdx.y, r0 = blockIdx.z * EXP_RPB;
+    if (x >= X) return;
+    double v[RIN];
+#pragma unroll
+    for (int c = 0; c < RIN; ++c) v[c] = basis[((size_t)grp * RIN + c) * X + x];
+    double acc[EXP_RPB];
+#pragma unroll
+    for (int i = 0; i < EXP_RPB; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int c = 0; c < RIN; ++c)
+#pragma unroll
+        for (int i = 0; i < EXP_RPB; ++i) acc[i] = fma(comb[(size_t)min(r0 + i, Rout - 1) * RIN + c], v[c], acc[i]);  // comb: wave-uniform
+#pragma unroll
+    for (int i = 0; i < EXP_RPB; ++i)
+        if (r0 + i < Rout) out[((size_t)grp * Rout + r0 + i) * X + x] = acc[i];
 }
 
 // ------------------------------------------------------------------------------------------------

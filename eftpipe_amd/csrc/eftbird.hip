@@ -51,9 +51,11 @@ struct eftb_engine {
     double *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
     double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][96][8], per-s records [B][NS][80]
     double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
-    double2* SAD = nullptr;                  // anti-diagonal sums S[B][nbasis + nbasis13][257]
-    double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of P22 [B][28][516] and P13 [B][10][260]
-    double *ACF = nullptr, *ALC = nullptr;   // ... of C22 / C13 [B][Nl*38][516] and C11 / Cct [B][2 Nl][260]
+    double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
+    double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
+    double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of the P22 basis [B][BAS22][KSYN] and of P13 [B][10][KLIN]
+    double *ACF = nullptr, *ALC = nullptr;   // ... of the weighted xi basis [B][BASC][KSYN] and of C11 / Cct [B][2 Nl][KLIN]
+    double *Y22 = nullptr, *YCF = nullptr;   // synthesised basis rows [B][BAS22][Nk], [B][BASC][NS]
     // linear post-AP operators (window / binning / chained), stored K-major for gemm_rows_kernel
     struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; };
     std::vector<Op> ops;
@@ -122,8 +124,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_ECT: return D * 2 * c.ntail * NCH;
         case EFTB_T_LNXTAIL: return D * c.ntail;
         case EFTB_T_AD: return 2 * D * (size_t)(c.nbasis + (c.with_resum ? c.nbasis13 : 0)) * NPOW * AD_T;
-        case EFTB_T_COMB22: return D * 28 * c.nbasis;
-        case EFTB_T_COMB13: return c.with_resum ? D * 10 * c.nbasis13 : 0;
+        case EFTB_T_EXP22: return D * 28 * BAS22;
+        case EFTB_T_EXPC: return c.with_resum ? D * (size_t)c.Nl * 38 * BASC : 0;
         case EFTB_T_MLJ: return c.with_resum ? 2 * D * c.Nl * NPOW : 0;
         case EFTB_T_LINVEC: return 2 * D * (size_t)(10 + (c.with_resum ? 2 * c.Nl : 0)) * NCH;
         case EFTB_T_SYNK: return D * (size_t)KSYN * c.Nk;
@@ -176,32 +178,36 @@ static size_t need_buffer_elems(const eftb_config& c, int id) {
 template <typename T>
 static inline const T* tb(const eftb_engine* e, int id) { return static_cast<const T*>(e->tab[id]); }
 
-// out[g][row][x] = sum_q A[g][row][q] Tab[q][x] on the FP64 matrix cores (synth_kernel): one wave per (32 x, 16 or 32 rows, g)
-static void launch_synth(hipStream_t st, int G, const double* A, long long a_group, int R, int K, const double* Tab, int X, double* out, const double* gscale,
-                         const double* xscale, int xscale_row0) {
+// out[row][x] = sum_q A[row][q] Tab[q][x] on the FP64 matrix cores (synth_kernel); rows = (group, member)
+static void launch_synth(hipStream_t st, const double* A, long long a_group, int groups, int rpg, int K, const double* Tab, int X, double* out,
+                         long long o_group, const double* gscale, const double* xscale) {
     SynthDesc d{};
-    d.A = A; d.a_group = a_group; d.Tab = Tab; d.out = out; d.gscale = gscale; d.xscale = xscale;
-    d.R = R; d.K = K; d.X = X; d.xscale_row0 = xscale_row0;
-    if (R > 16) hipLaunchKernelGGL((synth_kernel<2>), dim3((X + 31) / 32, (R + 31) / 32, G), dim3(64), 0, st, d);
-    else hipLaunchKernelGGL((synth_kernel<1>), dim3((X + 31) / 32, 1, G), dim3(64), 0, st, d);
+    d.A = A; d.Tab = Tab; d.out = out; d.gscale = gscale; d.xscale = xscale;
+    d.a_group = a_group; d.o_group = o_group; d.M = groups * rpg; d.rpg = rpg; d.K = K; d.X = X;
+    hipLaunchKernelGGL(synth_kernel, dim3((X + 63) / 64, (d.M + 31) / 32), dim3(256), 0, st, d);
 }
 
-// anti-diagonal sums of every loop matrix for the batch (shared by the k-space and the xi-space pieces)
-static int launch_antidiag(eftb_engine* e, hipStream_t st, int B) {
+// anti-diagonal sums of every loop matrix for the batch (shared by the k-space and the xi-space pieces), then the
+// synthesis rows selected by `sets` (build_rows_kernel)
+static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets) {
     const eftb_config& c = e->c;
     const int nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
-    const dim3 grid((NPOW + 3) / 4, B);
-    if (nc == 9) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(256), 0, st, e->buf[EFTB_B_COEF], tb<double2>(e, EFTB_T_AD), e->SAD);
-    else if (nc == 7) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(256), 0, st, e->buf[EFTB_B_COEF], tb<double2>(e, EFTB_T_AD), e->SAD);
-    else return fail("loop-matrix basis of dimension %d + %d is not instantiated (expected 7 + 2)", c.nbasis, c.with_resum ? c.nbasis13 : 0);
+    const dim3 grid(NPOW, (B + 63) / 64, AD_CH), rgrid(B, 2);
+#define AD_ARGS B, c.max_batch, e->coefT, tb<double2>(e, EFTB_T_AD), e->SAD
+#define ROW_ARGS sets, c.max_batch, c.Nl, c.nbasis, e->buf[EFTB_B_COEF], e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
+                 e->ACF, e->ALC
+    if (nc == 9) {
+        if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(64), 0, st, AD_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(320), 0, st, ROW_ARGS);
+    } else if (nc == 7) {
+        if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(64), 0, st, AD_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(320), 0, st, ROW_ARGS);
+    } else {
+        return fail("loop-matrix basis of dimension %d + %d is not instantiated (expected 7 + 2)", c.nbasis, c.with_resum ? c.nbasis13 : 0);
+    }
+#undef AD_ARGS
+#undef ROW_ARGS
     return 0;
-}
-
-static void launch_rows(eftb_engine* e, hipStream_t st, int B, int sets) {
-    const eftb_config& c = e->c;
-    hipLaunchKernelGGL(build_rows_kernel, dim3(B, 4), dim3(256), 0, st, sets, c.Nl, c.nbasis, c.with_resum ? c.nbasis13 : 0, e->buf[EFTB_B_COEF], e->SAD,
-                       tb<double>(e, EFTB_T_COMB22), tb<double>(e, EFTB_T_COMB13), tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22,
-                       e->A13, e->ACF, e->ALC);
 }
 
 // out[w][a][r][x] = sum_{l,k} T[w][l][r][k] * opT[(l,k)][(a,x)] on the FP64 matrix cores; the block changes shape
@@ -232,24 +238,32 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
         hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
-                           b[EFTB_B_P11], b[EFTB_B_COEF]);
+                           b[EFTB_B_P11], b[EFTB_B_COEF], e->coefT, c.max_batch);
     }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
-    // the anti-diagonal sums serve both the k-space and the xi-space pieces
-    if (mask & (EFTB_S_LOOPS | EFTB_S_CF | EFTB_K_P22 | EFTB_K_C22))
-        if (int rc = launch_antidiag(e, st, B)) return rc;
+    // the anti-diagonal sums serve both the k-space and the xi-space pieces: one pass, then the synthesis rows of
+    // whatever is requested (bit 0/1: quadratic rows of k / xi space, bit 2/3: single-sum rows, bit 4: the sums themselves)
+    if (mask & (EFTB_S_LOOPS | EFTB_S_CF | EFTB_K_P22 | EFTB_K_C22)) {
+        int sets = 0x10;
+        if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) sets |= 0x1;
+        if (mask & EFTB_S_LOOPS) sets |= 0x4;
+        if (mask & (EFTB_S_CF | EFTB_K_C22)) sets |= 0x2;
+        if (mask & EFTB_S_CF) sets |= 0x8;
+        if (int rc = launch_antidiag_rows(e, st, B, sets)) return rc;
+    }
     if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
-        launch_rows(e, st, B, (mask & EFTB_S_LOOPS) ? 0x3 : 0x1);
-        launch_synth(st, B, e->A22, 28LL * KSYN, 28, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, b[EFTB_B_P22], nullptr, nullptr, 0);
+        launch_synth(st, e->A22, 0, 1, B * BAS22, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, e->Y22, 0, nullptr, nullptr);
+        hipLaunchKernelGGL((expand_kernel<BAS22>), dim3((Nk + 63) / 64, B, (28 + EXP_RPB - 1) / EXP_RPB), dim3(64), 0, st, 28, Nk, e->Y22, tb<double>(e, EFTB_T_EXP22), b[EFTB_B_P22]);
         if (mask & EFTB_S_LOOPS)
-            launch_synth(st, B, e->A13, 10LL * KLIN, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], b[EFTB_B_P11], nullptr, 0);
+            launch_synth(st, e->A13, 10LL * KLIN, B, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], 10LL * Nk, b[EFTB_B_P11], nullptr);
     }
     if (mask & (EFTB_S_CF | EFTB_K_C22)) {
-        launch_rows(e, st, B, (mask & EFTB_S_CF) ? 0xc : 0x4);
-        launch_synth(st, B, e->ACF, (long long)Nl * 38 * KSYN, Nl * 38, KSYN, tb<double>(e, EFTB_T_SYNS), NS, b[EFTB_B_CC], nullptr, nullptr, 0);
+        launch_synth(st, e->ACF, 0, 1, B * BASC, KSYN, tb<double>(e, EFTB_T_SYNS), NS, e->YCF, 0, nullptr, nullptr);
+        hipLaunchKernelGGL((expand_kernel<BASC>), dim3((NS + 63) / 64, B, (Nl * 38 + EXP_RPB - 1) / EXP_RPB), dim3(64), 0, st, Nl * 38, NS, e->YCF, tb<double>(e, EFTB_T_EXPC), b[EFTB_B_CC]);
         if (mask & EFTB_S_CF) {
-            launch_synth(st, B, e->ALC, 2LL * Nl * KLIN, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], nullptr, nullptr, 0);
-            launch_synth(st, B, e->ALC + (size_t)Nl * KLIN, 2LL * Nl * KLIN, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCT], nullptr, e->sm2, 0);
+            launch_synth(st, e->ALC, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], (long long)Nl * NS, nullptr, nullptr);
+            launch_synth(st, e->ALC + (size_t)Nl * KLIN, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCT], (long long)Nl * NS,
+                         nullptr, e->sm2);
         }
     }
     if (mask & EFTB_S_REGROUP) {
@@ -357,7 +371,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (c.Nl != 2 && c.Nl != 3) return fail("eftb_create: Nl must be 2 or 3 (got %d)", c.Nl);
     if (c.Nk < 8 || c.Nkin < 4 || c.max_batch < 1) return fail("eftb_create: bad dimensions Nk=%d Nkin=%d max_batch=%d", c.Nk, c.Nkin, c.max_batch);
     if (c.nbasis < 1 || c.nbasis > 16) return fail("eftb_create: nbasis=%d outside [1, 16]", c.nbasis);
-    if (c.with_resum && (c.nbasis13 < 1 || c.nbasis13 > 4)) return fail("eftb_create: nbasis13=%d outside [1, 4]", c.nbasis13);
+    if (c.nbasis > BAS22 || (c.with_resum && c.Nl * (c.nbasis + c.nbasis13) > BASC)) return fail("eftb_create: loop basis %d + %d too large", c.nbasis, c.nbasis13);
     if (c.with_resum && !((c.Nl == 3 && c.NIR == 16 && c.Na == 3) || (c.Nl == 2 && c.NIR == 8 && c.Na == 2)))
         return fail("eftb_create: (Nl, NIR, Na) = (%d, %d, %d) unsupported", c.Nl, c.NIR, c.Na);
     int ndev = 0;
@@ -384,17 +398,18 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     }
     const size_t B = c.max_batch;
     HIPCHK(hipMalloc(&e->sm2, NS * sizeof(double)));
-    // scratch of the anti-diagonal pipeline; the synthesis rows are zero beyond their last coefficient (K padded to 4)
-    HIPCHK(hipMalloc(&e->SAD, B * (c.nbasis + (c.with_resum ? c.nbasis13 : 0)) * NPOW * sizeof(double2)));
-    HIPCHK(hipMalloc(&e->A22, B * 28 * KSYN * sizeof(double)));
-    HIPCHK(hipMemset(e->A22, 0, B * 28 * KSYN * sizeof(double)));
-    HIPCHK(hipMalloc(&e->A13, B * 10 * KLIN * sizeof(double)));
-    HIPCHK(hipMemset(e->A13, 0, B * 10 * KLIN * sizeof(double)));
-    if (c.with_resum) {
-        HIPCHK(hipMalloc(&e->ACF, B * c.Nl * 38 * KSYN * sizeof(double)));
-        HIPCHK(hipMemset(e->ACF, 0, B * c.Nl * 38 * KSYN * sizeof(double)));
-        HIPCHK(hipMalloc(&e->ALC, B * 2 * c.Nl * KLIN * sizeof(double)));
-        HIPCHK(hipMemset(e->ALC, 0, B * 2 * c.Nl * KLIN * sizeof(double)));
+    // scratch of the anti-diagonal pipeline; padded rows / coefficients of the synthesis rows stay zero
+    {
+        const size_t nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
+        auto zalloc = [](double** p, size_t n) {
+            if (hipMalloc(p, n * sizeof(double)) != hipSuccess) return 1;
+            return hipMemset(*p, 0, n * sizeof(double)) != hipSuccess ? 1 : 0;
+        };
+        int bad = zalloc(&e->coefT, 2 * NCH * B);
+        bad |= zalloc(reinterpret_cast<double**>(&e->SAD), 2 * (size_t)AD_CH * B * nc * NPOW);
+        bad |= zalloc(&e->A22, B * BAS22 * KSYN) | zalloc(&e->A13, B * 10 * KLIN) | zalloc(&e->Y22, B * BAS22 * c.Nk);
+        if (c.with_resum) bad |= zalloc(&e->ACF, B * BASC * KSYN) | zalloc(&e->ALC, B * 2 * c.Nl * KLIN) | zalloc(&e->YCF, B * BASC * NS);
+        if (bad) return fail("eftb_create: out of device memory for the loop scratch");
     }
     HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
     if (c.with_ap) {
@@ -516,7 +531,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->V, e->A22, e->A13, e->ACF, e->ALC, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->V, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1}) if (ev) (void)hipEventDestroy(ev);

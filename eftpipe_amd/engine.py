@@ -62,8 +62,10 @@ class Engine:
         self._set("ECT", t["Ec"].transpose(0, 2, 1))
         self._set("LNXTAIL", t["lnx_tail"])
         cplx = lambda z: np.stack([z.real, z.imag], axis=-1)  # complex -> (re, im) pairs (device double2)
-        self._set("AD", cplx(t["ad"]))
-        self._set("COMB22", t["comb22"])
+        self._set("AD", cplx(t["ad"].transpose(1, 2, 0)))                      # [j'][t][matrix]: wave-uniform 144-byte records
+        exp22 = np.zeros((28, 8))
+        exp22[:, : t["comb22"].shape[1]] = t["comb22"]
+        self._set("EXP22", exp22)
         self._set("LINVEC", cplx(t["linvec"]))
         self._set("SYNK", t["syn_k"])
         self._set("LINK", t["lin_k"])
@@ -71,7 +73,9 @@ class Engine:
             self._set(n, t[n.lower()])
         self._set("GRP", np.concatenate([t["grp22"], t["grp13"]]), np.int32)
         if cfg.with_resum:
-            self._set("COMB13", t["comb13"])
+            expc = np.zeros((cfg.Nl * 38, 32))
+            expc[:, : t["expand_c"].shape[1]] = t["expand_c"]
+            self._set("EXPC", expc)
             self._set("MLJ", cplx(t["mlj"]))
             self._set("SYNS", t["syn_s"])
             self._set("LINS", t["lin_s"])

@@ -145,10 +145,10 @@ def antidiagonal_tables(M22b, M13b):
 
 def synthesis_table(lnx, power, dpow, nharm, sign):
     """Real basis of  x^power [ Z_0 + 2 Re sum_{j=1..nharm} Z_j e^{sign i dpow j ln x} ]  for coefficient rows stored as
-    (Re Z_0, Re Z_1, Im Z_1, Re Z_2, Im Z_2, ...):  -> [Kpad, len(x)], Kpad = 1 + 2 nharm rounded up to 16 (zero rows; four
-    MFMA K-steps per loop iteration of synth_kernel)."""
+    (Re Z_0, Re Z_1, Im Z_1, Re Z_2, Im Z_2, ...):  -> [Kpad, len(x)], Kpad = 1 + 2 nharm rounded up to 48 (zero rows: the LDS
+    chunk of synth_kernel)."""
     K = 1 + 2 * nharm
-    out = np.zeros(((K + 15) // 16 * 16, lnx.size))
+    out = np.zeros(((K + 47) // 48 * 48, lnx.size))
     amp = np.exp(power * lnx)
     out[0] = amp
     j = np.arange(1, nharm + 1)
@@ -275,6 +275,13 @@ def build_tables(cfg: EngineConfig) -> dict:
     if cfg.with_resum:
         basis13, comb13 = loop_basis(M13)
         t["comb13"] = comb13                                                  # M13[b] = sum_c comb13[b, c] M13[basis13[c]]
+        # expansion of the synthesised basis rows (l, c) -> C22[l, b], C13[l, b]: dense [Nl*38, Nl*(nb + nb13)]
+        nb, nb13 = comb.shape[1], comb13.shape[1]
+        expc = np.zeros((Nl * 38, Nl * (nb + nb13)))
+        for l in range(Nl):
+            expc[l * 28 : (l + 1) * 28, l * (nb + nb13) : l * (nb + nb13) + nb] = comb
+            expc[Nl * 28 + l * 10 : Nl * 28 + (l + 1) * 10, l * (nb + nb13) + nb : (l + 1) * (nb + nb13)] = comb13
+        t["expand_c"] = expc
         t["ad"] = antidiagonal_tables(M22[basis], M13[basis13])
         jp = np.arange(NPOW)
         t["mlj"] = lm.bessel_weight(ells[:, None], -op.bias - 0.5j * op.dpow * jp[None, :] - 1.5)   # Ml depends on n + m only

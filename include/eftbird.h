@@ -48,7 +48,7 @@ typedef struct eftb_config {
 enum eftb_table {
     EFTB_T_K = 0, EFTB_T_S, EFTB_T_LNKIN, EFTB_T_SKT, EFTB_T_GCT, EFTB_T_ECT, EFTB_T_LNXTAIL,
     /* one-loop pieces in anti-diagonal form (tables.py antidiagonal_tables, synthesis_table) */
-    EFTB_T_AD, EFTB_T_COMB22, EFTB_T_COMB13, EFTB_T_MLJ, EFTB_T_LINVEC, EFTB_T_SYNK, EFTB_T_SYNS, EFTB_T_LINK, EFTB_T_LINS,
+    EFTB_T_AD, EFTB_T_EXP22, EFTB_T_EXPC, EFTB_T_MLJ, EFTB_T_LINVEC, EFTB_T_SYNK, EFTB_T_SYNS, EFTB_T_LINK, EFTB_T_LINS,
     EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
     EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
     EFTB_T_RSBASIS, EFTB_T_RSBASISS, EFTB_T_RSROWS,   /* matrix-core IR-resummation (Nl = 3): tables.py resum_mfma_tables */

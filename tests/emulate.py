@@ -46,7 +46,7 @@ def rows_from_sums(Z):
 def rows_from_vectors(c, V):
     """single sums: X_n = c_n V_n (n = 0..128) -> rows (Re X_128, Re X_127, Im X_127, ..., Re X_0, Im X_0, 0, 0, 0)"""
     X = (c[0] + 1j * c[1])[None, :] * V
-    out = np.zeros((V.shape[0], 272))
+    out = np.zeros((V.shape[0], 288))
     out[:, 0] = X[:, NH].real
     out[:, 1:257:2] = X[:, NH - 1 :: -1].real
     out[:, 2:257:2] = X[:, NH - 1 :: -1].imag
@@ -60,14 +60,16 @@ def pscf(t, Pin, with_cf):
     S = antidiagonal_sums(t, c)
     nb = t["comb22"].shape[1]
     out = dict(P11=P11)
-    out["P22"] = rows_from_sums(t["comb22"] @ S[:nb]) @ t["syn_k"]
+    out["P22"] = t["comb22"] @ (rows_from_sums(S[:nb]) @ t["syn_k"])
     L = t["linvec"]
     out["P13"] = P11[None, :] * (rows_from_vectors(c, L[:10]) @ t["lin_k"])
     if with_cf:
         Nl = t["l11"].shape[0]
-        S22, S13 = t["comb22"] @ S[:nb], t["comb13"] @ S[nb:]
-        out["C22"] = np.stack([rows_from_sums(t["mlj"][l][None, :] * S22) @ t["syn_s"] for l in range(Nl)])
-        out["C13"] = np.stack([rows_from_sums(t["mlj"][l][None, :] * S13) @ t["syn_s"] for l in range(Nl)])
+        # device order: synthesise the Nl*(nb + nb13) weighted basis rows, then expand (expand_kernel)
+        basis = np.concatenate([rows_from_sums(t["mlj"][l][None, :] * S) @ t["syn_s"] for l in range(Nl)])
+        full = t["expand_c"] @ basis
+        out["C22"] = full[: Nl * 28].reshape(Nl, 28, -1)
+        out["C13"] = full[Nl * 28 :].reshape(Nl, 10, -1)
         out["C11"] = rows_from_vectors(c, L[10 : 10 + Nl]) @ t["lin_s"]
         out["Cct"] = s[None, :] ** -2 * (rows_from_vectors(c, L[10 + Nl :]) @ t["lin_s"])
     return out
