@@ -33,7 +33,7 @@ TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD EXP22 EXPC MLJ LINVEC SYNK SYNS LINK
 T = {n: i for i, n in enumerate(TABLES)}
 BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF".split()
 B = {n: i for i, n in enumerate(BUFFERS)}
-S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22 = (1 << i for i in range(10))
+S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22, K_RESUM = (1 << i for i in range(11))
 
 EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_destroy eftb_add_operator eftb_apply_operator "
            "eftb_set_pipeline_operator eftb_set_template_dims eftb_put eftb_get eftb_buffer_size eftb_run "

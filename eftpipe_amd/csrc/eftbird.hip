@@ -274,17 +274,20 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             hipLaunchKernelGGL(regroup_cf_kernel, dim3(12, Nl, B), dim3(128), 0, st, Nl, b[EFTB_B_F], b[EFTB_B_CC], tb<double>(e, EFTB_T_L22),
                                tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_CLOOPL]);
     }
-    if (mask & EFTB_S_RESUM) {
+    if (mask & (EFTB_S_RESUM | EFTB_K_RESUM)) {
         if (!c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
+        const bool full = mask & EFTB_S_RESUM;  // EFTB_K_RESUM alone: only the main kernel, on the operands of an earlier full run
         const size_t lds = (size_t)(c.Nkin + c.nxtail) * sizeof(double);
-        hipLaunchKernelGGL(irfilter_kernel, dim3(B, 2), dim3(256), lds, st, c.Nkin, c.nxtail, Nl * Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
+        if (full)
+            hipLaunchKernelGGL(irfilter_kernel, dim3(B, 2), dim3(256), lds, st, c.Nkin, c.nxtail, Nl * Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
                            tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
                            tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
                            b[EFTB_B_XY], b[EFTB_B_Q]);
         if (Nl == 3) {
             // matrix-core form: polynomials as [96 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
-            hipLaunchKernelGGL(resum_prep_kernel, dim3(B), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
-                               tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL], e->RSA, e->RSC);
+            if (full)
+                hipLaunchKernelGGL(resum_prep_kernel, dim3(B), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
+                                   tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL], e->RSA, e->RSC);
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;

@@ -94,7 +94,8 @@ enum eftb_stage {
     EFTB_S_ALL     = 0xff,
     /* single-kernel selectors (profiling / roofline measurement only; need the stage's inputs in place) */
     EFTB_K_P22     = 1 << 8,  /* makeP22 alone: anti-diagonal sums + rows + synthesis */
-    EFTB_K_C22     = 1 << 9   /* makeC22 + makeC13 alone */
+    EFTB_K_C22     = 1 << 9,  /* makeC22 + makeC13 alone */
+    EFTB_K_RESUM   = 1 << 10  /* the main kernel of Resum.Ps alone (operands of an earlier EFTB_S_RESUM run) */
 };
 
 int  eftb_create(const eftb_config* cfg, eftb_engine** out);

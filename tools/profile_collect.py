@@ -4,7 +4,7 @@
     python tools/profile_collect.py r01
 
 Writes: rNN_bench.json, rNN_bench_under_rocprof.json, rNN_kernel_stats.csv (rocprofv3 --stats, verbatim),
-rNN_pmc_per_kernel.json (average counter values per kernel) and rNN_pmc_p22.json (the dominant kernel: HBM bytes
+rNN_pmc_per_kernel.json (average counter values per kernel) and rNN_pmc_dominant.json (the dominant kernel: HBM bytes
 per launch corrected as MI355X_MICROARCH.md prescribes, MFMA busy fraction, L2 hit rate, rocprof vs HIP-event time).
 """
 import collections
@@ -47,17 +47,17 @@ json.dump(avg, open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w"), inden
 
 bench = json.load(open(os.path.join(src, "bench.json")))
 stats = {short(r["Name"]): r for r in csv.DictReader(open(find("stats_kernel_stats.csv")))}
-dom = next(k for k in avg if k.startswith("eftb::pair_gemm2r_kernel"))
+dom = next(k for k in avg if k.startswith("eftb::resum_mfma_kernel"))
 c = avg[dom]
 B, NK = bench["config"]["batch_per_gpu"], 512
 out = {
-    "kernel": f"{dom} (makeP22), batch {B}, Nk {NK}",
+    "kernel": f"{dom} (Resum.Ps), batch {B}, Nk {NK}",
     "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
     "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
     "note": "(2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
-            "128-B requests of wide streams as 64 B; the 8-B/lane B-fragment loads are uncalibrated, so this is an upper bound). "
-            f"Algorithmic bytes per launch: u rows {B}*{NK}*260*8 = {B * NK * 260 * 8 / 1e6:.0f} MB + pair table + P22 basis out "
-            f"{B * NK * 7 * 8 / 1e6:.1f} MB.",
+            "128-B requests of wide streams as 64 B). "
+            f"Algorithmic bytes per launch: H table 3*80*{NK}*8 = {3 * 80 * NK * 8 / 1e6:.1f} MB (L2-resident, re-read per cosmology) + per-s records "
+            f"{B * 80 * 48 * 8 / 1e6:.1f} MB + template read-modify-write 2*{B}*63*{NK}*8 = {2 * B * 63 * NK * 8 / 1e6:.0f} MB.",
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
     "kernel_cycles_est": c["GRBM_GUI_ACTIVE"] / 8.0,
     "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
@@ -66,6 +66,6 @@ out = {
     "rocprof_avg_us": float(stats[dom]["AverageNs"]) / 1e3,
     "bench_hip_event_us": bench["roofline"]["ms_per_launch"] * 1e3,
 }
-json.dump(out, open(os.path.join(dst, f"{tag}_pmc_p22.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_dominant.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print("evaluations/s", bench["value"], "ms/step", bench["ms_per_step"], "stage_ms", bench["roofline"]["stage_ms"])
