@@ -1047,30 +1047,75 @@ __global__ __launch_bounds__(256) void ap_apply_kernel(int Nk, int nmu, const do
         const double* pa = ps + (size_t)ja * NS;
         const double* pb = ps + (size_t)jb * NS;
         const double* cw = YS + ((size_t)w * NL * NROW * Nk + i) * 2;
-#pragma unroll 1
-        for (int lp = 0; lp < NL; ++lp) {  // a real loop: keeps hipcc from hoisting all NL*NRT row loads (spills)
-            double ms[NL][4];
+        if constexpr (NRT <= 3) {
+            // few rows per lane: every load of the slot is issued up front (one memory round trip for the prefix sums, one
+            // for the spline data) instead of a pair of round trips per l'
+            double4 a4[NL][NL], b4[NL][NL];
 #pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                const double4 b4 = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
-                const double4 a4 = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
-                const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
-                ms[l][0] = d0;
-                ms[l][1] = fma(c10, d0, c11 * d1);
-                ms[l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
-                ms[l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+            for (int lp = 0; lp < NL; ++lp)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    b4[lp][l] = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
+                    a4[lp][l] = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
+                }
+            double2 ya[NL][NRT], yb[NL][NRT];
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const double2* cp = reinterpret_cast<const double2*>(cw + ((size_t)lp * NROW + min(rbase + r, NR - 1)) * Nk * 2);
+                    ya[lp][r] = cp[0];
+                    yb[lp][r] = cp[1];
+                }
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                double ms[NL][4];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const double d0 = b4[lp][l].x - a4[lp][l].x, d1 = b4[lp][l].y - a4[lp][l].y;
+                    const double d2 = b4[lp][l].z - a4[lp][l].z, d3 = b4[lp][l].w - a4[lp][l].w;
+                    ms[l][0] = d0;
+                    ms[l][1] = fma(c10, d0, c11 * d1);
+                    ms[l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
+                    ms[l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+                }
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const double2 ca = ya[lp][r], cb = yb[lp][r];
+                    const double sl = (cb.x - ca.x) * ih;
+                    const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
+                    const double c2 = (sl - ca.y) * ih - c3 * h;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], c2, fma(ms[l][3], c3, acc[l][r]))));
+                }
             }
-            const double* cl = cw + (size_t)lp * NROW * Nk * 2;
-#pragma unroll
-            for (int r = 0; r < NRT; ++r) {
-                const double2* cp = reinterpret_cast<const double2*>(cl + (size_t)min(rbase + r, NR - 1) * Nk * 2);
-                const double2 ca = cp[0], cb = cp[1];  // (y_i, s_i), (y_i+1, s_i+1) -> power form on [k_i, k_i+1]
-                const double sl = (cb.x - ca.x) * ih;
-                const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
-                const double c2 = (sl - ca.y) * ih - c3 * h;
-#pragma unroll
-                for (int l = 0; l < NL; ++l)
-                    acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], c2, fma(ms[l][3], c3, acc[l][r]))));
+        } else {
+    #pragma unroll 1
+            for (int lp = 0; lp < NL; ++lp) {  // a real loop: keeps hipcc from hoisting all NL*NRT row loads (spills)
+                double ms[NL][4];
+    #pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const double4 b4 = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
+                    const double4 a4 = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
+                    const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
+                    ms[l][0] = d0;
+                    ms[l][1] = fma(c10, d0, c11 * d1);
+                    ms[l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
+                    ms[l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+                }
+                const double* cl = cw + (size_t)lp * NROW * Nk * 2;
+    #pragma unroll
+                for (int r = 0; r < NRT; ++r) {
+                    const double2* cp = reinterpret_cast<const double2*>(cl + (size_t)min(rbase + r, NR - 1) * Nk * 2);
+                    const double2 ca = cp[0], cb = cp[1];  // (y_i, s_i), (y_i+1, s_i+1) -> power form on [k_i, k_i+1]
+                    const double sl = (cb.x - ca.x) * ih;
+                    const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
+                    const double c2 = (sl - ca.y) * ih - c3 * h;
+    #pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], c2, fma(ms[l][3], c3, acc[l][r]))));
+                }
             }
         }
     }

@@ -69,6 +69,10 @@ struct eftb_engine {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     double* gathered = nullptr;
+    // the gather runs on its own stream from a snapshot of P_l, so that it overlaps the next step's kernels
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t evSnap = nullptr, evGathered = nullptr;
+    double* plk_snap = nullptr;
 };
 
 // RCCL is resolved lazily so that single-GPU users never load it
@@ -341,7 +345,8 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     } while (0)
         if (rs == 1) AP_PICK(1);
         else if (rs == 2) AP_PICK(2);
-        else AP_PICK(3);
+        else if (rs == 3) AP_PICK(3);
+        else AP_PICK(7);
 #undef AP_PICK
 #undef AP_LAUNCH
 #undef AP_ARGS
@@ -387,7 +392,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->Nn = 2 * c.NIR * c.Na;
     e->cur_nl = c.Nl;
     e->cur_nx = c.Nk;
-    if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(3, std::max(1, atoi(f)));
+    if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(7, std::max(1, atoi(f)));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
@@ -465,8 +470,8 @@ int eftb_finalize(eftb_engine* e) {
     // opt in to the large dynamic LDS tiles
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define AP_LDS(NLV, NRV, RSV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_apply_kernel<NLV, NRV, RSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3);
-    AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3);
+    AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, 21, 7); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3); AP_LDS(3, NROW, 7);
+    AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
 #undef AP_LDS
     e->finalized = true;
     return 0;
@@ -532,12 +537,14 @@ void eftb_destroy(eftb_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->c.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->V, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->V, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evSnap, e->evGathered}) if (ev) (void)hipEventDestroy(ev);
+    if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -578,6 +585,7 @@ int eftb_run(eftb_engine* e, int mask, int B) {
 int eftb_sync(eftb_engine* e) {
     if (!e) return fail("eftb_sync: null engine");
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->comm_stream) HIPCHK(hipStreamSynchronize(e->comm_stream));  // an asynchronous gather may still be in flight
     return 0;
 }
 
@@ -656,19 +664,34 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
     const size_t count = (size_t)B * e->cur_nl * e->cur_nx;
     if (e->rank == root && !e->gathered)
         HIPCHK(hipMalloc(&e->gathered, (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
-    if (e->nranks == 1) {
-        HIPCHK(hipMemcpyAsync(e->gathered, e->buf[EFTB_B_PLK], count * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    } else {
+    if (!e->comm_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->evSnap, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->evGathered, hipEventDisableTiming));
+        HIPCHK(hipMalloc(&e->plk_snap, (size_t)e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
+        HIPCHK(hipEventRecord(e->evGathered, e->comm_stream));
+    }
+    // snapshot on the compute stream (after the previous gather has let go of the snapshot buffer) ...
+    HIPCHK(hipStreamWaitEvent(e->stream, e->evGathered, 0));
+    HIPCHK(hipMemcpyAsync(e->plk_snap, e->buf[EFTB_B_PLK], count * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->evSnap, e->stream));
+    // ... exchange on the communication stream, concurrently with whatever the compute stream does next
+    hipStream_t cs = e->comm_stream;
+    HIPCHK(hipStreamWaitEvent(cs, e->evSnap, 0));
+    if (e->nranks == 1 && !e->comm) {
+        HIPCHK(hipMemcpyAsync(e->gathered, e->plk_snap, count * sizeof(double), hipMemcpyDeviceToDevice, cs));
+    } else {  // with a communicator even a single rank goes through the RCCL send / recv group (self exchange)
         if (!e->comm) return fail("eftb_gather_plk: eftb_comm_init was not called");
         NCCLCHK(g_rccl.GroupStart());
         if (e->rank == root)
-            for (int r = 0; r < e->nranks; ++r) NCCLCHK(g_rccl.Recv(e->gathered + (size_t)r * count, count, ncclDouble, r, e->comm, e->stream));
-        NCCLCHK(g_rccl.Send(e->buf[EFTB_B_PLK], count, ncclDouble, root, e->comm, e->stream));
+            for (int r = 0; r < e->nranks; ++r) NCCLCHK(g_rccl.Recv(e->gathered + (size_t)r * count, count, ncclDouble, r, e->comm, cs));
+        NCCLCHK(g_rccl.Send(e->plk_snap, count, ncclDouble, root, e->comm, cs));
         NCCLCHK(g_rccl.GroupEnd());
     }
+    HIPCHK(hipEventRecord(e->evGathered, cs));
     if (host_out && e->rank == root) {
-        HIPCHK(hipMemcpyAsync(host_out, e->gathered, (size_t)e->nranks * count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpyAsync(host_out, e->gathered, (size_t)e->nranks * count * sizeof(double), hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipStreamSynchronize(cs));
     }
     return 0;
 }

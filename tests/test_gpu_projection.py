@@ -113,6 +113,15 @@ def test_rccl_gather_single_rank(golden):
     out = eng.gather_plk(3, root=0, to_host=True)
     assert out.shape == (1, 3, 2, 50)
     assert relerr(out[0, 0], g["plk_auto"]) < TOL and np.array_equal(out[0, 0], out[0, 2])
+    # asynchronous gathers (side stream, P_l snapshot) pipelined with further steps: the last one wins, nothing is torn
+    for scale in (2.0, 3.0, 0.5):
+        eng.put("BIAS", bias * scale)
+        eng.run(eng.full_mask(reduce=True), 3, sync=False)
+        eng.gather_plk(3, root=0)
+    eng.put("BIAS", bias)
+    eng.run(eng.full_mask(reduce=True), 3, sync=False)
+    last = eng.gather_plk(3, root=0, to_host=True)
+    assert np.array_equal(last, out)
     eng.close()
 
 

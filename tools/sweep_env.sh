@@ -3,5 +3,5 @@
 var=$1; shift
 for v in "$@"; do
   env $var=$v timeout -k 10 300 python bench.py --steps 10 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$var=$v', round(d['value']), round(d['ms_per_step'],3), 'p22', round(r['ms_per_launch'],4), 'c22', round(r['c22_pair_gemm_ms'],4), {k:round(x,3) for k,x in r['stage_ms'].items()})" || exit 1
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$var=$v', round(d['value']), round(d['ms_per_step'],3), {k:round(x,3) for k,x in r['stage_ms'].items()})" || exit 1
 done
