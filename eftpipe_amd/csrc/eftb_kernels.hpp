@@ -195,14 +195,32 @@ struct SynthDesc {
     const double* xscale; // [X] or null           (Cct: s^-2)
     long long a_group, o_group;
     int M, rpg, K, X;
+    int wg_end, wgx;      // batched launch: this problem owns workgroups [previous wg_end, wg_end), wgx of them per row tile
 };
 
-__global__ __launch_bounds__(256) void synth_kernel(SynthDesc d) {
+// Several independent syntheses in one launch (P22 basis, P13, xi basis, C11, Cct): each is latency-bound on its own
+// (a few hundred workgroups, a global-load round trip per K chunk), together they fill the chip.
+constexpr int SYN_MAXP = 5;
+struct SynthBatch {
+    SynthDesc p[SYN_MAXP];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
+    int pi = 0, wg0 = 0;
+#pragma unroll
+    for (int q = 0; q < SYN_MAXP - 1; ++q)
+        if (q + 1 < batch.n && (int)blockIdx.x >= batch.p[q].wg_end) {
+            pi = q + 1;
+            wg0 = batch.p[q].wg_end;
+        }
+    const SynthDesc& d = batch.p[pi];
+    const int wg = blockIdx.x - wg0, bx = wg % d.wgx, by = wg / d.wgx;
     constexpr int LDA = SYN_KC + 2, LDB = 80, NA = 32 * SYN_KC / 256, NB = SYN_KC * 64 / 256;
     __shared__ double As[32 * LDA];
     __shared__ double Bs[SYN_KC * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int row0 = blockIdx.y * 32, x0 = blockIdx.x * 64;
+    const int row0 = by * 32, x0 = bx * 64;
     const int rh = wave >> 1, xh = wave & 1;
     // this thread's share of every chunk: NA elements of the A tile, NB of the Tab tile (fixed positions, pointers hoisted)
     const double* pa[NA];
@@ -269,9 +287,9 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthDesc d) {
 constexpr int EXP_RPB = 8;
 
 template <int RIN>
-__global__ __launch_bounds__(64) void expand_kernel(int Rout, int X, const double* __restrict__ basis, const double* __restrict__ comb,
-                                                    double* __restrict__ out) {
-    const int x = blockIdx.x * 64 + threadIdx.x, grp = blockIdx.y, r0 = blockIdx.z * EXP_RPB;
+__device__ inline void expand_body(int bx, int grp, int bz, int Rout, int X, const double* __restrict__ basis,
+                                   const double* __restrict__ comb, double* __restrict__ out) {
+    const int x = bx * 64 + threadIdx.x, r0 = bz * EXP_RPB;
     if (x >= X) return;
     double v[RIN];
 #pragma unroll
@@ -286,6 +304,22 @@ __global__ __launch_bounds__(64) void expand_kernel(int Rout, int X, const doubl
 #pragma unroll
     for (int i = 0; i < EXP_RPB; ++i)
         if (r0 + i < Rout) out[((size_t)grp * Rout + r0 + i) * X + x] = acc[i];
+}
+
+// both expansions in one launch: workgroups [0, n22) -> P22 (28 rows from BAS22, X = Nk), the rest -> C22 / C13 (Nl*38 rows
+// from BASC, X = 80); within a part the index runs (x tile, row block, cosmology), x fastest
+__global__ __launch_bounds__(64) void expand_kernel(int n22, int Nk, int B, const double* __restrict__ Y22, const double* __restrict__ exp22,
+                                                    double* __restrict__ P22, int RoutC, const double* __restrict__ YCF,
+                                                    const double* __restrict__ expc, double* __restrict__ CC) {
+    int wg = blockIdx.x;
+    if (wg < n22) {
+        const int nx = (Nk + 63) / 64, nz = (28 + EXP_RPB - 1) / EXP_RPB;
+        expand_body<BAS22>(wg % nx, wg / (nx * nz), (wg / nx) % nz, 28, Nk, Y22, exp22, P22);
+    } else {
+        wg -= n22;
+        const int nx = (NS + 63) / 64, nz = (RoutC + EXP_RPB - 1) / EXP_RPB;
+        expand_body<BASC>(wg % nx, wg / (nx * nz), (wg / nx) % nz, RoutC, NS, YCF, expc, CC);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

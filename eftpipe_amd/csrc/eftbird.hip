@@ -40,8 +40,8 @@ static int fail(const char* fmt, ...) {
 
 struct eftb_engine {
     eftb_config c;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;   // side: the small input-only kernels (IR filters, AP prefix sums) run beside the loop path
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJoin = nullptr;
     bool finalized = false;
     void* tab[EFTB_T_COUNT] = {nullptr};
     size_t tab_bytes[EFTB_T_COUNT] = {0};
@@ -182,13 +182,20 @@ static size_t need_buffer_elems(const eftb_config& c, int id) {
 template <typename T>
 static inline const T* tb(const eftb_engine* e, int id) { return static_cast<const T*>(e->tab[id]); }
 
-// out[row][x] = sum_q A[row][q] Tab[q][x] on the FP64 matrix cores (synth_kernel); rows = (group, member)
-static void launch_synth(hipStream_t st, const double* A, long long a_group, int groups, int rpg, int K, const double* Tab, int X, double* out,
-                         long long o_group, const double* gscale, const double* xscale) {
-    SynthDesc d{};
+// out[row][x] = sum_q A[row][q] Tab[q][x] on the FP64 matrix cores (synth_kernel); rows = (group, member).  The requested
+// syntheses of a stage set are queued into one SynthBatch and launched together.
+static void queue_synth(SynthBatch& sb, const double* A, long long a_group, int groups, int rpg, int K, const double* Tab, int X, double* out,
+                        long long o_group, const double* gscale, const double* xscale) {
+    SynthDesc& d = sb.p[sb.n];
     d.A = A; d.Tab = Tab; d.out = out; d.gscale = gscale; d.xscale = xscale;
     d.a_group = a_group; d.o_group = o_group; d.M = groups * rpg; d.rpg = rpg; d.K = K; d.X = X;
-    hipLaunchKernelGGL(synth_kernel, dim3((X + 63) / 64, (d.M + 31) / 32), dim3(256), 0, st, d);
+    d.wgx = (X + 63) / 64;
+    d.wg_end = (sb.n ? sb.p[sb.n - 1].wg_end : 0) + d.wgx * ((d.M + 31) / 32);
+    ++sb.n;
+}
+
+static void launch_synth(hipStream_t st, const SynthBatch& sb) {
+    if (sb.n) hipLaunchKernelGGL(synth_kernel, dim3(sb.p[sb.n - 1].wg_end), dim3(256), 0, st, sb);
 }
 
 // anti-diagonal sums of every loop matrix for the batch (shared by the k-space and the xi-space pieces), then the
@@ -233,11 +240,44 @@ static int launch_operator(eftb_engine* e, int id, int B) {
     return 0;
 }
 
+static void launch_irfilter(eftb_engine* e, hipStream_t st, int B) {
+    const eftb_config& c = e->c;
+    double** b = e->buf;
+    const size_t lds = (size_t)(c.Nkin + c.nxtail) * sizeof(double);
+    hipLaunchKernelGGL(irfilter_kernel, dim3(B, 2), dim3(256), lds, st, c.Nkin, c.nxtail, c.Nl * c.Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
+                       tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
+                       tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
+                       b[EFTB_B_XY], b[EFTB_B_Q]);
+}
+
+static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
+    const eftb_config& c = e->c;
+    double** b = e->buf;
+    const size_t pflds = ((size_t)(1 + 2 * c.Nl) * c.nmu + (size_t)c.Nl * c.Nl * 4 * 8) * sizeof(double);
+#define PF_ARGS c.nmu, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
+                tb<double>(e, EFTB_T_LEGMU), e->APP, e->APR
+    if (c.Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(320), pflds, st, PF_ARGS);
+    else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(320), pflds, st, PF_ARGS);
+#undef PF_ARGS
+}
+
 static int launch_stages(eftb_engine* e, int mask, int B) {
     const eftb_config& c = e->c;
     hipStream_t st = e->stream;
     const int Nk = c.Nk, Nl = c.Nl;
     double** b = e->buf;
+    // The IR filters / Q(f) and the AP prefix sums depend on the inputs only: when they are part of a longer stage set they
+    // run on a side stream beside the (latency-bound) loop path and are joined right before their consumers.
+    const bool side_ir = (mask & EFTB_S_RESUM) && c.with_resum && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP));
+    const bool side_ap = (mask & EFTB_S_AP) && c.with_ap && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP | EFTB_S_RESUM));
+    if (side_ir || side_ap) {
+        if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
+            return fail("eftb_run: stream fork failed");
+        if (side_ir) launch_irfilter(e, e->side, B);
+        if (side_ap) launch_ap_prefix(e, e->side, B);
+        if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
+    }
+    bool joined = !(side_ir || side_ap);
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
         hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
@@ -255,19 +295,25 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (mask & EFTB_S_CF) sets |= 0x8;
         if (int rc = launch_antidiag_rows(e, st, B, sets)) return rc;
     }
-    if (mask & (EFTB_S_LOOPS | EFTB_K_P22)) {
-        launch_synth(st, e->A22, 0, 1, B * BAS22, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, e->Y22, 0, nullptr, nullptr);
-        hipLaunchKernelGGL((expand_kernel<BAS22>), dim3((Nk + 63) / 64, B, (28 + EXP_RPB - 1) / EXP_RPB), dim3(64), 0, st, 28, Nk, e->Y22, tb<double>(e, EFTB_T_EXP22), b[EFTB_B_P22]);
+    {
+        // every synthesis of the requested pieces in one launch, then both expansions in one launch
+        SynthBatch sb{};
+        const bool k22 = mask & (EFTB_S_LOOPS | EFTB_K_P22), c22 = mask & (EFTB_S_CF | EFTB_K_C22);
+        if (k22) queue_synth(sb, e->A22, 0, 1, B * BAS22, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, e->Y22, 0, nullptr, nullptr);
+        if (c22) queue_synth(sb, e->ACF, 0, 1, B * BASC, KSYN, tb<double>(e, EFTB_T_SYNS), NS, e->YCF, 0, nullptr, nullptr);
         if (mask & EFTB_S_LOOPS)
-            launch_synth(st, e->A13, 10LL * KLIN, B, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], 10LL * Nk, b[EFTB_B_P11], nullptr);
-    }
-    if (mask & (EFTB_S_CF | EFTB_K_C22)) {
-        launch_synth(st, e->ACF, 0, 1, B * BASC, KSYN, tb<double>(e, EFTB_T_SYNS), NS, e->YCF, 0, nullptr, nullptr);
-        hipLaunchKernelGGL((expand_kernel<BASC>), dim3((NS + 63) / 64, B, (Nl * 38 + EXP_RPB - 1) / EXP_RPB), dim3(64), 0, st, Nl * 38, NS, e->YCF, tb<double>(e, EFTB_T_EXPC), b[EFTB_B_CC]);
+            queue_synth(sb, e->A13, 10LL * KLIN, B, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], 10LL * Nk, b[EFTB_B_P11], nullptr);
         if (mask & EFTB_S_CF) {
-            launch_synth(st, e->ALC, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], (long long)Nl * NS, nullptr, nullptr);
-            launch_synth(st, e->ALC + (size_t)Nl * KLIN, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCT], (long long)Nl * NS,
-                         nullptr, e->sm2);
+            queue_synth(sb, e->ALC, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], (long long)Nl * NS, nullptr, nullptr);
+            queue_synth(sb, e->ALC + (size_t)Nl * KLIN, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCT], (long long)Nl * NS,
+                        nullptr, e->sm2);
+        }
+        launch_synth(st, sb);
+        if (k22 || c22) {
+            const int n22 = k22 ? ((Nk + 63) / 64) * ((28 + EXP_RPB - 1) / EXP_RPB) * B : 0;
+            const int ncf = c22 ? ((NS + 63) / 64) * ((Nl * 38 + EXP_RPB - 1) / EXP_RPB) * B : 0;
+            hipLaunchKernelGGL(expand_kernel, dim3(n22 + ncf), dim3(64), 0, st, n22, Nk, B, e->Y22, tb<double>(e, EFTB_T_EXP22), b[EFTB_B_P22], Nl * 38,
+                               e->YCF, c22 ? tb<double>(e, EFTB_T_EXPC) : nullptr, b[EFTB_B_CC]);
         }
     }
     if (mask & EFTB_S_REGROUP) {
@@ -281,12 +327,11 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & (EFTB_S_RESUM | EFTB_K_RESUM)) {
         if (!c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
         const bool full = mask & EFTB_S_RESUM;  // EFTB_K_RESUM alone: only the main kernel, on the operands of an earlier full run
-        const size_t lds = (size_t)(c.Nkin + c.nxtail) * sizeof(double);
-        if (full)
-            hipLaunchKernelGGL(irfilter_kernel, dim3(B, 2), dim3(256), lds, st, c.Nkin, c.nxtail, Nl * Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
-                           tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
-                           tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
-                           b[EFTB_B_XY], b[EFTB_B_Q]);
+        if (full && !side_ir) launch_irfilter(e, st, B);
+        if (!joined) {
+            if (hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+            joined = true;
+        }
         if (Nl == 3) {
             // matrix-core form: polynomials as [96 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
             if (full)
@@ -322,15 +367,14 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             const int ysplit = std::max(1, std::min(nseries, 2048 / kt));  // ~8 workgroups per CU, each sweeping nseries/ysplit series
             hipLaunchKernelGGL(spline_kernel, dim3(kt, ysplit), dim3(256), 0, st, Nk, nseries, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPBAND), e->SD);
         }
-        // prefix sums over mu per cosmology, then interval moments by differences x cubic coefficients
+        // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
         const int nr = c.ap_stochastic ? NROW : 21;
         const int rs = e->ap_rowsplit;
-        const size_t pflds = ((size_t)(1 + 2 * Nl) * c.nmu + (size_t)Nl * Nl * 4 * 8) * sizeof(double);
-#define PF_ARGS c.nmu, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
-                tb<double>(e, EFTB_T_LEGMU), e->APP, e->APR
-        if (Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(320), pflds, st, PF_ARGS);
-        else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(320), pflds, st, PF_ARGS);
-#undef PF_ARGS
+        if (!side_ap) launch_ap_prefix(e, st, B);
+        if (!joined) {
+            if (hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+            joined = true;
+        }
 #define AP_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), \
                 e->APP, e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt
         const dim3 apgrid((Nk + 63) / 64, B, rs);
@@ -394,6 +438,9 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->cur_nx = c.Nk;
     if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(7, std::max(1, atoi(f)));
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
     for (int id = 0; id < EFTB_B_COUNT; ++id) {
@@ -543,7 +590,8 @@ void eftb_destroy(eftb_engine* e) {
     for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->V, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evSnap, e->evGathered}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered}) if (ev) (void)hipEventDestroy(ev);
+    if (e->side) (void)hipStreamDestroy(e->side);
     if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
