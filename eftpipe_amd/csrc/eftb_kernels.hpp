@@ -682,22 +682,25 @@ __global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int sc
 // IR-resummation on the FP64 matrix cores (Nl = 3; tables.py resum_mfma_tables).
 // All 108 polynomials  sum_p Q_a[l,l',(half,p,v)](f) z^p  of one cosmology lie in a fixed 8-dimensional space, so with
 // an orthonormal basis beta_r(t), t = z / RS_ZS, of that space their values at 16 (k, s) points are one
-// [96 x 8] x [8 x 16] product:  rows = (tile tau, chunk, slot) as laid out by the host so that the four numbers a lane
+// [80 x 8] x [8 x 16] product:  rows = (tile tau, chunk, slot) as laid out by the host so that the four numbers a lane
 // receives from one v_mfma_f64_16x16x4 (rows (lane >> 4) + 4 q, column lane & 15) are the four (v, half) slots of ONE
 // (a, l, l') block at ONE k.  The lane then forms
 //     W_a[l,l'](k,s) = z H_l'(k,s) D0 + y (H_0 D1 + H_1 D2 + H_2 D3),   z = k^2 X(s), y = k^2 Y(s),
 // and contracts it with the s-dependent (wave-uniform, scalar-loaded) C11 / Cct / Cloopl columns into its own output
 // rows, accumulated over s in registers:  lanes (jg = lane >> 4, n = lane & 15) own k = k0 + n and
-//     tiles 0-2 (l' = tau):      jg < 3 -> (a = 1, l = jg): Pctl[6] + Ploopl[12];   jg = 3 -> (a = 0, l = 0): P11l[3]
-//     tiles 3-5 (l' = tau - 3):  jg < 2 -> (a = 0, l = jg + 1): P11l[3]             (jg >= 2: zero rows)
-// so every (l, row, k) is written by exactly one lane and no cross-lane reduction is needed.  The loop has no branches
-// (lane roles are applied through zeroed weights), which keeps hipcc from shuffling MFMA results through AGPRs.
+//     tiles 0-2 (l' = tau):  jg < 3 -> (a = 1, l = jg): Pctl[6] + Ploopl[12];   jg = 3 -> (a = 0, l = 0): P11l[3]
+//     tile 3:                jg < 3 -> (a = 0, l = 1, l' = jg);   jg = 3 -> (a = 0, l = 2, l' = 0)
+//     tile 4:                jg < 2 -> (a = 0, l = 2, l' = jg + 1)                     (jg >= 2: zero rows)
+// The 18 (a, l, l') blocks thus fill 18 of the 20 chunks of five row tiles.  Blocks of tiles 0-2 are accumulated over s in the
+// lane that owns the output rows; the six one-number (a = 0, l >= 1) sums of tiles 3-4 are combined across lane groups once,
+// after the loop.  The loop has no branches (lane roles are applied through zeroed weights and selects), which keeps hipcc from
+// shuffling MFMA results through AGPRs.
 // resum_prep_kernel builds, per cosmology, A = Q(f) diag(RS_ZS^p) V8^T and the per-s records
 //   RSC[w][s] = { [l'][14]: C11[l'], Cct[l'], Cloopl[l',0..11] } , X, Y, pad  (48 doubles);
 // the mu weights l11 / lct multiply the s-sums once, at the end.
 // ------------------------------------------------------------------------------------------------
 constexpr double RS_ZS = 8.0;  // tables.py RS_ZS
-constexpr int RS_NB = 8, RS_ROWS = 96, RS_REC = 48;
+constexpr int RS_NB = 8, RS_TILES = 5, RS_ROWS = 16 * RS_TILES, RS_REC = 48;
 
 __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na, const double* __restrict__ Q,
                                                          const double* __restrict__ V8S, const int* __restrict__ rows,
@@ -758,18 +761,18 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 16; ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
-    double aop[6][2];
+    double aop[RS_TILES][2];
 #pragma unroll
-    for (int tau = 0; tau < 6; ++tau)
+    for (int tau = 0; tau < RS_TILES; ++tau)
 #pragma unroll
         for (int t = 0; t < 2; ++t) aop[tau][t] = RSA[((size_t)w * RS_ROWS + 16 * tau + n) * RS_NB + jg + 4 * t];
-    // lane roles as weights (no branches in the s loop)
-    const double r1 = jg < 3 ? 1.0 : 0.0, r0 = jg < 3 ? 0.0 : 1.0;
-    double accL[12], accCt[3], acc11A[3], acc11B[3];  // s-sums: W Cloopl[l',i] (summed over l'), W Cct[l'], W C11[l'] (tiles 0-2 / 3-5)
+    const int lp3 = jg < 3 ? jg : 0, lp4 = jg < 2 ? jg + 1 : 0;  // l' of this lane's block in tiles 3 and 4
+    double accL[12], accCt[3], acc11A[3], acc11B[2];  // s-sums: W Cloopl[l',i] (summed over l'), W Cct[l'], W C11[l'] (tiles 0-2), tiles 3 / 4
 #pragma unroll
     for (int i = 0; i < 12; ++i) accL[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) accCt[i] = acc11A[i] = acc11B[i] = 0.0;
+    for (int i = 0; i < 3; ++i) accCt[i] = acc11A[i] = 0.0;
+    acc11B[0] = acc11B[1] = 0.0;
     const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
     const double* ct = RSC + ((size_t)w * NS + s0) * RS_REC;  // wave-uniform record of the current s
     double h[3];
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
     }
     // keep the A operand in registers (hipcc would otherwise re-load it from memory every step)
 #pragma unroll
-    for (int tau = 0; tau < 6; ++tau)
+    for (int tau = 0; tau < RS_TILES; ++tau)
 #pragma unroll
         for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(aop[tau][t]));
     for (int s = s0; s < s1; ++s) {
@@ -799,12 +802,12 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
 #pragma unroll
         for (int v = 0; v < 3; ++v) hn[v] = H[((size_t)v * NS + sn) * Nk + kc];
         __builtin_amdgcn_sched_barrier(0);
-        // all twelve MFMAs of this step (six independent accumulators) ...
-        v4d D[6];
+        // all ten MFMAs of this step (five independent accumulators) ...
+        v4d D[RS_TILES];
 #pragma unroll
-        for (int tau = 0; tau < 6; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
 #pragma unroll
-        for (int tau = 0; tau < 6; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
+        for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // ... under them the basis polynomials of the next step ...
         const double zn = k2 * xn, yn = k2 * yn0;
@@ -824,16 +827,19 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
 #pragma unroll
         for (int tau = 0; tau < 3; ++tau) {
             const double W = fma(zh[tau], D[tau][0], fma(yh[0], D[tau][1], fma(yh[1], D[tau][2], yh[2] * D[tau][3])));
-            const double W1 = W * r1, W0 = W * r0;
-            acc11A[tau] = fma(W0, cv[tau * 14], acc11A[tau]);
-            accCt[tau] = fma(W1, cv[tau * 14 + 1], accCt[tau]);
+            // every lane accumulates both roles; the sums of the role it does not own are never read
+            acc11A[tau] = fma(W, cv[tau * 14], acc11A[tau]);
+            accCt[tau] = fma(W, cv[tau * 14 + 1], accCt[tau]);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) accL[i] = fma(W1, cv[tau * 14 + 2 + i], accL[i]);
+            for (int i = 0; i < 12; ++i) accL[i] = fma(W, cv[tau * 14 + 2 + i], accL[i]);
         }
-#pragma unroll
-        for (int tau = 3; tau < 6; ++tau) {
-            const double W = fma(zh[tau - 3], D[tau][0], fma(yh[0], D[tau][1], fma(yh[1], D[tau][2], yh[2] * D[tau][3])));
-            acc11B[tau - 3] = fma(W, cv[(tau - 3) * 14], acc11B[tau - 3]);
+        {  // tiles 3 and 4: one (a = 0, l, l') block per lane, l' by lane group
+            const double zh3 = lp3 == 0 ? zh[0] : (lp3 == 1 ? zh[1] : zh[2]), c3 = lp3 == 0 ? cv[0] : (lp3 == 1 ? cv[14] : cv[28]);
+            const double zh4 = lp4 == 1 ? zh[1] : zh[2], c4 = lp4 == 1 ? cv[14] : cv[28];
+            const double W3 = fma(zh3, D[3][0], fma(yh[0], D[3][1], fma(yh[1], D[3][2], yh[2] * D[3][3])));
+            const double W4 = fma(zh4, D[4][0], fma(yh[0], D[4][1], fma(yh[1], D[4][2], yh[2] * D[4][3])));
+            acc11B[0] = fma(W3, c3, acc11B[0]);
+            acc11B[1] = fma(W4, c4, acc11B[1]);
         }
         __builtin_amdgcn_sched_barrier(0);
         ct = ctn;
@@ -844,9 +850,9 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
 #pragma unroll
         for (int v = 0; v < 3; ++v) h[v] = hn[v];
     }
-    if (!live) return;
-    // (a, l) blocks of this lane -> output rows, mu weights applied to the s-sums
-    double o18[18], oA[3], oB[3];
+    // (a, l) blocks -> output rows, mu weights applied to the s-sums.  The (a = 0, l = 1 | 2) blocks of tiles 3-4 are spread
+    // over lane groups (one l' each): their l11-weighted terms are gathered into the jg = 0 lane of every k.
+    double o18[18], oA[3], o1[3], o2[3];
 #pragma unroll
     for (int i = 0; i < 6; ++i) o18[i] = lct[i] * accCt[0] + lct[6 + i] * accCt[1] + lct[12 + i] * accCt[2];
 #pragma unroll
@@ -854,8 +860,12 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         oA[i] = l11[i] * acc11A[0] + l11[3 + i] * acc11A[1] + l11[6 + i] * acc11A[2];
-        oB[i] = l11[i] * acc11B[0] + l11[3 + i] * acc11B[1] + l11[6 + i] * acc11B[2];
+        const double t1 = jg < 3 ? l11[lp3 * 3 + i] * acc11B[0] : 0.0;                                  // (l = 1, l' = jg)
+        const double t2 = (jg == 3 ? l11[i] * acc11B[0] : 0.0) + (jg < 2 ? l11[lp4 * 3 + i] * acc11B[1] : 0.0);  // (l = 2, l' = 0 | jg + 1)
+        o1[i] = t1 + __shfl(t1, n + 16) + __shfl(t1, n + 32);
+        o2[i] = t2 + __shfl(t2, n + 16) + __shfl(t2, n + 48);
     }
+    if (!live) return;
     if (nsplit == 1) {
         if (jg < 3) {
             double* dst = T + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
@@ -866,10 +876,14 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
 #pragma unroll
             for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += oA[i];
         }
-        if (jg < 2) {
-            double* dst = T + (((size_t)w * NL + jg + 1) * NROW) * Nk + k;
+        if (jg == 0) {
+            double* d1 = T + (((size_t)w * NL + 1) * NROW) * Nk + k;
+            double* d2 = T + (((size_t)w * NL + 2) * NROW) * Nk + k;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += oB[i];
+            for (int i = 0; i < 3; ++i) {
+                d1[(size_t)i * Nk] += o1[i];
+                d2[(size_t)i * Nk] += o2[i];
+            }
         }
     } else {  // partial sums over the s slices, added in a fixed order by resum_sum_kernel
         double* pw = part + ((size_t)w * nsplit + split) * NL * 21 * Nk + k;
@@ -880,9 +894,12 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
 #pragma unroll
             for (int i = 0; i < 3; ++i) pw[(size_t)i * Nk] = oA[i];
         }
-        if (jg < 2) {
+        if (jg == 0) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) pw[((size_t)(jg + 1) * 21 + i) * Nk] = oB[i];
+            for (int i = 0; i < 3; ++i) {
+                pw[((size_t)21 + i) * Nk] = o1[i];
+                pw[((size_t)42 + i) * Nk] = o2[i];
+            }
         }
     }
 }

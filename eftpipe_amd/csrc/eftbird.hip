@@ -49,7 +49,7 @@ struct eftb_engine {
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
     double *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
-    double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][96][8], per-s records [B][NS][80]
+    double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][80][8], per-s records [B][NS][48]
     double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
     double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
@@ -333,7 +333,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             joined = true;
         }
         if (Nl == 3) {
-            // matrix-core form: polynomials as [96 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
+            // matrix-core form: polynomials as [80 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
             if (full)
                 hipLaunchKernelGGL(resum_prep_kernel, dim3(B), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
                                    tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL], e->RSA, e->RSC);

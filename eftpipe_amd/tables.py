@@ -344,7 +344,7 @@ def build_tables(cfg: EngineConfig) -> dict:
 # ----------------------------------------------------------------------------- IR-resummation on the matrix cores
 RS_ZS = 8.0     # the polynomials are evaluated in t = k^2 X / RS_ZS (must match csrc/eftb_kernels.hpp RS_ZS)
 RS_NB = 8       # dimension of the span of all resummation polynomials
-RS_ROWS = 96    # 6 MFMA row tiles x 16
+RS_ROWS = 80    # 5 MFMA row tiles x 16
 
 
 def resum_mfma_tables(Qpoly, NIR, Na):
@@ -353,14 +353,15 @@ def resum_mfma_tables(Qpoly, NIR, Na):
     Every polynomial  sum_p Q_a[l,l',(half,p,v)](f) z^p  of the IR-resummation (there are 108 per cosmology, degree 15)
     lies, for every f, in one fixed 8-dimensional space: q_p (p+1)! (-2)^(p+1) is a degree-7 polynomial in p.  With an
     orthonormal basis V8 of that space (in the scaled variable t = z / RS_ZS) the polynomials of all rows at 16 (k, s) points
-    become one [96 x 8] x [8 x 16] matrix product on the FP64 matrix cores, A = Q . diag(RS_ZS^p) . V8^T.
+    become one [80 x 8] x [8 x 16] matrix product on the FP64 matrix cores, A = Q . diag(RS_ZS^p) . V8^T.
 
     Row layout (tile tau, row i):  chunk = (tau, i % 4), slot = i // 4  -- exactly the 4 values a lane holds of one
-    v_mfma_f64_16x16x4 result (rows (lane >> 4) + 4 q).  Chunks:  tau < 3: l' = tau and i % 4 = 0, 1, 2 -> (a = 1, l = i % 4),
-    3 -> (a = 0, l = 0);  tau >= 3: l' = tau - 3 and i % 4 = 0, 1 -> (a = 0, l = 1), (a = 0, l = 2), 2, 3 -> unused.
+    v_mfma_f64_16x16x4 result (rows (lane >> 4) + 4 q).  The 18 (a, l, l') blocks fill 18 of the 20 chunks of 5 tiles:
+    tau < 3: l' = tau and i % 4 = 0, 1, 2 -> (a = 1, l = i % 4), 3 -> (a = 0, l = 0);  tau = 3: i % 4 = 0, 1, 2 -> (a = 0, l = 1,
+    l' = i % 4), 3 -> (a = 0, l = 2, l' = 0);  tau = 4: i % 4 = 0, 1 -> (a = 0, l = 2, l' = 1 + i % 4), 2, 3 -> unused.
     Slots: 0 -> (v = l', half 0) [the X^(p+1) series only couples v = l'],  1..3 -> (v = slot - 1, half 1).
 
-    -> rs_basis [8,16] (V8), rs_basis_scaled [8,16] (V8 diag(RS_ZS^p)), rs_rows int32[96] (offset of the row's p = 0
+    -> rs_basis [8,16] (V8), rs_basis_scaled [8,16] (V8 diag(RS_ZS^p)), rs_rows int32[80] (offset of the row's p = 0
        coefficient inside one cosmology's Q block [2,Nl,Nl,Nn], stride Na per p; -1 = zero row)."""
     Nl = 3
     NN = 2 * NIR * Na
@@ -374,14 +375,16 @@ def resum_mfma_tables(Qpoly, NIR, Na):
     V8 = np.ascontiguousarray(Vt[:RS_NB])
     rows = np.full(RS_ROWS, -1, dtype=np.int32)
     used = np.zeros((2, Nl, Nl, 2, Na), dtype=bool)                     # a (device convention), l, l', half, v
-    for tau in range(6):
-        lp = tau % 3
+    for tau in range(5):
         for i in range(16):
             jg, slot = i % 4, i // 4
             if tau < 3:
+                lp = tau
                 a, l = (1, jg) if jg < 3 else (0, 0)
+            elif tau == 3:
+                a, l, lp = ((0, 1, 0), (0, 1, 1), (0, 1, 2), (0, 2, 0))[jg]
             elif jg < 2:
-                a, l = 0, jg + 1
+                a, l, lp = 0, 2, jg + 1
             else:
                 continue
             v, half = (lp, 0) if slot == 0 else (slot - 1, 1)

@@ -133,7 +133,7 @@ def resum(t, f, Pin, st):
 
 def resum_mfma(t, f, Pin, st):
     """The matrix-core form of the same stage (device: resum_prep_kernel + resum_mfma_kernel, Nl = 3): polynomials as
-    A[96 rows, 8] x beta[8, points] in t = z / RS_ZS, rows laid out as (tile, chunk, slot) -- see tables.resum_mfma_tables."""
+    A[80 rows, 8] x beta[8, points] in t = z / RS_ZS, rows laid out as (tile, chunk, slot) -- see tables.resum_mfma_tables."""
     from eftpipe_amd.tables import RS_ZS
 
     NIR, Na, Nklow = t["resum_dims"]
@@ -144,21 +144,23 @@ def resum_mfma(t, f, Pin, st):
     z = k[:, None] ** 2 * X[None, :]
     yk = k[:, None] ** 2 * Y[None, :]
     rows = t["rs_rows"]
-    A = np.zeros((96, 8))
+    A = np.zeros((80, 8))
     for r in np.nonzero(rows >= 0)[0]:
         A[r] = t["rs_basis_scaled"] @ Q[rows[r] + np.arange(NIR) * Na]
     tt = z / RS_ZS
     beta = np.einsum("rp,pks->rks", t["rs_basis"], np.stack([tt**p for p in range(NIR)]))  # [8,Nk,Ns]
-    D = np.einsum("ir,rks->iks", A, beta).reshape(6, 4, 4, *z.shape)  # [tau, slot, jg, k, s]
+    D = np.einsum("ir,rks->iks", A, beta).reshape(5, 4, 4, *z.shape)  # [tau, slot, jg, k, s]
     H = t["H"]
     out = {n: st[n].copy() for n in ("P11l", "Pctl", "Ploopl")}
-    for tau in range(6):
-        lp = tau % 3
+    for tau in range(5):
         for jg in range(4):
             if tau < 3:
+                lp = tau
                 a, l = (1, jg) if jg < 3 else (0, 0)
+            elif tau == 3:
+                a, l, lp = ((0, 1, 0), (0, 1, 1), (0, 1, 2), (0, 2, 0))[jg]
             elif jg < 2:
-                a, l = 0, jg + 1
+                a, l, lp = 0, 2, jg + 1
             else:
                 continue
             d = D[tau, :, jg]
