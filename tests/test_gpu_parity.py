@@ -148,3 +148,53 @@ def test_ap_extreme_distortions(golden, name, APst):
             assert np.max(err[..., near]) < TOL, (i, n, qs[i])
             assert np.max(err) < 1e-5, (i, n, qs[i])
     eng.close()
+
+
+def test_batch_position_and_size_independence(golden):
+    """A cosmology's result must not depend on the batch it sits in: 70 seeded draws in one call (two lane groups of the
+    anti-diagonal kernel, a ragged last one) against the same draws evaluated alone and in small groups; plus the
+    size-independent properties of the path: P_l is linear in the bias vector and the templates do not depend on it."""
+    g = golden("caseE")
+    B = 70
+    draws = synth.draw_batch(B, z=0.7)
+    eng = make_engine(g, True, True, max_batch=B)
+    full = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"])
+    for sl in (slice(0, 1), slice(63, 65), slice(69, 70), slice(17, 40)):
+        part = eng.eval_batch(draws["Pin"][sl], draws["f"][sl], draws["DA"][sl], draws["H"][sl])
+        assert np.array_equal(part, full[sl]), sl  # same kernels, same order of operations: bit-identical
+    # linearity of the bias contraction
+    rng = np.random.default_rng(3)
+    b1, b2 = rng.normal(size=(B, 24)), rng.normal(size=(B, 24))
+    _, p1 = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias=b1)
+    _, p2 = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias=b2)
+    t3, p3 = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias=2.0 * b1 - 0.5 * b2)
+    assert np.array_equal(t3, full)
+    scale = np.max(np.abs(p1) + np.abs(p2), axis=-1, keepdims=True)
+    assert np.max(np.abs(p3 - (2.0 * p1 - 0.5 * p2)) / scale) < 1e-13
+    eng.close()
+
+
+def test_c_abi_error_paths(golden):
+    """Errors come back as status 1 + eftb_last_error (raised as EftbError by the ctypes layer), never as a crash."""
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseA")
+    eng = make_engine(g, False, False, max_batch=2)
+    with pytest.raises(L.EftbError, match="batch"):
+        eng.run(L.S_PREP, 3)  # larger than max_batch
+    with pytest.raises(L.EftbError, match="with_resum"):
+        eng.run(L.S_CF, 1)  # stage of a feature the engine was built without
+    with pytest.raises(L.EftbError, match="with_ap"):
+        eng.run(L.S_AP, 1)
+    with pytest.raises(L.EftbError, match="PROJECT"):
+        eng.run(L.S_PROJECT, 1)  # no pipeline operator registered
+    with pytest.raises(L.EftbError):
+        eng.put("PIN", np.zeros(10 * 200 + 1))  # beyond the buffer
+    with pytest.raises(L.EftbError, match="not used|expects"):
+        eng._set("H", np.zeros(4))  # table of a disabled feature / wrong size
+    # the engine is still usable afterwards
+    eng.load_inputs(g["Pin"], float(g["f"]))
+    eng.run(L.S_PREP | L.S_LOOPS)
+    assert relerr(eng.get("P22", (28, g["k"].size)), g["pscf_P22"]) < TOL
+    eng.close()
