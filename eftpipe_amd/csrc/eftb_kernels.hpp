@@ -921,38 +921,64 @@ __global__ __launch_bounds__(256) void resum_sum_kernel(int Nk, int Nl, int nchu
 //
 // spline_kernel: the knot derivatives are  s = A^-1 R y  with A the (constant) not-a-knot tridiagonal matrix;
 // A^-1 R decays like 0.27^|i-j|, so the host ships it as a band of half-width SPL_HB (truncation < 1e-18,
-// checked in tests) and the solve becomes a fully parallel, coalesced banded mat-vec.  Output: YS[series][i] = (y_i, s_i),
-// the Hermite data of the piecewise cubic on [k_i, k_i+1] (half the bytes of power-form coefficients).
+// checked in tests) and the solve becomes a banded matrix product.  Output: YS[series][i] = (y_i, s_i), the Hermite data of
+// the piecewise cubic on [k_i, k_i+1] (half the bytes of power-form coefficients).
 // ------------------------------------------------------------------------------------------------
 constexpr int SPL_HB = 32;
 
+// Matrix-core form: S[series][i] = sum_j y[series][j] BandT[j][i] with the band as the (register-resident) B operand.
+// Workgroup = 4 waves = 64 knots; wave q owns the 16-knot tile i0 + 16 q and needs the inputs j in [tile - 32, tile + 48): 20
+// K-steps whose 20 B fragments are loaded once and reused for every series.  The y window of 16 series x 128 knots goes
+// through LDS (register-prefetched one group ahead); one group of 16 series = 20 MFMAs per wave.
+constexpr int SPL_W = 128, SPL_LD = SPL_W + 2;  // staged window (64 knots + 2 x 32 halo), LDS row stride (conflict-free b64 reads)
+
 __global__ __launch_bounds__(256) void spline_kernel(int Nk, int nseries, const double* __restrict__ T, const double* __restrict__ band,
                                                      double* __restrict__ YS) {
-    // lane <-> knot: its band row stays in registers while the workgroup sweeps its share of the series; the y window of
-    // each series goes through LDS (double-buffered, one barrier per series).  Output: (y_i, s_i) pairs.
-    __shared__ double ys[2][256 + 2 * SPL_HB];
-    const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
-    double bnd[2 * SPL_HB + 1];
+    __shared__ double ys[16 * SPL_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int w0 = blockIdx.x * 64 - SPL_HB;      // first knot of the staged window
+    const int it0 = blockIdx.x * 64 + 16 * wave;  // this wave's output tile
+    // B fragments: K-step t, lane (g, r): weight of input j = it0 - 32 + 4 t + g for output knot i = it0 + r, i.e. band[d][i], d = 4 t + g - r
+    double bf[20];
 #pragma unroll
-    for (int d = 0; d <= 2 * SPL_HB; ++d) bnd[d] = i < Nk ? band[(size_t)d * Nk + i] : 0.0;
-    const int per = (nseries + gridDim.y - 1) / gridDim.y;
-    const int s0 = blockIdx.y * per, s1 = min(nseries, s0 + per);
-    for (int s = s0; s < s1; ++s) {
-        double* buf = ys[(s - s0) & 1];
-        const double* y = T + (size_t)s * Nk;
-        for (int e = threadIdx.x; e < 256 + 2 * SPL_HB; e += 256) {
-            const int jj = i0 - SPL_HB + e;
-            buf[e] = (jj >= 0 && jj < Nk) ? y[jj] : 0.0;
+    for (int t = 0; t < 20; ++t) {
+        const int d = 4 * t + g - r, i = it0 + r;
+        bf[t] = (d >= 0 && d <= 2 * SPL_HB && i < Nk) ? band[(size_t)d * Nk + i] : 0.0;
+    }
+    const int ngroups = (nseries + 15) / 16;
+    const int per = (ngroups + gridDim.y - 1) / gridDim.y;
+    const int g0 = blockIdx.y * per, g1 = min(ngroups, g0 + per);
+    // staging: 16 series x 128 knots = 2048 values, 8 per thread (series = e / 128, knot = e % 128: coalesced rows)
+    double pre[8];
+    auto fetch = [&](int grp) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u, sr = e >> 7, jj = w0 + (e & 127), series = grp * 16 + sr;
+            pre[u] = (series < nseries && jj >= 0 && jj < Nk) ? T[(size_t)series * Nk + jj] : 0.0;
+        }
+    };
+    if (g0 < g1) fetch(g0);
+    for (int grp = g0; grp < g1; ++grp) {
+        __syncthreads();  // the previous group's window has been consumed
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            ys[(e >> 7) * SPL_LD + (e & 127)] = pre[u];
         }
         __syncthreads();
-        double a0 = 0.0, a1 = 0.0;
+        if (grp + 1 < g1) fetch(grp + 1);
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        const double* yr = ys + r * SPL_LD + 16 * wave + g;  // A operand: series r, input j = it0 - 32 + 4 t + g -> window offset 16 wave + 4 t + g
 #pragma unroll
-        for (int d = 0; d + 1 <= 2 * SPL_HB; d += 2) {
-            a0 = fma(bnd[d], buf[threadIdx.x + d], a0);
-            a1 = fma(bnd[d + 1], buf[threadIdx.x + d + 1], a1);
+        for (int t = 0; t < 20; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[4 * t], bf[t], acc, 0, 0, 0);
+        // D: rows (series) g + 4 q, column (knot) r
+        const int i = it0 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sr = g + 4 * q, series = grp * 16 + sr;
+            if (series < nseries && i < Nk)
+                *reinterpret_cast<double2*>(YS + ((size_t)series * Nk + i) * 2) = make_double2(ys[sr * SPL_LD + 16 * wave + SPL_HB + r], acc[q]);
         }
-        a0 = fma(bnd[2 * SPL_HB], buf[threadIdx.x + 2 * SPL_HB], a0);
-        if (i < Nk) *reinterpret_cast<double2*>(YS + ((size_t)s * Nk + i) * 2) = make_double2(buf[threadIdx.x + SPL_HB], a0 + a1);
     }
 }
 
@@ -1042,7 +1068,7 @@ __global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* _
 // neighbouring slots, so the ranges tile [0, nmu) exactly).  Knots and roots sit in LDS; the four waves' partial sums
 // are added through LDS in a fixed order.
 template <int NL, int NR, int RS>
-__global__ __launch_bounds__(256) void ap_apply_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+__global__ __launch_bounds__(256, 2) void ap_apply_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
                                                        const double* __restrict__ Hw, const double* __restrict__ fid,
                                                        const double* __restrict__ mu, const double* __restrict__ PS,
                                                        const double* __restrict__ ROOT, const double* __restrict__ T,
@@ -1098,9 +1124,10 @@ __global__ __launch_bounds__(256) void ap_apply_kernel(int Nk, int nmu, const do
         const double* pa = ps + (size_t)ja * NS;
         const double* pb = ps + (size_t)jb * NS;
         const double* cw = YS + ((size_t)w * NL * NROW * Nk + i) * 2;
-        if constexpr (NRT <= 3) {
-            // few rows per lane: every load of the slot is issued up front (one memory round trip for the prefix sums, one
-            // for the spline data) instead of a pair of round trips per l'
+        // memory round trips are what this kernel waits for (PMC: 75 % of the wave cycles): the prefix sums of all l' are
+        // fetched in one batch, and the spline data of l' + 1 is in flight while l' is being accumulated
+        double ms[NL][NL][4];
+        {
             double4 a4[NL][NL], b4[NL][NL];
 #pragma unroll
             for (int lp = 0; lp < NL; ++lp)
@@ -1109,64 +1136,41 @@ __global__ __launch_bounds__(256) void ap_apply_kernel(int Nk, int nmu, const do
                     b4[lp][l] = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
                     a4[lp][l] = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
                 }
-            double2 ya[NL][NRT], yb[NL][NRT];
 #pragma unroll
             for (int lp = 0; lp < NL; ++lp)
-#pragma unroll
-                for (int r = 0; r < NRT; ++r) {
-                    const double2* cp = reinterpret_cast<const double2*>(cw + ((size_t)lp * NROW + min(rbase + r, NR - 1)) * Nk * 2);
-                    ya[lp][r] = cp[0];
-                    yb[lp][r] = cp[1];
-                }
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                double ms[NL][4];
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const double d0 = b4[lp][l].x - a4[lp][l].x, d1 = b4[lp][l].y - a4[lp][l].y;
                     const double d2 = b4[lp][l].z - a4[lp][l].z, d3 = b4[lp][l].w - a4[lp][l].w;
-                    ms[l][0] = d0;
-                    ms[l][1] = fma(c10, d0, c11 * d1);
-                    ms[l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
-                    ms[l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+                    ms[lp][l][0] = d0;
+                    ms[lp][l][1] = fma(c10, d0, c11 * d1);
+                    ms[lp][l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
+                    ms[lp][l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
                 }
+        }
+        double2 ya[2][NRT], yb[2][NRT];
+        auto fetch = [&](int lp, int buf) {
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) {
-                    const double2 ca = ya[lp][r], cb = yb[lp][r];
-                    const double sl = (cb.x - ca.x) * ih;
-                    const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
-                    const double c2 = (sl - ca.y) * ih - c3 * h;
-#pragma unroll
-                    for (int l = 0; l < NL; ++l)
-                        acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], c2, fma(ms[l][3], c3, acc[l][r]))));
-                }
+            for (int r = 0; r < NRT; ++r) {
+                const double2* cp = reinterpret_cast<const double2*>(cw + ((size_t)lp * NROW + min(rbase + r, NR - 1)) * Nk * 2);
+                ya[buf][r] = cp[0];  // (y_i, s_i)
+                yb[buf][r] = cp[1];  // (y_i+1, s_i+1)
             }
-        } else {
-    #pragma unroll 1
-            for (int lp = 0; lp < NL; ++lp) {  // a real loop: keeps hipcc from hoisting all NL*NRT row loads (spills)
-                double ms[NL][4];
-    #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const double4 b4 = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
-                    const double4 a4 = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
-                    const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
-                    ms[l][0] = d0;
-                    ms[l][1] = fma(c10, d0, c11 * d1);
-                    ms[l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
-                    ms[l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
-                }
-                const double* cl = cw + (size_t)lp * NROW * Nk * 2;
-    #pragma unroll
-                for (int r = 0; r < NRT; ++r) {
-                    const double2* cp = reinterpret_cast<const double2*>(cl + (size_t)min(rbase + r, NR - 1) * Nk * 2);
-                    const double2 ca = cp[0], cb = cp[1];  // (y_i, s_i), (y_i+1, s_i+1) -> power form on [k_i, k_i+1]
-                    const double sl = (cb.x - ca.x) * ih;
-                    const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
-                    const double c2 = (sl - ca.y) * ih - c3 * h;
-    #pragma unroll
-                    for (int l = 0; l < NL; ++l)
-                        acc[l][r] = fma(ms[l][0], ca.x, fma(ms[l][1], ca.y, fma(ms[l][2], c2, fma(ms[l][3], c3, acc[l][r]))));
-                }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            if (lp + 1 < NL) fetch(lp + 1, (lp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the arithmetic that consumes the previous buffer
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const double2 ca = ya[lp & 1][r], cb = yb[lp & 1][r];  // -> power form on [k_i, k_i+1]
+                const double sl = (cb.x - ca.x) * ih;
+                const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
+                const double c2 = (sl - ca.y) * ih - c3 * h;
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+                    acc[l][r] = fma(ms[lp][l][0], ca.x, fma(ms[lp][l][1], ca.y, fma(ms[lp][l][2], c2, fma(ms[lp][l][3], c3, acc[l][r]))));
             }
         }
     }

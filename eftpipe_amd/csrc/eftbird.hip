@@ -363,8 +363,8 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
         const int nseries = B * Nl * NROW;
         {
-            const int kt = (Nk + 255) / 256;
-            const int ysplit = std::max(1, std::min(nseries, 2048 / kt));  // ~8 workgroups per CU, each sweeping nseries/ysplit series
+            const int kt = (Nk + 63) / 64;
+            const int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
             hipLaunchKernelGGL(spline_kernel, dim3(kt, ysplit), dim3(256), 0, st, Nk, nseries, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPBAND), e->SD);
         }
         // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
