@@ -418,52 +418,45 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
                                                       const double* __restrict__ lct, const double* __restrict__ l22,
                                                       const double* __restrict__ l13, const int* __restrict__ grp,
                                                       double* __restrict__ T) {
-    // one lane = one k of one cosmology: reads the 28 + 10 loop pieces once and writes all Nl x 24 template rows
-    __shared__ double cf[3 * 38];  // f^power * mu-weight per (l, piece)
-    __shared__ double p0[38];      // the pieces at the first k (shot-noise subtraction, reference pybird.py:799-800)
+    // one lane = one k of one (cosmology, multipole): reads the 28 + 10 loop pieces and writes the 24 template rows of its l
+    __shared__ double cf[38];  // f^power * mu-weight per piece
+    __shared__ double p0[38];  // the pieces at the first k (shot-noise subtraction, reference pybird.py:799-800)
     __shared__ int gi[38];
-    const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
     const double f = fgrow[w];
-    for (int e = threadIdx.x; e < Nl * 38; e += blockDim.x) {
-        const int l = e / 38, b = e % 38;
-        cf[e] = ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
-    }
     for (int b = threadIdx.x; b < 38; b += blockDim.x) {
+        cf[b] = ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
         p0[b] = b < 28 ? P22[((size_t)w * 28 + b) * Nk] : P13[((size_t)w * 10 + (b - 28)) * Nk];
         gi[b] = grp[2 * b];
     }
     __syncthreads();
     if (k >= Nk) return;
     const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
-    double acc[3][12];
+    double d[38];
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int b = 0; b < 38; ++b) d[b] = (b < 28 ? P22[((size_t)w * 28 + b) * Nk + k] : P13[((size_t)w * 10 + (b - 28)) * Nk + k]) - p0[b];
+    double acc[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) acc[l][i] = 0.0;
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+#pragma unroll
     for (int b = 0; b < 38; ++b) {
-        const double d = (b < 28 ? P22[((size_t)w * 28 + b) * Nk + k] : P13[((size_t)w * 10 + (b - 28)) * Nk + k]) - p0[b];
         const int g = gi[b];  // workgroup-uniform
+        const double v = cf[b] * d[b];
 #pragma unroll
-        for (int i = 0; i < 12; ++i)
-            if (g == i) {
-#pragma unroll
-                for (int l = 0; l < 3; ++l)
-                    if (l < Nl) acc[l][i] = fma(cf[l * 38 + b], d, acc[l][i]);
-            }
+        for (int i = 0; i < 12; ++i) acc[i] += g == i ? v : 0.0;
     }
-    for (int l = 0; l < Nl; ++l) {
-        double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
+    double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) t[(size_t)r * Nk] = l11[l * 3 + r] * p11;
+    for (int r = 0; r < 3; ++r) t[(size_t)r * Nk] = l11[l * 3 + r] * p11;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) t[(size_t)(3 + r) * Nk] = lct[l * 6 + r] * kv * kv * p11;
+    for (int r = 0; r < 6; ++r) t[(size_t)(3 + r) * Nk] = lct[l * 6 + r] * kv * kv * p11;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) t[(size_t)(9 + i) * Nk] = l == 0 ? acc[0][i] : (l == 1 ? acc[1][i] : acc[2][i]);
-        t[(size_t)21 * Nk] = l == 0 ? 1.0 : 0.0;
-        t[(size_t)22 * Nk] = l == 0 ? kv * kv : 0.0;
-        t[(size_t)23 * Nk] = l == 1 ? kv * kv : 0.0;
-    }
+    for (int i = 0; i < 12; ++i) t[(size_t)(9 + i) * Nk] = acc[i];
+    t[(size_t)21 * Nk] = l == 0 ? 1.0 : 0.0;
+    t[(size_t)22 * Nk] = l == 0 ? kv * kv : 0.0;
+    t[(size_t)23 * Nk] = l == 1 ? kv * kv : 0.0;
 }
+
 
 // Cloopl[w][l][12][80] from CC[w][Nl*38][80] (C22 then C13; reference pybird.py:752-753, 805-846)
 __global__ __launch_bounds__(128) void regroup_cf_kernel(int Nl, const double* __restrict__ fgrow, const double* __restrict__ CC,

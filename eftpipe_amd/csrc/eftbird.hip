@@ -317,7 +317,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         }
     }
     if (mask & EFTB_S_REGROUP) {
-        hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
+        hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
                            b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
                            tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_TEMPL]);
         if (c.with_resum)
