@@ -151,10 +151,10 @@ def main():
         NIR, NA, NKLOW = 16, 3, 7
         alg_resum = 8.0 * NA * (NL * 14 * 2 * NIR) * 193 * (NK - NKLOW) * B
         alg_p22 = 8.0 * 28 * NK * NPOW**2 * B
-        # flops the kernel actually executes per launch: per 16 (k, s) points 12 MFMAs (6 row tiles x 2 K-steps, 2048 flops each) and
+        # flops the kernel actually executes per launch: per 16 (k, s) points 10 MFMAs (5 row tiles x 2 K-steps, 2048 flops each) and
         # ~125 FP64 vector instructions per lane (basis polynomials, W, contraction with the 14 C columns per l')
         pts = B * (NK - NKLOW) * 80
-        exe_resum = pts / 16.0 * (12 * 2048.0 + 125 * 64 * 2.0)
+        exe_resum = pts / 16.0 * (10 * 2048.0 + 125 * 64 * 2.0)
         achieved = alg_resum / (ms_resum * 1e-3) / 1e12
         try:
             measured_peak = mfma_f64_peak(cp.local_rank)
