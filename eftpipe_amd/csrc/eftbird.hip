@@ -48,7 +48,7 @@ struct eftb_engine {
     double* buf[EFTB_B_COUNT] = {nullptr};
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
-    double *SD = nullptr, *Talt = nullptr, *part = nullptr, *V = nullptr;
+    double *SD = nullptr, *Talt = nullptr, *part = nullptr;
     double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][80][8], per-s records [B][NS][48]
     double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
@@ -587,7 +587,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->V, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered}) if (ev) (void)hipEventDestroy(ev);
