@@ -31,11 +31,11 @@ class Config(C.Structure):
 TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD EXP22 EXPC MLJ LINVEC SYNK SYNS LINK LINS L11 LCT L22 L13 GRP "
           "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID").split()
 T = {n: i for i, n in enumerate(TABLES)}
-BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF".split()
+BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF GROWS LOGP".split()
 B = {n: i for i, n in enumerate(BUFFERS)}
-S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22, K_RESUM = (1 << i for i in range(11))
+S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22, K_RESUM, S_LOGP = (1 << i for i in range(12))
 
-EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_destroy eftb_add_operator eftb_apply_operator "
+EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_set_likelihood eftb_destroy eftb_add_operator eftb_apply_operator "
            "eftb_set_pipeline_operator eftb_set_template_dims eftb_put eftb_get eftb_buffer_size eftb_run "
            "eftb_sync eftb_run_timed eftb_eval_batch eftb_comm_unique_id eftb_comm_init eftb_gather_plk "
            "eftb_mfma_f64_peak eftb_last_error eftb_version").split()
@@ -57,6 +57,7 @@ def load():
     lib.eftb_set_table.argtypes, lib.eftb_set_table.restype = [vp, i32, vp, sz], i32
     lib.eftb_finalize.argtypes, lib.eftb_finalize.restype = [vp], i32
     lib.eftb_set_option.argtypes, lib.eftb_set_option.restype = [vp, i32, i32], i32
+    lib.eftb_set_likelihood.argtypes, lib.eftb_set_likelihood.restype = [vp, i32, C.POINTER(C.c_int32), dp, dp, i32, dp, dp], i32
     lib.eftb_add_operator.argtypes, lib.eftb_add_operator.restype = [vp, i32, i32, i32, i32, dp, C.POINTER(C.c_int)], i32
     lib.eftb_apply_operator.argtypes, lib.eftb_apply_operator.restype = [vp, i32, i32], i32
     lib.eftb_set_pipeline_operator.argtypes, lib.eftb_set_pipeline_operator.restype = [vp, i32], i32

@@ -1204,6 +1204,141 @@ __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Analytically marginalised log-posterior (reference marginal.py:79-203, likelihood.py:483-549).
+// One workgroup = one walker.  With the coefficient rows R[g][24] (g = 0: the model at zero Gaussian parameters, g >= 1:
+// its derivative with respect to Gaussian parameter g; parambasis.gaussian_rows) and the data-vector index map
+//     V[g][a] = sum_r R[g][r] T[l(a)][r][x(a)]          (V[0] -= data: the residual),
+//     U = C^-1 V,   G = V U^T   ((nG+1)^2 numbers),
+//     F2 = G[1:,1:] + sigma^-1,  F1 = -G[1:,0] + sigma^-1 mu,  F0 = G[0,0] + mu sigma^-1 mu,
+//     -2 ln P = -F1 F2^-1 F1 + F0 + ln det(F2 / 2 pi)   (LU with partial pivoting; the last term dropped with the Jeffreys option),
+//     full chi2 at the best-fit Gaussian parameters b = F2^-1 F1:  G00 + 2 b.G[1:,0] + b G[1:,1:] b.
+// out[w] = (ln P, full chi2, b[0..MARG_MAXG)).  det F2 <= 0 (reference: RuntimeError "det of F2ij <= 0") gives NaN.
+// ------------------------------------------------------------------------------------------------
+constexpr int MARG_MAXG = 16, MARG_NG1 = MARG_MAXG + 1, MARG_OUT = 2 + MARG_MAXG;
+
+__global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ndata, int nG, int jeffreys, const int* __restrict__ index,
+                                                        const double* __restrict__ data, const double* __restrict__ invcov,
+                                                        const double* __restrict__ mu, const double* __restrict__ sinv,
+                                                        const double* __restrict__ rows, const double* __restrict__ T,
+                                                        double* __restrict__ out) {
+    extern __shared__ double sm[];
+    const int ng1 = nG + 1, w = blockIdx.x, tid = threadIdx.x;
+    double* R = sm;                        // [ng1][24]
+    double* V = R + ng1 * NROW;            // [ng1][ndata]
+    double* U = V + (size_t)ng1 * ndata;   // [ng1][ndata]
+    double* G = U + (size_t)ng1 * ndata;   // [ng1][ng1]
+    for (int e = tid; e < ng1 * NROW; e += 256) R[e] = rows[(size_t)w * MARG_NG1 * NROW + e];
+    __syncthreads();
+    for (int a = tid; a < ndata; a += 256) {
+        const int l = index[a] / nx, x = index[a] % nx;
+        const double* t = T + ((size_t)w * nl + l) * NROW * nx + x;
+        double tv[NROW];
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) tv[r] = t[(size_t)r * nx];
+        for (int g = 0; g < ng1; ++g) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < NROW; r += 2) {
+                s0 = fma(R[g * NROW + r], tv[r], s0);
+                s1 = fma(R[g * NROW + r + 1], tv[r + 1], s1);
+            }
+            V[(size_t)g * ndata + a] = s0 + s1 - (g == 0 ? data[a] : 0.0);
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < ndata; b += 256) {  // U[g][b] = sum_a C^-1[a][b] V[g][a]  (symmetric: column reads are coalesced)
+        double u[MARG_NG1];
+#pragma unroll
+        for (int g = 0; g < MARG_NG1; ++g) u[g] = 0.0;
+        for (int a = 0; a < ndata; ++a) {
+            const double c = invcov[(size_t)a * ndata + b];
+#pragma unroll
+            for (int g = 0; g < MARG_NG1; ++g)
+                if (g < ng1) u[g] = fma(c, V[(size_t)g * ndata + a], u[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < MARG_NG1; ++g)
+            if (g < ng1) U[(size_t)g * ndata + b] = u[g];
+    }
+    __syncthreads();
+    for (int e = tid; e < ng1 * ng1; e += 256) {
+        const int i = e / ng1, j = e % ng1;
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = 0;
+        for (; b + 4 <= ndata; b += 4)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] = fma(V[(size_t)i * ndata + b + q], U[(size_t)j * ndata + b + q], s[q]);
+        for (; b < ndata; ++b) s[0] = fma(V[(size_t)i * ndata + b], U[(size_t)j * ndata + b], s[0]);
+        G[e] = (s[0] + s[1]) + (s[2] + s[3]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // LU with partial pivoting, as numpy's slogdet / solve (LAPACK getrf) in the reference: F2 may be ill-conditioned with a
+        // flat prior, where a Cholesky factorisation can lose positivity to rounding although det F2 > 0
+        double A[MARG_MAXG][MARG_MAXG], y[MARG_MAXG], F1[MARG_MAXG];
+        int piv[MARG_MAXG];
+        double logdet = 0.0, F0 = G[0];
+        int sign = 1;
+        for (int i = 0; i < nG; ++i) {
+            F1[i] = -G[(i + 1) * ng1] + sinv[i] * mu[i];
+            F0 = fma(mu[i] * sinv[i], mu[i], F0);
+            for (int j = 0; j < nG; ++j) A[i][j] = 0.5 * (G[(i + 1) * ng1 + j + 1] + G[(j + 1) * ng1 + i + 1]) + (i == j ? sinv[i] : 0.0);
+        }
+        for (int c = 0; c < nG; ++c) {
+            int p = c;
+            for (int i = c + 1; i < nG; ++i)
+                if (fabs(A[i][c]) > fabs(A[p][c])) p = i;
+            piv[c] = p;
+            if (p != c) {
+                sign = -sign;
+                for (int j = 0; j < nG; ++j) {
+                    const double t = A[c][j];
+                    A[c][j] = A[p][j];
+                    A[p][j] = t;
+                }
+            }
+            const double d = A[c][c];
+            if (d < 0.0) sign = -sign;
+            if (d == 0.0 || d != d) sign = 0;
+            logdet += log(fabs(d));
+            for (int i = c + 1; i < nG; ++i) {
+                const double m = A[i][c] / d;
+                A[i][c] = m;
+                for (int j = c + 1; j < nG; ++j) A[i][j] = fma(-m, A[c][j], A[i][j]);
+            }
+        }
+        const bool ok = sign > 0;
+        logdet -= nG * 1.8378770664093453;  // ln(2 pi) per dimension: ln det(F2 / 2 pi)
+        for (int i = 0; i < nG; ++i) y[i] = F1[i];
+        for (int c = 0; c < nG; ++c) {  // apply the row exchanges, then L y = P F1, U b = y
+            const double t = y[c];
+            y[c] = y[piv[c]];
+            y[piv[c]] = t;
+        }
+        for (int i = 0; i < nG; ++i)
+            for (int q = 0; q < i; ++q) y[i] = fma(-A[i][q], y[q], y[i]);
+        for (int i = nG - 1; i >= 0; --i) {
+            double t = y[i];
+            for (int q = i + 1; q < nG; ++q) t = fma(-A[i][q], y[q], t);
+            y[i] = t / A[i][i];  // y now holds the best-fit Gaussian parameters b = F2^-1 F1
+        }
+        double quad = 0.0;
+        for (int i = 0; i < nG; ++i) quad = fma(F1[i], y[i], quad);  // F1 F2^-1 F1
+        double full = G[0];
+        for (int i = 0; i < nG; ++i) {
+            full = fma(2.0 * y[i], G[(i + 1) * ng1], full);
+            for (int j = 0; j < nG; ++j) full = fma(y[i] * y[j], G[(i + 1) * ng1 + j + 1], full);
+        }
+        const double chi2 = -quad + F0 + (jeffreys ? 0.0 : logdet);
+        double* o = out + (size_t)w * MARG_OUT;
+        const double nan = __longlong_as_double(0x7ff8000000000000LL);
+        o[0] = ok ? -0.5 * chi2 : nan;
+        o[1] = ok ? full : nan;
+        for (int i = 0; i < MARG_MAXG; ++i) o[2 + i] = i < nG ? (ok ? y[i] : nan) : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FP64 MFMA issue-rate microbenchmark (roofline denominator): NACC independent accumulator chains.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(int iters, double* sink) {

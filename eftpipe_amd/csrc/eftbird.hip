@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +61,10 @@ struct eftb_engine {
     struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; };
     std::vector<Op> ops;
     int pipeline_op = -1;
+    // likelihood of the LOGP stage (eftb_set_likelihood)
+    int like_ndata = 0, like_nG = 0, jeffreys = 0;
+    int* like_index = nullptr;
+    double *like_data = nullptr, *like_invcov = nullptr, *like_mu = nullptr, *like_sinv = nullptr;
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
@@ -175,6 +180,8 @@ static size_t need_buffer_elems(const eftb_config& c, int id) {
         case EFTB_B_BIAS: return B * NROW;
         case EFTB_B_PLK: return B * c.Nl * c.Nk;
         case EFTB_B_COEF: return B * 2 * NCH;
+        case EFTB_B_GROWS: return B * MARG_NG1 * NROW;
+        case EFTB_B_LOGP: return B * MARG_OUT;
     }
     return 0;
 }
@@ -404,6 +411,12 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (e->pipeline_op < 0) return fail("eftb_run: stage PROJECT needs eftb_set_pipeline_operator");
         if (int rc = launch_operator(e, e->pipeline_op, B)) return rc;
     }
+    if (mask & EFTB_S_LOGP) {
+        if (!e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
+        const size_t lds = ((size_t)(e->like_nG + 1) * (NROW + 2 * e->like_ndata + e->like_nG + 1)) * sizeof(double);
+        hipLaunchKernelGGL(marg_logp_kernel, dim3(B), dim3(256), lds, st, e->cur_nl, e->cur_nx, e->like_ndata, e->like_nG, e->jeffreys, e->like_index,
+                           e->like_data, e->like_invcov, e->like_mu, e->like_sinv, b[EFTB_B_GROWS], b[EFTB_B_TEMPL], b[EFTB_B_LOGP]);
+    }
     if (mask & EFTB_S_REDUCE)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],
                            b[EFTB_B_TEMPL], b[EFTB_B_PLK]);
@@ -516,6 +529,7 @@ int eftb_finalize(eftb_engine* e) {
     }
     // opt in to the large dynamic LDS tiles
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&marg_logp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define AP_LDS(NLV, NRV, RSV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_apply_kernel<NLV, NRV, RSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, 21, 7); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3); AP_LDS(3, NROW, 7);
     AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
@@ -576,8 +590,42 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
     if (!e) return fail("eftb_set_option: null engine");
     switch (option) {
         case EFTB_O_AP_STOCHASTIC: e->c.ap_stochastic = value ? 1 : 0; return 0;
+        case EFTB_O_JEFFREYS: e->jeffreys = value ? 1 : 0; return 0;
     }
     return fail("eftb_set_option: unknown option %d", option);
+}
+
+int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov, int nG, const double* mu,
+                        const double* sigma_inv) {
+    if (!e || !index || !data || !invcov || !mu || !sigma_inv) return fail("eftb_set_likelihood: null argument");
+    if (nG < 1 || nG > MARG_MAXG) return fail("eftb_set_likelihood: nG=%d outside [1, %d]", nG, MARG_MAXG);
+    const size_t lds = ((size_t)(nG + 1) * (NROW + 2 * (size_t)ndata + nG + 1)) * sizeof(double);
+    if (ndata < 1 || lds > 160 * 1024) return fail("eftb_set_likelihood: ndata=%d does not fit the 160 KB LDS working set with nG=%d", ndata, nG);
+    const int npts = e->cur_nl * e->cur_nx;
+    for (int a = 0; a < ndata; ++a)
+        if (index[a] < 0 || index[a] >= npts)
+            return fail("eftb_set_likelihood: index[%d]=%d outside the current template block [%d][24][%d]", a, index[a], e->cur_nl, e->cur_nx);
+    for (int a = 0; a < ndata; ++a)
+        for (int b2 = 0; b2 < a; ++b2) {
+            const double x = invcov[(size_t)a * ndata + b2], y = invcov[(size_t)b2 * ndata + a];
+            if (fabs(x - y) > 1e-12 * (fabs(x) + fabs(y)) + 1e-300) return fail("eftb_set_likelihood: invcov is not symmetric at (%d, %d)", a, b2);
+        }
+    HIPCHK(hipSetDevice(e->c.device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv}) if (p) (void)hipFree(p);
+    HIPCHK(hipMalloc(&e->like_index, ndata * sizeof(int)));
+    HIPCHK(hipMalloc(&e->like_data, ndata * sizeof(double)));
+    HIPCHK(hipMalloc(&e->like_invcov, (size_t)ndata * ndata * sizeof(double)));
+    HIPCHK(hipMalloc(&e->like_mu, MARG_MAXG * sizeof(double)));
+    HIPCHK(hipMalloc(&e->like_sinv, MARG_MAXG * sizeof(double)));
+    HIPCHK(hipMemcpy(e->like_index, index, ndata * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->like_data, data, ndata * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->like_invcov, invcov, (size_t)ndata * ndata * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->like_mu, mu, nG * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->like_sinv, sigma_inv, nG * sizeof(double), hipMemcpyHostToDevice));
+    e->like_ndata = ndata;
+    e->like_nG = nG;
+    return 0;
 }
 
 void eftb_destroy(eftb_engine* e) {
@@ -589,6 +637,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& p : e->buf) if (p) (void)hipFree(p);
     for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
+    for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered}) if (ev) (void)hipEventDestroy(ev);
     if (e->side) (void)hipStreamDestroy(e->side);

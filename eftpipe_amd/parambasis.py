@@ -71,3 +71,57 @@ def reduce_Plk(bird, bsA, bsB=None, es=(0.0, 0.0, 0.0)):
         Pst=np.einsum("b,lbx->lx", bst, bird.Pstl[:No]),
         Picc=bird.Picc[:No],
     )
+
+
+# ----------------------------------------------------------------------------- Gaussian table
+GAUSSIAN = ("b3", "cct", "cr1", "cr2")
+STOCHASTIC = ("ce0", "cemono", "cequad")
+
+
+def gaussian_params(prefix="", cross_prefix=()):
+    """Names of the analytically marginalisable parameters, in table order (reference parambasis.py:209-223)."""
+    if cross_prefix:
+        return [x + p for x in cross_prefix for p in GAUSSIAN] + [prefix + p for p in STOCHASTIC]
+    return [prefix + p for p in GAUSSIAN + STOCHASTIC]
+
+
+def gaussian_rows(f, ngA, ngB=None, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None, ndB=None):
+    """Coefficient rows over the 24 template rows (P11l[3], Pctl[6], Ploopl[12], Pstl[3]) of
+
+        row 0        P_NG: the model with every Gaussian parameter at 0 (reference likelihood.py:524-549 via reduce_Plk)
+        rows 1..nG   dP/d(gaussian parameter) in the order of ``gaussian_params`` (reference parambasis.py:249-316)
+
+    for the non-Gaussian parameters ngA = (b1, b2, b4) [and ngB for a cross spectrum].  Everything downstream of the
+    templates is linear in these rows, so the device builds P_NG and P_G with one small contraction per walker."""
+    cross = ngB is not None
+    kmB = kmA if kmB is None else kmB
+    krB = krA if krB is None else krB
+    ndB = ndA if ndB is None else ndB
+    b1A, b2A, b4A = ngA
+    b1B, b2B, b4B = ngB if cross else ngA
+    bsA = [b1A, b2A, 0.0, b4A, 0.0, 0.0, 0.0]
+    bsB = [b1B, b2B, 0.0, b4B, 0.0, 0.0, 0.0] if cross else None
+    rows = [bias_row(f, bsA, bsB, (0.0, 0.0, 0.0), kmA=kmA, krA=krA, ndA=ndA, kmB=kmB, krB=krB, ndB=ndB)]
+    CT, LOOP, ST = 3, 9, 21  # first template row of Pctl, Ploopl, Pstl
+
+    def row(pairs):
+        r = np.zeros(24)
+        for i, c in pairs:
+            r[i] = c
+        return r
+
+    if cross:
+        for b1o, km, kr in ((b1B, kmA, krA), (b1A, kmB, krB)):
+            rows.append(row([(LOOP + 3, 0.5), (LOOP + 7, 0.5 * b1o)]))
+            rows.append(row([(CT + 0, b1o / km**2), (CT + 3, f / km**2)]))
+            rows.append(row([(CT + 1, b1o / kr**2), (CT + 4, f / kr**2)]))
+            rows.append(row([(CT + 2, b1o / kr**2), (CT + 5, f / kr**2)]))
+    else:
+        rows.append(row([(LOOP + 3, 1.0), (LOOP + 7, b1A)]))
+        rows.append(row([(CT + 0, 2.0 * b1A / kmA**2), (CT + 3, 2.0 * f / kmA**2)]))
+        rows.append(row([(CT + 1, 2.0 * b1A / krA**2), (CT + 4, 2.0 * f / krA**2)]))
+        rows.append(row([(CT + 2, 2.0 * b1A / krA**2), (CT + 5, 2.0 * f / krA**2)]))
+    x1 = 0.5 * (1.0 / ndA + 1.0 / ndB)
+    x2 = 0.5 * (1.0 / ndA / kmA**2 + 1.0 / ndB / kmB**2)
+    rows += [row([(ST + 0, x1)]), row([(ST + 1, x2)]), row([(ST + 2, x2)])]
+    return np.stack(rows)

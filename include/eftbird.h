@@ -77,6 +77,8 @@ enum eftb_buffer {
     EFTB_B_BIAS,      /* [B][24]              b11(3), bct(6), bloop(12), bst(3)   parambasis.py:69-126 */
     EFTB_B_PLK,       /* [B][nl][nx]          reduce_Plk(...).sum() without Picc  parambasis.py:128-136 */
     EFTB_B_COEF,      /* [B][2][129]          FFTLog coefficients (independent half, re/im) */
+    EFTB_B_GROWS,     /* [B][17][24]          coefficient rows of P_NG (row 0) and dP/d(gaussian parameter) (rows 1..nG)   parambasis.py:249-316 */
+    EFTB_B_LOGP,      /* [B][18]              marginalised ln P, full chi2 at the best fit, best-fit gaussian parameters  marginal.py:79-140 */
     EFTB_B_COUNT
 };
 
@@ -95,7 +97,8 @@ enum eftb_stage {
     /* single-kernel selectors (profiling / roofline measurement only; need the stage's inputs in place) */
     EFTB_K_P22     = 1 << 8,  /* makeP22 alone: anti-diagonal sums + rows + synthesis */
     EFTB_K_C22     = 1 << 9,  /* makeC22 + makeC13 alone */
-    EFTB_K_RESUM   = 1 << 10  /* the main kernel of Resum.Ps alone (operands of an earlier EFTB_S_RESUM run) */
+    EFTB_K_RESUM   = 1 << 10, /* the main kernel of Resum.Ps alone (operands of an earlier EFTB_S_RESUM run) */
+    EFTB_S_LOGP    = 1 << 11  /* Marginalizable.marginalized_logp on the current template block   marginal.py:79-140 */
 };
 
 int  eftb_create(const eftb_config* cfg, eftb_engine** out);
@@ -105,9 +108,20 @@ void eftb_destroy(eftb_engine* e);
 
 /* Run-time switches that the reference keeps on plugin objects rather than on Common. */
 enum eftb_option {
-    EFTB_O_AP_STOCHASTIC = 0  /* APeffect.APst                                pybird.py:1514, 1618 */
+    EFTB_O_AP_STOCHASTIC = 0, /* APeffect.APst                                pybird.py:1514, 1618 */
+    EFTB_O_JEFFREYS = 1       /* marginalized_logp(jeffreys=True): drop ln det(F2 / 2 pi)   marginal.py:118-121 */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
+
+/* Likelihood of the EFTB_S_LOGP stage.  Replaces, for a batch of walkers on the device,
+ * EFTLike.PNG / PG (likelihood.py:483-549: flatten the multipoles over the masked k bins) and
+ * Marginalizable.marginalized_logp (marginal.py:79-140).  index[a] = l * nx + x selects data point a from the current
+ * template block [nl][24][nx] (after the pipeline operator, if any); data[ndata]; invcov[ndata][ndata] symmetric;
+ * nG <= 16 marginalised parameters with Gaussian prior N(mu[i], sigma_i^2), sigma_inv[i] = 1 / sigma_i^2 (all zero: flat).
+ * Per walker the caller puts the coefficient rows EFTB_B_GROWS (eftpipe_amd.parambasis.gaussian_rows) and reads
+ * EFTB_B_LOGP after eftb_run(..., EFTB_S_LOGP, B). */
+int  eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov,
+                         int nG, const double* mu, const double* sigma_inv);
 
 /* Linear post-AP projections.  Window.Window (window.py:371-415), Binning.transform (binning.py:131-162) and
  * Chained.transform (chained.py:56-68) are linear maps of the template block on the k axis and the multipole

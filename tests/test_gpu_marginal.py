@@ -1,0 +1,91 @@
+"""GPU parity of the marginalised log-posterior stage through the C ABI, against the reference-generated
+fixture tests/golden/marg.npz and the oracle (oracle/marginal.py)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(g, B):
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    nx = g["binned_P11l"].shape[-1]
+    eng = Engine(EngineConfig(Nl=3), max_batch=B)
+    eng.set_template_dims(3, nx)
+    return eng, nx
+
+
+@pytest.mark.parametrize("tag", ["auto", "cross"])
+def test_marginalised_logp_matches_reference(golden, tag):
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index, gaussian_rows
+    from oracle import marginal as M
+
+    g = golden("marg")
+    B = 5
+    eng, nx = _engine(g, B)
+    T = np.concatenate([g["binned_P11l"], g["binned_Pctl"], g["binned_Ploopl"], g["binned_Pstl"]], axis=1)  # [3, 24, nx]
+    f = float(g["f"])
+    co = g[tag + "_co"]
+    ng = dict(zip(g[tag + "_ng_names"], g[tag + "_ng_values"]))
+    ls = list(g["ls"])
+    masks = {l: slice(a, b) for l, (a, b) in zip(ls, g["masks"])}
+    index = data_index(ls, masks, nx)
+    like = MarginalLikelihood(eng, index, g[tag + "_D"], g[tag + "_invcov"], g[tag + "_loc"], g[tag + "_scale"])
+    # walker 0 = the fixture; the others: rescaled templates and shifted b1 (checked against the oracle)
+    scales = 1.0 + 0.1 * np.arange(B)
+    shifts = 0.05 * np.arange(B)
+    templ = np.stack([T * s for s in scales])
+    rows, want = [], []
+    for i in range(B):
+        if tag == "auto":
+            A, Bp = (ng["b1"] + shifts[i], ng["b2"], ng["b4"]), None
+            rows.append(gaussian_rows(f, A, None, *co[:3]))
+        else:
+            A, Bp = (ng["A_b1"] + shifts[i], ng["A_b2"], ng["A_b4"]), (ng["B_b1"], ng["B_b2"], ng["B_b4"])
+            rows.append(gaussian_rows(f, A, Bp, *co))
+        V = np.einsum("gr,lrx->glx", rows[-1], templ[i]).reshape(rows[-1].shape[0], -1)[:, index]
+        want.append(M.marginalized_logp(V[1:], V[0], g[tag + "_D"], g[tag + "_invcov"], g[tag + "_loc"], g[tag + "_scale"], return_best=True))
+    eng.put("TEMPL", templ)
+    logp, full, best = like.logp(np.stack(rows), return_best=True)
+    assert np.isclose(logp[0], g[tag + "_logp"], rtol=1e-10) and np.isclose(full[0], g[tag + "_fullchi2"], rtol=1e-9)
+    assert relerr(best[0][None], g[tag + "_best"][None]) < 1e-8
+    for i in range(B):
+        assert np.isclose(logp[i], want[i][0], rtol=1e-10), i
+        assert np.isclose(full[i], want[i][1], rtol=1e-9), i
+        assert relerr(best[i][None], want[i][2][None]) < 1e-8, i
+    # Jeffreys and flat-prior variants (reference marginal.py:118-121, 73-75)
+    like_j = MarginalLikelihood(eng, index, g[tag + "_D"], g[tag + "_invcov"], g[tag + "_loc"], g[tag + "_scale"], jeffreys=True)
+    assert np.isclose(like_j.logp(np.stack(rows))[0], g[tag + "_logp_jeffreys"], rtol=1e-10)
+    if tag == "auto":  # (the 11 cross-tracer parameters are degenerate on 36 data points without a prior: cond F2 = 2e18,
+        nG = len(g[tag + "_loc"])  # the sign of det F2 is rounding noise there, in the reference as well)
+        like_f = MarginalLikelihood(eng, index, g[tag + "_D"], g[tag + "_invcov"], np.zeros(nG), np.full(nG, np.inf))
+        assert np.isclose(like_f.logp(np.stack(rows))[0], g[tag + "_logp_flat"], rtol=1e-9)
+    eng.close()
+
+
+def test_marginal_error_paths(golden):
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.marginal import MarginalLikelihood
+
+    g = golden("marg")
+    eng, nx = _engine(g, 2)
+    with pytest.raises(L.EftbError, match="eftb_set_likelihood"):
+        eng.run(L.S_LOGP, 1)  # no likelihood registered yet
+    D, C = g["auto_D"], g["auto_invcov"]
+    idx = np.arange(D.size, dtype=np.int32)
+    with pytest.raises(L.EftbError, match="outside"):
+        MarginalLikelihood(eng, idx + 3 * nx, D, C, np.zeros(7), np.ones(7))
+    bad = C.copy()
+    bad[0, 1] += 1.0
+    with pytest.raises(L.EftbError, match="symmetric"):
+        MarginalLikelihood(eng, idx, D, bad, np.zeros(7), np.ones(7))
+    with pytest.raises(ValueError, match="infinite scale"):
+        MarginalLikelihood(eng, idx, D, C, np.zeros(7), np.array([np.inf] + [1.0] * 6))
+    # a singular Fisher matrix (all derivative rows zero, flat prior) is reported like the reference does
+    like = MarginalLikelihood(eng, idx, D, C, np.zeros(7), np.full(7, np.inf))
+    with pytest.raises(RuntimeError, match="det of F2ij"):
+        like.logp(np.zeros((1, 8, 24)))
+    eng.close()

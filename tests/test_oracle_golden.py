@@ -124,3 +124,37 @@ def test_cfg3_shape_window_chained_cross(golden):
         assert relerr(ch[n], g["chained_" + n]) < 1e-9, n
     eng.kmB, eng.krB, eng.ndB, eng.No = 0.6, 0.3, 2.3e-4, 2
     assert relerr(eng.reduce_plk(f, ch, list(g["bsA"]), list(g["bsB"]), tuple(g["es"])), g["plk_chained_cross"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["auto", "cross"])
+def test_gaussian_table_and_marginalised_logp(golden, tag):
+    """oracle == reference (parambasis.derivative_table, likelihood.flatten, marginal.marginalized_logp)."""
+    from oracle import marginal as M
+
+    g = golden("marg")
+    st = {n: g["binned_" + n] for n in ("P11l", "Pctl", "Ploopl", "Pstl")}
+    f = float(g["f"])
+    kmA, krA, ndA, kmB, krB, ndB = g[tag + "_co"]
+    ng = dict(zip(g[tag + "_ng_names"], g[tag + "_ng_values"]))
+    names = M.gaussian_names("", ()) if tag == "auto" else M.gaussian_names("X_", ("A_", "B_"))
+    assert names == list(g[tag + "_names"])
+    if tag == "auto":
+        table = M.derivative_table(st, f, ng["b1"], None, kmA, krA, ndA)
+    else:
+        table = M.derivative_table(st, f, ng["A_b1"], ng["B_b1"], kmA, krA, ndA, kmB, krB, ndB)
+    assert relerr(np.stack(table).reshape(len(names), -1), g[tag + "_table"].reshape(len(names), -1)) < 1e-14
+    ls = list(g["ls"])
+    masks = {l: slice(a, b) for l, (a, b) in zip(ls, g["masks"])}
+    PG = np.stack([M.flatten(ls, t, masks) for t in table])
+    assert np.array_equal(M.flatten(ls, g[tag + "_PNGl"], masks), g[tag + "_PNG"])
+    assert relerr(PG, g[tag + "_PG"]) < 1e-14
+    args = (g[tag + "_PG"], g[tag + "_PNG"], g[tag + "_D"], g[tag + "_invcov"], g[tag + "_loc"], g[tag + "_scale"])
+    logp, fullchi2, best, F = M.marginalized_logp(*args, return_best=True)
+    assert relerr(F["F2"], g[tag + "_F2"]) < 1e-13 and relerr(F["F1"][None], g[tag + "_F1"][None]) < 1e-13
+    assert np.isclose(F["F0"], g[tag + "_F0"], rtol=1e-13)
+    assert np.isclose(logp, g[tag + "_logp"], rtol=1e-12) and np.isclose(fullchi2, g[tag + "_fullchi2"], rtol=1e-10)
+    assert relerr(best[None], g[tag + "_best"][None]) < 1e-10
+    assert np.isclose(M.marginalized_logp(*args, jeffreys=True), g[tag + "_logp_jeffreys"], rtol=1e-12)
+    if tag == "auto":  # cross + flat prior is singular (cond F2 = 2e18): the sign of det F2 is rounding noise there
+        flat = M.marginalized_logp(*args[:4], np.zeros(len(names)), np.full(len(names), np.inf))
+        assert np.isclose(flat, g[tag + "_logp_flat"], rtol=1e-12)

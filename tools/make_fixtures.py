@@ -143,6 +143,92 @@ def run_case(ref, name, spec):
     print(name, "written:", {k: np.shape(v) for k, v in out.items() if np.ndim(v) > 0 and k.startswith(("ap_", "plk"))})
 
 
+def marg_fixture(ref):
+    """the Gaussian (derivative) table and the analytically marginalised log-posterior, from the
+    REAL reference (parambasis.WestCoastBasis.reduce_Plk_gaussian_table, marginal.Marginalizable.marginalized_logp) on
+    the binned templates of the caseC configuration, auto and cross-tracer bases, with and without Jeffreys prior."""
+    pb = ref.pybird
+    g = dict(np.load(os.path.join(GOLD, "caseC.npz"), allow_pickle=True))  # native k grid, window + binning (18 bins)
+    Nl = int(g["Nl"])
+    rng = np.random.default_rng(20250817)
+    ls = [0, 2, 4]
+    masks = {0: slice(0, 16), 2: slice(2, 14), 4: slice(1, 9)}
+    out = dict(f=g["f"], keff=g["keff"], ls=np.array(ls), masks=np.array([[masks[l].start, masks[l].stop] for l in ls]))
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc"):
+        out["binned_" + n] = g["binned_" + n]
+
+    def holder(co):
+        nnlo = np.zeros((Nl, 2, g["binned_P11l"].shape[-1]))  # with_NNLO is off; derivative_table still slices the array
+        return ref.transformer.PlainBird(f=float(g["f"]), co=co, P11l=g["binned_P11l"], Ploopl=g["binned_Ploopl"], Pctl=g["binned_Pctl"],
+                                         Pstl=g["binned_Pstl"], Picc=g["binned_Picc"], PctNNLOl=nnlo)
+
+    flat = lambda a: np.hstack([a[l // 2, masks[l]] for l in ls])
+    cases = {
+        "auto": (ref.parambasis.WestCoastBasis(prefix=""), make_common(pb, Nl, None), {"b1": 2.1, "b2": 0.55, "b4": 0.3}),
+        "cross": (ref.parambasis.WestCoastBasis(prefix="X_", cross_prefix=["A_", "B_"]),
+                  make_common(pb, Nl, None, kmB=0.6, krB=0.3, ndB=2.3e-4),
+                  {"A_b1": 2.1, "A_b2": 0.55, "A_b4": 0.3, "B_b1": 1.3, "B_b2": -0.2, "B_b4": 0.6}),
+    }
+    for tag, (basis, co, ng) in cases.items():
+        bird = holder(co)
+        table = basis.reduce_Plk_gaussian_table(bird, ng)
+        names = [p for p in basis.gaussian_params() if p in table]
+        PNGl = basis.reduce_Plk(bird, ng).sum()
+        PG = np.stack([flat(table[p]) for p in names])
+        PNG = flat(PNGl)
+        ndata = PNG.size
+        # synthetic data: the model at perturbed parameters plus noise; a dense SPD precision matrix
+        truth = rng.normal(scale=0.5, size=len(names))
+        sig = 0.03 * np.abs(PNG) + 5.0
+        D = PNG + truth @ PG + sig * rng.normal(size=ndata)
+        A = rng.normal(size=(ndata, ndata)) * 0.05
+        cov = np.diag(sig) @ (np.eye(ndata) + A @ A.T) @ np.diag(sig)
+        invcov = np.linalg.inv(cov)
+        invcov = 0.5 * (invcov + invcov.T)
+        loc = rng.normal(scale=0.3, size=len(names))
+        scale = rng.uniform(1.0, 4.0, size=len(names))
+
+        class Like(ref.marginal.Marginalizable):
+            def marginalizable_params(self):
+                return list(names)
+
+            def PG(self):
+                return PG
+
+            def PNG(self):
+                return PNG
+
+            def get_data_vector(self):
+                return D
+
+            def get_invcov(self):
+                return invcov
+
+            def mpi_debug(self, *a, **k):
+                pass
+
+            mpi_warning = mpi_info = mpi_debug
+
+        like = Like()
+        like.setup_prior({p: {"loc": float(l0), "scale": float(s0)} for p, l0, s0 in zip(names, loc, scale)})
+        logp, fullchi2, best = like.marginalized_logp(return_bGbest=True)
+        out.update({
+            tag + "_names": np.array(names), tag + "_ng_names": np.array(list(ng)), tag + "_ng_values": np.array(list(ng.values())),
+            tag + "_co": np.array([co.kmA, co.krA, co.ndA, co.kmB, co.krB, co.ndB]),
+            tag + "_table": np.stack([table[p] for p in names]), tag + "_PNGl": PNGl, tag + "_PG": PG, tag + "_PNG": PNG,
+            tag + "_D": D, tag + "_invcov": invcov, tag + "_loc": loc, tag + "_scale": scale,
+            tag + "_F2": like.calc_F2ij(PG, invcov, like.sigma_inv), tag + "_F1": like.calc_F1i(PG, PNG, invcov, D, like.mu_G, like.sigma_inv),
+            tag + "_F0": like.calc_F0(PNG, invcov, D, like.mu_G, like.sigma_inv),
+            tag + "_logp": logp, tag + "_fullchi2": fullchi2, tag + "_best": np.array([best[p] for p in names]),
+            tag + "_logp_jeffreys": like.marginalized_logp(jeffreys=True),
+        })
+        # flat (infinite-scale) prior
+        like.setup_prior({p: {"loc": 0.0, "scale": np.inf} for p in names})
+        out[tag + "_logp_flat"] = like.marginalized_logp()
+    np.savez_compressed(os.path.join(GOLD, "marg.npz"), **out)
+    print("marg written:", {k: np.shape(v) for k, v in out.items() if k.endswith(("_PG", "_logp"))})
+
+
 def tables_fixture(ref):
     """Spot checks of the constant tables + the reference's own FFTLog test vector + known answers."""
     pb = ref.pybird
@@ -190,10 +276,12 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES))
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
+        elif name == "marg":
+            marg_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 

@@ -59,4 +59,5 @@ def load_reference():
     ns.chained = importlib.import_module("eftpipe.chained")
     ns.parambasis = importlib.import_module("eftpipe.parambasis")
     ns.transformer = importlib.import_module("eftpipe.transformer")
+    ns.marginal = importlib.import_module("eftpipe.marginal")
     return ns
