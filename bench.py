@@ -146,6 +146,19 @@ def main():
         ms_c22 = eng.run_timed(L.K_C22, B, reps)
         stages = {n: eng.run_timed(m, B, 3) for n, m in (("prep", L.S_PREP), ("loops", L.S_LOOPS), ("cf", L.S_CF),
                                                         ("regroup", L.S_REGROUP), ("resum", L.S_RESUM), ("ap", L.S_AP), ("reduce", L.S_REDUCE))}
+        # SURVEY 8(f) rank 1, reported beside the headline: the marginalised log-posterior stage on the same batch (synthetic data
+        # vector: l = 0, 2, 4 at every 8th k in [0.02, 0.2], 7 marginalised parameters) -- one float per walker leaves the GPU
+        from eftpipe_amd.marginal import MarginalLikelihood, gaussian_rows
+        kk = cfg.k
+        sel = np.nonzero((kk >= 0.02) & (kk <= 0.2))[0][::8]
+        index = np.concatenate([l * NK + sel for l in range(NL)]).astype(np.int32)
+        rng = np.random.default_rng(7)
+        rows = np.stack([gaussian_rows(float(f), (BS[0], BS[1], BS[3]), None, 0.7, 0.25, 4.5e-5) for f in draws["f"]])
+        model = np.einsum("r,lrx->lx", rows[0][0], eng.get("TEMPL", (B, NL, 24, NK))[0]).reshape(-1)[index]
+        sig = 0.05 * np.abs(model) + 10.0
+        like = MarginalLikelihood(eng, index, model + sig * rng.normal(size=index.size), np.diag(1.0 / sig**2), np.zeros(7), np.full(7, 2.0))
+        like.logp(rows)
+        stages["logp_marginalised"] = eng.run_timed(L.S_LOGP, B, 3)
         # ALGORITHMIC flops of SURVEY.md 8(d), as the reference computes the stage (not the reduced work the engine executes):
         #   F_IRn = 8 Na [Nl 14 2NIR] 193 (Nk - 7)  (Resum.Ps: FFTLog192 + Bessel sum of every X^p Y^h C product),  F_P22 = 8 28 Nk 257^2
         NIR, NA, NKLOW = 16, 3, 7
