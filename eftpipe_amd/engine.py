@@ -20,10 +20,10 @@ ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(
 
 
 class Engine:
-    def __init__(self, cfg: EngineConfig, max_batch: int = 1, device: int = 0):
+    def __init__(self, cfg: EngineConfig, max_batch: int = 1, device: int = 0, loop_cache=None):
         self.lib = L.load()
         self.cfg = cfg
-        t = self.tables = build_tables(cfg)
+        t = self.tables = build_tables(cfg, loop_cache)
         self.Nl, self.Nk, self.Nkin = cfg.Nl, t["k"].size, t["kin"].size
         self.k, self.kin, self.s = t["k"], t["kin"], t["s"]
         self.max_batch = int(max_batch)

@@ -90,7 +90,7 @@ common = Common()
 _ENGINES: "weakref.WeakKeyDictionary[Common, Engine]" = weakref.WeakKeyDictionary()
 
 
-def engine_for(co, nbinsmu=200):
+def engine_for(co, nbinsmu=200, loop_cache=None):
     """The engine serving `co`, created on first use with the resum and AP tables resident."""
     eng = _ENGINES.get(co)
     if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != nbinsmu):
@@ -99,7 +99,7 @@ def engine_for(co, nbinsmu=200):
     if eng is None:
         cfg = EngineConfig(Nl=co.Nl, k=np.array(co.k, dtype=np.float64), with_resum=True, with_ap=True, DA_AP=1.0, H_AP=1.0,
                            nbinsmu=nbinsmu)
-        eng = _ENGINES[co] = Engine(cfg, max_batch=1)
+        eng = _ENGINES[co] = Engine(cfg, max_batch=1, loop_cache=loop_cache)
     return eng
 
 
@@ -178,21 +178,47 @@ class Bird:
 
 # ----------------------------------------------------------------------------- NonLinear
 class NonLinear(HasLogger):
-    """One-loop P(k) and xi(s) pieces (reference pybird.py:870-1171).  `load/save/path` are accepted for
-    signature compatibility; the loop matrices are rebuilt in a few seconds on the host and kept,
-    real-reduced, in HBM (eftpipe_amd/tables.py), so no pyegg cache is read or written."""
+    """One-loop P(k) and xi(s) pieces (reference pybird.py:870-1171).  `load` / `save` / `path` follow the reference
+    (pybird.py:917-981): the loop matrices are read from / written to `path/pyegg{NFFT}_Nl{Nl}.npz` in the reference's own
+    layout (keys Pow, M22, M13, Mcf11, Mcf22, Mcf13, Mcfct, McfctNNLO), so existing caches drop in; a cache written for
+    another FFTLog configuration, or an unreadable one, is ignored with a warning and the matrices are recomputed."""
 
     def __init__(self, load=True, save=True, path="./", NFFT=256, co=common, name="pybird.nonlinear"):
+        from .tables import PYEGG_KEYS, loop_matrices, pyegg_path
+
         self.set_logger(name=name)
         if NFFT != 256:
             raise NotImplementedError("the HIP engine is specialised for NFFT=256 (reference default)")
         self.co = co
         self.fftsettings = dict(Nmax=NFFT, xmin=1.5e-5, xmax=1000.0, bias=-1.6)
-        self.engine = engine_for(co)
+        egg = pyegg_path(path, NFFT, co.Nl)
+        cache = None
+        if load is True:
+            try:
+                with np.load(egg) as z:
+                    cache = {k: z[k] for k in ("Pow", "M22", "M13", "Mcf11", "Mcfct")}
+                save = False
+            except Exception:  # same policy as the reference: warn and recompute
+                self.mpi_warning("Can't load loop matrices at %s, computing new matrices.", path)
+        if cache is not None:
+            try:
+                self.engine = engine_for(co, loop_cache=cache)
+            except ValueError:
+                self.mpi_warning("Loaded loop matrices do not correspond to asked FFTLog configuration, computing new matrices.")
+                cache, save = None, save
+        if cache is None:
+            self.engine = engine_for(co)
+        self.loaded = cache is not None
+        if save is True and cache is None:
+            try:
+                mats = loop_matrices(co.Nl, NFFT)
+                np.savez(egg, **{k: mats[k] for k in PYEGG_KEYS})
+            except Exception:
+                self.mpi_warning("Can't save loop matrices at %s.", path)
 
     def PsCf(self, bird, window=0.2):
         """FFTLog of P_lin + P22, P13, C11, Cct, C22, C13 (reference pybird.py:1143-1171) --
-        prep_kernel, uvec_kernel, pair_gemm_kernel (FP64 MFMA), rowdot_kernel."""
+        prep_kernel, antidiag_kernel, build_rows_kernel, synth_kernel (FP64 MFMA), expand_kernel."""
         if window != self.engine.cfg.fft_window:
             raise NotImplementedError(f"engine built for FFTLog window={self.engine.cfg.fft_window}")
         if not np.array_equal(bird.kin, self.engine.kin):
@@ -213,7 +239,7 @@ class NonLinear(HasLogger):
 
 # ----------------------------------------------------------------------------- Resum
 class Resum(HasLogger):
-    """IR-resummation (reference pybird.py:1174-1464) -- irfilter_kernel, resum_kernel."""
+    """IR-resummation (reference pybird.py:1174-1464) -- irfilter_kernel, resum_prep_kernel, resum_mfma_kernel."""
 
     def __init__(self, LambdaIR=0.2, NFFT=192, co=common, name="pybird.IRresum", snapshot=False):
         self.set_logger(name=name)

@@ -234,8 +234,33 @@ def legendre_table(Nl, mu):
     return np.array([legendre(2 * l)(mu) for l in range(Nl)])
 
 
-def build_tables(cfg: EngineConfig) -> dict:
-    """-> {name: ndarray} of every constant table, float64 / int32, C-contiguous, device layout."""
+PYEGG_KEYS = ("Pow", "M22", "M13", "Mcf11", "Mcf22", "Mcf13", "Mcfct", "McfctNNLO")
+
+
+def pyegg_path(path, NFFT, Nl):
+    """File name of the reference's loop-matrix cache (reference pybird.py:925)."""
+    import os
+
+    return os.path.join(path, f"pyegg{NFFT}_Nl{Nl}.npz")
+
+
+def loop_matrices(Nl, NFFT=256, bias=-1.6, xmin=1.5e-5, xmax=1000.0):
+    """The loop matrices in the reference's own cache layout (reference pybird.py:968-981):
+    Pow[N+1], M22[28,N+1,N+1], M13[10,N+1], Mcf11/Mcfct/McfctNNLO[Nl,N+1], Mcf22[28,Nl,N+1,N+1], Mcf13[10,Nl,N+1,N+1]."""
+    dx = np.log(xmax / xmin) / (NFFT - 1.0)
+    Pow = bias + 1j * 2.0 * np.pi / (NFFT * dx) * (np.arange(NFFT + 1) - NFFT / 2.0)
+    nu = -0.5 * Pow
+    ells = 2 * np.arange(Nl)
+    M22, M13 = lm.matrices_22(nu), lm.vectors_13(nu)
+    Ml = lm.bessel_weight(ells[:, None, None], nu[None, :, None] + nu[None, None, :] - 1.5)
+    return dict(Pow=Pow, M22=M22, M13=M13, Mcf11=lm.bessel_weight(ells[:, None], nu[None, :]),
+                Mcf22=np.einsum("lnm,bnm->blnm", Ml, M22), Mcf13=np.einsum("lnm,bn->blnm", Ml, M13),
+                Mcfct=lm.bessel_weight(ells[:, None], nu[None, :] - 1.0), McfctNNLO=lm.bessel_weight(ells[:, None], nu[None, :] - 2.0))
+
+
+def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
+    """-> {name: ndarray} of every constant table, float64 / int32, C-contiguous, device layout.
+    ``loop_cache``: the arrays of a reference ``pyegg*.npz`` (M22, M13, Mcf11, Mcfct are used) instead of recomputing them."""
     if cfg.NFFT != 256:
         raise ValueError("the HIP engine is specialised for NFFT=256 (the reference default, pybird.py:912)")
     Nl = cfg.Nl
@@ -266,8 +291,15 @@ def build_tables(cfg: EngineConfig) -> dict:
     Pow = op.Pow
     nu = -0.5 * Pow
     # ---- one-loop pieces through the anti-diagonal form (see antidiagonal_tables)
-    M22 = lm.matrices_22(nu)
-    M13 = lm.vectors_13(nu)
+    if loop_cache is not None:
+        if np.shape(loop_cache["Pow"]) != Pow.shape or np.any(np.asarray(loop_cache["Pow"]) != Pow):
+            raise ValueError("loop-matrix cache was written for a different FFTLog configuration")
+        M22, M13 = np.asarray(loop_cache["M22"]), np.asarray(loop_cache["M13"])
+        if M22.shape != (28, NPOW, NPOW) or M13.shape != (10, NPOW):
+            raise ValueError("loop-matrix cache has the wrong shapes")
+    else:
+        M22 = lm.matrices_22(nu)
+        M13 = lm.vectors_13(nu)
     ells = 2 * np.arange(Nl)
     basis, comb = loop_basis(M22)
     t["basis22"], t["comb22"] = basis.astype(np.int32), comb                 # M22[b] = sum_c comb[b, c] M22[basis[c]]
@@ -285,7 +317,10 @@ def build_tables(cfg: EngineConfig) -> dict:
         t["ad"] = antidiagonal_tables(M22[basis], M13[basis13])
         jp = np.arange(NPOW)
         t["mlj"] = lm.bessel_weight(ells[:, None], -op.bias - 0.5j * op.dpow * jp[None, :] - 1.5)   # Ml depends on n + m only
-        vecs += [lm.bessel_weight(ells[:, None], nu[None, :]), lm.bessel_weight(ells[:, None], nu[None, :] - 1.0)]
+        if loop_cache is not None and np.shape(loop_cache["Mcf11"]) == (Nl, NPOW):
+            vecs += [np.asarray(loop_cache["Mcf11"]), np.asarray(loop_cache["Mcfct"])]
+        else:
+            vecs += [lm.bessel_weight(ells[:, None], nu[None, :]), lm.bessel_weight(ells[:, None], nu[None, :] - 1.0)]
         t["syn_s"] = synthesis_table(np.log(s), -2.0 * op.bias - 6.0, op.dpow, NPOW - 1, sign=-1.0)
         t["lin_s"] = synthesis_table(np.log(s), -op.bias - 3.0, op.dpow, NHALF, sign=+1.0)
     else:

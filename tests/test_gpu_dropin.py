@@ -70,3 +70,32 @@ def test_q_override_and_snapshots(golden):
     assert np.max(np.abs(bird.P11l - np.einsum("x,ln->lnx", bird.P11, co.l11))) < 5e-4 * np.max(bird.P11)
     assert "APeffect" in bird.snapshots and np.array_equal(bird.snapshots["APeffect"].Ploopl, bird.Ploopl)
     assert np.max(np.abs(bird.Ploopl - before)) < 5e-3 * np.max(np.abs(before))
+
+
+def test_nonlinear_pyegg_cache_round_trip(golden, tmp_path):
+    """NonLinear(load, save, path) as in the reference (pybird.py:917-981): the first construction writes
+    pyegg256_Nl2.npz in the reference's layout, the second one loads it and gives bit-identical loop pieces."""
+    from eftpipe_amd import pybird
+    from eftpipe_amd.tables import PYEGG_KEYS
+
+    g = golden("caseA")
+    path = str(tmp_path)
+
+    def run(load, save):
+        co = pybird.Common(Nl=2, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+        nl = pybird.NonLinear(load=load, save=save, path=path, co=co)
+        bird = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), co=co)
+        nl.PsCf(bird)
+        return nl, bird
+
+    nl1, b1 = run(load=True, save=True)  # nothing to load yet: computed and saved
+    assert not nl1.loaded
+    egg = tmp_path / "pyegg256_Nl2.npz"
+    assert egg.exists()
+    with np.load(egg) as z:
+        assert list(z.files) == list(PYEGG_KEYS) and z["Mcf22"].shape == (28, 2, 257, 257)
+    nl2, b2 = run(load=True, save=True)
+    assert nl2.loaded
+    for n in ("P22", "P13", "C11", "Cct", "C22", "C13"):
+        assert np.array_equal(getattr(b1, n), getattr(b2, n)), n
+        assert relerr(getattr(b2, n), g["pscf_" + n]) < TOL, n

@@ -105,3 +105,33 @@ def test_control_plane_world_size_2_gloo(tmp_path):
            "--master-port", "29533", str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("Nl", [2, 3])
+def test_pyegg_cache_layout_matches_reference(golden, Nl):
+    """`tables.loop_matrices` reproduces the reference's loop-matrix cache (file name, keys, shapes,
+    dtypes, values at sampled positions) -- so caches written by either side are interchangeable."""
+    from eftpipe_amd.tables import PYEGG_KEYS, loop_matrices, pyegg_path
+
+    g = golden("pyegg")
+    assert pyegg_path("", 256, Nl) == str(g[f"name_Nl{Nl}"])
+    assert list(g[f"keys_Nl{Nl}"]) == list(PYEGG_KEYS)
+    m = loop_matrices(Nl)
+    for k in PYEGG_KEYS:
+        assert m[k].shape == tuple(g[f"shape_{k}_Nl{Nl}"]) and str(m[k].dtype) == str(g[f"dtype_{k}_Nl{Nl}"]), k
+        got, want = m[k].reshape(-1)[g[f"idx_{k}_Nl{Nl}"]], g[f"val_{k}_Nl{Nl}"]
+        assert np.max(np.abs(got - want) / np.abs(want)) < 1e-11, k
+
+
+def test_tables_from_loop_cache_equal_recomputed():
+    """Tables built from a pyegg-style cache are bit-identical to the recomputed ones; a cache for another FFTLog setup is refused."""
+    from eftpipe_amd.tables import EngineConfig, build_tables, loop_matrices
+
+    cfg = EngineConfig(Nl=2, with_resum=True)
+    mats = loop_matrices(2)
+    a, b = build_tables(cfg), build_tables(cfg, {k: mats[k] for k in ("Pow", "M22", "M13", "Mcf11", "Mcfct")})
+    for k in ("ad", "linvec", "comb22", "comb13"):
+        assert np.array_equal(a[k], b[k]), k
+    bad = dict(mats, Pow=mats["Pow"] + 0.1)
+    with pytest.raises(ValueError, match="different FFTLog"):
+        build_tables(cfg, bad)

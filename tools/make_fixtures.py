@@ -229,6 +229,33 @@ def marg_fixture(ref):
     print("marg written:", {k: np.shape(v) for k, v in out.items() if k.endswith(("_PG", "_logp"))})
 
 
+def pyegg_fixture(ref):
+    """the on-disk layout of the reference's loop-matrix cache pyegg{NFFT}_Nl{Nl}.npz (pybird.py:968-981):
+    keys, shapes, dtypes and spot values of every array (the 150 MB file itself is not committed)."""
+    import tempfile
+
+    pb = ref.pybird
+    out = {}
+    rng = np.random.default_rng(11)
+    for Nl in (2, 3):
+        co = make_common(pb, Nl, None)
+        with tempfile.TemporaryDirectory() as tmp:
+            pb.NonLinear(load=False, save=True, path=tmp, co=co)
+            (name,) = os.listdir(tmp)
+            z = np.load(os.path.join(tmp, name))
+            out[f"name_Nl{Nl}"] = np.array(name)
+            out[f"keys_Nl{Nl}"] = np.array(z.files)
+            for k in z.files:
+                a = z[k]
+                idx = rng.integers(0, a.size, size=64)
+                out[f"shape_{k}_Nl{Nl}"] = np.array(a.shape)
+                out[f"dtype_{k}_Nl{Nl}"] = np.array(str(a.dtype))
+                out[f"idx_{k}_Nl{Nl}"] = idx
+                out[f"val_{k}_Nl{Nl}"] = a.reshape(-1)[idx]
+    np.savez_compressed(os.path.join(GOLD, "pyegg.npz"), **out)
+    print("pyegg written:", [str(out[k]) for k in out if k.startswith("name")])
+
+
 def tables_fixture(ref):
     """Spot checks of the constant tables + the reference's own FFTLog test vector + known answers."""
     pb = ref.pybird
@@ -276,12 +303,14 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
         elif name == "marg":
             marg_fixture(ref)
+        elif name == "pyegg":
+            pyegg_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
