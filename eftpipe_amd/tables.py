@@ -529,6 +529,17 @@ def binning_operator(k, kout=None, accboost=1, decimals=2, kstart=None, kend=Non
     return op, keff, binmin, binmax
 
 
+def interp_operator(k, kout):
+    """PlkInterpolator as a matrix [len(kout), Nk] (reference theory.py:75-106): cubic (not-a-knot) interpolation of
+    k P(k) on the grid (0, k_0, ..., k_{N-1}) with the value 0 inserted at k = 0, evaluated at kout (end pieces
+    extrapolated) and divided by kout."""
+    k = np.asarray(k, dtype=float)
+    kout = np.atleast_1d(np.asarray(kout, dtype=float))
+    kg = np.concatenate([[0.0], k])
+    S = spline_matrix(kg, kout)[:, 1:]  # the inserted node carries the value 0
+    return np.ascontiguousarray(S * k[None, :] / kout[:, None])
+
+
 def chained_matrix(Nl):
     """Q_l = P_l - A_l P_{l+2}, A_l = (2l+1) L_l(0) / ((2l+5) L_{l+2}(0)) (reference chained.py:13-54)."""
     m = np.zeros((Nl - 1, Nl))

@@ -48,3 +48,27 @@ def apply_operator_to_birdlike(eng, op_id, birdlike):
     nlo, nxo = eng.dims
     out = eng.get("TEMPL", (nlo, 24, nxo))
     return {n: np.ascontiguousarray(out[:, sl]) for n, sl in ROWS.items()}
+
+
+class PlkInterpolator:
+    """Same surface as reference theory.py:75-106: ``PlkInterpolator(ls, kgrid, Plk)(l, k)`` interpolates k P_l(k) with a
+    cubic spline through (0, 0) and the grid and divides by k.  The interpolation is the linear operator
+    ``tables.interp_operator``; for a batch resident on the device register it with ``Engine.add_operator`` (as Binning
+    does) -- this host class serves the single-spectrum calls of the reference's provider API."""
+
+    def __init__(self, ls, kgrid, Plk):
+        self.ls = list(ls)
+        self._k = np.array(kgrid, dtype=np.float64)
+        self._P = np.array(Plk, dtype=np.float64)
+
+    def __call__(self, l, k):
+        from .tables import interp_operator
+
+        ll = [int(l)] if np.ndim(l) == 0 else [int(x) for x in l]
+        try:
+            idx = [self.ls.index(x) for x in ll]
+        except ValueError as ex:
+            raise ValueError(f"l={ll} not in {self.ls}") from ex
+        out = self._P[idx] @ interp_operator(self._k, k).T
+        out = out.reshape((len(idx),) + np.shape(k))
+        return out[0] if len(idx) == 1 else out

@@ -452,3 +452,16 @@ class OracleEngine:
             if taps is not None:
                 taps["window"] = dict(st)
         return st
+
+
+def plk_interpolate(ls, kgrid, Plk, l, k):
+    """PlkInterpolator (reference theory.py:75-106), restated with the same scipy call."""
+    from scipy.interpolate import interp1d
+
+    kg = np.hstack(([0], kgrid))
+    P = np.insert(Plk, 0, 0, axis=-1)
+    tmp = interp1d(kg, kg * P, axis=-1, kind="cubic", bounds_error=False, fill_value="extrapolate")
+    ll = [l] if np.ndim(l) == 0 else list(l)
+    idx = [list(ls).index(x) for x in ll]
+    out = (tmp(k) / k)[idx]
+    return out[0] if len(idx) == 1 else out

@@ -94,6 +94,47 @@ def test_folded_pipeline_operator_batched(golden):
     eng.close()
 
 
+def test_interpolation_operator_then_marginalised_logp(golden):
+    """The `with_interp` data path on the device: PlkInterpolator as the pipeline operator, P_l at the data k,
+    then the marginalised log-posterior of the interpolated templates (rank 1) -- against the oracle on the host."""
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index, gaussian_rows
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+    from oracle import marginal as M
+    from oracle.engine import plk_interpolate
+
+    g = golden("caseD")
+    k = g["k"]
+    kdata = np.arange(0.03, 0.2, 0.01)
+    eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=2)
+    op = eng.add_operator(np.einsum("al,xk->alxk", np.eye(3), TB.interp_operator(k, kdata)))
+    eng.set_pipeline_operator(op)
+    f = float(g["f"])
+    bias = bias_row(f, list(g["bsA"]), None, tuple(g["es"]), kmA=0.7, krA=0.25, ndA=4.5e-5)[None]
+    templ, plk = eng.eval_batch(g["Pin"][None], f, float(g["DA"]), float(g["H"]), bias=bias)
+    want = plk_interpolate([0, 2, 4], k, g["plk_auto"], [0, 2, 4], kdata)
+    assert relerr(plk[0], want) < TOL
+    # likelihood on the interpolated templates (still resident on the device)
+    nx = kdata.size
+    ls, masks = [0, 2], {0: slice(0, nx), 2: slice(2, nx - 3)}
+    index = data_index(ls, masks, nx)
+    rng = np.random.default_rng(5)
+    b1, b2, b4 = g["bsA"][0], g["bsA"][1], g["bsA"][3]
+    rows = gaussian_rows(f, (b1, b2, b4), None, 0.7, 0.25, 4.5e-5)
+    V = np.einsum("gr,lrx->glx", rows, templ[0]).reshape(rows.shape[0], -1)[:, index]
+    sig = 0.04 * np.abs(V[0]) + 20.0
+    D = V[0] + sig * rng.normal(size=index.size)
+    C = np.diag(1.0 / sig**2)
+    loc, scale = np.zeros(7), np.array([2.0, 2.0, 4.0, 4.0, 2.0, 2.0, 2.0])
+    like = MarginalLikelihood(eng, index, D, C, loc, scale)
+    logp, full, best = like.logp(rows[None], return_best=True)
+    w = M.marginalized_logp(V[1:], V[0], D, C, loc, scale, return_best=True)
+    assert np.isclose(logp[0], w[0], rtol=1e-10) and np.isclose(full[0], w[1], rtol=1e-9) and relerr(best, w[2][None]) < 1e-8
+    eng.close()
+
+
 def test_rccl_gather_single_rank(golden):
     """World size 1 exercises the whole RCCL code path short of the wire: lazy dlopen, unique id,
     ncclCommInitRank, gather into the root buffer, copy-out."""

@@ -135,3 +135,23 @@ def test_tables_from_loop_cache_equal_recomputed():
     bad = dict(mats, Pow=mats["Pow"] + 0.1)
     with pytest.raises(ValueError, match="different FFTLog"):
         build_tables(cfg, bad)
+
+
+def test_plk_interpolator_operator(golden):
+    """PlkInterpolator (theory.py:75-106) as a linear operator == the reference's scipy.interpolate.interp1d
+    call (scipy 1.15 make_interp_spline, not-a-knot), inside the grid and extrapolated beyond both ends."""
+    from eftpipe_amd.tables import interp_operator
+    from eftpipe_amd.transformer import PlkInterpolator
+    from oracle.engine import plk_interpolate
+
+    g = golden("caseD")
+    k, plk = g["k"], g["plk_auto"]
+    kout = np.concatenate([[5e-4, 0.0123], np.arange(0.02, 0.3, 0.0137), [0.31]])
+    want = plk_interpolate([0, 2, 4], k, plk, [0, 2, 4], kout)
+    got = plk @ interp_operator(k, kout).T
+    assert relerr(got, want) < 1e-11
+    fn = PlkInterpolator([0, 2, 4], k, plk)
+    assert relerr(fn([0, 2, 4], kout), want) < 1e-11
+    assert relerr(fn(2, kout)[None], want[1][None]) < 1e-11 and fn(4, 0.1).shape == ()
+    with pytest.raises(ValueError, match="not in"):
+        fn(6, kout)
