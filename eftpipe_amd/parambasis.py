@@ -1,4 +1,5 @@
-"""Bias contraction onto P_l(k): host mirror of reference eftpipe/parambasis.py:42-136 (west coast).
+"""Bias contraction onto P_l(k): host mirror of reference eftpipe/parambasis.py:42-136 and of its two parameter
+bases (WestCoastBasis :166-316, EastCoastBasis :320-454).
 
 ``bias_vectors`` builds the 3 + 6 + 12 + 3 coefficient vectors; the
 contraction itself runs on the device (``reduce_kernel``) when driven through ``Engine`` and is a
@@ -6,7 +7,7 @@ contraction itself runs on the device (``reduce_kernel``) when driven through ``
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 
@@ -25,8 +26,10 @@ class BirdComponent:
         return self.Plin + self.Ploop + self.Pct + self.Pst + self.Picc
 
 
-def bias_vectors(f, bsA, bsB=None, es=(0.0, 0.0, 0.0), kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None, ndB=None):
-    """-> b11[3], bct[6], bloop[12], bst[3] (reference parambasis.py:69-126, counterform='westcoast')."""
+def bias_vectors(f, bsA, bsB=None, es=(0.0, 0.0, 0.0), kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None, ndB=None,
+                 counterform="westcoast"):
+    """-> b11[3], bct[6], bloop[12], bst[3] (reference parambasis.py:69-126; counterform 'eastcoast' reads the last
+    three entries of bsA/bsB as ctilde_0, ctilde_2, ctilde_4, :93-102)."""
     kmB = kmA if kmB is None else kmB
     krB = krA if krB is None else krB
     ndB = ndA if ndB is None else ndB
@@ -34,7 +37,9 @@ def bias_vectors(f, bsA, bsB=None, es=(0.0, 0.0, 0.0), kmA=0.7, krA=0.25, ndA=3e
     b1B, b2B, b3B, b4B, cctB, cr1B, cr2B = bsB if bsB is not None else bsA
     ce0, cemono, cequad = es
     b11 = np.array([b1A * b1B, (b1A + b1B) * f, f * f])
-    bct = np.array([
+    if counterform not in ("westcoast", "eastcoast"):
+        raise ValueError(f"unexpected counterform: {counterform}")
+    bct = np.array([-cctA - cctB, -(cr1A + cr1B) * f, -(cr2A + cr2B) * f**2, 0.0, 0.0, 0.0]) if counterform == "eastcoast" else np.array([
         b1A * cctB / kmB**2 + b1B * cctA / kmA**2,
         b1B * cr1A / krA**2 + b1A * cr1B / krB**2,
         b1B * cr2A / krA**2 + b1A * cr2B / krB**2,
@@ -59,10 +64,14 @@ def bias_row(f, bsA, bsB=None, es=(0.0, 0.0, 0.0), **scales):
 
 
 def reduce_Plk(bird, bsA, bsB=None, es=(0.0, 0.0, 0.0)):
-    """BirdLike -> BirdComponent (reference parambasis.py:42-136; NNLO and east-coast not on the path)."""
+    """BirdLike -> BirdComponent (reference parambasis.py:42-136; the counter-term form is bird.co.counterform; the NNLO
+    counter-terms are not on the path)."""
     co = bird.co
+    if getattr(co, "with_NNLO", False):
+        raise NotImplementedError("with_NNLO is off the accelerated path")
     b11, bct, bloop, bst = bias_vectors(bird.f, list(bsA), None if bsB is None else list(bsB), tuple(es),
-                                        kmA=co.kmA, krA=co.krA, ndA=co.ndA, kmB=co.kmB, krB=co.krB, ndB=co.ndB)
+                                        kmA=co.kmA, krA=co.krA, ndA=co.ndA, kmB=co.kmB, krB=co.krB, ndB=co.ndB,
+                                        counterform=getattr(co, "counterform", "westcoast"))
     No = co.No
     return BirdComponent(
         Plin=np.einsum("b,lbx->lx", b11, bird.P11l[:No]),
@@ -85,14 +94,21 @@ def gaussian_params(prefix="", cross_prefix=()):
     return [prefix + p for p in GAUSSIAN + STOCHASTIC]
 
 
-def gaussian_rows(f, ngA, ngB=None, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None, ndB=None):
+def gaussian_rows(f, ngA, ngB=None, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None, ndB=None, basis="westcoast"):
     """Coefficient rows over the 24 template rows (P11l[3], Pctl[6], Ploopl[12], Pstl[3]) of
 
         row 0        P_NG: the model with every Gaussian parameter at 0 (reference likelihood.py:524-549 via reduce_Plk)
         rows 1..nG   dP/d(gaussian parameter) in the order of ``gaussian_params`` (reference parambasis.py:249-316)
 
     for the non-Gaussian parameters ngA = (b1, b2, b4) [and ngB for a cross spectrum].  Everything downstream of the
-    templates is linear in these rows, so the device builds P_NG and P_G with one small contraction per walker."""
+    templates is linear in these rows, so the device builds P_NG and P_G with one small contraction per walker.
+    basis="eastcoast": ngA = (b1, b2, bG2), rows in the order of EastCoastBasis.gaussian_params (reference :413-444)."""
+    if basis == "eastcoast":
+        if ngB is not None:
+            raise NotImplementedError("EastCoastBasis does not support cross yet")
+        return _eastcoast_rows(f, ngA, kmA, krA, ndA)
+    if basis != "westcoast":
+        raise ValueError(f"unexpected basis: {basis}")
     cross = ngB is not None
     kmB = kmA if kmB is None else kmB
     krB = krA if krB is None else krB
@@ -102,7 +118,6 @@ def gaussian_rows(f, ngA, ngB=None, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=N
     bsA = [b1A, b2A, 0.0, b4A, 0.0, 0.0, 0.0]
     bsB = [b1B, b2B, 0.0, b4B, 0.0, 0.0, 0.0] if cross else None
     rows = [bias_row(f, bsA, bsB, (0.0, 0.0, 0.0), kmA=kmA, krA=krA, ndA=ndA, kmB=kmB, krB=krB, ndB=ndB)]
-    CT, LOOP, ST = 3, 9, 21  # first template row of Pctl, Ploopl, Pstl
 
     def row(pairs):
         r = np.zeros(24)
@@ -125,3 +140,188 @@ def gaussian_rows(f, ngA, ngB=None, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=N
     x2 = 0.5 * (1.0 / ndA / kmA**2 + 1.0 / ndB / kmB**2)
     rows += [row([(ST + 0, x1)]), row([(ST + 1, x2)]), row([(ST + 2, x2)])]
     return np.stack(rows)
+
+
+# ----------------------------------------------------------------------------- parameter bases
+CT, LOOP, ST = 3, 9, 21  # first template row of Pctl, Ploopl, Pstl in the 24-row order
+
+
+def eastcoast_to_bs(f, b1, b2, bG2, bGamma3, c0, c2, c4, Pshot=0.0, a0=0.0, a2=0.0):
+    """East-coast parameters -> (bsA, es) of reduce_Plk with counterform='eastcoast' (reference parambasis.py:378-397)."""
+    bsA = [b1, b1 + 7 / 2 * bG2, b1 + 15 * bG2 + 6 * bGamma3, 1 / 2 * b2 - 7 / 2 * bG2,
+           c0 - f / 3 * c2 + 3 / 35 * f**2 * c4, c2 - 6 / 7 * f * c4, c4]
+    es = [Pshot, a0 + 1 / 3 * a2, 2 / 3 * a2]
+    return bsA, es
+
+
+def eastcoast_bias_row(f, b1, b2, bG2, bGamma3=0.0, c0=0.0, c2=0.0, c4=0.0, Pshot=0.0, a0=0.0, a2=0.0, **scales):
+    """The 24 device-reduce coefficients for east-coast parameters (arxiv 2106.12580 convention of the reference)."""
+    bsA, es = eastcoast_to_bs(f, b1, b2, bG2, bGamma3, c0, c2, c4, Pshot, a0, a2)
+    return bias_row(f, bsA, None, es, counterform="eastcoast", **scales)
+
+
+def _eastcoast_rows(f, ng, kmA, krA, ndA):
+    b1, b2, bG2 = ng
+    rows = [eastcoast_bias_row(f, b1, b2, bG2, kmA=kmA, krA=krA, ndA=ndA)]
+
+    def row(pairs):
+        r = np.zeros(24)
+        for i, c in pairs:
+            r[i] = c
+        return r
+
+    rows.append(row([(LOOP + 3, 6.0), (LOOP + 7, 6.0 * b1)]))                                      # bGamma3
+    rows.append(row([(CT + 0, -2.0)]))                                                             # c0
+    rows.append(row([(CT + 0, 2 / 3 * f), (CT + 1, -2.0 * f)]))                                    # c2
+    rows.append(row([(CT + 0, -6 / 35 * f**2), (CT + 1, 12 / 7 * f**2), (CT + 2, -2.0 * f**2)]))   # c4
+    x1 = 1.0 / ndA
+    x2 = 1.0 / ndA / kmA**2
+    rows.append(row([(ST + 0, x1)]))                                                               # Pshot
+    rows.append(row([(ST + 1, x2)]))                                                               # a0
+    rows.append(row([(ST + 1, x2 / 3), (ST + 2, 2 * x2 / 3)]))                                     # a2
+    return np.stack(rows)
+
+
+def _table_from_rows(bird, rows, names, requires):
+    No = bird.co.No
+    T = np.concatenate([bird.P11l[:No], bird.Pctl[:No], bird.Ploopl[:No], bird.Pstl[:No]], axis=1)  # [No, 24, nx]
+    return {p: np.einsum("b,lbx->lx", r, T) for p, r in zip(names, rows) if requires is None or p in requires}
+
+
+@dataclass(frozen=True)
+class WestCoastBasis:
+    """Same surface as reference parambasis.py:166-316 (b1 b2 b3 b4 cct cr1 cr2 | ce0 cemono cequad)."""
+
+    prefix: str = ""
+    cross_prefix: list = field(default_factory=list)
+
+    def default(self):
+        return {p: 0.0 for p in self.gaussian_params()}
+
+    def bsA(self):
+        prefix = self.cross_prefix[0] if self.is_cross() else self.prefix
+        return [prefix + p for p in ("b1", "b2", "b3", "b4", "cct", "cr1", "cr2")]
+
+    def bsB(self):
+        return [self.cross_prefix[1] + p for p in ("b1", "b2", "b3", "b4", "cct", "cr1", "cr2")] if self.is_cross() else []
+
+    def es(self):
+        return [self.prefix + p for p in STOCHASTIC]
+
+    def cnnloA(self):
+        return [self.prefix + p for p in ("cr4", "cr6")]
+
+    def is_cross(self):
+        return bool(self.cross_prefix)
+
+    @classmethod
+    def get_name(cls):
+        return "westcoast"
+
+    @classmethod
+    def counterform(cls):
+        return "westcoast"
+
+    def non_gaussian_params(self):
+        names = ("b1", "b2", "b4")
+        if self.is_cross():
+            return [x + p for x in self.cross_prefix for p in names]
+        return [self.prefix + p for p in names]
+
+    def gaussian_params(self):
+        if self.is_cross():
+            return gaussian_params(self.prefix, self.cross_prefix)
+        return gaussian_params(self.prefix) + self.cnnloA()  # the NNLO names never enter the table (as the reference)
+
+    def reduce_Plk(self, bird, params_values_dict):
+        v = self.default()
+        v.update(params_values_dict)
+        return reduce_Plk(bird, [v[p] for p in self.bsA()], [v[p] for p in self.bsB()] or None, [v[p] for p in self.es()])
+
+    def bias_row(self, f, params_values_dict, **scales):
+        """Device-reduce coefficients for one walker (the batched counterpart of reduce_Plk)."""
+        v = self.default()
+        v.update(params_values_dict)
+        return bias_row(f, [v[p] for p in self.bsA()], [v[p] for p in self.bsB()] or None, [v[p] for p in self.es()], **scales)
+
+    def gaussian_rows(self, f, params_values_dict, **scales):
+        ng = [[params_values_dict[x + p] for p in ("b1", "b2", "b4")] for x in (self.cross_prefix or [self.prefix])]
+        return gaussian_rows(f, ng[0], ng[1] if self.is_cross() else None, **scales)
+
+    def reduce_Plk_gaussian_table(self, bird, params_values_dict, requires=None):
+        co = bird.co
+        rows = self.gaussian_rows(bird.f, params_values_dict, kmA=co.kmA, krA=co.krA, ndA=co.ndA, kmB=co.kmB, krB=co.krB, ndB=co.ndB)
+        return _table_from_rows(bird, rows[1:], gaussian_params(self.prefix, self.cross_prefix), requires)
+
+
+@dataclass(frozen=True)
+class EastCoastBasis:
+    """Same surface as reference parambasis.py:320-454 (b1 b2 bG2 bGamma3 c0 c2 c4 | Pshot a0 a2; auto spectra only)."""
+
+    prefix: str = ""
+    cross_prefix: list = field(default_factory=list)
+
+    def __post_init__(self):
+        if self.cross_prefix:
+            raise NotImplementedError("EastCoastBasis does not support cross yet")
+
+    def default(self):
+        return {p: 0.0 for p in self.gaussian_params()}
+
+    def bsA(self):
+        return [self.prefix + p for p in ("b1", "b2", "bG2", "bGamma3", "c0", "c2", "c4")]
+
+    def es(self):
+        return [self.prefix + p for p in ("Pshot", "a0", "a2")]
+
+    def cnnloA(self):
+        return [self.prefix + "ctilde"]
+
+    def is_cross(self):
+        return False
+
+    @classmethod
+    def get_name(cls):
+        return "eastcoast"
+
+    @classmethod
+    def counterform(cls):
+        return "eastcoast"
+
+    def non_gaussian_params(self):
+        return [self.prefix + p for p in ("b1", "b2", "bG2")]
+
+    def gaussian_params(self):
+        return [self.prefix + p for p in ("bGamma3", "c0", "c2", "c4", "Pshot", "a0", "a2")] + self.cnnloA()
+
+    def _values(self, params_values_dict):
+        v = self.default()
+        v.update(params_values_dict)
+        return [v[p] for p in self.bsA() + self.es()]
+
+    def reduce_Plk(self, bird, params_values_dict):
+        bsA, es = eastcoast_to_bs(bird.f, *self._values(params_values_dict))
+        return reduce_Plk(bird, bsA, None, es)  # bird.co.counterform must be 'eastcoast', as in the reference
+
+    def bias_row(self, f, params_values_dict, **scales):
+        return eastcoast_bias_row(f, *self._values(params_values_dict), **scales)
+
+    def gaussian_rows(self, f, params_values_dict, **scales):
+        return gaussian_rows(f, [params_values_dict[self.prefix + p] for p in ("b1", "b2", "bG2")], basis="eastcoast", **scales)
+
+    def reduce_Plk_gaussian_table(self, bird, params_values_dict, requires=None):
+        co = bird.co
+        rows = self.gaussian_rows(bird.f, params_values_dict, kmA=co.kmA, krA=co.krA, ndA=co.ndA)
+        return _table_from_rows(bird, rows[1:], self.gaussian_params()[:7], requires)
+
+
+def find_param_basis(name):
+    """reference parambasis.py:457-466"""
+    if name == "westcoast":
+        return WestCoastBasis
+    if name == "eastcoast":
+        return EastCoastBasis
+    import importlib
+
+    module_name, class_name = name.rsplit(".", 1)
+    return getattr(importlib.import_module(module_name), class_name)

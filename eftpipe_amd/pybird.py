@@ -55,8 +55,8 @@ class Common(object):
                  ndB=None, counterform="westcoast", with_NNLO=False, kIR=None, IRcutoff=False):
         if optiresum or with_NNLO or IRcutoff:
             raise NotImplementedError("optiresum / with_NNLO / IRcutoff are outside the accelerated hot path (SURVEY.md 8a)")
-        if counterform != "westcoast":
-            raise NotImplementedError("only counterform='westcoast' is on the accelerated path")
+        if counterform not in ("westcoast", "eastcoast"):  # the templates are the same; only reduce_Plk reads it
+            raise ValueError(f"unexpected counterform: {counterform}")
         self.optiresum, self.with_NNLO, self.IRcutoff, self.kIR = False, False, False, kIR
         self.counterform = counterform
         self.kmA, self.krA, self.ndA = kmA, krA, ndA

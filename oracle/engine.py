@@ -389,8 +389,8 @@ class OracleEngine:
             out[name] = np.einsum("al,l...->a...", mat, st[name], optimize=True)
         return out
 
-    def bias_vectors(self, f, bsA, bsB=None, es=(0.0, 0.0, 0.0)):
-        """West-coast bias vectors (reference parambasis.py:69-126)."""
+    def bias_vectors(self, f, bsA, bsB=None, es=(0.0, 0.0, 0.0), counterform="westcoast"):
+        """Bias vectors (reference parambasis.py:69-126); east-coast counter-terms: :99-106."""
         b1A, b2A, b3A, b4A, cctA, cr1A, cr2A = bsA
         b1B, b2B, b3B, b4B, cctB, cr1B, cr2B = bsB or bsA
         kmA, krA, ndA, kmB, krB, ndB = self.kmA, self.krA, self.ndA, self.kmB, self.krB, self.ndB
@@ -416,11 +416,13 @@ class OracleEngine:
         x1 = 0.5 * (1.0 / ndA + 1.0 / ndB)
         x2 = 0.5 * (1.0 / ndA / kmA**2 + 1.0 / ndB / kmB**2)
         bst = np.array([ce0 * x1, cemono * x2, cequad * x2])
+        if counterform == "eastcoast":
+            bct = np.array([-cctA - cctB, -(cr1A + cr1B) * f, -(cr2A + cr2B) * f**2, 0.0, 0.0, 0.0])
         return b11, bloop, bct, bst
 
-    def reduce_plk(self, f, st, bsA, bsB=None, es=(0.0, 0.0, 0.0)):
+    def reduce_plk(self, f, st, bsA, bsB=None, es=(0.0, 0.0, 0.0), counterform="westcoast"):
         """P_l(k) = b11.P11l + bloop.Ploopl + bct.Pctl + bst.Pstl + Picc (parambasis.py:128-136)."""
-        b11, bloop, bct, bst = self.bias_vectors(f, bsA, bsB, es)
+        b11, bloop, bct, bst = self.bias_vectors(f, bsA, bsB, es, counterform)
         No = min(self.No, st["P11l"].shape[0])
         return (
             np.einsum("b,lbx->lx", b11, st["P11l"][:No])

@@ -1,7 +1,7 @@
 """CPU restatement of the Gaussian (derivative) table and the analytically marginalised log-posterior.
 
 TEST INFRASTRUCTURE: imported only by tests/, smoke() and bench.py's cpu_baseline.  Follows
-  * reference eftpipe/parambasis.py:249-316  (WestCoastBasis.derivative_table: dP_l/d(gaussian parameter))
+  * reference eftpipe/parambasis.py:249-316  (WestCoastBasis.derivative_table: dP_l/d(gaussian parameter)), :378-444 (EastCoastBasis)
   * reference eftpipe/likelihood.py:167-195  (flatten: multipoles x masked k bins -> data-vector order)
   * reference eftpipe/marginal.py:79-203     (Marginalizable.marginalized_logp and calc_F0 / calc_F1i / calc_F2ij)
 Pinned by tests/test_oracle_golden.py against tests/golden/marg.npz (outputs of the real reference, tools/make_fixtures.py marg).
@@ -43,6 +43,31 @@ def derivative_table(st, f, b1A, b1B=None, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None
     x2 = 0.5 * (1.0 / ndA / kmA**2 + 1.0 / ndB / kmB**2)
     out += [Pstl[:, 0] * x1, Pstl[:, 1] * x2, Pstl[:, 2] * x2]
     return out
+
+
+EAST_GAUSSIAN = ("bGamma3", "c0", "c2", "c4", "Pshot", "a0", "a2")
+
+
+def eastcoast_bs(f, b1, b2, bG2, bGamma3=0.0, c0=0.0, c2=0.0, c4=0.0, Pshot=0.0, a0=0.0, a2=0.0):
+    """EastCoastBasis.reduce_Plk's parameter map (parambasis.py:378-397) -> (bsA, es) for reduce_plk(counterform='eastcoast')"""
+    bsA = [b1, b1 + 7 / 2 * bG2, b1 + 15 * bG2 + 6 * bGamma3, 1 / 2 * b2 - 7 / 2 * bG2,
+           c0 - f / 3 * c2 + 3 / 35 * f**2 * c4, c2 - 6 / 7 * f * c4, c4]
+    return bsA, [Pshot, a0 + 1 / 3 * a2, 2 / 3 * a2]
+
+
+def eastcoast_derivative_table(st, f, b1, kmA=0.7, ndA=3e-4):
+    """EastCoastBasis.reduce_Plk_gaussian_table (parambasis.py:399-444), order EAST_GAUSSIAN; auto spectra only."""
+    Ploopl, Pctl, Pstl = st["Ploopl"], st["Pctl"], st["Pstl"]
+    x1, x2 = 1.0 / ndA, 1.0 / ndA / kmA**2
+    return [
+        6.0 * (Ploopl[:, 3] + b1 * Ploopl[:, 7]),
+        -2.0 * Pctl[:, 0],
+        2 / 3 * f * Pctl[:, 0] - 2.0 * f * Pctl[:, 1],
+        -6 / 35 * f**2 * Pctl[:, 0] + 12 / 7 * f**2 * Pctl[:, 1] - 2.0 * f**2 * Pctl[:, 2],
+        x1 * Pstl[:, 0],
+        x2 * Pstl[:, 1],
+        x2 / 3 * (Pstl[:, 1] + 2.0 * Pstl[:, 2]),
+    ]
 
 
 def flatten(ls, array, masks):

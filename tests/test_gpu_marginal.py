@@ -89,3 +89,58 @@ def test_marginal_error_paths(golden):
     with pytest.raises(RuntimeError, match="det of F2ij"):
         like.logp(np.zeros((1, 8, 24)))
     eng.close()
+
+
+def test_eastcoast_basis_on_device(golden):
+    """EastCoastBasis (reference parambasis.py:320-454).  The templates are basis independent, so the
+    east-coast parameters enter the device through the 24 reduce coefficients (REDUCE stage) and the Gaussian rows (LOGP stage)."""
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index
+    from eftpipe_amd.parambasis import EastCoastBasis
+    from oracle import marginal as M
+
+    g, c = golden("east"), golden("caseC")
+    B = 4
+    nx = c["binned_P11l"].shape[-1]
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    eng = Engine(EngineConfig(Nl=3), max_batch=B)
+    eng.set_template_dims(3, nx)
+    T = np.concatenate([c["binned_P11l"], c["binned_Pctl"], c["binned_Ploopl"], c["binned_Pstl"]], axis=1)
+    f = float(g["f"])
+    kmA, krA, ndA = g["co"]
+    basis = EastCoastBasis(prefix="")
+    full = dict(zip(g["full_names"], g["full_values"]))
+    walkers = [dict(full, b1=full["b1"] + 0.1 * i, bG2=full["bG2"] - 0.05 * i, c2=full["c2"] * (1 + i)) for i in range(B)]
+    templ = np.stack([T * (1.0 + 0.1 * i) for i in range(B)])
+    eng.put("TEMPL", templ)
+    # REDUCE: P_l = east-coast coefficients . templates
+    eng.put("BIAS", np.stack([basis.bias_row(f, w, kmA=kmA, krA=krA, ndA=ndA) for w in walkers]))
+    eng.run(L.S_REDUCE, B)
+    plk = eng.get("PLK", (B, 3, nx))
+    assert relerr(plk[0], g["plk"]) < 1e-13
+    from oracle import OracleConfig, OracleEngine
+
+    orc = OracleEngine(OracleConfig(Nl=3, kmA=kmA, krA=krA, ndA=ndA))
+    for i, w in enumerate(walkers):
+        st = {"P11l": templ[i][:, 0:3], "Pctl": templ[i][:, 3:9], "Ploopl": templ[i][:, 9:21], "Pstl": templ[i][:, 21:24], "Picc": np.zeros((3, nx))}
+        bsA, es = M.eastcoast_bs(f, **w)
+        assert relerr(plk[i], orc.reduce_plk(f, st, bsA, None, es, counterform="eastcoast")) < 1e-13, i
+    # LOGP: marginalise bGamma3, c0, c2, c4, Pshot, a0, a2
+    ls = list(g["ls"])
+    index = data_index(ls, {l: slice(a, b) for l, (a, b) in zip(ls, g["masks"])}, nx)
+    like = MarginalLikelihood(eng, index, g["D"], g["invcov"], g["loc"], g["scale"])
+    rows = np.stack([basis.gaussian_rows(f, w, kmA=kmA, krA=krA, ndA=ndA) for w in walkers])
+    logp, fullchi2, best = like.logp(rows, return_best=True)
+    assert np.isclose(logp[0], g["logp"], rtol=1e-10) and np.isclose(fullchi2[0], g["fullchi2"], rtol=1e-9)
+    assert relerr(best[0][None], g["best"][None]) < 1e-8
+    for i, w in enumerate(walkers):
+        st = {"Pctl": templ[i][:, 3:9], "Ploopl": templ[i][:, 9:21], "Pstl": templ[i][:, 21:24]}
+        PG = np.stack([M.flatten(ls, t, {l: slice(a, b) for l, (a, b) in zip(ls, g["masks"])}) for t in M.eastcoast_derivative_table(st, f, w["b1"], kmA, ndA)])
+        PNG = (np.einsum("b,lbx->lx", rows[i][0], templ[i])).reshape(-1)[index]
+        want = M.marginalized_logp(PG, PNG, g["D"], g["invcov"], g["loc"], g["scale"])
+        assert np.isclose(logp[i], want, rtol=1e-10), i
+    like_j = MarginalLikelihood(eng, index, g["D"], g["invcov"], g["loc"], g["scale"], jeffreys=True)
+    assert np.isclose(like_j.logp(rows)[0], g["logp_jeffreys"], rtol=1e-10)
+    eng.close()

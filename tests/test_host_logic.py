@@ -155,3 +155,52 @@ def test_plk_interpolator_operator(golden):
     assert relerr(fn(2, kout)[None], want[1][None]) < 1e-11 and fn(4, 0.1).shape == ()
     with pytest.raises(ValueError, match="not in"):
         fn(6, kout)
+
+
+def test_parameter_bases_mirror_reference(golden):
+    """WestCoastBasis / EastCoastBasis / find_param_basis (reference parambasis.py:166-466) on reference-generated fixtures."""
+    from types import SimpleNamespace
+
+    from eftpipe_amd import parambasis as P
+    from eftpipe_amd import pybird
+
+    c = golden("caseC")
+    templ = {n: c["binned_" + n] for n in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc")}
+    # east coast
+    g = golden("east")
+    basis = P.find_param_basis("eastcoast")(prefix="")
+    assert basis.get_name() == basis.counterform() == "eastcoast"
+    assert basis.gaussian_params() == list(g["gaussian_params"]) and basis.non_gaussian_params() == list(g["non_gaussian_params"])
+    with pytest.raises(NotImplementedError):
+        P.EastCoastBasis(prefix="X_", cross_prefix=["A_", "B_"])
+    kmA, krA, ndA = g["co"]
+    co = pybird.Common(Nl=3, kmA=kmA, krA=krA, ndA=ndA, counterform="eastcoast")
+    bird = SimpleNamespace(f=float(g["f"]), co=co, **templ)
+    full = dict(zip(g["full_names"], g["full_values"]))
+    comp = basis.reduce_Plk(bird, full)
+    for n in ("Plin", "Ploop", "Pct", "Pst"):
+        assert relerr(getattr(comp, n), g[n]) < 1e-14, n
+    assert relerr(comp.sum(), g["plk"]) < 1e-14
+    ng = {p: full[p] for p in ("b1", "b2", "bG2")}
+    table = basis.reduce_Plk_gaussian_table(bird, ng)
+    assert list(table) == list(g["names"])
+    assert relerr(np.stack(list(table.values())).reshape(7, -1), g["table"].reshape(7, -1)) < 1e-14
+    assert list(basis.reduce_Plk_gaussian_table(bird, ng, requires={"c2", "a2"})) == ["c2", "a2"]
+    T = np.concatenate([templ[n] for n in ("P11l", "Pctl", "Ploopl", "Pstl")], axis=1)
+    row = basis.bias_row(bird.f, full, kmA=kmA, krA=krA, ndA=ndA)
+    assert relerr(np.einsum("b,lbx->lx", row, T), g["plk"]) < 1e-14  # what the device reduce contracts
+    rows = basis.gaussian_rows(bird.f, ng, kmA=kmA, krA=krA, ndA=ndA)
+    assert relerr(np.einsum("b,lbx->lx", rows[0], T), g["PNGl"]) < 1e-14
+    with pytest.raises(ValueError):
+        pybird.Common(Nl=3, counterform="southcoast")
+    # west coast, auto and cross
+    m = golden("marg")
+    for tag, basis in (("auto", P.find_param_basis("westcoast")(prefix="")), ("cross", P.WestCoastBasis(prefix="X_", cross_prefix=["A_", "B_"]))):
+        kmA, krA, ndA, kmB, krB, ndB = m[tag + "_co"]
+        bird = SimpleNamespace(f=float(m["f"]), co=pybird.Common(Nl=3, kmA=kmA, krA=krA, ndA=ndA, kmB=kmB, krB=krB, ndB=ndB), **templ)
+        ng = dict(zip(m[tag + "_ng_names"], m[tag + "_ng_values"]))
+        assert list(ng) == basis.non_gaussian_params() and basis.get_name() == "westcoast"
+        table = basis.reduce_Plk_gaussian_table(bird, ng)
+        assert list(table) == list(m[tag + "_names"])
+        assert relerr(np.stack(list(table.values())).reshape(len(table), -1), m[tag + "_table"].reshape(len(table), -1)) < 1e-14
+        assert relerr(basis.reduce_Plk(bird, ng).sum(), m[tag + "_PNGl"]) < 1e-14

@@ -158,3 +158,29 @@ def test_gaussian_table_and_marginalised_logp(golden, tag):
     if tag == "auto":  # cross + flat prior is singular (cond F2 = 2e18): the sign of det F2 is rounding noise there
         flat = M.marginalized_logp(*args[:4], np.zeros(len(names)), np.full(len(names), np.inf))
         assert np.isclose(flat, g[tag + "_logp_flat"], rtol=1e-12)
+
+
+def test_eastcoast_basis(golden):
+    """oracle == reference EastCoastBasis (reduce_Plk with counterform='eastcoast', Gaussian table)."""
+    from oracle import OracleConfig
+    from oracle import marginal as M
+
+    g, c = golden("east"), golden("caseC")
+    st = {n: c["binned_" + n] for n in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc")}
+    f = float(g["f"])
+    kmA, krA, ndA = g["co"]
+    eng = OracleEngine(OracleConfig(Nl=3, kmA=kmA, krA=krA, ndA=ndA))
+    full = dict(zip(g["full_names"], g["full_values"]))
+    bsA, es = M.eastcoast_bs(f, **full)
+    assert relerr(eng.reduce_plk(f, st, bsA, None, es, counterform="eastcoast"), g["plk"]) < 1e-14
+    b11, bloop, bct, bst = eng.bias_vectors(f, bsA, None, es, counterform="eastcoast")
+    assert relerr(np.einsum("b,lbx->lx", bct, st["Pctl"]), g["Pct"]) < 1e-14
+    assert relerr(np.einsum("b,lbx->lx", bst, st["Pstl"]), g["Pst"]) < 1e-14
+    assert list(g["names"]) == list(M.EAST_GAUSSIAN)
+    table = M.eastcoast_derivative_table(st, f, full["b1"], kmA, ndA)
+    assert relerr(np.stack(table).reshape(7, -1), g["table"].reshape(7, -1)) < 1e-14
+    bs0, es0 = M.eastcoast_bs(f, full["b1"], full["b2"], full["bG2"])
+    assert relerr(eng.reduce_plk(f, st, bs0, None, es0, counterform="eastcoast"), g["PNGl"]) < 1e-14
+    logp, fullchi2, best, _ = M.marginalized_logp(g["PG"], g["PNG"], g["D"], g["invcov"], g["loc"], g["scale"], return_best=True)
+    assert np.isclose(logp, g["logp"], rtol=1e-12) and np.isclose(fullchi2, g["fullchi2"], rtol=1e-10)
+    assert relerr(best[None], g["best"][None]) < 1e-10

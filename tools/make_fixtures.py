@@ -229,6 +229,74 @@ def marg_fixture(ref):
     print("marg written:", {k: np.shape(v) for k, v in out.items() if k.endswith(("_PG", "_logp"))})
 
 
+def east_fixture(ref):
+    """the east-coast parameter basis, from the REAL reference (parambasis.EastCoastBasis.reduce_Plk,
+    .reduce_Plk_gaussian_table with Common(counterform='eastcoast')) on the binned templates of caseC, plus the
+    marginalised log-posterior over its Gaussian parameters."""
+    pb = ref.pybird
+    g = dict(np.load(os.path.join(GOLD, "caseC.npz"), allow_pickle=True))
+    Nl = int(g["Nl"])
+    rng = np.random.default_rng(20250818)
+    ls = [0, 2, 4]
+    masks = {0: slice(0, 16), 2: slice(2, 14), 4: slice(1, 9)}
+    flat = lambda a: np.hstack([a[l // 2, masks[l]] for l in ls])
+    co = make_common(pb, Nl, None, counterform="eastcoast")
+    nnlo = np.zeros((Nl, 3, g["binned_P11l"].shape[-1]))
+    bird = ref.transformer.PlainBird(f=float(g["f"]), co=co, P11l=g["binned_P11l"], Ploopl=g["binned_Ploopl"], Pctl=g["binned_Pctl"],
+                                     Pstl=g["binned_Pstl"], Picc=g["binned_Picc"], PctNNLOl=nnlo)
+    basis = ref.parambasis.EastCoastBasis(prefix="")
+    assert basis.counterform() == "eastcoast" and ref.parambasis.find_param_basis("eastcoast") is type(basis)
+    full = {"b1": 2.1, "b2": -0.4, "bG2": 0.25, "bGamma3": -0.3, "c0": 5.0, "c2": 12.0, "c4": -3.0, "Pshot": 0.4, "a0": -0.6, "a2": 1.1}
+    ng = {p: full[p] for p in ("b1", "b2", "bG2")}
+    table = basis.reduce_Plk_gaussian_table(bird, ng)
+    names = [p for p in basis.gaussian_params() if p in table]
+    comp = basis.reduce_Plk(bird, full)
+    PNGl = basis.reduce_Plk(bird, ng).sum()
+    PG, PNG = np.stack([flat(table[p]) for p in names]), flat(PNGl)
+    ndata = PNG.size
+    truth = rng.normal(scale=0.5, size=len(names))
+    sig = 0.03 * np.abs(PNG) + 5.0
+    D = PNG + truth @ PG + sig * rng.normal(size=ndata)
+    A = rng.normal(size=(ndata, ndata)) * 0.05
+    invcov = np.linalg.inv(np.diag(sig) @ (np.eye(ndata) + A @ A.T) @ np.diag(sig))
+    invcov = 0.5 * (invcov + invcov.T)
+    loc = rng.normal(scale=0.3, size=len(names))
+    scale = rng.uniform(1.0, 4.0, size=len(names))
+
+    class Like(ref.marginal.Marginalizable):
+        def marginalizable_params(self):
+            return list(names)
+
+        def PG(self):
+            return PG
+
+        def PNG(self):
+            return PNG
+
+        def get_data_vector(self):
+            return D
+
+        def get_invcov(self):
+            return invcov
+
+        def mpi_debug(self, *a, **k):
+            pass
+
+        mpi_warning = mpi_info = mpi_debug
+
+    like = Like()
+    like.setup_prior({p: {"loc": float(l0), "scale": float(s0)} for p, l0, s0 in zip(names, loc, scale)})
+    logp, fullchi2, best = like.marginalized_logp(return_bGbest=True)
+    out = dict(f=g["f"], ls=np.array(ls), masks=np.array([[masks[l].start, masks[l].stop] for l in ls]),
+               co=np.array([co.kmA, co.krA, co.ndA]), names=np.array(names), gaussian_params=np.array(basis.gaussian_params()),
+               non_gaussian_params=np.array(basis.non_gaussian_params()), full_names=np.array(list(full)),
+               full_values=np.array(list(full.values())), Plin=comp.Plin, Ploop=comp.Ploop, Pct=comp.Pct, Pst=comp.Pst, plk=comp.sum(),
+               table=np.stack([table[p] for p in names]), PNGl=PNGl, PG=PG, PNG=PNG, D=D, invcov=invcov, loc=loc, scale=scale,
+               logp=logp, fullchi2=fullchi2, best=np.array([best[p] for p in names]), logp_jeffreys=like.marginalized_logp(jeffreys=True))
+    np.savez_compressed(os.path.join(GOLD, "east.npz"), **out)
+    print("east written:", names, float(logp))
+
+
 def pyegg_fixture(ref):
     """the on-disk layout of the reference's loop-matrix cache pyegg{NFFT}_Nl{Nl}.npz (pybird.py:968-981):
     keys, shapes, dtypes and spot values of every array (the 150 MB file itself is not committed)."""
@@ -303,7 +371,7 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -311,6 +379,8 @@ def main():
             marg_fixture(ref)
         elif name == "pyegg":
             pyegg_fixture(ref)
+        elif name == "east":
+            east_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
