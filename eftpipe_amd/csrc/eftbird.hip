@@ -63,6 +63,7 @@ struct eftb_engine {
     int pipeline_op = -1;
     // likelihood of the LOGP stage (eftb_set_likelihood)
     int like_ndata = 0, like_nG = 0, jeffreys = 0;
+    std::vector<double> like_host;  // eftb_eval_logp_batch: D2H landing block [B][MARG_OUT]
     int* like_index = nullptr;
     double *like_data = nullptr, *like_invcov = nullptr, *like_mu = nullptr, *like_sinv = nullptr;
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
@@ -701,14 +702,13 @@ int eftb_run_timed(eftb_engine* e, int mask, int B, int repeats, float* ms) {
     return 0;
 }
 
-int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, double* templ,
-                    const double* bias, double* plk) {
-    if (!e || !Pin || !f || !templ) return fail("eftb_eval_batch: null argument");
-    if (!e->finalized) return fail("eftb_eval_batch: engine not finalized");
+// inputs of one batch -> device (engine stream), then the theory stages of reference theory.py:557-585
+static int upload_and_launch(eftb_engine* e, const char* who, int B, const double* Pin, const double* f, const double* DA, const double* H,
+                             int extra_mask) {
+    if (!e->finalized) return fail("%s: engine not finalized", who);
     const eftb_config& c = e->c;
-    if (B < 1 || B > c.max_batch) return fail("eftb_eval_batch: batch %d outside [1, %d]", B, c.max_batch);
-    if (c.with_ap && (!DA || !H)) return fail("eftb_eval_batch: DA and H are required when with_ap=1");
-    if (plk && !bias) return fail("eftb_eval_batch: bias is required when plk is requested");
+    if (B < 1 || B > c.max_batch) return fail("%s: batch %d outside [1, %d]", who, B, c.max_batch);
+    if (c.with_ap && (!DA || !H)) return fail("%s: DA and H are required when with_ap=1", who);
     HIPCHK(hipSetDevice(c.device));
     hipStream_t st = e->stream;
     HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double), hipMemcpyHostToDevice, st));
@@ -717,17 +717,67 @@ int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, c
         HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_DA], DA, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_H], H, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
     }
-    if (plk) HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_BIAS], bias, (size_t)B * NROW * sizeof(double), hipMemcpyHostToDevice, st));
-    int mask = EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_REGROUP;
+    int mask = EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_REGROUP | extra_mask;
     if (c.with_resum) mask |= EFTB_S_CF | EFTB_S_RESUM;
     if (c.with_ap) mask |= EFTB_S_AP;
     if (e->pipeline_op >= 0) mask |= EFTB_S_PROJECT;
-    if (plk) mask |= EFTB_S_REDUCE;
-    if (int rc = launch_stages(e, mask, B)) return rc;
-    HIPCHK(hipMemcpyAsync(templ, e->buf[EFTB_B_TEMPL], (size_t)B * e->cur_nl * NROW * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, st));
+    return launch_stages(e, mask, B);
+}
+
+int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, double* templ,
+                    const double* bias, double* plk) {
+    if (!e || !Pin || !f || (!templ && !plk)) return fail("eftb_eval_batch: null argument");
+    if (plk && !bias) return fail("eftb_eval_batch: bias is required when plk is requested");
+    if (plk && B >= 1 && B <= e->c.max_batch) {
+        HIPCHK(hipSetDevice(e->c.device));
+        HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_BIAS], bias, (size_t)B * NROW * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    }
+    if (int rc = upload_and_launch(e, "eftb_eval_batch", B, Pin, f, DA, H, plk ? EFTB_S_REDUCE : 0)) return rc;
+    hipStream_t st = e->stream;
+    if (templ)
+        HIPCHK(hipMemcpyAsync(templ, e->buf[EFTB_B_TEMPL], (size_t)B * e->cur_nl * NROW * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, st));
     if (plk) HIPCHK(hipMemcpyAsync(plk, e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
+}
+
+int eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* rows,
+                         double* logp, double* fullchi2, double* best) {
+    if (!e || !Pin || !f || !rows || !logp) return fail("eftb_eval_logp_batch: null argument");
+    if (!e->finalized) return fail("eftb_eval_logp_batch: engine not finalized");
+    if (!e->like_ndata) return fail("eftb_eval_logp_batch: needs eftb_set_likelihood");
+    if (B < 1 || B > e->c.max_batch) return fail("eftb_eval_logp_batch: batch %d outside [1, %d]", B, e->c.max_batch);
+    HIPCHK(hipSetDevice(e->c.device));
+    hipStream_t st = e->stream;
+    const int ng1 = e->like_nG + 1;
+    // rows arrive packed [B][nG+1][24]; the device block is [B][MARG_NG1][24]
+    HIPCHK(hipMemcpy2DAsync(e->buf[EFTB_B_GROWS], (size_t)MARG_NG1 * NROW * sizeof(double), rows, (size_t)ng1 * NROW * sizeof(double),
+                            (size_t)ng1 * NROW * sizeof(double), B, hipMemcpyHostToDevice, st));
+    if (int rc = upload_and_launch(e, "eftb_eval_logp_batch", B, Pin, f, DA, H, EFTB_S_LOGP)) return rc;
+    e->like_host.resize((size_t)B * MARG_OUT);
+    HIPCHK(hipMemcpyAsync(e->like_host.data(), e->buf[EFTB_B_LOGP], (size_t)B * MARG_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int w = 0; w < B; ++w) {
+        const double* o = e->like_host.data() + (size_t)w * MARG_OUT;
+        logp[w] = o[0];
+        if (fullchi2) fullchi2[w] = o[1];
+        if (best)
+            for (int i = 0; i < e->like_nG; ++i) best[(size_t)w * e->like_nG + i] = o[2 + i];
+    }
+    return 0;
+}
+
+void* eftb_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail("eftb_host_alloc: hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void eftb_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int eftb_comm_unique_id(char id[128]) {

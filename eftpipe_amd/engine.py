@@ -186,22 +186,39 @@ class Engine:
         return m
 
     # ------------------------------------------------------------------ whole path
-    def eval_batch(self, Pin, f, DA=None, H=None, bias=None):
-        """Pin [B, Nkin], f/DA/H [B] -> templates [B, nl, 24, nx] (+ P_l [B, nl, nx] if bias [B, 24]);
-        (nl, nx) = out_dims(): (Nl, Nk) unless a pipeline operator (window / binning / chained) is set."""
+    def _inputs(self, Pin, f, DA, H):
         Pin = np.ascontiguousarray(np.atleast_2d(Pin), dtype=np.float64)
         B = Pin.shape[0]
         as1 = lambda x: None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (B,)))
-        f, DA, H = as1(f), as1(DA), as1(H)
+        return B, Pin, as1(f), as1(DA), as1(H)
+
+    def eval_batch(self, Pin, f, DA=None, H=None, bias=None, templates=True, out=None):
+        """Pin [B, Nkin], f/DA/H [B] -> templates [B, nl, 24, nx] (+ P_l [B, nl, nx] if bias [B, 24]);
+        (nl, nx) = out_dims(): (Nl, Nk) unless a pipeline operator (window / binning / chained) is set.
+        templates=False (needs bias): only P_l crosses PCIe.  out: a template array to fill, e.g. ``pinned_empty`` memory
+        re-used across calls (D2H at the PCIe rate instead of through the pageable staging copy)."""
+        B, Pin, f, DA, H = self._inputs(Pin, f, DA, H)
         nl, nx = self.out_dims()
-        templ = np.empty((B, nl, NROW, nx))
+        if not templates and bias is None:
+            raise ValueError("templates=False needs bias (nothing to return otherwise)")
+        templ = None
+        if templates:
+            templ = np.empty((B, nl, NROW, nx)) if out is None else out
+            if templ.shape != (B, nl, NROW, nx) or templ.dtype != np.float64 or not templ.flags["C_CONTIGUOUS"]:
+                raise ValueError(f"out must be C-contiguous float64 {(B, nl, NROW, nx)}")
         plk = None
         if bias is not None:
             bias = np.ascontiguousarray(bias, dtype=np.float64).reshape(B, NROW)
             plk = np.empty((B, nl, nx))
         L.check(self.lib.eftb_eval_batch(self._h, B, L.dptr(Pin), L.dptr(f), L.dptr(DA), L.dptr(H), L.dptr(templ),
                                          L.dptr(bias), L.dptr(plk)))
+        if not templates:
+            return plk
         return (templ, plk) if bias is not None else templ
+
+    def pinned_empty(self, shape):
+        """Page-locked float64 host array for eval_batch(out=...) / put / get."""
+        return L.pinned_empty(shape)
 
     def load_inputs(self, Pin, f, DA=None, H=None, bias=None):
         """Make a batch resident in HBM (what a sampler would keep there between steps)."""

@@ -75,4 +75,20 @@ class MarginalLikelihood:
         return out[:, 0]
 
 
+    def eval_logp(self, Pin, f, DA, H, rows, return_best=False):
+        """Theory + likelihood in one call (``eftb_eval_logp_batch``): Pin [B, Nkin], f/DA/H [B], rows [B, nG + 1, 24] ->
+        ln P_marg [B]; only the inputs and B floats cross PCIe.  The engine's pipeline operator must bring the templates to
+        the shape the data index refers to."""
+        B, Pin, f, DA, H = self.eng._inputs(Pin, f, DA, H)
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if rows.shape != (B, self.nG + 1, 24):
+            raise ValueError(f"rows must be [{B}, {self.nG + 1}, 24]")
+        logp, full, best = np.empty(B), np.empty(B), np.empty((B, self.nG))
+        L.check(self.eng.lib.eftb_eval_logp_batch(self.eng._h, B, L.dptr(Pin), L.dptr(f), L.dptr(DA), L.dptr(H), L.dptr(rows),
+                                                  L.dptr(logp), L.dptr(full), L.dptr(best)))
+        if np.any(np.isnan(logp)):
+            raise RuntimeError("det of F2ij <= 0")
+        return (logp, full, best) if return_best else logp
+
+
 __all__ = ["MarginalLikelihood", "data_index", "gaussian_params", "gaussian_rows"]

@@ -149,9 +149,23 @@ int  eftb_run_timed(eftb_engine* e, int stage_mask, int B, int repeats, float* m
 
 /* One call = reference theory.py:557-585 for a batch: host inputs in, templates out.
  * templ is [B][nl][24][nx] (rows as EFTB_B_TEMPL; (nl, nx) = the pipeline operator's output shape, else (Nl, Nk));
- * plk [B][nl][nx] may be NULL, else bias must be [B][24]. */
+ * plk [B][nl][nx] may be NULL, else bias must be [B][24]; templ may be NULL when plk is requested (P_l only: 12 KB instead
+ * of 0.3 MB per cosmology over PCIe at Nl=3, Nk=512). */
 int  eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA,
                      const double* H, double* templ, const double* bias, double* plk);
+
+/* One call = theory + likelihood for a batch of walkers: reference theory.py:557-609, then EFTLike.PNG/PG
+ * (likelihood.py:483-549) and Marginalizable.marginalized_logp (marginal.py:79-140).  Host inputs in, one marginalised
+ * log-posterior per walker out; nothing else crosses PCIe.  Needs eftb_set_likelihood (and the pipeline operator that
+ * brings the templates to the data's shape).  rows is PACKED [B][nG+1][24] (eftpipe_amd.parambasis.gaussian_rows);
+ * logp [B] (NaN where det F2 <= 0: the reference raises there); fullchi2 [B] and best [B][nG] may be NULL. */
+int  eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H,
+                          const double* rows, double* logp, double* fullchi2, double* best);
+
+/* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
+ * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */
+void* eftb_host_alloc(size_t bytes);
+void  eftb_host_free(void* p);
 
 /* Multi-GPU: cosmologies are sharded over ranks (one process per GPU); the only exchange is the gather of
  * the per-cosmology P_l(k) to `root` over RCCL (xGMI).  No reference counterpart: cobaya chains are

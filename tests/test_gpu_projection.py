@@ -132,6 +132,24 @@ def test_interpolation_operator_then_marginalised_logp(golden):
     logp, full, best = like.logp(rows[None], return_best=True)
     w = M.marginalized_logp(V[1:], V[0], D, C, loc, scale, return_best=True)
     assert np.isclose(logp[0], w[0], rtol=1e-10) and np.isclose(full[0], w[1], rtol=1e-9) and relerr(best, w[2][None]) < 1e-8
+    # theory + likelihood in ONE C-ABI call (eftb_eval_logp_batch): only inputs and one float per walker cross PCIe
+    Pin2 = np.stack([g["Pin"], 1.1 * g["Pin"]])
+    rows2 = np.stack([rows, gaussian_rows(f, (b1 + 0.1, b2, b4), None, 0.7, 0.25, 4.5e-5)])
+    lp2, full2, best2 = like.eval_logp(Pin2, f, float(g["DA"]), float(g["H"]), rows2, return_best=True)
+    assert lp2[0] == logp[0] and full2[0] == full[0] and np.array_equal(best2[0], best[0])
+    pinned = eng.pinned_empty((2, 3, 24, nx))  # page-locked landing buffer
+    t2 = eng.eval_batch(Pin2, f, float(g["DA"]), float(g["H"]), out=pinned)
+    assert t2 is pinned and np.array_equal(t2[0], templ[0])
+    V1 = np.einsum("gr,lrx->glx", rows2[1], t2[1]).reshape(rows2.shape[1], -1)[:, index]
+    assert np.isclose(lp2[1], M.marginalized_logp(V1[1:], V1[0], D, C, loc, scale), rtol=1e-10)
+    # P_l only (templ = NULL)
+    plk_only = eng.eval_batch(Pin2, f, float(g["DA"]), float(g["H"]), bias=np.repeat(bias, 2, axis=0), templates=False)
+    assert np.array_equal(plk_only[0], plk[0])
+    with pytest.raises(ValueError):
+        eng.eval_batch(Pin2, f, float(g["DA"]), float(g["H"]), templates=False)
+    with pytest.raises(ValueError):
+        like.eval_logp(Pin2, f, float(g["DA"]), float(g["H"]), rows2[:1])
+    del t2, pinned
     eng.close()
 
 
