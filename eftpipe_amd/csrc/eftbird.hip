@@ -58,7 +58,7 @@ struct eftb_engine {
     double *ACF = nullptr, *ALC = nullptr;   // ... of the weighted xi basis [B][BASC][KSYN] and of C11 / Cct [B][2 Nl][KLIN]
     double *Y22 = nullptr, *YCF = nullptr;   // synthesised basis rows [B][BAS22][Nk], [B][BASC][NS]
     // linear post-AP operators (window / binning / chained), stored K-major for gemm_rows_kernel
-    struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; };
+    struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; int st_op; };  // st_op >= 0: matrix used for the Pstl rows instead
     std::vector<Op> ops;
     int pipeline_op = -1;
     // likelihood of the LOGP stage (eftb_set_likelihood)
@@ -235,13 +235,23 @@ static int launch_operator(eftb_engine* e, int id, int B) {
     const eftb_engine::Op& o = e->ops[id];
     if (o.nl_in != e->cur_nl || o.nx_in != e->cur_nx)
         return fail("operator %d expects templates [%d][24][%d], the block is [%d][24][%d]", id, o.nl_in, o.nx_in, e->cur_nl, e->cur_nx);
-    GemmDesc g{};
-    g.A = e->buf[EFTB_B_TEMPL]; g.a_group = (long long)o.nl_in * NROW * o.nx_in; g.a_row = o.nx_in; g.a_seg = (long long)NROW * o.nx_in;
-    g.rows = B * NROW; g.rows_per_group = NROW; g.nseg = o.nl_in; g.kseg = o.nx_in;
-    g.B = o.dev; g.ldb = o.ld; g.ncols = o.nl_out * o.nx_out;
-    g.C = e->Talt; g.c_group = (long long)o.nl_out * NROW * o.nx_out; g.c_row = o.nx_out; g.c_colgroup = (long long)NROW * o.nx_out;
-    g.cols_per_group = o.nx_out;
-    hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
+    // rows [r0, r0 + nr) of every (cosmology, multipole) through matrix `m`
+    auto launch = [&](const eftb_engine::Op& m, int r0, int nr) {
+        GemmDesc g{};
+        g.A = e->buf[EFTB_B_TEMPL] + (size_t)r0 * o.nx_in; g.a_group = (long long)o.nl_in * NROW * o.nx_in; g.a_row = o.nx_in;
+        g.a_seg = (long long)NROW * o.nx_in;
+        g.rows = B * nr; g.rows_per_group = nr; g.nseg = o.nl_in; g.kseg = o.nx_in;
+        g.B = m.dev; g.ldb = m.ld; g.ncols = o.nl_out * o.nx_out;
+        g.C = e->Talt + (size_t)r0 * o.nx_out; g.c_group = (long long)o.nl_out * NROW * o.nx_out; g.c_row = o.nx_out;
+        g.c_colgroup = (long long)NROW * o.nx_out;
+        g.cols_per_group = o.nx_out;
+        hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
+    };
+    if (o.st_op < 0) launch(o, 0, NROW);
+    else {
+        launch(o, 0, NROW - 3);                 // P11l, Pctl, Ploopl
+        launch(e->ops[o.st_op], NROW - 3, 3);   // Pstl (window_st / fiberst semantics of the reference)
+    }
     std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     e->cur_nl = o.nl_out;
     e->cur_nx = o.nx_out;
@@ -545,7 +555,7 @@ int eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx_
     if ((size_t)nl_out * nx_out > (size_t)e->c.Nl * e->c.Nk || (size_t)nl_in * nx_in > (size_t)e->c.Nl * e->c.Nk)
         return fail("eftb_add_operator: operator shapes must not exceed the engine's [Nl=%d][Nk=%d] block", e->c.Nl, e->c.Nk);
     HIPCHK(hipSetDevice(e->c.device));
-    eftb_engine::Op o{nl_out, nx_out, nl_in, nx_in, (nl_out * nx_out + 15) / 16 * 16, nullptr};
+    eftb_engine::Op o{nl_out, nx_out, nl_in, nx_in, (nl_out * nx_out + 15) / 16 * 16, nullptr, -1};
     // K-major copy: opT[(l,k)][(a,x)]
     std::vector<double> t((size_t)nl_in * nx_in * o.ld, 0.0);
     for (int a = 0; a < nl_out; ++a)
@@ -558,6 +568,19 @@ int eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx_
     HIPCHK(hipMemcpy(o.dev, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
     e->ops.push_back(o);
     *op_id = (int)e->ops.size() - 1;
+    return 0;
+}
+
+int eftb_set_operator_stochastic(eftb_engine* e, int op_id, int st_op_id) {
+    if (!e) return fail("eftb_set_operator_stochastic: null engine");
+    const int n = (int)e->ops.size();
+    if (op_id < 0 || op_id >= n || st_op_id < -1 || st_op_id >= n) return fail("eftb_set_operator_stochastic: operator id out of range");
+    if (st_op_id >= 0) {
+        const eftb_engine::Op &a = e->ops[op_id], &b = e->ops[st_op_id];
+        if (a.nl_out != b.nl_out || a.nx_out != b.nx_out || a.nl_in != b.nl_in || a.nx_in != b.nx_in)
+            return fail("eftb_set_operator_stochastic: operators %d and %d differ in shape", op_id, st_op_id);
+    }
+    e->ops[op_id].st_op = st_op_id;
     return 0;
 }
 

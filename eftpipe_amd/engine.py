@@ -145,13 +145,16 @@ class Engine:
         return ms.value / repeats
 
     # ------------------------------------------------------------------ linear operators (window / binning / chained)
-    def add_operator(self, op):
-        """op [nl_out, nl_in, nx_out, nx_in]: out[a, row, x] = sum_{l,k} op[a,l,x,k] in[l, row, k]  -> operator id"""
+    def add_operator(self, op, stochastic=None):
+        """op [nl_out, nl_in, nx_out, nx_in]: out[a, row, x] = sum_{l,k} op[a,l,x,k] in[l, row, k]  -> operator id.
+        stochastic: a second matrix of the same shape for the Pstl rows (window_st=False / fiberst=False semantics)."""
         op = np.ascontiguousarray(op, dtype=np.float64)
         nl_out, nl_in, nx_out, nx_in = op.shape
         oid = C.c_int()
         L.check(self.lib.eftb_add_operator(self._h, nl_out, nx_out, nl_in, nx_in, L.dptr(op), C.byref(oid)))
         self._op_shapes.append((nl_out, nx_out, nl_in, nx_in))
+        if stochastic is not None:
+            L.check(self.lib.eftb_set_operator_stochastic(self._h, oid.value, self.add_operator(stochastic)))
         return oid.value
 
     def apply_operator(self, op_id, B=1, sync=True):

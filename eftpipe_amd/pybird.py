@@ -333,8 +333,52 @@ class APeffect(HasLogger):
             bird.create_snapshot("APeffect")
 
 
-class FiberCollision:
-    """Not on the accelerated path (`with_fiber: false` in every shipped yaml; SURVEY.md 2 #13)."""
+class FiberCollision(HasLogger):
+    """Fibre-collision correction, effective-window method (same surface as reference pybird.py:1630-1810).
+    The correlated correction is linear in the templates: F is built once on the host (tables.fiber_operator) and
+    ``fibcolWindow`` is one dense operator on the FP64 matrix cores (P += F P; Pstl only if ``fiberst``)."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("FiberCollision is outside the accelerated hot path")
+    def __init__(self, fs, Dfc, ktrust=0.25, fiberst=False, co=None, name="pybird.fiber", snapshot=False):
+        self.set_logger(name=name)
+        self.ktrust, self.fiberst, self.fs, self.Dfc = ktrust, fiberst, fs, Dfc
+        self.co = common if co is None else co
+        self.snapshot = snapshot
+        self._F = None
+        self._op = None
+
+    def dPuncorr(self, kout, fs=0.6, Dfc=0.43 / 0.6777):
+        """Uncorrelated contribution (reference pybird.py:1680-1701)"""
+        from scipy.special import legendre
+
+        kout = np.asarray(kout, dtype=float)
+        return np.stack([-fs * np.pi * Dfc**2.0 * (2.0 * np.pi / kout) * (2.0 * l + 1.0) / 2.0 * legendre(l)(0) * (1.0 - (kout * Dfc) ** 2 / 8.0)
+                         for l in (0, 2, 4)])
+
+    def operator(self):
+        """F [Nl, Nl, Nk, Nk] of dPcorr on the engine grid"""
+        if self._F is None:
+            from .tables import fiber_operator
+
+            self._F = fiber_operator(self.co.k, self.co.Nl, self.fs, self.Dfc, self.ktrust)
+        return self._F
+
+    def dPcorr(self, kout, kPS, PS, ktrust=0.25, fs=0.6, Dfc=0.43 / 0.6777):
+        """Correlated contribution for PS [Nl, n, len(kPS)] -> [Nl, n, len(kout)] (host; reference pybird.py:1703-1757)"""
+        from .tables import fiber_operator
+
+        return np.einsum("alxk,lnk->anx", fiber_operator(kPS, self.co.Nl, fs, Dfc, ktrust, kout=kout), np.asarray(PS)[: self.co.Nl])
+
+    def fibcolWindow(self, bird):
+        """P11l, Pctl, Ploopl (and Pstl if fiberst) += dPcorr, in place (reference pybird.py:1760-1810)"""
+        from .tables import compose_operator
+        from .transformer import apply_operator_to_birdlike
+
+        eng = engine_for(bird.co)
+        if self._op is None or self._op[0] is not eng:
+            self._op = (eng, eng.add_operator(compose_operator(self.co.Nl, self.co.Nk, fiber=self.operator())))
+        keep = bird.Pstl
+        out = apply_operator_to_birdlike(eng, self._op[1], bird)
+        bird.P11l, bird.Pctl, bird.Ploopl = out["P11l"], out["Pctl"], out["Ploopl"]
+        bird.Pstl = out["Pstl"] if self.fiberst else keep
+        if self.snapshot:
+            bird.create_snapshot("fiber")

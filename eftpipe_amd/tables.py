@@ -550,9 +550,71 @@ def chained_matrix(Nl):
     return m
 
 
-def compose_operator(Nl, Nk, Wfold=None, binning=None, chained=False):
-    """Fold window [Na,Nl,Nk,Nk], binning [nb,Nk] and the chained matrix into one [nl_out, Nl, nx_out, Nk]."""
+def linear_interp_matrix(x, xnew):
+    """scipy interp1d(kind='linear', fill_value='extrapolate') as a matrix [len(xnew), len(x)] (end segments extended)."""
+    x, xnew = np.asarray(x, dtype=float), np.asarray(xnew, dtype=float)
+    lo = np.clip(np.searchsorted(x, xnew) - 1, 0, x.size - 2)
+    t = (xnew - x[lo]) / (x[lo + 1] - x[lo])
+    L = np.zeros((xnew.size, x.size))
+    rows = np.arange(xnew.size)
+    L[rows, lo] = 1.0 - t
+    L[rows, lo + 1] += t
+    return L
+
+
+def _fiber_H(l, lp, x):
+    """Legendre-overlap polynomials of the effective-window method, l > lp (reference pybird.py:49-65)"""
+    if (l, lp) == (2, 0):
+        return x**2 - 1.0
+    if (l, lp) == (4, 0):
+        return 1.75 * x**4 - 2.5 * x**2 + 0.75
+    if (l, lp) == (4, 2):
+        return x**4 - x**2
+    return np.zeros_like(x)
+
+
+def fiber_operator(k, Nl, fs, Dfc, ktrust=0.25, kout=None, nq=1024):
+    """The correlated fibre-collision correction as a matrix (reference pybird.py:1703-1757, FiberCollision.dPcorr):
+        dP_l(kout_i) = sum_{l', k'} F[l, l', i, k'] P_l'(k')
+    The reference interpolates P linearly onto 1024 log-spaced q in [k_min, ktrust] and sums q dq P(q) f_ll'(k, q) over q < k
+    (l' <= l) and k < q < ktrust (l' >= l); both steps are linear in P, so they fold into F = W @ L."""
+    from scipy.special import j1
+
+    k = np.asarray(k, dtype=float)
+    kout = k if kout is None else np.asarray(kout, dtype=float)
+    q = np.geomspace(k.min(), ktrust, num=nq)
+    dq = np.concatenate([[0.0], np.diff(q)])
+    Lq = linear_interp_matrix(k, q)
+    w2d = 2.0 * j1(q * Dfc) / (q * Dfc)
+    ir = q[None, :] < kout[:, None]
+    uv = (q[None, :] > kout[:, None]) & (q[None, :] < ktrust)
+    xi = q[None, :] / kout[:, None]      # q/k (IR side)
+    xu = kout[:, None] / q[None, :]      # k/q (UV side)
+    F = np.zeros((Nl, Nl, kout.size, k.size))
+    for a in range(Nl):
+        for b in range(Nl):
+            l, lp = 2 * a, 2 * b
+            W = np.zeros((kout.size, nq))
+            if l == lp:
+                fir, fuv = xi * w2d * xi**l, w2d * xu**l
+            else:
+                pre = (2.0 * l + 1.0) / 2.0
+                fir = xi * w2d * pre * _fiber_H(max(l, lp), min(l, lp), xi)
+                fuv = w2d * pre * _fiber_H(max(l, lp), min(l, lp), xu)
+            if lp <= l:
+                W += np.where(ir, fir, 0.0)
+            if lp >= l:
+                W += np.where(uv, fuv, 0.0)
+            F[a, b] = (-0.5 * fs * Dfc**2 * W * (q * dq)[None, :]) @ Lq
+    return F
+
+
+def compose_operator(Nl, Nk, Wfold=None, binning=None, chained=False, fiber=None):
+    """Fold window [Na,Nl,Nk,Nk], fibre collisions (F of ``fiber_operator``: P += F P), binning [nb,Nk] and the chained
+    matrix into one [nl_out, Nl, nx_out, Nk], in the reference's order (theory.py:583-600)."""
     op = Wfold if Wfold is not None else np.einsum("al,xk->alxk", np.eye(Nl), np.eye(Nk))
+    if fiber is not None:
+        op = op + np.einsum("abxy,blyk->alxk", fiber, op)
     if binning is not None:
         op = np.einsum("bx,alxk->albk", binning, op)
     if chained:

@@ -129,6 +129,10 @@ int  eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const 
  * (the cubic splines onto the window p grid / the bin quadrature points are folded in on the host) and applied
  * on the FP64 matrix cores.  `op` is [nl_out][nl_in][nx_out][nx_in]; requires nl_out*nx_out <= Nl*Nk. */
 int  eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx_in, const double* op, int* op_id);
+/* The stochastic rows (Pstl, rows 21-23) of operator `op_id` go through the matrix of `st_op_id` (same shape) instead:
+ * Window(window_st=False) (window.py:412-415) and FiberCollision(fiberst=False) (pybird.py:1788-1797) leave Pstl alone while
+ * binning / chained still act on it.  st_op_id = -1 restores one matrix for all rows. */
+int  eftb_set_operator_stochastic(eftb_engine* e, int op_id, int st_op_id);
 /* Apply to the current template block of cosmologies [0, B); the block takes the operator's output shape. */
 int  eftb_apply_operator(eftb_engine* e, int op_id, int B);
 /* Operator run by the EFTB_S_PROJECT stage of eftb_run / eftb_eval_batch (-1 = none). */

@@ -247,3 +247,51 @@ def test_cfg5_shape_nk2048_window_binning(golden):
     want = np.einsum("alxk,lrk->arx", op, templ[0])
     assert relerr(proj[0], want) < 1e-10 and np.array_equal(proj[0], proj[1])
     eng.close()
+
+
+def test_fiber_collision_mirror_and_folded_operator(golden):
+    """FiberCollision.fibcolWindow as a device operator (drop-in call, reference pybird.py:1760-1810) and inside
+    the folded pipeline operator window -> fibre -> binning with the stochastic rows taking the fibre-less matrix (fiberst=False)."""
+    from types import SimpleNamespace
+
+    from eftpipe_amd import pybird
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+    from oracle import fiber as F
+
+    g, c = golden("fiber"), golden("caseC")
+    k, fs, Dfc, kt = c["k"], float(g["fs"]), float(g["Dfc"]), float(g["ktrust"])
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+    for fiberst in (False, True):
+        fib = pybird.FiberCollision(fs=fs, Dfc=Dfc, ktrust=kt, fiberst=fiberst, co=co)
+        bird = SimpleNamespace(co=co, **{n: c["window_" + n].copy() for n in NAMES})
+        fib.fibcolWindow(bird)
+        tag = "st_" if fiberst else ""
+        for n in NAMES:
+            assert relerr(getattr(bird, n), g["fiber_" + tag + n]) < 1e-11, (fiberst, n)
+    assert relerr(fib.dPuncorr(k, fs=fs, Dfc=Dfc), g["dPuncorr"]) < 1e-14
+    sub = c["window_Ploopl"][:, :2]
+    assert relerr(fib.dPcorr(k, k, sub, ktrust=kt, fs=fs, Dfc=Dfc).reshape(6, -1), F.dpcorr(k, k, sub, 3, ktrust=kt, fs=fs, Dfc=Dfc).reshape(6, -1)) < 1e-12
+    # batched: AP-stage templates -> window -> fibre -> binning in ONE operator; Pstl skips the fibre matrix
+    tab = np.load(WIN)
+    Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+    Wfold, _ = TB.window_fold(k, Wal, p)
+    Bm, _, _, _ = TB.binning_operator(k, c["kout"])
+    Fm = TB.fiber_operator(k, 3, fs, Dfc, kt)
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, APst=True, DA_AP=float(c["DA_AP"]), H_AP=float(c["H_AP"])), max_batch=3)
+    op = eng.add_operator(TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm, fiber=Fm),
+                          stochastic=TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm))
+    eng.set_pipeline_operator(op)
+    Pin = np.stack([c["Pin"], 0.9 * c["Pin"], c["Pin"]])
+    templ = eng.eval_batch(Pin, float(c["f"]), float(c["DA"]), float(c["H"]))
+    binned = lambda a: np.einsum("bx,lnx->lnb", Bm, a)
+    for i in (0, 2):
+        assert relerr(templ[i][:, 0:3], binned(g["fiber_P11l"])) < TOL
+        assert relerr(templ[i][:, 3:9], binned(g["fiber_Pctl"])) < TOL
+        assert relerr(templ[i][:, 9:21], binned(g["fiber_Ploopl"])) < TOL
+        assert relerr(templ[i][:, 21:24], c["binned_Pstl"]) < TOL      # no fibre correction on the stochastic rows
+    assert np.max(np.abs(templ[1] - templ[0])) > 0
+    with pytest.raises(Exception):
+        eng.add_operator(np.zeros((3, 3, 5, k.size)), stochastic=np.zeros((3, 3, 6, k.size)))
+    eng.close()

@@ -204,3 +204,33 @@ def test_parameter_bases_mirror_reference(golden):
         assert list(table) == list(m[tag + "_names"])
         assert relerr(np.stack(list(table.values())).reshape(len(table), -1), m[tag + "_table"].reshape(len(table), -1)) < 1e-14
         assert relerr(basis.reduce_Plk(bird, ng).sum(), m[tag + "_PNGl"]) < 1e-14
+
+
+def test_fiber_operator_matches_reference(golden):
+    """tables.fiber_operator (the dense form of FiberCollision.dPcorr, reference pybird.py:1703-1757) against the reference-generated
+    fixture, the oracle's loop form on a non-native grid with kout != kPS, and its place in the folded pipeline operator."""
+    from eftpipe_amd import tables as TB
+    from oracle import fiber as F
+
+    g, c = golden("fiber"), golden("caseC")
+    k, fs, Dfc, kt = c["k"], float(g["fs"]), float(g["Dfc"]), float(g["ktrust"])
+    Fm = TB.fiber_operator(k, 3, fs, Dfc, kt)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        got = c["window_" + n] + np.einsum("alxk,lnk->anx", Fm, c["window_" + n])
+        assert relerr(got, g["fiber_st_" + n]) < 1e-12, n
+    rng = np.random.default_rng(3)
+    kps, kout = np.sort(rng.uniform(0.004, 0.3, 37)), np.sort(rng.uniform(0.01, 0.28, 11))
+    PS = rng.normal(size=(3, 4, 37))
+    want = F.dpcorr(kout, kps, PS, 3, ktrust=0.22, fs=0.3, Dfc=0.5)
+    got = np.einsum("alxk,lnk->anx", TB.fiber_operator(kps, 3, 0.3, 0.5, 0.22, kout=kout), PS)
+    assert relerr(got.reshape(12, -1), want.reshape(12, -1)) < 1e-12
+    # order in the folded operator: window -> fibre -> binning -> chained (reference theory.py:583-600)
+    W = rng.normal(size=(3, 3, 50, 50)) * 0.1
+    Bn = rng.normal(size=(7, 50))
+    P = rng.normal(size=(3, 5, 50))
+    op = TB.compose_operator(3, 50, Wfold=W, binning=Bn, chained=True, fiber=Fm)
+    x = np.einsum("alxk,lnk->anx", W, P)
+    x = x + np.einsum("alxk,lnk->anx", Fm, x)
+    x = np.einsum("bx,anx->anb", Bn, x)
+    x = np.einsum("ca,anb->cnb", TB.chained_matrix(3), x)
+    assert relerr(np.einsum("alxk,lnk->anx", op, P).reshape(10, -1), x.reshape(10, -1)) < 1e-12

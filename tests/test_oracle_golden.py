@@ -184,3 +184,17 @@ def test_eastcoast_basis(golden):
     logp, fullchi2, best, _ = M.marginalized_logp(g["PG"], g["PNG"], g["D"], g["invcov"], g["loc"], g["scale"], return_best=True)
     assert np.isclose(logp, g["logp"], rtol=1e-12) and np.isclose(fullchi2, g["fullchi2"], rtol=1e-10)
     assert relerr(best[None], g["best"][None]) < 1e-10
+
+
+def test_fiber_collision(golden):
+    """oracle == reference FiberCollision.fibcolWindow on the post-window templates of caseC."""
+    from oracle import fiber as F
+
+    g, c = golden("fiber"), golden("caseC")
+    st = {n: c["window_" + n] for n in ("P11l", "Pctl", "Ploopl", "Pstl")}
+    for fiberst in (False, True):
+        out = F.fibcol_window(st, c["k"], 3, float(g["fs"]), float(g["Dfc"]), float(g["ktrust"]), fiberst=fiberst)
+        tag = "st_" if fiberst else ""
+        for n in st:
+            assert relerr(out[n], g["fiber_" + tag + n]) < 1e-13, (fiberst, n)
+    assert np.array_equal(g["fiber_Pstl"], c["window_Pstl"])

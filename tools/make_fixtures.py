@@ -297,6 +297,28 @@ def east_fixture(ref):
     print("east written:", names, float(logp))
 
 
+def fiber_fixture(ref):
+    """FiberCollision.fibcolWindow of the REAL reference (pybird.py:1630-1810) applied to the
+    post-window templates of caseC (native 50-point k grid), with and without the stochastic terms, plus dPuncorr."""
+    pb = ref.pybird
+    g = dict(np.load(os.path.join(GOLD, "caseC.npz"), allow_pickle=True))
+    Nl = int(g["Nl"])
+    co = make_common(pb, Nl, None)
+    out = dict(fs=0.46, Dfc=0.43 / 0.6777, ktrust=0.25)
+    for fiberst in (False, True):
+        fib = pb.FiberCollision(fs=out["fs"], Dfc=out["Dfc"], ktrust=out["ktrust"], fiberst=fiberst, co=co)
+        bird = ref.transformer.PlainBird(f=float(g["f"]), co=co, P11l=g["window_P11l"].copy(), Ploopl=g["window_Ploopl"].copy(),
+                                         Pctl=g["window_Pctl"].copy(), Pstl=g["window_Pstl"].copy(), Picc=np.zeros_like(g["window_P11l"][:, 0]),
+                                         PctNNLOl=None)
+        fib.fibcolWindow(bird)
+        tag = "st_" if fiberst else ""
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            out["fiber_" + tag + n] = getattr(bird, n)
+    out["dPuncorr"] = fib.dPuncorr(co.k, fs=out["fs"], Dfc=out["Dfc"])
+    np.savez_compressed(os.path.join(GOLD, "fiber.npz"), **out)
+    print("fiber written:", {k: np.shape(v) for k, v in out.items()})
+
+
 def pyegg_fixture(ref):
     """the on-disk layout of the reference's loop-matrix cache pyegg{NFFT}_Nl{Nl}.npz (pybird.py:968-981):
     keys, shapes, dtypes and spot values of every array (the 150 MB file itself is not committed)."""
@@ -371,7 +393,7 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -381,6 +403,8 @@ def main():
             pyegg_fixture(ref)
         elif name == "east":
             east_fixture(ref)
+        elif name == "fiber":
+            fiber_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
