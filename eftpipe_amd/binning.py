@@ -35,7 +35,8 @@ class Binning(HasLogger):
         if key not in self._ops:
             self._ops[key] = eng.add_operator(np.einsum("al,xk->alxk", np.eye(Nl), self.matrix))
         out = apply_operator_to_birdlike(eng, self._ops[key], bird)
-        return PlainBird(f=bird.f, co=bird.co, Picc=bird.Picc @ self.matrix.T, PctNNLOl=None, **out)
+        out.setdefault("PctNNLOl", None)
+        return PlainBird(f=bird.f, co=bird.co, Picc=bird.Picc @ self.matrix.T, **out)
 
     def transform(self, birdlike):
         return self.kbinning(birdlike)

@@ -34,4 +34,5 @@ class Chained:
             self._ops[key] = eng.add_operator(np.einsum("al,xk->alxk", self.chained_matrix(Nl), np.eye(nx)))
         out = apply_operator_to_birdlike(eng, self._ops[key], birdlike)
         mat = self.chained_matrix(Nl)
-        return PlainBird(f=birdlike.f, co=birdlike.co, Picc=np.einsum("al,l...->a...", mat, birdlike.Picc), PctNNLOl=None, **out)
+        out.setdefault("PctNNLOl", None)
+        return PlainBird(f=birdlike.f, co=birdlike.co, Picc=np.einsum("al,l...->a...", mat, birdlike.Picc), **out)

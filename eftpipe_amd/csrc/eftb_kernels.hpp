@@ -124,10 +124,10 @@ __global__ __launch_bounds__(64) void antidiag_kernel(int B, int Bmax, const dou
 
 // One lane = one j' of one cosmology: sums the AD_CH partials of the nc anti-diagonal sums once, then writes
 //   blockIdx.y = 0: the nb P22 basis rows  (A22[w][BAS22][KSYN])  and the 10 P13 rows (A13[w][10][KLIN])
-//   blockIdx.y = 1: the Nl*nc weighted rows Ml[l] S_c (ACF[w][BASC][KSYN]) and the 2 Nl C11 / Cct rows (ALC[w][2 Nl][KLIN])
+//   blockIdx.y = 1: the Nl*nc weighted rows Ml[l] S_c (ACF[w][BASC][KSYN]) and the nlc Nl C11 / Cct (/ CctNNLO) rows (ALC[w][nlc Nl][KLIN])
 // as real synthesis coefficients (Re Z_0, Re Z_1, Im Z_1, ...).  `sets` bit 0/1: quadratic rows of y = 0/1, bit 2/3: linear rows.
 template <int NC>
-__global__ __launch_bounds__(320) void build_rows_kernel(int sets, int Bmax, int Nl, int nb, const double* __restrict__ coef,
+__global__ __launch_bounds__(320) void build_rows_kernel(int sets, int Bmax, int Nl, int nlc, int nb, const double* __restrict__ coef,
                                                          const double2* __restrict__ S, const double2* __restrict__ mlj,
                                                          const double2* __restrict__ linvec, double* __restrict__ A22,
                                                          double* __restrict__ A13, double* __restrict__ ACF, double* __restrict__ ALC) {
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(320) void build_rows_kernel(int sets, int Bmax, int
         }
     }
     if ((sets >> (2 + cf)) & 1) {
-        const int nrows = cf == 0 ? 10 : 2 * Nl, v0 = cf == 0 ? 0 : 10;
-        double* out = cf == 0 ? A13 + (size_t)w * 10 * KLIN : ALC + (size_t)w * 2 * Nl * KLIN;
+        const int nrows = cf == 0 ? 10 : nlc * Nl, v0 = cf == 0 ? 0 : 10;  // nlc = 2 (C11, Cct) or 3 (+ CctNNLO)
+        double* out = cf == 0 ? A13 + (size_t)w * 10 * KLIN : ALC + (size_t)w * nlc * Nl * KLIN;
         const double* c = coef + (size_t)w * 2 * NCH;
         for (int e = threadIdx.x; e < nrows * NCH; e += blockDim.x) {
             const int row = e / NCH, mp = e % NCH, n = NHALF - mp;  // harmonic mp <-> coefficient n = 128 - mp
@@ -200,7 +200,7 @@ struct SynthDesc {
 
 // Several independent syntheses in one launch (P22 basis, P13, xi basis, C11, Cct): each is latency-bound on its own
 // (a few hundred workgroups, a global-load round trip per K chunk), together they fill the chip.
-constexpr int SYN_MAXP = 5;
+constexpr int SYN_MAXP = 6;
 struct SynthBatch {
     SynthDesc p[SYN_MAXP];
     int n;
@@ -457,6 +457,17 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
     t[(size_t)23 * Nk] = l == 1 ? kv * kv : 0.0;
 }
 
+
+// NNLO block: rows 3-5 = k^4 P11 lctNNLO (reference pybird.py:741-748), every other row zero.  lctn is [Nl][6] (zero padded).
+__global__ __launch_bounds__(256) void nnlo_rows_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
+                                                        const double* __restrict__ lctn, double* __restrict__ T) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
+    if (k >= Nk) return;
+    const double kv = kk[k], k4p = kv * kv * kv * kv * P11[(size_t)w * Nk + k];
+    double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) t[(size_t)r * Nk] = (r >= 3 && r < 6) ? lctn[l * 6 + (r - 3)] * k4p : 0.0;
+}
 
 // Cloopl[w][l][12][80] from CC[w][Nl*38][80] (C22 then C13; reference pybird.py:752-753, 805-846)
 __global__ __launch_bounds__(128) void regroup_cf_kernel(int Nl, const double* __restrict__ fgrow, const double* __restrict__ CC,
@@ -1201,6 +1212,16 @@ __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const doubl
 #pragma unroll
     for (int r = 0; r < NROW; ++r) a = fma(b[r], t[(size_t)r * Nx], a);
     Plk[((size_t)w * Nl + l) * Nx + k] = a;
+}
+
+// P_l(k) += bctNNLO . PctNNLOl (rows 3-5 of the NNLO block; reference parambasis.py:132-134)
+__global__ __launch_bounds__(256) void reduce_nnlo_kernel(int Nx, int Nl, const double* __restrict__ biasn, const double* __restrict__ TN,
+                                                          double* __restrict__ Plk) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, w = blockIdx.z;
+    if (k >= Nx) return;
+    const double* b = biasn + (size_t)w * 3;
+    const double* t = TN + (((size_t)w * Nl + l) * NROW + 3) * Nx + k;
+    Plk[((size_t)w * Nl + l) * Nx + k] += b[0] * t[0] + b[1] * t[(size_t)Nx] + b[2] * t[(size_t)2 * Nx];
 }
 
 // ------------------------------------------------------------------------------------------------

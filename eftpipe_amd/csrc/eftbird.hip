@@ -71,6 +71,8 @@ struct eftb_engine {
     int resum_splits = 1;
     int Nn = 0;
     double* sm2 = nullptr;  // s^-2 row scale of Cct
+    double* sm4 = nullptr;  // s^-4 row scale of CctNNLO
+    double *ZC = nullptr, *ZC2 = nullptr;  // with_nnlo: zeros standing in for C11 [B][Nl][80] / Cloopl [B][Nl][12][80] in the NNLO pass of Resum.Ps
     // RCCL gather (multi-GPU batches)
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -137,7 +139,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_EXP22: return D * 28 * BAS22;
         case EFTB_T_EXPC: return c.with_resum ? D * (size_t)c.Nl * 38 * BASC : 0;
         case EFTB_T_MLJ: return c.with_resum ? 2 * D * c.Nl * NPOW : 0;
-        case EFTB_T_LINVEC: return 2 * D * (size_t)(10 + (c.with_resum ? 2 * c.Nl : 0)) * NCH;
+        case EFTB_T_LINVEC: return 2 * D * (size_t)(10 + (c.with_resum ? (c.with_nnlo ? 3 : 2) * c.Nl : 0)) * NCH;  // M13, Mcf11, Mcfct (, McfctNNLO)
         case EFTB_T_SYNK: return D * (size_t)KSYN * c.Nk;
         case EFTB_T_LINK: return D * (size_t)KLIN * c.Nk;
         case EFTB_T_SYNS: return c.with_resum ? D * (size_t)KSYN * NS : 0;
@@ -159,6 +161,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_LEGMU: return c.with_ap ? D * c.Nl * c.nmu : 0;
         case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
         case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
+        case EFTB_T_LCTN: return c.with_nnlo ? D * c.Nl * 6 : 0;
     }
     return 0;
 }
@@ -183,6 +186,9 @@ static size_t need_buffer_elems(const eftb_config& c, int id) {
         case EFTB_B_COEF: return B * 2 * NCH;
         case EFTB_B_GROWS: return B * MARG_NG1 * NROW;
         case EFTB_B_LOGP: return B * MARG_OUT;
+        case EFTB_B_CCTN: return c.with_nnlo && c.with_resum ? B * c.Nl * NS : 0;
+        case EFTB_B_TEMPLN: return c.with_nnlo ? B * c.Nl * NROW * c.Nk : 0;
+        case EFTB_B_BIASN: return c.with_nnlo ? B * 3 : 0;
     }
     return 0;
 }
@@ -213,7 +219,7 @@ static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets)
     const int nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
     const dim3 grid(NPOW, (B + 63) / 64, AD_CH), rgrid(B, 2);
 #define AD_ARGS B, c.max_batch, e->coefT, tb<double2>(e, EFTB_T_AD), e->SAD
-#define ROW_ARGS sets, c.max_batch, c.Nl, c.nbasis, e->buf[EFTB_B_COEF], e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
+#define ROW_ARGS sets, c.max_batch, c.Nl, c.with_nnlo ? 3 : 2, c.nbasis, e->buf[EFTB_B_COEF], e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
                  e->ACF, e->ALC
     if (nc == 9) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(64), 0, st, AD_ARGS);
@@ -279,15 +285,16 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
 #undef PF_ARGS
 }
 
-static int launch_stages(eftb_engine* e, int mask, int B) {
+// nnlo_pass: the linear stages (RESUM / AP / PROJECT) once more, on the NNLO block (pointers swapped in by launch_stages)
+static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     const eftb_config& c = e->c;
     hipStream_t st = e->stream;
     const int Nk = c.Nk, Nl = c.Nl;
     double** b = e->buf;
     // The IR filters / Q(f) and the AP prefix sums depend on the inputs only: when they are part of a longer stage set they
     // run on a side stream beside the (latency-bound) loop path and are joined right before their consumers.
-    const bool side_ir = (mask & EFTB_S_RESUM) && c.with_resum && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP));
-    const bool side_ap = (mask & EFTB_S_AP) && c.with_ap && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP | EFTB_S_RESUM));
+    const bool side_ir = !nnlo_pass && (mask & EFTB_S_RESUM) && c.with_resum && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP));
+    const bool side_ap = !nnlo_pass && (mask & EFTB_S_AP) && c.with_ap && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP | EFTB_S_RESUM));
     if (side_ir || side_ap) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
@@ -322,9 +329,13 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         if (mask & EFTB_S_LOOPS)
             queue_synth(sb, e->A13, 10LL * KLIN, B, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], 10LL * Nk, b[EFTB_B_P11], nullptr);
         if (mask & EFTB_S_CF) {
-            queue_synth(sb, e->ALC, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], (long long)Nl * NS, nullptr, nullptr);
-            queue_synth(sb, e->ALC + (size_t)Nl * KLIN, 2LL * Nl * KLIN, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCT], (long long)Nl * NS,
+            const long long ag = (c.with_nnlo ? 3LL : 2LL) * Nl * KLIN;
+            queue_synth(sb, e->ALC, ag, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], (long long)Nl * NS, nullptr, nullptr);
+            queue_synth(sb, e->ALC + (size_t)Nl * KLIN, ag, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCT], (long long)Nl * NS,
                         nullptr, e->sm2);
+            if (c.with_nnlo)  // makeCctNNLO (reference pybird.py:1098-1101)
+                queue_synth(sb, e->ALC + (size_t)2 * Nl * KLIN, ag, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCTN], (long long)Nl * NS,
+                            nullptr, e->sm4);
         }
         launch_synth(st, sb);
         if (k22 || c22) {
@@ -338,6 +349,9 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
                            b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
                            tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_TEMPL]);
+        if (c.with_nnlo)
+            hipLaunchKernelGGL(nnlo_rows_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11],
+                               tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN]);
         if (c.with_resum)
             hipLaunchKernelGGL(regroup_cf_kernel, dim3(12, Nl, B), dim3(128), 0, st, Nl, b[EFTB_B_F], b[EFTB_B_CC], tb<double>(e, EFTB_T_L22),
                                tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_CLOOPL]);
@@ -345,7 +359,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & (EFTB_S_RESUM | EFTB_K_RESUM)) {
         if (!c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
         const bool full = mask & EFTB_S_RESUM;  // EFTB_K_RESUM alone: only the main kernel, on the operands of an earlier full run
-        if (full && !side_ir) launch_irfilter(e, st, B);
+        if (full && !side_ir && !nnlo_pass) launch_irfilter(e, st, B);  // X, Y, Q(f) of the first pass stay valid
         if (!joined) {
             if (hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess) return fail("eftb_run: stream join failed");
             joined = true;
@@ -361,7 +375,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             const int schunk = (NS + nsplit - 1) / nsplit;
             if (kblocks > 0)
                 hipLaunchKernelGGL(resum_mfma_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K),
-                                   tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
+                                   tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT),
                                    b[EFTB_B_TEMPL], e->part, nsplit);
             if (nsplit > 1)
                 hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nsplit, e->part, b[EFTB_B_TEMPL]);
@@ -373,7 +387,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             const int schunk = (NS + nsplit - 1) / nsplit;
             hipLaunchKernelGGL((resum_kernel<2>), dim3(kblocks, 4 * Nl, B * Nl * nsplit), dim3(256), 0, st, Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K),
                                b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL],
-                               tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), e->part, nsplit);
+                               tb<double>(e, EFTB_T_L11), tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), e->part, nsplit);
             hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, 2 * Nl * nsplit, e->part, b[EFTB_B_TEMPL]);
         }
     }
@@ -386,9 +400,9 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
             hipLaunchKernelGGL(spline_kernel, dim3(kt, ysplit), dim3(256), 0, st, Nk, nseries, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPBAND), e->SD);
         }
         // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
-        const int nr = c.ap_stochastic ? NROW : 21;
+        const int nr = c.ap_stochastic && !nnlo_pass ? NROW : 21;
         const int rs = e->ap_rowsplit;
-        if (!side_ap) launch_ap_prefix(e, st, B);
+        if (!side_ap && !nnlo_pass) launch_ap_prefix(e, st, B);
         if (!joined) {
             if (hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess) return fail("eftb_run: stream join failed");
             joined = true;
@@ -424,6 +438,7 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     }
     if (mask & EFTB_S_LOGP) {
         if (!e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
+        if (c.with_nnlo) return fail("eftb_run: stage LOGP does not take the NNLO block yet (with_nnlo=1)");
         const size_t lds = ((size_t)(e->like_nG + 1) * (NROW + 2 * e->like_ndata + e->like_nG + 1)) * sizeof(double);
         hipLaunchKernelGGL(marg_logp_kernel, dim3(B), dim3(256), lds, st, e->cur_nl, e->cur_nx, e->like_ndata, e->like_nG, e->jeffreys, e->like_index,
                            e->like_data, e->like_invcov, e->like_mu, e->like_sinv, b[EFTB_B_GROWS], b[EFTB_B_TEMPL], b[EFTB_B_LOGP]);
@@ -431,9 +446,43 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     if (mask & EFTB_S_REDUCE)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],
                            b[EFTB_B_TEMPL], b[EFTB_B_PLK]);
+    if ((mask & EFTB_S_REDUCE) && c.with_nnlo)
+        hipLaunchKernelGGL(reduce_nnlo_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIASN],
+                           b[EFTB_B_TEMPLN], b[EFTB_B_PLK]);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
     return 0;
+}
+
+static int launch_stages(eftb_engine* e, int mask, int B) {
+    const eftb_config& c = e->c;
+    const int lin = mask & (EFTB_S_RESUM | EFTB_S_AP | EFTB_S_PROJECT);
+    if (!c.with_nnlo || !lin) return launch_stages_impl(e, mask, B, false);
+    // with_NNLO: the counter-terms k^4 P11 lctNNLO go through the same linear stages as a second template block whose Pctl
+    // slots carry them (reference pybird.py:1447-1458 Resum with Q[1], CctNNLO, lctNNLO; :1615 AP; window.py:399, 410):
+    // everything but the tail, then the linear stages again with the NNLO operands swapped in, then LOGP / REDUCE.
+    const int tail = mask & (EFTB_S_LOGP | EFTB_S_REDUCE);
+    const int in_nl = (mask & EFTB_S_REGROUP) ? c.Nl : e->cur_nl, in_nx = (mask & EFTB_S_REGROUP) ? c.Nk : e->cur_nx;
+    if (int rc = launch_stages_impl(e, mask & ~tail, B, false)) return rc;
+    const int out_nl = e->cur_nl, out_nx = e->cur_nx;
+    double** b = e->buf;
+    auto swap_in = [&]() {
+        std::swap(b[EFTB_B_TEMPL], b[EFTB_B_TEMPLN]);
+        if (c.with_resum) {
+            std::swap(b[EFTB_B_CCT], b[EFTB_B_CCTN]);
+            std::swap(b[EFTB_B_C11], e->ZC);
+            std::swap(b[EFTB_B_CLOOPL], e->ZC2);
+        }
+    };
+    swap_in();
+    e->cur_nl = in_nl;
+    e->cur_nx = in_nx;
+    const int rc = launch_stages_impl(e, lin, B, true);
+    swap_in();  // the same swaps undo themselves
+    e->cur_nl = out_nl;
+    e->cur_nx = out_nx;
+    if (rc) return rc;
+    return tail ? launch_stages_impl(e, tail, B, false) : 0;
 }
 
 extern "C" {
@@ -477,6 +526,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     }
     const size_t B = c.max_batch;
     HIPCHK(hipMalloc(&e->sm2, NS * sizeof(double)));
+    HIPCHK(hipMalloc(&e->sm4, NS * sizeof(double)));
     // scratch of the anti-diagonal pipeline; padded rows / coefficients of the synthesis rows stay zero
     {
         const size_t nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
@@ -487,7 +537,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         int bad = zalloc(&e->coefT, 2 * NCH * B);
         bad |= zalloc(reinterpret_cast<double**>(&e->SAD), 2 * (size_t)AD_CH * B * nc * NPOW);
         bad |= zalloc(&e->A22, B * BAS22 * KSYN) | zalloc(&e->A13, B * 10 * KLIN) | zalloc(&e->Y22, B * BAS22 * c.Nk);
-        if (c.with_resum) bad |= zalloc(&e->ACF, B * BASC * KSYN) | zalloc(&e->ALC, B * 2 * c.Nl * KLIN) | zalloc(&e->YCF, B * BASC * NS);
+        if (c.with_resum) bad |= zalloc(&e->ACF, B * BASC * KSYN) | zalloc(&e->ALC, B * (c.with_nnlo ? 3 : 2) * c.Nl * KLIN) | zalloc(&e->YCF, B * BASC * NS);
         if (bad) return fail("eftb_create: out of device memory for the loop scratch");
     }
     HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
@@ -515,6 +565,8 @@ int eftb_set_table(eftb_engine* e, int id, const void* host, size_t nbytes) {
         const double* sv = static_cast<const double*>(host);
         for (int i = 0; i < NS; ++i) v[i] = 1.0 / (sv[i] * sv[i]);
         HIPCHK(hipMemcpy(e->sm2, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+        for (int i = 0; i < NS; ++i) v[i] = 1.0 / (sv[i] * sv[i] * sv[i] * sv[i]);
+        HIPCHK(hipMemcpy(e->sm4, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -532,6 +584,12 @@ int eftb_finalize(eftb_engine* e) {
             const size_t pbytes = (size_t)c.max_batch * e->resum_splits * 2 * c.Nl * c.Nl * 21 * c.Nk * sizeof(double);
             HIPCHK(hipMalloc(&e->part, pbytes));
             HIPCHK(hipMemset(e->part, 0, pbytes));  // the matrix-core kernel never touches k < Nklow
+        }
+        if (c.with_nnlo) {
+            HIPCHK(hipMalloc(&e->ZC, e->buf_elems[EFTB_B_C11] * sizeof(double)));
+            HIPCHK(hipMalloc(&e->ZC2, e->buf_elems[EFTB_B_CLOOPL] * sizeof(double)));
+            HIPCHK(hipMemset(e->ZC, 0, e->buf_elems[EFTB_B_C11] * sizeof(double)));
+            HIPCHK(hipMemset(e->ZC2, 0, e->buf_elems[EFTB_B_CLOOPL] * sizeof(double)));
         }
         if (c.Nl == 3) {
             HIPCHK(hipMalloc(&e->RSA, (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double)));
@@ -659,7 +717,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);

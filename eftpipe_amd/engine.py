@@ -40,6 +40,7 @@ class Engine:
         if cfg.with_resum:
             c.nxtail = t["lnx_xtail"].size
             c.NIR, c.Na, c.Nklow = (int(x) for x in t["resum_dims"])
+        c.with_nnlo = int(cfg.with_NNLO)
         self._cconf = c
         h = C.c_void_p()
         L.check(self.lib.eftb_create(C.byref(c), C.byref(h)))
@@ -72,6 +73,8 @@ class Engine:
         for n in ("L11", "LCT", "L22", "L13"):
             self._set(n, t[n.lower()])
         self._set("GRP", np.concatenate([t["grp22"], t["grp13"]]), np.int32)
+        if cfg.with_NNLO:
+            self._set("LCTN", t["lctn"])
         if cfg.with_resum:
             expc = np.zeros((cfg.Nl * 38, 32))
             expc[:, : t["expand_c"].shape[1]] = t["expand_c"]
@@ -195,13 +198,16 @@ class Engine:
         as1 = lambda x: None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (B,)))
         return B, Pin, as1(f), as1(DA), as1(H)
 
-    def eval_batch(self, Pin, f, DA=None, H=None, bias=None, templates=True, out=None):
+    def eval_batch(self, Pin, f, DA=None, H=None, bias=None, templates=True, out=None, bias_nnlo=None):
         """Pin [B, Nkin], f/DA/H [B] -> templates [B, nl, 24, nx] (+ P_l [B, nl, nx] if bias [B, 24]);
         (nl, nx) = out_dims(): (Nl, Nk) unless a pipeline operator (window / binning / chained) is set.
         templates=False (needs bias): only P_l crosses PCIe.  out: a template array to fill, e.g. ``pinned_empty`` memory
-        re-used across calls (D2H at the PCIe rate instead of through the pageable staging copy)."""
+        re-used across calls (D2H at the PCIe rate instead of through the pageable staging copy).
+        With cfg.with_NNLO the NNLO block stays on the device: ``get("TEMPLN", (B, nl, 24, nx))[:, :, 3:6]`` is PctNNLOl."""
         B, Pin, f, DA, H = self._inputs(Pin, f, DA, H)
         nl, nx = self.out_dims()
+        if self.cfg.with_NNLO and bias is not None:  # bctNNLO [B, 3] of the NNLO block (parambasis.nnlo_vector); zeros if not given
+            self.put("BIASN", np.zeros((B, 3)) if bias_nnlo is None else np.ascontiguousarray(bias_nnlo, dtype=np.float64).reshape(B, 3))
         if not templates and bias is None:
             raise ValueError("templates=False needs bias (nothing to return otherwise)")
         templ = None

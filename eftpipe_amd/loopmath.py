@@ -107,7 +107,7 @@ def vectors_13(nu):
 
 
 def mu_weights(Nl):
-    """l11[Nl,3], lct[Nl,6], l22[Nl,28], l13[Nl,10] (pybird.py:562-582), incl. 48/148 as written."""
+    """l11[Nl,3], lct[Nl,6], lctNNLO[Nl,3], l22[Nl,28], l13[Nl,10] (pybird.py:562-582), incl. 48/148 as written."""
     mu = {int(p): v for p, v in formula_data()["mu"].items()}
     pick = lambda plist: np.array([[mu[p][i] for p in plist] for i in range(Nl)], dtype=np.float64)
-    return dict(l11=pick(MU_POWER_11), lct=pick(MU_POWER_CT), l22=pick(MU_POWER_22), l13=pick(MU_POWER_13))
+    return dict(l11=pick(MU_POWER_11), lct=pick(MU_POWER_CT), lctNNLO=pick((4, 6, 8)), l22=pick(MU_POWER_22), l13=pick(MU_POWER_13))

@@ -63,12 +63,20 @@ def bias_row(f, bsA, bsB=None, es=(0.0, 0.0, 0.0), **scales):
     return np.concatenate(bias_vectors(f, bsA, bsB, es, **scales))
 
 
-def reduce_Plk(bird, bsA, bsB=None, es=(0.0, 0.0, 0.0)):
-    """BirdLike -> BirdComponent (reference parambasis.py:42-136; the counter-term form is bird.co.counterform; the NNLO
-    counter-terms are not on the path)."""
+def nnlo_vector(f, b1A, cnnloA, krA=0.25, counterform="westcoast"):
+    """bctNNLOAB[3] (reference parambasis.py:96-106): west coast cnnloA = (cr4, cr6); east coast (ctilde, _).
+    These are the EFTB_B_BIASN coefficients of the device reduce."""
+    if counterform == "westcoast":
+        cr4, cr6 = cnnloA
+        return np.array([1 / 4 * b1A**2 / krA**4 * cr4, 1 / 4 * b1A / krA**4 * cr6, 0.0])
+    ctilde = cnnloA[0]
+    return ctilde * np.array([-(b1A**2) * f**4, -2 * b1A * f**5, -(f**6)])
+
+
+def reduce_Plk(bird, bsA, bsB=None, es=(0.0, 0.0, 0.0), cnnloA=(0.0, 0.0), cnnloB=None):
+    """BirdLike -> BirdComponent (reference parambasis.py:42-136; the counter-term form is bird.co.counterform; with
+    bird.co.with_NNLO the k^4 counter-terms bctNNLO . PctNNLOl are added to Pct)."""
     co = bird.co
-    if getattr(co, "with_NNLO", False):
-        raise NotImplementedError("with_NNLO is off the accelerated path")
     b11, bct, bloop, bst = bias_vectors(bird.f, list(bsA), None if bsB is None else list(bsB), tuple(es),
                                         kmA=co.kmA, krA=co.krA, ndA=co.ndA, kmB=co.kmB, krB=co.krB, ndB=co.ndB,
                                         counterform=getattr(co, "counterform", "westcoast"))
@@ -76,7 +84,9 @@ def reduce_Plk(bird, bsA, bsB=None, es=(0.0, 0.0, 0.0)):
     return BirdComponent(
         Plin=np.einsum("b,lbx->lx", b11, bird.P11l[:No]),
         Ploop=np.einsum("b,lbx->lx", bloop, bird.Ploopl[:No]),
-        Pct=np.einsum("b,lbx->lx", bct, bird.Pctl[:No]),
+        Pct=np.einsum("b,lbx->lx", bct, bird.Pctl[:No])
+        + (np.einsum("b,lbx->lx", nnlo_vector(bird.f, list(bsA)[0], tuple(cnnloA), co.krA, getattr(co, "counterform", "westcoast")),
+                     bird.PctNNLOl[:No]) if getattr(co, "with_NNLO", False) else 0.0),
         Pst=np.einsum("b,lbx->lx", bst, bird.Pstl[:No]),
         Picc=bird.Picc[:No],
     )
@@ -236,7 +246,14 @@ class WestCoastBasis:
     def reduce_Plk(self, bird, params_values_dict):
         v = self.default()
         v.update(params_values_dict)
-        return reduce_Plk(bird, [v[p] for p in self.bsA()], [v[p] for p in self.bsB()] or None, [v[p] for p in self.es()])
+        cnnloA = [v[p] for p in self.cnnloA()] if getattr(bird.co, "with_NNLO", False) else (0.0, 0.0)
+        return reduce_Plk(bird, [v[p] for p in self.bsA()], [v[p] for p in self.bsB()] or None, [v[p] for p in self.es()], cnnloA)
+
+    def nnlo_row(self, f, params_values_dict, krA=0.25):
+        """EFTB_B_BIASN coefficients (cr4, cr6) for one walker"""
+        v = self.default()
+        v.update(params_values_dict)
+        return nnlo_vector(f, v[self.bsA()[0]], [v[p] for p in self.cnnloA()], krA, "westcoast")
 
     def bias_row(self, f, params_values_dict, **scales):
         """Device-reduce coefficients for one walker (the batched counterpart of reduce_Plk)."""
@@ -251,7 +268,16 @@ class WestCoastBasis:
     def reduce_Plk_gaussian_table(self, bird, params_values_dict, requires=None):
         co = bird.co
         rows = self.gaussian_rows(bird.f, params_values_dict, kmA=co.kmA, krA=co.krA, ndA=co.ndA, kmB=co.kmB, krB=co.krB, ndB=co.ndB)
-        return _table_from_rows(bird, rows[1:], gaussian_params(self.prefix, self.cross_prefix), requires)
+        PG = _table_from_rows(bird, rows[1:], gaussian_params(self.prefix, self.cross_prefix), requires)
+        if getattr(co, "with_NNLO", False) and not self.is_cross():  # reference parambasis.py:303-307
+            b1, No, st = params_values_dict[self.prefix + "b1"], co.No, PG.pop(self.prefix + "ce0", None)
+            extra = {self.prefix + "cr4": 1 / 4 * b1**2 / co.krA**4 * bird.PctNNLOl[:No, 0], self.prefix + "cr6": 1 / 4 * b1 / co.krA**4 * bird.PctNNLOl[:No, 1]}
+            PG.update({p: v for p, v in extra.items() if requires is None or p in requires})
+            if st is not None:  # keep the reference's insertion order: ..., cr4, cr6, ce0, cemono, cequad
+                rest = {p: PG.pop(p) for p in (self.prefix + "cemono", self.prefix + "cequad") if p in PG}
+                PG[self.prefix + "ce0"] = st
+                PG.update(rest)
+        return PG
 
 
 @dataclass(frozen=True)
@@ -301,7 +327,16 @@ class EastCoastBasis:
 
     def reduce_Plk(self, bird, params_values_dict):
         bsA, es = eastcoast_to_bs(bird.f, *self._values(params_values_dict))
-        return reduce_Plk(bird, bsA, None, es)  # bird.co.counterform must be 'eastcoast', as in the reference
+        v = self.default()
+        v.update(params_values_dict)
+        cnnloA = [v[self.prefix + "ctilde"], 0.0] if getattr(bird.co, "with_NNLO", False) else (0.0, 0.0)
+        return reduce_Plk(bird, bsA, None, es, cnnloA)  # bird.co.counterform must be 'eastcoast', as in the reference
+
+    def nnlo_row(self, f, params_values_dict, krA=0.25):
+        """EFTB_B_BIASN coefficients (ctilde) for one walker"""
+        v = self.default()
+        v.update(params_values_dict)
+        return nnlo_vector(f, v[self.prefix + "b1"], [v[self.prefix + "ctilde"], 0.0], krA, "eastcoast")
 
     def bias_row(self, f, params_values_dict, **scales):
         return eastcoast_bias_row(f, *self._values(params_values_dict), **scales)
@@ -312,7 +347,16 @@ class EastCoastBasis:
     def reduce_Plk_gaussian_table(self, bird, params_values_dict, requires=None):
         co = bird.co
         rows = self.gaussian_rows(bird.f, params_values_dict, kmA=co.kmA, krA=co.krA, ndA=co.ndA)
-        return _table_from_rows(bird, rows[1:], self.gaussian_params()[:7], requires)
+        PG = _table_from_rows(bird, rows[1:], self.gaussian_params()[:7], requires)
+        p = self.prefix + "ctilde"
+        if getattr(co, "with_NNLO", False) and (requires is None or p in requires):  # reference parambasis.py:429-435
+            b1, f, Pn = params_values_dict[self.prefix + "b1"], bird.f, bird.PctNNLOl[: co.No]
+            ct = -(b1**2) * f**4 * Pn[:, 0] - 2.0 * b1 * f**5 * Pn[:, 1] - f**6 * Pn[:, 2]
+            keys = list(PG)
+            st = {q: PG.pop(q) for q in keys if q in (self.prefix + "Pshot", self.prefix + "a0", self.prefix + "a2")}
+            PG[p] = ct  # reference order: bGamma3, c0, c2, c4, ctilde, Pshot, a0, a2
+            PG.update(st)
+        return PG
 
 
 def find_param_basis(name):

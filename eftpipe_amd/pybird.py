@@ -53,11 +53,11 @@ class Common(object):
 
     def __init__(self, Nl=None, No=None, kmax=0.3, optiresum=False, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None,
                  ndB=None, counterform="westcoast", with_NNLO=False, kIR=None, IRcutoff=False):
-        if optiresum or with_NNLO or IRcutoff:
-            raise NotImplementedError("optiresum / with_NNLO / IRcutoff are outside the accelerated hot path (SURVEY.md 8a)")
+        if optiresum or IRcutoff:
+            raise NotImplementedError("optiresum / IRcutoff are outside the accelerated hot path (SURVEY.md 8a)")
         if counterform not in ("westcoast", "eastcoast"):  # the templates are the same; only reduce_Plk reads it
             raise ValueError(f"unexpected counterform: {counterform}")
-        self.optiresum, self.with_NNLO, self.IRcutoff, self.kIR = False, False, False, kIR
+        self.optiresum, self.with_NNLO, self.IRcutoff, self.kIR = False, bool(with_NNLO), False, kIR
         self.counterform = counterform
         self.kmA, self.krA, self.ndA = kmA, krA, ndA
         self.kmB = kmA if kmB is None else kmB
@@ -82,6 +82,7 @@ class Common(object):
         self.Nklow = self.Nk - self.Nkr
         w = lm.mu_weights(self.Nl)
         self.l11, self.lct, self.l22, self.l13 = w["l11"], w["lct"], w["l22"], w["l13"]
+        self.lctNNLO = w["lctNNLO"]
 
 
 common = Common()
@@ -93,12 +94,13 @@ _ENGINES: "weakref.WeakKeyDictionary[Common, Engine]" = weakref.WeakKeyDictionar
 def engine_for(co, nbinsmu=200, loop_cache=None):
     """The engine serving `co`, created on first use with the resum and AP tables resident."""
     eng = _ENGINES.get(co)
-    if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != nbinsmu):
+    if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != nbinsmu
+                            or eng.cfg.with_NNLO != bool(co.with_NNLO)):
         eng.close()
         eng = None
     if eng is None:
         cfg = EngineConfig(Nl=co.Nl, k=np.array(co.k, dtype=np.float64), with_resum=True, with_ap=True, DA_AP=1.0, H_AP=1.0,
-                           nbinsmu=nbinsmu)
+                           nbinsmu=nbinsmu, with_NNLO=bool(co.with_NNLO))
         eng = _ENGINES[co] = Engine(cfg, max_batch=1, loop_cache=loop_cache)
     return eng
 
@@ -113,7 +115,7 @@ class BirdSnapshot:
         self.co, self.f = bird.co, bird.f
         for n in ("P11l", "Ploopl", "Pctl", "Pstl", "Picc"):
             setattr(self, n, getattr(bird, n).copy())
-        self.PctNNLOl = None
+        self.PctNNLOl = None if bird.PctNNLOl is None else bird.PctNNLOl.copy()
 
 
 class Bird:
@@ -132,7 +134,7 @@ class Bird:
         self.P22, self.P13 = None, None
         self.C11 = self.Cct = self.C22 = self.C13 = None
         self.P11l = self.Pctl = self.Ploopl = self.Cloopl = self.Pstl = None
-        self.PctNNLOl = None
+        self.PctNNLOl = self.CctNNLO = None  # filled when co.with_NNLO (reference pybird.py:741-748, 1098-1101)
         self.Picc = np.zeros((Nl, Nk))
         self.snapshots = {}
         self._engine = None
@@ -151,11 +153,17 @@ class Bird:
         for n, sl in ROWS.items():
             T[:, sl] = getattr(self, n)
         eng.put("TEMPL", T)
+        if self.co.with_NNLO:  # second block: PctNNLOl in the Pctl slots, zero elsewhere (include/eftbird.h EFTB_B_TEMPLN)
+            T[:] = 0.0
+            T[:, 3:6] = self.PctNNLOl
+            eng.put("TEMPLN", T)
 
     def _templates_from_device(self, eng, names=("P11l", "Pctl", "Ploopl", "Pstl")):
         T = eng.get("TEMPL", (self.co.Nl, 24, self.co.Nk))
         for n in names:
             setattr(self, n, np.ascontiguousarray(T[:, ROWS[n]]))
+        if self.co.with_NNLO:
+            self.PctNNLOl = np.ascontiguousarray(eng.get("TEMPLN", (self.co.Nl, 24, self.co.Nk))[:, 3:6])
 
     def setPsCfl(self):
         """Multipole weights, regrouping into the 12 bias groups, shot-noise subtraction, stochastic
@@ -196,7 +204,7 @@ class NonLinear(HasLogger):
         if load is True:
             try:
                 with np.load(egg) as z:
-                    cache = {k: z[k] for k in ("Pow", "M22", "M13", "Mcf11", "Mcfct")}
+                    cache = {k: z[k] for k in ("Pow", "M22", "M13", "Mcf11", "Mcfct", "McfctNNLO")}
                 save = False
             except Exception:  # same policy as the reference: warn and recompute
                 self.mpi_warning("Can't load loop matrices at %s, computing new matrices.", path)
@@ -232,6 +240,8 @@ class NonLinear(HasLogger):
         bird.P13 = eng.get("P13", (co.N13, co.Nk))
         bird.C11 = eng.get("C11", (co.Nl, co.Ns))
         bird.Cct = eng.get("CCT", (co.Nl, co.Ns))
+        if co.with_NNLO:
+            bird.CctNNLO = eng.get("CCTN", (co.Nl, co.Ns))
         cc = eng.get("CC", (co.Nl * 38, co.Ns))
         bird.C22 = np.ascontiguousarray(cc[: co.Nl * 28].reshape(co.Nl, 28, co.Ns))
         bird.C13 = np.ascontiguousarray(cc[co.Nl * 28 :].reshape(co.Nl, 10, co.Ns))
@@ -272,6 +282,8 @@ class Resum(HasLogger):
         eng.put("C11", bird.C11)
         eng.put("CCT", bird.Cct)
         eng.put("CLOOPL", bird.Cloopl)
+        if co.with_NNLO:
+            eng.put("CCTN", bird.CctNNLO)
         bird._templates_to_device(eng)
         eng.run(L.S_RESUM)
         bird._templates_from_device(eng, ("P11l", "Pctl", "Ploopl"))
@@ -380,5 +392,7 @@ class FiberCollision(HasLogger):
         out = apply_operator_to_birdlike(eng, self._op[1], bird)
         bird.P11l, bird.Pctl, bird.Ploopl = out["P11l"], out["Pctl"], out["Ploopl"]
         bird.Pstl = out["Pstl"] if self.fiberst else keep
+        if "PctNNLOl" in out:
+            bird.PctNNLOl = out["PctNNLOl"]
         if self.snapshot:
             bird.create_snapshot("fiber")

@@ -227,6 +227,7 @@ class EngineConfig:
     H_AP: Optional[float] = None
     nbinsmu: int = 200
     APst: bool = False
+    with_NNLO: bool = False                 # Common(with_NNLO=True): the k^4 P11 counter-terms (pybird.py:741-748)
     extra: dict = field(default_factory=dict)
 
 
@@ -321,11 +322,18 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
             vecs += [np.asarray(loop_cache["Mcf11"]), np.asarray(loop_cache["Mcfct"])]
         else:
             vecs += [lm.bessel_weight(ells[:, None], nu[None, :]), lm.bessel_weight(ells[:, None], nu[None, :] - 1.0)]
+        if cfg.with_NNLO:  # McfctNNLO (reference pybird.py:1054-1056)
+            if loop_cache is not None and np.shape(loop_cache.get("McfctNNLO")) == (Nl, NPOW):
+                vecs.append(np.asarray(loop_cache["McfctNNLO"]))
+            else:
+                vecs.append(lm.bessel_weight(ells[:, None], nu[None, :] - 2.0))
         t["syn_s"] = synthesis_table(np.log(s), -2.0 * op.bias - 6.0, op.dpow, NPOW - 1, sign=-1.0)
         t["lin_s"] = synthesis_table(np.log(s), -op.bias - 3.0, op.dpow, NHALF, sign=+1.0)
     else:
         t["ad"] = antidiagonal_tables(M22[basis], None)
-    t["linvec"] = np.ascontiguousarray(np.concatenate(vecs)[:, :nh])          # [10 (+ 2 Nl), 129] complex: M13, Mcf11, Mcfct
+    t["linvec"] = np.ascontiguousarray(np.concatenate(vecs)[:, :nh])          # [10 (+ 2|3 Nl), 129] complex: M13, Mcf11, Mcfct (, McfctNNLO)
+    if cfg.with_NNLO:
+        t["lctn"] = np.concatenate([w["lctNNLO"], np.zeros((Nl, 3))], axis=1)  # the NNLO block keeps lctNNLO in the first 3 Pctl slots
     t["syn_k"] = synthesis_table(np.log(k), 3.0 + 2.0 * op.bias, op.dpow, NPOW - 1, sign=+1.0)
     t["lin_k"] = synthesis_table(np.log(k), 3.0 + op.bias, op.dpow, NHALF, sign=-1.0)
 

@@ -37,7 +37,7 @@ class BirdCopier:
 
 def apply_operator_to_birdlike(eng, op_id, birdlike):
     """Upload the four template arrays of a BirdLike, run one registered operator on the device, download.
-    -> dict(P11l, Pctl, Ploopl, Pstl) with the operator's output shape."""
+    -> dict(P11l, Pctl, Ploopl, Pstl[, PctNNLOl]) with the operator's output shape."""
     nl, nx = birdlike.P11l.shape[0], birdlike.P11l.shape[-1]
     T = np.empty((nl, 24, nx))
     for n, sl in ROWS.items():
@@ -47,7 +47,16 @@ def apply_operator_to_birdlike(eng, op_id, birdlike):
     eng.apply_operator(op_id, 1)
     nlo, nxo = eng.dims
     out = eng.get("TEMPL", (nlo, 24, nxo))
-    return {n: np.ascontiguousarray(out[:, sl]) for n, sl in ROWS.items()}
+    res = {n: np.ascontiguousarray(out[:, sl]) for n, sl in ROWS.items()}
+    nnlo = getattr(birdlike, "PctNNLOl", None)
+    if nnlo is not None:  # the NNLO counter-terms ride through the same operator in the Pctl slots of a second block
+        T[:] = 0.0
+        T[:, 3:6] = nnlo
+        eng.set_template_dims(nl, nx)
+        eng.put("TEMPL", T)
+        eng.apply_operator(op_id, 1)
+        res["PctNNLOl"] = np.ascontiguousarray(eng.get("TEMPL", (nlo, 24, nxo))[:, 3:6])
+    return res
 
 
 class PlkInterpolator:

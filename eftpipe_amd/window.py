@@ -111,5 +111,7 @@ class Window(HasLogger):
         out = apply_operator_to_birdlike(eng, self._op[1], bird)
         bird.P11l, bird.Pctl, bird.Ploopl = out["P11l"], out["Pctl"], out["Ploopl"]
         bird.Pstl = out["Pstl"] if self.window_st else keep
+        if "PctNNLOl" in out:
+            bird.PctNNLOl = out["PctNNLOl"]
         if self.snapshot:
             bird.create_snapshot("window")

@@ -42,6 +42,7 @@ typedef struct eftb_config {
     int32_t nbasis;        /* dimension of the span of the 28 M22 loop matrices (7)     tables.py loop_basis */
     int32_t nbasis13;      /* dimension of the span of the 10 M13 vectors (2)           tables.py loop_basis */
     int32_t NIR, Na, Nklow;/* Resum.NIR, Resum.Na, Common.Nklow                         pybird.py:1247-1259, 560 */
+    int32_t with_nnlo;     /* Common.with_NNLO: the k^4 P11 counter-terms PctNNLOl       pybird.py:741-748, 1447-1458, 1615 */
 } eftb_config;
 
 /* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file). */
@@ -53,6 +54,7 @@ enum eftb_table {
     EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
     EFTB_T_RSBASIS, EFTB_T_RSBASISS, EFTB_T_RSROWS,   /* matrix-core IR-resummation (Nl = 3): tables.py resum_mfma_tables */
     EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
+    EFTB_T_LCTN,      /* with_nnlo: Common.lctNNLO [Nl][3] zero padded to [Nl][6]     pybird.py:575 */
     EFTB_T_COUNT
 };
 
@@ -79,6 +81,11 @@ enum eftb_buffer {
     EFTB_B_COEF,      /* [B][2][129]          FFTLog coefficients (independent half, re/im) */
     EFTB_B_GROWS,     /* [B][17][24]          coefficient rows of P_NG (row 0) and dP/d(gaussian parameter) (rows 1..nG)   parambasis.py:249-316 */
     EFTB_B_LOGP,      /* [B][18]              marginalised ln P, full chi2 at the best fit, best-fit gaussian parameters  marginal.py:79-140 */
+    /* with_nnlo only.  The NNLO counter-terms travel as a second template block whose Pctl slots (rows 3-5) hold PctNNLOl and
+     * whose other rows are zero: every linear stage (Resum with Q[1] and lctNNLO, AP, the operators) runs on it unchanged. */
+    EFTB_B_CCTN,      /* [B][Nl][80]          Bird.CctNNLO                        pybird.py:1098-1101 */
+    EFTB_B_TEMPLN,    /* [B][nl][24][nx]      rows 3-5 = Bird.PctNNLOl            pybird.py:741-748 */
+    EFTB_B_BIASN,     /* [B][3]               bctNNLO                             parambasis.py:96-106 */
     EFTB_B_COUNT
 };
 

@@ -75,6 +75,7 @@ class OracleConfig:
     H_AP: Optional[float] = None
     nbinsmu: int = 200
     APst: bool = False
+    with_NNLO: bool = False  # Common(with_NNLO=True) (pybird.py:511, 741-748)
     # window
     window_file: Optional[str] = None  # config-space window "s Q0 Q2 ..."
     window_accboost: int = 1
@@ -110,6 +111,7 @@ class OracleEngine:
         self.ndB = cfg.ndA if cfg.ndB is None else cfg.ndB
         w = T.mu_weights(Nl)
         self.l11, self.lct, self.l22, self.l13 = w["l11"], w["lct"], w["l22"], w["l13"]
+        self.lctNNLO = w["lctNNLO"]
         self._init_loops()
         if cfg.with_resum:
             self._init_resum()
@@ -133,6 +135,7 @@ class OracleEngine:
         self.Mcf11 = T.mpc(ells[:, None], nu[None, :])
         self.Ml = T.mpc(ells[:, None, None], nu[None, :, None] + nu[None, None, :] - 1.5)
         self.Mcfct = T.mpc(ells[:, None], nu - 1.0)
+        self.McfctNNLO = T.mpc(ells[:, None], nu - 2.0)  # pybird.py:1054-1056
         self.Mcf22 = np.einsum("lnm,bnm->blnm", self.Ml, self.M22)
         self.Mcf13 = np.einsum("lnm,bn->blnm", self.Ml, self.M13)
         self.kPow = np.exp(np.einsum("n,k->nk", self.fft.Pow, np.log(self.k)))
@@ -166,6 +169,8 @@ class OracleEngine:
         out["P13"] = self.k**3 * P11 * np.real(np.einsum("nk,bn->bk", ck, self.M13, optimize=self.path_P13))
         out["C11"] = np.real(np.einsum("ns,ln->ls", cs, self.Mcf11, optimize=self.path_C11))
         out["Cct"] = self.s**-2 * np.real(np.einsum("ns,ln->ls", cs, self.Mcfct, optimize=self.path_C11))
+        if self.cfg.with_NNLO:  # makeCctNNLO (pybird.py:1098-1101)
+            out["CctNNLO"] = self.s**-4 * np.real(np.einsum("ns,ln->ls", cs, self.McfctNNLO, optimize=self.path_C11))
         out["C22"] = np.real(np.einsum("ns,ms,blnm->lbs", cs, cs, self.Mcf22, optimize=self.path_C22))
         out["C13"] = np.real(np.einsum("ns,ms,blnm->lbs", cs, cs, self.Mcf13, optimize=self.path_C13))
         return out
@@ -213,7 +218,10 @@ class OracleEngine:
         Pstl[0, 1] = k2
         if self.Nl >= 2:
             Pstl[1, 2] = k2
-        return dict(P11l=P11l, Pctl=Pctl, Ploopl=Ploopl, Cloopl=Cloopl, Pstl=Pstl, Picc=np.zeros((self.Nl, self.Nk)))
+        out = dict(P11l=P11l, Pctl=Pctl, Ploopl=Ploopl, Cloopl=Cloopl, Pstl=Pstl, Picc=np.zeros((self.Nl, self.Nk)))
+        if self.cfg.with_NNLO:  # pybird.py:741-748
+            out["PctNNLOl"] = np.einsum("x,x,ln->lnx", self.k**4, st["P11"], self.lctNNLO)
+        return out
 
     # ------------------------------------------------------------------ Resum
     def _init_resum(self):
@@ -271,6 +279,9 @@ class OracleEngine:
         out["P11l"] = st["P11l"] + np.einsum("lpn,pnk,pi->lik", Q[0], IR11, self.l11)
         out["Pctl"] = st["Pctl"] + np.einsum("lpn,pnk,pi->lik", Q[1], IRct, self.lct)
         out["Ploopl"] = st["Ploopl"] + np.einsum("lpn,pink->lik", Q[1], IRloop)
+        if self.cfg.with_NNLO:  # pybird.py:1447-1458
+            IRn = self._ir_block(XpYp, st["CctNNLO"])
+            out["PctNNLOl"] = st["PctNNLOl"] + np.einsum("lpn,pnk,pi->lik", Q[1], IRn, self.lctNNLO)
         out.update(X=X, Y=Y, Q=Q)
         return out
 
@@ -305,7 +316,7 @@ class OracleEngine:
         leg_mup = np.array([legendre(2 * i)(mup) for i in range(self.Nl)])
         c = 1.0 / (qperp**2 * qpar)
         out = dict(st)
-        for name in ("P11l", "Pctl", "Ploopl") + (("Pstl",) if self.cfg.APst else ()):
+        for name in ("P11l", "Pctl", "Ploopl") + (("Pstl",) if self.cfg.APst else ()) + (("PctNNLOl",) if self.cfg.with_NNLO else ()):
             out[name] = c * self._integr_ap(st[name], kp, leg_mup)
         return out
 
@@ -349,7 +360,7 @@ class OracleEngine:
     def window(self, st):
         """Window convolution of every template (reference window.py:371-415)."""
         out = dict(st)
-        for name in ("P11l", "Pctl", "Ploopl") + (("Pstl",) if self.cfg.window_st else ()):
+        for name in ("P11l", "Pctl", "Ploopl") + (("Pstl",) if self.cfg.window_st else ()) + (("PctNNLOl",) if self.cfg.with_NNLO else ()):
             Pp = cubic_to(self.k, st[name], self.p)
             out[name] = np.einsum("alkp,lsp->ask", self.Waldk, Pp, optimize=True)
         return out
@@ -368,7 +379,7 @@ class OracleEngine:
     def binning(self, st):
         """k^2-weighted bin average (reference binning.py:131-162)."""
         out = dict(st)
-        for name in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc"):
+        for name in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc") + (("PctNNLOl",) if "PctNNLOl" in st else ()):
             Pk = interp1d(self.k, st[name], axis=-1, kind="cubic", bounds_error=False, fill_value="extrapolate")
             out[name] = _trapz(Pk(self.points) * self.points**2, x=self.points, axis=-1) / self.binvol
         return out
@@ -385,7 +396,7 @@ class OracleEngine:
         for a in range(Nl - 1):
             mat[a, a], mat[a, a + 1] = 1.0, -self.chain_coeff(2 * a)
         out = dict(st)
-        for name in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc"):
+        for name in ("P11l", "Pctl", "Ploopl", "Pstl", "Picc") + (("PctNNLOl",) if "PctNNLOl" in st else ()):
             out[name] = np.einsum("al,l...->a...", mat, st[name], optimize=True)
         return out
 
@@ -420,11 +431,23 @@ class OracleEngine:
             bct = np.array([-cctA - cctB, -(cr1A + cr1B) * f, -(cr2A + cr2B) * f**2, 0.0, 0.0, 0.0])
         return b11, bloop, bct, bst
 
-    def reduce_plk(self, f, st, bsA, bsB=None, es=(0.0, 0.0, 0.0), counterform="westcoast"):
-        """P_l(k) = b11.P11l + bloop.Ploopl + bct.Pctl + bst.Pstl + Picc (parambasis.py:128-136)."""
+    def nnlo_vector(self, f, bsA, cnnloA, counterform="westcoast"):
+        """bctNNLOAB (parambasis.py:96-106): west coast (cr4, cr6), east coast (ctilde, _)"""
+        b1A = bsA[0]
+        if counterform == "westcoast":
+            cr4, cr6 = cnnloA
+            return np.array([1 / 4 * b1A**2 / self.krA**4 * cr4, 1 / 4 * b1A / self.krA**4 * cr6, 0.0])
+        ctilde = cnnloA[0]
+        return ctilde * np.array([-(b1A**2) * f**4, -2 * b1A * f**5, -(f**6)])
+
+    def reduce_plk(self, f, st, bsA, bsB=None, es=(0.0, 0.0, 0.0), counterform="westcoast", cnnloA=None):
+        """P_l(k) = b11.P11l + bloop.Ploopl + bct.Pctl (+ bctNNLO.PctNNLOl) + bst.Pstl + Picc (parambasis.py:128-136)."""
         b11, bloop, bct, bst = self.bias_vectors(f, bsA, bsB, es, counterform)
         No = min(self.No, st["P11l"].shape[0])
-        return (
+        extra = 0.0
+        if cnnloA is not None:
+            extra = np.einsum("b,lbx->lx", self.nnlo_vector(f, bsA, cnnloA, counterform), st["PctNNLOl"][:No])
+        return extra + (
             np.einsum("b,lbx->lx", b11, st["P11l"][:No])
             + np.einsum("b,lbx->lx", bloop, st["Ploopl"][:No])
             + np.einsum("b,lbx->lx", bct, st["Pctl"][:No])

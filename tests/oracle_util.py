@@ -16,6 +16,7 @@ CASE_FLAGS = {
     "caseE": dict(resum=True, ap=True),
     "caseF": dict(resum=True, ap=True),
     "caseG": dict(resum=True, ap=True, APst=True, window=True),
+    "nnlo": dict(resum=True, ap=True, APst=True, window=True, binning=True, with_NNLO=True),
 }
 
 
@@ -27,7 +28,7 @@ def oracle_config(g, name, **over):
         with_resum=fl.get("resum", False), with_ap=fl.get("ap", False), APst=fl.get("APst", False),
         Om_AP=synth.OM_AP, z_AP=float(g["z"]),
         window_file=WINDOW_FIXTURE if fl.get("window") else None,
-        kout=g["kout"] if fl.get("binning") else None,
+        kout=g["kout"] if fl.get("binning") else None, with_NNLO=fl.get("with_NNLO", False),
     )
     for k, v in over.items():
         setattr(cfg, k, v)

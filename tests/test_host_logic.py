@@ -22,7 +22,11 @@ def test_common_mirror_matches_reference_tables(golden):
     with pytest.raises(ValueError):
         pybird.Common(Nl=2, No=3)
     with pytest.raises(NotImplementedError):
-        pybird.Common(Nl=2, with_NNLO=True)
+        pybird.Common(Nl=2, optiresum=True)
+    from oracle import tables as OT
+
+    con = pybird.Common(Nl=3, with_NNLO=True)
+    assert con.with_NNLO and np.array_equal(con.lctNNLO, OT.mu_weights(3)["lctNNLO"]) and con.NctNNLO == 3
     # reference tests/test_pybird.py:5-11
     assert np.isclose(pybird.Hubble(0.2, 1.0), 1.549193338482967, atol=0.0)
     assert np.isclose(pybird.DAfunc(0.2, 1.0), 0.4117451980802465, atol=0.0)

@@ -198,3 +198,43 @@ def test_fiber_collision(golden):
         for n in st:
             assert relerr(out[n], g["fiber_" + tag + n]) < 1e-13, (fiberst, n)
     assert np.array_equal(g["fiber_Pstl"], c["window_Pstl"])
+
+
+def test_nnlo_counterterms(golden):
+    """oracle == reference with Common(with_NNLO=True), stage by stage, both counter-term forms."""
+    from oracle import fiber as F
+    from oracle import marginal as M
+
+    g = golden("nnlo")
+    eng = oracle_engine(g, "nnlo")
+    f = float(g["f"])
+    taps = {}
+    st = eng.evaluate(g["kin"], g["Pin"], f, float(g["DA"]), float(g["H"]), taps=taps)
+    assert relerr(taps["pscf"]["CctNNLO"], g["pscf_CctNNLO"]) < TOL
+    assert relerr(taps["setpscfl"]["PctNNLOl"], g["setpscfl_PctNNLOl"]) < TOL
+    assert relerr(taps["resum"]["PctNNLOl"], g["resum_PctNNLOl"]) < TOL
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl", "PctNNLOl"):
+        assert relerr(taps["ap"][n], g["ap_" + n]) < TOL, n
+        assert relerr(st[n], g["window_" + n]) < 1e-9, n
+    bsA, es, cn = list(g["bsA"]), tuple(g["es"]), list(g["cnnlo"])
+    assert relerr(eng.reduce_plk(f, taps["ap"], bsA, es=es, cnnloA=cn), g["plk_ap_west"]) < TOL
+    fib = F.fibcol_window(st, g["k"], 3, float(g["fs"]), float(g["Dfc"]), float(g["ktrust"]))
+    fib["PctNNLOl"] = st["PctNNLOl"] + F.dpcorr(g["k"], g["k"], st["PctNNLOl"], 3, ktrust=float(g["ktrust"]), fs=float(g["fs"]), Dfc=float(g["Dfc"]))
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl", "PctNNLOl"):
+        assert relerr(fib[n], g["fiber_" + n]) < 1e-9, n
+    binned = eng.binning(fib)
+    ch = eng.chained(binned)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl", "PctNNLOl"):
+        assert relerr(binned[n], g["binned_" + n]) < 1e-9, n
+        assert relerr(ch[n], g["chained_" + n]) < 1e-9, n
+    assert relerr(eng.reduce_plk(f, binned, bsA, es=es, cnnloA=cn), g["plk_binned_west"]) < 1e-9
+    full = dict(zip(g["east_names"], g["east_values"]))
+    ctilde = full.pop("ctilde")
+    bsE, esE = M.eastcoast_bs(f, **full)
+    assert relerr(eng.reduce_plk(f, binned, bsE, None, esE, counterform="eastcoast", cnnloA=[ctilde, 0.0]), g["plk_binned_east"]) < 1e-9
+    # Gaussian-table entries of the NNLO parameters (parambasis.py:303-307, 429-435)
+    Pn = binned["PctNNLOl"]
+    b1 = full["b1"]
+    assert relerr(-(b1**2) * f**4 * Pn[:, 0] - 2.0 * b1 * f**5 * Pn[:, 1] - f**6 * Pn[:, 2], g["east_table_ctilde"]) < 1e-9
+    assert relerr(0.25 * 2.1**2 / eng.krA**4 * Pn[:, 0], g["west_table_cr4"]) < 1e-9
+    assert relerr(0.25 * 2.1 / eng.krA**4 * Pn[:, 1], g["west_table_cr6"]) < 1e-9

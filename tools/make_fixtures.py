@@ -143,6 +143,68 @@ def run_case(ref, name, spec):
     print(name, "written:", {k: np.shape(v) for k, v in out.items() if np.ndim(v) > 0 and k.startswith(("ap_", "plk"))})
 
 
+def nnlo_fixture(ref):
+    """Common(with_NNLO=True) through the REAL reference: CctNNLO, PctNNLOl after setPsCfl, Resum.Ps,
+    APeffect.AP, Window, FiberCollision, Binning, Chained; reduce_Plk with the NNLO counter-terms in both counter-term forms."""
+    pb = ref.pybird
+    Nl, z = 3, 0.7
+    cos = synth.cosmology(z=z)
+    out = dict(kin=cos["kin"], Pin=cos["Pin"], f=cos["f"], DA=cos["DA"], H=cos["H"], z=z, Nl=Nl, bsA=BS_A, es=ES, cnnlo=[0.7, -1.3],
+               ctilde=[400.0])
+    co = make_common(pb, Nl, None, with_NNLO=True)
+    out["k"] = co.k
+    nl = pb.NonLinear(load=False, save=False, co=co)
+    bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+    nl.PsCf(bird)
+    out["pscf_CctNNLO"] = bird.CctNNLO.copy()
+    bird.setPsCfl()
+    out["setpscfl_PctNNLOl"] = bird.PctNNLOl.copy()
+    pb.Resum(co=co).Ps(bird)
+    out["resum_PctNNLOl"] = bird.PctNNLOl.copy()
+    ap = pb.APeffect(Om_AP=synth.OM_AP, z_AP=z, co=co, APst=True)
+    out["DA_AP"], out["H_AP"] = ap.DA, ap.H
+    ap.AP(bird)
+    names = ("P11l", "Pctl", "Ploopl", "Pstl", "PctNNLOl")
+    for n in names:
+        out["ap_" + n] = getattr(bird, n).copy()
+    out["plk_ap_west"] = ref.parambasis.reduce_Plk(bird, BS_A, es=ES, cnnloA=out["cnnlo"]).sum()
+    wfile = os.path.join(REFERENCE_ROOT, "data", "DR16_noric", "win_NGC_LRG.txt")
+    ref.window.Window(window_configspace_file=wfile, co=co, load=False, save=False).Window(bird)
+    for n in names:
+        out["window_" + n] = getattr(bird, n).copy()
+    out["fs"], out["Dfc"], out["ktrust"] = 0.46, 0.43 / 0.6777, 0.25
+    pb.FiberCollision(fs=out["fs"], Dfc=out["Dfc"], ktrust=out["ktrust"], fiberst=False, co=co).fibcolWindow(bird)
+    for n in names:
+        out["fiber_" + n] = getattr(bird, n).copy()
+    kout = np.arange(0.025, 0.2, 0.01)
+    out["kout"] = kout
+    binned = ref.binning.Binning(kout=kout, co=co).transform(bird)
+    for n in names:
+        out["binned_" + n] = np.array(getattr(binned, n), copy=True)
+    out["plk_binned_west"] = ref.parambasis.reduce_Plk(binned, BS_A, es=ES, cnnloA=out["cnnlo"]).sum()
+    ch = ref.chained.Chained().transform(binned)
+    for n in names:
+        out["chained_" + n] = np.array(getattr(ch, n), copy=True)
+    # east coast: same templates, counterform='eastcoast', ctilde (parambasis.py:99-106, 378-397)
+    coe = make_common(pb, Nl, None, with_NNLO=True, counterform="eastcoast")
+    east = ref.parambasis.EastCoastBasis(prefix="")
+    full = {"b1": 2.1, "b2": -0.4, "bG2": 0.25, "bGamma3": -0.3, "c0": 5.0, "c2": 12.0, "c4": -3.0, "Pshot": 0.4, "a0": -0.6, "a2": 1.1,
+            "ctilde": out["ctilde"][0]}
+    holder = ref.transformer.PlainBird(f=binned.f, co=coe, P11l=binned.P11l, Ploopl=binned.Ploopl, Pctl=binned.Pctl, Pstl=binned.Pstl,
+                                       Picc=binned.Picc, PctNNLOl=binned.PctNNLOl)
+    out["east_names"], out["east_values"] = np.array(list(full)), np.array(list(full.values()))
+    out["plk_binned_east"] = east.reduce_Plk(holder, full).sum()
+    tab = east.reduce_Plk_gaussian_table(holder, {p: full[p] for p in ("b1", "b2", "bG2")})
+    out["east_table_ctilde"] = tab["ctilde"]
+    cow = make_common(pb, Nl, None, with_NNLO=True)
+    holder.co = cow
+    west = ref.parambasis.WestCoastBasis(prefix="")
+    tabw = west.reduce_Plk_gaussian_table(holder, {"b1": 2.1, "b2": 0.5, "b4": 0.1})
+    out["west_table_cr4"], out["west_table_cr6"] = tabw["cr4"], tabw["cr6"]
+    np.savez_compressed(os.path.join(GOLD, "nnlo.npz"), **out)
+    print("nnlo written:", {k: np.shape(v) for k, v in out.items() if "NNLO" in k})
+
+
 def marg_fixture(ref):
     """the Gaussian (derivative) table and the analytically marginalised log-posterior, from the
     REAL reference (parambasis.WestCoastBasis.reduce_Plk_gaussian_table, marginal.Marginalizable.marginalized_logp) on
@@ -393,7 +455,7 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -405,6 +467,8 @@ def main():
             east_fixture(ref)
         elif name == "fiber":
             fiber_fixture(ref)
+        elif name == "nnlo":
+            nnlo_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
