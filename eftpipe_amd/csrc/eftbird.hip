@@ -72,6 +72,7 @@ struct eftb_engine {
     int Nn = 0;
     double* sm2 = nullptr;  // s^-2 row scale of Cct
     double* sm4 = nullptr;  // s^-4 row scale of CctNNLO
+    double *coef2 = nullptr, *coefT2 = nullptr;  // dual_coef: FFTLog coefficients of the xi-space pieces (layouts of EFTB_B_COEF / coefT)
     double *ZC = nullptr, *ZC2 = nullptr;  // with_nnlo: zeros standing in for C11 [B][Nl][80] / Cloopl [B][Nl][12][80] in the NNLO pass of Resum.Ps
     // RCCL gather (multi-GPU batches)
     ncclComm_t comm = nullptr;
@@ -162,6 +163,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
         case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
         case EFTB_T_LCTN: return c.with_nnlo ? D * c.Nl * 6 : 0;
+        case EFTB_T_GCT2: return c.dual_coef ? D * 2 * c.Nkin * NCH : 0;
     }
     return 0;
 }
@@ -214,12 +216,12 @@ static void launch_synth(hipStream_t st, const SynthBatch& sb) {
 
 // anti-diagonal sums of every loop matrix for the batch (shared by the k-space and the xi-space pieces), then the
 // synthesis rows selected by `sets` (build_rows_kernel)
-static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets) {
+static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets, const double* coef, const double* coefT) {
     const eftb_config& c = e->c;
     const int nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
     const dim3 grid(NPOW, (B + 63) / 64, AD_CH), rgrid(B, 2);
-#define AD_ARGS B, c.max_batch, e->coefT, tb<double2>(e, EFTB_T_AD), e->SAD
-#define ROW_ARGS sets, c.max_batch, c.Nl, c.with_nnlo ? 3 : 2, c.nbasis, e->buf[EFTB_B_COEF], e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
+#define AD_ARGS B, c.max_batch, coefT, tb<double2>(e, EFTB_T_AD), e->SAD
+#define ROW_ARGS sets, c.max_batch, c.Nl, c.with_nnlo ? 3 : 2, c.nbasis, coef, e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
                  e->ACF, e->ALC
     if (nc == 9) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(64), 0, st, AD_ARGS);
@@ -308,6 +310,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
                            b[EFTB_B_P11], b[EFTB_B_COEF], e->coefT, c.max_batch);
+        if (c.dual_coef)  // IRcutoff "loop" / "resum": a second coefficient set for the xi-space pieces (reference pybird.py:1151-1160)
+            hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN],
+                               tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT2), tb<double>(e, EFTB_T_ECT),
+                               tb<double>(e, EFTB_T_LNXTAIL), b[EFTB_B_P11], e->coef2, e->coefT2, c.max_batch);
     }
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
     // the anti-diagonal sums serve both the k-space and the xi-space pieces: one pass, then the synthesis rows of
@@ -318,7 +324,14 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (mask & EFTB_S_LOOPS) sets |= 0x4;
         if (mask & (EFTB_S_CF | EFTB_K_C22)) sets |= 0x2;
         if (mask & EFTB_S_CF) sets |= 0x8;
-        if (int rc = launch_antidiag_rows(e, st, B, sets)) return rc;
+        if (!c.dual_coef) {
+            if (int rc = launch_antidiag_rows(e, st, B, sets, b[EFTB_B_COEF], e->coefT)) return rc;
+        } else {  // k-space rows from the first coefficient set, xi-space rows from the second (the sums are recomputed in between)
+            if (sets & 0x5)
+                if (int rc = launch_antidiag_rows(e, st, B, (sets & 0x5) | 0x10, b[EFTB_B_COEF], e->coefT)) return rc;
+            if (sets & 0xa)
+                if (int rc = launch_antidiag_rows(e, st, B, (sets & 0xa) | 0x10, e->coef2, e->coefT2)) return rc;
+        }
     }
     {
         // every synthesis of the requested pieces in one launch, then both expansions in one launch
@@ -535,6 +548,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
             return hipMemset(*p, 0, n * sizeof(double)) != hipSuccess ? 1 : 0;
         };
         int bad = zalloc(&e->coefT, 2 * NCH * B);
+        if (c.dual_coef) bad |= zalloc(&e->coef2, 2 * NCH * B) | zalloc(&e->coefT2, 2 * NCH * B);
         bad |= zalloc(reinterpret_cast<double**>(&e->SAD), 2 * (size_t)AD_CH * B * nc * NPOW);
         bad |= zalloc(&e->A22, B * BAS22 * KSYN) | zalloc(&e->A13, B * 10 * KLIN) | zalloc(&e->Y22, B * BAS22 * c.Nk);
         if (c.with_resum) bad |= zalloc(&e->ACF, B * BASC * KSYN) | zalloc(&e->ALC, B * (c.with_nnlo ? 3 : 2) * c.Nl * KLIN) | zalloc(&e->YCF, B * BASC * NS);
@@ -717,7 +731,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);

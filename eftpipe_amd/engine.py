@@ -41,6 +41,7 @@ class Engine:
             c.nxtail = t["lnx_xtail"].size
             c.NIR, c.Na, c.Nklow = (int(x) for x in t["resum_dims"])
         c.with_nnlo = int(cfg.with_NNLO)
+        c.dual_coef = int("Gc2" in t)
         self._cconf = c
         h = C.c_void_p()
         L.check(self.lib.eftb_create(C.byref(c), C.byref(h)))
@@ -75,6 +76,8 @@ class Engine:
         self._set("GRP", np.concatenate([t["grp22"], t["grp13"]]), np.int32)
         if cfg.with_NNLO:
             self._set("LCTN", t["lctn"])
+        if "Gc2" in t:
+            self._set("GCT2", t["Gc2"].transpose(0, 2, 1))
         if cfg.with_resum:
             expc = np.zeros((cfg.Nl * 38, 32))
             expc[:, : t["expand_c"].shape[1]] = t["expand_c"]

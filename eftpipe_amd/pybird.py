@@ -53,11 +53,17 @@ class Common(object):
 
     def __init__(self, Nl=None, No=None, kmax=0.3, optiresum=False, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None,
                  ndB=None, counterform="westcoast", with_NNLO=False, kIR=None, IRcutoff=False):
-        if optiresum or IRcutoff:
-            raise NotImplementedError("optiresum / IRcutoff are outside the accelerated hot path (SURVEY.md 8a)")
+        if optiresum:
+            raise NotImplementedError("optiresum is outside the accelerated hot path (SURVEY.md 8a)")
+        if IRcutoff and kIR is None:
+            raise ValueError("kIR must be specified when doing IRcutoff")
+        if IRcutoff is True:
+            IRcutoff = "all"
+        if IRcutoff not in (False, "all", "loop", "resum"):
+            raise ValueError(f"unexpected IRcutoff option: {IRcutoff}")
         if counterform not in ("westcoast", "eastcoast"):  # the templates are the same; only reduce_Plk reads it
             raise ValueError(f"unexpected counterform: {counterform}")
-        self.optiresum, self.with_NNLO, self.IRcutoff, self.kIR = False, bool(with_NNLO), False, kIR
+        self.optiresum, self.with_NNLO, self.IRcutoff, self.kIR = False, bool(with_NNLO), IRcutoff, kIR
         self.counterform = counterform
         self.kmA, self.krA, self.ndA = kmA, krA, ndA
         self.kmB = kmA if kmB is None else kmB
@@ -95,12 +101,12 @@ def engine_for(co, nbinsmu=200, loop_cache=None):
     """The engine serving `co`, created on first use with the resum and AP tables resident."""
     eng = _ENGINES.get(co)
     if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != nbinsmu
-                            or eng.cfg.with_NNLO != bool(co.with_NNLO)):
+                            or eng.cfg.with_NNLO != bool(co.with_NNLO) or eng.cfg.IRcutoff != co.IRcutoff or eng.cfg.kIR != co.kIR):
         eng.close()
         eng = None
     if eng is None:
         cfg = EngineConfig(Nl=co.Nl, k=np.array(co.k, dtype=np.float64), with_resum=True, with_ap=True, DA_AP=1.0, H_AP=1.0,
-                           nbinsmu=nbinsmu, with_NNLO=bool(co.with_NNLO))
+                           nbinsmu=nbinsmu, with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR)
         eng = _ENGINES[co] = Engine(cfg, max_batch=1, loop_cache=loop_cache)
     return eng
 

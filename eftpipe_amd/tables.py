@@ -228,6 +228,8 @@ class EngineConfig:
     nbinsmu: int = 200
     APst: bool = False
     with_NNLO: bool = False                 # Common(with_NNLO=True): the k^4 P11 counter-terms (pybird.py:741-748)
+    IRcutoff: object = False                # Common(IRcutoff=False | True | "all" | "loop" | "resum", kIR) (pybird.py:528-533)
+    kIR: Optional[float] = None
     extra: dict = field(default_factory=dict)
 
 
@@ -282,11 +284,31 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
     t["Sk"] = np.ascontiguousarray(CubicSpline(kin, np.eye(Nkin), axis=0)(k))
 
     # ---- loop FFTLog as an operator on Pin; only the 129 independent coefficients are kept
+    ircut = "all" if cfg.IRcutoff is True else cfg.IRcutoff
+    if ircut not in (False, "all", "loop", "resum"):
+        raise ValueError(f"unexpected IRcutoff option: {ircut}")
+    if ircut and cfg.kIR is None:
+        raise ValueError("kIR must be specified when doing IRcutoff")
+    icut = int(np.searchsorted(kin, cfg.kIR)) if ircut else 0
+
+    def cut_operator(N, xmin, xmax, bias, window):
+        """The FFTLog operator of the samples at kin >= kIR, zero padded below (reference pybird.py:1136-1140, 1327-1335),
+        as a matrix on the full input grid."""
+        o = FFTLogOperator(N, xmin, xmax, bias, kin[icut:], window, extrap=("padding", "extrap"))
+        o.G = np.hstack([np.zeros((o.G.shape[0], icut), dtype=complex), o.G])
+        return o
+
     op = FFTLogOperator(256, 1.5e-5, 1000.0, -1.6, kin, cfg.fft_window)
     if op.low_active:
         raise ValueError("kin[0] must not exceed the FFTLog xmin=1.5e-5 (low-k extrapolation unsupported)")
     nh = NHALF + 1
-    t["Gc"] = np.ascontiguousarray(np.stack([op.G[:nh].real, op.G[:nh].imag]))            # [2,129,Nkin]
+    # coefficient sets of the k-space (P22, P13) and xi-space (C11, Cct, C22, C13) pieces (reference pybird.py:1151-1160)
+    op_cut = cut_operator(256, 1.5e-5, 1000.0, -1.6, cfg.fft_window) if ircut else None
+    op_k = op_cut if ircut in ("all", "loop") else op
+    op_s = op_cut if ircut in ("all", "resum") else op
+    t["Gc"] = np.ascontiguousarray(np.stack([op_k.G[:nh].real, op_k.G[:nh].imag]))        # [2,129,Nkin]
+    if op_s is not op_k:
+        t["Gc2"] = np.ascontiguousarray(np.stack([op_s.G[:nh].real, op_s.G[:nh].imag]))
     t["Ec"] = np.ascontiguousarray(np.stack([op.E_hi[:nh].real, op.E_hi[:nh].imag]))      # [2,129,Ntail]
     t["lnx_tail"] = op.lnx_hi
     Pow = op.Pow
@@ -352,7 +374,7 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
         t["H"] = H
         # IR filters: q = Pin * exp(-k^2/L^2)/k^2 -> FFTLog(32) -> j0/j2 sums -> X, Y
         wq = np.exp(-(kin**2) / cfg.LambdaIR**2) / kin**2
-        xop = FFTLogOperator(32, 1.5e-5, 10.0, -2.6, kin, None)
+        xop = cut_operator(32, 1.5e-5, 10.0, -2.6, None) if ircut in ("all", "resum") else FFTLogOperator(32, 1.5e-5, 10.0, -2.6, kin, None)
         if xop.low_active:
             raise ValueError("kin[0] must not exceed 1.5e-5")
         XM = np.stack([lm.bessel_weight(2 * l, -0.5 * xop.Pow) for l in range(2)])

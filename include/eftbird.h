@@ -43,6 +43,8 @@ typedef struct eftb_config {
     int32_t nbasis13;      /* dimension of the span of the 10 M13 vectors (2)           tables.py loop_basis */
     int32_t NIR, Na, Nklow;/* Resum.NIR, Resum.Na, Common.Nklow                         pybird.py:1247-1259, 560 */
     int32_t with_nnlo;     /* Common.with_NNLO: the k^4 P11 counter-terms PctNNLOl       pybird.py:741-748, 1447-1458, 1615 */
+    int32_t dual_coef;     /* Common.IRcutoff = "loop" | "resum": the xi-space pieces use a second FFTLog operator (EFTB_T_GCT2)
+                              pybird.py:1151-1160  ("all" needs no switch: both operators are the cut one) */
 } eftb_config;
 
 /* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file). */
@@ -55,6 +57,7 @@ enum eftb_table {
     EFTB_T_RSBASIS, EFTB_T_RSBASISS, EFTB_T_RSROWS,   /* matrix-core IR-resummation (Nl = 3): tables.py resum_mfma_tables */
     EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
     EFTB_T_LCTN,      /* with_nnlo: Common.lctNNLO [Nl][3] zero padded to [Nl][6]     pybird.py:575 */
+    EFTB_T_GCT2,      /* dual_coef: FFTLog operator of the xi-space coefficients (layout of EFTB_T_GCT) */
     EFTB_T_COUNT
 };
 

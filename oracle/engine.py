@@ -76,6 +76,8 @@ class OracleConfig:
     nbinsmu: int = 200
     APst: bool = False
     with_NNLO: bool = False  # Common(with_NNLO=True) (pybird.py:511, 741-748)
+    IRcutoff: object = False  # False | True (= "all") | "all" | "loop" | "resum"  (pybird.py:528-533)
+    kIR: Optional[float] = None
     # window
     window_file: Optional[str] = None  # config-space window "s Q0 Q2 ..."
     window_accboost: int = 1
@@ -153,16 +155,35 @@ class OracleEngine:
         """P11 on the engine k grid (reference pybird.py:694-695)."""
         return interp1d(kin, Pin, kind="cubic")(self.k)
 
-    def loop_coef(self, kin, Pin, window=0.2):
-        """FFTLog of P_lin (reference pybird.py:1127-1141, 1143)."""
-        return self.fft.coef(kin, Pin, extrap=("extrap", "extrap"), window=window)
+    def loop_coef(self, kin, Pin, window=0.2, IRcut=False):
+        """FFTLog of P_lin (reference pybird.py:1127-1141, 1143); IRcut drops the samples below kIR and pads with zeros."""
+        extrap = ("extrap", "extrap")
+        if IRcut:
+            idx = np.searchsorted(kin, self.cfg.kIR)
+            kin, Pin = kin[idx:], Pin[idx:]
+            extrap = ("padding", "extrap")
+        return self.fft.coef(kin, Pin, extrap=extrap, window=window)
+
+    def _ircutoff(self):
+        mode = self.cfg.IRcutoff
+        if mode and self.cfg.kIR is None:
+            raise ValueError("kIR must be specified when doing IRcutoff")
+        return "all" if mode is True else mode
 
     def pscf(self, kin, Pin, pairwise=False):
         """One-loop P and xi pieces (reference pybird.py:1066-1125, 1143-1171)."""
         P11 = self.linear(kin, Pin)
-        coef = self.loop_coef(kin, Pin)
+        mode = self._ircutoff()  # which of the two coefficient sets is cut (pybird.py:1151-1160)
+        if mode in ("all", False):
+            coef = coef_cf = self.loop_coef(kin, Pin, IRcut=bool(mode))
+        elif mode == "loop":
+            coef, coef_cf = self.loop_coef(kin, Pin, IRcut=True), self.loop_coef(kin, Pin)
+        elif mode == "resum":
+            coef, coef_cf = self.loop_coef(kin, Pin), self.loop_coef(kin, Pin, IRcut=True)
+        else:
+            raise ValueError(f"unexpected IRcutoff option: {mode}")
         ck = coef[:, None] * self.kPow
-        cs = coef[:, None] * self.sPow
+        cs = coef_cf[:, None] * self.sPow
         path22 = self.path_P22_pairwise if pairwise else self.path_P22
         out = dict(P11=P11, coef=coef)
         out["P22"] = self.k**3 * np.real(np.einsum("nk,mk,bnm->bk", ck, ck, self.M22, optimize=path22))
@@ -242,7 +263,12 @@ class OracleEngine:
     def ir_filters(self, kin, Pin):
         """X(s), Y(s) (reference pybird.py:1316-1353)."""
         L = self.cfg.LambdaIR
-        coef = self.xfft.coef(kin, Pin * np.exp(-(kin**2) / L**2) / kin**2, window=None)
+        if self._ircutoff() in ("loop", False):
+            coef = self.xfft.coef(kin, Pin * np.exp(-(kin**2) / L**2) / kin**2, window=None)
+        else:  # pybird.py:1327-1335
+            idx = np.searchsorted(kin, self.cfg.kIR)
+            kc, Pc = kin[idx:], Pin[idx:]
+            coef = self.xfft.coef(kc, Pc * np.exp(-(kc**2) / L**2) / kc**2, window=None, extrap=("padding", "extrap"))
         cs = np.einsum("n,ns->ns", coef, self.XsPow)
         X02 = np.real(np.einsum("ns,ln->ls", cs, self.XM))
         X0off = np.real(np.einsum("n,n->", np.einsum("n,n->n", coef, 1.0 ** (-self.xfft.Pow - 3.0)), self.XM[0]))

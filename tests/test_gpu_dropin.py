@@ -192,3 +192,39 @@ def test_with_nnlo_sequence_and_batched(golden):
         eng.run(L.S_LOGP, 3)  # the LOGP stage does not take the NNLO block yet: loud failure
     eng.close()
 
+
+
+@pytest.mark.parametrize("mode", ["all", "loop", "resum"])
+def test_ircutoff_modes(golden, mode):
+    """SURVEY 8(f) rank 3: Common(IRcutoff=mode, kIR) (reference pybird.py:1127-1160, 1316-1335): the cut FFTLog operator is a table;
+    "loop" / "resum" use two coefficient sets on the device.  Drop-in sequence and batched engine against reference outputs."""
+    from eftpipe_amd import pybird
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("ircut")
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5, IRcutoff=mode, kIR=float(g["kIR"]))
+    f = float(g["f"])
+    bird = pybird.Bird(g["kin"], g["Pin"], f, float(g["DA"]), float(g["H"]), 0.7, co=co)
+    pybird.NonLinear(load=False, save=False, co=co).PsCf(bird)
+    for n in ("P22", "P13", "C11", "Cct"):
+        assert relerr(getattr(bird, n), g[f"{mode}_pscf_{n}"]) < TOL, n
+    assert relerr(bird.C22[0], g[f"{mode}_pscf_C22_l0"]) < TOL and relerr(bird.C13[1], g[f"{mode}_pscf_C13_l2"]) < TOL
+    bird.setPsCfl()
+    rs = pybird.Resum(co=co)
+    X, Y = rs.IRFilters(bird)
+    assert relerr(X[None], g[f"{mode}_X"][None]) < TOL and relerr(Y[None], g[f"{mode}_Y"][None]) < TOL
+    rs.Ps(bird)
+    pybird.APeffect(DA=float(g["DA_AP"]), H=float(g["H_AP"]), co=co).AP(bird)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        assert relerr(getattr(bird, n), g[f"{mode}_ap_{n}"]) < TOL, n
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"]), IRcutoff=mode, kIR=float(g["kIR"])),
+                 max_batch=2)
+    templ = eng.eval_batch(np.stack([g["Pin"], 1.02 * g["Pin"]]), f, float(g["DA"]), float(g["H"]))
+    assert relerr(templ[0][:, 9:21], g[f"{mode}_ap_Ploopl"]) < TOL and relerr(templ[0][:, 0:3], g[f"{mode}_ap_P11l"]) < TOL
+    assert relerr(templ[1][:, 9:21] / 1.02**2, g[f"{mode}_ap_Ploopl"]) > 1e-6  # (X, Y enter the resummation non-linearly)
+    eng.close()
+    with pytest.raises(ValueError):
+        pybird.Common(Nl=3, IRcutoff="all")
+    with pytest.raises(ValueError):
+        pybird.Common(Nl=3, IRcutoff="some", kIR=0.01)

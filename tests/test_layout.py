@@ -35,7 +35,7 @@ def test_enums_in_sync_with_header():
 
     src = open(os.path.join(ROOT, "include", "eftbird.h")).read()
     tables = re.search(r"enum eftb_table \{(.*?)\};", src, re.S).group(1)
-    names = re.findall(r"EFTB_T_([A-Z0-9]+)", tables)
+    names = re.findall(r"EFTB_T_([A-Z0-9]+)", re.sub(r"/\*.*?\*/", "", tables, flags=re.S))
     assert names[:-1] == _lib.TABLES and names[-1] == "COUNT"
     buffers = re.search(r"enum eftb_buffer \{(.*?)\};", src, re.S).group(1)
     names = re.findall(r"EFTB_B_([A-Z0-9]+)", re.sub(r"/\*.*?\*/", "", buffers, flags=re.S))

@@ -238,3 +238,23 @@ def test_nnlo_counterterms(golden):
     assert relerr(-(b1**2) * f**4 * Pn[:, 0] - 2.0 * b1 * f**5 * Pn[:, 1] - f**6 * Pn[:, 2], g["east_table_ctilde"]) < 1e-9
     assert relerr(0.25 * 2.1**2 / eng.krA**4 * Pn[:, 0], g["west_table_cr4"]) < 1e-9
     assert relerr(0.25 * 2.1 / eng.krA**4 * Pn[:, 1], g["west_table_cr6"]) < 1e-9
+
+
+@pytest.mark.parametrize("mode", ["all", "loop", "resum"])
+def test_ircutoff(golden, mode):
+    """oracle == reference with Common(IRcutoff=mode, kIR)."""
+    from oracle import OracleConfig
+
+    g = golden("ircut")
+    eng = OracleEngine(OracleConfig(Nl=3, kmA=0.7, krA=0.25, ndA=4.5e-5, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]),
+                                    H_AP=float(g["H_AP"]), IRcutoff=mode, kIR=float(g["kIR"])))
+    taps = {}
+    st = eng.evaluate(g["kin"], g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), taps=taps)
+    for n in ("P22", "P13", "C11", "Cct"):
+        assert relerr(taps["pscf"][n], g[f"{mode}_pscf_{n}"]) < TOL, n
+    assert relerr(taps["pscf"]["C22"][0], g[f"{mode}_pscf_C22_l0"]) < TOL and relerr(taps["pscf"]["C13"][1], g[f"{mode}_pscf_C13_l2"]) < TOL
+    assert relerr(taps["resum"]["X"][None], g[f"{mode}_X"][None]) < TOL and relerr(taps["resum"]["Y"][None], g[f"{mode}_Y"][None]) < TOL
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        assert relerr(st[n], g[f"{mode}_ap_{n}"]) < TOL, n
+    with pytest.raises(ValueError):
+        OracleEngine(OracleConfig(Nl=2, IRcutoff="all")).pscf(g["kin"], g["Pin"])

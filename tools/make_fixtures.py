@@ -205,6 +205,37 @@ def nnlo_fixture(ref):
     print("nnlo written:", {k: np.shape(v) for k, v in out.items() if "NNLO" in k})
 
 
+def ircut_fixture(ref):
+    """Common(IRcutoff=..., kIR=...) through the REAL reference (pybird.py:1127-1160, 1316-1335) for the three
+    modes: loop pieces, IR filters and the templates after resummation + AP."""
+    pb = ref.pybird
+    Nl, z = 3, 0.7
+    cos = synth.cosmology(z=z)
+    out = dict(kin=cos["kin"], Pin=cos["Pin"], f=cos["f"], DA=cos["DA"], H=cos["H"], z=z, Nl=Nl, kIR=0.004)
+    for mode in ("all", "loop", "resum"):
+        co = make_common(pb, Nl, None, IRcutoff=mode, kIR=out["kIR"])
+        out["k"] = co.k
+        nl = pb.NonLinear(load=False, save=False, co=co)
+        bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+        nl.PsCf(bird)
+        for n in ("P22", "P13", "C11", "Cct"):
+            out[f"{mode}_pscf_{n}"] = np.array(getattr(bird, n), copy=True)
+        out[f"{mode}_pscf_C22_l0"] = bird.C22[0].copy()
+        out[f"{mode}_pscf_C13_l2"] = bird.C13[1].copy()
+        bird.setPsCfl()
+        rs = pb.Resum(co=co)
+        X, Y = rs.IRFilters(bird)
+        out[f"{mode}_X"], out[f"{mode}_Y"] = X, Y
+        rs.Ps(bird)
+        ap = pb.APeffect(Om_AP=synth.OM_AP, z_AP=z, co=co)
+        out["DA_AP"], out["H_AP"] = ap.DA, ap.H
+        ap.AP(bird)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            out[f"{mode}_ap_{n}"] = getattr(bird, n).copy()
+    np.savez_compressed(os.path.join(GOLD, "ircut.npz"), **out)
+    print("ircut written:", len(out), "arrays")
+
+
 def marg_fixture(ref):
     """the Gaussian (derivative) table and the analytically marginalised log-posterior, from the
     REAL reference (parambasis.WestCoastBasis.reduce_Plk_gaussian_table, marginal.Marginalizable.marginalized_logp) on
@@ -455,7 +486,7 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -469,6 +500,8 @@ def main():
             fiber_fixture(ref)
         elif name == "nnlo":
             nnlo_fixture(ref)
+        elif name == "ircut":
+            ircut_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
