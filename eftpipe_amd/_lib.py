@@ -24,12 +24,12 @@ class Config(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "device", "Nl", "Nk", "Nkin", "max_batch", "with_resum", "with_ap", "ap_stochastic", "nmu",
-        "ntail", "nxtail", "nbasis", "nbasis13", "NIR", "Na", "Nklow", "with_nnlo", "dual_coef")]
+        "ntail", "nxtail", "nbasis", "nbasis13", "NIR", "Na", "Nklow", "with_nnlo", "optiresum", "dual_coef")]
 
 
 # enum eftb_table / eftb_buffer / eftb_stage (same order as the header)
 TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD EXP22 EXPC MLJ LINVEC SYNK SYNS LINK LINS L11 LCT L22 L13 GRP "
-          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID LCTN GCT2").split()
+          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID LCTN BAO GCT2").split()
 T = {n: i for i, n in enumerate(TABLES)}
 BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF GROWS LOGP CCTN TEMPLN BIASN".split()
 B = {n: i for i, n in enumerate(BUFFERS)}

@@ -458,6 +458,15 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 }
 
 
+// optiresum: the BAO peak of every xi piece (one workgroup = one series of 80 s slots; reference pybird.py:1382-1400)
+__global__ __launch_bounds__(128) void extract_bao_kernel(const double* __restrict__ bao, const double* __restrict__ in, double* __restrict__ out) {
+    const int s = threadIdx.x;
+    if (s >= NS) return;
+    const int ilo = (int)bao[2 * NS], ihi = (int)bao[2 * NS + 1], i0 = (int)bao[2 * NS + 2], i1 = (int)bao[2 * NS + 3];
+    const double* c = in + (size_t)blockIdx.x * NS;
+    out[(size_t)blockIdx.x * NS + s] = (s >= i0 && s < i1) ? c[s] - bao[s] * c[ilo] - bao[NS + s] * c[ihi] : 0.0;
+}
+
 // NNLO block: rows 3-5 = k^4 P11 lctNNLO (reference pybird.py:741-748), every other row zero.  lctn is [Nl][6] (zero padded).
 __global__ __launch_bounds__(256) void nnlo_rows_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
                                                         const double* __restrict__ lctn, double* __restrict__ T) {

@@ -72,6 +72,7 @@ struct eftb_engine {
     int Nn = 0;
     double* sm2 = nullptr;  // s^-2 row scale of Cct
     double* sm4 = nullptr;  // s^-4 row scale of CctNNLO
+    double* XB = nullptr;  // optiresum: BAO-extracted copies of C11 [B][Nl][80], Cct [B][Nl][80], Cloopl [B][Nl][12][80], in this order
     double *coef2 = nullptr, *coefT2 = nullptr;  // dual_coef: FFTLog coefficients of the xi-space pieces (layouts of EFTB_B_COEF / coefT)
     double *ZC = nullptr, *ZC2 = nullptr;  // with_nnlo: zeros standing in for C11 [B][Nl][80] / Cloopl [B][Nl][12][80] in the NNLO pass of Resum.Ps
     // RCCL gather (multi-GPU batches)
@@ -163,6 +164,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
         case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
         case EFTB_T_LCTN: return c.with_nnlo ? D * c.Nl * 6 : 0;
+        case EFTB_T_BAO: return c.optiresum && c.with_resum ? D * (2 * NS + 4) : 0;
         case EFTB_T_GCT2: return c.dual_coef ? D * 2 * c.Nkin * NCH : 0;
     }
     return 0;
@@ -377,11 +379,19 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             if (hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess) return fail("eftb_run: stream join failed");
             joined = true;
         }
+        const double *c11 = b[EFTB_B_C11], *cct = b[EFTB_B_CCT], *cloopl = b[EFTB_B_CLOOPL];
+        if (c.optiresum && full) {  // Resum.extractBAO (reference pybird.py:1382-1400) into scratch: the stage inputs stay as the CF stage left them
+            double *x11 = e->XB, *xct = x11 + (size_t)c.max_batch * Nl * NS, *xl = xct + (size_t)c.max_batch * Nl * NS;
+            hipLaunchKernelGGL(extract_bao_kernel, dim3(B * Nl), dim3(128), 0, st, tb<double>(e, EFTB_T_BAO), c11, x11);
+            hipLaunchKernelGGL(extract_bao_kernel, dim3(B * Nl), dim3(128), 0, st, tb<double>(e, EFTB_T_BAO), cct, xct);
+            hipLaunchKernelGGL(extract_bao_kernel, dim3(B * Nl * 12), dim3(128), 0, st, tb<double>(e, EFTB_T_BAO), cloopl, xl);
+            c11 = x11; cct = xct; cloopl = xl;
+        }
         if (Nl == 3) {
             // matrix-core form: polynomials as [80 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
             if (full)
                 hipLaunchKernelGGL(resum_prep_kernel, dim3(B), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
-                                   tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL], e->RSA, e->RSC);
+                                   tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], c11, cct, cloopl, e->RSA, e->RSC);
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
@@ -399,7 +409,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * 4 * Nl * Nl * B * nsplit < 8192) nsplit *= 2;
             const int schunk = (NS + nsplit - 1) / nsplit;
             hipLaunchKernelGGL((resum_kernel<2>), dim3(kblocks, 4 * Nl, B * Nl * nsplit), dim3(256), 0, st, Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K),
-                               b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), b[EFTB_B_C11], b[EFTB_B_CCT], b[EFTB_B_CLOOPL],
+                               b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), c11, cct, cloopl,
                                tb<double>(e, EFTB_T_L11), tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), e->part, nsplit);
             hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, 2 * Nl * nsplit, e->part, b[EFTB_B_TEMPL]);
         }
@@ -599,6 +609,7 @@ int eftb_finalize(eftb_engine* e) {
             HIPCHK(hipMalloc(&e->part, pbytes));
             HIPCHK(hipMemset(e->part, 0, pbytes));  // the matrix-core kernel never touches k < Nklow
         }
+        if (c.optiresum) HIPCHK(hipMalloc(&e->XB, (size_t)c.max_batch * c.Nl * 14 * NS * sizeof(double)));
         if (c.with_nnlo) {
             HIPCHK(hipMalloc(&e->ZC, e->buf_elems[EFTB_B_C11] * sizeof(double)));
             HIPCHK(hipMalloc(&e->ZC2, e->buf_elems[EFTB_B_CLOOPL] * sizeof(double)));
@@ -731,7 +742,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);

@@ -42,6 +42,7 @@ class Engine:
             c.NIR, c.Na, c.Nklow = (int(x) for x in t["resum_dims"])
         c.with_nnlo = int(cfg.with_NNLO)
         c.dual_coef = int("Gc2" in t)
+        c.optiresum = int(cfg.optiresum and cfg.with_resum)
         self._cconf = c
         h = C.c_void_p()
         L.check(self.lib.eftb_create(C.byref(c), C.byref(h)))
@@ -76,6 +77,8 @@ class Engine:
         self._set("GRP", np.concatenate([t["grp22"], t["grp13"]]), np.int32)
         if cfg.with_NNLO:
             self._set("LCTN", t["lctn"])
+        if "bao" in t:
+            self._set("BAO", t["bao"])
         if "Gc2" in t:
             self._set("GCT2", t["Gc2"].transpose(0, 2, 1))
         if cfg.with_resum:

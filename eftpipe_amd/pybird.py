@@ -53,8 +53,6 @@ class Common(object):
 
     def __init__(self, Nl=None, No=None, kmax=0.3, optiresum=False, kmA=0.7, krA=0.25, ndA=3e-4, kmB=None, krB=None,
                  ndB=None, counterform="westcoast", with_NNLO=False, kIR=None, IRcutoff=False):
-        if optiresum:
-            raise NotImplementedError("optiresum is outside the accelerated hot path (SURVEY.md 8a)")
         if IRcutoff and kIR is None:
             raise ValueError("kIR must be specified when doing IRcutoff")
         if IRcutoff is True:
@@ -63,7 +61,7 @@ class Common(object):
             raise ValueError(f"unexpected IRcutoff option: {IRcutoff}")
         if counterform not in ("westcoast", "eastcoast"):  # the templates are the same; only reduce_Plk reads it
             raise ValueError(f"unexpected counterform: {counterform}")
-        self.optiresum, self.with_NNLO, self.IRcutoff, self.kIR = False, bool(with_NNLO), IRcutoff, kIR
+        self.optiresum, self.with_NNLO, self.IRcutoff, self.kIR = bool(optiresum), bool(with_NNLO), IRcutoff, kIR
         self.counterform = counterform
         self.kmA, self.krA, self.ndA = kmA, krA, ndA
         self.kmB = kmA if kmB is None else kmB
@@ -81,7 +79,7 @@ class Common(object):
         self.N11, self.Nct, self.NctNNLO, self.N22, self.N13, self.Nloop = 3, 6, 3, 28, 10, 12
         self.k = get_kbird(kmax)
         self.Nk = self.k.shape[0]
-        self.s = sbird
+        self.s = np.arange(70.0, 200.0, 2.5) if self.optiresum else sbird  # reference pybird.py:553-556
         self.Ns = self.s.shape[0]
         self.kr = self.k[0.02 <= self.k]
         self.Nkr = self.kr.shape[0]
@@ -101,14 +99,33 @@ def engine_for(co, nbinsmu=200, loop_cache=None):
     """The engine serving `co`, created on first use with the resum and AP tables resident."""
     eng = _ENGINES.get(co)
     if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != nbinsmu
-                            or eng.cfg.with_NNLO != bool(co.with_NNLO) or eng.cfg.IRcutoff != co.IRcutoff or eng.cfg.kIR != co.kIR):
+                            or eng.cfg.with_NNLO != bool(co.with_NNLO) or eng.cfg.IRcutoff != co.IRcutoff or eng.cfg.kIR != co.kIR
+                            or eng.cfg.optiresum != bool(co.optiresum)):
         eng.close()
         eng = None
     if eng is None:
         cfg = EngineConfig(Nl=co.Nl, k=np.array(co.k, dtype=np.float64), with_resum=True, with_ap=True, DA_AP=1.0, H_AP=1.0,
-                           nbinsmu=nbinsmu, with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR)
+                           nbinsmu=nbinsmu, with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR, optiresum=bool(co.optiresum))
         eng = _ENGINES[co] = Engine(cfg, max_batch=1, loop_cache=loop_cache)
     return eng
+
+
+NS_DEV = 80  # s slots on the device; Common(optiresum=True) uses the first 52 (include/eftbird.h eftb_config.optiresum)
+
+
+def _s_pad(a):
+    """[..., Ns] -> [..., 80] (zeros in the unused slots)"""
+    a = np.asarray(a, dtype=np.float64)
+    if a.shape[-1] == NS_DEV:
+        return a
+    out = np.zeros(a.shape[:-1] + (NS_DEV,))
+    out[..., : a.shape[-1]] = a
+    return out
+
+
+def _s_get(eng, name, shape, Ns):
+    """device [..., 80] -> host [..., Ns]"""
+    return np.ascontiguousarray(eng.get(name, tuple(shape) + (NS_DEV,))[..., :Ns])
 
 
 # ----------------------------------------------------------------------------- Bird
@@ -179,10 +196,10 @@ class Bird:
         eng.put("P11", self.P11)
         eng.put("P22", self.P22)
         eng.put("P13", self.P13)
-        eng.put("CC", np.concatenate([self.C22.reshape(-1), self.C13.reshape(-1)]))
+        eng.put("CC", np.concatenate([_s_pad(self.C22).reshape(-1), _s_pad(self.C13).reshape(-1)]))
         eng.run(L.S_REGROUP)
         self._templates_from_device(eng)
-        self.Cloopl = eng.get("CLOOPL", (co.Nl, co.Nloop, co.Ns))
+        self.Cloopl = _s_get(eng, "CLOOPL", (co.Nl, co.Nloop), co.Ns)
         # the reference also leaves the mu-weighted pieces on the bird (pybird.py:749-753)
         self.P22l = co.l22[:, :, None] * self.P22[None]
         self.P13l = co.l13[:, :, None] * self.P13[None]
@@ -244,11 +261,11 @@ class NonLinear(HasLogger):
         bird.P11 = eng.get("P11", (co.Nk,))
         bird.P22 = eng.get("P22", (co.N22, co.Nk))
         bird.P13 = eng.get("P13", (co.N13, co.Nk))
-        bird.C11 = eng.get("C11", (co.Nl, co.Ns))
-        bird.Cct = eng.get("CCT", (co.Nl, co.Ns))
+        bird.C11 = _s_get(eng, "C11", (co.Nl,), co.Ns)
+        bird.Cct = _s_get(eng, "CCT", (co.Nl,), co.Ns)
         if co.with_NNLO:
-            bird.CctNNLO = eng.get("CCTN", (co.Nl, co.Ns))
-        cc = eng.get("CC", (co.Nl * 38, co.Ns))
+            bird.CctNNLO = _s_get(eng, "CCTN", (co.Nl,), co.Ns)
+        cc = _s_get(eng, "CC", (co.Nl * 38,), co.Ns)
         bird.C22 = np.ascontiguousarray(cc[: co.Nl * 28].reshape(co.Nl, 28, co.Ns))
         bird.C13 = np.ascontiguousarray(cc[co.Nl * 28 :].reshape(co.Nl, 10, co.Ns))
 
@@ -268,6 +285,17 @@ class Resum(HasLogger):
         self.snapshot = snapshot
         self.engine = engine_for(co)
         self.Q = None
+        if co.optiresum:  # reference pybird.py:1235-1244
+            self.sLow, self.sHigh = 70.0, 190.0
+            self.idlow = int(np.where(co.s > self.sLow)[0][0])
+            self.idhigh = int(np.where(co.s > self.sHigh)[0][0])
+            self.sbao = co.s[self.idlow : self.idhigh]
+            self.snobao = np.concatenate([co.s[: self.idlow], co.s[self.idhigh :]])
+            self.sr = self.sbao
+            self._sr = slice(self.idlow, self.idhigh)
+        else:
+            self.sr = co.s
+            self._sr = slice(0, co.Ns)
 
     def IRFilters(self, bird):
         """X(s), Y(s) (reference pybird.py:1316-1353)."""
@@ -275,8 +303,8 @@ class Resum(HasLogger):
         eng.put("PIN", bird.Pin)
         eng.put("F", np.array([bird.f]))
         eng.run(L.S_RESUM)  # cheap at B=1; filters are a by-product
-        xy = eng.get("XY", (2, self.co.Ns))
-        return xy[0], xy[1]
+        xy = eng.get("XY", (2, NS_DEV))[:, self._sr]
+        return np.ascontiguousarray(xy[0]), np.ascontiguousarray(xy[1])
 
     def Ps(self, bird, window=None):
         """Adds the IR corrections to bird.P11l / Pctl / Ploopl in place (reference pybird.py:1413-1464)."""
@@ -285,11 +313,11 @@ class Resum(HasLogger):
         eng, co = self.engine, self.co
         eng.put("PIN", bird.Pin)
         eng.put("F", np.array([bird.f]))
-        eng.put("C11", bird.C11)
-        eng.put("CCT", bird.Cct)
-        eng.put("CLOOPL", bird.Cloopl)
+        eng.put("C11", _s_pad(bird.C11))
+        eng.put("CCT", _s_pad(bird.Cct))
+        eng.put("CLOOPL", _s_pad(bird.Cloopl))
         if co.with_NNLO:
-            eng.put("CCTN", bird.CctNNLO)
+            eng.put("CCTN", _s_pad(bird.CctNNLO))
         bird._templates_to_device(eng)
         eng.run(L.S_RESUM)
         bird._templates_from_device(eng, ("P11l", "Pctl", "Ploopl"))

@@ -228,6 +228,7 @@ class EngineConfig:
     nbinsmu: int = 200
     APst: bool = False
     with_NNLO: bool = False                 # Common(with_NNLO=True): the k^4 P11 counter-terms (pybird.py:741-748)
+    optiresum: bool = False                 # Common(optiresum=True): resum only the BAO peak (pybird.py:553-556, 1382-1400)
     IRcutoff: object = False                # Common(IRcutoff=False | True | "all" | "loop" | "resum", kIR) (pybird.py:528-533)
     kIR: Optional[float] = None
     extra: dict = field(default_factory=dict)
@@ -272,6 +273,21 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
     k = lm.native_k() if cfg.k is None else np.ascontiguousarray(cfg.k, dtype=np.float64)
     kin = np.logspace(-5, 0, 200) if cfg.kin is None else np.ascontiguousarray(cfg.kin, dtype=np.float64)
     s = lm.native_s()
+    sr_idx = np.arange(NS)                      # the s slots that enter the resummation
+    if cfg.optiresum:
+        # the s axis keeps its 80 device slots: the first 52 carry the optiresum grid, the rest repeat the last value and
+        # get zero weight everywhere they could matter (H columns, BAO mask)
+        s_opt = np.arange(70.0, 200.0, 2.5)
+        idlow, idhigh = int(np.where(s_opt > 70.0)[0][0]), int(np.where(s_opt > 190.0)[0][0])   # pybird.py:1236-1239
+        s = np.concatenate([s_opt, np.full(NS - s_opt.size, s_opt[-1])])
+        sr_idx = np.arange(idlow, idhigh)
+        # Resum.extractBAO: linear interpolation of s^2 xi(s) between the last point below and the first point above the window
+        ilo, ihi = idlow - 1, idhigh
+        tt = (s[sr_idx] - s[ilo]) / (s[ihi] - s[ilo])
+        bao = np.zeros(2 * NS + 4)
+        bao[sr_idx] = (1.0 - tt) * s[ilo] ** 2 / s[sr_idx] ** 2
+        bao[NS + sr_idx] = tt * s[ihi] ** 2 / s[sr_idx] ** 2
+        bao[2 * NS :] = [ilo, ihi, idlow, idhigh]
     Nk, Nkin = k.size, kin.size
     t = dict(k=k, kin=kin, s=s)
     w = lm.mu_weights(Nl)
@@ -365,13 +381,15 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
         Na = 3 if Nl == 3 else 2
         kr_mask = k >= 0.02
         kr = k[kr_mask]
-        rop = FFTLogOperator(cfg.NFFT_resum, 0.1, 10000.0, -0.6, s, None, extrap=("padding", "padding"))
+        rop = FFTLogOperator(cfg.NFFT_resum, 0.1, 10000.0, -0.6, s[sr_idx], None, extrap=("padding", "padding"))
         rM = np.stack([8.0 * np.pi**3 * lm.bessel_weight(2 * l, -0.5 * rop.Pow) for l in range(Na)])
         rk = np.exp(np.outer(-rop.Pow - 3.0, np.log(kr)))                # [193,Nkr]
         H = np.zeros((Na, Nk, NS))
         for v in range(Na):
-            H[v, kr_mask] = np.real((rM[v][:, None] * rk).T @ rop.G)
+            H[np.ix_([v], np.where(kr_mask)[0], sr_idx)] = np.real((rM[v][:, None] * rk).T @ rop.G)[None]
         t["H"] = H
+        if cfg.optiresum:
+            t["bao"] = bao
         # IR filters: q = Pin * exp(-k^2/L^2)/k^2 -> FFTLog(32) -> j0/j2 sums -> X, Y
         wq = np.exp(-(kin**2) / cfg.LambdaIR**2) / kin**2
         xop = cut_operator(32, 1.5e-5, 10.0, -2.6, None) if ircut in ("all", "resum") else FFTLogOperator(32, 1.5e-5, 10.0, -2.6, kin, None)

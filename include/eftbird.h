@@ -43,6 +43,8 @@ typedef struct eftb_config {
     int32_t nbasis13;      /* dimension of the span of the 10 M13 vectors (2)           tables.py loop_basis */
     int32_t NIR, Na, Nklow;/* Resum.NIR, Resum.Na, Common.Nklow                         pybird.py:1247-1259, 560 */
     int32_t with_nnlo;     /* Common.with_NNLO: the k^4 P11 counter-terms PctNNLOl       pybird.py:741-748, 1447-1458, 1615 */
+    int32_t optiresum;     /* Common.optiresum: only the BAO peak is resummed (EFTB_T_BAO); the s axis keeps 80 slots, the first 52
+                              hold arange(70, 200, 2.5), the rest repeat the last value and carry no weight   pybird.py:553-556, 1382-1400 */
     int32_t dual_coef;     /* Common.IRcutoff = "loop" | "resum": the xi-space pieces use a second FFTLog operator (EFTB_T_GCT2)
                               pybird.py:1151-1160  ("all" needs no switch: both operators are the cut one) */
 } eftb_config;
@@ -57,6 +59,8 @@ enum eftb_table {
     EFTB_T_RSBASIS, EFTB_T_RSBASISS, EFTB_T_RSROWS,   /* matrix-core IR-resummation (Nl = 3): tables.py resum_mfma_tables */
     EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
     EFTB_T_LCTN,      /* with_nnlo: Common.lctNNLO [Nl][3] zero padded to [Nl][6]     pybird.py:575 */
+    EFTB_T_BAO,       /* optiresum: a(s)[80], b(s)[80], then i_lo, i_hi, i_first, i_end as doubles: inside [i_first, i_end)
+                         bao(s) = C(s) - a(s) C(s[i_lo]) - b(s) C(s[i_hi]), 0 elsewhere     Resum.extractBAO pybird.py:1382-1400 */
     EFTB_T_GCT2,      /* dual_coef: FFTLog operator of the xi-space coefficients (layout of EFTB_T_GCT) */
     EFTB_T_COUNT
 };

@@ -76,6 +76,7 @@ class OracleConfig:
     nbinsmu: int = 200
     APst: bool = False
     with_NNLO: bool = False  # Common(with_NNLO=True) (pybird.py:511, 741-748)
+    optiresum: bool = False  # Common(optiresum=True): resum only the BAO peak (pybird.py:553-556, 1235-1244, 1382-1400)
     IRcutoff: object = False  # False | True (= "all") | "all" | "loop" | "resum"  (pybird.py:528-533)
     kIR: Optional[float] = None
     # window
@@ -102,7 +103,7 @@ class OracleEngine:
         # Common (pybird.py:498-582)
         self.k = np.array(pt["kbird"]) if cfg.k is None else np.asarray(cfg.k, dtype=float)
         self.Nk = self.k.size
-        self.s = np.array(pt["sbird"])
+        self.s = np.arange(70.0, 200.0, 2.5) if cfg.optiresum else np.array(pt["sbird"])  # pybird.py:553-556
         self.Ns = self.s.size
         self.kr = self.k[0.02 <= self.k]
         self.Nkr = self.kr.size
@@ -258,7 +259,23 @@ class OracleEngine:
         self.rkPow = np.exp(np.einsum("n,s->ns", -self.rfft.Pow - 3.0, np.log(self.kr)))
         self.xfft = FFTLogGrid(32, 1.5e-5, 10.0, -2.6)
         self.XM = np.stack([T.mpc(2 * l, -0.5 * self.xfft.Pow) for l in range(2)])
-        self.XsPow = np.exp(np.einsum("n,s->ns", -self.xfft.Pow - 3.0, np.log(self.s)))
+        if cfg.optiresum:  # pybird.py:1235-1244
+            self.idlow = np.where(self.s > 70.0)[0][0]
+            self.idhigh = np.where(self.s > 190.0)[0][0]
+            self.sbao = self.s[self.idlow : self.idhigh]
+            self.snobao = np.concatenate([self.s[: self.idlow], self.s[self.idhigh :]])
+            self.sr = self.sbao
+        else:
+            self.sr = self.s
+        self.XsPow = np.exp(np.einsum("n,s->ns", -self.xfft.Pow - 3.0, np.log(self.sr)))
+
+    def extract_bao(self, cf):
+        """(pybird.py:1382-1400): subtract the smooth part interpolated (linearly in s^2 xi) across the BAO window"""
+        if not self.cfg.optiresum:
+            return cf
+        nobao_in = np.concatenate([cf[..., : self.idlow], cf[..., self.idhigh :]], axis=-1)
+        nobao = interp1d(self.snobao, self.snobao**2 * nobao_in, kind="linear", axis=-1)(self.sbao) * self.sbao**-2
+        return cf[..., self.idlow : self.idhigh] - nobao
 
     def ir_filters(self, kin, Pin):
         """X(s), Y(s) (reference pybird.py:1316-1353)."""
@@ -280,7 +297,7 @@ class OracleEngine:
     def _ir_block(self, XpYp, C):
         """FFTLog(192) of XpYp (x) C followed by the Bessel sum (pybird.py:1361-1365, 1409-1441)."""
         inp = np.einsum("jk,...k->...jk", XpYp, C)
-        coef = self.rfft.coef(self.s, inp, extrap="padding", window=None)
+        coef = self.rfft.coef(self.sr, inp, extrap="padding", window=None)
         out = np.zeros(C.shape[:-1] + (self.Nn, self.Nk))
         flat_c = coef.reshape(-1, 2 * self.NIR, coef.shape[-1])
         flat_o = out.reshape(-1, self.Nn, self.Nk)
@@ -298,15 +315,15 @@ class OracleEngine:
         Xp = np.array([X ** (p + 1) for p in range(self.NIR)])
         XpY = np.array([Y * X**p for p in range(self.NIR)])
         XpYp = np.concatenate((Xp, XpY))
-        IR11 = self._ir_block(XpYp, st["C11"])
-        IRct = self._ir_block(XpYp, st["Cct"])
-        IRloop = self._ir_block(XpYp, st["Cloopl"])
+        IR11 = self._ir_block(XpYp, self.extract_bao(st["C11"]))
+        IRct = self._ir_block(XpYp, self.extract_bao(st["Cct"]))
+        IRloop = self._ir_block(XpYp, self.extract_bao(st["Cloopl"]))
         out = dict(st)
         out["P11l"] = st["P11l"] + np.einsum("lpn,pnk,pi->lik", Q[0], IR11, self.l11)
         out["Pctl"] = st["Pctl"] + np.einsum("lpn,pnk,pi->lik", Q[1], IRct, self.lct)
         out["Ploopl"] = st["Ploopl"] + np.einsum("lpn,pink->lik", Q[1], IRloop)
         if self.cfg.with_NNLO:  # pybird.py:1447-1458
-            IRn = self._ir_block(XpYp, st["CctNNLO"])
+            IRn = self._ir_block(XpYp, self.extract_bao(st["CctNNLO"]))
             out["PctNNLOl"] = st["PctNNLOl"] + np.einsum("lpn,pnk,pi->lik", Q[1], IRn, self.lctNNLO)
         out.update(X=X, Y=Y, Q=Q)
         return out

@@ -228,3 +228,38 @@ def test_ircutoff_modes(golden, mode):
         pybird.Common(Nl=3, IRcutoff="all")
     with pytest.raises(ValueError):
         pybird.Common(Nl=3, IRcutoff="some", kIR=0.01)
+
+
+def test_optiresum(golden):
+    """Common(optiresum=True) (reference pybird.py:553-556, 1235-1244, 1382-1400): xi pieces on the 52-point s grid,
+    BAO-peak extraction on the device, resummation over the 48 BAO points -- drop-in sequence and batched engine vs reference outputs."""
+    from eftpipe_amd import pybird
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("opti")
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5, optiresum=True)
+    assert np.array_equal(co.s, g["s"]) and co.Ns == 52
+    f = float(g["f"])
+    bird = pybird.Bird(g["kin"], g["Pin"], f, float(g["DA"]), float(g["H"]), 0.7, co=co)
+    pybird.NonLinear(load=False, save=False, co=co).PsCf(bird)
+    assert bird.C11.shape == (3, 52) and bird.C22.shape == (3, 28, 52)
+    assert relerr(bird.C11, g["pscf_C11"]) < TOL and relerr(bird.Cct, g["pscf_Cct"]) < TOL
+    assert relerr(bird.C22[1], g["pscf_C22_l2"]) < TOL
+    bird.setPsCfl()
+    assert relerr(bird.Cloopl.reshape(36, -1), g["setpscfl_Cloopl"].reshape(36, -1)) < TOL
+    rs = pybird.Resum(co=co)
+    assert np.array_equal(rs.sr, g["sr"])
+    X, Y = rs.IRFilters(bird)
+    assert relerr(X[None], g["X"][None]) < TOL and relerr(Y[None], g["Y"][None]) < TOL
+    rs.Ps(bird)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(getattr(bird, n), g["resum_" + n]) < TOL, n
+    pybird.APeffect(DA=float(g["DA_AP"]), H=float(g["H_AP"]), co=co).AP(bird)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        assert relerr(getattr(bird, n), g["ap_" + n]) < TOL, n
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"]), optiresum=True), max_batch=2)
+    templ = eng.eval_batch(np.stack([g["Pin"], g["Pin"]]), f, float(g["DA"]), float(g["H"]))
+    for i in range(2):
+        assert relerr(templ[i][:, 9:21], g["ap_Ploopl"]) < TOL and relerr(templ[i][:, 3:9], g["ap_Pctl"]) < TOL
+    eng.close()

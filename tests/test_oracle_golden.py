@@ -258,3 +258,24 @@ def test_ircutoff(golden, mode):
         assert relerr(st[n], g[f"{mode}_ap_{n}"]) < TOL, n
     with pytest.raises(ValueError):
         OracleEngine(OracleConfig(Nl=2, IRcutoff="all")).pscf(g["kin"], g["Pin"])
+
+
+def test_optiresum(golden):
+    """oracle == reference with Common(optiresum=True)."""
+    from oracle import OracleConfig
+
+    g = golden("opti")
+    eng = OracleEngine(OracleConfig(Nl=3, kmA=0.7, krA=0.25, ndA=4.5e-5, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]),
+                                    H_AP=float(g["H_AP"]), optiresum=True))
+    assert np.array_equal(eng.s, g["s"]) and np.array_equal(eng.sr, g["sr"])
+    taps = {}
+    st = eng.evaluate(g["kin"], g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), taps=taps)
+    assert relerr(taps["pscf"]["C11"], g["pscf_C11"]) < TOL and relerr(taps["pscf"]["Cct"], g["pscf_Cct"]) < TOL
+    assert relerr(taps["pscf"]["C22"][1], g["pscf_C22_l2"]) < TOL
+    assert relerr(taps["setpscfl"]["Cloopl"].reshape(36, -1), g["setpscfl_Cloopl"].reshape(36, -1)) < TOL
+    assert relerr(eng.extract_bao(taps["pscf"]["Cct"]), g["bao_Cct"]) < 1e-9
+    assert relerr(taps["resum"]["X"][None], g["X"][None]) < TOL and relerr(taps["resum"]["Y"][None], g["Y"][None]) < TOL
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(taps["resum"][n], g["resum_" + n]) < TOL, n
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        assert relerr(st[n], g["ap_" + n]) < TOL, n

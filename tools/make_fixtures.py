@@ -236,6 +236,39 @@ def ircut_fixture(ref):
     print("ircut written:", len(out), "arrays")
 
 
+def opti_fixture(ref):
+    """Common(optiresum=True) through the REAL reference (pybird.py:553-556, 1235-1244, 1382-1400): the xi pieces
+    on the 52-point s grid, the IR filters on the 48 BAO points, and the templates after Resum.Ps and APeffect.AP."""
+    pb = ref.pybird
+    Nl, z = 3, 0.7
+    cos = synth.cosmology(z=z)
+    out = dict(kin=cos["kin"], Pin=cos["Pin"], f=cos["f"], DA=cos["DA"], H=cos["H"], z=z, Nl=Nl)
+    co = make_common(pb, Nl, None, optiresum=True)
+    out["k"], out["s"] = co.k, co.s
+    nl = pb.NonLinear(load=False, save=False, co=co)
+    bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+    nl.PsCf(bird)
+    for n in ("C11", "Cct"):
+        out["pscf_" + n] = np.array(getattr(bird, n), copy=True)
+    out["pscf_C22_l2"] = bird.C22[1].copy()
+    bird.setPsCfl()
+    out["setpscfl_Cloopl"] = bird.Cloopl.copy()
+    rs = pb.Resum(co=co)
+    out["sr"] = rs.sr
+    out["X"], out["Y"] = rs.IRFilters(bird)
+    out["bao_Cct"] = rs.extractBAO(bird.Cct)
+    rs.Ps(bird)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        out["resum_" + n] = getattr(bird, n).copy()
+    ap = pb.APeffect(Om_AP=synth.OM_AP, z_AP=z, co=co)
+    out["DA_AP"], out["H_AP"] = ap.DA, ap.H
+    ap.AP(bird)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        out["ap_" + n] = getattr(bird, n).copy()
+    np.savez_compressed(os.path.join(GOLD, "opti.npz"), **out)
+    print("opti written:", {k: np.shape(v) for k, v in out.items() if np.ndim(v) > 0})
+
+
 def marg_fixture(ref):
     """the Gaussian (derivative) table and the analytically marginalised log-posterior, from the
     REAL reference (parambasis.WestCoastBasis.reduce_Plk_gaussian_table, marginal.Marginalizable.marginalized_logp) on
@@ -486,7 +519,7 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -502,6 +535,8 @@ def main():
             nnlo_fixture(ref)
         elif name == "ircut":
             ircut_fixture(ref)
+        elif name == "opti":
+            opti_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
