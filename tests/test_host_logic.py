@@ -21,8 +21,8 @@ def test_common_mirror_matches_reference_tables(golden):
     assert np.array_equal(pybird.Common(Nl=3).k, golden("caseC")["k"])
     with pytest.raises(ValueError):
         pybird.Common(Nl=2, No=3)
-    with pytest.raises(NotImplementedError):
-        pybird.Common(Nl=2, optiresum=True)
+    co = pybird.Common(Nl=2, optiresum=True)
+    assert co.Ns == 52 and co.s[0] == 70.0 and co.s[-1] == 197.5
     from oracle import tables as OT
 
     con = pybird.Common(Nl=3, with_NNLO=True)
