@@ -31,7 +31,7 @@ class Config(C.Structure):
 TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD EXP22 EXPC MLJ LINVEC SYNK SYNS LINK LINS L11 LCT L22 L13 GRP "
           "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID LCTN BAO GCT2").split()
 T = {n: i for i, n in enumerate(TABLES)}
-BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF GROWS LOGP CCTN TEMPLN BIASN".split()
+BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF GROWS LOGP CCTN TEMPLN BIASN GROWSN".split()
 B = {n: i for i, n in enumerate(BUFFERS)}
 S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22, K_RESUM, S_LOGP = (1 << i for i in range(12))
 

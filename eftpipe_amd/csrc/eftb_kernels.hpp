@@ -1250,7 +1250,9 @@ __global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ndat
                                                         const double* __restrict__ data, const double* __restrict__ invcov,
                                                         const double* __restrict__ mu, const double* __restrict__ sinv,
                                                         const double* __restrict__ rows, const double* __restrict__ T,
+                                                        const double* __restrict__ rowsn, const double* __restrict__ TN,
                                                         double* __restrict__ out) {
+    // rowsn [B][MARG_NG1][3], TN: the NNLO block (with_nnlo), contributing sum_j rowsn[g][j] TN[l][3 + j][x]; both null otherwise
     extern __shared__ double sm[];
     const int ng1 = nG + 1, w = blockIdx.x, tid = threadIdx.x;
     double* R = sm;                        // [ng1][24]
@@ -1271,6 +1273,11 @@ __global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ndat
             for (int r = 0; r < NROW; r += 2) {
                 s0 = fma(R[g * NROW + r], tv[r], s0);
                 s1 = fma(R[g * NROW + r + 1], tv[r + 1], s1);
+            }
+            if (TN) {
+                const double* tn = TN + (((size_t)w * nl + l) * NROW + 3) * nx + x;
+                const double* rn = rowsn + ((size_t)w * MARG_NG1 + g) * 3;
+                s0 += rn[0] * tn[0] + rn[1] * tn[(size_t)nx] + rn[2] * tn[(size_t)2 * nx];
             }
             V[(size_t)g * ndata + a] = s0 + s1 - (g == 0 ? data[a] : 0.0);
         }

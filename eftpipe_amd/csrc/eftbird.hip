@@ -193,6 +193,7 @@ static size_t need_buffer_elems(const eftb_config& c, int id) {
         case EFTB_B_CCTN: return c.with_nnlo && c.with_resum ? B * c.Nl * NS : 0;
         case EFTB_B_TEMPLN: return c.with_nnlo ? B * c.Nl * NROW * c.Nk : 0;
         case EFTB_B_BIASN: return c.with_nnlo ? B * 3 : 0;
+        case EFTB_B_GROWSN: return c.with_nnlo ? B * MARG_NG1 * 3 : 0;
     }
     return 0;
 }
@@ -461,10 +462,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     }
     if (mask & EFTB_S_LOGP) {
         if (!e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
-        if (c.with_nnlo) return fail("eftb_run: stage LOGP does not take the NNLO block yet (with_nnlo=1)");
         const size_t lds = ((size_t)(e->like_nG + 1) * (NROW + 2 * e->like_ndata + e->like_nG + 1)) * sizeof(double);
         hipLaunchKernelGGL(marg_logp_kernel, dim3(B), dim3(256), lds, st, e->cur_nl, e->cur_nx, e->like_ndata, e->like_nG, e->jeffreys, e->like_index,
-                           e->like_data, e->like_invcov, e->like_mu, e->like_sinv, b[EFTB_B_GROWS], b[EFTB_B_TEMPL], b[EFTB_B_LOGP]);
+                           e->like_data, e->like_invcov, e->like_mu, e->like_sinv, b[EFTB_B_GROWS], b[EFTB_B_TEMPL],
+                           c.with_nnlo ? b[EFTB_B_GROWSN] : nullptr, c.with_nnlo ? b[EFTB_B_TEMPLN] : nullptr, b[EFTB_B_LOGP]);
     }
     if (mask & EFTB_S_REDUCE)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],

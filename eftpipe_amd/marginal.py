@@ -56,7 +56,7 @@ class MarginalLikelihood:
                                                L.dptr(invcov), self.nG, L.dptr(loc), L.dptr(sinv)))
         L.check(engine.lib.eftb_set_option(engine._h, 1, int(bool(jeffreys))))
 
-    def logp(self, rows, return_best=False):
+    def logp(self, rows, return_best=False, rows_nnlo=None):
         """rows [B, nG + 1, 24] (``parambasis.gaussian_rows`` per walker) -> ln P_marg [B]
         (+ full chi2 [B] and best-fit Gaussian parameters [B, nG]).  Raises like the reference when det F2 <= 0."""
         rows = np.ascontiguousarray(rows, dtype=np.float64)
@@ -66,6 +66,13 @@ class MarginalLikelihood:
         buf = np.zeros((B, MAXG + 1, 24))
         buf[:, : self.nG + 1] = rows
         self.eng.put("GROWS", buf)
+        if self.eng.cfg.with_NNLO:  # coefficients of PctNNLOl per row (zeros unless given): [B, nG + 1, 3]
+            bn = np.zeros((B, MAXG + 1, 3))
+            if rows_nnlo is not None:
+                bn[:, : self.nG + 1] = np.asarray(rows_nnlo, dtype=np.float64).reshape(B, self.nG + 1, 3)
+            self.eng.put("GROWSN", bn)
+        elif rows_nnlo is not None:
+            raise ValueError("rows_nnlo needs an engine built with with_NNLO")
         self.eng.run(L.S_LOGP, B)
         out = self.eng.get("LOGP", (B, 2 + MAXG))
         if np.any(np.isnan(out[:, 0])):

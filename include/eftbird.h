@@ -93,6 +93,8 @@ enum eftb_buffer {
     EFTB_B_CCTN,      /* [B][Nl][80]          Bird.CctNNLO                        pybird.py:1098-1101 */
     EFTB_B_TEMPLN,    /* [B][nl][24][nx]      rows 3-5 = Bird.PctNNLOl            pybird.py:741-748 */
     EFTB_B_BIASN,     /* [B][3]               bctNNLO                             parambasis.py:96-106 */
+    EFTB_B_GROWSN,    /* [B][17][3]           NNLO part of the EFTB_B_GROWS rows: coefficients of PctNNLOl in P_NG (row 0) and in
+                                              dP/d(cr4, cr6 | ctilde) (parambasis.py:303-307, 429-435); zero-initialised */
     EFTB_B_COUNT
 };
 

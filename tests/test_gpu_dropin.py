@@ -188,8 +188,29 @@ def test_with_nnlo_sequence_and_batched(golden):
 
     eng.run(L.S_REDUCE, 3)
     assert np.array_equal(eng.get("PLK", (3, 3, nb)), plk)
-    with pytest.raises(Exception):
-        eng.run(L.S_LOGP, 3)  # the LOGP stage does not take the NNLO block yet: loud failure
+    # LOGP with the NNLO parameters cr4, cr6 marginalised as well (reference parambasis.py:303-307): rows over both blocks
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index
+    from eftpipe_amd.parambasis import gaussian_rows
+    from oracle import marginal as M
+
+    b1, b2, b4 = bsA[0], bsA[1], bsA[3]
+    rows = np.zeros((3, 10, 24))
+    rows[:, :8] = gaussian_rows(f, (b1, b2, b4), None, 0.7, 0.25, 4.5e-5)
+    rn = np.zeros((3, 10, 3))
+    rn[:, 8, 0], rn[:, 9, 1] = 0.25 * b1**2 / 0.25**4, 0.25 * b1 / 0.25**4
+    index = data_index([0, 2, 4], {0: slice(0, nb), 2: slice(1, nb - 2), 4: slice(2, 10)}, nb)
+    rng = np.random.default_rng(11)
+    V = [(np.einsum("gr,lrx->glx", rows[i], templ[i]) + np.einsum("gj,ljx->glx", rn[i], tn[i][:, 3:6])).reshape(10, -1)[:, index] for i in range(3)]
+    sig = 0.05 * np.abs(V[0][0]) + 15.0
+    D = V[0][0] + sig * rng.normal(size=index.size)
+    C = np.diag(1.0 / sig**2)
+    loc, scale = np.zeros(9), np.array([2.0, 2.0, 4.0, 4.0, 2.0, 2.0, 2.0, 3.0, 3.0])
+    like = MarginalLikelihood(eng, index, D, C, loc, scale)
+    lp, full, best = like.logp(rows, return_best=True, rows_nnlo=rn)
+    for i in range(3):
+        w = M.marginalized_logp(V[i][1:], V[i][0], D, C, loc, scale, return_best=True)
+        assert np.isclose(lp[i], w[0], rtol=1e-10) and np.isclose(full[i], w[1], rtol=1e-9) and relerr(best[i][None], w[2][None]) < 1e-8, i
+    assert abs(lp[0] - like.logp(rows)[0]) > 1e-3  # the NNLO rows matter
     eng.close()
 
 
