@@ -198,3 +198,28 @@ def test_c_abi_error_paths(golden):
     eng.run(L.S_PREP | L.S_LOOPS)
     assert relerr(eng.get("P22", (28, g["k"].size)), g["pscf_P22"]) < TOL
     eng.close()
+
+
+@pytest.mark.parametrize("opts", [dict(with_NNLO=True), dict(optiresum=True), dict(IRcutoff="resum", kIR=0.004),
+                                  dict(with_NNLO=True, optiresum=True, IRcutoff="loop", kIR=0.006)])
+def test_nl2_option_branches_against_oracle(golden, opts):
+    """The option branches (NNLO, optiresum, IRcutoff) on the Nl = 2 engine, whose resummation runs on the generic
+    kernel instead of the matrix-core one -- against the oracle (pinned to the reference for these options at Nl = 3)."""
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+    from oracle import OracleConfig, OracleEngine
+
+    g = golden("caseE")
+    f, DA, H = float(g["f"]), float(g["DA"]), float(g["H"])
+    orc = OracleEngine(OracleConfig(Nl=2, kmA=0.7, krA=0.25, ndA=4.5e-5, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]),
+                                    H_AP=float(g["H_AP"]), **opts))
+    want = orc.evaluate(g["kin"], g["Pin"], f, DA, H)
+    eng = Engine(EngineConfig(Nl=2, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"]), **opts), max_batch=2)
+    templ = eng.eval_batch(np.stack([g["Pin"], g["Pin"]]), f, DA, H)
+    for i in range(2):
+        assert relerr(templ[i][:, 0:3], want["P11l"]) < TOL and relerr(templ[i][:, 3:9], want["Pctl"]) < TOL
+        assert relerr(templ[i][:, 9:21], want["Ploopl"]) < TOL and relerr(templ[i][:, 21:24], want["Pstl"]) < TOL
+    if opts.get("with_NNLO"):
+        tn = eng.get("TEMPLN", (2, 2, 24, g["k"].size))
+        assert relerr(tn[1][:, 3:6], want["PctNNLOl"]) < TOL
+    eng.close()
