@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import json
 from pathlib import Path
+from typing import NamedTuple
 
 import numpy as np
 
@@ -113,5 +114,107 @@ class Window(HasLogger):
         bird.Pstl = out["Pstl"] if self.window_st else keep
         if "PctNNLOl" in out:
             bird.PctNNLOl = out["PctNNLOl"]
+        if self.snapshot:
+            bird.create_snapshot("window")
+
+
+# ----------------------------------------------------------------------------- window as a ready-made matrix
+class PInfo(NamedTuple):
+    """Layout of one axis of a stacked window-matrix file (reference window.py:418-423)."""
+
+    ells: tuple
+    kmin: float
+    kmax: float
+    nbins: int
+
+
+class PolesInfo(NamedTuple):
+    """(reference window.py:470-474)"""
+
+    nells: int
+    kstart: float
+    kend: float
+    nbin: int
+
+
+def _axis_mask(info, ells_keep, lo, hi):
+    """rows / columns of the stacked [len(ells) * nbins] axis that belong to the kept multipoles and to bin-centre range [lo, hi)"""
+    edges = np.linspace(info.kmin, info.kmax, info.nbins + 1)
+    centres = 0.5 * (edges[1:] + edges[:-1])
+    a, b = int(np.searchsorted(centres, lo)), int(np.searchsorted(centres, hi))
+    mask = np.zeros(info.nbins * len(info.ells), dtype=bool)
+    for n, ell in enumerate(info.ells):
+        if ell in ells_keep:
+            mask[n * info.nbins + a : n * info.nbins + b] = True
+    return mask
+
+
+def to_window_matrix(matrix, inpoles, outpoles, ells_in, kmax_in, ells_out, kmin_out, kmax_out):
+    """Stacked window matrix [out rows, in columns] -> [len(ells_out), len(ells_in), nk_out, nk_in] restricted to the requested
+    multipoles and k ranges (reference window.py:426-467; like the reference, the multipoles keep the file's order)."""
+    m_in = _axis_mask(inpoles, ells_in, -np.inf, kmax_in)
+    m_out = _axis_mask(outpoles, ells_out, kmin_out, kmax_out)
+    sub = np.asarray(matrix)[np.ix_(m_out, m_in)]
+    no, ni = len(ells_out), len(ells_in)
+    return np.ascontiguousarray(sub.reshape(no, sub.shape[0] // no, ni, sub.shape[1] // ni).transpose(0, 2, 1, 3))
+
+
+class WindowMatrix(HasLogger):
+    """Window convolution with a ready-made matrix (same surface as reference window.py:479-586): cubic interpolation of
+    the templates onto ``kavg`` folded with ``matrix`` into one dense device operator."""
+
+    def __init__(self, matrix, inpoles, outpoles, co=None, window_st=False, icc=None, name="pybird.WindowMatrix", snapshot=False):
+        from . import pybird
+        from .tables import spline_matrix
+
+        self.set_logger(name=name)
+        self.matrix, self.inpoles, self.outpoles = np.asarray(matrix, dtype=np.float64), inpoles, outpoles
+        self.co = pybird.common if co is None else co
+        self.window_st, self.snapshot = window_st, snapshot
+        if icc:
+            raise NotImplementedError("ICC not implemented for WindowMatrix")
+        if self.matrix.shape != (outpoles.nells, inpoles.nells, outpoles.nbin, inpoles.nbin):
+            raise ValueError("matrix shape does not match meta information")
+        if inpoles.nells != self.co.Nl:
+            raise ValueError("input poles do not match self.co.Nl")
+        if self.matrix.shape[3] != self.kavg.size:
+            raise ValueError("matrix columns do not match kavg")
+        self.operator = np.einsum("alxp,pk->alxk", self.matrix, spline_matrix(self.co.k, self.kavg))
+        self._op = None
+
+    @classmethod
+    def load(cls, path, ells, kmin, kmax, co=None, window_st=False, icc=None, name="pybird.WindowMatrix", snapshot=False):
+        """(reference window.py:511-545, with its hard-coded file layout)"""
+        from . import pybird
+
+        co = pybird.common if co is None else co
+        m = to_window_matrix(np.loadtxt(path), PInfo((0, 2, 4), 0, 0.4, 400), PInfo((0, 1, 2, 3, 4), 0, 0.4, 40),
+                             ells_in=tuple(2 * i for i in range(co.Nl)), kmax_in=co.k.max(), ells_out=tuple(ells), kmin_out=kmin, kmax_out=kmax)
+        return cls(m, PolesInfo(co.Nl, 0, co.k.max(), m.shape[3]), PolesInfo(len(ells), kmin, kmax, m.shape[2]), co=co, window_st=window_st,
+                   icc=icc, name=name, snapshot=snapshot)
+
+    @property
+    def kavg(self):
+        return np.linspace(0, 0.4, 400)[:300]  # as hard-coded in the reference (window.py:548-550)
+
+    def convolve(self, Plk):
+        """host form (reference window.py:557-564)"""
+        return np.einsum("alxk,l...k->a...x", self.operator, np.asarray(Plk))
+
+    def Window(self, bird):
+        """(reference window.py:566-586)"""
+        from .pybird import engine_for
+
+        eng = engine_for(bird.co)
+        if self._op is None or self._op[0] is not eng:
+            self._op = (eng, eng.add_operator(self.operator))
+        keep = bird.Pstl
+        out = apply_operator_to_birdlike(eng, self._op[1], bird)
+        bird.P11l, bird.Pctl, bird.Ploopl = out["P11l"], out["Pctl"], out["Ploopl"]
+        if "PctNNLOl" in out:
+            bird.PctNNLOl = out["PctNNLOl"]
+        if self.window_st:
+            bird.Pstl = out["Pstl"]
+        bird.Picc = np.zeros((self.outpoles.nells, self.outpoles.nbin))
         if self.snapshot:
             bird.create_snapshot("window")

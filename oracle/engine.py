@@ -533,3 +533,38 @@ def plk_interpolate(ls, kgrid, Plk, l, k):
     idx = [list(ls).index(x) for x in ll]
     out = (tmp(k) / k)[idx]
     return out[0] if len(idx) == 1 else out
+
+
+# ----------------------------------------------------------------------------- WindowMatrix (reference window.py:426-586)
+def to_window_matrix(matrix, in_ells, in_kmin, in_kmax, in_nbins, out_ells, out_kmin, out_kmax, out_nbins, ells_in, kmax_in, ells_out, kmin_out,
+                     kmax_out):
+    """Stacked matrix -> [len(ells_out), len(ells_in), nk_out, nk_in] (window.py:426-467, same masking rules)."""
+    kedges = np.linspace(in_kmin, in_kmax, in_nbins + 1)
+    kin = (kedges[1:] + kedges[:-1]) / 2
+    mask_in = np.zeros(in_nbins * len(in_ells), dtype=bool)
+    ileft, iright = 0, np.searchsorted(kin, kmax_in)
+    for ell in in_ells:
+        if ell in ells_in:
+            mask_in[ileft:iright] = True
+        ileft, iright = ileft + in_nbins, iright + in_nbins
+    kedges = np.linspace(out_kmin, out_kmax, out_nbins + 1)
+    kout = (kedges[1:] + kedges[:-1]) / 2
+    mask_out = np.zeros(out_nbins * len(out_ells), dtype=bool)
+    ileft, iright = np.searchsorted(kout, kmin_out), np.searchsorted(kout, kmax_out)
+    for ell in out_ells:
+        if ell in ells_out:
+            mask_out[ileft:iright] = True
+        ileft, iright = ileft + out_nbins, iright + out_nbins
+    sub = matrix[np.ix_(mask_out, mask_in)]
+    nk_out, nk_in = sub.shape[0] // len(ells_out), sub.shape[1] // len(ells_in)
+    res = np.zeros((len(ells_out), len(ells_in), nk_out, nk_in))
+    for i in range(len(ells_out)):
+        for j in range(len(ells_in)):
+            res[i, j] = sub[i * nk_out : (i + 1) * nk_out, j * nk_in : (j + 1) * nk_in]
+    return res
+
+
+def window_matrix_convolve(k, matrix, Plk):
+    """WindowMatrix.convolve (window.py:548-564) with its hard-coded kavg"""
+    kavg = np.linspace(0, 0.4, 400)[:300]
+    return np.einsum("alkp,l...p->a...k", matrix, cubic_to(k, Plk, kavg), optimize=True)

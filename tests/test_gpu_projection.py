@@ -295,3 +295,25 @@ def test_fiber_collision_mirror_and_folded_operator(golden):
     with pytest.raises(Exception):
         eng.add_operator(np.zeros((3, 3, 5, k.size)), stochastic=np.zeros((3, 3, 6, k.size)))
     eng.close()
+
+
+def test_window_matrix_on_device(golden):
+    """WindowMatrix.Window (reference window.py:566-586) as a device operator, window_st on and off"""
+    from types import SimpleNamespace
+
+    from eftpipe_amd import pybird
+    from eftpipe_amd import window as W
+
+    g, c = golden("wmat"), golden("caseC")
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+    m = W.to_window_matrix(g["stacked"].astype(np.float64), W.PInfo((0, 2, 4), 0, 0.4, 400), W.PInfo((0, 1, 2, 3, 4), 0, 0.4, 40), (0, 2, 4), co.k.max(),
+                           tuple(g["ells"]), float(g["kmin"]), float(g["kmax"]))
+    for st in (False, True):
+        wm = W.WindowMatrix(m, W.PolesInfo(3, 0, co.k.max(), m.shape[3]), W.PolesInfo(2, float(g["kmin"]), float(g["kmax"]), m.shape[2]), co=co,
+                            window_st=st)
+        bird = SimpleNamespace(co=co, Picc=np.zeros((3, 50)), **{n: c["ap_" + n].copy() for n in NAMES})
+        wm.Window(bird)
+        tag = "st_" if st else ""
+        for n in NAMES:
+            assert relerr(getattr(bird, n), g[tag + "wm_" + n]) < TOL, (st, n)
+        assert bird.Picc.shape == (2, m.shape[2])

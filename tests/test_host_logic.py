@@ -238,3 +238,20 @@ def test_fiber_operator_matches_reference(golden):
     x = np.einsum("bx,anx->anb", Bn, x)
     x = np.einsum("ca,anb->cnb", TB.chained_matrix(3), x)
     assert relerr(np.einsum("alxk,lnk->anx", op, P).reshape(10, -1), x.reshape(10, -1)) < 1e-12
+
+
+def test_window_matrix_host_side(golden):
+    """to_window_matrix / WindowMatrix.convolve mirrors (reference window.py:426-564) against reference outputs"""
+    from eftpipe_amd import pybird
+    from eftpipe_amd import window as W
+
+    g, c = golden("wmat"), golden("caseC")
+    co = pybird.Common(Nl=3, kmax=0.3)
+    m = W.to_window_matrix(g["stacked"].astype(np.float64), W.PInfo((0, 2, 4), 0, 0.4, 400), W.PInfo((0, 1, 2, 3, 4), 0, 0.4, 40), (0, 2, 4), co.k.max(),
+                           tuple(g["ells"]), float(g["kmin"]), float(g["kmax"]))
+    assert m.shape == tuple(g["matrix_shape"]) and np.array_equal(m[:, :, ::5, ::37], g["matrix_spot"])
+    wm = W.WindowMatrix(m, W.PolesInfo(3, 0, co.k.max(), m.shape[3]), W.PolesInfo(2, float(g["kmin"]), float(g["kmax"]), m.shape[2]), co=co)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(wm.convolve(c["ap_" + n]), g["wm_" + n]) < 1e-10, n
+    with pytest.raises(ValueError):
+        W.WindowMatrix(m[:, :2], W.PolesInfo(3, 0, 0.3, 300), W.PolesInfo(2, 0.02, 0.2, 18), co=co)

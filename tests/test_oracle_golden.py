@@ -279,3 +279,18 @@ def test_optiresum(golden):
         assert relerr(taps["resum"][n], g["resum_" + n]) < TOL, n
     for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
         assert relerr(st[n], g["ap_" + n]) < TOL, n
+
+
+def test_window_matrix(golden):
+    """oracle == reference WindowMatrix (to_window_matrix + convolve) on the AP-stage templates of caseC"""
+    from oracle import engine as OE
+
+    g, c = golden("wmat"), golden("caseC")
+    st = g["stacked"].astype(np.float64)
+    m = OE.to_window_matrix(st, (0, 2, 4), 0, 0.4, 400, (0, 1, 2, 3, 4), 0, 0.4, 40, (0, 2, 4), c["k"].max(), tuple(g["ells"]), float(g["kmin"]),
+                            float(g["kmax"]))
+    assert m.shape == tuple(g["matrix_shape"]) and np.array_equal(m[:, :, ::5, ::37], g["matrix_spot"])
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(OE.window_matrix_convolve(c["k"], m, c["ap_" + n]), g["wm_" + n]) < 1e-12, n
+    assert relerr(OE.window_matrix_convolve(c["k"], m, c["ap_Pstl"]), g["st_wm_Pstl"]) < 1e-12
+    assert np.array_equal(g["wm_Pstl"], c["ap_Pstl"])

@@ -269,6 +269,34 @@ def opti_fixture(ref):
     print("opti written:", {k: np.shape(v) for k, v in out.items() if np.ndim(v) > 0})
 
 
+def wmat_fixture(ref):
+    """WindowMatrix of the REAL reference (window.py:426-586): to_window_matrix on a seeded stacked matrix and the convolution of
+    the AP-stage templates of caseC (window_st on and off)."""
+    pb, W = ref.pybird, ref.window
+    g = dict(np.load(os.path.join(GOLD, "caseC.npz"), allow_pickle=True))
+    co = make_common(pb, 3, None)
+    rng = np.random.default_rng(77)
+    inp, outp = W.PInfo(ells=(0, 2, 4), kmin=0, kmax=0.4, nbins=400), W.PInfo(ells=(0, 1, 2, 3, 4), kmin=0, kmax=0.4, nbins=40)
+    # banded + smooth stacked matrix (values only matter as data); float32-rounded so the fixture stays small
+    kc_in, kc_out = np.tile((np.arange(400) + 0.5) * 1e-3, 3), np.tile((np.arange(40) + 0.5) * 1e-2, 5)
+    stacked = np.exp(-0.5 * ((kc_out[:, None] - kc_in[None, :]) / 0.01) ** 2) * (1.0 + 0.3 * rng.normal(size=(200, 1200)))
+    stacked = stacked.astype(np.float32).astype(np.float64)
+    ells, kmin, kmax = [0, 2], 0.02, 0.2
+    m = W.to_window_matrix(stacked, inp, outp, ells_in=(0, 2, 4), kmax_in=co.k.max(), ells_out=tuple(ells), kmin_out=kmin, kmax_out=kmax)
+    out = dict(stacked=stacked.astype(np.float32), ells=np.array(ells), kmin=kmin, kmax=kmax, matrix_shape=np.array(m.shape),
+               matrix_spot=m[:, :, ::5, ::37])
+    for st in (False, True):
+        wm = W.WindowMatrix(m, inpoles=W.PolesInfo(3, 0, co.k.max(), m.shape[3]), outpoles=W.PolesInfo(len(ells), kmin, kmax, m.shape[2]),
+                            co=co, window_st=st)
+        bird = ref.transformer.PlainBird(f=float(g["f"]), co=co, P11l=g["ap_P11l"].copy(), Ploopl=g["ap_Ploopl"].copy(), Pctl=g["ap_Pctl"].copy(),
+                                         Pstl=g["ap_Pstl"].copy(), Picc=np.zeros((3, co.Nk)), PctNNLOl=None)
+        wm.Window(bird)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            out[("st_" if st else "") + "wm_" + n] = np.array(getattr(bird, n))
+    np.savez_compressed(os.path.join(GOLD, "wmat.npz"), **out)
+    print("wmat written:", m.shape, {k: np.shape(v) for k, v in out.items() if k.startswith("wm_")})
+
+
 def marg_fixture(ref):
     """the Gaussian (derivative) table and the analytically marginalised log-posterior, from the
     REAL reference (parambasis.WestCoastBasis.reduce_Plk_gaussian_table, marginal.Marginalizable.marginalized_logp) on
@@ -519,7 +547,7 @@ def tables_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti", "wmat"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -537,6 +565,8 @@ def main():
             ircut_fixture(ref)
         elif name == "opti":
             opti_fixture(ref)
+        elif name == "wmat":
+            wmat_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
