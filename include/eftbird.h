@@ -178,7 +178,8 @@ int  eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, 
  * (likelihood.py:483-549) and Marginalizable.marginalized_logp (marginal.py:79-140).  Host inputs in, one marginalised
  * log-posterior per walker out; nothing else crosses PCIe.  Needs eftb_set_likelihood (and the pipeline operator that
  * brings the templates to the data's shape).  rows is PACKED [B][nG+1][24] (eftpipe_amd.parambasis.gaussian_rows);
- * logp [B] (NaN where det F2 <= 0: the reference raises there); fullchi2 [B] and best [B][nG] may be NULL. */
+ * logp [B] (NaN where det F2 <= 0: the reference raises there); fullchi2 [B] and best [B][nG] may be NULL.
+ * With with_nnlo the NNLO part of the rows is whatever EFTB_B_GROWSN holds (eftb_put it beforehand; zero-initialised). */
 int  eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H,
                           const double* rows, double* logp, double* fullchi2, double* best);
 
