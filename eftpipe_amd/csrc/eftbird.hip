@@ -705,8 +705,8 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
 
 int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov, int nG, const double* mu,
                         const double* sigma_inv) {
-    if (!e || !index || !data || !invcov || !mu || !sigma_inv) return fail("eftb_set_likelihood: null argument");
-    if (nG < 1 || nG > MARG_MAXG) return fail("eftb_set_likelihood: nG=%d outside [1, %d]", nG, MARG_MAXG);
+    if (!e || !index || !data || !invcov || (nG > 0 && (!mu || !sigma_inv))) return fail("eftb_set_likelihood: null argument");
+    if (nG < 0 || nG > MARG_MAXG) return fail("eftb_set_likelihood: nG=%d outside [0, %d]", nG, MARG_MAXG);  // nG = 0: plain -chi2 / 2
     const size_t lds = ((size_t)(nG + 1) * (NROW + 2 * (size_t)ndata + nG + 1)) * sizeof(double);
     if (ndata < 1 || lds > 160 * 1024) return fail("eftb_set_likelihood: ndata=%d does not fit the 160 KB LDS working set with nG=%d", ndata, nG);
     const int npts = e->cur_nl * e->cur_nx;
@@ -729,8 +729,10 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
     HIPCHK(hipMemcpy(e->like_index, index, ndata * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->like_data, data, ndata * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->like_invcov, invcov, (size_t)ndata * ndata * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->like_mu, mu, nG * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->like_sinv, sigma_inv, nG * sizeof(double), hipMemcpyHostToDevice));
+    if (nG > 0) {
+        HIPCHK(hipMemcpy(e->like_mu, mu, nG * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->like_sinv, sigma_inv, nG * sizeof(double), hipMemcpyHostToDevice));
+    }
     e->like_ndata = ndata;
     e->like_nG = nG;
     return 0;

@@ -133,7 +133,7 @@ int  eftb_set_option(eftb_engine* e, int option, int value);
  * EFTLike.PNG / PG (likelihood.py:483-549: flatten the multipoles over the masked k bins) and
  * Marginalizable.marginalized_logp (marginal.py:79-140).  index[a] = l * nx + x selects data point a from the current
  * template block [nl][24][nx] (after the pipeline operator, if any); data[ndata]; invcov[ndata][ndata] symmetric;
- * nG <= 16 marginalised parameters with Gaussian prior N(mu[i], sigma_i^2), sigma_inv[i] = 1 / sigma_i^2 (all zero: flat).
+ * 0 <= nG <= 16 marginalised parameters (nG = 0: the plain Gaussian likelihood -chi2 / 2 of row 0) with Gaussian prior N(mu[i], sigma_i^2), sigma_inv[i] = 1 / sigma_i^2 (all zero: flat).
  * Per walker the caller puts the coefficient rows EFTB_B_GROWS (eftpipe_amd.parambasis.gaussian_rows) and reads
  * EFTB_B_LOGP after eftb_run(..., EFTB_S_LOGP, B). */
 int  eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov,

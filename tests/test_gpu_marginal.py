@@ -144,3 +144,26 @@ def test_eastcoast_basis_on_device(golden):
     like_j = MarginalLikelihood(eng, index, g["D"], g["invcov"], g["loc"], g["scale"], jeffreys=True)
     assert np.isclose(like_j.logp(rows)[0], g["logp_jeffreys"], rtol=1e-10)
     eng.close()
+
+
+def test_plain_chi2_without_marginalised_parameters(golden):
+    """nG = 0: the LOGP stage is the plain Gaussian likelihood -chi2 / 2 of the full model (reference likelihood.py calculate without
+    marginalisation: every parameter sampled)."""
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index
+    from eftpipe_amd.parambasis import bias_row
+
+    g = golden("marg")
+    eng, nx = _engine(g, 3)
+    T = np.concatenate([g["binned_P11l"], g["binned_Pctl"], g["binned_Ploopl"], g["binned_Pstl"]], axis=1)
+    ls = list(g["ls"])
+    index = data_index(ls, {l: slice(a, b) for l, (a, b) in zip(ls, g["masks"])}, nx)
+    D, C = g["auto_D"], g["auto_invcov"]
+    like = MarginalLikelihood(eng, index, D, C, np.zeros(0), np.zeros(0))
+    f = float(g["f"])
+    rows = np.stack([bias_row(f, [2.1 + 0.1 * i, 0.5, 0.3, 0.2, -1.0, -2.0, 0.5], None, (0.3, 0.1, -0.4), kmA=0.7, krA=0.25, ndA=4.5e-5) for i in range(3)])
+    eng.put("TEMPL", np.stack([T, T, 1.1 * T]))
+    logp = like.logp(rows[:, None, :])
+    for i in range(3):
+        r = np.einsum("r,lrx->lx", rows[i], (1.1 if i == 2 else 1.0) * T).reshape(-1)[index] - D
+        assert np.isclose(logp[i], -0.5 * r @ C @ r, rtol=1e-11), i
+    eng.close()
