@@ -36,7 +36,7 @@ B = {n: i for i, n in enumerate(BUFFERS)}
 S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22, K_RESUM, S_LOGP = (1 << i for i in range(12))
 
 EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_set_likelihood eftb_destroy eftb_add_operator eftb_apply_operator "
-           "eftb_set_operator_stochastic eftb_set_pipeline_operator eftb_set_template_dims eftb_put eftb_get eftb_buffer_size eftb_run "
+           "eftb_set_operator_stochastic eftb_set_tracers eftb_set_pipeline_operator_tracer eftb_set_pipeline_operator eftb_set_template_dims eftb_put eftb_get eftb_buffer_size eftb_run "
            "eftb_sync eftb_run_timed eftb_eval_batch eftb_eval_logp_batch eftb_host_alloc eftb_host_free eftb_comm_unique_id eftb_comm_init eftb_gather_plk "
            "eftb_mfma_f64_peak eftb_last_error eftb_version").split()
 
@@ -60,6 +60,8 @@ def load():
     lib.eftb_set_likelihood.argtypes, lib.eftb_set_likelihood.restype = [vp, i32, C.POINTER(C.c_int32), dp, dp, i32, dp, dp], i32
     lib.eftb_add_operator.argtypes, lib.eftb_add_operator.restype = [vp, i32, i32, i32, i32, dp, C.POINTER(C.c_int)], i32
     lib.eftb_set_operator_stochastic.argtypes, lib.eftb_set_operator_stochastic.restype = [vp, i32, i32], i32
+    lib.eftb_set_tracers.argtypes, lib.eftb_set_tracers.restype = [vp, i32], i32
+    lib.eftb_set_pipeline_operator_tracer.argtypes, lib.eftb_set_pipeline_operator_tracer.restype = [vp, i32, i32], i32
     lib.eftb_apply_operator.argtypes, lib.eftb_apply_operator.restype = [vp, i32, i32], i32
     lib.eftb_set_pipeline_operator.argtypes, lib.eftb_set_pipeline_operator.restype = [vp, i32], i32
     lib.eftb_set_template_dims.argtypes, lib.eftb_set_template_dims.restype = [vp, i32, i32], i32

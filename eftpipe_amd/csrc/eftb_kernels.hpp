@@ -1244,9 +1244,12 @@ __global__ __launch_bounds__(256) void reduce_nnlo_kernel(int Nx, int Nl, const 
 //     full chi2 at the best-fit Gaussian parameters b = F2^-1 F1:  G00 + 2 b.G[1:,0] + b G[1:,1:] b.
 // out[w] = (ln P, full chi2, b[0..MARG_MAXG)).  det F2 <= 0 (reference: RuntimeError "det of F2ij <= 0") gives NaN.
 // ------------------------------------------------------------------------------------------------
-constexpr int MARG_MAXG = 16, MARG_NG1 = MARG_MAXG + 1, MARG_OUT = 2 + MARG_MAXG;
+// Several tracers per likelihood point (EFTLike with tracers = [LRG, ELG, X], reference likelihood.py:483-549): the batch holds
+// ntr consecutive entries per walker, the data index addresses them as one block of ntr * nl multipoles, and every entry brings
+// its own coefficient rows (its bias values; zero rows for the parameters of the other tracers).
+constexpr int MARG_MAXG = 24, MARG_NG1 = MARG_MAXG + 1, MARG_OUT = 2 + MARG_MAXG;
 
-__global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ndata, int nG, int jeffreys, const int* __restrict__ index,
+__global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ntr, int ndata, int nG, int jeffreys, const int* __restrict__ index,
                                                         const double* __restrict__ data, const double* __restrict__ invcov,
                                                         const double* __restrict__ mu, const double* __restrict__ sinv,
                                                         const double* __restrict__ rows, const double* __restrict__ T,
@@ -1255,15 +1258,17 @@ __global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ndat
     // rowsn [B][MARG_NG1][3], TN: the NNLO block (with_nnlo), contributing sum_j rowsn[g][j] TN[l][3 + j][x]; both null otherwise
     extern __shared__ double sm[];
     const int ng1 = nG + 1, w = blockIdx.x, tid = threadIdx.x;
-    double* R = sm;                        // [ng1][24]
-    double* V = R + ng1 * NROW;            // [ng1][ndata]
+    double* R = sm;                        // [ntr][ng1][24]
+    double* V = R + ntr * ng1 * NROW;      // [ng1][ndata]
     double* U = V + (size_t)ng1 * ndata;   // [ng1][ndata]
     double* G = U + (size_t)ng1 * ndata;   // [ng1][ng1]
-    for (int e = tid; e < ng1 * NROW; e += 256) R[e] = rows[(size_t)w * MARG_NG1 * NROW + e];
+    for (int e = tid; e < ntr * ng1 * NROW; e += 256)
+        R[e] = rows[((size_t)w * ntr + e / (ng1 * NROW)) * MARG_NG1 * NROW + e % (ng1 * NROW)];
     __syncthreads();
     for (int a = tid; a < ndata; a += 256) {
-        const int l = index[a] / nx, x = index[a] % nx;
-        const double* t = T + ((size_t)w * nl + l) * NROW * nx + x;
+        const int l = index[a] / nx, x = index[a] % nx, tr = l / nl;  // l counts the ntr * nl multipoles of the walker's entries
+        const double* t = T + ((size_t)w * ntr * nl + l) * NROW * nx + x;
+        const double* Rt = R + tr * ng1 * NROW;
         double tv[NROW];
 #pragma unroll
         for (int r = 0; r < NROW; ++r) tv[r] = t[(size_t)r * nx];
@@ -1271,12 +1276,12 @@ __global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ndat
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int r = 0; r < NROW; r += 2) {
-                s0 = fma(R[g * NROW + r], tv[r], s0);
-                s1 = fma(R[g * NROW + r + 1], tv[r + 1], s1);
+                s0 = fma(Rt[g * NROW + r], tv[r], s0);
+                s1 = fma(Rt[g * NROW + r + 1], tv[r + 1], s1);
             }
             if (TN) {
-                const double* tn = TN + (((size_t)w * nl + l) * NROW + 3) * nx + x;
-                const double* rn = rowsn + ((size_t)w * MARG_NG1 + g) * 3;
+                const double* tn = TN + (((size_t)w * ntr * nl + l) * NROW + 3) * nx + x;
+                const double* rn = rowsn + (((size_t)w * ntr + tr) * MARG_NG1 + g) * 3;
                 s0 += rn[0] * tn[0] + rn[1] * tn[(size_t)nx] + rn[2] * tn[(size_t)2 * nx];
             }
             V[(size_t)g * ndata + a] = s0 + s1 - (g == 0 ? data[a] : 0.0);

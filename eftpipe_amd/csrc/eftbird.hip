@@ -61,6 +61,8 @@ struct eftb_engine {
     struct Op { int nl_out, nx_out, nl_in, nx_in, ld; double* dev; int st_op; };  // st_op >= 0: matrix used for the Pstl rows instead
     std::vector<Op> ops;
     int pipeline_op = -1;
+    int ntr = 1;                    // tracers per likelihood point: batch entry = walker * ntr + tracer (eftb_set_tracers)
+    std::vector<int> tracer_ops;    // per-tracer pipeline operators (eftb_set_pipeline_operator_tracer), empty = pipeline_op for all
     // likelihood of the LOGP stage (eftb_set_likelihood)
     int like_ndata = 0, like_nG = 0, jeffreys = 0;
     std::vector<double> like_host;  // eftb_eval_logp_batch: D2H landing block [B][MARG_OUT]
@@ -241,7 +243,9 @@ static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets,
 }
 
 // out[w][a][r][x] = sum_{l,k} T[w][l][r][k] * opT[(l,k)][(a,x)] on the FP64 matrix cores; the block changes shape
-static int launch_operator(eftb_engine* e, int id, int B) {
+// Entries t0, t0 + tstride, ... of the batch go through operator `id`; with commit the block pointers are swapped and the
+// block takes the operator's output shape (the last of a set of per-tracer launches commits).
+static int launch_operator(eftb_engine* e, int id, int B, int t0 = 0, int tstride = 1, bool commit = true) {
     if (id < 0 || id >= (int)e->ops.size()) return fail("operator id %d out of range", id);
     const eftb_engine::Op& o = e->ops[id];
     if (o.nl_in != e->cur_nl || o.nx_in != e->cur_nx)
@@ -249,11 +253,12 @@ static int launch_operator(eftb_engine* e, int id, int B) {
     // rows [r0, r0 + nr) of every (cosmology, multipole) through matrix `m`
     auto launch = [&](const eftb_engine::Op& m, int r0, int nr) {
         GemmDesc g{};
-        g.A = e->buf[EFTB_B_TEMPL] + (size_t)r0 * o.nx_in; g.a_group = (long long)o.nl_in * NROW * o.nx_in; g.a_row = o.nx_in;
+        const long long bin = (long long)o.nl_in * NROW * o.nx_in, bout = (long long)o.nl_out * NROW * o.nx_out;
+        g.A = e->buf[EFTB_B_TEMPL] + (size_t)t0 * bin + (size_t)r0 * o.nx_in; g.a_group = bin * tstride; g.a_row = o.nx_in;
         g.a_seg = (long long)NROW * o.nx_in;
-        g.rows = B * nr; g.rows_per_group = nr; g.nseg = o.nl_in; g.kseg = o.nx_in;
+        g.rows = ((B - t0 + tstride - 1) / tstride) * nr; g.rows_per_group = nr; g.nseg = o.nl_in; g.kseg = o.nx_in;
         g.B = m.dev; g.ldb = m.ld; g.ncols = o.nl_out * o.nx_out;
-        g.C = e->Talt + (size_t)r0 * o.nx_out; g.c_group = (long long)o.nl_out * NROW * o.nx_out; g.c_row = o.nx_out;
+        g.C = e->Talt + (size_t)t0 * bout + (size_t)r0 * o.nx_out; g.c_group = bout * tstride; g.c_row = o.nx_out;
         g.c_colgroup = (long long)NROW * o.nx_out;
         g.cols_per_group = o.nx_out;
         hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
@@ -263,9 +268,22 @@ static int launch_operator(eftb_engine* e, int id, int B) {
         launch(o, 0, NROW - 3);                 // P11l, Pctl, Ploopl
         launch(e->ops[o.st_op], NROW - 3, 3);   // Pstl (window_st / fiberst semantics of the reference)
     }
+    if (!commit) return 0;
     std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     e->cur_nl = o.nl_out;
     e->cur_nx = o.nx_out;
+    return 0;
+}
+
+// PROJECT stage: one operator for every entry, or one per tracer on the strided subsets
+static int launch_pipeline_operator(eftb_engine* e, int B) {
+    if (e->tracer_ops.empty()) {
+        if (e->pipeline_op < 0) return fail("eftb_run: stage PROJECT needs eftb_set_pipeline_operator");
+        return launch_operator(e, e->pipeline_op, B);
+    }
+    if (B % e->ntr) return fail("eftb_run: batch %d is not a multiple of the %d tracers per likelihood point", B, e->ntr);
+    for (int t = 0; t < e->ntr; ++t)
+        if (int rc = launch_operator(e, e->tracer_ops[t], B, t, e->ntr, t == e->ntr - 1)) return rc;
     return 0;
 }
 
@@ -457,13 +475,14 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         e->cur_nx = Nk;
     }
     if (mask & EFTB_S_PROJECT) {
-        if (e->pipeline_op < 0) return fail("eftb_run: stage PROJECT needs eftb_set_pipeline_operator");
-        if (int rc = launch_operator(e, e->pipeline_op, B)) return rc;
+        if (int rc = launch_pipeline_operator(e, B)) return rc;
     }
     if (mask & EFTB_S_LOGP) {
         if (!e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
-        const size_t lds = ((size_t)(e->like_nG + 1) * (NROW + 2 * e->like_ndata + e->like_nG + 1)) * sizeof(double);
-        hipLaunchKernelGGL(marg_logp_kernel, dim3(B), dim3(256), lds, st, e->cur_nl, e->cur_nx, e->like_ndata, e->like_nG, e->jeffreys, e->like_index,
+        if (B % e->ntr) return fail("eftb_run: batch %d is not a multiple of the %d tracers per likelihood point", B, e->ntr);
+        const size_t lds = ((size_t)(e->like_nG + 1) * (e->ntr * NROW + 2 * e->like_ndata + e->like_nG + 1)) * sizeof(double);
+        if (lds > 160 * 1024) return fail("eftb_run: stage LOGP needs %zu bytes of LDS with %d tracers", lds, e->ntr);
+        hipLaunchKernelGGL(marg_logp_kernel, dim3(B / e->ntr), dim3(256), lds, st, e->cur_nl, e->cur_nx, e->ntr, e->like_ndata, e->like_nG, e->jeffreys, e->like_index,
                            e->like_data, e->like_invcov, e->like_mu, e->like_sinv, b[EFTB_B_GROWS], b[EFTB_B_TEMPL],
                            c.with_nnlo ? b[EFTB_B_GROWSN] : nullptr, c.with_nnlo ? b[EFTB_B_TEMPLN] : nullptr, b[EFTB_B_LOGP]);
     }
@@ -668,6 +687,30 @@ int eftb_set_operator_stochastic(eftb_engine* e, int op_id, int st_op_id) {
     return 0;
 }
 
+int eftb_set_tracers(eftb_engine* e, int ntr) {
+    if (!e) return fail("eftb_set_tracers: null engine");
+    if (ntr < 1 || ntr > e->c.max_batch) return fail("eftb_set_tracers: %d tracers outside [1, max_batch]", ntr);
+    e->ntr = ntr;
+    e->tracer_ops.clear();
+    e->like_ndata = 0;  // a likelihood set for another grouping does not survive
+    return 0;
+}
+
+int eftb_set_pipeline_operator_tracer(eftb_engine* e, int tracer, int op_id) {
+    if (!e) return fail("eftb_set_pipeline_operator_tracer: null engine");
+    const int n = (int)e->ops.size();
+    if (tracer < 0 || tracer >= e->ntr || op_id < 0 || op_id >= n) return fail("eftb_set_pipeline_operator_tracer: tracer %d / operator %d out of range", tracer, op_id);
+    if (e->tracer_ops.empty()) e->tracer_ops.assign(e->ntr, op_id);  // until told otherwise every tracer uses the first one given
+    const eftb_engine::Op& b = e->ops[op_id];
+    for (int t = 0; t < e->ntr; ++t) {
+        const eftb_engine::Op& a = e->ops[e->tracer_ops[t]];
+        if (t != tracer && (a.nl_out != b.nl_out || a.nx_out != b.nx_out || a.nl_in != b.nl_in || a.nx_in != b.nx_in))
+            return fail("eftb_set_pipeline_operator_tracer: the tracers' operators must share one shape (pad chained outputs with zero rows)");
+    }
+    e->tracer_ops[tracer] = op_id;
+    return 0;
+}
+
 int eftb_apply_operator(eftb_engine* e, int op_id, int B) {
     if (!e) return fail("eftb_apply_operator: null engine");
     if (!e->finalized) return fail("eftb_apply_operator: engine not finalized");
@@ -707,9 +750,9 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
                         const double* sigma_inv) {
     if (!e || !index || !data || !invcov || (nG > 0 && (!mu || !sigma_inv))) return fail("eftb_set_likelihood: null argument");
     if (nG < 0 || nG > MARG_MAXG) return fail("eftb_set_likelihood: nG=%d outside [0, %d]", nG, MARG_MAXG);  // nG = 0: plain -chi2 / 2
-    const size_t lds = ((size_t)(nG + 1) * (NROW + 2 * (size_t)ndata + nG + 1)) * sizeof(double);
+    const size_t lds = ((size_t)(nG + 1) * (e->ntr * NROW + 2 * (size_t)ndata + nG + 1)) * sizeof(double);
     if (ndata < 1 || lds > 160 * 1024) return fail("eftb_set_likelihood: ndata=%d does not fit the 160 KB LDS working set with nG=%d", ndata, nG);
-    const int npts = e->cur_nl * e->cur_nx;
+    const int npts = e->ntr * e->cur_nl * e->cur_nx;  // the walker's ntr entries are addressed as one block of ntr * nl multipoles
     for (int a = 0; a < ndata; ++a)
         if (index[a] < 0 || index[a] >= npts)
             return fail("eftb_set_likelihood: index[%d]=%d outside the current template block [%d][24][%d]", a, index[a], e->cur_nl, e->cur_nx);
@@ -829,7 +872,7 @@ static int upload_and_launch(eftb_engine* e, const char* who, int B, const doubl
     int mask = EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_REGROUP | extra_mask;
     if (c.with_resum) mask |= EFTB_S_CF | EFTB_S_RESUM;
     if (c.with_ap) mask |= EFTB_S_AP;
-    if (e->pipeline_op >= 0) mask |= EFTB_S_PROJECT;
+    if (e->pipeline_op >= 0 || !e->tracer_ops.empty()) mask |= EFTB_S_PROJECT;
     return launch_stages(e, mask, B);
 }
 
@@ -863,10 +906,11 @@ int eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double*
     HIPCHK(hipMemcpy2DAsync(e->buf[EFTB_B_GROWS], (size_t)MARG_NG1 * NROW * sizeof(double), rows, (size_t)ng1 * NROW * sizeof(double),
                             (size_t)ng1 * NROW * sizeof(double), B, hipMemcpyHostToDevice, st));
     if (int rc = upload_and_launch(e, "eftb_eval_logp_batch", B, Pin, f, DA, H, EFTB_S_LOGP)) return rc;
-    e->like_host.resize((size_t)B * MARG_OUT);
-    HIPCHK(hipMemcpyAsync(e->like_host.data(), e->buf[EFTB_B_LOGP], (size_t)B * MARG_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
+    const int nw = B / e->ntr;  // one result per likelihood point
+    e->like_host.resize((size_t)nw * MARG_OUT);
+    HIPCHK(hipMemcpyAsync(e->like_host.data(), e->buf[EFTB_B_LOGP], (size_t)nw * MARG_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int w = 0; w < B; ++w) {
+    for (int w = 0; w < nw; ++w) {
         const double* o = e->like_host.data() + (size_t)w * MARG_OUT;
         logp[w] = o[0];
         if (fullchi2) fullchi2[w] = o[1];

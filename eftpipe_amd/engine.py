@@ -30,6 +30,8 @@ class Engine:
         self.dims = (cfg.Nl, self.Nk)      # shape (nl, nx) of the template block after the last stage run
         self._op_shapes = []               # (nl_out, nx_out, nl_in, nx_in) per registered operator
         self._pipeline_op = -1
+        self.ntracers = 1
+        self._tracer_ops = []
         c = L.Config()
         c.device, c.Nl, c.Nk, c.Nkin, c.max_batch = device, cfg.Nl, self.Nk, self.Nkin, self.max_batch
         c.with_resum, c.with_ap, c.ap_stochastic = int(cfg.with_resum), int(cfg.with_ap), int(cfg.APst)
@@ -181,8 +183,23 @@ class Engine:
         L.check(self.lib.eftb_set_template_dims(self._h, nl, nx))
         self.dims = (nl, nx)
 
+    def set_tracers(self, ntr, operators=None):
+        """ntr tracers per likelihood point: batch entry = walker * ntr + tracer (EFTLike(tracers=[...]), reference
+        likelihood.py:483-549).  operators: one registered operator id per tracer for the PROJECT stage (same shape; pad a
+        chained output with zero multipoles).  Resets any likelihood set before."""
+        L.check(self.lib.eftb_set_tracers(self._h, int(ntr)))
+        self.ntracers, self._tracer_ops = int(ntr), []
+        if operators is not None:
+            if len(operators) != ntr:
+                raise ValueError("one operator per tracer")
+            for t, op in enumerate(operators):
+                L.check(self.lib.eftb_set_pipeline_operator_tracer(self._h, t, int(op)))
+            self._tracer_ops = [int(op) for op in operators]
+
     def out_dims(self):
         """(nl, nx) of the templates / P_l that a full pipeline run produces."""
+        if self._tracer_ops:
+            return self._op_shapes[self._tracer_ops[0]][:2]
         return self._op_shapes[self._pipeline_op][:2] if self._pipeline_op >= 0 else (self.Nl, self.Nk)
 
     def full_mask(self, reduce=False):
@@ -191,7 +208,7 @@ class Engine:
             m |= L.S_CF | L.S_RESUM
         if self.cfg.with_ap:
             m |= L.S_AP
-        if self._pipeline_op >= 0:
+        if self._pipeline_op >= 0 or self._tracer_ops:
             m |= L.S_PROJECT
         if reduce:
             m |= L.S_REDUCE

@@ -14,16 +14,18 @@ import numpy as np
 from . import _lib as L
 from .parambasis import gaussian_params, gaussian_rows
 
-MAXG = 16
+MAXG = 24
 
 
-def data_index(ls, masks, nx):
+def data_index(ls, masks, nx, tracer=0, nl=None):
     """Flat indices l * nx + x of the data vector in the order of reference likelihood.py:167-195 (``flatten``):
-    multipoles ``ls`` (even), each restricted to ``masks[ell]`` (a slice, or None for all bins)."""
+    multipoles ``ls`` (even), each restricted to ``masks[ell]`` (a slice, or None for all bins).  With several tracers per
+    likelihood point (``Engine.set_tracers``) the block of tracer t starts at multipole t * nl: pass ``tracer`` and ``nl`` (the
+    multipoles per entry of the template block) and concatenate the tracers' indices in data-vector order."""
     out = []
     for ell in ls:
         sl = masks[ell] if masks and masks.get(ell) is not None else slice(0, nx)
-        out.append((ell // 2) * nx + np.arange(nx)[sl])
+        out.append((tracer * (nl or 0) + ell // 2) * nx + np.arange(nx)[sl])
     return np.concatenate(out).astype(np.int32)
 
 
@@ -58,7 +60,9 @@ class MarginalLikelihood:
 
     def logp(self, rows, return_best=False, rows_nnlo=None):
         """rows [B, nG + 1, 24] (``parambasis.gaussian_rows`` per walker) -> ln P_marg [B]
-        (+ full chi2 [B] and best-fit Gaussian parameters [B, nG]).  Raises like the reference when det F2 <= 0."""
+        (+ full chi2 [B] and best-fit Gaussian parameters [B, nG]).  Raises like the reference when det F2 <= 0.
+        With ``Engine.set_tracers(ntr)``: B = walkers * ntr entries (each tracer its own rows, zero rows for parameters that do
+        not act on it) -> results per walker [B / ntr]."""
         rows = np.ascontiguousarray(rows, dtype=np.float64)
         B = rows.shape[0]
         if rows.shape[1:] != (self.nG + 1, 24):
@@ -74,7 +78,7 @@ class MarginalLikelihood:
         elif rows_nnlo is not None:
             raise ValueError("rows_nnlo needs an engine built with with_NNLO")
         self.eng.run(L.S_LOGP, B)
-        out = self.eng.get("LOGP", (B, 2 + MAXG))
+        out = self.eng.get("LOGP", (B // self.eng.ntracers, 2 + MAXG))
         if np.any(np.isnan(out[:, 0])):
             raise RuntimeError("det of F2ij <= 0")
         if return_best:
@@ -90,7 +94,8 @@ class MarginalLikelihood:
         rows = np.ascontiguousarray(rows, dtype=np.float64)
         if rows.shape != (B, self.nG + 1, 24):
             raise ValueError(f"rows must be [{B}, {self.nG + 1}, 24]")
-        logp, full, best = np.empty(B), np.empty(B), np.empty((B, self.nG))
+        nw = B // self.eng.ntracers
+        logp, full, best = np.empty(nw), np.empty(nw), np.empty((nw, self.nG))
         L.check(self.eng.lib.eftb_eval_logp_batch(self.eng._h, B, L.dptr(Pin), L.dptr(f), L.dptr(DA), L.dptr(H), L.dptr(rows),
                                                   L.dptr(logp), L.dptr(full), L.dptr(best)))
         if np.any(np.isnan(logp)):

@@ -86,14 +86,14 @@ enum eftb_buffer {
     EFTB_B_BIAS,      /* [B][24]              b11(3), bct(6), bloop(12), bst(3)   parambasis.py:69-126 */
     EFTB_B_PLK,       /* [B][nl][nx]          reduce_Plk(...).sum() without Picc  parambasis.py:128-136 */
     EFTB_B_COEF,      /* [B][2][129]          FFTLog coefficients (independent half, re/im) */
-    EFTB_B_GROWS,     /* [B][17][24]          coefficient rows of P_NG (row 0) and dP/d(gaussian parameter) (rows 1..nG)   parambasis.py:249-316 */
-    EFTB_B_LOGP,      /* [B][18]              marginalised ln P, full chi2 at the best fit, best-fit gaussian parameters  marginal.py:79-140 */
+    EFTB_B_GROWS,     /* [B][25][24]          coefficient rows of P_NG (row 0) and dP/d(gaussian parameter) (rows 1..nG)   parambasis.py:249-316 */
+    EFTB_B_LOGP,      /* [B][26]              marginalised ln P, full chi2 at the best fit, best-fit gaussian parameters  marginal.py:79-140 */
     /* with_nnlo only.  The NNLO counter-terms travel as a second template block whose Pctl slots (rows 3-5) hold PctNNLOl and
      * whose other rows are zero: every linear stage (Resum with Q[1] and lctNNLO, AP, the operators) runs on it unchanged. */
     EFTB_B_CCTN,      /* [B][Nl][80]          Bird.CctNNLO                        pybird.py:1098-1101 */
     EFTB_B_TEMPLN,    /* [B][nl][24][nx]      rows 3-5 = Bird.PctNNLOl            pybird.py:741-748 */
     EFTB_B_BIASN,     /* [B][3]               bctNNLO                             parambasis.py:96-106 */
-    EFTB_B_GROWSN,    /* [B][17][3]           NNLO part of the EFTB_B_GROWS rows: coefficients of PctNNLOl in P_NG (row 0) and in
+    EFTB_B_GROWSN,    /* [B][25][3]           NNLO part of the EFTB_B_GROWS rows: coefficients of PctNNLOl in P_NG (row 0) and in
                                               dP/d(cr4, cr6 | ctilde) (parambasis.py:303-307, 429-435); zero-initialised */
     EFTB_B_COUNT
 };
@@ -133,7 +133,7 @@ int  eftb_set_option(eftb_engine* e, int option, int value);
  * EFTLike.PNG / PG (likelihood.py:483-549: flatten the multipoles over the masked k bins) and
  * Marginalizable.marginalized_logp (marginal.py:79-140).  index[a] = l * nx + x selects data point a from the current
  * template block [nl][24][nx] (after the pipeline operator, if any); data[ndata]; invcov[ndata][ndata] symmetric;
- * 0 <= nG <= 16 marginalised parameters (nG = 0: the plain Gaussian likelihood -chi2 / 2 of row 0) with Gaussian prior N(mu[i], sigma_i^2), sigma_inv[i] = 1 / sigma_i^2 (all zero: flat).
+ * 0 <= nG <= 24 marginalised parameters (nG = 0: the plain Gaussian likelihood -chi2 / 2 of row 0) with Gaussian prior N(mu[i], sigma_i^2), sigma_inv[i] = 1 / sigma_i^2 (all zero: flat).
  * Per walker the caller puts the coefficient rows EFTB_B_GROWS (eftpipe_amd.parambasis.gaussian_rows) and reads
  * EFTB_B_LOGP after eftb_run(..., EFTB_S_LOGP, B). */
 int  eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov,
@@ -149,6 +149,17 @@ int  eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx
  * Window(window_st=False) (window.py:412-415) and FiberCollision(fiberst=False) (pybird.py:1788-1797) leave Pstl alone while
  * binning / chained still act on it.  st_op_id = -1 restores one matrix for all rows. */
 int  eftb_set_operator_stochastic(eftb_engine* e, int op_id, int st_op_id);
+/* Several tracers per likelihood point (EFTLike(tracers=[LRG, ELG, X]): reference likelihood.py:483-549, cfg 3 of BASELINE).
+ * The batch then holds ntr consecutive entries per walker (entry = walker * ntr + tracer), each with its own P_lin, f, DA, H
+ * (for a per-tracer AP fiducial pass DA * DA_fid_engine / DA_fid_tracer and H * H_fid_engine / H_fid_tracer) and bias rows.
+ *  - eftb_set_pipeline_operator_tracer: the PROJECT stage uses operator op_id for the entries of `tracer` (window / fibre /
+ *    binning / chained differ per tracer); all operators must share one shape -- pad a chained output with zero multipoles;
+ *  - the LOGP stage treats the ntr entries of a walker as ONE block of ntr * nl multipoles: index[a] = (tracer * nl + l) * nx + x,
+ *    rows (EFTB_B_GROWS) per entry with zero rows for the parameters that do not act on that tracer, results per walker
+ *    (EFTB_B_LOGP [B / ntr][26], eftb_eval_logp_batch outputs [B / ntr]).
+ * eftb_set_tracers resets the per-tracer operators and the likelihood; call it first. */
+int  eftb_set_tracers(eftb_engine* e, int ntr);
+int  eftb_set_pipeline_operator_tracer(eftb_engine* e, int tracer, int op_id);
 /* Apply to the current template block of cosmologies [0, B); the block takes the operator's output shape. */
 int  eftb_apply_operator(eftb_engine* e, int op_id, int B);
 /* Operator run by the EFTB_S_PROJECT stage of eftb_run / eftb_eval_batch (-1 = none). */
@@ -178,7 +189,7 @@ int  eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, 
  * (likelihood.py:483-549) and Marginalizable.marginalized_logp (marginal.py:79-140).  Host inputs in, one marginalised
  * log-posterior per walker out; nothing else crosses PCIe.  Needs eftb_set_likelihood (and the pipeline operator that
  * brings the templates to the data's shape).  rows is PACKED [B][nG+1][24] (eftpipe_amd.parambasis.gaussian_rows);
- * logp [B] (NaN where det F2 <= 0: the reference raises there); fullchi2 [B] and best [B][nG] may be NULL.
+ * logp [B / ntr] (NaN where det F2 <= 0: the reference raises there); fullchi2 [B / ntr] and best [B / ntr][nG] may be NULL.
  * With with_nnlo the NNLO part of the rows is whatever EFTB_B_GROWSN holds (eftb_put it beforehand; zero-initialised). */
 int  eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H,
                           const double* rows, double* logp, double* fullchi2, double* best);

@@ -317,3 +317,84 @@ def test_window_matrix_on_device(golden):
         for n in NAMES:
             assert relerr(getattr(bird, n), g[tag + "wm_" + n]) < TOL, (st, n)
         assert bird.Picc.shape == (2, m.shape[2])
+
+
+def test_three_tracers_per_likelihood_point(golden):
+    """BASELINE cfg 3 / EFTLike(tracers=[LRG, ELG, X]) (reference likelihood.py:483-549): three entries per walker, each with its own
+    projection operator (ELG chained, X without window), joint data vector and covariance, 17 jointly marginalised parameters."""
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index
+    from eftpipe_amd.parambasis import gaussian_rows
+    from eftpipe_amd.tables import EngineConfig
+    from oracle import marginal as M
+
+    g = golden("caseC")
+    k, nb = g["k"], len(g["kout"])
+    tab = np.load(WIN)
+    Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+    Wfold, _ = TB.window_fold(k, Wal, p)
+    Bm, _, _, _ = TB.binning_operator(k, g["kout"])
+    opE = np.zeros((3, 3, nb, k.size))
+    opE[:2] = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm, chained=True)  # chained: 2 multipoles, padded with a zero third
+    ops_host = [TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm), opE, TB.compose_operator(3, k.size, binning=Bm)]
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, APst=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=6)
+    ops = [eng.add_operator(o) for o in ops_host]
+    nW, ntr = 2, 3
+    f0, DA0, H0 = float(g["f"]), float(g["DA"]), float(g["H"])
+    Pin = np.stack([g["Pin"] * (1.0 + 0.04 * w) * (1.0 - 0.1 * t) for w in range(nW) for t in range(ntr)])
+    f = np.array([f0 * (1.0 + 0.02 * t) for w in range(nW) for t in range(ntr)])
+    DA = np.array([DA0 * (1.0 + 0.01 * t + 0.005 * w) for w in range(nW) for t in range(ntr)])
+    H = np.array([H0 * (1.0 - 0.01 * t) for w in range(nW) for t in range(ntr)])
+    # reference for the templates: the same entries through one operator at a time
+    want_t = np.empty((nW * ntr, 3, 24, nb))
+    for t in range(ntr):
+        eng.set_tracers(1)
+        eng.set_pipeline_operator(ops[t])
+        want_t[t::ntr] = eng.eval_batch(Pin[t::ntr], f[t::ntr], DA[t::ntr], H[t::ntr])
+    eng.set_pipeline_operator(-1)
+    eng.set_tracers(ntr, ops)
+    templ = eng.eval_batch(Pin, f, DA, H)
+    assert templ.shape == (nW * ntr, 3, 24, nb) and relerr(templ.reshape(-1, nb), want_t.reshape(-1, nb)) < 1e-13
+    assert np.all(templ[1::ntr, 2] == 0.0)  # the padded multipole of the chained tracer
+    # joint likelihood: parameters 0-6 LRG, 7-13 ELG (b3 cct cr1 cr2 ce0 cemono cequad), 14-16 the cross spectrum's stochastic terms
+    ngL, ngE = (2.1, 0.5, 0.3), (1.3, -0.2, 0.6)
+    nG = 17
+    rows = np.zeros((nW * ntr, nG + 1, 24))
+    for w in range(nW):
+        eL, eE, eX = w * ntr, w * ntr + 1, w * ntr + 2
+        rL = gaussian_rows(f[eL], ngL, None, 0.7, 0.25, 4.5e-5)
+        rE = gaussian_rows(f[eE], ngE, None, 0.7, 0.25, 2.3e-4)
+        rX = gaussian_rows(f[eX], ngL, ngE, 0.7, 0.25, 4.5e-5, 0.6, 0.3, 2.3e-4)  # A_(b3 cct cr1 cr2), B_(...), X_(ce0 cemono cequad)
+        rows[eL, 0], rows[eL, 1:8] = rL[0], rL[1:]
+        rows[eE, 0], rows[eE, 8:15] = rE[0], rE[1:]
+        rows[eX, 0] = rX[0]
+        rows[eX, 1:5], rows[eX, 8:12], rows[eX, 15:18] = rX[1:5], rX[5:9], rX[9:12]
+    index = np.concatenate([data_index([0, 2, 4], {0: slice(0, 16), 2: slice(2, 14), 4: slice(1, 9)}, nb, tracer=0, nl=3),
+                            data_index([0, 2], {0: slice(1, 15), 2: slice(3, 12)}, nb, tracer=1, nl=3),
+                            data_index([0, 2, 4], {0: slice(0, 12), 2: slice(0, 12), 4: slice(4, 8)}, nb, tracer=2, nl=3)])
+    V = []
+    for w in range(nW):
+        blocks = [np.einsum("gr,lrx->glx", rows[w * ntr + t], templ[w * ntr + t]) for t in range(ntr)]
+        V.append(np.concatenate(blocks, axis=1).reshape(nG + 1, -1)[:, index])
+    rng = np.random.default_rng(4)
+    nd = index.size
+    sig = 0.04 * np.abs(V[0][0]) + 20.0
+    D = V[0][0] + sig * rng.normal(size=nd)
+    A = rng.normal(size=(nd, nd)) * 0.03
+    C = np.linalg.inv(np.diag(sig) @ (np.eye(nd) + A @ A.T) @ np.diag(sig))
+    C = 0.5 * (C + C.T)
+    loc, scale = rng.normal(scale=0.2, size=nG), rng.uniform(1.0, 4.0, size=nG)
+    like = MarginalLikelihood(eng, index, D, C, loc, scale)
+    logp, full, best = like.logp(rows, return_best=True)
+    assert logp.shape == (nW,) and best.shape == (nW, nG)
+    for w in range(nW):
+        ww = M.marginalized_logp(V[w][1:], V[w][0], D, C, loc, scale, return_best=True)
+        assert np.isclose(logp[w], ww[0], rtol=1e-10) and np.isclose(full[w], ww[1], rtol=1e-9), w
+        assert relerr(best[w][None], ww[2][None]) < 1e-7, w
+    # theory + likelihood in one call for the grouped batch
+    lp2 = like.eval_logp(Pin, f, DA, H, rows)
+    assert lp2.shape == (nW,) and np.array_equal(lp2, logp)
+    with pytest.raises(Exception):
+        eng.run(eng.full_mask(), 5)  # not a multiple of the three tracers
+    eng.close()
