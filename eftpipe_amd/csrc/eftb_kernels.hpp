@@ -401,6 +401,64 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmDesc d) {
             }
 }
 
+// Narrow outputs (ncols <= 128: templates projected onto a few dozen data bins): gemm_rows_kernel would run on a handful of
+// workgroups, each walking the whole K serially.  Here a workgroup owns 16 rows, its four waves take a quarter of K each (all
+// column tiles), and the quarters are added through LDS in a fixed order -- 4x the workgroups, 1/4 of the serial depth,
+// bit-reproducible.  Same descriptor and addressing as gemm_rows_kernel.
+constexpr int GN_MAXT = 8;  // column tiles of 16
+__global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmDesc d) {
+    __shared__ double red[3 * GN_MAXT * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 16, nt = (d.ncols + 15) / 16;
+    const int K = d.nseg * d.kseg, kq = ((K + 15) / 16) * 4;  // K quarter, a multiple of 4
+    const int k0 = wave * kq, k1 = min(K, k0 + kq);
+    const int grow = row0 + r;
+    const bool rlive = grow < d.rows;
+    const double* arow = d.A + (long long)((rlive ? grow : 0) / d.rows_per_group) * d.a_group + (long long)((rlive ? grow : 0) % d.rows_per_group) * d.a_row;
+    v4d acc[GN_MAXT];
+#pragma unroll
+    for (int j = 0; j < GN_MAXT; ++j) acc[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int kb = k0; kb < k1; kb += 16) {  // four k-steps per trip: their loads are in flight together
+        double a[4], bv[4][GN_MAXT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = kb + 4 * u + g;
+            const bool klive = kk < k1;
+            const int seg = klive ? kk / d.kseg : 0, kin = klive ? kk % d.kseg : 0;
+            a[u] = (rlive && klive) ? arow[(long long)seg * d.a_seg + kin] : 0.0;
+            const double* bp = d.B + (long long)(klive ? kk : 0) * d.ldb + r;
+#pragma unroll
+            for (int j = 0; j < GN_MAXT; ++j) bv[u][j] = (j < nt && klive && 16 * j + r < d.ncols) ? bp[16 * j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < GN_MAXT; ++j)
+                if (j < nt) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv[u][j], acc[j], 0, 0, 0);  // nt: workgroup-uniform
+    }
+    if (wave > 0)
+#pragma unroll
+        for (int j = 0; j < GN_MAXT; ++j)
+            if (j < nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[(((wave - 1) * GN_MAXT + j) * 4 + q) * 64 + lane] = acc[j][q];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int j = 0; j < GN_MAXT; ++j)
+        if (j < nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = ((acc[j][q] + red[((0 * GN_MAXT + j) * 4 + q) * 64 + lane]) + red[((1 * GN_MAXT + j) * 4 + q) * 64 + lane]) +
+                                 red[((2 * GN_MAXT + j) * 4 + q) * 64 + lane];
+                const int orow = row0 + g + 4 * q, col = 16 * j + r;
+                if (orow < d.rows && col < d.ncols)
+                    d.C[(long long)(orow / d.rows_per_group) * d.c_group + (long long)(orow % d.rows_per_group) * d.c_row +
+                        (long long)(col / d.cols_per_group) * d.c_colgroup + (col % d.cols_per_group)] = v;
+            }
+}
+
 // ------------------------------------------------------------------------------------------------
 // regroup: Bird.setPsCfl -- multipole weights, 28+10 -> 12 bias groups with powers of f, shot-noise
 // subtraction, stochastic templates (reference pybird.py:737-866).  grp[b] = (group, power of f).
@@ -1235,7 +1293,7 @@ __global__ __launch_bounds__(256) void reduce_nnlo_kernel(int Nx, int Nl, const 
 
 // ------------------------------------------------------------------------------------------------
 // Analytically marginalised log-posterior (reference marginal.py:79-203, likelihood.py:483-549).
-// One workgroup = one walker.  With the coefficient rows R[g][24] (g = 0: the model at zero Gaussian parameters, g >= 1:
+// Three launches (marg_build_kernel, one GEMM for all walkers, marg_solve_kernel).  With the coefficient rows R[g][24] (g = 0: the model at zero Gaussian parameters, g >= 1:
 // its derivative with respect to Gaussian parameter g; parambasis.gaussian_rows) and the data-vector index map
 //     V[g][a] = sum_r R[g][r] T[l(a)][r][x(a)]          (V[0] -= data: the residual),
 //     U = C^-1 V,   G = V U^T   ((nG+1)^2 numbers),
@@ -1249,19 +1307,16 @@ __global__ __launch_bounds__(256) void reduce_nnlo_kernel(int Nx, int Nl, const 
 // its own coefficient rows (its bias values; zero rows for the parameters of the other tracers).
 constexpr int MARG_MAXG = 24, MARG_NG1 = MARG_MAXG + 1, MARG_OUT = 2 + MARG_MAXG;
 
-__global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ntr, int ndata, int nG, int jeffreys, const int* __restrict__ index,
-                                                        const double* __restrict__ data, const double* __restrict__ invcov,
-                                                        const double* __restrict__ mu, const double* __restrict__ sinv,
-                                                        const double* __restrict__ rows, const double* __restrict__ T,
-                                                        const double* __restrict__ rowsn, const double* __restrict__ TN,
-                                                        double* __restrict__ out) {
+// Stage 1 of 3: V[w][g][a] (packed [walkers][nG + 1][ndata]) from the template block(s) and the coefficient rows.
+__global__ __launch_bounds__(256) void marg_build_kernel(int nl, int nx, int ntr, int ndata, int nG, const int* __restrict__ index,
+                                                         const double* __restrict__ data, const double* __restrict__ rows,
+                                                         const double* __restrict__ T, const double* __restrict__ rowsn,
+                                                         const double* __restrict__ TN, double* __restrict__ Vout) {
     // rowsn [B][MARG_NG1][3], TN: the NNLO block (with_nnlo), contributing sum_j rowsn[g][j] TN[l][3 + j][x]; both null otherwise
     extern __shared__ double sm[];
     const int ng1 = nG + 1, w = blockIdx.x, tid = threadIdx.x;
     double* R = sm;                        // [ntr][ng1][24]
-    double* V = R + ntr * ng1 * NROW;      // [ng1][ndata]
-    double* U = V + (size_t)ng1 * ndata;   // [ng1][ndata]
-    double* G = U + (size_t)ng1 * ndata;   // [ng1][ng1]
+    double* V = Vout + (size_t)w * ng1 * ndata;
     for (int e = tid; e < ntr * ng1 * NROW; e += 256)
         R[e] = rows[((size_t)w * ntr + e / (ng1 * NROW)) * MARG_NG1 * NROW + e % (ng1 * NROW)];
     __syncthreads();
@@ -1287,22 +1342,17 @@ __global__ __launch_bounds__(256) void marg_logp_kernel(int nl, int nx, int ntr,
             V[(size_t)g * ndata + a] = s0 + s1 - (g == 0 ? data[a] : 0.0);
         }
     }
-    __syncthreads();
-    for (int b = tid; b < ndata; b += 256) {  // U[g][b] = sum_a C^-1[a][b] V[g][a]  (symmetric: column reads are coalesced)
-        double u[MARG_NG1];
-#pragma unroll
-        for (int g = 0; g < MARG_NG1; ++g) u[g] = 0.0;
-        for (int a = 0; a < ndata; ++a) {
-            const double c = invcov[(size_t)a * ndata + b];
-#pragma unroll
-            for (int g = 0; g < MARG_NG1; ++g)
-                if (g < ng1) u[g] = fma(c, V[(size_t)g * ndata + a], u[g]);
-        }
-#pragma unroll
-        for (int g = 0; g < MARG_NG1; ++g)
-            if (g < ng1) U[(size_t)g * ndata + b] = u[g];
-    }
-    __syncthreads();
+}
+
+// Stage 2 is U = V C^-1 for all walkers at once on the matrix cores (gemm_rows_kernel; C^-1 is symmetric).
+// Stage 3 of 3: G = V U^T per walker, then the small dense algebra.
+__global__ __launch_bounds__(256) void marg_solve_kernel(int ndata, int nG, int jeffreys, const double* __restrict__ mu,
+                                                         const double* __restrict__ sinv, const double* __restrict__ Vall,
+                                                         const double* __restrict__ Uall, double* __restrict__ out) {
+    __shared__ double G[MARG_NG1 * MARG_NG1];
+    const int ng1 = nG + 1, w = blockIdx.x, tid = threadIdx.x;
+    const double* V = Vall + (size_t)w * ng1 * ndata;
+    const double* U = Uall + (size_t)w * ng1 * ndata;
     for (int e = tid; e < ng1 * ng1; e += 256) {
         const int i = e / ng1, j = e % ng1;
         double s[4] = {0.0, 0.0, 0.0, 0.0};

@@ -68,6 +68,7 @@ struct eftb_engine {
     std::vector<double> like_host;  // eftb_eval_logp_batch: D2H landing block [B][MARG_OUT]
     int* like_index = nullptr;
     double *like_data = nullptr, *like_invcov = nullptr, *like_mu = nullptr, *like_sinv = nullptr;
+    double *like_V = nullptr, *like_U = nullptr;  // LOGP scratch: V and U = V C^-1, packed [walkers][nG + 1][ndata]
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
@@ -261,7 +262,10 @@ static int launch_operator(eftb_engine* e, int id, int B, int t0 = 0, int tstrid
         g.C = e->Talt + (size_t)t0 * bout + (size_t)r0 * o.nx_out; g.c_group = bout * tstride; g.c_row = o.nx_out;
         g.c_colgroup = (long long)NROW * o.nx_out;
         g.cols_per_group = o.nx_out;
-        hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
+        if (g.ncols <= 16 * GN_MAXT && g.rows <= 64 * 1024)  // few output columns: K split over the waves, 16-row workgroups
+            hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16), dim3(256), 0, e->stream, g);
+        else
+            hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
     };
     if (o.st_op < 0) launch(o, 0, NROW);
     else {
@@ -480,11 +484,21 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     if (mask & EFTB_S_LOGP) {
         if (!e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
         if (B % e->ntr) return fail("eftb_run: batch %d is not a multiple of the %d tracers per likelihood point", B, e->ntr);
-        const size_t lds = ((size_t)(e->like_nG + 1) * (e->ntr * NROW + 2 * e->like_ndata + e->like_nG + 1)) * sizeof(double);
-        if (lds > 160 * 1024) return fail("eftb_run: stage LOGP needs %zu bytes of LDS with %d tracers", lds, e->ntr);
-        hipLaunchKernelGGL(marg_logp_kernel, dim3(B / e->ntr), dim3(256), lds, st, e->cur_nl, e->cur_nx, e->ntr, e->like_ndata, e->like_nG, e->jeffreys, e->like_index,
-                           e->like_data, e->like_invcov, e->like_mu, e->like_sinv, b[EFTB_B_GROWS], b[EFTB_B_TEMPL],
-                           c.with_nnlo ? b[EFTB_B_GROWSN] : nullptr, c.with_nnlo ? b[EFTB_B_TEMPLN] : nullptr, b[EFTB_B_LOGP]);
+        const int nw = B / e->ntr, ng1 = e->like_nG + 1, nd = e->like_ndata;
+        const size_t lds = (size_t)e->ntr * ng1 * NROW * sizeof(double);
+        if (lds > 64 * 1024) return fail("eftb_run: stage LOGP: %d tracers x %d rows do not fit the coefficient block in LDS", e->ntr, ng1);
+        // V (residual and derivatives on the data vector) per walker, U = V C^-1 for all walkers in one matrix-core GEMM, then the
+        // (nG + 1)^2 products and the small dense solve per walker
+        hipLaunchKernelGGL(marg_build_kernel, dim3(nw), dim3(256), lds, st, e->cur_nl, e->cur_nx, e->ntr, nd, e->like_nG, e->like_index, e->like_data,
+                           b[EFTB_B_GROWS], b[EFTB_B_TEMPL], c.with_nnlo ? b[EFTB_B_GROWSN] : nullptr, c.with_nnlo ? b[EFTB_B_TEMPLN] : nullptr,
+                           e->like_V);
+        GemmDesc gd{};
+        gd.A = e->like_V; gd.a_group = 0; gd.a_row = nd; gd.a_seg = 0; gd.rows = nw * ng1; gd.rows_per_group = nw * ng1; gd.nseg = 1; gd.kseg = nd;
+        gd.B = e->like_invcov; gd.ldb = nd; gd.ncols = nd;
+        gd.C = e->like_U; gd.c_group = 0; gd.c_row = nd; gd.c_colgroup = 0; gd.cols_per_group = nd;
+        hipLaunchKernelGGL(gemm_rows_kernel, dim3((gd.rows + 63) / 64, (gd.ncols + 255) / 256), dim3(256), GEMM_LDS, st, gd);
+        hipLaunchKernelGGL(marg_solve_kernel, dim3(nw), dim3(256), 0, st, nd, e->like_nG, e->jeffreys, e->like_mu, e->like_sinv, e->like_V, e->like_U,
+                           b[EFTB_B_LOGP]);
     }
     if (mask & EFTB_S_REDUCE)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],
@@ -643,7 +657,6 @@ int eftb_finalize(eftb_engine* e) {
     }
     // opt in to the large dynamic LDS tiles
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&marg_logp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define AP_LDS(NLV, NRV, RSV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_apply_kernel<NLV, NRV, RSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, 21, 7); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3); AP_LDS(3, NROW, 7);
     AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
@@ -750,8 +763,7 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
                         const double* sigma_inv) {
     if (!e || !index || !data || !invcov || (nG > 0 && (!mu || !sigma_inv))) return fail("eftb_set_likelihood: null argument");
     if (nG < 0 || nG > MARG_MAXG) return fail("eftb_set_likelihood: nG=%d outside [0, %d]", nG, MARG_MAXG);  // nG = 0: plain -chi2 / 2
-    const size_t lds = ((size_t)(nG + 1) * (e->ntr * NROW + 2 * (size_t)ndata + nG + 1)) * sizeof(double);
-    if (ndata < 1 || lds > 160 * 1024) return fail("eftb_set_likelihood: ndata=%d does not fit the 160 KB LDS working set with nG=%d", ndata, nG);
+    if (ndata < 1) return fail("eftb_set_likelihood: ndata=%d", ndata);
     const int npts = e->ntr * e->cur_nl * e->cur_nx;  // the walker's ntr entries are addressed as one block of ntr * nl multipoles
     for (int a = 0; a < ndata; ++a)
         if (index[a] < 0 || index[a] >= npts)
@@ -763,7 +775,13 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
         }
     HIPCHK(hipSetDevice(e->c.device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
+    e->like_index = nullptr; e->like_data = e->like_invcov = e->like_mu = e->like_sinv = e->like_V = e->like_U = nullptr;
+    {
+        const size_t vb = (size_t)(e->c.max_batch / e->ntr + 1) * (nG + 1) * ndata * sizeof(double);
+        HIPCHK(hipMalloc(&e->like_V, vb));
+        HIPCHK(hipMalloc(&e->like_U, vb));
+    }
     HIPCHK(hipMalloc(&e->like_index, ndata * sizeof(int)));
     HIPCHK(hipMalloc(&e->like_data, ndata * sizeof(double)));
     HIPCHK(hipMalloc(&e->like_invcov, (size_t)ndata * ndata * sizeof(double)));
@@ -790,7 +808,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& p : e->buf) if (p) (void)hipFree(p);
     for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
-    for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered}) if (ev) (void)hipEventDestroy(ev);
     if (e->side) (void)hipStreamDestroy(e->side);
