@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmDesc d) {
             }
 }
 
-// Narrow outputs (ncols <= 128: templates projected onto a few dozen data bins): gemm_rows_kernel would run on a handful of
+// Narrow outputs (templates projected onto a few dozen data bins; blockIdx.y walks column groups of 128 for wider ones): gemm_rows_kernel would run on a handful of
 // workgroups, each walking the whole K serially.  Here a workgroup owns 16 rows, its four waves take a quarter of K each (all
 // column tiles), and the quarters are added through LDS in a fixed order -- 4x the workgroups, 1/4 of the serial depth,
 // bit-reproducible.  Same descriptor and addressing as gemm_rows_kernel.
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmDesc d) {
     __shared__ double red[3 * GN_MAXT * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int row0 = blockIdx.x * 16, nt = (d.ncols + 15) / 16;
+    const int row0 = blockIdx.x * 16, c0 = blockIdx.y * 16 * GN_MAXT, nt = min(GN_MAXT, (d.ncols - c0 + 15) / 16);
     const int K = d.nseg * d.kseg, kq = ((K + 15) / 16) * 4;  // K quarter, a multiple of 4
     const int k0 = wave * kq, k1 = min(K, k0 + kq);
     const int grow = row0 + r;
@@ -427,9 +427,9 @@ __global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmDesc d) {
             const bool klive = kk < k1;
             const int seg = klive ? kk / d.kseg : 0, kin = klive ? kk % d.kseg : 0;
             a[u] = (rlive && klive) ? arow[(long long)seg * d.a_seg + kin] : 0.0;
-            const double* bp = d.B + (long long)(klive ? kk : 0) * d.ldb + r;
+            const double* bp = d.B + (long long)(klive ? kk : 0) * d.ldb + c0 + r;
 #pragma unroll
-            for (int j = 0; j < GN_MAXT; ++j) bv[u][j] = (j < nt && klive && 16 * j + r < d.ncols) ? bp[16 * j] : 0.0;
+            for (int j = 0; j < GN_MAXT; ++j) bv[u][j] = (j < nt && klive && c0 + 16 * j + r < d.ncols) ? bp[16 * j] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmDesc d) {
             for (int q = 0; q < 4; ++q) {
                 const double v = ((acc[j][q] + red[((0 * GN_MAXT + j) * 4 + q) * 64 + lane]) + red[((1 * GN_MAXT + j) * 4 + q) * 64 + lane]) +
                                  red[((2 * GN_MAXT + j) * 4 + q) * 64 + lane];
-                const int orow = row0 + g + 4 * q, col = 16 * j + r;
+                const int orow = row0 + g + 4 * q, col = c0 + 16 * j + r;
                 if (orow < d.rows && col < d.ncols)
                     d.C[(long long)(orow / d.rows_per_group) * d.c_group + (long long)(orow % d.rows_per_group) * d.c_row +
                         (long long)(col / d.cols_per_group) * d.c_colgroup + (col % d.cols_per_group)] = v;
@@ -1350,57 +1350,81 @@ __global__ __launch_bounds__(256) void marg_solve_kernel(int ndata, int nG, int 
                                                          const double* __restrict__ sinv, const double* __restrict__ Vall,
                                                          const double* __restrict__ Uall, double* __restrict__ out) {
     __shared__ double G[MARG_NG1 * MARG_NG1];
+    __shared__ double A[MARG_MAXG][MARG_MAXG + 1];
+    __shared__ double mrow[MARG_MAXG];
+    __shared__ int s_piv, s_sign;
+    __shared__ double s_logdet;
     const int ng1 = nG + 1, w = blockIdx.x, tid = threadIdx.x;
     const double* V = Vall + (size_t)w * ng1 * ndata;
     const double* U = Uall + (size_t)w * ng1 * ndata;
-    for (int e = tid; e < ng1 * ng1; e += 256) {
+    // G = V U^T: one wave-quarter (16 lanes) per entry, lanes stride the data index (coalesced), shuffle reduction in a fixed order
+    const int sub = tid & 15, grp = tid >> 4;
+    for (int e = grp; e < ng1 * ng1; e += 16) {
         const int i = e / ng1, j = e % ng1;
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-        int b = 0;
-        for (; b + 4 <= ndata; b += 4)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s[q] = fma(V[(size_t)i * ndata + b + q], U[(size_t)j * ndata + b + q], s[q]);
-        for (; b < ndata; ++b) s[0] = fma(V[(size_t)i * ndata + b], U[(size_t)j * ndata + b], s[0]);
-        G[e] = (s[0] + s[1]) + (s[2] + s[3]);
+        double s0 = 0.0;
+        for (int b = sub; b < ndata; b += 16) s0 = fma(V[(size_t)i * ndata + b], U[(size_t)j * ndata + b], s0);
+        s0 += __shfl_xor(s0, 8, 16);
+        s0 += __shfl_xor(s0, 4, 16);
+        s0 += __shfl_xor(s0, 2, 16);
+        s0 += __shfl_xor(s0, 1, 16);
+        if (sub == 0) G[e] = s0;
     }
     __syncthreads();
+    // F2 in LDS; LU with partial pivoting, as numpy's slogdet / solve (LAPACK getrf) in the reference: F2 may be ill-conditioned with a
+    // flat prior, where a Cholesky factorisation can lose positivity to rounding although det F2 > 0.  The trailing update of every
+    // step is spread over the workgroup.
+    for (int e = tid; e < nG * nG; e += 256) {
+        const int i = e / nG, j = e % nG;
+        A[i][j] = 0.5 * (G[(i + 1) * ng1 + j + 1] + G[(j + 1) * ng1 + i + 1]) + (i == j ? sinv[i] : 0.0);
+    }
     if (tid == 0) {
-        // LU with partial pivoting, as numpy's slogdet / solve (LAPACK getrf) in the reference: F2 may be ill-conditioned with a
-        // flat prior, where a Cholesky factorisation can lose positivity to rounding although det F2 > 0
-        double A[MARG_MAXG][MARG_MAXG], y[MARG_MAXG], F1[MARG_MAXG];
-        int piv[MARG_MAXG];
-        double logdet = 0.0, F0 = G[0];
-        int sign = 1;
-        for (int i = 0; i < nG; ++i) {
-            F1[i] = -G[(i + 1) * ng1] + sinv[i] * mu[i];
-            F0 = fma(mu[i] * sinv[i], mu[i], F0);
-            for (int j = 0; j < nG; ++j) A[i][j] = 0.5 * (G[(i + 1) * ng1 + j + 1] + G[(j + 1) * ng1 + i + 1]) + (i == j ? sinv[i] : 0.0);
-        }
-        for (int c = 0; c < nG; ++c) {
+        s_sign = 1;
+        s_logdet = 0.0;
+    }
+    __syncthreads();
+    __shared__ int piv[MARG_MAXG];
+    for (int c = 0; c < nG; ++c) {
+        if (tid == 0) {
             int p = c;
             for (int i = c + 1; i < nG; ++i)
                 if (fabs(A[i][c]) > fabs(A[p][c])) p = i;
             piv[c] = p;
-            if (p != c) {
-                sign = -sign;
-                for (int j = 0; j < nG; ++j) {
-                    const double t = A[c][j];
-                    A[c][j] = A[p][j];
-                    A[p][j] = t;
-                }
-            }
-            const double d = A[c][c];
-            if (d < 0.0) sign = -sign;
-            if (d == 0.0 || d != d) sign = 0;
-            logdet += log(fabs(d));
-            for (int i = c + 1; i < nG; ++i) {
-                const double m = A[i][c] / d;
-                A[i][c] = m;
-                for (int j = c + 1; j < nG; ++j) A[i][j] = fma(-m, A[c][j], A[i][j]);
-            }
+            s_piv = p;
         }
-        const bool ok = sign > 0;
-        logdet -= nG * 1.8378770664093453;  // ln(2 pi) per dimension: ln det(F2 / 2 pi)
+        __syncthreads();
+        const int p = s_piv;
+        if (p != c && tid < nG) {
+            const double t = A[c][tid];
+            A[c][tid] = A[p][tid];
+            A[p][tid] = t;
+        }
+        __syncthreads();
+        const double dpiv = A[c][c];
+        if (tid == 0) {
+            if (p != c) s_sign = -s_sign;
+            if (dpiv < 0.0) s_sign = -s_sign;
+            if (dpiv == 0.0 || dpiv != dpiv) s_sign = 0;
+            s_logdet += log(fabs(dpiv));
+        }
+        if (tid > c && tid < nG) mrow[tid] = A[tid][c] / dpiv;
+        __syncthreads();
+        const int n = nG - c - 1;
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = c + 1 + e / n, j = c + 1 + e % n;
+            A[i][j] = fma(-mrow[i], A[c][j], A[i][j]);
+        }
+        if (tid > c && tid < nG) A[tid][c] = mrow[tid];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double y[MARG_MAXG], F1[MARG_MAXG];
+        double F0 = G[0];
+        for (int i = 0; i < nG; ++i) {
+            F1[i] = -G[(i + 1) * ng1] + sinv[i] * mu[i];
+            F0 = fma(mu[i] * sinv[i], mu[i], F0);
+        }
+        const bool ok = s_sign > 0;
+        const double logdet = s_logdet - nG * 1.8378770664093453;  // ln(2 pi) per dimension: ln det(F2 / 2 pi)
         for (int i = 0; i < nG; ++i) y[i] = F1[i];
         for (int c = 0; c < nG; ++c) {  // apply the row exchanges, then L y = P F1, U b = y
             const double t = y[c];

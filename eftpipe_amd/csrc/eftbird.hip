@@ -262,8 +262,8 @@ static int launch_operator(eftb_engine* e, int id, int B, int t0 = 0, int tstrid
         g.C = e->Talt + (size_t)t0 * bout + (size_t)r0 * o.nx_out; g.c_group = bout * tstride; g.c_row = o.nx_out;
         g.c_colgroup = (long long)NROW * o.nx_out;
         g.cols_per_group = o.nx_out;
-        if (g.ncols <= 16 * GN_MAXT && g.rows <= 64 * 1024)  // few output columns: K split over the waves, 16-row workgroups
-            hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16), dim3(256), 0, e->stream, g);
+        if (g.ncols <= 16 * GN_MAXT)  // few output columns: K split over the waves, 16-row workgroups
+            hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1), dim3(256), 0, e->stream, g);
         else
             hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
     };
@@ -496,7 +496,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         gd.A = e->like_V; gd.a_group = 0; gd.a_row = nd; gd.a_seg = 0; gd.rows = nw * ng1; gd.rows_per_group = nw * ng1; gd.nseg = 1; gd.kseg = nd;
         gd.B = e->like_invcov; gd.ldb = nd; gd.ncols = nd;
         gd.C = e->like_U; gd.c_group = 0; gd.c_row = nd; gd.c_colgroup = 0; gd.cols_per_group = nd;
-        hipLaunchKernelGGL(gemm_rows_kernel, dim3((gd.rows + 63) / 64, (gd.ncols + 255) / 256), dim3(256), GEMM_LDS, st, gd);
+        hipLaunchKernelGGL(gemm_narrow_kernel, dim3((gd.rows + 15) / 16, (gd.ncols + 16 * GN_MAXT - 1) / (16 * GN_MAXT)), dim3(256), 0, st, gd);
         hipLaunchKernelGGL(marg_solve_kernel, dim3(nw), dim3(256), 0, st, nd, e->like_nG, e->jeffreys, e->like_mu, e->like_sinv, e->like_V, e->like_U,
                            b[EFTB_B_LOGP]);
     }
