@@ -406,7 +406,17 @@ __global__ __launch_bounds__(256, 1) void gemm_rows_kernel(GemmDesc d) {
 // column tiles), and the quarters are added through LDS in a fixed order -- 4x the workgroups, 1/4 of the serial depth,
 // bit-reproducible.  Same descriptor and addressing as gemm_rows_kernel.
 constexpr int GN_MAXT = 8;  // column tiles of 16
-__global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmDesc d) {
+constexpr int GN_MAXZ = 8;  // problems per launch (blockIdx.z): the per-tracer operators of one PROJECT stage
+struct GemmZ {              // problem z reads A + z a_off, writes C + z c_off and multiplies by B[z] (all null / zero: one problem, d.B)
+    const double* B[GN_MAXZ];
+    long long a_off, c_off;
+};
+__global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmDesc d, GemmZ z) {
+    if (z.B[blockIdx.z]) {
+        d.B = z.B[blockIdx.z];
+        d.A += blockIdx.z * z.a_off;
+        d.C += blockIdx.z * z.c_off;
+    }
     __shared__ double red[3 * GN_MAXT * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;

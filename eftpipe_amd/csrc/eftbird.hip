@@ -263,7 +263,7 @@ static int launch_operator(eftb_engine* e, int id, int B, int t0 = 0, int tstrid
         g.c_colgroup = (long long)NROW * o.nx_out;
         g.cols_per_group = o.nx_out;
         if (g.ncols <= 16 * GN_MAXT)  // few output columns: K split over the waves, 16-row workgroups
-            hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1), dim3(256), 0, e->stream, g);
+            hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1), dim3(256), 0, e->stream, g, GemmZ{});
         else
             hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
     };
@@ -286,8 +286,31 @@ static int launch_pipeline_operator(eftb_engine* e, int B) {
         return launch_operator(e, e->pipeline_op, B);
     }
     if (B % e->ntr) return fail("eftb_run: batch %d is not a multiple of the %d tracers per likelihood point", B, e->ntr);
-    for (int t = 0; t < e->ntr; ++t)
-        if (int rc = launch_operator(e, e->tracer_ops[t], B, t, e->ntr, t == e->ntr - 1)) return rc;
+    const eftb_engine::Op& o = e->ops[e->tracer_ops[0]];
+    bool one_launch = e->ntr <= GN_MAXZ && o.nl_out * o.nx_out <= 16 * GN_MAXT;
+    for (int t = 0; t < e->ntr; ++t) one_launch = one_launch && e->ops[e->tracer_ops[t]].st_op < 0;
+    if (!one_launch) {
+        for (int t = 0; t < e->ntr; ++t)
+            if (int rc = launch_operator(e, e->tracer_ops[t], B, t, e->ntr, t == e->ntr - 1)) return rc;
+        return 0;
+    }
+    // narrow outputs, one matrix per tracer: the tracers are the z dimension of a single launch
+    if (o.nl_in != e->cur_nl || o.nx_in != e->cur_nx)
+        return fail("the tracers' operators expect templates [%d][24][%d], the block is [%d][24][%d]", o.nl_in, o.nx_in, e->cur_nl, e->cur_nx);
+    GemmDesc g{};
+    GemmZ z{};
+    const long long bin = (long long)o.nl_in * NROW * o.nx_in, bout = (long long)o.nl_out * NROW * o.nx_out;
+    g.A = e->buf[EFTB_B_TEMPL]; g.a_group = bin * e->ntr; g.a_row = o.nx_in; g.a_seg = (long long)NROW * o.nx_in;
+    g.rows = (B / e->ntr) * NROW; g.rows_per_group = NROW; g.nseg = o.nl_in; g.kseg = o.nx_in;
+    g.B = o.dev; g.ldb = o.ld; g.ncols = o.nl_out * o.nx_out;
+    g.C = e->Talt; g.c_group = bout * e->ntr; g.c_row = o.nx_out; g.c_colgroup = (long long)NROW * o.nx_out; g.cols_per_group = o.nx_out;
+    for (int t = 0; t < e->ntr; ++t) z.B[t] = e->ops[e->tracer_ops[t]].dev;
+    z.a_off = bin;
+    z.c_off = bout;
+    hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1, e->ntr), dim3(256), 0, e->stream, g, z);
+    std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
+    e->cur_nl = o.nl_out;
+    e->cur_nx = o.nx_out;
     return 0;
 }
 
@@ -496,7 +519,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         gd.A = e->like_V; gd.a_group = 0; gd.a_row = nd; gd.a_seg = 0; gd.rows = nw * ng1; gd.rows_per_group = nw * ng1; gd.nseg = 1; gd.kseg = nd;
         gd.B = e->like_invcov; gd.ldb = nd; gd.ncols = nd;
         gd.C = e->like_U; gd.c_group = 0; gd.c_row = nd; gd.c_colgroup = 0; gd.cols_per_group = nd;
-        hipLaunchKernelGGL(gemm_narrow_kernel, dim3((gd.rows + 15) / 16, (gd.ncols + 16 * GN_MAXT - 1) / (16 * GN_MAXT)), dim3(256), 0, st, gd);
+        hipLaunchKernelGGL(gemm_narrow_kernel, dim3((gd.rows + 15) / 16, (gd.ncols + 16 * GN_MAXT - 1) / (16 * GN_MAXT)), dim3(256), 0, st, gd, GemmZ{});
         hipLaunchKernelGGL(marg_solve_kernel, dim3(nw), dim3(256), 0, st, nd, e->like_nG, e->jeffreys, e->like_mu, e->like_sinv, e->like_V, e->like_U,
                            b[EFTB_B_LOGP]);
     }
