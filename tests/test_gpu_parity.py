@@ -223,3 +223,20 @@ def test_nl2_option_branches_against_oracle(golden, opts):
         tn = eng.get("TEMPLN", (2, 2, 24, g["k"].size))
         assert relerr(tn[1][:, 3:6], want["PctNNLOl"]) < TOL
     eng.close()
+
+
+def test_no_rsd_growth_rate_zero(golden):
+    """with_RSD: false sets f = 0 (reference theory.py:565-566): every f-power of the regrouping and of Q(f) at its edge."""
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+    from oracle import OracleConfig, OracleEngine
+
+    g = golden("caseC")
+    kw = dict(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"]))
+    want = OracleEngine(OracleConfig(kmA=0.7, krA=0.25, ndA=4.5e-5, **kw)).evaluate(g["kin"], g["Pin"], 0.0, float(g["DA"]), float(g["H"]))
+    eng = Engine(EngineConfig(**kw), max_batch=2)
+    templ = eng.eval_batch(np.stack([g["Pin"], g["Pin"]]), np.array([0.0, float(g["f"])]), float(g["DA"]), float(g["H"]))
+    for n, sl in (("P11l", slice(0, 3)), ("Pctl", slice(3, 9)), ("Ploopl", slice(9, 21)), ("Pstl", slice(21, 24))):
+        assert relerr(templ[0][:, sl], want[n]) < TOL, n
+    assert relerr(templ[1][:, 9:21], g["ap_Ploopl"]) < TOL  # the neighbour with f > 0 is untouched
+    eng.close()
