@@ -13,7 +13,7 @@ from eftpipe_amd.engine import Engine
 from eftpipe_amd.parambasis import bias_row
 from eftpipe_amd.tables import EngineConfig
 
-Z, B = 0.7, 128
+Z, B = 0.7, int(os.environ.get('LANES_TOTAL', 128))
 cfg = EngineConfig(Nl=3, k=synth.survey_kgrid(512), with_resum=True, with_ap=True,
                    DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
 d = synth.draw_batch(B, z=Z)
