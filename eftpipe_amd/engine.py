@@ -113,6 +113,10 @@ class Engine:
         """Replace the fiducial (DA, H) of the AP stage (APeffect constructor, pybird.py:1522-1530)."""
         self._set("APFID", np.array([DA, H], dtype=np.float64))
 
+    def set_graph_replay(self, flag):
+        """Replay whole-pipeline runs from captured HIP graphs (one host call per step; for busy hosts)."""
+        L.check(self.lib.eftb_set_option(self._h, 2, int(bool(flag))))
+
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
 

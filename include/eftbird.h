@@ -125,7 +125,9 @@ void eftb_destroy(eftb_engine* e);
 /* Run-time switches that the reference keeps on plugin objects rather than on Common. */
 enum eftb_option {
     EFTB_O_AP_STOCHASTIC = 0, /* APeffect.APst                                pybird.py:1514, 1618 */
-    EFTB_O_JEFFREYS = 1       /* marginalized_logp(jeffreys=True): drop ln det(F2 / 2 pi)   marginal.py:118-121 */
+    EFTB_O_JEFFREYS = 1,      /* marginalized_logp(jeffreys=True): drop ln det(F2 / 2 pi)   marginal.py:118-121 */
+    EFTB_O_GRAPH = 2          /* replay whole-pipeline runs (stage masks starting at PREP) from captured HIP graphs: one host call per
+                                 step; for busy hosts (no reference counterpart; off by default, also EFTB_GRAPH=1) */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 

@@ -240,3 +240,31 @@ def test_no_rsd_growth_rate_zero(golden):
         assert relerr(templ[0][:, sl], want[n]) < TOL, n
     assert relerr(templ[1][:, 9:21], g["ap_Ploopl"]) < TOL  # the neighbour with f > 0 is untouched
     eng.close()
+
+
+def test_graph_replay_is_bit_identical(golden):
+    """EFTB_O_GRAPH: captured-graph replay of the whole pipeline (AP swaps the two template blocks, so two graphs alternate) gives
+    exactly the plain-launch results, also after the launch state changes (another batch size, a pipeline operator)."""
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, APst=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=3)
+    Pin = np.stack([g["Pin"], 1.1 * g["Pin"], 0.9 * g["Pin"]])
+    args = (float(g["f"]), float(g["DA"]), float(g["H"]))
+    plain = [eng.eval_batch(Pin, *args), eng.eval_batch(Pin[:2], *args)]
+    eng.set_graph_replay(True)
+    for _ in range(4):  # capture (two pointer parities), then replays
+        assert np.array_equal(eng.eval_batch(Pin, *args), plain[0])
+    assert np.array_equal(eng.eval_batch(Pin[:2], *args), plain[1])
+    op = eng.add_operator(np.einsum("al,xk->alxk", np.eye(3), np.eye(50)[::2]))
+    eng.set_pipeline_operator(op)
+    a = eng.eval_batch(Pin, *args)
+    b = eng.eval_batch(Pin, *args)
+    assert np.array_equal(a, b) and np.array_equal(a, plain[0][..., ::2])
+    eng.load_inputs(Pin, *args)
+    for _ in range(3):
+        eng.run(eng.full_mask(), 3)
+    assert np.array_equal(eng.get("TEMPL", (3, 3, 24, 25)), a)
+    eng.close()
