@@ -90,7 +90,15 @@ def main():
     B = args.batch
     cfg = EngineConfig(Nl=NL, k=synth.survey_kgrid(NK), with_resum=True, with_ap=True,
                        DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
-    eng = Engine(cfg, max_batch=B, device=cp.local_rank)
+    # host tables with a bounded BLAS pool: the init-time NumPy work must not eat the CPU share the launch loop needs right after
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:  # pragma: no cover
+        import contextlib
+
+        threadpool_limits = lambda limits: contextlib.nullcontext()
+    with threadpool_limits(limits=8):
+        eng = Engine(cfg, max_batch=B, device=cp.local_rank)
     gather = "none"
     if world > 1:
         # RCCL communicator for the P_l gather; if it cannot be built on this node every rank agrees to fall back to
