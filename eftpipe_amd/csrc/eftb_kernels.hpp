@@ -783,12 +783,12 @@ __global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int sc
 constexpr double RS_ZS = 8.0;  // tables.py RS_ZS
 constexpr int RS_NB = 8, RS_TILES = 5, RS_ROWS = 16 * RS_TILES, RS_REC = 48;
 
+template <int NL>
 __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na, const double* __restrict__ Q,
                                                          const double* __restrict__ V8S, const int* __restrict__ rows,
                                                          const double* __restrict__ XY, const double* __restrict__ C11,
                                                          const double* __restrict__ Cct, const double* __restrict__ Cloopl,
                                                          double* __restrict__ RSA, double* __restrict__ RSC) {
-    constexpr int NL = 3;
     const int w = blockIdx.x;
     const double* q = Q + (size_t)w * 2 * NL * NL * NN;
     for (int idx = threadIdx.x; idx < RS_ROWS * RS_NB; idx += blockDim.x) {
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
     for (int idx = threadIdx.x; idx < NS * RS_REC; idx += blockDim.x) {
         const int c = idx / NS, s = idx % NS;  // s fastest: coalesced reads of the s-major inputs
         double v = 0.0;
-        if (c < 42) {
+        if (c < 14 * NL) {
             const int lp = c / 14, j = c % 14;
             if (j == 0) v = C11[((size_t)w * NL + lp) * NS + s];
             else if (j == 1) v = Cct[((size_t)w * NL + lp) * NS + s];
@@ -981,6 +981,125 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
                 pw[((size_t)21 + i) * Nk] = o1[i];
                 pw[((size_t)42 + i) * Nk] = o2[i];
             }
+        }
+    }
+}
+
+// The same scheme for Nl = 2 (NIR = 8, Na = 2): the polynomials have degree 7, so the monomials of t = z / RS_ZS are the basis
+// (V8 = identity); the 8 (a, l, l') blocks x 4 slots are 32 rows = two row tiles: tile tau <-> l' = tau, lane group jg <-> (a, l) =
+// (1, 0), (1, 1), (0, 0), (0, 1); slots 0 -> (v = l', half 0), 1, 2 -> (v = slot - 1, half 1), 3 -> empty.  Four MFMAs per step, every
+// output row owned by one lane group, no cross-lane traffic.
+__global__ __launch_bounds__(256, 2) void resum_mfma2_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
+                                                             const double* __restrict__ H, const double* __restrict__ V8,
+                                                             const double* __restrict__ RSA, const double* __restrict__ RSC,
+                                                             const double* __restrict__ l11, const double* __restrict__ lct,
+                                                             double* __restrict__ T, double* __restrict__ part, int nsplit) {
+    constexpr int NL = 2, NT = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jg = lane >> 4, n = lane & 15;
+    const int k = Nklow + (blockIdx.x * 4 + wave) * 16 + n, w = blockIdx.y, split = blockIdx.z;
+    const bool live = k < Nk;
+    const int kc = live ? k : Nk - 1;
+    const double k2 = kk[kc] * kk[kc];
+    double vb[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 16; ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
+    double aop[NT][2];
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) aop[tau][t] = RSA[((size_t)w * RS_ROWS + 16 * tau + n) * RS_NB + jg + 4 * t];
+    double accL[12], accCt[NT], acc11[NT];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) accL[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) accCt[i] = acc11[i] = 0.0;
+    const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
+    const double* ct = RSC + ((size_t)w * NS + s0) * RS_REC;
+    double h[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) h[v] = H[((size_t)v * NS + s0) * Nk + kc];
+    double z = k2 * ct[42], y = k2 * ct[43];
+    double b0, b1;
+    {
+        const double t = z * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
+        b0 = estrin16(vb[0], t, t2, t4, t8);
+        b1 = estrin16(vb[1], t, t2, t4, t8);
+    }
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(aop[tau][t]));
+    for (int s = s0; s < s1; ++s) {
+        const int sn = s + 1 < s1 ? s + 1 : s;
+        const double* ctn = RSC + ((size_t)w * NS + sn) * RS_REC;
+        double cv[14 * NT];
+#pragma unroll
+        for (int i = 0; i < 14 * NT; ++i) cv[i] = ct[i];
+        const double xn = ctn[42], yn0 = ctn[43];
+        double hn[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) hn[v] = H[((size_t)v * NS + sn) * Nk + kc];
+        __builtin_amdgcn_sched_barrier(0);
+        v4d D[NT];
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const double zn = k2 * xn, yn = k2 * yn0;
+        double bn0, bn1;
+        {
+            const double t = zn * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
+            bn0 = estrin16(vb[0], t, t2, t4, t8);
+            bn1 = estrin16(vb[1], t, t2, t4, t8);
+        }
+        const double zh[2] = {z * h[0], z * h[1]}, yh[2] = {y * h[0], y * h[1]};
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            const double W = fma(zh[tau], D[tau][0], fma(yh[0], D[tau][1], yh[1] * D[tau][2]));
+            acc11[tau] = fma(W, cv[tau * 14], acc11[tau]);          // every lane accumulates both roles; only its own is read
+            accCt[tau] = fma(W, cv[tau * 14 + 1], accCt[tau]);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) accL[i] = fma(W, cv[tau * 14 + 2 + i], accL[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ct = ctn;
+        z = zn;
+        y = yn;
+        b0 = bn0;
+        b1 = bn1;
+        h[0] = hn[0];
+        h[1] = hn[1];
+    }
+    if (!live) return;
+    const int l = jg & 1;  // multipole of this lane group's block
+    double o18[18], oA[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o18[i] = lct[i] * accCt[0] + lct[6 + i] * accCt[1];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) o18[6 + i] = accL[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) oA[i] = l11[i] * acc11[0] + l11[3 + i] * acc11[1];
+    if (nsplit == 1) {
+        double* dst = T + (((size_t)w * NL + l) * NROW) * Nk + k;
+        if (jg < 2) {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) dst[(size_t)(3 + i) * Nk] += o18[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dst[(size_t)i * Nk] += oA[i];
+        }
+    } else {  // partial sums over the s slices, added in a fixed order by resum_sum_kernel
+        double* pw = part + (((size_t)w * nsplit + split) * NL + l) * 21 * Nk + k;
+        if (jg < 2) {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) pw[(size_t)(3 + i) * Nk] = o18[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pw[(size_t)i * Nk] = oA[i];
         }
     }
 }

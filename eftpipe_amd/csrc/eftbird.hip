@@ -84,6 +84,7 @@ struct eftb_engine {
     std::vector<GraphEntry> graphs;
     unsigned long long epoch = 0;  // bumped by every setter that can change what launch_stages launches
     bool use_graphs = false;
+    bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
@@ -175,8 +176,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_WQLAST2: return c.with_resum ? D * 2 : 0;
         case EFTB_T_QPOLY: return c.with_resum ? D * 2 * c.Nl * c.Nl * Nn * 15 : 0;
         case EFTB_T_H: return c.with_resum ? D * c.Na * NS * c.Nk : 0;
-        case EFTB_T_RSBASIS: case EFTB_T_RSBASISS: return c.with_resum && c.Nl == 3 ? D * RS_NB * 16 : 0;
-        case EFTB_T_RSROWS: return c.with_resum && c.Nl == 3 ? sizeof(int32_t) * RS_ROWS : 0;
+        case EFTB_T_RSBASIS: case EFTB_T_RSBASISS: return c.with_resum ? D * RS_NB * 16 : 0;
+        case EFTB_T_RSROWS: return c.with_resum ? sizeof(int32_t) * RS_ROWS : 0;
         case EFTB_T_MU: case EFTB_T_WMU: return c.with_ap ? D * c.nmu : 0;
         case EFTB_T_LEGMU: return c.with_ap ? D * c.Nl * c.nmu : 0;
         case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
@@ -448,19 +449,21 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             hipLaunchKernelGGL(extract_bao_kernel, dim3(B * Nl * 12), dim3(128), 0, st, tb<double>(e, EFTB_T_BAO), cloopl, xl);
             c11 = x11; cct = xct; cloopl = xl;
         }
-        if (Nl == 3) {
-            // matrix-core form: polynomials as [80 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
-            if (full)
-                hipLaunchKernelGGL(resum_prep_kernel, dim3(B), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
-                                   tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], c11, cct, cloopl, e->RSA, e->RSC);
+        if (Nl == 3 || !e->generic_resum) {
+            // matrix-core form: polynomials as [80 | 32 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
+#define RP_ARGS e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS), tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], c11, cct, cloopl, e->RSA, e->RSC
+            if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), dim3(B), dim3(256), 0, st, RP_ARGS);
+            else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), dim3(B), dim3(256), 0, st, RP_ARGS);
+#undef RP_ARGS
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
             const int schunk = (NS + nsplit - 1) / nsplit;
-            if (kblocks > 0)
-                hipLaunchKernelGGL(resum_mfma_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K),
-                                   tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT),
-                                   b[EFTB_B_TEMPL], e->part, nsplit);
+#define RM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), \
+                tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
+            if (kblocks > 0 && Nl == 3) hipLaunchKernelGGL(resum_mfma_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
+            else if (kblocks > 0) hipLaunchKernelGGL(resum_mfma2_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
+#undef RM_ARGS
             if (nsplit > 1)
                 hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nsplit, e->part, b[EFTB_B_TEMPL]);
         } else {
@@ -668,6 +671,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->cur_nx = c.Nk;
     if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(7, std::max(1, atoi(f)));
     if (const char* f = getenv("EFTB_GRAPH")) e->use_graphs = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_GENERIC_RESUM")) e->generic_resum = atoi(f) != 0;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
@@ -752,7 +756,7 @@ int eftb_finalize(eftb_engine* e) {
             HIPCHK(hipMemset(e->ZC, 0, e->buf_elems[EFTB_B_C11] * sizeof(double)));
             HIPCHK(hipMemset(e->ZC2, 0, e->buf_elems[EFTB_B_CLOOPL] * sizeof(double)));
         }
-        if (c.Nl == 3) {
+        {
             HIPCHK(hipMalloc(&e->RSA, (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double)));
             HIPCHK(hipMalloc(&e->RSC, (size_t)c.max_batch * NS * RS_REC * sizeof(double)));
         }

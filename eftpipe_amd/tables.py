@@ -409,8 +409,7 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
         t["wq_last2"] = wq[-2:].copy()
         t["Qpoly"] = lm.q_polynomials(Nl)
         t["resum_dims"] = np.array([NIR, Na, int(np.sum(~kr_mask))], dtype=np.int32)
-        if Nl == 3:
-            t.update(resum_mfma_tables(t["Qpoly"], NIR, Na))
+        t.update(resum_mfma_tables(t["Qpoly"], NIR, Na))
 
     # ---- AP
     if cfg.with_ap:
@@ -446,6 +445,8 @@ def resum_mfma_tables(Qpoly, NIR, Na):
 
     -> rs_basis [8,16] (V8), rs_basis_scaled [8,16] (V8 diag(RS_ZS^p)), rs_rows int32[80] (offset of the row's p = 0
        coefficient inside one cosmology's Q block [2,Nl,Nl,Nn], stride Na per p; -1 = zero row)."""
+    if NIR == 8:
+        return _resum_mfma_tables_nl2(Qpoly, NIR, Na)
     Nl = 3
     NN = 2 * NIR * Na
     Qr = Qpoly.reshape(2, Nl, Nl, 2, NIR, Na, Qpoly.shape[-1])          # table, l, l', half, p, v, f-power
@@ -475,6 +476,34 @@ def resum_mfma_tables(Qpoly, NIR, Na):
             used[a, l, lp, half, v] = True
     # device Q[a] = table[1 - a] (reference pybird.py:1374-1376): every nonzero polynomial must have a row
     nz = np.abs(Qr).max(axis=(4, 6)) > 0                                 # table, l, l', half, v
+    if np.any(nz[::-1] & ~used):
+        raise ValueError("resummation table has entries outside the (v = l' | half 1) slot pattern")
+    return dict(rs_basis=V8, rs_basis_scaled=np.ascontiguousarray(V8 * scale[None, :]), rs_rows=rows)
+
+
+def _resum_mfma_tables_nl2(Qpoly, NIR, Na):
+    """Nl = 2 (NIR = 8, Na = 2): the polynomials have degree 7, so the monomials of t = z / RS_ZS are the basis (V8 = identity) and
+    A = Q diag(RS_ZS^p).  32 rows = two tiles: tile tau <-> l' = tau; row i: lane group i % 4 <-> (a, l) = (1, 0), (1, 1), (0, 0), (0, 1);
+    slot i // 4: 0 -> (v = l', half 0), 1, 2 -> (v = slot - 1, half 1), 3 -> empty (resum_mfma2_kernel)."""
+    Nl = 2
+    NN = 2 * NIR * Na
+    Qr = Qpoly.reshape(2, Nl, Nl, 2, NIR, Na, Qpoly.shape[-1])
+    V8 = np.zeros((RS_NB, 16))
+    V8[np.arange(RS_NB), np.arange(RS_NB)] = 1.0
+    scale = np.zeros(16)
+    scale[:NIR] = RS_ZS ** np.arange(NIR)
+    rows = np.full(RS_ROWS, -1, dtype=np.int32)
+    used = np.zeros((2, Nl, Nl, 2, Na), dtype=bool)
+    for tau in range(2):
+        for i in range(16):
+            jg, slot = i % 4, i // 4
+            a, l = ((1, 0), (1, 1), (0, 0), (0, 1))[jg]
+            if slot == 3:
+                continue
+            v, half = (tau, 0) if slot == 0 else (slot - 1, 1)
+            rows[16 * tau + i] = ((a * Nl + l) * Nl + tau) * NN + half * NIR * Na + v
+            used[a, l, tau, half, v] = True
+    nz = np.abs(Qr).max(axis=(4, 6)) > 0
     if np.any(nz[::-1] & ~used):
         raise ValueError("resummation table has entries outside the (v = l' | half 1) slot pattern")
     return dict(rs_basis=V8, rs_basis_scaled=np.ascontiguousarray(V8 * scale[None, :]), rs_rows=rows)

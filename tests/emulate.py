@@ -132,12 +132,12 @@ def resum(t, f, Pin, st):
 
 
 def resum_mfma(t, f, Pin, st):
-    """The matrix-core form of the same stage (device: resum_prep_kernel + resum_mfma_kernel, Nl = 3): polynomials as
-    A[80 rows, 8] x beta[8, points] in t = z / RS_ZS, rows laid out as (tile, chunk, slot) -- see tables.resum_mfma_tables."""
+    """The matrix-core form of the same stage (device: resum_prep_kernel + resum_mfma_kernel / resum_mfma2_kernel): polynomials as
+    A[80 | 32 rows, 8] x beta[8, points] in t = z / RS_ZS, rows laid out as (tile, chunk, slot) -- see tables.resum_mfma_tables."""
     from eftpipe_amd.tables import RS_ZS
 
     NIR, Na, Nklow = t["resum_dims"]
-    Nl = 3
+    Nl = 3 if NIR == 16 else 2
     k = t["k"]
     Q = (t["Qpoly"] @ f ** np.arange(15))[::-1].reshape(-1)
     X, Y = ir_filters(t, Pin)
@@ -146,15 +146,18 @@ def resum_mfma(t, f, Pin, st):
     rows = t["rs_rows"]
     A = np.zeros((80, 8))
     for r in np.nonzero(rows >= 0)[0]:
-        A[r] = t["rs_basis_scaled"] @ Q[rows[r] + np.arange(NIR) * Na]
+        A[r] = t["rs_basis_scaled"][:, :NIR] @ Q[rows[r] + np.arange(NIR) * Na]
     tt = z / RS_ZS
-    beta = np.einsum("rp,pks->rks", t["rs_basis"], np.stack([tt**p for p in range(NIR)]))  # [8,Nk,Ns]
+    beta = np.einsum("rp,pks->rks", t["rs_basis"][:, :NIR], np.stack([tt**p for p in range(NIR)]))  # [8,Nk,Ns]
     D = np.einsum("ir,rks->iks", A, beta).reshape(5, 4, 4, *z.shape)  # [tau, slot, jg, k, s]
     H = t["H"]
     out = {n: st[n].copy() for n in ("P11l", "Pctl", "Ploopl")}
-    for tau in range(5):
+    for tau in range(5 if Nl == 3 else 2):
         for jg in range(4):
-            if tau < 3:
+            if Nl == 2:
+                lp = tau
+                a, l = ((1, 0), (1, 1), (0, 0), (0, 1))[jg]
+            elif tau < 3:
                 lp = tau
                 a, l = (1, jg) if jg < 3 else (0, 0)
             elif tau == 3:
@@ -164,7 +167,7 @@ def resum_mfma(t, f, Pin, st):
             else:
                 continue
             d = D[tau, :, jg]
-            W = z * H[lp] * d[0] + yk * (H[0] * d[1] + H[1] * d[2] + H[2] * d[3])  # [Nk,Ns]
+            W = z * H[lp] * d[0] + yk * (H[0] * d[1] + H[1] * d[2] + (H[2] * d[3] if Na == 3 else 0.0))  # [Nk,Ns]
             if a == 0:
                 out["P11l"][l] += np.einsum("ks,s,i->ik", W, st["C11"][lp], t["l11"][lp])
             else:

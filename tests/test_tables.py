@@ -38,7 +38,7 @@ def test_device_algebra_matches_oracle(golden, name, resum, ap):
         assert relerr(st["Y"], taps["resum"]["Y"]) < 1e-10
         for n in ("P11l", "Pctl", "Ploopl"):
             assert relerr(st[n], taps["resum"][n]) < 1e-9, n
-        if "rs_rows" in t:  # matrix-core form of the stage (Nl = 3)
+        if "rs_rows" in t:  # matrix-core form of the stage
             pre = {n: taps["setpscfl"][n] for n in ("P11l", "Pctl", "Ploopl", "Cloopl")}
             pre.update(C11=taps["pscf"]["C11"], Cct=taps["pscf"]["Cct"])
             alt = E.resum_mfma(t, f, g["Pin"], pre)

@@ -4,7 +4,7 @@ from eftpipe_amd import synth, _lib as L
 from eftpipe_amd.engine import Engine
 from eftpipe_amd.tables import EngineConfig
 Z=0.7; B=128
-for Nl in (3,3,3,2,2):
+for Nl in (2,3):
     cfg = EngineConfig(Nl=Nl, k=synth.survey_kgrid(512), with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
     eng = Engine(cfg, max_batch=B)
     d = synth.draw_batch(B, z=Z)
