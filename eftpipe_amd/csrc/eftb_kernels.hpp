@@ -1001,11 +1001,12 @@ __global__ __launch_bounds__(256, 2) void resum_mfma2_kernel(int Nk, int Nklow, 
     const bool live = k < Nk;
     const int kc = live ? k : Nk - 1;
     const double k2 = kk[kc] * kk[kc];
-    double vb[2][16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 16; ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
+    // B operand: the monomials t^jg and t^(jg + 4) of this lane's point (V8 is the identity for Nl = 2: nothing to evaluate)
+    auto powers = [&](double t, double& p0, double& p1) {
+        const double t2 = t * t;
+        p0 = jg == 0 ? 1.0 : (jg == 1 ? t : (jg == 2 ? t2 : t2 * t));
+        p1 = p0 * (t2 * t2);
+    };
     double aop[NT][2];
 #pragma unroll
     for (int tau = 0; tau < NT; ++tau)
@@ -1023,11 +1024,7 @@ __global__ __launch_bounds__(256, 2) void resum_mfma2_kernel(int Nk, int Nklow, 
     for (int v = 0; v < 2; ++v) h[v] = H[((size_t)v * NS + s0) * Nk + kc];
     double z = k2 * ct[42], y = k2 * ct[43];
     double b0, b1;
-    {
-        const double t = z * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
-        b0 = estrin16(vb[0], t, t2, t4, t8);
-        b1 = estrin16(vb[1], t, t2, t4, t8);
-    }
+    powers(z * (1.0 / RS_ZS), b0, b1);
 #pragma unroll
     for (int tau = 0; tau < NT; ++tau)
 #pragma unroll
@@ -1051,11 +1048,7 @@ __global__ __launch_bounds__(256, 2) void resum_mfma2_kernel(int Nk, int Nklow, 
         __builtin_amdgcn_sched_barrier(0);
         const double zn = k2 * xn, yn = k2 * yn0;
         double bn0, bn1;
-        {
-            const double t = zn * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
-            bn0 = estrin16(vb[0], t, t2, t4, t8);
-            bn1 = estrin16(vb[1], t, t2, t4, t8);
-        }
+        powers(zn * (1.0 / RS_ZS), bn0, bn1);
         const double zh[2] = {z * h[0], z * h[1]}, yh[2] = {y * h[0], y * h[1]};
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
