@@ -84,6 +84,11 @@ struct eftb_engine {
     std::vector<GraphEntry> graphs;
     unsigned long long epoch = 0;  // bumped by every setter that can change what launch_stages launches
     bool use_graphs = false;
+    // Back-to-back asynchronous runs: the first stage of run i+1 (P11 spline + FFTLog, 20 us, inputs only) goes to its own stream and
+    // overlaps the tail of run i (resum / AP) -- it waits for evInFree, recorded once run i no longer reads P11 / the coefficients
+    hipStream_t pre = nullptr;
+    hipEvent_t evPrep = nullptr, evInFree = nullptr;
+    bool prep_overlap = true, inputs_settled = false;  // EFTB_PREP_OVERLAP=0 disables; inputs_settled: set by eftb_run only
     bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
@@ -369,8 +374,16 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
     }
     bool joined = !(side_ir || side_ap);
+    // cross-run overlap of the first stage (see engine.pre): only for asynchronous runs whose inputs are already in place
+    const bool pre_side = (mask & EFTB_S_PREP) && (mask & EFTB_S_REGROUP) && e->prep_overlap && e->inputs_settled && !e->use_graphs && !nnlo_pass &&
+                          !c.with_nnlo;  // (the NNLO pass of the previous run still reads CctNNLO late)
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
+        hipStream_t st0 = st;
+        if (pre_side) {
+            st = e->pre;
+            if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+        }
         hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
                            b[EFTB_B_P11], b[EFTB_B_COEF], e->coefT, c.max_batch);
@@ -378,7 +391,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN],
                                tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT2), tb<double>(e, EFTB_T_ECT),
                                tb<double>(e, EFTB_T_LNXTAIL), b[EFTB_B_P11], e->coef2, e->coefT2, c.max_batch);
+        if (!pre_side) st = st0;
     }
+    // with pre_side the whole front half (first stage, anti-diagonal sums, rows, syntheses, expansions: inputs -> P22, P13, C11, Cct, CC)
+    // stays on the `pre` stream; the main stream picks up at the regrouping
+    hipStream_t st_main = e->stream;
     if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
     // the anti-diagonal sums serve both the k-space and the xi-space pieces: one pass, then the synthesis rows of
     // whatever is requested (bit 0/1: quadratic rows of k / xi space, bit 2/3: single-sum rows, bit 4: the sums themselves)
@@ -422,6 +439,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
                                e->YCF, c22 ? tb<double>(e, EFTB_T_EXPC) : nullptr, b[EFTB_B_CC]);
         }
     }
+    if (pre_side) {
+        if (hipEventRecord(e->evPrep, st) != hipSuccess || hipStreamWaitEvent(st_main, e->evPrep, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+        st = st_main;
+    }
     if (mask & EFTB_S_REGROUP) {
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
                            b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
@@ -432,6 +453,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (c.with_resum)
             hipLaunchKernelGGL(regroup_cf_kernel, dim3(12, Nl, B), dim3(128), 0, st, Nl, b[EFTB_B_F], b[EFTB_B_CC], tb<double>(e, EFTB_T_L22),
                                tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_CLOOPL]);
+        // nothing later in this run reads the front half's outputs (P11, coefficients, P22, P13, CC; C11 / Cct only if a resummation
+        // follows): the next run's front half may overwrite them from here on
+        if (!(mask & EFTB_S_RESUM) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess)
+            return fail("eftb_run: event record failed");
     }
     if (mask & (EFTB_S_RESUM | EFTB_K_RESUM)) {
         if (!c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
@@ -455,6 +480,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), dim3(B), dim3(256), 0, st, RP_ARGS);
             else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), dim3(B), dim3(256), 0, st, RP_ARGS);
 #undef RP_ARGS
+            // C11 / Cct / Cloopl now live in the per-s records: the next run's front half may overwrite its outputs (see the regrouping)
+            if (full && (mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess)
+                return fail("eftb_run: event record failed");
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
@@ -476,6 +504,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
                                b[EFTB_B_XY], b[EFTB_B_Q], tb<double>(e, EFTB_T_H), c11, cct, cloopl,
                                tb<double>(e, EFTB_T_L11), tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), e->part, nsplit);
             hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, 2 * Nl * nsplit, e->part, b[EFTB_B_TEMPL]);
+            if (full && (mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess)
+                return fail("eftb_run: event record failed");
         }
     }
     if (mask & EFTB_S_AP) {
@@ -547,6 +577,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     if ((mask & EFTB_S_REDUCE) && c.with_nnlo)
         hipLaunchKernelGGL(reduce_nnlo_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIASN],
                            b[EFTB_B_TEMPLN], b[EFTB_B_PLK]);
+    if (!(mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess) return fail("eftb_run: event record failed");
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
     return 0;
@@ -600,6 +631,7 @@ static int run_stages(eftb_engine* e, int mask, int B) {
         if (g.mask == mask && g.B == B && g.epoch == e->epoch && g.templ == b[EFTB_B_TEMPL] && g.talt == e->Talt && g.templn == b[EFTB_B_TEMPLN] &&
             g.cur_nl == e->cur_nl && g.cur_nx == e->cur_nx) {
             if (hipGraphLaunch(g.exec, e->stream) != hipSuccess) return fail("eftb_run: hipGraphLaunch failed");
+            (void)hipEventRecord(e->evInFree, e->stream);
             b[EFTB_B_TEMPL] = const_cast<double*>(g.post_templ);
             e->Talt = const_cast<double*>(g.post_talt);
             b[EFTB_B_TEMPLN] = const_cast<double*>(g.post_templn);
@@ -642,6 +674,7 @@ static int run_stages(eftb_engine* e, int mask, int B) {
     }
     e->graphs.push_back(g);
     if (hipGraphLaunch(g.exec, e->stream) != hipSuccess) return fail("eftb_run: hipGraphLaunch failed");
+    (void)hipEventRecord(e->evInFree, e->stream);
     return 0;
 }
 
@@ -672,8 +705,13 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(7, std::max(1, atoi(f)));
     if (const char* f = getenv("EFTB_GRAPH")) e->use_graphs = atoi(f) != 0;
     if (const char* f = getenv("EFTB_GENERIC_RESUM")) e->generic_resum = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_PREP_OVERLAP")) e->prep_overlap = atoi(f) != 0;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->pre, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evInFree, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->evInFree, e->pre));
     HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&e->ev0));
@@ -926,7 +964,8 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered, e->evPrep, e->evInFree}) if (ev) (void)hipEventDestroy(ev);
+    if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -963,7 +1002,10 @@ int eftb_run(eftb_engine* e, int mask, int B) {
     if (!e->finalized) return fail("eftb_run: engine not finalized");
     if (B < 1 || B > e->c.max_batch) return fail("eftb_run: batch %d outside [1, %d]", B, e->c.max_batch);
     HIPCHK(hipSetDevice(e->c.device));
-    return run_stages(e, mask, B);
+    e->inputs_settled = true;  // eftb_put is synchronous: the inputs of this run are in place, its first stage may start early
+    const int rc = run_stages(e, mask, B);
+    e->inputs_settled = false;
+    return rc;
 }
 
 int eftb_sync(eftb_engine* e) {
