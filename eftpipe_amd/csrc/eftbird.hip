@@ -89,6 +89,14 @@ struct eftb_engine {
     hipStream_t pre = nullptr;
     hipEvent_t evPrep = nullptr, evInFree = nullptr;
     bool prep_overlap = true, inputs_settled = false;  // EFTB_PREP_OVERLAP=0 disables; inputs_settled: set by eftb_run only
+    // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous): two sets of the per-step inputs (PIN, F, DA,
+    // H, BIAS, GROWS) and outputs (PLK, LOGP); the host fills the idle set through a copy stream while the other set is being evaluated
+    double* alt[EFTB_B_COUNT] = {nullptr};
+    double* stage_host[2] = {nullptr, nullptr};  // page-locked staging, one per set
+    size_t stage_elems = 0;
+    hipStream_t cpy = nullptr;
+    hipEvent_t evStaged[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr};
+    int cur_set = 0, staged_B = 0;
     bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
@@ -966,6 +974,13 @@ void eftb_destroy(eftb_engine* e) {
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered, e->evPrep, e->evInFree}) if (ev) (void)hipEventDestroy(ev);
     if (e->pre) (void)hipStreamDestroy(e->pre);
+    if (e->cpy) (void)hipStreamDestroy(e->cpy);
+    for (int q = 0; q < 2; ++q) {
+        if (e->evStaged[q]) (void)hipEventDestroy(e->evStaged[q]);
+        if (e->evSetDone[q]) (void)hipEventDestroy(e->evSetDone[q]);
+        if (e->stage_host[q]) (void)hipHostFree(e->stage_host[q]);
+    }
+    for (auto& p : e->alt) if (p) (void)hipFree(p);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1107,6 +1122,103 @@ void* eftb_host_alloc(size_t bytes) {
 
 void eftb_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+static const int kStagedIds[] = {EFTB_B_PIN, EFTB_B_F, EFTB_B_DA, EFTB_B_H, EFTB_B_BIAS, EFTB_B_GROWS, EFTB_B_PLK, EFTB_B_LOGP};
+
+static int staged_setup(eftb_engine* e) {
+    if (e->cpy) return 0;
+    HIPCHK(hipSetDevice(e->c.device));
+    HIPCHK(hipStreamCreateWithFlags(&e->cpy, hipStreamNonBlocking));
+    for (int id : kStagedIds)
+        if (e->buf_elems[id]) {
+            HIPCHK(hipMalloc(&e->alt[id], e->buf_elems[id] * sizeof(double)));
+            HIPCHK(hipMemset(e->alt[id], 0, e->buf_elems[id] * sizeof(double)));
+        }
+    e->stage_elems = e->buf_elems[EFTB_B_PIN] + 3 * (size_t)e->c.max_batch + e->buf_elems[EFTB_B_BIAS] + e->buf_elems[EFTB_B_GROWS];
+    for (int q = 0; q < 2; ++q) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->stage_host[q]), e->stage_elems * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&e->evStaged[q], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->evSetDone[q], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e->evStaged[q], e->cpy));
+        HIPCHK(hipEventRecord(e->evSetDone[q], e->cpy));
+    }
+    return 0;
+}
+
+int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
+                      const double* rows) {
+    if (!e || !Pin || !f) return fail("eftb_stage_inputs: null argument");
+    if (!e->finalized) return fail("eftb_stage_inputs: engine not finalized");
+    const eftb_config& c = e->c;
+    if (B < 1 || B > c.max_batch) return fail("eftb_stage_inputs: batch %d outside [1, %d]", B, c.max_batch);
+    if (c.with_ap && (!DA || !H)) return fail("eftb_stage_inputs: DA and H are required when with_ap=1");
+    if (rows && !e->like_ndata) return fail("eftb_stage_inputs: rows need eftb_set_likelihood");
+    if (int rc = staged_setup(e)) return rc;
+    HIPCHK(hipSetDevice(c.device));
+    const int t = 1 - e->cur_set;  // the idle set
+    HIPCHK(hipEventSynchronize(e->evStaged[t]));  // its staging block is free again (the previous upload from it has finished)
+    double* h = e->stage_host[t];
+    const size_t nPin = (size_t)B * c.Nkin, nB = (size_t)B, nBias = (size_t)B * NROW;
+    const int ng1 = e->like_nG + 1;
+    const size_t nRows = rows ? (size_t)B * ng1 * NROW : 0;
+    double *hPin = h, *hF = hPin + nPin, *hDA = hF + nB, *hH = hDA + nB, *hBias = hH + nB, *hRows = hBias + nBias;
+    memcpy(hPin, Pin, nPin * sizeof(double));
+    memcpy(hF, f, nB * sizeof(double));
+    if (c.with_ap) {
+        memcpy(hDA, DA, nB * sizeof(double));
+        memcpy(hH, H, nB * sizeof(double));
+    }
+    if (bias) memcpy(hBias, bias, nBias * sizeof(double));
+    if (rows) memcpy(hRows, rows, nRows * sizeof(double));
+    hipStream_t cs = e->cpy;
+    HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[t], 0));  // the last run on this set (and the fetch of its results) is over
+    HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_PIN], hPin, nPin * sizeof(double), hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_F], hF, nB * sizeof(double), hipMemcpyHostToDevice, cs));
+    if (c.with_ap) {
+        HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_DA], hDA, nB * sizeof(double), hipMemcpyHostToDevice, cs));
+        HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_H], hH, nB * sizeof(double), hipMemcpyHostToDevice, cs));
+    }
+    if (bias) HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_BIAS], hBias, nBias * sizeof(double), hipMemcpyHostToDevice, cs));
+    if (rows)  // packed [B][nG+1][24] -> device rows of MARG_NG1
+        HIPCHK(hipMemcpy2DAsync(e->alt[EFTB_B_GROWS], (size_t)MARG_NG1 * NROW * sizeof(double), hRows, (size_t)ng1 * NROW * sizeof(double),
+                                (size_t)ng1 * NROW * sizeof(double), B, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipEventRecord(e->evStaged[t], cs));
+    e->staged_B = B;
+    return 0;
+}
+
+int eftb_run_staged(eftb_engine* e, int mask, int B) {
+    if (!e) return fail("eftb_run_staged: null engine");
+    if (!e->cpy || e->staged_B == 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
+    if (B != e->staged_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->staged_B);
+    HIPCHK(hipSetDevice(e->c.device));
+    for (int id : kStagedIds) std::swap(e->buf[id], e->alt[id]);
+    e->cur_set ^= 1;
+    e->staged_B = 0;
+    ++e->epoch;  // (captured graphs hold the other set's pointers)
+    HIPCHK(hipStreamWaitEvent(e->stream, e->evStaged[e->cur_set], 0));  // the side stream forks from here, so it inherits the wait
+    HIPCHK(hipStreamWaitEvent(e->pre, e->evStaged[e->cur_set], 0));
+    e->inputs_settled = true;
+    const int rc = run_stages(e, mask, B);
+    e->inputs_settled = false;
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], e->stream));
+    return 0;
+}
+
+int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) {
+    if (!e || !host) return fail("eftb_fetch_previous: null argument");
+    if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_previous: only EFTB_B_PLK and EFTB_B_LOGP are double-buffered outputs");
+    if (!e->cpy) return fail("eftb_fetch_previous: no staged run yet");
+    if (count > e->buf_elems[id]) return fail("eftb_fetch_previous: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
+    HIPCHK(hipSetDevice(e->c.device));
+    const int t = 1 - e->cur_set;
+    HIPCHK(hipStreamWaitEvent(e->cpy, e->evSetDone[t], 0));
+    HIPCHK(hipMemcpyAsync(host, e->alt[id], count * sizeof(double), hipMemcpyDeviceToHost, e->cpy));
+    HIPCHK(hipEventRecord(e->evSetDone[t], e->cpy));  // staging into this set has to wait for this read as well
+    HIPCHK(hipStreamSynchronize(e->cpy));
+    return 0;
 }
 
 int eftb_comm_unique_id(char id[128]) {

@@ -252,6 +252,29 @@ class Engine:
             return plk
         return (templ, plk) if bias is not None else templ
 
+    # ------------------------------------------------------------------ pipelined steps (double-buffered inputs / outputs)
+    def stage_inputs(self, Pin, f, DA=None, H=None, bias=None, rows=None):
+        """Copy the inputs of the NEXT step into the idle input set while the current step runs (``eftb_stage_inputs``)."""
+        B, Pin, f, DA, H = self._inputs(Pin, f, DA, H)
+        as2 = lambda x: None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+        bias, rows = as2(bias), as2(rows)
+        L.check(self.lib.eftb_stage_inputs(self._h, B, L.dptr(Pin), L.dptr(f), L.dptr(DA), L.dptr(H), L.dptr(bias), L.dptr(rows)))
+        return B
+
+    def run_staged(self, mask, B):
+        """Make the staged set current and launch (asynchronous; does not wait for the step in flight)."""
+        L.check(self.lib.eftb_run_staged(self._h, mask, B))
+        if mask & L.S_REGROUP:
+            self.dims = (self.Nl, self.Nk)
+        if mask & L.S_PROJECT:
+            self.dims = self.out_dims()
+
+    def fetch_previous(self, name, shape):
+        """PLK / LOGP of the step before the one in flight."""
+        out = np.empty(shape, dtype=np.float64)
+        L.check(self.lib.eftb_fetch_previous(self._h, L.B[name], L.dptr(out), out.size))
+        return out
+
     def pinned_empty(self, shape):
         """Page-locked float64 host array for eval_batch(out=...) / put / get."""
         return L.pinned_empty(shape)

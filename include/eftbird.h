@@ -196,6 +196,19 @@ int  eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, 
 int  eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H,
                           const double* rows, double* logp, double* fullchi2, double* best);
 
+/* Pipelined sampler steps.  The per-step inputs (Pin, f, DA, H, bias rows, likelihood rows) and outputs (EFTB_B_PLK, EFTB_B_LOGP)
+ * exist twice: while one set is being evaluated the host fills the other one, and fetches the results of the step before --
+ *     eftb_stage_inputs(step i+1);  eftb_run_staged(step i+1);  eftb_fetch_previous(step i);   ...
+ * nothing in this loop waits for the step in flight, so consecutive steps overlap on the GPU (the front half of step i+1 runs beside
+ * the resummation / AP of step i) and the PCIe traffic hides behind the kernels.  The host arrays may be reused as soon as
+ * eftb_stage_inputs returns (they are copied into page-locked staging memory).  bias ([B][24]) and rows (packed [B][nG+1][24])
+ * may be NULL.  No reference counterpart (cobaya evaluates one point at a time). */
+int  eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H,
+                       const double* bias, const double* rows);
+int  eftb_run_staged(eftb_engine* e, int stage_mask, int B);
+/* EFTB_B_PLK or EFTB_B_LOGP of the step before the one in flight (waits only for that step). */
+int  eftb_fetch_previous(eftb_engine* e, int buffer_id, double* host, size_t count);
+
 /* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
  * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */
 void* eftb_host_alloc(size_t bytes);

@@ -268,3 +268,42 @@ def test_graph_replay_is_bit_identical(golden):
         eng.run(eng.full_mask(), 3)
     assert np.array_equal(eng.get("TEMPL", (3, 3, 24, 25)), a)
     eng.close()
+
+
+def test_pipelined_steps_with_changing_inputs(golden):
+    """eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous: a sampler loop whose inputs change every step, with the next step's
+    inputs staged and the previous step's results fetched while a step is in flight -- every step must equal the synchronous call."""
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    B, nsteps = 4, 6
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=B)
+    rng = np.random.default_rng(8)
+    f0, DA0, H0 = float(g["f"]), float(g["DA"]), float(g["H"])
+    steps = []
+    for s in range(nsteps):
+        f = f0 * (1.0 + 0.05 * rng.uniform(-1, 1, B))
+        steps.append(dict(Pin=g["Pin"][None] * (1.0 + 0.2 * rng.uniform(-1, 1, (B, 1))), f=f, DA=DA0 * (1.0 + 0.03 * rng.uniform(-1, 1, B)),
+                          H=H0 * (1.0 + 0.03 * rng.uniform(-1, 1, B)),
+                          bias=np.stack([bias_row(fi, [2.0 + 0.1 * s, 0.5, 0.3, 0.2, -1.0, -2.0, 0.5], None, (0.3, 0.1, -0.4), kmA=0.7, krA=0.25, ndA=4.5e-5) for fi in f])))
+    want = [eng.eval_batch(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"], templates=False) for st in steps]
+    mask = eng.full_mask(reduce=True)
+    got = []
+    st = steps[0]
+    eng.stage_inputs(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"])
+    eng.run_staged(mask, B)
+    for s in range(1, nsteps):
+        st = steps[s]
+        eng.stage_inputs(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"])   # while step s - 1 runs
+        eng.run_staged(mask, B)                                                     # queued behind it, front half overlapping
+        got.append(eng.fetch_previous("PLK", (B, 3, g["k"].size)))                  # step s - 1
+    eng.sync()
+    got.append(eng.get("PLK", (B, 3, g["k"].size)))
+    for s in range(nsteps):
+        assert np.array_equal(got[s], want[s]), s
+    with pytest.raises(Exception):
+        eng.run_staged(mask, B)  # nothing staged
+    eng.close()

@@ -46,4 +46,24 @@ for name, fn in (("templates + P_l -> pageable host", lambda: eng.eval_batch(*ar
                  ("marginalised ln P only (eftb_eval_logp_batch)", lambda: like.eval_logp(*args, rows))):
     ms, r = rate(fn)
     print(f"{name:48s} {ms:7.3f} ms per {B} -> {r:9.0f} evaluations/s", flush=True)
+# pipelined: stage the next step, launch, fetch the previous step's results -- new inputs every step, nothing waits for the step in flight
+from eftpipe_amd import _lib as L
+
+draws = [synth.draw_batch(B, z=Z, seed=100 + i) for i in range(4)]
+for name, mask, out, shape, kw in (("pipelined, P_l back (eftb_stage_inputs / run_staged / fetch_previous)", eng.full_mask(reduce=True), "PLK", (B, 3, 512), dict(bias=bias)),
+                                  ("pipelined, marginalised ln P back", eng.full_mask() | L.S_LOGP, "LOGP", (B, 26), dict(rows=rows))):
+    n = 40
+    dd = draws[0]
+    eng.stage_inputs(dd["Pin"], dd["f"], dd["DA"], dd["H"], **kw)
+    eng.run_staged(mask, B)
+    t0 = time.perf_counter()
+    for i in range(1, n + 1):
+        dd = draws[i % 4]
+        eng.stage_inputs(dd["Pin"], dd["f"], dd["DA"], dd["H"], **kw)
+        eng.run_staged(mask, B)
+        res = eng.fetch_previous(out, shape)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / n
+    assert np.all(np.isfinite(res[:, :2]))
+    print(f"{name:48s} {dt * 1e3:7.3f} ms per {B} -> {B / dt:9.0f} evaluations/s", flush=True)
 eng.close()
