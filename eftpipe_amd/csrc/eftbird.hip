@@ -51,7 +51,7 @@ struct eftb_engine {
     // scratch
     double *SD = nullptr, *Talt = nullptr, *part = nullptr;
     double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][80][8], per-s records [B][NS][48]
-    double *APP = nullptr, *APR = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
+    double *APP = nullptr, *APR = nullptr, *APP2 = nullptr, *APR2 = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
     double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
     double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of the P22 basis [B][BAS22][KSYN] and of P13 [B][10][KLIN]
@@ -374,7 +374,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     // run on a side stream beside the (latency-bound) loop path and are joined right before their consumers.
     const bool side_ir = !nnlo_pass && (mask & EFTB_S_RESUM) && c.with_resum && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP));
     const bool side_ap = !nnlo_pass && (mask & EFTB_S_AP) && c.with_ap && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP | EFTB_S_RESUM));
-    if (side_ir || side_ap) {
+    // cross-run overlap of the front half (see engine.pre): only for asynchronous runs whose inputs are already in place
+    const bool pre_side = (mask & EFTB_S_PREP) && (mask & EFTB_S_REGROUP) && e->prep_overlap && e->inputs_settled && !e->use_graphs && !nnlo_pass &&
+                          !c.with_nnlo;  // (the NNLO pass of the previous run still reads CctNNLO late)
+    if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
         if (side_ir) launch_irfilter(e, e->side, B);
@@ -382,9 +385,6 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
     }
     bool joined = !(side_ir || side_ap);
-    // cross-run overlap of the first stage (see engine.pre): only for asynchronous runs whose inputs are already in place
-    const bool pre_side = (mask & EFTB_S_PREP) && (mask & EFTB_S_REGROUP) && e->prep_overlap && e->inputs_settled && !e->use_graphs && !nnlo_pass &&
-                          !c.with_nnlo;  // (the NNLO pass of the previous run still reads CctNNLO late)
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
         hipStream_t st0 = st;
@@ -449,6 +449,15 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     }
     if (pre_side) {
         if (hipEventRecord(e->evPrep, st) != hipSuccess || hipStreamWaitEvent(st_main, e->evPrep, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+        // the input-only kernels follow on the same stream: X, Y, Q(f) are free since the previous run built its resummation operands (that
+        // is what this stream waited for); the AP prefix sums alternate between two buffers because the previous run's AP reads its own late
+        if (side_ir) launch_irfilter(e, st, B);
+        if (side_ap) {
+            std::swap(e->APP, e->APP2);
+            std::swap(e->APR, e->APR2);
+            launch_ap_prefix(e, st, B);
+        }
+        if ((side_ir || side_ap) && hipEventRecord(e->evJoin, st) != hipSuccess) return fail("eftb_run: stream join failed");
         st = st_main;
     }
     if (mask & EFTB_S_REGROUP) {
@@ -754,6 +763,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         HIPCHK(hipMalloc(&e->SD, 2 * e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // (y, s) pairs of the splines
         HIPCHK(hipMalloc(&e->APP, (size_t)c.max_batch * (c.nmu + 1) * c.Nl * c.Nl * 4 * sizeof(double)));
         HIPCHK(hipMalloc(&e->APR, (size_t)c.max_batch * c.nmu * sizeof(double)));
+        HIPCHK(hipMalloc(&e->APP2, (size_t)c.max_batch * (c.nmu + 1) * c.Nl * c.Nl * 4 * sizeof(double)));
+        HIPCHK(hipMalloc(&e->APR2, (size_t)c.max_batch * c.nmu * sizeof(double)));
     }
     *out = e;
     return 0;
@@ -968,7 +979,7 @@ void eftb_destroy(eftb_engine* e) {
     drop_graphs(e);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
