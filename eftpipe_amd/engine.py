@@ -275,6 +275,25 @@ class Engine:
         L.check(self.lib.eftb_fetch_previous(self._h, L.B[name], L.dptr(out), out.size))
         return out
 
+    def pipeline(self, steps, mask=None, fetch="PLK"):
+        """Generator over a stream of steps (dicts with Pin, f, DA, H and bias and/or rows): stages step i + 1 and launches it
+        before fetching the results of step i, so the GPU never waits for the host.  Yields one result per step, in order:
+        P_l [B, nl, nx] (fetch="PLK", needs bias) or the raw LOGP block [walkers, 26] (fetch="LOGP", needs rows + a likelihood)."""
+        if mask is None:
+            mask = self.full_mask(reduce=(fetch == "PLK")) | (L.S_LOGP if fetch == "LOGP" else 0)
+        nl, nx = self.out_dims()
+        shape_of = lambda B: (B, nl, nx) if fetch == "PLK" else (B // self.ntracers, 2 + 24)
+        prev_B = None
+        for st in steps:
+            B = self.stage_inputs(st["Pin"], st["f"], st.get("DA"), st.get("H"), bias=st.get("bias"), rows=st.get("rows"))
+            self.run_staged(mask, B)
+            if prev_B is not None:
+                yield self.fetch_previous(fetch, shape_of(prev_B))
+            prev_B = B
+        if prev_B is not None:
+            self.sync()
+            yield self.get(fetch, shape_of(prev_B))
+
     def pinned_empty(self, shape):
         """Page-locked float64 host array for eval_batch(out=...) / put / get."""
         return L.pinned_empty(shape)

@@ -306,4 +306,7 @@ def test_pipelined_steps_with_changing_inputs(golden):
         assert np.array_equal(got[s], want[s]), s
     with pytest.raises(Exception):
         eng.run_staged(mask, B)  # nothing staged
+    # the same loop through the generator
+    for s, res in enumerate(eng.pipeline(steps)):
+        assert np.array_equal(res, want[s]), s
     eng.close()
