@@ -370,6 +370,13 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     hipStream_t st = e->stream;
     const int Nk = c.Nk, Nl = c.Nl;
     double** b = e->buf;
+    // every configuration error is raised before the first launch: no half-issued run is left behind on the look-ahead stream
+    if ((mask & (EFTB_S_CF | EFTB_K_C22)) && !c.with_resum) return fail("eftb_run: stage CF needs with_resum=1");
+    if ((mask & (EFTB_S_RESUM | EFTB_K_RESUM)) && !c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
+    if ((mask & EFTB_S_AP) && !c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
+    if ((mask & EFTB_S_PROJECT) && e->tracer_ops.empty() && e->pipeline_op < 0) return fail("eftb_run: stage PROJECT needs eftb_set_pipeline_operator");
+    if ((mask & EFTB_S_LOGP) && !e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
+    if ((mask & (EFTB_S_PROJECT | EFTB_S_LOGP)) && (B % e->ntr)) return fail("eftb_run: batch %d is not a multiple of the %d tracers per likelihood point", B, e->ntr);
     // The IR filters / Q(f) and the AP prefix sums depend on the inputs only: when they are part of a longer stage set they
     // run on a side stream beside the (latency-bound) loop path and are joined right before their consumers.
     const bool side_ir = !nnlo_pass && (mask & EFTB_S_RESUM) && c.with_resum && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP));
