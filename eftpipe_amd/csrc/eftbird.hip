@@ -705,7 +705,7 @@ static int run_stages(eftb_engine* e, int mask, int B) {
 extern "C" {
 
 const char* eftb_last_error(void) { return g_err.c_str(); }
-const char* eftb_version(void) { return "eftbird 0.2 (gfx950, fp64: anti-diagonal loops + mfma synthesis)"; }
+const char* eftb_version(void) { return "eftbird 0.3 (gfx950, fp64: anti-diagonal loops, mfma synthesis / resummation, overlapped steps)"; }
 
 int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (!cfg || !out) return fail("eftb_create: null argument");

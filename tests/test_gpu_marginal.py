@@ -167,3 +167,36 @@ def test_plain_chi2_without_marginalised_parameters(golden):
         r = np.einsum("r,lrx->lx", rows[i], (1.1 if i == 2 else 1.0) * T).reshape(-1)[index] - D
         assert np.isclose(logp[i], -0.5 * r @ C @ r, rtol=1e-11), i
     eng.close()
+
+
+def test_pipelined_steps_to_log_posterior(golden):
+    """Staged inputs + likelihood rows, theory + LOGP per step, results fetched one step behind (Engine.pipeline): every step must equal
+    the synchronous eftb_eval_logp_batch on the same inputs."""
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index, gaussian_rows
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    k = g["k"]
+    Bm, _, _, _ = TB.binning_operator(k, g["kout"])
+    nb = len(g["kout"])
+    B = 3
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=B)
+    eng.set_pipeline_operator(eng.add_operator(TB.compose_operator(3, k.size, binning=Bm)))
+    index = data_index([0, 2], {0: slice(0, nb), 2: slice(1, nb - 1)}, nb)
+    rng = np.random.default_rng(21)
+    f0, DA0, H0 = float(g["f"]), float(g["DA"]), float(g["H"])
+    mk = lambda: dict(Pin=g["Pin"][None] * (1.0 + 0.1 * rng.uniform(-1, 1, (B, 1))), f=f0 * (1.0 + 0.03 * rng.uniform(-1, 1, B)),
+                      DA=DA0 * (1.0 + 0.02 * rng.uniform(-1, 1, B)), H=H0 * (1.0 + 0.02 * rng.uniform(-1, 1, B)))
+    steps = [mk() for _ in range(5)]
+    for st in steps:
+        st["rows"] = np.stack([gaussian_rows(fi, (2.0 + 0.1 * rng.uniform(), 0.5, 0.3), None, 0.7, 0.25, 4.5e-5) for fi in st["f"]])
+    templ = eng.eval_batch(steps[0]["Pin"], steps[0]["f"], steps[0]["DA"], steps[0]["H"])
+    model = np.einsum("r,lrx->lx", steps[0]["rows"][0, 0], templ[0]).reshape(-1)[index]
+    sig = 0.05 * np.abs(model) + 10.0
+    like = MarginalLikelihood(eng, index, model * 1.02, np.diag(1.0 / sig**2), np.zeros(7), np.full(7, 3.0))
+    want = [like.eval_logp(st["Pin"], st["f"], st["DA"], st["H"], st["rows"]) for st in steps]
+    for s, res in enumerate(eng.pipeline(steps, fetch="LOGP")):
+        assert res.shape == (B, 26) and np.array_equal(res[:, 0], want[s]), s
+    eng.close()
