@@ -18,7 +18,7 @@ from eftpipe_amd.marginal import MarginalLikelihood, data_index
 from eftpipe_amd.parambasis import gaussian_rows
 from eftpipe_amd.tables import EngineConfig
 
-NW, NTR, NK = 42, 3, 512
+NW, NTR, NK = int(os.environ.get("CFG3_NW", 42)), 3, 512
 ZS = (0.696, 0.849, 0.763)
 k = synth.survey_kgrid(NK)
 cfg = EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, APst=True, DA_AP=float(synth.da_func(synth.OM_AP, 0.7)), H_AP=float(synth.hubble(synth.OM_AP, 0.7)))
