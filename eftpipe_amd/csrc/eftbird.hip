@@ -985,6 +985,7 @@ void eftb_destroy(eftb_engine* e) {
     (void)hipSetDevice(e->c.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
+    for (hipStream_t q : {e->pre, e->side, e->cpy}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work and staged uploads still in flight
     drop_graphs(e);
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
