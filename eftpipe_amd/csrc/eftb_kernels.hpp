@@ -1388,6 +1388,12 @@ __global__ __launch_bounds__(256, 2) void ap_apply_kernel(int Nk, int nmu, const
         }
 }
 
+// Staged inputs: page-locked host block -> device block, as a kernel on the copy stream (a DMA transfer brings cache maintenance on the
+// compute queue with it; this one is ordinary loads from mapped host memory and ordinary stores)
+__global__ __launch_bounds__(256) void stage_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // reduce: P_l(k) = sum_row bias[row] * T[l][row][k]  (reference parambasis.py:128-136)
 // ------------------------------------------------------------------------------------------------

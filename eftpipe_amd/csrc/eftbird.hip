@@ -89,13 +89,16 @@ struct eftb_engine {
     hipStream_t pre = nullptr;
     hipEvent_t evPrep = nullptr, evInFree = nullptr;
     bool prep_overlap = true, inputs_settled = false;  // EFTB_PREP_OVERLAP=0 disables; inputs_settled: set by eftb_run only
-    // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous): two sets of the per-step inputs (PIN, F, DA,
-    // H, BIAS, GROWS) and outputs (PLK, LOGP); the host fills the idle set through a copy stream while the other set is being evaluated
-    double* alt[EFTB_B_COUNT] = {nullptr};
-    double* stage_host[2] = {nullptr, nullptr};  // page-locked staging, one per set
+    // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous): three sets of the per-step inputs (PIN, F, DA,
+    // H, BIAS, GROWS) and outputs (PLK, LOGP) -- one being evaluated, one queued behind it, one whose results are being fetched / refilled
+    double* setbuf[3][EFTB_B_COUNT] = {{nullptr}};
+    double* setblock[3] = {nullptr, nullptr, nullptr};   // one contiguous input block per set (PIN, F, DA, H, BIAS, GROWS at stage_off[])
+    double* orig[EFTB_B_COUNT] = {nullptr};              // the engine's own buffers, current until the first staged run
+    size_t stage_off[EFTB_B_COUNT] = {0};
+    double* stage_host[3] = {nullptr, nullptr, nullptr};  // page-locked staging, one per set
     size_t stage_elems = 0;
     hipStream_t cpy = nullptr;
-    hipEvent_t evStaged[2] = {nullptr, nullptr}, evSetDone[2] = {nullptr, nullptr};
+    hipEvent_t evStaged[3] = {nullptr, nullptr, nullptr}, evSetDone[3] = {nullptr, nullptr, nullptr};
     int cur_set = 0, staged_B = 0;
     bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
@@ -732,9 +735,9 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_PREP_OVERLAP")) e->prep_overlap = atoi(f) != 0;
     int prio_lo = 0, prio_hi = 0;  // the main stream carries the critical path (resummation, AP): it gets the high priority, the
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // look-ahead stream the low one, so its kernels fill gaps instead of competing
-    HIPCHK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, getenv("EFTB_NOPRIO") ? 0 : prio_hi));
     HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_lo));
+    HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, getenv("EFTB_NOPRIO") ? 0 : prio_lo));
     HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evInFree, hipEventDisableTiming));
     HIPCHK(hipEventRecord(e->evInFree, e->pre));
@@ -987,6 +990,9 @@ void eftb_destroy(eftb_engine* e) {
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
     for (hipStream_t q : {e->pre, e->side, e->cpy}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work and staged uploads still in flight
     drop_graphs(e);
+    if (e->cpy)
+        for (int id = 0; id < EFTB_B_COUNT; ++id)
+            if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
     for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
@@ -996,12 +1002,13 @@ void eftb_destroy(eftb_engine* e) {
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered, e->evPrep, e->evInFree}) if (ev) (void)hipEventDestroy(ev);
     if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {
         if (e->evStaged[q]) (void)hipEventDestroy(e->evStaged[q]);
         if (e->evSetDone[q]) (void)hipEventDestroy(e->evSetDone[q]);
         if (e->stage_host[q]) (void)hipHostFree(e->stage_host[q]);
+        if (e->setblock[q]) (void)hipFree(e->setblock[q]);
+        for (int id : {EFTB_B_PLK, EFTB_B_LOGP}) if (e->setbuf[q][id]) (void)hipHostFree(e->setbuf[q][id]);
     }
-    for (auto& p : e->alt) if (p) (void)hipFree(p);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1147,23 +1154,44 @@ void eftb_host_free(void* p) {
 
 static const int kStagedIds[] = {EFTB_B_PIN, EFTB_B_F, EFTB_B_DA, EFTB_B_H, EFTB_B_BIAS, EFTB_B_GROWS, EFTB_B_PLK, EFTB_B_LOGP};
 
+static const int kStagedIn[] = {EFTB_B_PIN, EFTB_B_F, EFTB_B_DA, EFTB_B_H, EFTB_B_BIAS, EFTB_B_GROWS};  // order inside a set's input block
+static const int kStagedOut[] = {EFTB_B_PLK, EFTB_B_LOGP};
+
+// Every set keeps its inputs in ONE device block with the layout of the page-locked staging block, so that staging is a single
+// large asynchronous copy (small separate copies are carried out by the host thread once the stream's dependencies have resolved,
+// which would stall the sampler loop for a whole step).
 static int staged_setup(eftb_engine* e) {
     if (e->cpy) return 0;
     HIPCHK(hipSetDevice(e->c.device));
-    HIPCHK(hipStreamCreateWithFlags(&e->cpy, hipStreamNonBlocking));
-    for (int id : kStagedIds)
-        if (e->buf_elems[id]) {
-            HIPCHK(hipMalloc(&e->alt[id], e->buf_elems[id] * sizeof(double)));
-            HIPCHK(hipMemset(e->alt[id], 0, e->buf_elems[id] * sizeof(double)));
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    HIPCHK(hipStreamCreateWithPriority(&e->cpy, hipStreamNonBlocking, prio_hi));
+    size_t off = 0;
+    for (int id : kStagedIn) {
+        e->stage_off[id] = off;
+        off += e->buf_elems[id];
+    }
+    e->stage_elems = (off + 1) & ~(size_t)1;  // whole double2s for the copy kernel
+    for (int id : kStagedIds) e->orig[id] = e->buf[id];
+    for (int q = 0; q < 3; ++q) {
+        HIPCHK(hipMalloc(&e->setblock[q], e->stage_elems * sizeof(double)));
+        HIPCHK(hipMemset(e->setblock[q], 0, e->stage_elems * sizeof(double)));
+        for (int id : kStagedIn) e->setbuf[q][id] = e->buf_elems[id] ? e->setblock[q] + e->stage_off[id] : nullptr;
+        // the per-step outputs (P_l, ln P) live in page-locked host memory mapped into the device: the kernels write them over PCIe
+        // as they finish, and fetching is a wait on the step's event plus a host copy -- no D2H transfer, whose cache maintenance
+        // was measured to stall the compute queue for ~70 us per step
+        for (int id : kStagedOut) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double), hipHostMallocMapped));
+            memset(e->setbuf[q][id], 0, e->buf_elems[id] * sizeof(double));
         }
-    e->stage_elems = e->buf_elems[EFTB_B_PIN] + 3 * (size_t)e->c.max_batch + e->buf_elems[EFTB_B_BIAS] + e->buf_elems[EFTB_B_GROWS];
-    for (int q = 0; q < 2; ++q) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->stage_host[q]), e->stage_elems * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->stage_host[q]), e->stage_elems * sizeof(double), hipHostMallocMapped));
+        memset(e->stage_host[q], 0, e->stage_elems * sizeof(double));
         HIPCHK(hipEventCreateWithFlags(&e->evStaged[q], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&e->evSetDone[q], hipEventDisableTiming));
         HIPCHK(hipEventRecord(e->evStaged[q], e->cpy));
         HIPCHK(hipEventRecord(e->evSetDone[q], e->cpy));
     }
+    e->cur_set = 2;  // the engine's own buffers are current until the first eftb_run_staged; sets 0, 1, 2 follow in turn
     return 0;
 }
 
@@ -1177,33 +1205,25 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     if (rows && !e->like_ndata) return fail("eftb_stage_inputs: rows need eftb_set_likelihood");
     if (int rc = staged_setup(e)) return rc;
     HIPCHK(hipSetDevice(c.device));
-    const int t = 1 - e->cur_set;  // the idle set
+    const int t = (e->cur_set + 1) % 3;  // the set after the current one: its last run was fetched two steps ago
     HIPCHK(hipEventSynchronize(e->evStaged[t]));  // its staging block is free again (the previous upload from it has finished)
     double* h = e->stage_host[t];
-    const size_t nPin = (size_t)B * c.Nkin, nB = (size_t)B, nBias = (size_t)B * NROW;
-    const int ng1 = e->like_nG + 1;
-    const size_t nRows = rows ? (size_t)B * ng1 * NROW : 0;
-    double *hPin = h, *hF = hPin + nPin, *hDA = hF + nB, *hH = hDA + nB, *hBias = hH + nB, *hRows = hBias + nBias;
-    memcpy(hPin, Pin, nPin * sizeof(double));
-    memcpy(hF, f, nB * sizeof(double));
+    memcpy(h + e->stage_off[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double));
+    memcpy(h + e->stage_off[EFTB_B_F], f, (size_t)B * sizeof(double));
     if (c.with_ap) {
-        memcpy(hDA, DA, nB * sizeof(double));
-        memcpy(hH, H, nB * sizeof(double));
+        memcpy(h + e->stage_off[EFTB_B_DA], DA, (size_t)B * sizeof(double));
+        memcpy(h + e->stage_off[EFTB_B_H], H, (size_t)B * sizeof(double));
     }
-    if (bias) memcpy(hBias, bias, nBias * sizeof(double));
-    if (rows) memcpy(hRows, rows, nRows * sizeof(double));
+    if (bias) memcpy(h + e->stage_off[EFTB_B_BIAS], bias, (size_t)B * NROW * sizeof(double));
+    if (rows) {  // packed [B][nG+1][24] -> device rows of MARG_NG1
+        const int ng1 = e->like_nG + 1;
+        for (int w = 0; w < B; ++w)
+            memcpy(h + e->stage_off[EFTB_B_GROWS] + (size_t)w * MARG_NG1 * NROW, rows + (size_t)w * ng1 * NROW, (size_t)ng1 * NROW * sizeof(double));
+    }
     hipStream_t cs = e->cpy;
     HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[t], 0));  // the last run on this set (and the fetch of its results) is over
-    HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_PIN], hPin, nPin * sizeof(double), hipMemcpyHostToDevice, cs));
-    HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_F], hF, nB * sizeof(double), hipMemcpyHostToDevice, cs));
-    if (c.with_ap) {
-        HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_DA], hDA, nB * sizeof(double), hipMemcpyHostToDevice, cs));
-        HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_H], hH, nB * sizeof(double), hipMemcpyHostToDevice, cs));
-    }
-    if (bias) HIPCHK(hipMemcpyAsync(e->alt[EFTB_B_BIAS], hBias, nBias * sizeof(double), hipMemcpyHostToDevice, cs));
-    if (rows)  // packed [B][nG+1][24] -> device rows of MARG_NG1
-        HIPCHK(hipMemcpy2DAsync(e->alt[EFTB_B_GROWS], (size_t)MARG_NG1 * NROW * sizeof(double), hRows, (size_t)ng1 * NROW * sizeof(double),
-                                (size_t)ng1 * NROW * sizeof(double), B, hipMemcpyHostToDevice, cs));
+    hipLaunchKernelGGL(stage_copy_kernel, dim3(64), dim3(256), 0, cs, reinterpret_cast<const double2*>(h), reinterpret_cast<double2*>(e->setblock[t]),
+                       (e->stage_elems + 1) / 2);
     HIPCHK(hipEventRecord(e->evStaged[t], cs));
     e->staged_B = B;
     return 0;
@@ -1214,8 +1234,9 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     if (!e->cpy || e->staged_B == 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
     if (B != e->staged_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->staged_B);
     HIPCHK(hipSetDevice(e->c.device));
-    for (int id : kStagedIds) std::swap(e->buf[id], e->alt[id]);
-    e->cur_set ^= 1;
+    e->cur_set = (e->cur_set + 1) % 3;
+    for (int id : kStagedIds)
+        if (e->setbuf[e->cur_set][id]) e->buf[id] = e->setbuf[e->cur_set][id];
     e->staged_B = 0;
     ++e->epoch;  // (captured graphs hold the other set's pointers)
     HIPCHK(hipStreamWaitEvent(e->stream, e->evStaged[e->cur_set], 0));  // the side stream forks from here, so it inherits the wait
@@ -1234,11 +1255,15 @@ int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) {
     if (!e->cpy) return fail("eftb_fetch_previous: no staged run yet");
     if (count > e->buf_elems[id]) return fail("eftb_fetch_previous: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
     HIPCHK(hipSetDevice(e->c.device));
-    const int t = 1 - e->cur_set;
-    HIPCHK(hipStreamWaitEvent(e->cpy, e->evSetDone[t], 0));
-    HIPCHK(hipMemcpyAsync(host, e->alt[id], count * sizeof(double), hipMemcpyDeviceToHost, e->cpy));
-    HIPCHK(hipEventRecord(e->evSetDone[t], e->cpy));  // staging into this set has to wait for this read as well
-    HIPCHK(hipStreamSynchronize(e->cpy));
+    const int t = (e->cur_set + 2) % 3;  // the set of the step before the current one
+    // spin on the step's event instead of sleeping in a synchronize call: the sampler thread is about to enqueue the next step, and the
+    // wake-up latency of a blocking wait would be paid once per step
+    for (;;) {
+        const hipError_t q = hipEventQuery(e->evSetDone[t]);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail("eftb_fetch_previous: %s", hipGetErrorString(q));
+    }
+    memcpy(host, e->setbuf[t][id], count * sizeof(double));  // the results are already in (mapped) host memory
     return 0;
 }
 

@@ -197,7 +197,7 @@ int  eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double
                           const double* rows, double* logp, double* fullchi2, double* best);
 
 /* Pipelined sampler steps.  The per-step inputs (Pin, f, DA, H, bias rows, likelihood rows) and outputs (EFTB_B_PLK, EFTB_B_LOGP)
- * exist twice: while one set is being evaluated the host fills the other one, and fetches the results of the step before --
+ * exist three times: one set is being evaluated, the next is already queued behind it, the third is being fetched from / refilled --
  *     eftb_stage_inputs(step i+1);  eftb_run_staged(step i+1);  eftb_fetch_previous(step i);   ...
  * nothing in this loop waits for the step in flight, so consecutive steps overlap on the GPU (the front half of step i+1 runs beside
  * the resummation / AP of step i) and the PCIe traffic hides behind the kernels.  The host arrays may be reused as soon as
