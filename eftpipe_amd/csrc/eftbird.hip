@@ -735,9 +735,9 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_PREP_OVERLAP")) e->prep_overlap = atoi(f) != 0;
     int prio_lo = 0, prio_hi = 0;  // the main stream carries the critical path (resummation, AP): it gets the high priority, the
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // look-ahead stream the low one, so its kernels fill gaps instead of competing
-    HIPCHK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, getenv("EFTB_NOPRIO") ? 0 : prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi));
     HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, getenv("EFTB_NOPRIO") ? 0 : prio_lo));
+    HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_lo));
     HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evInFree, hipEventDisableTiming));
     HIPCHK(hipEventRecord(e->evInFree, e->pre));
