@@ -1394,6 +1394,11 @@ __global__ __launch_bounds__(256) void stage_copy_kernel(const double2* __restri
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// device-to-device snapshot as a kernel, for the same reason (P_l of a step, taken before the RCCL exchange on the communication stream)
+__global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // reduce: P_l(k) = sum_row bias[row] * T[l][row][k]  (reference parambasis.py:128-136)
 // ------------------------------------------------------------------------------------------------
