@@ -1588,6 +1588,64 @@ __global__ __launch_bounds__(256) void marg_solve_kernel(int ndata, int nG, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Window precompute (reference window.py:262-359).  tables.py window_tables collapses the reference's per-(a, l, k)
+// FFTLog(4096) + power-law sum into  W_al(k, p) = sum_i Qt_al[i] j_{2a}(k x_i) T_l[i][p]:  window_bessel_kernel writes the
+// left factor A[a][l][k][i] = Qt_al[i] j_{2a}(k x_i), gemm_rows_kernel multiplies it with T_l on the matrix cores (one launch
+// per l, rows = (a, k)), window_maskdp_kernel applies the |p - k| < windowk band and the trapezoid dp weights, and a last
+// gemm_rows_kernel folds the k -> p cubic spline in (Wfold = Waldk S), so Window.Window is one dense operator.
+// ------------------------------------------------------------------------------------------------
+// spherical Bessel j_0, j_2, j_4: ascending series below x = 4 (the closed forms cancel like x^-(2n+1) there), upward
+// recurrence from sin / cos above (stable for x > n)
+__device__ inline void sph_j024(double x, double j[3]) {
+    if (x < 4.0) {
+        const double h = -0.5 * x * x;
+        const double lead[3] = {1.0, x * x / 15.0, x * x * x * x / 945.0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int n = 2 * a;
+            double t = 1.0, sum = 1.0;
+#pragma unroll 4
+            for (int m = 1; m <= 24; ++m) {
+                t *= h / (double)(m * (2 * n + 2 * m + 1));
+                sum += t;
+            }
+            j[a] = lead[a] * sum;
+        }
+    } else {
+        double sn, cs;
+        sincos(x, &sn, &cs);
+        const double r = 1.0 / x;
+        const double j0 = sn * r, j1 = (sn * r - cs) * r;
+        const double j2 = 3.0 * r * j1 - j0, j3 = 5.0 * r * j2 - j1;
+        j[0] = j0; j[1] = j2; j[2] = 7.0 * r * j3 - j2;
+    }
+}
+
+__global__ __launch_bounds__(256) void window_bessel_kernel(int Na, int Nl, int Nk, int nx, const double* __restrict__ k,
+                                                            const double* __restrict__ x, const double* __restrict__ Qt,
+                                                            double* __restrict__ A) {
+    const int i = blockIdx.x * 256 + threadIdx.x, kk = blockIdx.y;
+    if (i >= nx || kk >= Nk) return;
+    double j[3];
+    sph_j024(k[kk] * x[i], j);
+    for (int a = 0; a < Na; ++a)
+        for (int l = 0; l < Nl; ++l) A[(((size_t)a * Nl + l) * Nk + kk) * nx + i] = Qt[((size_t)a * Nl + l) * nx + i] * j[a];
+}
+
+// Waldk[r][k][p] = Wal[r][k][p] * [k - windowk < p < k + windowk] * (p_p - p_{p-1})   (reference window.py:348-359), r = (a, l)
+__global__ __launch_bounds__(256) void window_maskdp_kernel(int R, int Nk, int Np, const double* __restrict__ k, const double* __restrict__ p,
+                                                            int withmask, double windowk, const double* __restrict__ Wal,
+                                                            double* __restrict__ Waldk) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)R * Nk * Np) return;
+    const int ip = (int)(idx % Np), ik = (int)((idx / Np) % Nk);
+    const double pv = p[ip], kv = k[ik];
+    const double dp = ip ? pv - p[ip - 1] : 0.0;
+    const bool in = !withmask || (pv < kv + windowk && pv > kv - windowk);
+    Waldk[idx] = in ? Wal[idx] * dp : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // FP64 MFMA issue-rate microbenchmark (roofline denominator): NACC independent accumulator chains.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(int iters, double* sink) {

@@ -1370,4 +1370,74 @@ int eftb_mfma_f64_peak(int device, double* tflops) {
     return 0;
 }
 
+/* Window precompute on the device (reference window.py:262-359); see window_bessel_kernel. */
+int eftb_window_precompute(int device, int Na, int Nl, int Nk, int nx, int Np, const double* k, const double* x, const double* Qt,
+                           const double* T, const double* p, int withmask, double windowk, const double* S, double* Wal,
+                           double* Waldk, double* Wfold, double* device_ms) {
+    if (!k || !x || !Qt || !T || !p || !Wal) return fail("eftb_window_precompute: null argument");
+    if (Na < 1 || Na > 3 || Nl < 1 || Nl > 3 || Na > Nl) return fail("eftb_window_precompute: need 1 <= Na <= Nl <= 3 (got Na=%d, Nl=%d)", Na, Nl);
+    if (Nk < 1 || nx < 1 || Np < 1 || Nk > 65535) return fail("eftb_window_precompute: bad sizes Nk=%d nx=%d Np=%d", Nk, nx, Np);
+    if ((Waldk || Wfold) && !(windowk > 0.0)) return fail("eftb_window_precompute: windowk must be positive");
+    if (Wfold && !S) return fail("eftb_window_precompute: Wfold needs the spline matrix S [Np][Nk]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("eftb_window_precompute: no HIP device visible");
+    HIPCHK(hipSetDevice(device));
+    const size_t R = (size_t)Na * Nl, nW = R * Nk * Np;
+    struct Pool {
+        std::vector<void*> v;
+        ~Pool() { for (void* q : v) (void)hipFree(q); }
+    } pool;
+    auto dalloc = [&](size_t n, double** out) -> hipError_t {
+        hipError_t st = hipMalloc((void**)out, n * sizeof(double));
+        if (st == hipSuccess) pool.v.push_back(*out);
+        return st;
+    };
+    double *dk, *dx, *dQ, *dT, *dp, *dA, *dW, *dWd = nullptr, *dS = nullptr, *dF = nullptr;
+    HIPCHK(dalloc(Nk, &dk)); HIPCHK(dalloc(nx, &dx)); HIPCHK(dalloc(R * nx, &dQ)); HIPCHK(dalloc((size_t)Nl * nx * Np, &dT));
+    HIPCHK(dalloc(Np, &dp)); HIPCHK(dalloc(R * Nk * nx, &dA)); HIPCHK(dalloc(nW, &dW));
+    if (Waldk || Wfold) HIPCHK(dalloc(nW, &dWd));
+    if (Wfold) { HIPCHK(dalloc((size_t)Np * Nk, &dS)); HIPCHK(dalloc(R * Nk * Nk, &dF)); }
+    HIPCHK(hipMemcpy(dk, k, Nk * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dx, x, nx * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dQ, Qt, R * nx * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dT, T, (size_t)Nl * nx * Np * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp, p, Np * sizeof(double), hipMemcpyHostToDevice));
+    if (Wfold) HIPCHK(hipMemcpy(dS, S, (size_t)Np * Nk * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t ev0, ev1;
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    HIPCHK(hipEventRecord(ev0, 0));
+    hipLaunchKernelGGL(window_bessel_kernel, dim3((nx + 255) / 256, Nk), dim3(256), 0, 0, Na, Nl, Nk, nx, dk, dx, dQ, dA);
+    for (int l = 0; l < Nl; ++l) {  // rows = (a, k), A_al [Nk][nx] @ T_l [nx][Np]
+        GemmDesc g{};
+        g.A = dA + (size_t)l * Nk * nx; g.a_group = (long long)Nl * Nk * nx; g.a_row = nx; g.a_seg = 0;
+        g.rows = Na * Nk; g.rows_per_group = Nk; g.nseg = 1; g.kseg = nx;
+        g.B = dT + (size_t)l * nx * Np; g.ldb = Np; g.ncols = Np;
+        g.C = dW + (size_t)l * Nk * Np; g.c_group = (long long)Nl * Nk * Np; g.c_row = Np; g.c_colgroup = 0; g.cols_per_group = Np;
+        hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, 0, g);
+    }
+    if (dWd) hipLaunchKernelGGL(window_maskdp_kernel, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, 0, (int)R, Nk, Np, dk, dp, withmask, windowk, dW, dWd);
+    if (Wfold) {  // rows = (a, l, k), Waldk [.][Np] @ S [Np][Nk]
+        GemmDesc g{};
+        g.A = dWd; g.a_group = 0; g.a_row = Np; g.a_seg = 0;
+        g.rows = (int)(R * Nk); g.rows_per_group = g.rows; g.nseg = 1; g.kseg = Np;
+        g.B = dS; g.ldb = Nk; g.ncols = Nk;
+        g.C = dF; g.c_group = 0; g.c_row = Nk; g.c_colgroup = 0; g.cols_per_group = Nk;
+        hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, 0, g);
+    }
+    HIPCHK(hipEventRecord(ev1, 0));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+    if (device_ms) *device_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    HIPCHK(hipMemcpy(Wal, dW, nW * sizeof(double), hipMemcpyDeviceToHost));
+    if (Waldk) HIPCHK(hipMemcpy(Waldk, dWd, nW * sizeof(double), hipMemcpyDeviceToHost));
+    if (Wfold) HIPCHK(hipMemcpy(Wfold, dF, R * Nk * Nk * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // extern "C"

@@ -527,13 +527,15 @@ _CALQ = np.array(
 )  # (2a+1) (a l q; 0 0 0)^2, reference window.py:286-303
 
 
-def window_matrix(k, sw, Qq, Na, Nl, accboost=1, Nmax=4096, xmin_factor=1.0, xmax_factor=100.0, bias=-1.6,
+def window_tables(k, sw, Qq, Na, Nl, accboost=1, Nmax=4096, xmin_factor=1.0, xmax_factor=100.0, bias=-1.6,
                   window_param=1, pmax=None):
-    """W_{a l}(k, p) [Na, Nl, Nk, Np] and the p grid from a configuration-space window Q_q(s)
-    (reference window.py:262-346): FFTLog(Nmax) of Q_{al}(s) j_{2a}(k s) followed by the j_{2l}(p s) sum.
-    One real FFT batch per (a, l) and one (Nk x Nmax+1) @ (Nmax+1 x Np) product."""
-    from numpy.fft import rfft
-
+    """k-independent tables of the window precompute (reference window.py:262-346).  The reference takes, per (a, l, k),
+    the FFTLog(Nmax) of Q_{al}(s) j_{2a}(k s) and sums the coefficients against p^{-Pow-3}; the FFT and the sum are both
+    linear in the sampled integrand, so they collapse into one real table per l,
+        T_l[i, p] = p^2 Re sum_m e^{-2 pi i (m - N/2) i / N} w_l[m] p^{-Pow_m - 3},
+    and  W_{al}(k, p) = sum_i (-1)^a Qt_{al}[i] j_{2a}(k x_i) T_l[i, p]  with Qt = Q_{al}(x_i) e^{-bias i dx}: a dense
+    (Nk x nx) @ (nx x Np) product whose left factor is generated from Bessel functions (eftb_window_wal on the device).
+    Returns x [nx], Qt [Na, Nl, nx] (sign included), T [Nl, nx, Np], p [Np]."""
     k = np.asarray(k, dtype=float)
     Nq = Qq.shape[0]
     Qal = np.einsum("alq,qs->als", _CALQ[:Na, :Nl, :Nq], Qq)
@@ -547,20 +549,28 @@ def window_matrix(k, sw, Qq, Na, Nl, accboost=1, Nmax=4096, xmin_factor=1.0, xma
     cw = xmin ** (-Pow) / float(N) * edge_window(N, window_param)
     lo, hi = int(np.searchsorted(x, sw[0])), int(np.searchsorted(x, sw[-1], side="right"))
     Qx = CubicSpline(sw, Qal, axis=-1, extrapolate=False)(x[lo:hi])          # [Na,Nl,nx]
-    tilt = np.exp(-bias * i[lo:hi] * dx)
-    pPow = np.exp(np.outer(-Pow - 3.0, np.log(p)))                           # [N+1,Np]
+    sign = np.real((-1j) ** (2 * np.arange(Na)))                               # (-i)^{2a}
+    Qt = Qx * np.exp(-bias * i[lo:hi] * dx) * sign[:, None, None]
+    pPow = np.exp(np.outer(-Pow - 3.0, np.log(p))) * p**2                      # [N+1,Np]
+    alt = np.where(i[lo:hi] % 2 == 0, 1.0, -1.0)[:, None]
+    T = np.empty((Nl, hi - lo, p.size))
+    for l in range(Nl):
+        a = (cw * (1j) ** (2 * l) * 4.0 * np.pi * lm.bessel_weight(2 * l, -0.5 * Pow))[:, None] * pPow
+        T[l] = alt * np.real(np.fft.fft(a[:N], axis=0)[lo:hi] + a[N])
+    return x[lo:hi].copy(), np.ascontiguousarray(Qt), T, p
+
+
+def window_matrix(k, sw, Qq, Na, Nl, **kw):
+    """W_{al}(k, p) [Na, Nl, Nk, Np] and the p grid from a configuration-space window Q_q(s) (reference window.py:262-346)
+    on the host, through window_tables: the table-building restatement the device version (window.window_matrix_device)
+    is checked against."""
+    x, Qt, T, p = window_tables(k, sw, Qq, Na, Nl, **kw)
+    k = np.asarray(k, dtype=float)
     Wal = np.empty((Na, Nl, k.size, p.size))
     for a in range(Na):
-        jk = spherical_jn(2 * a, x[lo:hi][None, :] * k[:, None])             # [Nk,nx]
+        jk = spherical_jn(2 * a, x[None, :] * k[:, None])                    # [Nk,nx]
         for l in range(Nl):
-            fx = np.zeros((k.size, N))
-            fx[:, lo:hi] = (Qx[a, l] * tilt)[None, :] * jk
-            half = rfft(fx, axis=-1)
-            c = np.empty((k.size, N + 1), dtype=complex)
-            c[:, : N // 2] = np.conj(half[:, 1:][:, ::-1])
-            c[:, N // 2 :] = half
-            weight = cw * ((-1j) ** (2 * a) * (1j) ** (2 * l)) * 4.0 * np.pi * lm.bessel_weight(2 * l, -0.5 * Pow)
-            Wal[a, l] = p**2 * np.real((c * weight[None, :]) @ pPow)
+            Wal[a, l] = (jk * Qt[a, l]) @ T[l]
     return Wal, p
 
 

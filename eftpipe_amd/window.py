@@ -1,7 +1,8 @@
 """Survey-window convolution (same surface as reference eftpipe/window.py:40-415).
 
-Init (host): W_{al}(k, p) from the configuration-space window by FFTLog (tables.window_matrix), or from an
-existing ``*.npy`` cache written by the reference (same array layout [Na, Nl, Nk, Np]); the band mask, the
+Init: W_{al}(k, p) from the configuration-space window on the device (window_matrix_device: k-independent tables from
+tables.window_tables on the host, Bessel factor + FP64-MFMA products + mask / dp / spline fold in eftb_window_precompute),
+or from an existing ``*.npy`` cache written by the reference (same array layout [Na, Nl, Nk, Np]); the band mask, the
 dp weights and the cubic spline k -> p are folded into one dense [Na, Nl, Nk, Nk] operator.
 Per evaluation (device): one FP64-MFMA GEMM over the template block (gemm_rows_kernel)."""
 from __future__ import annotations
@@ -13,12 +14,40 @@ from typing import NamedTuple
 import numpy as np
 
 from ._log import HasLogger
-from .tables import window_fold, window_matrix, window_pgrid
+from .tables import spline_matrix, window_fold, window_pgrid, window_tables
 from .transformer import apply_operator_to_birdlike
 
 
 class MetaInfoError(Exception):
     pass
+
+
+def window_matrix_device(k, sw, Qq, Na, Nl, withmask=True, windowk=0.05, device=0, timing=None, **kw):
+    """Wal [Na, Nl, Nk, Np], p, Waldk, Wfold [Na, Nl, Nk, Nk] through eftb_window_precompute (reference window.py:262-359);
+    kw as tables.window_tables.  ``timing`` (a dict) receives the host-table and device-kernel times."""
+    import ctypes as C
+    import time
+
+    from . import _lib as L
+
+    lib = L.load()
+    k = np.ascontiguousarray(k, dtype=np.float64)
+    t0 = time.perf_counter()
+    x, Qt, T, p = window_tables(k, sw, Qq, Na, Nl, **kw)
+    S = np.ascontiguousarray(spline_matrix(k, p))
+    t1 = time.perf_counter()
+    Wal = np.empty((Na, Nl, k.size, p.size))
+    Waldk = np.empty_like(Wal)
+    Wfold = np.empty((Na, Nl, k.size, k.size))
+    ms = C.c_double()
+    T = np.ascontiguousarray(T)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    L.check(lib.eftb_window_precompute(device, Na, Nl, k.size, x.size, p.size, L.dptr(k), L.dptr(x), L.dptr(Qt), L.dptr(T), L.dptr(p),
+                                       int(bool(withmask)), float(windowk), L.dptr(S), L.dptr(Wal), L.dptr(Waldk), L.dptr(Wfold),
+                                       C.cast(C.byref(ms), C.POINTER(C.c_double))))
+    if timing is not None:
+        timing.update(host_tables_s=t1 - t0, device_kernels_ms=ms.value, call_s=time.perf_counter() - t1)
+    return Wal, p, Waldk, Wfold
 
 
 class Window(HasLogger):
@@ -55,8 +84,9 @@ class Window(HasLogger):
         self.Wal = self._load_Wal(load, check_meta)
         computed = self.Wal is None
         if computed:
-            self.Wal = self._compute_Wal()
-        self.Wfold, self.Waldk = window_fold(self.co.k, self.Wal, self.p, windowk=windowk, withmask=withmask)
+            self.Wal, self.Waldk, self.Wfold = self._compute_Wal()
+        else:  # cached matrix (possibly written by the reference): only the fold is left to do
+            self.Wfold, self.Waldk = window_fold(self.co.k, self.Wal, self.p, windowk=windowk, withmask=withmask)
         if save and computed and self.window_fourier_file is not None:
             self._save_Wal()
         self.snapshot = snapshot
@@ -95,11 +125,12 @@ class Window(HasLogger):
             tab = tab[1:]
         m = self.meta
         tab = tab[:, : 1 + m["Nq"]]
-        Wal, p = window_matrix(self.co.k, tab[:, 0], tab[:, 1:].T, m["Na"], m["Nl"], accboost=m["accboost"], Nmax=m["Nmax"],
-                               xmin_factor=m["xmin_factor"], xmax_factor=m["xmax_factor"], bias=m["bias"],
-                               window_param=m["window_param"], pmax=m["pmax"])
+        Wal, p, Waldk, Wfold = window_matrix_device(self.co.k, tab[:, 0], tab[:, 1:].T, m["Na"], m["Nl"], withmask=self.withmask,
+                                                    windowk=self.windowk, device=0, accboost=m["accboost"],
+                                                    Nmax=m["Nmax"], xmin_factor=m["xmin_factor"], xmax_factor=m["xmax_factor"],
+                                                    bias=m["bias"], window_param=m["window_param"], pmax=m["pmax"])
         assert np.array_equal(p, self.p)
-        return Wal
+        return Wal, Waldk, Wfold
 
     def Window(self, bird):
         """Convolve P11l, Pctl, Ploopl (and Pstl if window_st) in place (reference window.py:389-415)."""

@@ -225,6 +225,17 @@ int  eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]);
  * if host_out != NULL (root only) the gathered block [nranks][B][Nl][Nx] is copied out after the gather. */
 int  eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out);
 
+/* Window precompute (reference Window._compute_Wal / _compute_Waldk, window.py:262-359) on the device.  The caller passes
+ * the k-independent tables of eftpipe_amd.tables.window_tables: x [nx] (FFTLog samples inside the tabulated window), Qt
+ * [Na][Nl][nx] (Q_al(x) with the FFTLog tilt and (-1)^a), T [Nl][nx][Np] (FFT + power-law sum collapsed per l) and the p grid;
+ *   Wal [Na][Nl][Nk][Np]  = sum_i Qt_al[i] j_{2a}(k x_i) T_l[i][p]                (the reference's *.npy cache content)
+ *   Waldk (optional)      = Wal * [|p - k| < windowk, if withmask] * dp            (window.py:348-359)
+ *   Wfold (optional, needs S [Np][Nk], the k -> p cubic-spline matrix) = Waldk S  [Na][Nl][Nk][Nk], what Window.Window applies.
+ * All pointers are host buffers, C-contiguous float64; device_ms (optional) receives the kernel time without the copies. */
+int  eftb_window_precompute(int device, int Na, int Nl, int Nk, int nx, int Np, const double* k, const double* x,
+                            const double* Qt, const double* T, const double* p, int withmask, double windowk,
+                            const double* S, double* Wal, double* Waldk, double* Wfold, double* device_ms);
+
 /* Measured FP64 MFMA issue rate (v_mfma_f64_16x16x4_f64), TFLOP/s, for the roofline denominator. */
 int  eftb_mfma_f64_peak(int device, double* tflops);
 

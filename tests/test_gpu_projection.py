@@ -398,3 +398,47 @@ def test_three_tracers_per_likelihood_point(golden):
     with pytest.raises(Exception):
         eng.run(eng.full_mask(), 5)  # not a multiple of the three tracers
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["caseC", "caseG"])
+def test_window_precompute_device(golden, case):
+    """W_al(k, p), the masked dp-weighted Waldk and the folded operator from eftb_window_precompute against the
+    reference's own Waldk (window.py:262-359; fixtures hold one k row and the p sums) and against the host table builder."""
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.window import window_matrix_device
+
+    g = golden(case)
+    k = g["k"]
+    tab = np.load(WIN)
+    timing = {}
+    Wal, p, Waldk, Wfold = window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 3, timing=timing)
+    assert np.array_equal(p, g["window_p"]) if "window_p" in g else True
+    assert relerr(Waldk[:, :, 10, :], g["window_Waldk_k10"]) < 1e-9
+    if "window_Waldk_sum_p" in g:
+        assert relerr(Waldk.sum(axis=-1), g["window_Waldk_sum_p"]) < 1e-9
+    Wal_h, p_h = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+    Wfold_h, Waldk_h = TB.window_fold(k, Wal_h, p_h)
+    assert np.array_equal(p, p_h)
+    for a in range(3):
+        for l in range(3):
+            assert relerr(Wal[a, l], Wal_h[a, l]) < 1e-11, (a, l)
+            assert relerr(Wfold[a, l], Wfold_h[a, l]) < 1e-11, (a, l)
+    assert np.array_equal(Waldk == 0.0, Waldk_h == 0.0)          # same band
+    assert relerr(Waldk, Waldk_h) < 1e-11
+    # no mask, Na < Nl
+    Wal2, _, Waldk2, Wfold2 = window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 2, 3, withmask=False)
+    Wfold2_h, Waldk2_h = TB.window_fold(k, Wal_h[:2], p_h, withmask=False)
+    assert relerr(Wal2, Wal_h[:2]) < 1e-11 and relerr(Waldk2, Waldk2_h) < 1e-11 and relerr(Wfold2, Wfold2_h) < 1e-11
+    print(case, "window precompute:", timing)
+
+
+def test_window_precompute_rejects_bad_arguments():
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.window import window_matrix_device
+
+    tab = np.load(WIN)
+    k = np.linspace(0.01, 0.3, 16)
+    with pytest.raises(L.EftbError):
+        window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 2)          # Na > Nl
+    with pytest.raises(L.EftbError):
+        window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 3, windowk=0.0)

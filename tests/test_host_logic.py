@@ -255,3 +255,20 @@ def test_window_matrix_host_side(golden):
         assert relerr(wm.convolve(c["ap_" + n]), g["wm_" + n]) < 1e-10, n
     with pytest.raises(ValueError):
         W.WindowMatrix(m[:, :2], W.PolesInfo(3, 0, 0.3, 300), W.PolesInfo(2, 0.02, 0.2, 18), co=co)
+
+
+@pytest.mark.parametrize("case", ["caseC", "caseG"])
+def test_window_tables_against_reference(golden, case):
+    """tables.window_tables / window_matrix (FFT + power-law sum collapsed into one real table per l) + window_fold reproduce the
+    reference's Waldk (window.py:262-359): one k row and the p sums held by the fixtures."""
+    import os
+
+    from eftpipe_amd import tables as TB
+
+    g = golden(case)
+    tab = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "win_NGC_LRG_sQ024.npy"))
+    Wal, p = TB.window_matrix(g["k"], tab[:, 0], tab[:, 1:].T, 3, 3)
+    _, Waldk = TB.window_fold(g["k"], Wal, p)
+    assert relerr(Waldk[:, :, 10, :], g["window_Waldk_k10"]) < 1e-9
+    if "window_Waldk_sum_p" in g:
+        assert relerr(Waldk.sum(axis=-1), g["window_Waldk_sum_p"]) < 1e-9
