@@ -89,6 +89,14 @@ struct eftb_engine {
     hipStream_t pre = nullptr;
     hipEvent_t evPrep = nullptr, evInFree = nullptr;
     bool prep_overlap = true, inputs_settled = false;  // EFTB_PREP_OVERLAP=0 disables; inputs_settled: set by eftb_run only
+    // back half (spline, AP, reduce) of run i on its own stream beside the resummation of run i+1 (EFTB_AP_OVERLAP=1): three template
+    // blocks rotate (work block of this run, work block of the previous run = AP output of this one, AP output of the previous run)
+    hipStream_t back = nullptr;
+    hipEvent_t evResum = nullptr, evBack[2] = {nullptr, nullptr};
+    double* T3 = nullptr;
+    bool ap_overlap = true, back_pending = false, allow_back = false;  // EFTB_AP_OVERLAP=0 disables
+    unsigned back_step = 0;
+    hipStream_t opstream = nullptr;  // where the operator launchers put their kernels (null: the main stream)
     // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous): three sets of the per-step inputs (PIN, F, DA,
     // H, BIAS, GROWS) and outputs (PLK, LOGP) -- one being evaluated, one queued behind it, one whose results are being fetched / refilled
     double* setbuf[3][EFTB_B_COUNT] = {{nullptr}};
@@ -295,9 +303,9 @@ static int launch_operator(eftb_engine* e, int id, int B, int t0 = 0, int tstrid
         g.c_colgroup = (long long)NROW * o.nx_out;
         g.cols_per_group = o.nx_out;
         if (g.ncols <= 16 * GN_MAXT)  // few output columns: K split over the waves, 16-row workgroups
-            hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1), dim3(256), 0, e->stream, g, GemmZ{});
+            hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1), dim3(256), 0, (e->opstream ? e->opstream : e->stream), g, GemmZ{});
         else
-            hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, e->stream, g);
+            hipLaunchKernelGGL(gemm_rows_kernel, dim3((g.rows + 63) / 64, (g.ncols + 255) / 256), dim3(256), GEMM_LDS, (e->opstream ? e->opstream : e->stream), g);
     };
     if (o.st_op < 0) launch(o, 0, NROW);
     else {
@@ -339,7 +347,7 @@ static int launch_pipeline_operator(eftb_engine* e, int B) {
     for (int t = 0; t < e->ntr; ++t) z.B[t] = e->ops[e->tracer_ops[t]].dev;
     z.a_off = bin;
     z.c_off = bout;
-    hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1, e->ntr), dim3(256), 0, e->stream, g, z);
+    hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1, e->ntr), dim3(256), 0, (e->opstream ? e->opstream : e->stream), g, z);
     std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     e->cur_nl = o.nl_out;
     e->cur_nx = o.nx_out;
@@ -368,6 +376,13 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
 }
 
 // nnlo_pass: the linear stages (RESUM / AP / PROJECT) once more, on the NNLO block (pointers swapped in by launch_stages)
+// the main stream picks up behind a back half that is still in flight on its own stream (see engine.back)
+static inline void join_back(eftb_engine* e) {
+    if (!e->back_pending) return;
+    (void)hipStreamWaitEvent(e->stream, e->evBack[(e->back_step + 1) & 1], 0);  // the last one recorded
+    e->back_pending = false;
+}
+
 static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     const eftb_config& c = e->c;
     hipStream_t st = e->stream;
@@ -387,6 +402,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     // cross-run overlap of the front half (see engine.pre): only for asynchronous runs whose inputs are already in place
     const bool pre_side = (mask & EFTB_S_PREP) && (mask & EFTB_S_REGROUP) && e->prep_overlap && e->inputs_settled && !e->use_graphs && !nnlo_pass &&
                           !c.with_nnlo;  // (the NNLO pass of the previous run still reads CctNNLO late)
+    const bool ap_side = pre_side && e->ap_overlap && e->allow_back && (mask & EFTB_S_RESUM) && (mask & EFTB_S_AP) && (Nl == 3 || !e->generic_resum);
+    if (!ap_side) join_back(e);
+    const int bslot = e->back_step & 1;  // evBack[bslot] was recorded two runs ago
     if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
@@ -465,10 +483,16 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (side_ap) {
             std::swap(e->APP, e->APP2);
             std::swap(e->APR, e->APR2);
+            if (ap_side && hipStreamWaitEvent(st, e->evBack[bslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");  // its reader
             launch_ap_prefix(e, st, B);
         }
         if ((side_ir || side_ap) && hipEventRecord(e->evJoin, st) != hipSuccess) return fail("eftb_run: stream join failed");
         st = st_main;
+    }
+    if (ap_side) {
+        // regroup into the block the run before the previous one left its AP output in (its readers are done: evBack)
+        if (hipStreamWaitEvent(st, e->evBack[bslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+        std::swap(b[EFTB_B_TEMPL], e->T3);
     }
     if (mask & EFTB_S_REGROUP) {
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
@@ -535,6 +559,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
                 return fail("eftb_run: event record failed");
         }
     }
+    if (ap_side) {
+        if (hipEventRecord(e->evResum, st) != hipSuccess || hipStreamWaitEvent(e->back, e->evResum, 0) != hipSuccess) return fail("eftb_run: stream fork failed");
+        st = e->back;
+    }
     if (mask & EFTB_S_AP) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
         const int nseries = B * Nl * NROW;
@@ -577,7 +605,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         e->cur_nx = Nk;
     }
     if (mask & EFTB_S_PROJECT) {
-        if (int rc = launch_pipeline_operator(e, B)) return rc;
+        e->opstream = st;
+        const int rc = launch_pipeline_operator(e, B);
+        e->opstream = nullptr;
+        if (rc) return rc;
     }
     if (mask & EFTB_S_LOGP) {
         if (!e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
@@ -605,6 +636,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         hipLaunchKernelGGL(reduce_nnlo_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIASN],
                            b[EFTB_B_TEMPLN], b[EFTB_B_PLK]);
     if (!(mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess) return fail("eftb_run: event record failed");
+    if (ap_side) {
+        if (hipEventRecord(e->evBack[bslot], st) != hipSuccess) return fail("eftb_run: event record failed");
+        ++e->back_step;
+        e->back_pending = true;
+    }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
     return 0;
@@ -739,6 +775,15 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_lo));
     HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
+    if (const char* f = getenv("EFTB_AP_OVERLAP")) e->ap_overlap = atoi(f) != 0;
+    {
+        int bp = prio_lo;  // measured: 290 k evaluations/s with the back half at low priority, 286 k at high, 278 k without the stream
+        if (const char* f = getenv("EFTB_BACK_PRIO")) bp = atoi(f) > 0 ? prio_lo : (atoi(f) < 0 ? prio_hi : 0);
+        HIPCHK(hipStreamCreateWithPriority(&e->back, hipStreamNonBlocking, bp));
+    }
+    HIPCHK(hipEventCreateWithFlags(&e->evResum, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evBack[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evBack[1], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evInFree, hipEventDisableTiming));
     HIPCHK(hipEventRecord(e->evInFree, e->pre));
     HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
@@ -836,6 +881,7 @@ int eftb_finalize(eftb_engine* e) {
     AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, 21, 7); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3); AP_LDS(3, NROW, 7);
     AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
 #undef AP_LDS
+    if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // third template block (engine.back)
     e->finalized = true;
     return 0;
 }
@@ -908,6 +954,7 @@ int eftb_apply_operator(eftb_engine* e, int op_id, int B) {
     if (!e->finalized) return fail("eftb_apply_operator: engine not finalized");
     if (B < 1 || B > e->c.max_batch) return fail("eftb_apply_operator: batch %d outside [1, %d]", B, e->c.max_batch);
     HIPCHK(hipSetDevice(e->c.device));
+    join_back(e);
     if (int rc = launch_operator(e, op_id, B)) return rc;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
@@ -995,12 +1042,13 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered, e->evPrep, e->evInFree}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1]}) if (ev) (void)hipEventDestroy(ev);
     if (e->pre) (void)hipStreamDestroy(e->pre);
+    if (e->back) (void)hipStreamDestroy(e->back);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
     for (int q = 0; q < 3; ++q) {
         if (e->evStaged[q]) (void)hipEventDestroy(e->evStaged[q]);
@@ -1025,6 +1073,7 @@ int eftb_put(eftb_engine* e, int id, size_t offset, const double* host, size_t c
     if (id < 0 || id >= EFTB_B_COUNT || !e->buf[id]) return fail("eftb_put: buffer %d not available in this configuration", id);
     if (offset + count > e->buf_elems[id]) return fail("eftb_put: buffer %d holds %zu elements, asked [%zu, %zu)", id, e->buf_elems[id], offset, offset + count);
     HIPCHK(hipSetDevice(e->c.device));
+    join_back(e);
     HIPCHK(hipMemcpyAsync(e->buf[id] + offset, host, count * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -1035,6 +1084,7 @@ int eftb_get(eftb_engine* e, int id, size_t offset, double* host, size_t count) 
     if (id < 0 || id >= EFTB_B_COUNT || !e->buf[id]) return fail("eftb_get: buffer %d not available in this configuration", id);
     if (offset + count > e->buf_elems[id]) return fail("eftb_get: buffer %d holds %zu elements, asked [%zu, %zu)", id, e->buf_elems[id], offset, offset + count);
     HIPCHK(hipSetDevice(e->c.device));
+    join_back(e);
     HIPCHK(hipMemcpyAsync(host, e->buf[id] + offset, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -1046,13 +1096,15 @@ int eftb_run(eftb_engine* e, int mask, int B) {
     if (B < 1 || B > e->c.max_batch) return fail("eftb_run: batch %d outside [1, %d]", B, e->c.max_batch);
     HIPCHK(hipSetDevice(e->c.device));
     e->inputs_settled = true;  // eftb_put is synchronous: the inputs of this run are in place, its first stage may start early
+    e->allow_back = true;
     const int rc = run_stages(e, mask, B);
-    e->inputs_settled = false;
+    e->inputs_settled = e->allow_back = false;
     return rc;
 }
 
 int eftb_sync(eftb_engine* e) {
     if (!e) return fail("eftb_sync: null engine");
+    join_back(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->comm_stream) HIPCHK(hipStreamSynchronize(e->comm_stream));  // an asynchronous gather may still be in flight
     return 0;
@@ -1064,6 +1116,7 @@ int eftb_run_timed(eftb_engine* e, int mask, int B, int repeats, float* ms) {
     if (B < 1 || B > e->c.max_batch) return fail("eftb_run_timed: batch %d outside [1, %d]", B, e->c.max_batch);
     if (repeats < 1) repeats = 1;
     HIPCHK(hipSetDevice(e->c.device));
+    join_back(e);
     HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (int r = 0; r < repeats; ++r)
         if (int rc = launch_stages(e, mask, B)) return rc;
@@ -1081,6 +1134,7 @@ static int upload_and_launch(eftb_engine* e, const char* who, int B, const doubl
     if (B < 1 || B > c.max_batch) return fail("%s: batch %d outside [1, %d]", who, B, c.max_batch);
     if (c.with_ap && (!DA || !H)) return fail("%s: DA and H are required when with_ap=1", who);
     HIPCHK(hipSetDevice(c.device));
+    join_back(e);
     hipStream_t st = e->stream;
     HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_F], f, (size_t)B * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1241,11 +1295,11 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     ++e->epoch;  // (captured graphs hold the other set's pointers)
     HIPCHK(hipStreamWaitEvent(e->stream, e->evStaged[e->cur_set], 0));  // the side stream forks from here, so it inherits the wait
     HIPCHK(hipStreamWaitEvent(e->pre, e->evStaged[e->cur_set], 0));
-    e->inputs_settled = true;
+    e->inputs_settled = e->allow_back = true;
     const int rc = run_stages(e, mask, B);
-    e->inputs_settled = false;
+    e->inputs_settled = e->allow_back = false;
     if (rc) return rc;
-    HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], e->stream));
+    HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], e->back_pending ? e->back : e->stream));  // the step ends where its back half ran
     return 0;
 }
 
@@ -1312,9 +1366,11 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
     // runs, so keeping the compute stream "free" beside it buys nothing, and the look-ahead stream carries the next step's front half anyway.
     static const bool inline_exchange = !(getenv("EFTB_GATHER_ASYNC") && atoi(getenv("EFTB_GATHER_ASYNC")));
     hipStream_t cs = e->comm_stream;
+    const bool on_back = inline_exchange && e->back_pending;  // P_l is being written on the back-half stream: the exchange follows it there
     if (inline_exchange) {
-        cs = e->stream;
+        cs = on_back ? e->back : e->stream;
     } else {
+        join_back(e);
         // snapshot on the compute stream (after the previous gather has let go of the snapshot buffer) ...
         HIPCHK(hipStreamWaitEvent(e->stream, e->evGathered, 0));
         hipLaunchKernelGGL(copy_kernel, dim3(64), dim3(256), 0, e->stream, e->buf[EFTB_B_PLK], e->plk_snap, count);
@@ -1334,6 +1390,7 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
         NCCLCHK(g_rccl.GroupEnd());
     }
     HIPCHK(hipEventRecord(e->evGathered, cs));
+    if (on_back) HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], cs));  // whoever joins the back half also waits for the exchange
     if (host_out && e->rank == root) {
         HIPCHK(hipMemcpyAsync(host_out, e->gathered, (size_t)e->nranks * count * sizeof(double), hipMemcpyDeviceToHost, cs));
         HIPCHK(hipStreamSynchronize(cs));

@@ -270,6 +270,45 @@ def test_graph_replay_is_bit_identical(golden):
     eng.close()
 
 
+def test_overlapped_steps_are_bit_identical(golden, monkeypatch):
+    """Asynchronous runs overlap on three streams (front half of run i+1 and back half -- spline, AP, reduce -- of run i beside the
+    resummation, three template blocks rotating): any number of queued runs, and input changes in between, must give exactly what an
+    engine with every overlap switched off gives."""
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    B = 5
+    cfg = EngineConfig(Nl=3, with_resum=True, with_ap=True, APst=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"]))
+    monkeypatch.setenv("EFTB_AP_OVERLAP", "0")
+    monkeypatch.setenv("EFTB_PREP_OVERLAP", "0")
+    serial = Engine(cfg, max_batch=B)
+    monkeypatch.delenv("EFTB_AP_OVERLAP")
+    monkeypatch.delenv("EFTB_PREP_OVERLAP")
+    eng = Engine(cfg, max_batch=B)
+    rng = np.random.default_rng(11)
+    f0, DA0, H0 = float(g["f"]), float(g["DA"]), float(g["H"])
+    mask = eng.full_mask(reduce=True)
+    shape_t, shape_p = (B, 3, 24, g["k"].size), (B, 3, g["k"].size)
+    for nrun in (1, 2, 3, 4, 7):
+        scale = 1.0 + 0.1 * rng.standard_normal(B)
+        f = f0 * (1.0 + 0.05 * rng.standard_normal(B))
+        DA, H = DA0 * (1.0 + 0.03 * rng.standard_normal(B)), H0 * (1.0 + 0.03 * rng.standard_normal(B))
+        Pin = scale[:, None] * g["Pin"][None, :]
+        bias = np.stack([bias_row(float(fi), list(g["bsA"]), None, tuple(g["es"]), kmA=0.7, krA=0.25, ndA=4.5e-5) for fi in f])
+        serial.load_inputs(Pin, f, DA, H, bias)
+        serial.run(mask, B)
+        want_t, want_p = serial.get("TEMPL", shape_t), serial.get("PLK", shape_p)
+        eng.load_inputs(Pin, f, DA, H, bias)
+        for _ in range(nrun):
+            eng.run(mask, B, sync=False)
+        assert np.array_equal(eng.get("PLK", shape_p), want_p), nrun
+        assert np.array_equal(eng.get("TEMPL", shape_t), want_t), nrun
+    serial.close()
+    eng.close()
+
+
 def test_pipelined_steps_with_changing_inputs(golden):
     """eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous: a sampler loop whose inputs change every step, with the next step's
     inputs staged and the previous step's results fetched while a step is in flight -- every step must equal the synchronous call."""
