@@ -174,7 +174,11 @@ int  eftb_put(eftb_engine* e, int buffer_id, size_t offset, const double* host, 
 int  eftb_get(eftb_engine* e, int buffer_id, size_t offset, double* host, size_t count);
 size_t eftb_buffer_size(const eftb_engine* e, int buffer_id); /* elements */
 
-/* Launch the selected stages for cosmologies [0, B) on the engine stream (asynchronous). */
+/* Launch the selected stages for cosmologies [0, B) (asynchronous; every other entry point orders itself behind it).
+ * A full pipeline run spreads over three streams so that consecutive runs overlap: the front half (first stage .. expansions)
+ * of run i+1 and the back half (spline, AP, projection, likelihood, reduce) of run i execute beside the resummation.
+ * Environment switches, read by eftb_create: EFTB_PREP_OVERLAP=0 / EFTB_AP_OVERLAP=0 put the front / back half back on
+ * the main stream (results are bit-identical either way). */
 int  eftb_run(eftb_engine* e, int stage_mask, int B);
 int  eftb_sync(eftb_engine* e);
 /* Same, bracketed by HIP events on the engine stream; *ms receives the elapsed device time. */
@@ -220,8 +224,9 @@ void  eftb_host_free(void* p);
  * (eftb_comm_unique_id) and is handed to every rank by the host (any side channel). */
 int  eftb_comm_unique_id(char id[128]);
 int  eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]);
-/* Gather EFTB_B_PLK rows [0, B) of every rank into root's device buffer (rank-major), in line on the engine's
- * compute stream (about 0.02 ms per step; EFTB_GATHER_ASYNC=1 moves it to a communication stream instead);
+/* Gather EFTB_B_PLK rows [0, B) of every rank into root's device buffer (rank-major), in line behind the kernel that
+ * wrote them (on the back-half stream of an overlapped run, else on the compute stream; EFTB_GATHER_ASYNC=1 moves it to a
+ * communication stream instead);
  * if host_out != NULL (root only) the gathered block [nranks][B][Nl][Nx] is copied out after the gather. */
 int  eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out);
 
