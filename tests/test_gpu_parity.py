@@ -270,6 +270,37 @@ def test_graph_replay_is_bit_identical(golden):
     eng.close()
 
 
+def test_bench_workload_against_oracle():
+    """The cfg-2 workload exactly as bench.py runs it (Nl = 3, survey k grid of 512 points, IR-resum + AP, seeded synthetic draws, west-coast
+    bias contraction, asynchronous overlapped runs): templates and P_l of the first draws against the oracle."""
+    import bench
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+    from oracle import OracleConfig, OracleEngine
+
+    B, ncheck = 16, 3
+    k = synth.survey_kgrid(bench.NK)
+    cfg = EngineConfig(Nl=bench.NL, k=k, with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, bench.Z)),
+                       H_AP=float(synth.hubble(synth.OM_AP, bench.Z)))
+    eng = Engine(cfg, max_batch=B)
+    draws = synth.draw_batch(B, z=bench.Z, seed=12345)
+    bias = np.stack([bias_row(float(f), bench.BS, None, bench.ES, kmA=0.7, krA=0.25, ndA=4.5e-5) for f in draws["f"]])
+    eng.load_inputs(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias)
+    mask = eng.full_mask(reduce=True)
+    for _ in range(3):
+        eng.run(mask, B, sync=False)
+    templ, plk = eng.get("TEMPL", (B, bench.NL, 24, bench.NK)), eng.get("PLK", (B, bench.NL, bench.NK))
+    orc = OracleEngine(OracleConfig(Nl=bench.NL, k=k, ndA=4.5e-5, with_resum=True, with_ap=True, Om_AP=synth.OM_AP, z_AP=bench.Z))
+    for i in range(ncheck):
+        f = float(draws["f"][i])
+        st = orc.evaluate(draws["kin"], draws["Pin"][i], f, float(draws["DA"][i]), float(draws["H"][i]), pairwise=True)
+        for n, sl in ROWS.items():
+            assert relerr(templ[i][:, sl], st[n]) < TOL, (i, n)
+        assert relerr(plk[i], orc.reduce_plk(f, st, list(bench.BS), es=tuple(bench.ES))) < TOL, i
+    eng.close()
+
+
 def test_overlapped_steps_are_bit_identical(golden, monkeypatch):
     """Asynchronous runs overlap on three streams (front half of run i+1 and back half -- spline, AP, reduce -- of run i beside the
     resummation, three template blocks rotating): any number of queued runs, and input changes in between, must give exactly what an
