@@ -1035,7 +1035,7 @@ void eftb_destroy(eftb_engine* e) {
     (void)hipSetDevice(e->c.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
-    for (hipStream_t q : {e->pre, e->side, e->cpy}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work and staged uploads still in flight
+    for (hipStream_t q : {e->pre, e->side, e->cpy, e->back}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work and staged uploads still in flight
     drop_graphs(e);
     if (e->cpy)
         for (int id = 0; id < EFTB_B_COUNT; ++id)
