@@ -197,6 +197,7 @@ def main():
                     "executes an algebraically reduced form; executed_* count the flops the kernel really issues",
             "p22_path_ms": ms_p22, "p22_algorithmic_flops_per_launch": alg_p22, "p22_algorithmic_tflops": alg_p22 / (ms_p22 * 1e-3) / 1e12,
             "c22_path_ms": ms_c22, "stage_ms": stages,
+            "stage_ms_note": "stages timed alone on the main stream after the overlapped loop; 'ap' then includes about 0.04 ms of scratch hand-over between queues (its kernels take 0.15 ms, profiles/r01_kernel_stats.csv)",
         }
         value = B * world * args.steps / elapsed
         out = {
