@@ -1005,6 +1005,7 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
             if (fabs(x - y) > 1e-12 * (fabs(x) + fabs(y)) + 1e-300) return fail("eftb_set_likelihood: invcov is not symmetric at (%d, %d)", a, b2);
         }
     HIPCHK(hipSetDevice(e->c.device));
+    join_back(e);  // a likelihood stage of an overlapped run may still be reading the old tables on the back-half stream
     HIPCHK(hipStreamSynchronize(e->stream));
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     e->like_index = nullptr; e->like_data = e->like_invcov = e->like_mu = e->like_sinv = e->like_V = e->like_U = nullptr;
