@@ -97,8 +97,16 @@ def main():
         import contextlib
 
         threadpool_limits = lambda limits: contextlib.nullcontext()
+    device = cp.local_rank
+    if world > 1:
+        import torch  # (already loaded by the control plane; counting devices does not initialise the GPU)
+
+        ndev = torch.cuda.device_count()
+        if 0 < ndev <= cp.local_rank:  # fewer GPUs than ranks: ranks share devices (a rehearsal of the launch path, not a measurement)
+            device = cp.local_rank % ndev
+            print(f"[bench] rank {rank}: only {ndev} GPU(s) visible, sharing device {device}", file=sys.stderr)
     with threadpool_limits(limits=8):
-        eng = Engine(cfg, max_batch=B, device=cp.local_rank)
+        eng = Engine(cfg, max_batch=B, device=device)
     gather = "none"
     if world > 1:
         # RCCL communicator for the P_l gather; if it cannot be built on this node every rank agrees to fall back to
