@@ -46,12 +46,19 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
                                                    const double* __restrict__ lnkin, const double* __restrict__ SkT,
                                                    const double* __restrict__ GcT, const double* __restrict__ EcT,
                                                    const double* __restrict__ lnxtail, double* __restrict__ P11,
-                                                   double* __restrict__ coef, double* __restrict__ coefT, int Bmax) {
+                                                   double* __restrict__ coef, double* __restrict__ coefT, int Bmax, int* __restrict__ status) {
     extern __shared__ double sm[];
     double* pin = sm;
     double* tail = sm + Nkin;
     const int w = blockIdx.x, tid = threadIdx.x;
-    for (int j = tid; j < Nkin; j += blockDim.x) pin[j] = Pin[(size_t)w * Nkin + j];
+    bool bad = false;
+    for (int j = tid; j < Nkin; j += blockDim.x) {
+        const double v = Pin[(size_t)w * Nkin + j];
+        pin[j] = v;
+        bad = bad || !(fabs(v) <= 1.79769313486231570815e308) || (j >= Nkin - 2 && !(v > 0.0));  // non-finite anywhere, non-positive where the logarithm is taken
+    }
+    // input guard (reference fftlog.py:146-151 needs the last two samples positive): the flag sits in mapped host memory and is only written in the error case
+    if (bad && status && blockIdx.y == 0) atomicMax(status, w + 1);
     __syncthreads();
     // slope / amplitude from the last two samples (reference fftlog.py:146-151)
     const double slope = (log(pin[Nkin - 1]) - log(pin[Nkin - 2])) / (lnkin[Nkin - 1] - lnkin[Nkin - 2]);
@@ -1403,7 +1410,7 @@ __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ sr
 // reduce: P_l(k) = sum_row bias[row] * T[l][row][k]  (reference parambasis.py:128-136)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const double* __restrict__ bias, const double* __restrict__ T,
-                                                     double* __restrict__ Plk) {
+                                                     double* __restrict__ Plk, int* __restrict__ nonfinite) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, w = blockIdx.z;
     if (k >= Nx) return;
     const double* b = bias + (size_t)w * NROW;
@@ -1412,16 +1419,19 @@ __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const doubl
 #pragma unroll
     for (int r = 0; r < NROW; ++r) a = fma(b[r], t[(size_t)r * Nx], a);
     Plk[((size_t)w * Nl + l) * Nx + k] = a;
+    if (nonfinite && !(fabs(a) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);  // EFTB_O_CHECK_FINITE
 }
 
 // P_l(k) += bctNNLO . PctNNLOl (rows 3-5 of the NNLO block; reference parambasis.py:132-134)
 __global__ __launch_bounds__(256) void reduce_nnlo_kernel(int Nx, int Nl, const double* __restrict__ biasn, const double* __restrict__ TN,
-                                                          double* __restrict__ Plk) {
+                                                          double* __restrict__ Plk, int* __restrict__ nonfinite) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, w = blockIdx.z;
     if (k >= Nx) return;
     const double* b = biasn + (size_t)w * 3;
     const double* t = TN + (((size_t)w * Nl + l) * NROW + 3) * Nx + k;
-    Plk[((size_t)w * Nl + l) * Nx + k] += b[0] * t[0] + b[1] * t[(size_t)Nx] + b[2] * t[(size_t)2 * Nx];
+    const double a = Plk[((size_t)w * Nl + l) * Nx + k] + (b[0] * t[0] + b[1] * t[(size_t)Nx] + b[2] * t[(size_t)2 * Nx]);
+    Plk[((size_t)w * Nl + l) * Nx + k] = a;
+    if (nonfinite && !(fabs(a) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -65,6 +66,11 @@ struct eftb_engine {
     std::vector<int> tracer_ops;    // per-tracer pipeline operators (eftb_set_pipeline_operator_tracer), empty = pipeline_op for all
     // likelihood of the LOGP stage (eftb_set_likelihood)
     int like_ndata = 0, like_nG = 0, jeffreys = 0;
+    int like_nl = 0, like_nx = 0;   // template-block shape the data index was validated against (checked again when the LOGP stage launches)
+    // input / output guards: kernels raise flags in mapped page-locked memory (status[0]: 1 + index of a cosmology whose P_lin is
+    // non-finite or non-positive at its last two samples; status[1]: 1 + index of a cosmology with a non-finite P_l, EFTB_O_CHECK_FINITE)
+    int* status = nullptr;
+    bool check_finite = false;
     std::vector<double> like_host;  // eftb_eval_logp_batch: D2H landing block [B][MARG_OUT]
     int* like_index = nullptr;
     double *like_data = nullptr, *like_invcov = nullptr, *like_mu = nullptr, *like_sinv = nullptr;
@@ -108,6 +114,7 @@ struct eftb_engine {
     hipStream_t cpy = nullptr;
     hipEvent_t evStaged[3] = {nullptr, nullptr, nullptr}, evSetDone[3] = {nullptr, nullptr, nullptr};
     int cur_set = 0, staged_B = 0;
+    bool staged_plk_device = false;  // staged sets keep P_l in device memory (a communicator exists: RCCL sends from it) instead of mapped host memory
     bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
     int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
@@ -122,6 +129,9 @@ struct eftb_engine {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     double* gathered = nullptr;
+    double* gathered2[2] = {nullptr, nullptr};  // the gathered block alternates between two buffers, so that the root can read step i while step i + 1 is exchanged
+    hipEvent_t evGath2[2] = {nullptr, nullptr};
+    int gather_slot = 0;
     // the gather runs on its own stream from a snapshot of P_l, so that it overlaps the next step's kernels
     hipStream_t comm_stream = nullptr;
     hipEvent_t evSnap = nullptr, evGathered = nullptr;
@@ -383,6 +393,45 @@ static inline void join_back(eftb_engine* e) {
     e->back_pending = false;
 }
 
+// every stream of the engine drained (setters that replace resident tables / likelihood data)
+static hipError_t sync_all(eftb_engine* e) {
+    join_back(e);
+    for (hipStream_t q : {e->stream, e->side, e->pre, e->back, e->cpy, e->comm_stream})
+        if (q) {
+            const hipError_t rc = hipStreamSynchronize(q);
+            if (rc != hipSuccess) return rc;
+        }
+    return hipSuccess;
+}
+
+// flags raised by the kernels of finished runs (call after a stream synchronisation); reported once, then cleared
+static int check_status(eftb_engine* e, const char* who) {
+    if (!e->status) return 0;
+    volatile int* s = e->status;
+    const int bad_in = s[0], bad_out = s[1];
+    if (!bad_in && !bad_out) return 0;
+    s[0] = s[1] = 0;
+    if (bad_in)
+        return fail("%s: P_lin of cosmology %d is non-finite, or not positive at its last two samples (the FFTLog power-law extrapolation needs "
+                    "them positive, reference fftlog.py:146-151); the outputs of that run are invalid", who, bad_in - 1);
+    return fail("%s: non-finite P_l(k) for cosmology %d (EFTB_O_CHECK_FINITE)", who, bad_out - 1);
+}
+
+// host inputs of one batch, before anything is copied: finite everywhere, P_lin positive where its logarithm is taken, distances positive
+static int validate_inputs(const eftb_config& c, const char* who, int B, const double* Pin, const double* f, const double* DA, const double* H) {
+    for (int w = 0; w < B; ++w) {
+        const double* p = Pin + (size_t)w * c.Nkin;
+        for (int j = 0; j < c.Nkin; ++j)
+            if (!std::isfinite(p[j])) return fail("%s: Pin[%d][%d] is not finite", who, w, j);
+        if (!(p[c.Nkin - 1] > 0.0) || !(p[c.Nkin - 2] > 0.0))
+            return fail("%s: Pin[%d] must be positive at its last two samples (power-law extrapolation of the FFTLog, reference fftlog.py:146-151)", who, w);
+        if (!std::isfinite(f[w])) return fail("%s: f[%d] is not finite", who, w);
+        if (c.with_ap && (!std::isfinite(DA[w]) || !std::isfinite(H[w]) || !(DA[w] > 0.0) || !(H[w] > 0.0)))
+            return fail("%s: DA[%d], H[%d] must be finite and positive", who, w, w);
+    }
+    return 0;
+}
+
 static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     const eftb_config& c = e->c;
     hipStream_t st = e->stream;
@@ -422,11 +471,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         }
         hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
-                           b[EFTB_B_P11], b[EFTB_B_COEF], e->coefT, c.max_batch);
+                           b[EFTB_B_P11], b[EFTB_B_COEF], e->coefT, c.max_batch, e->status);
         if (c.dual_coef)  // IRcutoff "loop" / "resum": a second coefficient set for the xi-space pieces (reference pybird.py:1151-1160)
             hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN],
                                tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT2), tb<double>(e, EFTB_T_ECT),
-                               tb<double>(e, EFTB_T_LNXTAIL), b[EFTB_B_P11], e->coef2, e->coefT2, c.max_batch);
+                               tb<double>(e, EFTB_T_LNXTAIL), b[EFTB_B_P11], e->coef2, e->coefT2, c.max_batch, nullptr);
         if (!pre_side) st = st0;
     }
     // with pre_side the whole front half (first stage, anti-diagonal sums, rows, syntheses, expansions: inputs -> P22, P13, C11, Cct, CC)
@@ -613,6 +662,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     if (mask & EFTB_S_LOGP) {
         if (!e->like_ndata) return fail("eftb_run: stage LOGP needs eftb_set_likelihood");
         if (B % e->ntr) return fail("eftb_run: batch %d is not a multiple of the %d tracers per likelihood point", B, e->ntr);
+        if (e->cur_nl != e->like_nl || e->cur_nx != e->like_nx)
+            return fail("eftb_run: stage LOGP: the likelihood's data index addresses templates [%d][24][%d], the block is [%d][24][%d]", e->like_nl,
+                        e->like_nx, e->cur_nl, e->cur_nx);
         const int nw = B / e->ntr, ng1 = e->like_nG + 1, nd = e->like_ndata;
         const size_t lds = (size_t)e->ntr * ng1 * NROW * sizeof(double);
         if (lds > 64 * 1024) return fail("eftb_run: stage LOGP: %d tracers x %d rows do not fit the coefficient block in LDS", e->ntr, ng1);
@@ -631,10 +683,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     }
     if (mask & EFTB_S_REDUCE)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],
-                           b[EFTB_B_TEMPL], b[EFTB_B_PLK]);
+                           b[EFTB_B_TEMPL], b[EFTB_B_PLK], e->check_finite && !c.with_nnlo ? e->status + 1 : nullptr);
     if ((mask & EFTB_S_REDUCE) && c.with_nnlo)
         hipLaunchKernelGGL(reduce_nnlo_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIASN],
-                           b[EFTB_B_TEMPLN], b[EFTB_B_PLK]);
+                           b[EFTB_B_TEMPLN], b[EFTB_B_PLK], e->check_finite ? e->status + 1 : nullptr);
     if (!(mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess) return fail("eftb_run: event record failed");
     if (ap_side) {
         if (hipEventRecord(e->evBack[bslot], st) != hipSuccess) return fail("eftb_run: event record failed");
@@ -823,6 +875,9 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         HIPCHK(hipMalloc(&e->APP2, (size_t)c.max_batch * (c.nmu + 1) * c.Nl * c.Nl * 4 * sizeof(double)));
         HIPCHK(hipMalloc(&e->APR2, (size_t)c.max_batch * c.nmu * sizeof(double)));
     }
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 4 * sizeof(int), hipHostMallocMapped));
+    memset(e->status, 0, 4 * sizeof(int));
+    HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
     *out = e;
     return 0;
 }
@@ -836,6 +891,7 @@ int eftb_set_table(eftb_engine* e, int id, const void* host, size_t nbytes) {
     if (need != nbytes) return fail("eftb_set_table: table %d expects %zu bytes, got %zu", id, need, nbytes);
     HIPCHK(hipSetDevice(e->c.device));
     if (!e->tab[id]) HIPCHK(hipMalloc(&e->tab[id], nbytes));
+    else if (e->finalized) HIPCHK(sync_all(e));  // replacing a resident table (e.g. the AP fiducial): no run may still be reading it
     HIPCHK(hipMemcpy(e->tab[id], host, nbytes, hipMemcpyHostToDevice));
     e->tab_bytes[id] = nbytes;
     if (id == EFTB_T_S) {
@@ -882,6 +938,7 @@ int eftb_finalize(eftb_engine* e) {
     AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
 #undef AP_LDS
     if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // third template block (engine.back)
+    HIPCHK(hipDeviceSynchronize());  // null-stream zero fills (part, ZC, ZC2) are not ordered against the engine's non-blocking streams
     e->finalized = true;
     return 0;
 }
@@ -985,6 +1042,7 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_AP_STOCHASTIC: e->c.ap_stochastic = value ? 1 : 0; return 0;
         case EFTB_O_JEFFREYS: e->jeffreys = value ? 1 : 0; return 0;
         case EFTB_O_GRAPH: e->use_graphs = value != 0; return 0;
+        case EFTB_O_CHECK_FINITE: e->check_finite = value != 0; return 0;
     }
     return fail("eftb_set_option: unknown option %d", option);
 }
@@ -995,18 +1053,27 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
     if (!e || !index || !data || !invcov || (nG > 0 && (!mu || !sigma_inv))) return fail("eftb_set_likelihood: null argument");
     if (nG < 0 || nG > MARG_MAXG) return fail("eftb_set_likelihood: nG=%d outside [0, %d]", nG, MARG_MAXG);  // nG = 0: plain -chi2 / 2
     if (ndata < 1) return fail("eftb_set_likelihood: ndata=%d", ndata);
-    const int npts = e->ntr * e->cur_nl * e->cur_nx;  // the walker's ntr entries are addressed as one block of ntr * nl multipoles
+    // the shape the index refers to: what the PROJECT stage will produce if an operator is registered for it and the block has not been
+    // projected yet, else the block as it is; the LOGP stage checks it again at launch
+    int lnl = e->cur_nl, lnx = e->cur_nx;
+    {
+        const int op = !e->tracer_ops.empty() ? e->tracer_ops[0] : e->pipeline_op;
+        if (op >= 0 && e->ops[op].nl_in == e->cur_nl && e->ops[op].nx_in == e->cur_nx) {
+            lnl = e->ops[op].nl_out;
+            lnx = e->ops[op].nx_out;
+        }
+    }
+    const int npts = e->ntr * lnl * lnx;  // the walker's ntr entries are addressed as one block of ntr * nl multipoles
     for (int a = 0; a < ndata; ++a)
         if (index[a] < 0 || index[a] >= npts)
-            return fail("eftb_set_likelihood: index[%d]=%d outside the current template block [%d][24][%d]", a, index[a], e->cur_nl, e->cur_nx);
+            return fail("eftb_set_likelihood: index[%d]=%d outside the template block [%d x %d][24][%d]", a, index[a], e->ntr, lnl, lnx);
     for (int a = 0; a < ndata; ++a)
         for (int b2 = 0; b2 < a; ++b2) {
             const double x = invcov[(size_t)a * ndata + b2], y = invcov[(size_t)b2 * ndata + a];
             if (fabs(x - y) > 1e-12 * (fabs(x) + fabs(y)) + 1e-300) return fail("eftb_set_likelihood: invcov is not symmetric at (%d, %d)", a, b2);
         }
     HIPCHK(hipSetDevice(e->c.device));
-    join_back(e);  // a likelihood stage of an overlapped run may still be reading the old tables on the back-half stream
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(sync_all(e));  // a likelihood stage of an overlapped run may still be reading the old tables on the back-half stream
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     e->like_index = nullptr; e->like_data = e->like_invcov = e->like_mu = e->like_sinv = e->like_V = e->like_U = nullptr;
     {
@@ -1028,6 +1095,8 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
     }
     e->like_ndata = ndata;
     e->like_nG = nG;
+    e->like_nl = lnl;
+    e->like_nx = lnx;
     return 0;
 }
 
@@ -1043,7 +1112,12 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->gathered, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (int q = 0; q < 2; ++q) {
+        if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
+        if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
+    }
+    e->gathered = nullptr;  // (one of gathered2)
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
@@ -1056,8 +1130,13 @@ void eftb_destroy(eftb_engine* e) {
         if (e->evSetDone[q]) (void)hipEventDestroy(e->evSetDone[q]);
         if (e->stage_host[q]) (void)hipHostFree(e->stage_host[q]);
         if (e->setblock[q]) (void)hipFree(e->setblock[q]);
-        for (int id : {EFTB_B_PLK, EFTB_B_LOGP}) if (e->setbuf[q][id]) (void)hipHostFree(e->setbuf[q][id]);
+        for (int id : {EFTB_B_PLK, EFTB_B_LOGP})
+            if (e->setbuf[q][id]) {
+                if (id == EFTB_B_PLK && e->staged_plk_device) (void)hipFree(e->setbuf[q][id]);
+                else (void)hipHostFree(e->setbuf[q][id]);
+            }
     }
+    if (e->status) (void)hipHostFree(e->status);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1088,7 +1167,7 @@ int eftb_get(eftb_engine* e, int id, size_t offset, double* host, size_t count) 
     join_back(e);
     HIPCHK(hipMemcpyAsync(host, e->buf[id] + offset, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    return 0;
+    return check_status(e, "eftb_get");
 }
 
 int eftb_run(eftb_engine* e, int mask, int B) {
@@ -1108,7 +1187,7 @@ int eftb_sync(eftb_engine* e) {
     join_back(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->comm_stream) HIPCHK(hipStreamSynchronize(e->comm_stream));  // an asynchronous gather may still be in flight
-    return 0;
+    return check_status(e, "eftb_sync");
 }
 
 int eftb_run_timed(eftb_engine* e, int mask, int B, int repeats, float* ms) {
@@ -1134,6 +1213,7 @@ static int upload_and_launch(eftb_engine* e, const char* who, int B, const doubl
     const eftb_config& c = e->c;
     if (B < 1 || B > c.max_batch) return fail("%s: batch %d outside [1, %d]", who, B, c.max_batch);
     if (c.with_ap && (!DA || !H)) return fail("%s: DA and H are required when with_ap=1", who);
+    if (int rc = validate_inputs(c, who, B, Pin, f, DA, H)) return rc;
     HIPCHK(hipSetDevice(c.device));
     join_back(e);
     hipStream_t st = e->stream;
@@ -1156,6 +1236,7 @@ int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, c
     if (plk && !bias) return fail("eftb_eval_batch: bias is required when plk is requested");
     if (plk && B >= 1 && B <= e->c.max_batch) {
         HIPCHK(hipSetDevice(e->c.device));
+        join_back(e);  // a back half still in flight (reduce / likelihood of an asynchronous eftb_run) reads BIAS
         HIPCHK(hipMemcpyAsync(e->buf[EFTB_B_BIAS], bias, (size_t)B * NROW * sizeof(double), hipMemcpyHostToDevice, e->stream));
     }
     if (int rc = upload_and_launch(e, "eftb_eval_batch", B, Pin, f, DA, H, plk ? EFTB_S_REDUCE : 0)) return rc;
@@ -1164,7 +1245,7 @@ int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, c
         HIPCHK(hipMemcpyAsync(templ, e->buf[EFTB_B_TEMPL], (size_t)B * e->cur_nl * NROW * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, st));
     if (plk) HIPCHK(hipMemcpyAsync(plk, e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    return 0;
+    return check_status(e, "eftb_eval_batch");
 }
 
 int eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* rows,
@@ -1176,6 +1257,7 @@ int eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double*
     HIPCHK(hipSetDevice(e->c.device));
     hipStream_t st = e->stream;
     const int ng1 = e->like_nG + 1;
+    join_back(e);  // a back half still in flight reads GROWS
     // rows arrive packed [B][nG+1][24]; the device block is [B][MARG_NG1][24]
     HIPCHK(hipMemcpy2DAsync(e->buf[EFTB_B_GROWS], (size_t)MARG_NG1 * NROW * sizeof(double), rows, (size_t)ng1 * NROW * sizeof(double),
                             (size_t)ng1 * NROW * sizeof(double), B, hipMemcpyHostToDevice, st));
@@ -1184,6 +1266,7 @@ int eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double*
     e->like_host.resize((size_t)nw * MARG_OUT);
     HIPCHK(hipMemcpyAsync(e->like_host.data(), e->buf[EFTB_B_LOGP], (size_t)nw * MARG_OUT * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (int rc = check_status(e, "eftb_eval_logp_batch")) return rc;
     for (int w = 0; w < nw; ++w) {
         const double* o = e->like_host.data() + (size_t)w * MARG_OUT;
         logp[w] = o[0];
@@ -1228,6 +1311,7 @@ static int staged_setup(eftb_engine* e) {
     }
     e->stage_elems = (off + 1) & ~(size_t)1;  // whole double2s for the copy kernel
     for (int id : kStagedIds) e->orig[id] = e->buf[id];
+    e->staged_plk_device = e->comm != nullptr;
     for (int q = 0; q < 3; ++q) {
         HIPCHK(hipMalloc(&e->setblock[q], e->stage_elems * sizeof(double)));
         HIPCHK(hipMemset(e->setblock[q], 0, e->stage_elems * sizeof(double)));
@@ -1236,6 +1320,11 @@ static int staged_setup(eftb_engine* e) {
         // as they finish, and fetching is a wait on the step's event plus a host copy -- no D2H transfer, whose cache maintenance
         // was measured to stall the compute queue for ~70 us per step
         for (int id : kStagedOut) {
+            if (id == EFTB_B_PLK && e->staged_plk_device) {
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double)));
+                HIPCHK(hipMemset(e->setbuf[q][id], 0, e->buf_elems[id] * sizeof(double)));
+                continue;
+            }
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double), hipHostMallocMapped));
             memset(e->setbuf[q][id], 0, e->buf_elems[id] * sizeof(double));
         }
@@ -1247,6 +1336,7 @@ static int staged_setup(eftb_engine* e) {
         HIPCHK(hipEventRecord(e->evSetDone[q], e->cpy));
     }
     e->cur_set = 2;  // the engine's own buffers are current until the first eftb_run_staged; sets 0, 1, 2 follow in turn
+    HIPCHK(hipDeviceSynchronize());  // the zero fills ran on the null stream; the copy stream is about to write into these blocks
     return 0;
 }
 
@@ -1258,6 +1348,7 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     if (B < 1 || B > c.max_batch) return fail("eftb_stage_inputs: batch %d outside [1, %d]", B, c.max_batch);
     if (c.with_ap && (!DA || !H)) return fail("eftb_stage_inputs: DA and H are required when with_ap=1");
     if (rows && !e->like_ndata) return fail("eftb_stage_inputs: rows need eftb_set_likelihood");
+    if (int rc = validate_inputs(c, "eftb_stage_inputs", B, Pin, f, DA, H)) return rc;
     if (int rc = staged_setup(e)) return rc;
     HIPCHK(hipSetDevice(c.device));
     const int t = (e->cur_set + 1) % 3;  // the set after the current one: its last run was fetched two steps ago
@@ -1313,13 +1404,20 @@ int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) {
     const int t = (e->cur_set + 2) % 3;  // the set of the step before the current one
     // spin on the step's event instead of sleeping in a synchronize call: the sampler thread is about to enqueue the next step, and the
     // wake-up latency of a blocking wait would be paid once per step
-    for (;;) {
+    static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
         const hipError_t q = hipEventQuery(e->evSetDone[t]);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return fail("eftb_fetch_previous: %s", hipGetErrorString(q));
+        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+            return fail("eftb_fetch_previous: the step did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", limit_s);
     }
-    memcpy(host, e->setbuf[t][id], count * sizeof(double));  // the results are already in (mapped) host memory
-    return 0;
+    if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
+        HIPCHK(hipMemcpy(host, e->setbuf[t][id], count * sizeof(double), hipMemcpyDeviceToHost));
+    else
+        memcpy(host, e->setbuf[t][id], count * sizeof(double));  // the results are already in (mapped) host memory
+    return check_status(e, "eftb_fetch_previous");
 }
 
 int eftb_comm_unique_id(char id[128]) {
@@ -1335,6 +1433,7 @@ int eftb_comm_unique_id(char id[128]) {
 int eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]) {
     if (!e || !id) return fail("eftb_comm_init: null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("eftb_comm_init: bad rank %d of %d", rank, nranks);
+    if (e->cpy) return fail("eftb_comm_init: call it before the first eftb_stage_inputs (the staged sets place P_l where the exchange can read it)");
     if (int rc = rccl_load()) return rc;
     HIPCHK(hipSetDevice(e->c.device));
     ncclUniqueId u;
@@ -1351,8 +1450,15 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
     if (root < 0 || root >= e->nranks) return fail("eftb_gather_plk: bad root %d", root);
     HIPCHK(hipSetDevice(e->c.device));
     const size_t count = (size_t)B * e->cur_nl * e->cur_nx;
-    if (e->rank == root && !e->gathered)
-        HIPCHK(hipMalloc(&e->gathered, (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
+    if (e->rank == root) {
+        e->gather_slot ^= 1;
+        const int q = e->gather_slot;
+        if (!e->gathered2[q]) {
+            HIPCHK(hipMalloc(&e->gathered2[q], (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
+            HIPCHK(hipEventCreateWithFlags(&e->evGath2[q], hipEventDisableTiming));
+        }
+        e->gathered = e->gathered2[q];
+    }
     if (!e->comm_stream) {
         int prio_lo = 0, prio_hi = 0;  // the exchange kernel is small and must not queue behind the next step's compute
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -1391,12 +1497,25 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
         NCCLCHK(g_rccl.GroupEnd());
     }
     HIPCHK(hipEventRecord(e->evGathered, cs));
+    if (e->rank == root) HIPCHK(hipEventRecord(e->evGath2[e->gather_slot], cs));
     if (on_back) HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], cs));  // whoever joins the back half also waits for the exchange
     if (host_out && e->rank == root) {
         HIPCHK(hipMemcpyAsync(host_out, e->gathered, (size_t)e->nranks * count * sizeof(double), hipMemcpyDeviceToHost, cs));
         HIPCHK(hipStreamSynchronize(cs));
     }
     return 0;
+}
+
+int eftb_fetch_gathered(eftb_engine* e, int which, double* host, size_t count) {
+    if (!e || !host) return fail("eftb_fetch_gathered: null argument");
+    if (which != 0 && which != 1) return fail("eftb_fetch_gathered: which must be 0 (the exchange before the last one enqueued) or 1 (the last one)");
+    const int q = which ? e->gather_slot : e->gather_slot ^ 1;
+    if (!e->gathered2[q]) return fail("eftb_fetch_gathered: no such exchange yet");
+    if (count > (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk) return fail("eftb_fetch_gathered: asked %zu elements", count);
+    HIPCHK(hipSetDevice(e->c.device));
+    HIPCHK(hipEventSynchronize(e->evGath2[q]));
+    HIPCHK(hipMemcpy(host, e->gathered2[q], count * sizeof(double), hipMemcpyDeviceToHost));
+    return check_status(e, "eftb_fetch_gathered");
 }
 
 int eftb_mfma_f64_peak(int device, double* tflops) {

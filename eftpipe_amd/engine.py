@@ -117,6 +117,10 @@ class Engine:
         """Replay whole-pipeline runs from captured HIP graphs (one host call per step; for busy hosts)."""
         L.check(self.lib.eftb_set_option(self._h, 2, int(bool(flag))))
 
+    def set_check_finite(self, flag):
+        """The REDUCE stage flags non-finite P_l(k); the next synchronising call raises, naming the cosmology (off by default)."""
+        L.check(self.lib.eftb_set_option(self._h, 3, int(bool(flag))))
+
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
 
@@ -269,9 +273,10 @@ class Engine:
         if mask & L.S_PROJECT:
             self.dims = self.out_dims()
 
-    def fetch_previous(self, name, shape):
-        """PLK / LOGP of the step before the one in flight."""
-        out = np.empty(shape, dtype=np.float64)
+    def fetch_previous(self, name, shape, out=None):
+        """PLK / LOGP of the step before the one in flight (``out``: a C-contiguous float64 array of ``shape`` to fill)."""
+        if out is None:
+            out = np.empty(shape, dtype=np.float64)
         L.check(self.lib.eftb_fetch_previous(self._h, L.B[name], L.dptr(out), out.size))
         return out
 
@@ -325,6 +330,15 @@ class Engine:
             nl, nx = self.out_dims()
             out = np.empty((nranks, B, nl, nx))
         L.check(self.lib.eftb_gather_plk(self._h, B, root, L.dptr(out)))
+        return out
+
+
+    def fetch_gathered(self, B, latest=False, out=None):
+        """Root only: the gathered block [nranks, B, nl, nx] of the exchange before the last one enqueued (or of the last one)."""
+        nl, nx = self.out_dims()
+        if out is None:
+            out = np.empty((getattr(self, "nranks", 1), B, nl, nx))
+        L.check(self.lib.eftb_fetch_gathered(self._h, int(bool(latest)), L.dptr(out), out.size))
         return out
 
 

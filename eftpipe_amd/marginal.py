@@ -29,6 +29,23 @@ def data_index(ls, masks, nx, tracer=0, nl=None):
     return np.concatenate(out).astype(np.int32)
 
 
+def joint_gaussian_rows(bases, fs, params, names, scales):
+    """Coefficient rows of a joint likelihood over several tracers (the device form of ``EFTLike.PNG`` / ``EFTLike.PG``, reference
+    likelihood.py:430-530): tracer t contributes to marginalised parameter ``names[i]`` iff its basis lists that parameter.
+    bases   one ``WestCoastBasis`` / ``EastCoastBasis`` per tracer (a cross spectrum's basis carries ``cross_prefix``)
+    fs      growth rate per tracer entry; params: the non-Gaussian parameter values by name; scales: per tracer dict(kmA=, krA=, ndA=[, kmB=, ...])
+    -> rows [ntr, len(names) + 1, 24] for one walker (row 0: the model at zero Gaussian parameters)."""
+    out = np.zeros((len(bases), len(names) + 1, 24))
+    for t, (basis, f, sc) in enumerate(zip(bases, fs, scales)):
+        r = basis.gaussian_rows(float(f), params, **sc)
+        own = gaussian_params(basis.prefix, tuple(basis.cross_prefix)) if basis.get_name() == "westcoast" else basis.gaussian_params()
+        out[t, 0] = r[0]
+        for i, n in enumerate(names):
+            if n in own:
+                out[t, 1 + i] = r[1 + own.index(n)]
+    return out
+
+
 class MarginalLikelihood:
     """Gaussian likelihood of one data vector with the linear bias parameters marginalised analytically.
 
@@ -103,4 +120,4 @@ class MarginalLikelihood:
         return (logp, full, best) if return_best else logp
 
 
-__all__ = ["MarginalLikelihood", "data_index", "gaussian_params", "gaussian_rows"]
+__all__ = ["MarginalLikelihood", "data_index", "gaussian_params", "gaussian_rows", "joint_gaussian_rows"]

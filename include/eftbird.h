@@ -126,8 +126,10 @@ void eftb_destroy(eftb_engine* e);
 enum eftb_option {
     EFTB_O_AP_STOCHASTIC = 0, /* APeffect.APst                                pybird.py:1514, 1618 */
     EFTB_O_JEFFREYS = 1,      /* marginalized_logp(jeffreys=True): drop ln det(F2 / 2 pi)   marginal.py:118-121 */
-    EFTB_O_GRAPH = 2          /* replay whole-pipeline runs (stage masks starting at PREP) from captured HIP graphs: one host call per
+    EFTB_O_GRAPH = 2,         /* replay whole-pipeline runs (stage masks starting at PREP) from captured HIP graphs: one host call per
                                  step; for busy hosts (no reference counterpart; off by default, also EFTB_GRAPH=1) */
+    EFTB_O_CHECK_FINITE = 3   /* the REDUCE stage flags non-finite P_l(k): the next synchronising call (eftb_sync, eftb_get, eftb_eval_*,
+                                 eftb_fetch_*) then returns non-zero naming the cosmology (off by default) */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 
@@ -168,6 +170,12 @@ int  eftb_apply_operator(eftb_engine* e, int op_id, int B);
 int  eftb_set_pipeline_operator(eftb_engine* e, int op_id);
 /* Declare the shape of the template block before eftb_put(EFTB_B_TEMPL, ...) of already-projected templates. */
 int  eftb_set_template_dims(eftb_engine* e, int nl, int nx);
+
+/* Input guards.  P_lin must be finite, and positive at its last two samples: the FFTLog extrapolates it beyond kin[-1] with the power
+ * law through them (reference fftlog.py:146-151 takes their logarithm); f must be finite, DA and H finite and positive.  The entry
+ * points that take host inputs (eftb_eval_batch, eftb_eval_logp_batch, eftb_stage_inputs) check this before anything is copied and
+ * return non-zero; for inputs placed with eftb_put the first kernel raises a flag instead and the next synchronising call (eftb_sync,
+ * eftb_get, eftb_fetch_*) returns non-zero, naming the cosmology.  The reference has no such check: NaNs propagate silently there. */
 
 /* Host <-> device state.  `offset`/`count` are in elements (doubles). */
 int  eftb_put(eftb_engine* e, int buffer_id, size_t offset, const double* host, size_t count);
@@ -229,6 +237,12 @@ int  eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]);
  * communication stream instead);
  * if host_out != NULL (root only) the gathered block [nranks][B][Nl][Nx] is copied out after the gather. */
 int  eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out);
+/* Pipelined multi-GPU steps (eftb_stage_inputs / eftb_run_staged / eftb_gather_plk per step, nothing waits for the step in flight): the
+ * gathered block alternates between two device buffers; this copies out, on the root, the block ([nranks][B][nl][nx], count elements)
+ * of the exchange BEFORE the last one enqueued (which = 0) or of the last one (which = 1), waiting only for that exchange.  With a
+ * communicator (eftb_comm_init, to be called before the first eftb_stage_inputs) the staged sets keep P_l in device memory, where
+ * RCCL reads it. */
+int  eftb_fetch_gathered(eftb_engine* e, int which, double* host, size_t count);
 
 /* Window precompute (reference Window._compute_Wal / _compute_Waldk, window.py:262-359) on the device.  The caller passes
  * the k-independent tables of eftpipe_amd.tables.window_tables: x [nx] (FFTLog samples inside the tabulated window), Qt

@@ -193,6 +193,33 @@ def test_c_abi_error_paths(golden):
         eng.put("PIN", np.zeros(10 * 200 + 1))  # beyond the buffer
     with pytest.raises(L.EftbError, match="not used|expects"):
         eng._set("H", np.zeros(4))  # table of a disabled feature / wrong size
+    # input guards (include/eftbird.h "Input guards"; reference fftlog.py:146-151 takes the logarithm of the last two samples):
+    # host inputs are refused before anything is copied ...
+    bad_tail, bad_nan = g["Pin"].copy(), g["Pin"].copy()
+    bad_tail[-1] = -1.0
+    bad_nan[57] = np.nan
+    with pytest.raises(L.EftbError, match="positive at its last two samples"):
+        eng.eval_batch(np.stack([g["Pin"], bad_tail]), float(g["f"]))
+    with pytest.raises(L.EftbError, match=r"Pin\[0\]\[57\] is not finite"):
+        eng.eval_batch(bad_nan, float(g["f"]))
+    with pytest.raises(L.EftbError, match="f\\[1\\] is not finite"):
+        eng.eval_batch(np.stack([g["Pin"], g["Pin"]]), np.array([0.7, np.inf]))
+    with pytest.raises(L.EftbError, match="positive at its last two samples"):
+        eng.stage_inputs(np.stack([g["Pin"], bad_tail]), np.array([0.7, 0.7]))
+    # ... inputs placed with eftb_put raise a flag in the first kernel, reported by the next synchronising call, once
+    eng.put("PIN", np.stack([g["Pin"], bad_tail]))
+    eng.put("F", np.array([0.7, 0.7]))
+    with pytest.raises(L.EftbError, match="cosmology 1"):
+        eng.run(L.S_PREP | L.S_LOOPS, 2)
+    eng.sync()
+    # optional output check: non-finite P_l is flagged by the REDUCE stage (huge bias coefficients overflow the contraction)
+    eng.load_inputs(np.stack([g["Pin"], g["Pin"]]), float(g["f"]), bias=np.stack([np.ones(24), np.full(24, 1e308)]))
+    eng.run(eng.full_mask(reduce=True), 2)                      # check off: silent, as the reference
+    assert not np.all(np.isfinite(eng.get("PLK", (2, 2, g["k"].size))[1]))
+    eng.set_check_finite(True)
+    with pytest.raises(L.EftbError, match="non-finite P_l.*cosmology 1"):
+        eng.run(eng.full_mask(reduce=True), 2)
+    eng.set_check_finite(False)
     # the engine is still usable afterwards
     eng.load_inputs(g["Pin"], float(g["f"]))
     eng.run(L.S_PREP | L.S_LOOPS)

@@ -1,4 +1,4 @@
-"""Host logic on the CPU: Common mirror, bias vectors, wave plan, sharding, gloo control plane."""
+"""Host logic on the CPU: Common mirror, bias vectors, wave plan, sharding, socket control plane."""
 import os
 import subprocess
 import sys
@@ -100,15 +100,74 @@ cp.close()
 """
 
 
-def test_control_plane_world_size_2_gloo(tmp_path):
-    """The N > 1 control path (rendezvous bytes, barrier, max over ranks, host gather) on gloo."""
+def test_control_plane_world_size_2_under_torchrun(tmp_path):
+    """The N > 1 control path (rendezvous bytes, barrier, max over ranks, host gather) launched the way the driver launches bench.py:
+    `python -m torch.distributed.run` only provides RANK / WORLD_SIZE / MASTER_*; the control plane itself is socket-only."""
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
+    script.write_text(WORKER % ROOT + "assert 'torch' not in sys.modules, 'the control plane must not import torch'\n")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+SHARD_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from eftpipe_amd import dist, synth
+cp = dist.ControlPlane()
+total = 1024
+draws = synth.draw_batch(total, z=0.7, seed=12345)              # every rank derives the same 1 024 draws ...
+a, b = dist.shard_bounds(total, cp.world, cp.rank)              # ... and evaluates its contiguous share
+stand_in = lambda Pin, f: np.stack([Pin[:, 100] * f, Pin[:, 150] + f, np.arange(Pin.shape[0]) * 0.0 + f], axis=1)   # [n, 3] per-draw result
+mine = stand_in(draws["Pin"][a:b], draws["f"][a:b])
+parts = cp.gather_ragged(mine)
+tmax = cp.max(float(cp.rank))
+cp.barrier()
+if cp.rank == 0:
+    assert tmax == cp.world - 1
+    got = dist.reassemble(parts)
+    want = stand_in(draws["Pin"], draws["f"])
+    assert [p.shape[0] for p in parts] == [dist.shard_bounds(total, cp.world, r)[1] - dist.shard_bounds(total, cp.world, r)[0] for r in range(cp.world)]
+    assert got.shape == (total, 3) and np.array_equal(got, want)
+    print("REASSEMBLED_OK", cp.world)
+else:
+    assert parts is None
+assert "torch" not in sys.modules
+cp.close()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_shards_reassemble_in_rank_order(tmp_path, world):
+    """BASELINE cfg 4 on the CPU: 1 024 draws sharded over `world` ranks (plain processes, no launcher, no torch), each rank's block
+    gathered to rank 0 and reassembled in draw order."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % ROOT)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29540 + world),
+                   OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+        env.pop("TORCHELASTIC_RUN_ID", None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
+    assert f"REASSEMBLED_OK {world}" in outs[0][0]
+
+
+def test_control_plane_tcp_transport(tmp_path):
+    """EFTB_CP_TCP_PORT switches the hub to TCP on MASTER_ADDR (same protocol)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", EFTB_CP_TCP_PORT="29562")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
+    assert "GATHER_OK" in outs[0][0]
 
 
 @pytest.mark.parametrize("Nl", [2, 3])
@@ -272,3 +331,45 @@ def test_window_tables_against_reference(golden, case):
     assert relerr(Waldk[:, :, 10, :], g["window_Waldk_k10"]) < 1e-9
     if "window_Waldk_sum_p" in g:
         assert relerr(Waldk.sum(axis=-1), g["window_Waldk_sum_p"]) < 1e-9
+
+
+def test_cfg3_host_tables_and_joint_rows(golden):
+    """BASELINE cfg 3 at the reference's production settings, host side: the window table builder at accboost 4 / windowk 0.1 against
+    the reference's Waldk rows for the LRG and ELG windows (the cross window goes through the oracle in test_oracle_golden.py), the folded
+    window -> binning [-> chained] operators against the reference's binned / chained templates, and joint_gaussian_rows + data_index
+    against EFTLike's P_NG / P_G on the reference's DR16 data layout."""
+    import cfg3_util as U
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.marginal import data_index, joint_gaussian_rows
+
+    g = golden("cfg3")
+    k = g["k"]
+    assert np.array_equal(TB.window_pgrid(float(k.max()), 4), g["window_p"])
+    for t in ("LRG_NGC", "ELG_NGC"):
+        tab = U.window_table(t)
+        Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3, accboost=4)
+        Wfold, Waldk = TB.window_fold(k, Wal, p, windowk=0.1)
+        assert relerr(Waldk[:, :, 10, :], g[t + "_Waldk_k10"]) < 1e-9 and relerr(Waldk[:, :, 37, :], g[t + "_Waldk_k37"]) < 1e-9
+        assert relerr(Waldk.sum(axis=-1), g[t + "_Waldk_sum_p"]) < 1e-9
+        Bm, keff, _, _ = TB.binning_operator(k, g[t + "_kout"])
+        assert relerr(keff[None], g[t + "_keff"][None]) < 1e-13
+        op = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm, chained=U.CHAINED[t])
+        want = U.final_templates(g, t)
+        for n in U.NAMES:
+            assert relerr(np.einsum("alxk,lnk->anx", op, g[f"{t}_ap_{n}"]), want[n]) < 1e-9, (t, n)
+    # rows x final templates == EFTLike.PNG / PG
+    nb = 18
+    p = U.params(g)
+    fs = [float(g[t + "_f"]) for t in U.TRACERS]
+    index = np.concatenate([data_index([int(l) for l in g[t + "_ls"]], U.masks(g, t), nb, tracer=i, nl=3) for i, t in enumerate(U.TRACERS)])
+    assert index.size == g["data_vector"].size == 142
+    block = np.zeros((3, 3, 24, nb))
+    for i, t in enumerate(U.TRACERS):
+        st = U.final_templates(g, t)
+        no, nx = st["P11l"].shape[0], st["P11l"].shape[-1]
+        block[i, :no, :, :nx] = np.concatenate([st[n] for n in U.NAMES], axis=1)
+    for tag in ("full", "xnost"):
+        names = [str(n) for n in g[tag + "_names"]]
+        rows = joint_gaussian_rows(U.bases(), fs, p, names, U.scales(g))
+        V = np.einsum("tgr,tlrx->gtlx", rows, block).reshape(len(names) + 1, -1)[:, index]
+        assert relerr(V[0][None], g["PNG"][None]) < 1e-13 and relerr(V[1:], g[tag + "_PG"]) < 1e-13, tag

@@ -294,3 +294,72 @@ def test_window_matrix(golden):
         assert relerr(OE.window_matrix_convolve(c["k"], m, c["ap_" + n]), g["wm_" + n]) < 1e-12, n
     assert relerr(OE.window_matrix_convolve(c["k"], m, c["ap_Pstl"]), g["st_wm_Pstl"]) < 1e-12
     assert np.array_equal(g["wm_Pstl"], c["ap_Pstl"])
+
+
+def test_cfg3_production_window_and_joint_likelihood(golden):
+    """BASELINE cfg 3 with the parameters the reference ships (yaml: accboost 4, windowk 0.1, per-tracer DR16 windows, ELG chained,
+    window_st off as a variant): oracle window / binning / chained on the reference's AP-stage templates, then EFTLike.PNG / PG and the
+    Jeffreys, flat-prior marginalised log-posterior on the reference's own data vector and covariance -- full and `_xnost` sets."""
+    import os
+
+    import cfg3_util as U
+    from oracle import OracleConfig
+    from oracle import marginal as M
+
+    g = golden("cfg3")
+    p = U.params(g)
+    # oracle window at production settings: the cross spectrum's window (one FFTLog(4096) precompute ~ 20 s; the other two tracers go
+    # through the host table builder in test_tables.py and through the device precompute in the GPU tests)
+    t = "X_NGC"
+    eng = OracleEngine(OracleConfig(Nl=3, ndA=4.5e-5, window_file=os.path.join(U.GOLD, "win_NGC_X_sQ024.npy"), window_accboost=int(g["accboost"]),
+                                    windowk=float(g["windowk"]), kout=g[t + "_kout"]))
+    assert np.array_equal(eng.p, g["window_p"]) and eng.p.size == 1540
+    assert relerr(eng.Waldk[:, :, 10, :], g[t + "_Waldk_k10"]) < 1e-12 and relerr(eng.Waldk[:, :, 37, :], g[t + "_Waldk_k37"]) < 1e-12
+    assert relerr(eng.Waldk.sum(axis=-1), g[t + "_Waldk_sum_p"]) < 1e-12
+    st = {n: g[f"{t}_ap_{n}"] for n in U.NAMES}
+    st["Picc"] = np.zeros((3, 50))
+    w = eng.window(st)
+    for n in U.NAMES:
+        assert relerr(w[n], g[f"{t}_window_{n}"]) < TOL, n
+    b = eng.binning(w)
+    assert relerr(eng.keff[None], g[t + "_keff"][None]) < 1e-14
+    for n in U.NAMES:
+        assert relerr(b[n], g[f"{t}_binned_{n}"]) < TOL, n
+    # chained ELG from its binned templates
+    ch = eng.chained({n: g["ELG_NGC_binned_" + n] for n in U.NAMES} | {"Picc": np.zeros((3, 17))})
+    for n in U.NAMES:
+        assert relerr(ch[n], g["ELG_NGC_chained_" + n]) < 1e-13, n
+    # joint data vector: P_NG and P_G of every tracer in EFTLike's order
+    PNG, PGrows = [], {}
+    for t, sc in zip(U.TRACERS, U.scales(g)):
+        st = U.final_templates(g, t)
+        No = st["P11l"].shape[0]
+        cross = t in U.CROSS
+        A, B = (U.CROSS[t] if cross else (t, t))
+        ngA = [p[A + "_b1"], p[A + "_b2"], 0.0, p[A + "_b4"], 0.0, 0.0, 0.0]
+        ngB = [p[B + "_b1"], p[B + "_b2"], 0.0, p[B + "_b4"], 0.0, 0.0, 0.0] if cross else None
+        oe = OracleEngine(OracleConfig(Nl=3, No=No, **sc))
+        plk = oe.reduce_plk(float(g[t + "_f"]), dict(st, Picc=np.zeros((No, st["P11l"].shape[-1]))), ngA, ngB, (0.0, 0.0, 0.0))
+        assert relerr(plk, g[t + "_plk"][:No]) < 1e-13, t
+        mk = U.masks(g, t)
+        ls = [int(l) for l in g[t + "_ls"]]
+        PNG.append(M.flatten(ls, plk, mk))
+        tab = M.derivative_table(st, float(g[t + "_f"]), p[A + "_b1"], p[B + "_b1"] if cross else None, **sc)
+        for name, arr in zip(M.gaussian_names(t + "_", tuple(x + "_" for x in U.CROSS[t]) if cross else ()), tab):
+            PGrows.setdefault(name, []).append((t, M.flatten(ls, arr, mk)))
+    PNG = np.hstack(PNG)
+    assert relerr(PNG[None], g["PNG"][None]) < 1e-13
+    sizes = {t: int(sum(b - a for a, b in g[t + "_mask"])) for t in U.TRACERS}
+    starts = dict(zip(U.TRACERS, np.concatenate([[0], np.cumsum([sizes[t] for t in U.TRACERS])])))
+    for tag in ("full", "xnost"):
+        names = [str(n) for n in g[tag + "_names"]]
+        PG = np.zeros((len(names), PNG.size))
+        for i, n in enumerate(names):
+            for t, v in PGrows[n]:
+                PG[i, starts[t] : starts[t] + sizes[t]] = v
+        assert relerr(PG, g[tag + "_PG"]) < 1e-13, tag
+        flat = (np.zeros(len(names)), np.full(len(names), np.inf))
+        logp, fullchi2, best, _ = M.marginalized_logp(PG, PNG, g["data_vector"], g["invcov"], *flat, jeffreys=True, return_best=True)
+        assert np.isclose(logp, g[tag + "_logp"], rtol=1e-11) and np.isclose(fullchi2, g[tag + "_fullchi2"], rtol=1e-9), tag
+        assert relerr(best[None], g[tag + "_best"][None]) < 1e-8, tag
+        assert np.isclose(M.marginalized_logp(PG, PNG, g["data_vector"], g["invcov"], *flat), g[tag + "_logp_nojeffreys"], rtol=1e-11)

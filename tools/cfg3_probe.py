@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE cfg 3 on one GPU: three tracers per likelihood point (LRG, ELG chained, X cross), Nk = 512, window + with_interp data k,
 joint marginalised log-posterior.  Prints likelihood points per second, inputs resident (run + LOGP) and PCIe-inclusive
-(eftb_eval_logp_batch).  GPU box.  The window of all three tracers is the LRG fixture (the workload, not the data, is what is timed)."""
+(eftb_eval_logp_batch).  GPU box.  Production window settings of the reference's yamls (accboost 4, windowk 0.1) with the per-tracer
+DR16 windows win_NGC_{LRG,ELG,X}; the window matrices come from the device precompute (eftb_window_precompute)."""
 import os
 import sys
 import time
@@ -23,16 +24,22 @@ ZS = (0.696, 0.849, 0.763)
 k = synth.survey_kgrid(NK)
 cfg = EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, APst=True, DA_AP=float(synth.da_func(synth.OM_AP, 0.7)), H_AP=float(synth.hubble(synth.OM_AP, 0.7)))
 eng = Engine(cfg, max_batch=NW * NTR)
-tab = np.load(os.path.join(ROOT, "tests", "golden", "win_NGC_LRG_sQ024.npy"))
-Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3, accboost=1)
-Wfold, _ = TB.window_fold(k, Wal, p, windowk=0.1)
+from eftpipe_amd.window import window_matrix_device
+
 kdata = np.arange(0.02, 0.2, 0.005)
 interp = TB.interp_operator(k, kdata)
 nd = kdata.size
-opL = TB.compose_operator(3, NK, Wfold=Wfold, binning=interp)
-opE = np.zeros_like(opL)
-opE[:2] = TB.compose_operator(3, NK, Wfold=Wfold, binning=interp, chained=True)
-ops = [eng.add_operator(o) for o in (opL, opE, opL)]
+ops_host = []
+for name, chained in (("LRG", False), ("ELG", True), ("X", False)):
+    tab = np.load(os.path.join(ROOT, "tests", "golden", f"win_NGC_{name}_sQ024.npy"))
+    timing = {}
+    _, p, _, Wfold = window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 3, windowk=0.1, accboost=4, timing=timing)
+    print(f"window {name}: Np = {p.size}, host tables {timing['host_tables_s']:.2f} s, device kernels {timing['device_kernels_ms']:.2f} ms")
+    op = np.zeros((3, 3, nd, NK))
+    o = TB.compose_operator(3, NK, Wfold=Wfold, binning=interp, chained=chained)
+    op[: o.shape[0]] = o
+    ops_host.append(op)
+ops = [eng.add_operator(o) for o in ops_host]
 eng.set_tracers(NTR, ops)
 Pin, f, DA, H = [], [], [], []
 for w in range(NW):

@@ -544,10 +544,166 @@ def tables_fixture(ref):
     print("tables written")
 
 
+# ----------------------------------------------------------------------------- BASELINE cfg 3 as shipped
+# reference cobaya/yamls/DR16_noric_LEX_NS_LP024_kmax0.20_EQ02_kmax0.20_XP024_kmax0.20.yaml:6-27 (tracers), :52-65 (defaults: km, kr,
+# APeffect, window accboost 4 / windowk 0.1), :66-111 (likelihood LEX_NGC: data files, kmin/kmax, chained, binning, Jeffreys, marg)
+CFG3_TRACERS = {
+    "LRG_NGC": dict(z=0.696, nd=4.5e-5, win="win_NGC_LRG.txt", data="NGC_LRG_P.txt", ls=[0, 2, 4], kmin=0.02, kmax=0.20, chained=False),
+    "ELG_NGC": dict(z=0.849, nd=2.3e-4, win="win_NGC_ELG.txt", data="NGC_ELG_Q.txt", ls=[0, 2], kmin=0.03, kmax=0.20, chained=True),
+    "X_NGC": dict(z=0.763, cross=("LRG_NGC", "ELG_NGC"), win="win_NGC_X.txt", data="NGC_X_P.txt", ls=[0, 2, 4], kmin=0.02, kmax=0.20, chained=False),
+}
+CFG3_KM, CFG3_KR = 0.7, 0.25
+CFG3_AP = dict(Om_AP=0.307115, rdrag_AP=147.66, h_AP=0.6777, APst=True)
+CFG3_WINDOW = dict(accboost=4, windowk=0.1)
+CFG3_COV, CFG3_NREAL = "cov_NGC_L024E02X024_PQP.txt", 1000
+CFG3_NG = {"LRG_NGC_b1": 2.1, "LRG_NGC_c2": 0.31, "LRG_NGC_c4": 0.0, "ELG_NGC_b1": 1.307, "ELG_NGC_c2": 0.31, "ELG_NGC_c4": 0.0}  # yaml refs
+CFG3_MARG = ["b3", "cct", "cr1", "cr2", "ce0", "cequad"]  # per auto tracer (cemono excluded); the cross spectrum: X_NGC_ce0, X_NGC_cequad
+
+
+def cfg3_fixture(ref):
+    """BASELINE cfg 3 with the parameters the reference ships: three kernels per likelihood point (LRG z=0.696, ELG z=0.849, cross
+    spectrum z=0.763), each with its own P_lin, AP fiducial and DR16 window at accboost=4 / windowk=0.1, ELG chained, every spectrum
+    binned onto its data k; then the joint EFTLike data vector / covariance of the reference's own DR16 files (kmin/kmax masks, Hartlap)
+    and Marginalizable.marginalized_logp (Jeffreys, flat priors) in the full and the `_xnost` (no cross-spectrum stochastic terms)
+    parameter sets.  Native 50-point k grid.  Everything below is computed by reference code; the glue follows theory.py:557-609 and
+    likelihood.py:281-307, 340-372, 483-549."""
+    pb, LK = ref.pybird, ref.likelihood
+    ddir = os.path.join(REFERENCE_ROOT, "data", "DR16_noric")
+    Nl = 3
+    out = dict(Nl=Nl, km=CFG3_KM, kr=CFG3_KR, tracers=np.array(list(CFG3_TRACERS)), accboost=CFG3_WINDOW["accboost"], windowk=CFG3_WINDOW["windowk"],
+               Om_AP=CFG3_AP["Om_AP"], ng_names=np.array(list(CFG3_NG)), ng_values=np.array(list(CFG3_NG.values())))
+    ng = dict(CFG3_NG)
+    for t in ("LRG_NGC_", "ELG_NGC_"):
+        ng[t + "b2"] = (ng[t + "c2"] + ng[t + "c4"]) / np.sqrt(2.0)
+        ng[t + "b4"] = (ng[t + "c2"] - ng[t + "c4"]) / np.sqrt(2.0)
+    minfo, birds, bases, plk, tables = {}, {}, {}, {}, {}
+    for t, spec in CFG3_TRACERS.items():
+        z = spec["z"]
+        if "cross" in spec:
+            A, B = (CFG3_TRACERS[x] for x in spec["cross"])
+            co = pb.Common(Nl=Nl, No=Nl, kmax=0.3, kmA=CFG3_KM, krA=CFG3_KR, ndA=A["nd"], kmB=CFG3_KM, krB=CFG3_KR, ndB=B["nd"])
+            bases[t] = ref.parambasis.WestCoastBasis(prefix=t + "_", cross_prefix=[x + "_" for x in spec["cross"]])
+        else:
+            co = pb.Common(Nl=Nl, No=Nl, kmax=0.3, kmA=CFG3_KM, krA=CFG3_KR, ndA=spec["nd"])
+            bases[t] = ref.parambasis.WestCoastBasis(prefix=t + "_")
+        m = minfo[t] = LK.MultipoleInfo.load(os.path.join(ddir, spec["data"]), spec["ls"], spec["kmin"], spec["kmax"])
+        # synthetic linear spectrum at the tracer's redshift (amplitude ~ growth^2 relative to z = 0.7)
+        cos = synth.cosmology(z=z, A=((1.0 + 0.7) / (1.0 + z)) ** 2)
+        out.update({f"{t}_z": z, f"{t}_Pin": cos["Pin"], f"{t}_f": cos["f"], f"{t}_DA": cos["DA"], f"{t}_H": cos["H"], f"{t}_kout": m.kout,
+                    f"{t}_ls": np.array(m.ls), f"{t}_mask": np.array([[m.kout_mask[l].start, m.kout_mask[l].stop] for l in m.ls]),
+                    f"{t}_co": np.array([co.kmA, co.krA, co.ndA, co.kmB, co.krB, co.ndB])})
+        out["k"], out["kin"] = co.k, cos["kin"]
+        nl = pb.NonLinear(load=False, save=False, co=co)
+        bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+        nl.PsCf(bird)
+        bird.setPsCfl()
+        pb.Resum(co=co).Ps(bird)
+        ap = pb.APeffect(z_AP=z, co=co, **CFG3_AP)
+        out[f"{t}_DA_AP"], out[f"{t}_H_AP"] = ap.DA, ap.H
+        ap.AP(bird)
+        for n, v in stage(bird).items():
+            out[f"{t}_ap_{n}"] = v
+        win = ref.window.Window(window_configspace_file=os.path.join(ddir, spec["win"]), co=co, load=False, save=False, **CFG3_WINDOW)
+        out["window_p"] = win.p
+        out[f"{t}_Waldk_sum_p"] = win.Waldk.sum(axis=-1)
+        out[f"{t}_Waldk_k10"], out[f"{t}_Waldk_k37"] = win.Waldk[:, :, 10, :], win.Waldk[:, :, 37, :]
+        if t == "LRG_NGC":  # window_st=False keeps the stochastic rows (reference window.py:412-415)
+            b2 = ref.transformer.BirdCopier().transform(bird)
+            b2.co = co
+            wns = ref.window.Window(window_configspace_file=os.path.join(ddir, spec["win"]), co=co, load=False, save=False, window_st=False,
+                                    **CFG3_WINDOW)
+            wns.Window(b2)
+            for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+                out[f"{t}_windownost_{n}"] = np.array(getattr(b2, n), copy=True)
+        win.Window(bird)
+        for n, v in stage(bird).items():
+            out[f"{t}_window_{n}"] = v
+        bn = ref.binning.Binning(kout=m.kout, co=co)
+        out[f"{t}_keff"] = bn.keff
+        like = bn.transform(bird)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            out[f"{t}_binned_{n}"] = np.array(getattr(like, n), copy=True)
+        if spec["chained"]:
+            like = ref.chained.Chained().transform(like)
+            for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+                out[f"{t}_chained_{n}"] = np.array(getattr(like, n), copy=True)
+            like.co = pb.Common(Nl=Nl, No=Nl - 1, kmax=0.3, kmA=CFG3_KM, krA=CFG3_KR, ndA=spec["nd"])  # EFTLeaf: ls of a chained product
+            like.PctNNLOl = np.zeros((Nl, 2, m.kout.size))
+        else:
+            like.PctNNLOl = np.zeros((Nl, 2, m.kout.size))
+        birds[t] = like
+        plk[t] = bases[t].reduce_Plk(like, ng).sum()
+        tables[t] = bases[t].reduce_Plk_gaussian_table(like, ng)
+        out[f"{t}_plk"] = plk[t]
+    # ---- EFTLike: joint data vector, masked + Hartlap-corrected covariance (likelihood.py:281-307, 340-372)
+    D = np.hstack([m.data_vector for m in minfo.values()])
+    cov = np.loadtxt(os.path.join(ddir, CFG3_COV))
+    hart = LK.hartlap(CFG3_NREAL, D.size)
+    cov = cov / hart
+    args = ()
+    for m in minfo.values():
+        args += (m.ls, m.ls_tot, m.df.index, m.kmin, m.kmax)
+    invcov = np.linalg.inv(LK.mask_covariance(cov, *args))
+    out.update(data_vector=D, invcov=invcov, hartlap=hart)
+    sizes = [m.data_vector.size for m in minfo.values()]
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    PNG = np.zeros(D.size)
+    for (t, m), i0, i1 in zip(minfo.items(), starts[:-1], starts[1:]):
+        LK.flatten(m.ls, plk[t], m.kout_mask, out=PNG[i0:i1])
+    out["PNG"] = PNG
+    for tag, marg in (("full", [f"{t}_{p}" for t in ("LRG_NGC", "ELG_NGC") for p in CFG3_MARG] + ["X_NGC_ce0", "X_NGC_cequad"]),
+                      ("xnost", [f"{t}_{p}" for t in ("LRG_NGC", "ELG_NGC") for p in CFG3_MARG])):
+
+        class Like(ref.marginal.Marginalizable):
+            log = None
+
+            def marginalizable_params(self):  # likelihood.py:463-468
+                params = []
+                for b in bases.values():
+                    params += b.gaussian_params()
+                return list(dict.fromkeys(params))
+
+            def PG(self):
+                return PGm
+
+            def PNG(self):
+                return PNG
+
+            def get_data_vector(self):
+                return D
+
+            def get_invcov(self):
+                return invcov
+
+            def mpi_debug(self, *a, **k):
+                pass
+
+            mpi_warning = mpi_info = mpi_debug
+
+        like = Like()
+        like.setup_prior({p: None for p in marg})       # `scale:` left empty in the yaml -> flat prior on every parameter
+        names = list(like.valid_prior)
+        PGm = np.zeros((len(names), D.size))           # likelihood.py:483-530: every tracer contributes to the parameters its basis knows
+        for (t, m), i0, i1 in zip(minfo.items(), starts[:-1], starts[1:]):
+            for i, p in enumerate(names):
+                if p in bases[t].gaussian_params() and p in tables[t]:
+                    LK.flatten(m.ls, tables[t][p], m.kout_mask, out=PGm[i, i0:i1])
+        logp, fullchi2, best = like.marginalized_logp(return_bGbest=True, jeffreys=True)
+        out.update({f"{tag}_names": np.array(names), f"{tag}_PG": PGm, f"{tag}_logp": logp, f"{tag}_fullchi2": fullchi2,
+                    f"{tag}_best": np.array([best[p] for p in names]), f"{tag}_logp_nojeffreys": like.marginalized_logp()})
+        print("cfg3", tag, "ndata", D.size, "nG", len(names), "logp", logp, "fullchi2", fullchi2)
+    # the configuration-space windows themselves (data: columns s, Q0, Q2, Q4 of the reference's data/DR16_noric/win_NGC_*.txt)
+    for t, spec in CFG3_TRACERS.items():
+        tab = np.loadtxt(os.path.join(ddir, spec["win"]))[:, :4]
+        np.save(os.path.join(GOLD, spec["win"].replace(".txt", "_sQ024.npy")), tab)
+    np.savez_compressed(os.path.join(GOLD, "cfg3.npz"), **out)
+    print("cfg3 written:", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti", "wmat"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti", "wmat", "cfg3"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -567,6 +723,8 @@ def main():
             opti_fixture(ref)
         elif name == "wmat":
             wmat_fixture(ref)
+        elif name == "cfg3":
+            cfg3_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 

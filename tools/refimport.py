@@ -45,8 +45,16 @@ def load_reference():
         log.logger_setup = lambda *a, **k: None
         mpi.is_main_process = lambda: True
         mpi.root_only = lambda f: f
-        cob.log, cob.mpi = log, mpi
-        sys.modules.update({"cobaya": cob, "cobaya.log": log, "cobaya.mpi": mpi})
+        # eftpipe/likelihood.py subclasses cobaya's Likelihood; only its module-level helpers (MultipoleInfo.load, parse_kmask,
+        # mask_covariance, hartlap, flatten) are used by the fixture generator, so an empty base class is all the import needs
+        lik = types.ModuleType("cobaya.likelihood")
+
+        class Likelihood:
+            pass
+
+        lik.Likelihood = Likelihood
+        cob.log, cob.mpi, cob.likelihood = log, mpi, lik
+        sys.modules.update({"cobaya": cob, "cobaya.log": log, "cobaya.mpi": mpi, "cobaya.likelihood": lik})
         pkg = types.ModuleType("eftpipe")
         pkg.__path__ = [os.path.join(REFERENCE_ROOT, "eftpipe")]
         sys.modules["eftpipe"] = pkg
@@ -60,4 +68,5 @@ def load_reference():
     ns.parambasis = importlib.import_module("eftpipe.parambasis")
     ns.transformer = importlib.import_module("eftpipe.transformer")
     ns.marginal = importlib.import_module("eftpipe.marginal")
+    ns.likelihood = importlib.import_module("eftpipe.likelihood")
     return ns
