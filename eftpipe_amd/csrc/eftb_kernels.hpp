@@ -1272,9 +1272,11 @@ __global__ __launch_bounds__(256, 2) void ap_apply_kernel(int Nk, int nmu, const
                                                        const double* __restrict__ Hw, const double* __restrict__ fid,
                                                        const double* __restrict__ mu, const double* __restrict__ PS,
                                                        const double* __restrict__ ROOT, const double* __restrict__ T,
-                                                       const double* __restrict__ YS, double* __restrict__ Tout) {
+                                                       const double* __restrict__ YS, double* __restrict__ Tout,
+                                                       const int4* __restrict__ META) {
     constexpr int NS = NL * NL * 4;
     constexpr int NRT = (NR + RS - 1) / RS;  // rows per lane: the NR rows are split over RS workgroups (blockIdx.z)
+    if (META && !META[(size_t)blockIdx.y * gridDim.x + blockIdx.x].w) return;  // fallback duty only: the tile went through ap_rows_kernel
     constexpr int NACC = NL * NRT;
     extern __shared__ double sm[];
     double* s_k = sm;               // [Nk]
@@ -1393,6 +1395,240 @@ __global__ __launch_bounds__(256, 2) void ap_apply_kernel(int Nk, int nmu, const
             const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
             Tout[o] = T[o];
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AP, two-kernel form (the default path; ap_apply_kernel above stays as the fallback for distortions that cross more knot
+// intervals than the fast path keeps).  The stage is LINEAR in the spline data: for one cosmology and one output k
+//     out[l][row][k] = c sum_{l'} sum_{d} ( Wy[l'][l][d] y[l'][row][i0 + d] + Ws[l'][l][d] s[l'][row][i0 + d] ),
+// where (y, s) are the knot values / derivatives written by spline_kernel, i0 = i0(w, k) the lowest knot interval k'(mu) visits and
+// the knot weights follow from the interval moments of ap_apply_kernel by inserting the Hermite form of the cubic:
+//     c0 = y_i, c1 = s_i, c2 = (3 sl - 2 s_i - s_i+1) / h, c3 = (s_i + s_i+1 - 2 sl) / h^2, sl = (y_i+1 - y_i) / h   =>
+//     left knot :  Wy += m0 - 3 m2 / h^2 + 2 m3 / h^3,   Ws += m1 - 2 m2 / h + m3 / h^2
+//     right knot:  Wy += 3 m2 / h^2 - 2 m3 / h^3,        Ws += - m2 / h + m3 / h^2            (m_p = M_i[l][l'][p]).
+// The weights depend on (DA, H) only -- inputs -- so ap_weights_kernel runs on the look-ahead stream with the prefix sums, off the
+// critical path; what is left behind the resummation is ap_rows_kernel, a banded product that streams the spline data once
+// through LDS: 66 MB in, 33 MB out, a few dozen FMAs per output.
+//   ap_weights_kernel  workgroup = 64 k x 4 waves of one cosmology; wave <-> a share of the (l', l) pairs, the thread walks its k's
+//                      intervals in mu order carrying the shared knot's contribution; writes W[w][tile][d][l][l'][{y,s}][64], i0[w][k] and
+//                      the tile's window (lowest knot, span, knots per k); tiles that need more than APW_DCAP knots per k or a window
+//                      of more than APW_WIN knots are flagged and left to ap_apply_kernel
+//   ap_rows_kernel     workgroup = (tile of 64 k, cosmology, chunk of NRC template rows); wave <-> output multipole l; the (y, s)
+//                      window of the chunk's rows (all l') sits in LDS, the weights of knot d are six coalesced loads per thread
+// ------------------------------------------------------------------------------------------------
+constexpr int APW_DCAP = 12;  // knots per k on the fast path
+constexpr int APW_WIN = 96;   // LDS window of a tile, in knots (64 k + the drift of i0 across the tile + the knots per k)
+
+template <int NL>
+__global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+                                                         const double* __restrict__ Hw, const double* __restrict__ fid,
+                                                         const double* __restrict__ mu, const double* __restrict__ PS,
+                                                         const double* __restrict__ ROOT, double* __restrict__ W, int* __restrict__ I0,
+                                                         int4* __restrict__ META) {
+    constexpr int NS = NL * NL * 4, NP = NL * NL, PPW = (NP + 3) / 4;  // prefix sequences, (l', l) pairs, pairs per wave
+    extern __shared__ double sm[];
+    double* s_k = sm;          // [Nk]
+    double* s_root = sm + Nk;  // [nmu]
+    __shared__ int s_red[3];   // min i0, max i0, max knots per k over the tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, k = kt * 64 + lane;
+    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
+    for (int e = threadIdx.x; e < nmu; e += 256) s_root[e] = ROOT[(size_t)w * nmu + e];
+    if (threadIdx.x == 0) {
+        s_red[0] = 0x7fffffff;
+        s_red[1] = 0;
+        s_red[2] = 0;
+    }
+    __syncthreads();
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
+    const bool live = k < Nk;
+    const double kq = s_k[live ? k : Nk - 1] / qperp;
+    const double* ps = PS + (size_t)w * (nmu + 1) * NS;
+    const bool up = g > 0.0;
+    const int dir = up ? 1 : -1;
+    const double jscale = (nmu - 1) / mu[nmu - 1];
+    auto cross = [&](double kb) -> int {  // first node past knot kb (as in ap_apply_kernel)
+        const double rc = kb / kq, x = (rc * rc - 1.0) / g;
+        int j = nmu;
+        if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
+        j = max(0, min(j, nmu));
+        while (j > 0 && (up ? kq * s_root[j - 1] >= kb : kq * s_root[j - 1] < kb)) --j;
+        while (j < nmu && !(up ? kq * s_root[j] >= kb : kq * s_root[j] < kb)) ++j;
+        return j;
+    };
+    const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
+    const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
+    const int nslot = (up ? i_last - i_first : i_first - i_last) + 1;
+    const int ilo = min(i_first, i_last);
+    if (wave == 0) {
+        if (live) {
+            I0[(size_t)w * KT * 64 + k] = ilo;
+            atomicMin(&s_red[0], ilo);
+            atomicMax(&s_red[1], ilo);
+            atomicMax(&s_red[2], nslot + 1);
+        } else {
+            I0[(size_t)w * KT * 64 + k] = -1;  // resolved to the tile's lowest knot by the consumer
+        }
+    }
+    __syncthreads();
+    const int jmin = s_red[0], D = s_red[2], span = s_red[1] - jmin + D;
+    const bool fallback = D > APW_DCAP || span > APW_WIN;
+    if (threadIdx.x == 0) META[(size_t)w * KT + kt] = make_int4(jmin, span, D, fallback ? 1 : 0);
+    if (fallback) return;
+    double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + lane;  // + ((d * NL + l) * NL + lp) * 128 (+ 64 for the s weight)
+    double cy[PPW], cs[PPW];  // contribution to the knot shared with the next interval in mu order
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) cy[q] = cs[q] = 0.0;
+    int jb_prev = 0;
+    for (int s = 0; s < (live ? nslot : 0); ++s) {
+        const int i = i_first + s * dir;
+        const double klo = s_k[i], khi = s_k[i + 1];
+        const int ja = jb_prev;
+        const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
+        jb_prev = jb;
+        const double h = khi - klo, ih = 1.0 / h, ih2 = ih * ih, ih3 = ih2 * ih;
+        const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
+        const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
+        const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
+        const double* pa = ps + (size_t)ja * NS;
+        const double* pb = ps + (size_t)jb * NS;
+        // knot written by this step: the one this interval does NOT share with the next interval in mu order
+        const int dk = up ? s : nslot - s;  // relative to ilo: rising k' leaves the left knot behind, falling k' the right one
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            const int p = wave + 4 * q;  // pair (l', l) = (p / NL, p % NL), the order of the prefix sums
+            if (p < NP) {
+                double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+                if (jb > ja) {
+                    const double4 b4 = *reinterpret_cast<const double4*>(pb + p * 4), a4 = *reinterpret_cast<const double4*>(pa + p * 4);
+                    const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
+                    m0 = d0;
+                    m1 = fma(c10, d0, c11 * d1);
+                    m2 = fma(c20, d0, fma(c21, d1, c22 * d2));
+                    m3 = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+                }
+                const double yL = m0 - 3.0 * m2 * ih2 + 2.0 * m3 * ih3, sL = m1 - 2.0 * m2 * ih + m3 * ih2;
+                const double yR = 3.0 * m2 * ih2 - 2.0 * m3 * ih3, sR = -m2 * ih + m3 * ih2;
+                const int lp = p / NL, l = p % NL;
+                double* o = wt + (size_t)((dk * NL + l) * NL + lp) * 128;
+                o[0] = cy[q] + (up ? yL : yR);
+                o[64] = cs[q] + (up ? sL : sR);
+                cy[q] = up ? yR : yL;
+                cs[q] = up ? sR : sL;
+            }
+        }
+    }
+    // the far knot of the last interval, then zeros up to the tile's knot count (lanes past the grid: zeros throughout)
+    const int nk = live ? nslot + 1 : 0;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int p = wave + 4 * q;
+        if (p < NP) {
+            const int lp = p / NL, l = p % NL;
+            if (live) {
+                double* o = wt + (size_t)(((up ? nslot : 0) * NL + l) * NL + lp) * 128;
+                o[0] = cy[q];
+                o[64] = cs[q];
+            }
+            for (int d = nk; d < D; ++d) {
+                double* o = wt + (size_t)((d * NL + l) * NL + lp) * 128;
+                o[0] = 0.0;
+                o[64] = 0.0;
+            }
+        }
+    }
+}
+
+template <int NL, int NR, int NRC>
+__global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, const double* __restrict__ DAw, const double* __restrict__ Hw,
+                                                          const double* __restrict__ fid, const double* __restrict__ W,
+                                                          const int* __restrict__ I0, const int4* __restrict__ META,
+                                                          const double* __restrict__ T, const double* __restrict__ YS,
+                                                          double* __restrict__ Tout) {
+    constexpr int NP = NL * NL;
+    __shared__ double2 win[NL * NRC * APW_WIN];  // (y, s) of series (l', row of the chunk) at knots jmin .. jmin + span
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, r0 = blockIdx.z * NRC, k = kt * 64 + lane;
+    const int4 meta = META[(size_t)w * KT + kt];
+    if (meta.w) return;  // left to ap_apply_kernel
+    const int jmin = meta.x, D = meta.z;  // (meta.y, the span, is bounded by APW_WIN: flagged tiles never get here)
+    const int nrow = min(NRC, NR - r0);
+    // stage the window: one series = span contiguous double2, read as one or two 1 KB wave loads
+    {
+        const double2* ys = reinterpret_cast<const double2*>(YS) + (size_t)w * NL * NROW * Nk;
+        const int nser = NL * nrow;
+        for (int e0 = l * 4; e0 < nser; e0 += 4 * NL) {  // four series per wave and trip: eight loads in flight
+            double2 v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u, nser - 1), lp = e / nrow, r = e % nrow;
+                const double2* src = ys + ((size_t)lp * NROW + r0 + r) * Nk;
+                v[u][0] = src[min(jmin + lane, Nk - 1)];
+                v[u][1] = src[min(jmin + 64 + lane, Nk - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u;
+                if (e < nser) {
+                    const int lp = e / nrow, r = e % nrow;
+                    double2* dst = win + (lp * NRC + r) * APW_WIN;
+                    dst[lane] = v[u][0];
+                    if (64 + lane < APW_WIN) dst[64 + lane] = v[u][1];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool live = k < Nk;
+    int o = I0[(size_t)w * KT * 64 + k] - jmin;
+    if (o < 0) o = 0;  // lanes past the grid carry zero weights
+    const double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + (size_t)l * NL * 128 + lane;
+    double acc[NRC];
+#pragma unroll
+    for (int r = 0; r < NRC; ++r) acc[r] = 0.0;
+    double wy[NL], ws[NL], wyn[NL], wsn[NL];
+#pragma unroll
+    for (int lp = 0; lp < NL; ++lp) {
+        wyn[lp] = wt[lp * 128];
+        wsn[lp] = wt[lp * 128 + 64];
+    }
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            wy[lp] = wyn[lp];
+            ws[lp] = wsn[lp];
+        }
+        if (d + 1 < D) {  // the next knot's weights fly under this knot's rows
+            const double* wn = wt + (size_t)(d + 1) * NP * 128;
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                wyn[lp] = wn[lp * 128];
+                wsn[lp] = wn[lp * 128 + 64];
+            }
+        }
+        const double2* wp = win + o + d;
+#pragma unroll
+        for (int r = 0; r < NRC; ++r) {
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                const double2 v = wp[(lp * NRC + r) * APW_WIN];
+                acc[r] = fma(wy[lp], v.x, fma(ws[lp], v.y, acc[r]));
+            }
+        }
+    }
+    if (!live) return;
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double c = 2.0 / (qperp * qperp * qpar);
+    double* dst = Tout + (((size_t)w * NL + l) * NROW + r0) * Nk + k;
+#pragma unroll
+    for (int r = 0; r < NRC; ++r)
+        if (r < nrow) dst[(size_t)r * Nk] = c * acc[r];
+    if (NR < NROW && blockIdx.z == 0) {  // rows that APeffect leaves alone (Pstl unless APst)
+        const size_t base = (((size_t)w * NL + l) * NROW + NR) * Nk + k;
+#pragma unroll
+        for (int r = 0; r < NROW - NR; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];
+    }
 }
 
 // Staged inputs: page-locked host block -> device block, as a kernel on the copy stream (a DMA transfer brings cache maintenance on the

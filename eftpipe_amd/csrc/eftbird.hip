@@ -53,6 +53,13 @@ struct eftb_engine {
     double *SD = nullptr, *Talt = nullptr, *part = nullptr;
     double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][80][8], per-s records [B][NS][48]
     double *APP = nullptr, *APR = nullptr, *APP2 = nullptr, *APR2 = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
+    // AP fast path (ap_weights_kernel / ap_rows_kernel): knot weights [B][tiles][APW_DCAP][Nl][Nl][2][64], lowest knot per k [B][tiles * 64],
+    // window per tile [B][tiles]; second set for the look-ahead of overlapped runs (swapped together with APP / APR)
+    double *APW = nullptr, *APW2 = nullptr;
+    int *API = nullptr, *API2 = nullptr;
+    int4 *APM = nullptr, *APM2 = nullptr;
+    bool ap_fast = true;  // EFTB_AP_FAST=0: every tile through ap_apply_kernel (the pre-weights form, kept as the fallback)
+    int ap_chunk = 8;     // template rows per workgroup of ap_rows_kernel (EFTB_AP_CHUNK=6|8|12)
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
     double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
     double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of the P22 basis [B][BAS22][KSYN] and of P13 [B][10][KLIN]
@@ -383,6 +390,15 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     if (c.Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(320), pflds, st, PF_ARGS);
     else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(320), pflds, st, PF_ARGS);
 #undef PF_ARGS
+    if (!e->ap_fast) return;
+    // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
+    const dim3 wgrid((c.Nk + 63) / 64, B);
+    const size_t wlds = ((size_t)c.Nk + c.nmu) * sizeof(double);
+#define APW_ARGS c.Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, \
+                 e->APW, e->API, e->APM
+    if (c.Nl == 3) hipLaunchKernelGGL((ap_weights_kernel<3>), wgrid, dim3(256), wlds, st, APW_ARGS);
+    else hipLaunchKernelGGL((ap_weights_kernel<2>), wgrid, dim3(256), wlds, st, APW_ARGS);
+#undef APW_ARGS
 }
 
 // nnlo_pass: the linear stages (RESUM / AP / PROJECT) once more, on the NNLO block (pointers swapped in by launch_stages)
@@ -532,6 +548,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (side_ap) {
             std::swap(e->APP, e->APP2);
             std::swap(e->APR, e->APR2);
+            std::swap(e->APW, e->APW2);
+            std::swap(e->API, e->API2);
+            std::swap(e->APM, e->APM2);
             if (ap_side && hipStreamWaitEvent(st, e->evBack[bslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");  // its reader
             launch_ap_prefix(e, st, B);
         }
@@ -628,8 +647,29 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             if (hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess) return fail("eftb_run: stream join failed");
             joined = true;
         }
+        if (e->ap_fast) {
+            // banded product of the knot weights with the spline data; rows [nr, 24) are copied through
+            const int kt = (Nk + 63) / 64;
+#define APR_ARGS Nk, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, b[EFTB_B_TEMPL], e->SD, e->Talt
+#define APR_LAUNCH(NLV, NRV, NRC) hipLaunchKernelGGL((ap_rows_kernel<NLV, NRV, NRC>), dim3(kt, B, (NRV + NRC - 1) / NRC), dim3(64 * NLV), 0, st, APR_ARGS)
+#define APR_PICK(NRC)                                  \
+    do {                                               \
+        if (Nl == 3 && nr == 21) APR_LAUNCH(3, 21, NRC);    \
+        else if (Nl == 3) APR_LAUNCH(3, NROW, NRC);         \
+        else if (nr == 21) APR_LAUNCH(2, 21, NRC);          \
+        else APR_LAUNCH(2, NROW, NRC);                      \
+    } while (0)
+            if (e->ap_chunk == 6) APR_PICK(6);
+            else if (e->ap_chunk == 12) APR_PICK(12);
+            else APR_PICK(8);
+#undef APR_PICK
+#undef APR_LAUNCH
+#undef APR_ARGS
+        }
+        // the pre-weights form: every tile (EFTB_AP_FAST=0), or only the tiles the fast path flagged (strong distortions)
+        const int4* gate = e->ap_fast ? e->APM : nullptr;
 #define AP_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), \
-                e->APP, e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt
+                e->APP, e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt, gate
         const dim3 apgrid((Nk + 63) / 64, B, rs);
         const size_t aplds = ((size_t)Nk + c.nmu + (size_t)4 * Nl * ((nr + rs - 1) / rs) * 64) * sizeof(double);
 #define AP_LAUNCH(NLV, NRV, RSV) hipLaunchKernelGGL((ap_apply_kernel<NLV, NRV, RSV>), apgrid, dim3(256), aplds, st, AP_ARGS)
@@ -874,7 +914,15 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         HIPCHK(hipMalloc(&e->APR, (size_t)c.max_batch * c.nmu * sizeof(double)));
         HIPCHK(hipMalloc(&e->APP2, (size_t)c.max_batch * (c.nmu + 1) * c.Nl * c.Nl * 4 * sizeof(double)));
         HIPCHK(hipMalloc(&e->APR2, (size_t)c.max_batch * c.nmu * sizeof(double)));
+        const size_t kt = (c.Nk + 63) / 64;
+        for (int q = 0; q < 2; ++q) {
+            HIPCHK(hipMalloc(q ? &e->APW2 : &e->APW, (size_t)c.max_batch * kt * APW_DCAP * c.Nl * c.Nl * 2 * 64 * sizeof(double)));
+            HIPCHK(hipMalloc(q ? &e->API2 : &e->API, (size_t)c.max_batch * kt * 64 * sizeof(int)));
+            HIPCHK(hipMalloc(q ? &e->APM2 : &e->APM, (size_t)c.max_batch * kt * sizeof(int4)));
+        }
     }
+    if (const char* f = getenv("EFTB_AP_FAST")) e->ap_fast = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_AP_CHUNK")) e->ap_chunk = atoi(f);
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 4 * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 4 * sizeof(int));
     HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
@@ -1069,8 +1117,11 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
             return fail("eftb_set_likelihood: index[%d]=%d outside the template block [%d x %d][24][%d]", a, index[a], e->ntr, lnl, lnx);
     for (int a = 0; a < ndata; ++a)
         for (int b2 = 0; b2 < a; ++b2) {
+            // symmetric up to the rounding of a matrix inversion (the reference passes np.linalg.inv(cov) as it comes out, likelihood.py:372):
+            // measured against the diagonal, not against the element itself -- small off-diagonal entries carry the inversion's absolute error
             const double x = invcov[(size_t)a * ndata + b2], y = invcov[(size_t)b2 * ndata + a];
-            if (fabs(x - y) > 1e-12 * (fabs(x) + fabs(y)) + 1e-300) return fail("eftb_set_likelihood: invcov is not symmetric at (%d, %d)", a, b2);
+            const double sc = sqrt(fabs(invcov[(size_t)a * ndata + a] * invcov[(size_t)b2 * ndata + b2]));
+            if (fabs(x - y) > 1e-8 * sc + 1e-300) return fail("eftb_set_likelihood: invcov is not symmetric at (%d, %d)", a, b2);
         }
     HIPCHK(hipSetDevice(e->c.device));
     HIPCHK(sync_all(e));  // a likelihood stage of an overlapped run may still be reading the old tables on the back-half stream
@@ -1118,6 +1169,7 @@ void eftb_destroy(eftb_engine* e) {
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
     }
     e->gathered = nullptr;  // (one of gathered2)
+    for (void* p : {(void*)e->APW, (void*)e->APW2, (void*)e->API, (void*)e->API2, (void*)e->APM, (void*)e->APM2}) if (p) (void)hipFree(p);
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);

@@ -1,24 +1,14 @@
 #!/bin/bash
-# per-kernel times of one bench run (GPU box): rocprofv3 --kernel-trace --stats, printed as a table
-set -e
-cd "$GRAFT_REPO_ROOT"
+# rocprofv3 kernel-trace summary of a short bench run -> $1/stats_kernel_stats.csv (GPU box; the program itself follows `--`)
+OUT=$1; shift
 export TMPDIR=/tmp
-OUT=gpurun_out/kstats
-rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/err.log
-python3 - <<'PY'
-import csv,glob
-f=glob.glob('gpurun_out/kstats/**/*kernel_stats.csv',recursive=True)[0]
-for r in csv.DictReader(open(f)):
-    print(f"{r['Name'][:72]:72s} {r['Calls']:>5s} {float(r['AverageNs'])/1e3:10.1f} us {r['Percentage']:>6s}%")
-PY
-python3 - <<'PY'
-import csv,glob,collections
-f=glob.glob('gpurun_out/kstats/**/*kernel_trace.csv',recursive=True)[0]
-agg=collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
-    n=r['Kernel_Name']
-    if 'synth' in n or 'expand' in n:
-        agg[(n.split('(')[0][-24:], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
-for k,v in agg.items(): print('  per-grid', k, len(v), round(sum(v)/len(v),1), 'us')
+mkdir -p "$OUT"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras "$@" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+f=$(ls "$OUT"/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$f" ] && python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+for r in rows[:28]:
+    print(f'{r["Name"][:70]:70s} calls {int(r["Calls"]):5d}  avg {float(r["AverageNs"])/1e3:9.1f} us  total {float(r["TotalDurationNs"])/1e6:8.2f} ms  {float(r["Percentage"]):5.1f} %')
 PY
