@@ -7,7 +7,7 @@ P22/P13/C11/Cct/C22/C13 -> regroup -> resum -> AP -> bias contraction) over one 
 
     timed region, per step:  eftb_stage_inputs (H2D of Pin, f, DA, H, bias rows of a draw set never seen before)
                              eftb_run_staged   (all stages)
-                             eftb_fetch_previous (P_l of the step before, D2H)            [N > 1: RCCL gather to rank 0, rank 0 copies out]
+                             eftb_fetch_back     (P_l of the step two back, D2H)          [N > 1: RCCL gather to rank 0, rank 0 copies out]
 
 so `value` is the input-to-output rate a sampler sees (H2D + D2H inclusive, every step's P_l lands in host memory inside the timed
 region; pipeline fill and drain are inside it too).  All draws are generated before the clock starts.  The rate of the same kernels
@@ -173,26 +173,37 @@ def main():
         eng.run_staged(mask, B)
 
     def loop(first, n, keep):
-        """n pipelined steps over sets[first : first + n]; every step's output is fetched to the host before the function returns"""
+        """n pipelined steps over sets[first : first + n]; every step's output is fetched to the host before the function returns.
+        The output of step i - 2 is copied out after step i has been launched, so two steps are always queued on the GPU while the
+        host copies and prepares (the engine keeps three sets of per-step inputs / outputs)."""
         for i in range(n):
             stage_and_run(sets[first + i])
             if exchange == "rccl":
                 eng.gather_plk(B, root=0)
-                if i > 0 and rank == 0:
-                    eng.fetch_gathered(B, out=gathered[i - 1] if keep else None)
+                if i > 1 and rank == 0:
+                    eng.fetch_gathered(B, back=2, out=gathered[i - 2] if keep else None)
             elif exchange == "host-fallback":
                 eng.sync()
                 cp.gather_host(eng.get("PLK", (B, NL, NK)))
-            elif i > 0:
-                eng.fetch_previous("PLK", (B, NL, NK), out=results[i - 1] if keep else None)
-        eng.sync()
-        if n and exchange == "rccl":
+            elif i > 1:
+                eng.fetch_previous("PLK", (B, NL, NK), out=results[i - 2] if keep else None, back=2)
+        # drain: the last two steps
+        if exchange == "rccl":
+            eng.sync()
             if rank == 0:
-                eng.fetch_gathered(B, latest=True, out=gathered[n - 1] if keep else None)
-        elif n and exchange == "none":
-            got = eng.get("PLK", (B, NL, NK))
-            if keep:
-                results[n - 1] = got
+                for back in (1, 0):
+                    if n - 1 - back >= 0:
+                        eng.fetch_gathered(B, back=back, out=gathered[n - 1 - back] if keep else None)
+        elif exchange == "none":
+            if n > 1:
+                eng.fetch_previous("PLK", (B, NL, NK), out=results[n - 2] if keep else None, back=1)
+            eng.sync()
+            if n:
+                got = eng.get("PLK", (B, NL, NK))
+                if keep:
+                    results[n - 1] = got
+        else:
+            eng.sync()
 
     loop(0, W, keep=False)
     cp.barrier()

@@ -831,7 +831,10 @@ __device__ inline double estrin16(const double* __restrict__ c, double t, double
     return fma(g1, t8, g0);
 }
 
-__global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
+// RS_WPS = waves per SIMD the kernel is built for (launch bounds): with the basis coefficients in LDS instead of 64 VGPRs the kernel fits three
+// waves per SIMD (<= 168 VGPRs); the 16-byte LDS reads of the next step's polynomials fly under this step's MFMAs.
+template <int RS_WPS>
+__global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
                                                             const double* __restrict__ H, const double* __restrict__ V8,
                                                             const double* __restrict__ RSA, const double* __restrict__ RSC,
                                                             const double* __restrict__ l11, const double* __restrict__ lct,
@@ -844,11 +847,31 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
     const int kc = live ? k : Nk - 1;
     const double k2 = kk[kc] * kk[kc];
     // B operand: this lane evaluates basis polynomials jg and jg + 4 at its point; A operand: rows (16 tau + n), columns jg + 4 t
-    double vb[2][16];
+    __shared__ double s_vb[RS_WPS >= 3 ? RS_NB * 16 : 1];
+    double vb[2][RS_WPS >= 3 ? 1 : 16];
+    int vboff = jg * 16;  // lanes of one group read the same address: broadcast, no conflicts
+    if (RS_WPS >= 3) {
+        if (threadIdx.x < RS_NB * 16) s_vb[threadIdx.x] = V8[threadIdx.x];
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int p = 0; p < 16; ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
+            for (int p = 0; p < (RS_WPS >= 3 ? 1 : 16); ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
+    }
+#define RS_POLY(out0, out1, tt)                                                        \
+    do {                                                                               \
+        const double t_ = (tt), t2_ = t_ * t_, t4_ = t2_ * t2_, t8_ = t4_ * t4_;       \
+        if (RS_WPS >= 3) {                                                             \
+            asm volatile("" : "+v"(vboff)); /* re-read every step: not hoisted back into registers */ \
+            const double* vp = s_vb + vboff;                                           \
+            out0 = estrin16(vp, t_, t2_, t4_, t8_);                                    \
+            out1 = estrin16(vp + 64, t_, t2_, t4_, t8_);                               \
+        } else {                                                                       \
+            out0 = estrin16(vb[0], t_, t2_, t4_, t8_);                                 \
+            out1 = estrin16(vb[1], t_, t2_, t4_, t8_);                                 \
+        }                                                                              \
+    } while (0)
     double aop[RS_TILES][2];
 #pragma unroll
     for (int tau = 0; tau < RS_TILES; ++tau)
@@ -868,11 +891,7 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
     for (int v = 0; v < 3; ++v) h[v] = H[((size_t)v * NS + s0) * Nk + kc];
     double z = k2 * ct[42], y = k2 * ct[43];
     double b0, b1;
-    {
-        const double t = z * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
-        b0 = estrin16(vb[0], t, t2, t4, t8);
-        b1 = estrin16(vb[1], t, t2, t4, t8);
-    }
+    RS_POLY(b0, b1, z * (1.0 / RS_ZS));
     // keep the A operand in registers (hipcc would otherwise re-load it from memory every step)
 #pragma unroll
     for (int tau = 0; tau < RS_TILES; ++tau)
@@ -882,53 +901,80 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
         // memory first: this step's C columns (scalar loads, consumed after the MFMAs) and the next step's X, Y, H
         const int sn = s + 1 < s1 ? s + 1 : s;
         const double* ctn = RSC + ((size_t)w * NS + sn) * RS_REC;
+        // (WPS >= 3: the third l' block of the record is requested only after the first tile has been consumed -- 42 doubles at once
+        // overflow the scalar file and come back as v_writelane / v_readlane traffic)
+        constexpr int NCV = RS_WPS >= 3 ? 28 : 42;
         double cv[42];
 #pragma unroll
-        for (int i = 0; i < 42; ++i) cv[i] = ct[i];
+        for (int i = 0; i < NCV; ++i) cv[i] = ct[i];
         const double xn = ctn[42], yn0 = ctn[43];
         double hn[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) hn[v] = H[((size_t)v * NS + sn) * Nk + kc];
         __builtin_amdgcn_sched_barrier(0);
-        // all ten MFMAs of this step (five independent accumulators) ...
-        v4d D[RS_TILES];
-#pragma unroll
-        for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-#pragma unroll
-        for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ... under them the basis polynomials of the next step ...
         const double zn = k2 * xn, yn = k2 * yn0;
         double bn0, bn1;
-        {
-            const double t = zn * (1.0 / RS_ZS), t2 = t * t, t4 = t2 * t2, t8 = t4 * t4;
-            bn0 = estrin16(vb[0], t, t2, t4, t8);
-            bn1 = estrin16(vb[1], t, t2, t4, t8);
-        }
-        // ... and the contraction of this step
         double zh[3], yh[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             zh[v] = z * h[v];
             yh[v] = y * h[v];
         }
+#define RS_TILE(tau) \
+    __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0), 0, 0, 0)
+        // every lane accumulates both roles; the sums of the role it does not own are never read
+#define RS_USE012(tau, Dt)                                                                                                  \
+    do {                                                                                                                    \
+        const double W_ = fma(zh[tau], Dt[0], fma(yh[0], Dt[1], fma(yh[1], Dt[2], yh[2] * Dt[3])));                         \
+        acc11A[tau] = fma(W_, cv[tau * 14], acc11A[tau]);                                                                   \
+        accCt[tau] = fma(W_, cv[tau * 14 + 1], accCt[tau]);                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 12; ++i) accL[i] = fma(W_, cv[tau * 14 + 2 + i], accL[i]);                    \
+    } while (0)
+        // tiles 3 and 4: one (a = 0, l, l') block per lane, l' by lane group
+#define RS_USE34(which, lpx, Dt)                                                                                            \
+    do {                                                                                                                    \
+        const double zhx_ = lpx == 0 ? zh[0] : (lpx == 1 ? zh[1] : zh[2]), cx_ = lpx == 0 ? c11_0 : (lpx == 1 ? c11_1 : cv[28]); \
+        const double Wx_ = fma(zhx_, Dt[0], fma(yh[0], Dt[1], fma(yh[1], Dt[2], yh[2] * Dt[3])));                           \
+        acc11B[which] = fma(Wx_, cx_, acc11B[which]);                                                                       \
+    } while (0)
+        const double c11_0 = cv[0], c11_1 = cv[14];
+        if (RS_WPS >= 3) {
+            // tile by tile: the MFMA pair of tile tau + 1 is issued before tile tau is consumed, so only two result tiles are live (the
+            // third wave of the SIMD covers what this order leaves exposed); the next step's basis polynomials sit in the middle
+            const v4d D0 = RS_TILE(0);
+            const v4d D1 = RS_TILE(1);
+            RS_USE012(0, D0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tau = 0; tau < 3; ++tau) {
-            const double W = fma(zh[tau], D[tau][0], fma(yh[0], D[tau][1], fma(yh[1], D[tau][2], yh[2] * D[tau][3])));
-            // every lane accumulates both roles; the sums of the role it does not own are never read
-            acc11A[tau] = fma(W, cv[tau * 14], acc11A[tau]);
-            accCt[tau] = fma(W, cv[tau * 14 + 1], accCt[tau]);
+            for (int i = 28; i < 42; ++i) cv[i] = ct[i];
+            const v4d D2 = RS_TILE(2);
+            RS_POLY(bn0, bn1, zn * (1.0 / RS_ZS));
+            RS_USE012(1, D1);
+            __builtin_amdgcn_sched_barrier(0);
+            const v4d D3 = RS_TILE(3);
+            RS_USE012(2, D2);
+            const v4d D4 = RS_TILE(4);
+            RS_USE34(0, lp3, D3);
+            RS_USE34(1, lp4, D4);
+        } else {
+            // all ten MFMAs of this step (five independent accumulators) ...
+            v4d D[RS_TILES];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) accL[i] = fma(W, cv[tau * 14 + 2 + i], accL[i]);
+            for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+            for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ... under them the basis polynomials of the next step and the contraction of this step
+            RS_POLY(bn0, bn1, zn * (1.0 / RS_ZS));
+            RS_USE012(0, D[0]);
+            RS_USE012(1, D[1]);
+            RS_USE012(2, D[2]);
+            RS_USE34(0, lp3, D[3]);
+            RS_USE34(1, lp4, D[4]);
         }
-        {  // tiles 3 and 4: one (a = 0, l, l') block per lane, l' by lane group
-            const double zh3 = lp3 == 0 ? zh[0] : (lp3 == 1 ? zh[1] : zh[2]), c3 = lp3 == 0 ? cv[0] : (lp3 == 1 ? cv[14] : cv[28]);
-            const double zh4 = lp4 == 1 ? zh[1] : zh[2], c4 = lp4 == 1 ? cv[14] : cv[28];
-            const double W3 = fma(zh3, D[3][0], fma(yh[0], D[3][1], fma(yh[1], D[3][2], yh[2] * D[3][3])));
-            const double W4 = fma(zh4, D[4][0], fma(yh[0], D[4][1], fma(yh[1], D[4][2], yh[2] * D[4][3])));
-            acc11B[0] = fma(W3, c3, acc11B[0]);
-            acc11B[1] = fma(W4, c4, acc11B[1]);
-        }
+#undef RS_TILE
+#undef RS_USE012
+#undef RS_USE34
         __builtin_amdgcn_sched_barrier(0);
         ct = ctn;
         z = zn;
@@ -1416,8 +1462,8 @@ __global__ __launch_bounds__(256, 2) void ap_apply_kernel(int Nk, int nmu, const
 //   ap_rows_kernel     workgroup = (tile of 64 k, cosmology, chunk of NRC template rows); wave <-> output multipole l; the (y, s)
 //                      window of the chunk's rows (all l') sits in LDS, the weights of knot d are six coalesced loads per thread
 // ------------------------------------------------------------------------------------------------
-constexpr int APW_DCAP = 12;  // knots per k on the fast path
-constexpr int APW_WIN = 96;   // LDS window of a tile, in knots (64 k + the drift of i0 across the tile + the knots per k)
+constexpr int APW_DCAP = 32;  // knots per k on the fast path
+constexpr int APW_WIN = 112;  // LDS window of a tile, in knots (64 k + the drift of i0 across the tile + the knots per k)
 
 template <int NL>
 __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
@@ -1427,11 +1473,17 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
                                                          int4* __restrict__ META) {
     constexpr int NS = NL * NL * 4, NP = NL * NL, PPW = (NP + 3) / 4;  // prefix sequences, (l', l) pairs, pairs per wave
     extern __shared__ double sm[];
-    double* s_k = sm;          // [Nk]
-    double* s_root = sm + Nk;  // [nmu]
-    __shared__ int s_red[3];   // min i0, max i0, max knots per k over the tile
+    double* s_k = sm;                   // [Nk]
+    double* s_root = sm + Nk;           // [nmu]
+    double* s_ps = sm + Nk + nmu + (nmu & 1);  // [(nmu + 1) * NS] the cosmology's prefix sums (58 KB at Nl = 3, 200 nodes): every gather below is an LDS read
+    __shared__ int s_red[3];            // min i0, max i0, max knots per k over the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, k = kt * 64 + lane;
+    {
+        const double2* src = reinterpret_cast<const double2*>(PS + (size_t)w * (nmu + 1) * NS);
+        double2* dst = reinterpret_cast<double2*>(s_ps);
+        for (int e = threadIdx.x; e < (nmu + 1) * NS / 2; e += 256) dst[e] = src[e];
+    }
     for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
     for (int e = threadIdx.x; e < nmu; e += 256) s_root[e] = ROOT[(size_t)w * nmu + e];
     if (threadIdx.x == 0) {
@@ -1444,7 +1496,7 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
     const bool live = k < Nk;
     const double kq = s_k[live ? k : Nk - 1] / qperp;
-    const double* ps = PS + (size_t)w * (nmu + 1) * NS;
+    const double* ps = s_ps;
     const bool up = g > 0.0;
     const int dir = up ? 1 : -1;
     const double jscale = (nmu - 1) / mu[nmu - 1];
@@ -1540,29 +1592,48 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     }
 }
 
-template <int NL, int NR, int NRC>
-__global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, const double* __restrict__ DAw, const double* __restrict__ Hw,
-                                                          const double* __restrict__ fid, const double* __restrict__ W,
-                                                          const int* __restrict__ I0, const int4* __restrict__ META,
-                                                          const double* __restrict__ T, const double* __restrict__ YS,
-                                                          double* __restrict__ Tout) {
-    constexpr int NP = NL * NL;
+// Workgroup = (tile of 64 k, cosmology, chunk of NRC template rows) x NL multipoles x NSG row subgroups: wave (l, sg) owns output
+// multipole l of rows sg * NRC / NSG ... of the chunk.  Everything the inner loop needs is requested before the first wait: the tile's
+// window (one trip of 1 KB wave loads into LDS), the thread's lowest knot and the weights of the first APR_DP knots (registers); only
+// tiles with more knots per k than that go back to memory inside the loop (one knot ahead).
+constexpr int APR_DP = 4;
+
+template <int NL, int NR, int NRC, int NSG>
+__global__ __launch_bounds__(64 * NL * NSG) void ap_rows_kernel(int Nk, const double* __restrict__ DAw, const double* __restrict__ Hw,
+                                                                const double* __restrict__ fid, const double* __restrict__ W,
+                                                                const int* __restrict__ I0, const int4* __restrict__ META,
+                                                                const double* __restrict__ T, const double* __restrict__ YS,
+                                                                double* __restrict__ Tout) {
+    constexpr int NP = NL * NL, RPT = NRC / NSG, NW = NL * NSG;  // pairs, rows per thread, waves
+    static_assert(NRC % NSG == 0, "row chunk must split evenly over the subgroups");
     __shared__ double2 win[NL * NRC * APW_WIN];  // (y, s) of series (l', row of the chunk) at knots jmin .. jmin + span
-    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = wv % NL, sg = wv / NL;
     const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, r0 = blockIdx.z * NRC, k = kt * 64 + lane;
+    const int i0 = I0[(size_t)w * KT * 64 + k];
     const int4 meta = META[(size_t)w * KT + kt];
     if (meta.w) return;  // left to ap_apply_kernel
     const int jmin = meta.x, D = meta.z;  // (meta.y, the span, is bounded by APW_WIN: flagged tiles never get here)
     const int nrow = min(NRC, NR - r0);
-    // stage the window: one series = span contiguous double2, read as one or two 1 KB wave loads
+    // weights of the first knots: in flight together with the window
+    const double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + (size_t)l * NL * 128 + lane;
+    double wy[APR_DP][NL], ws[APR_DP][NL];
+#pragma unroll
+    for (int d = 0; d < APR_DP; ++d)
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            const double* q = wt + (size_t)min(d, D - 1) * NP * 128 + lp * 128;
+            wy[d][lp] = q[0];
+            ws[d][lp] = q[64];
+        }
+    // stage the window: one series = span contiguous double2, read as two 1 KB wave loads; four series per wave
     {
         const double2* ys = reinterpret_cast<const double2*>(YS) + (size_t)w * NL * NROW * Nk;
         const int nser = NL * nrow;
-        for (int e0 = l * 4; e0 < nser; e0 += 4 * NL) {  // four series per wave and trip: eight loads in flight
+        for (int e0 = wv * 4; e0 < nser; e0 += 4 * NW) {
             double2 v[4][2];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u, nser - 1), lp = e / nrow, r = e % nrow;
+                const int e = min(e0 + u, nser - 1), lp = e / nrow, r = e - lp * nrow;
                 const double2* src = ys + ((size_t)lp * NROW + r0 + r) * Nk;
                 v[u][0] = src[min(jmin + lane, Nk - 1)];
                 v[u][1] = src[min(jmin + 64 + lane, Nk - 1)];
@@ -1571,7 +1642,7 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, const double* 
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + u;
                 if (e < nser) {
-                    const int lp = e / nrow, r = e % nrow;
+                    const int lp = e / nrow, r = e - lp * nrow;
                     double2* dst = win + (lp * NRC + r) * APW_WIN;
                     dst[lane] = v[u][0];
                     if (64 + lane < APW_WIN) dst[64 + lane] = v[u][1];
@@ -1581,50 +1652,55 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, const double* 
     }
     __syncthreads();
     const bool live = k < Nk;
-    int o = I0[(size_t)w * KT * 64 + k] - jmin;
-    if (o < 0) o = 0;  // lanes past the grid carry zero weights
-    const double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + (size_t)l * NL * 128 + lane;
-    double acc[NRC];
+    const int o = max(i0 - jmin, 0);  // lanes past the grid (i0 = -1) carry zero weights
+    double acc[RPT];
 #pragma unroll
-    for (int r = 0; r < NRC; ++r) acc[r] = 0.0;
-    double wy[NL], ws[NL], wyn[NL], wsn[NL];
+    for (int r = 0; r < RPT; ++r) acc[r] = 0.0;
+    const double2* wrow = win + (size_t)(sg * RPT) * APW_WIN + o;
+    auto knot = [&](int d, const double* cy, const double* cs) {
 #pragma unroll
-    for (int lp = 0; lp < NL; ++lp) {
-        wyn[lp] = wt[lp * 128];
-        wsn[lp] = wt[lp * 128 + 64];
-    }
-    for (int d = 0; d < D; ++d) {
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                const double2 v = wrow[(lp * NRC + r) * APW_WIN + d];
+                acc[r] = fma(cy[lp], v.x, fma(cs[lp], v.y, acc[r]));
+            }
+    };
+#pragma unroll
+    for (int d = 0; d < APR_DP; ++d)
+        if (d < D) knot(d, wy[d], ws[d]);  // D: workgroup-uniform
+    if (D > APR_DP) {
+        double cy[NL], cs[NL], ny[NL], ns[NL];
 #pragma unroll
         for (int lp = 0; lp < NL; ++lp) {
-            wy[lp] = wyn[lp];
-            ws[lp] = wsn[lp];
+            ny[lp] = wt[(size_t)APR_DP * NP * 128 + lp * 128];
+            ns[lp] = wt[(size_t)APR_DP * NP * 128 + lp * 128 + 64];
         }
-        if (d + 1 < D) {  // the next knot's weights fly under this knot's rows
-            const double* wn = wt + (size_t)(d + 1) * NP * 128;
+        for (int d = APR_DP; d < D; ++d) {
 #pragma unroll
             for (int lp = 0; lp < NL; ++lp) {
-                wyn[lp] = wn[lp * 128];
-                wsn[lp] = wn[lp * 128 + 64];
+                cy[lp] = ny[lp];
+                cs[lp] = ns[lp];
             }
-        }
-        const double2* wp = win + o + d;
+            if (d + 1 < D) {
+                const double* wn = wt + (size_t)(d + 1) * NP * 128;
 #pragma unroll
-        for (int r = 0; r < NRC; ++r) {
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                const double2 v = wp[(lp * NRC + r) * APW_WIN];
-                acc[r] = fma(wy[lp], v.x, fma(ws[lp], v.y, acc[r]));
+                for (int lp = 0; lp < NL; ++lp) {
+                    ny[lp] = wn[lp * 128];
+                    ns[lp] = wn[lp * 128 + 64];
+                }
             }
+            knot(d, cy, cs);
         }
     }
     if (!live) return;
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
     const double c = 2.0 / (qperp * qperp * qpar);
-    double* dst = Tout + (((size_t)w * NL + l) * NROW + r0) * Nk + k;
+    double* dst = Tout + (((size_t)w * NL + l) * NROW + r0 + sg * RPT) * Nk + k;
 #pragma unroll
-    for (int r = 0; r < NRC; ++r)
-        if (r < nrow) dst[(size_t)r * Nk] = c * acc[r];
-    if (NR < NROW && blockIdx.z == 0) {  // rows that APeffect leaves alone (Pstl unless APst)
+    for (int r = 0; r < RPT; ++r)
+        if (sg * RPT + r < nrow) dst[(size_t)r * Nk] = c * acc[r];
+    if (NR < NROW && blockIdx.z == 0 && sg == 0) {  // rows that APeffect leaves alone (Pstl unless APst)
         const size_t base = (((size_t)w * NL + l) * NROW + NR) * Nk + k;
 #pragma unroll
         for (int r = 0; r < NROW - NR; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];

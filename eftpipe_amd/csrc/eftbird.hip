@@ -60,6 +60,7 @@ struct eftb_engine {
     int4 *APM = nullptr, *APM2 = nullptr;
     bool ap_fast = true;  // EFTB_AP_FAST=0: every tile through ap_apply_kernel (the pre-weights form, kept as the fallback)
     int ap_chunk = 8;     // template rows per workgroup of ap_rows_kernel (EFTB_AP_CHUNK=6|8|12)
+    int resum_wps = 3;    // waves per SIMD resum_mfma_kernel is built for (EFTB_RESUM_WPS=2: basis coefficients in registers, 205 VGPRs)
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
     double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
     double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of the P22 basis [B][BAS22][KSYN] and of P13 [B][10][KLIN]
@@ -136,8 +137,8 @@ struct eftb_engine {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     double* gathered = nullptr;
-    double* gathered2[2] = {nullptr, nullptr};  // the gathered block alternates between two buffers, so that the root can read step i while step i + 1 is exchanged
-    hipEvent_t evGath2[2] = {nullptr, nullptr};
+    double* gathered2[3] = {nullptr, nullptr, nullptr};  // the gathered block rotates through three buffers: the root reads step i while steps i + 1, i + 2 are exchanged
+    hipEvent_t evGath2[3] = {nullptr, nullptr, nullptr};
     int gather_slot = 0;
     // the gather runs on its own stream from a snapshot of P_l, so that it overlaps the next step's kernels
     hipStream_t comm_stream = nullptr;
@@ -393,7 +394,7 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     if (!e->ap_fast) return;
     // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
     const dim3 wgrid((c.Nk + 63) / 64, B);
-    const size_t wlds = ((size_t)c.Nk + c.nmu) * sizeof(double);
+    const size_t wlds = ((size_t)c.Nk + c.nmu + (c.nmu & 1) + (size_t)(c.nmu + 1) * c.Nl * c.Nl * 4) * sizeof(double);
 #define APW_ARGS c.Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, \
                  e->APW, e->API, e->APM
     if (c.Nl == 3) hipLaunchKernelGGL((ap_weights_kernel<3>), wgrid, dim3(256), wlds, st, APW_ARGS);
@@ -577,6 +578,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (!(mask & EFTB_S_RESUM) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess)
             return fail("eftb_run: event record failed");
     }
+    if ((mask & EFTB_K_IRFILTER) && !(mask & EFTB_S_RESUM)) {
+        if (!c.with_resum) return fail("eftb_run: EFTB_K_IRFILTER needs with_resum=1");
+        launch_irfilter(e, st, B);
+    }
     if (mask & (EFTB_S_RESUM | EFTB_K_RESUM)) {
         if (!c.with_resum) return fail("eftb_run: stage RESUM needs with_resum=1");
         const bool full = mask & EFTB_S_RESUM;  // EFTB_K_RESUM alone: only the main kernel, on the operands of an earlier full run
@@ -608,7 +613,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             const int schunk = (NS + nsplit - 1) / nsplit;
 #define RM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), \
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
-            if (kblocks > 0 && Nl == 3) hipLaunchKernelGGL(resum_mfma_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
+            if (kblocks > 0 && Nl == 3 && e->resum_wps >= 3) hipLaunchKernelGGL((resum_mfma_kernel<3>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
+            else if (kblocks > 0 && Nl == 3) hipLaunchKernelGGL((resum_mfma_kernel<2>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
             else if (kblocks > 0) hipLaunchKernelGGL(resum_mfma2_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
 #undef RM_ARGS
             if (nsplit > 1)
@@ -651,17 +657,20 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             // banded product of the knot weights with the spline data; rows [nr, 24) are copied through
             const int kt = (Nk + 63) / 64;
 #define APR_ARGS Nk, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, b[EFTB_B_TEMPL], e->SD, e->Talt
-#define APR_LAUNCH(NLV, NRV, NRC) hipLaunchKernelGGL((ap_rows_kernel<NLV, NRV, NRC>), dim3(kt, B, (NRV + NRC - 1) / NRC), dim3(64 * NLV), 0, st, APR_ARGS)
-#define APR_PICK(NRC)                                  \
-    do {                                               \
-        if (Nl == 3 && nr == 21) APR_LAUNCH(3, 21, NRC);    \
-        else if (Nl == 3) APR_LAUNCH(3, NROW, NRC);         \
-        else if (nr == 21) APR_LAUNCH(2, 21, NRC);          \
-        else APR_LAUNCH(2, NROW, NRC);                      \
+#define APR_LAUNCH(NLV, NRV, NRC, NSG) \
+    hipLaunchKernelGGL((ap_rows_kernel<NLV, NRV, NRC, NSG>), dim3(kt, B, (NRV + NRC - 1) / NRC), dim3(64 * NLV * NSG), 0, st, APR_ARGS)
+#define APR_PICK(NRC, NSG)                                  \
+    do {                                                    \
+        if (Nl == 3 && nr == 21) APR_LAUNCH(3, 21, NRC, NSG);    \
+        else if (Nl == 3) APR_LAUNCH(3, NROW, NRC, NSG);         \
+        else if (nr == 21) APR_LAUNCH(2, 21, NRC, NSG);          \
+        else APR_LAUNCH(2, NROW, NRC, NSG);                      \
     } while (0)
-            if (e->ap_chunk == 6) APR_PICK(6);
-            else if (e->ap_chunk == 12) APR_PICK(12);
-            else APR_PICK(8);
+            if (e->ap_chunk == 6) APR_PICK(6, 2);
+            else if (e->ap_chunk == 12) APR_PICK(12, 2);
+            else if (e->ap_chunk == 81) APR_PICK(8, 1);
+            else if (e->ap_chunk == 84) APR_PICK(8, 4);
+            else APR_PICK(8, 2);
 #undef APR_PICK
 #undef APR_LAUNCH
 #undef APR_ARGS
@@ -923,6 +932,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     }
     if (const char* f = getenv("EFTB_AP_FAST")) e->ap_fast = atoi(f) != 0;
     if (const char* f = getenv("EFTB_AP_CHUNK")) e->ap_chunk = atoi(f);
+    if (const char* f = getenv("EFTB_RESUM_WPS")) e->resum_wps = atoi(f);
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 4 * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 4 * sizeof(int));
     HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
@@ -985,6 +995,10 @@ int eftb_finalize(eftb_engine* e) {
     AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, 21, 7); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3); AP_LDS(3, NROW, 7);
     AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
 #undef AP_LDS
+    if (c.with_ap) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // third template block (engine.back)
     HIPCHK(hipDeviceSynchronize());  // null-stream zero fills (part, ZC, ZC2) are not ordered against the engine's non-blocking streams
     e->finalized = true;
@@ -1164,7 +1178,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
     for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
     }
@@ -1447,13 +1461,14 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     return 0;
 }
 
-int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) {
-    if (!e || !host) return fail("eftb_fetch_previous: null argument");
-    if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_previous: only EFTB_B_PLK and EFTB_B_LOGP are double-buffered outputs");
-    if (!e->cpy) return fail("eftb_fetch_previous: no staged run yet");
-    if (count > e->buf_elems[id]) return fail("eftb_fetch_previous: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
+int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count) {
+    if (!e || !host) return fail("eftb_fetch_back: null argument");
+    if (back != 1 && back != 2) return fail("eftb_fetch_back: back must be 1 (the step before the one launched last) or 2 (the one before that)");
+    if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_back: only EFTB_B_PLK and EFTB_B_LOGP are triple-buffered outputs");
+    if (!e->cpy) return fail("eftb_fetch_back: no staged run yet");
+    if (count > e->buf_elems[id]) return fail("eftb_fetch_back: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
     HIPCHK(hipSetDevice(e->c.device));
-    const int t = (e->cur_set + 2) % 3;  // the set of the step before the current one
+    const int t = (e->cur_set + 3 - back) % 3;  // back = 2 is the set that the next eftb_stage_inputs refills
     // spin on the step's event instead of sleeping in a synchronize call: the sampler thread is about to enqueue the next step, and the
     // wake-up latency of a blocking wait would be paid once per step
     static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
@@ -1461,16 +1476,18 @@ int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) {
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = hipEventQuery(e->evSetDone[t]);
         if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) return fail("eftb_fetch_previous: %s", hipGetErrorString(q));
+        if (q != hipErrorNotReady) return fail("eftb_fetch_back: %s", hipGetErrorString(q));
         if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
-            return fail("eftb_fetch_previous: the step did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", limit_s);
+            return fail("eftb_fetch_back: the step did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", limit_s);
     }
     if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
         HIPCHK(hipMemcpy(host, e->setbuf[t][id], count * sizeof(double), hipMemcpyDeviceToHost));
     else
         memcpy(host, e->setbuf[t][id], count * sizeof(double));  // the results are already in (mapped) host memory
-    return check_status(e, "eftb_fetch_previous");
+    return check_status(e, "eftb_fetch_back");
 }
+
+int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) { return eftb_fetch_back(e, 1, id, host, count); }
 
 int eftb_comm_unique_id(char id[128]) {
     if (!id) return fail("eftb_comm_unique_id: null argument");
@@ -1503,7 +1520,7 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
     HIPCHK(hipSetDevice(e->c.device));
     const size_t count = (size_t)B * e->cur_nl * e->cur_nx;
     if (e->rank == root) {
-        e->gather_slot ^= 1;
+        e->gather_slot = (e->gather_slot + 1) % 3;
         const int q = e->gather_slot;
         if (!e->gathered2[q]) {
             HIPCHK(hipMalloc(&e->gathered2[q], (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
@@ -1558,10 +1575,10 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
     return 0;
 }
 
-int eftb_fetch_gathered(eftb_engine* e, int which, double* host, size_t count) {
+int eftb_fetch_gathered(eftb_engine* e, int which /* = back */, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_gathered: null argument");
-    if (which != 0 && which != 1) return fail("eftb_fetch_gathered: which must be 0 (the exchange before the last one enqueued) or 1 (the last one)");
-    const int q = which ? e->gather_slot : e->gather_slot ^ 1;
+    if (which < 0 || which > 2) return fail("eftb_fetch_gathered: `back` must be 0 (the last exchange enqueued), 1 or 2 (one / two exchanges before it)");
+    const int q = (e->gather_slot + 3 - which) % 3;
     if (!e->gathered2[q]) return fail("eftb_fetch_gathered: no such exchange yet");
     if (count > (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk) return fail("eftb_fetch_gathered: asked %zu elements", count);
     HIPCHK(hipSetDevice(e->c.device));

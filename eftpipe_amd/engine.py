@@ -273,11 +273,12 @@ class Engine:
         if mask & L.S_PROJECT:
             self.dims = self.out_dims()
 
-    def fetch_previous(self, name, shape, out=None):
-        """PLK / LOGP of the step before the one in flight (``out``: a C-contiguous float64 array of ``shape`` to fill)."""
+    def fetch_previous(self, name, shape, out=None, back=1):
+        """PLK / LOGP of the step launched `back` (1 or 2) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
+        to fill).  back=2 keeps two steps queued while the host works (see ``pipeline``)."""
         if out is None:
             out = np.empty(shape, dtype=np.float64)
-        L.check(self.lib.eftb_fetch_previous(self._h, L.B[name], L.dptr(out), out.size))
+        L.check(self.lib.eftb_fetch_back(self._h, int(back), L.B[name], L.dptr(out), out.size))
         return out
 
     def pipeline(self, steps, mask=None, fetch="PLK"):
@@ -288,16 +289,18 @@ class Engine:
             mask = self.full_mask(reduce=(fetch == "PLK")) | (L.S_LOGP if fetch == "LOGP" else 0)
         nl, nx = self.out_dims()
         shape_of = lambda B: (B, nl, nx) if fetch == "PLK" else (B // self.ntracers, 2 + 24)
-        prev_B = None
+        queued = []  # batch sizes of the steps launched and not yet fetched (at most two)
         for st in steps:
             B = self.stage_inputs(st["Pin"], st["f"], st.get("DA"), st.get("H"), bias=st.get("bias"), rows=st.get("rows"))
             self.run_staged(mask, B)
-            if prev_B is not None:
-                yield self.fetch_previous(fetch, shape_of(prev_B))
-            prev_B = B
-        if prev_B is not None:
+            queued.append(B)
+            if len(queued) == 3:  # two steps stay queued on the GPU while the oldest one is copied out
+                yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=2)
+        if len(queued) == 2:
+            yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=1)
+        if queued:
             self.sync()
-            yield self.get(fetch, shape_of(prev_B))
+            yield self.get(fetch, shape_of(queued.pop(0)))
 
     def pinned_empty(self, shape):
         """Page-locked float64 host array for eval_batch(out=...) / put / get."""
@@ -333,12 +336,12 @@ class Engine:
         return out
 
 
-    def fetch_gathered(self, B, latest=False, out=None):
-        """Root only: the gathered block [nranks, B, nl, nx] of the exchange before the last one enqueued (or of the last one)."""
+    def fetch_gathered(self, B, back=1, out=None):
+        """Root only: the gathered block [nranks, B, nl, nx] of the last exchange enqueued (back=0) or of the one `back` exchanges before it."""
         nl, nx = self.out_dims()
         if out is None:
             out = np.empty((getattr(self, "nranks", 1), B, nl, nx))
-        L.check(self.lib.eftb_fetch_gathered(self._h, int(bool(latest)), L.dptr(out), out.size))
+        L.check(self.lib.eftb_fetch_gathered(self._h, int(back), L.dptr(out), out.size))
         return out
 
 

@@ -101,6 +101,7 @@ def engine_for(co, nbinsmu=200, loop_cache=None):
     if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != nbinsmu
                             or eng.cfg.with_NNLO != bool(co.with_NNLO) or eng.cfg.IRcutoff != co.IRcutoff or eng.cfg.kIR != co.kIR
                             or eng.cfg.optiresum != bool(co.optiresum)):
+        release(eng)
         eng.close()
         eng = None
     if eng is None:
@@ -108,6 +109,27 @@ def engine_for(co, nbinsmu=200, loop_cache=None):
                            nbinsmu=nbinsmu, with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR, optiresum=bool(co.optiresum))
         eng = _ENGINES[co] = Engine(cfg, max_batch=1, loop_cache=loop_cache)
     return eng
+
+
+def release(eng):
+    """Bring the device-resident results of the bird that currently owns `eng` to the host (they are about to be overwritten)."""
+    ref = getattr(eng, "_owner", None)
+    owner = ref() if ref is not None else None
+    if owner is not None:
+        owner._flush()
+    eng._owner = None
+
+
+def claim(eng, bird):
+    """`bird` is about to run a stage on `eng`: one engine serves one Common, so another bird's pending results are fetched first."""
+    ref = getattr(eng, "_owner", None)
+    owner = ref() if ref is not None else None
+    if owner is not bird:
+        if owner is not None:
+            owner._flush()
+        if getattr(bird, "_dev", None) is not None:
+            bird._dev.clear()
+        eng._owner = weakref.ref(bird)
 
 
 NS_DEV = 80  # s slots on the device; Common(optiresum=True) uses the first 52 (include/eftbird.h eftb_config.optiresum)
@@ -141,18 +163,35 @@ class BirdSnapshot:
         self.PctNNLOl = None if bird.PctNNLOl is None else bird.PctNNLOl.copy()
 
 
+# host attribute -> (device buffer, fetch group).  One group = one transfer that fills every pending attribute of the group.
+_LAZY = {
+    "P11": "P11", "P22": "P22", "P13": "P13", "C11": "C11", "Cct": "CCT", "CctNNLO": "CCTN", "C22": "CC", "C13": "CC",
+    "Cloopl": "CLOOPL", "P11l": "TEMPL", "Pctl": "TEMPL", "Ploopl": "TEMPL", "Pstl": "TEMPL", "PctNNLOl": "TEMPLN",
+    "P22l": "P22", "P13l": "P13",
+}
+_INPUTS = {"Pin": "PIN", "f": "F"}  # re-binding these invalidates the device copy too
+
+
 class Bird:
-    """Container of one evaluation (reference pybird.py:635-866).  Arrays are host NumPy, C-contiguous
-    float64, re-bound by each stage exactly as in the reference; ``P11`` is filled by ``NonLinear.PsCf``
-    (the reference interpolates it in ``__init__``; here the spline runs on the device with the loops)."""
+    """Container of one evaluation (reference pybird.py:635-866).  Arrays are host NumPy, C-contiguous float64, re-bound by each stage
+    exactly as in the reference -- but LAZILY: a stage leaves its outputs on the device and the attribute is fetched on first access
+    (``bird.P11l`` etc. behave as ordinary arrays from then on).  The next stage uses the device copy as long as the attribute has
+    neither been read nor re-bound on the host (a read hands out an array the caller may modify in place, so it ends the device
+    copy's validity); the call sequence of reference theory.py:568-604 therefore moves P_lin, f, DA, H in and the final templates out.
+    ``P11`` is filled by ``NonLinear.PsCf`` (the reference interpolates it in ``__init__``; here the spline runs on the device with the loops)."""
 
     def __init__(self, kin, Plin, f, DA=None, H=None, z=None, co=common, rdrag=None, h=None):
+        d = self.__dict__
+        d["_pending"] = {}      # attribute -> fetch group (device buffer) whose content is this bird's current value
+        d["_dev"] = set()       # device buffers that hold this bird's current values (valid while the engine's owner is this bird)
+        d["_shape"] = None      # (nl, nx) of the template block on the device
+        d["_engine"] = None
         self.co = co
         self.f = f
         self.DA, self.H, self.z, self.rdrag, self.h = DA, H, z, rdrag, h
         self.kin = np.asarray(kin, dtype=np.float64)
         self.Pin = np.asarray(Plin, dtype=np.float64)
-        Nl, Nk, Ns = co.Nl, co.Nk, co.Ns
+        Nl, Nk = co.Nl, co.Nk
         self.P11 = None
         self.P22, self.P13 = None, None
         self.C11 = self.Cct = self.C22 = self.C13 = None
@@ -160,7 +199,79 @@ class Bird:
         self.PctNNLOl = self.CctNNLO = None  # filled when co.with_NNLO (reference pybird.py:741-748, 1098-1101)
         self.Picc = np.zeros((Nl, Nk))
         self.snapshots = {}
-        self._engine = None
+
+    # ---- lazy attributes
+    def __getattr__(self, name):  # reached only when `name` is not in __dict__: a pending device result, or a genuine miss
+        pend = self.__dict__.get("_pending")
+        if pend and name in pend:
+            self._materialize(pend[name])
+            return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if "_pending" in d:
+            d["_pending"].pop(name, None)
+            buf = _LAZY.get(name) or _INPUTS.get(name)
+            if buf is not None:
+                d["_dev"].discard(buf)  # the host value is the truth from now on
+        d[name] = value
+
+    def _set_pending(self, names, group):
+        for n in names:
+            self.__dict__.pop(n, None)
+            self._pending[n] = group
+        self._dev.add(group)
+
+    def _owns(self, eng):
+        ref = getattr(eng, "_owner", None)
+        return ref is not None and ref() is self
+
+    def _materialize(self, group):
+        """One transfer for every pending attribute of the group; a fetched array may be modified by the caller, so the device copy
+        stops counting as this bird's value (the next stage uploads the host arrays again)."""
+        eng, co, d = self._engine, self.co, self.__dict__
+        want = [n for n, g in self._pending.items() if g == group]
+        if not want:
+            return
+        if not self._owns(eng):
+            raise RuntimeError("device results of this Bird were overwritten (one engine serves one Common; evaluate birds one at a time)")
+        if group in ("TEMPL", "TEMPLN"):
+            nl, nx = self._shape
+            T = eng.get(group, (nl, 24, nx))
+            for n in want:
+                d[n] = np.ascontiguousarray(T[:, 3:6] if n == "PctNNLOl" else T[:, ROWS[n]])
+        elif group == "CC":
+            cc = _s_get(eng, "CC", (co.Nl * 38,), co.Ns)
+            raw = {"C22": cc[: co.Nl * 28].reshape(co.Nl, 28, co.Ns), "C13": cc[co.Nl * 28 :].reshape(co.Nl, 10, co.Ns)}
+            wt = {"C22": co.l22, "C13": co.l13}
+            for n in want:  # after setPsCfl the reference leaves the mu-weighted pieces on the bird (pybird.py:752-753)
+                d[n] = np.ascontiguousarray(raw[n] * wt[n][:, :, None] if self.__dict__.get("_cf_weighted") else raw[n])
+        elif group in ("P22", "P13"):
+            n0 = group
+            full = eng.get(group, (co.N22 if group == "P22" else co.N13, co.Nk))
+            for n in want:
+                d[n] = full if n == n0 else (co.l22 if group == "P22" else co.l13)[:, :, None] * full[None]  # P22l / P13l (pybird.py:749-750)
+        elif group == "P11":
+            d["P11"] = eng.get("P11", (co.Nk,))
+        elif group in ("C11", "CCT", "CCTN"):
+            for n in want:
+                d[n] = _s_get(eng, group, (co.Nl,), co.Ns)
+        elif group == "CLOOPL":
+            d["Cloopl"] = _s_get(eng, "CLOOPL", (co.Nl, co.Nloop), co.Ns)
+        else:  # pragma: no cover
+            raise KeyError(group)
+        for n in want:
+            del self._pending[n]
+        self._dev.discard(group)
+
+    def _flush(self):
+        """Fetch everything still pending (another bird is about to use the engine)."""
+        for group in list(dict.fromkeys(self._pending.values())):
+            self._materialize(group)
+
+    def _on_device(self, eng, buf):
+        return self._owns(eng) and buf in self._dev
 
     def create_snapshot(self, name):
         if name not in self.snapshots:
@@ -172,39 +283,90 @@ class Bird:
         return self._engine
 
     def _templates_to_device(self, eng):
-        T = np.empty((self.co.Nl, 24, self.co.Nk))
-        for n, sl in ROWS.items():
-            T[:, sl] = getattr(self, n)
-        eng.put("TEMPL", T)
-        if self.co.with_NNLO:  # second block: PctNNLOl in the Pctl slots, zero elsewhere (include/eftbird.h EFTB_B_TEMPLN)
-            T[:] = 0.0
+        """The template block (and the NNLO block) on the device: nothing to do while the stage outputs are still there."""
+        if not self._on_device(eng, "TEMPL"):
+            T = np.empty((self.P11l.shape[0], 24, self.P11l.shape[-1]))
+            for n, sl in ROWS.items():
+                T[:, sl] = getattr(self, n)
+            eng.set_template_dims(T.shape[0], T.shape[2])
+            eng.put("TEMPL", T)
+            self._dev.add("TEMPL")
+            self._shape = (T.shape[0], T.shape[2])
+        if self.co.with_NNLO and not self._on_device(eng, "TEMPLN"):  # second block: PctNNLOl in the Pctl slots, zero elsewhere (include/eftbird.h EFTB_B_TEMPLN)
+            T = np.zeros((self.PctNNLOl.shape[0], 24, self.PctNNLOl.shape[-1]))
             T[:, 3:6] = self.PctNNLOl
             eng.put("TEMPLN", T)
+            self._dev.add("TEMPLN")
 
-    def _templates_from_device(self, eng, names=("P11l", "Pctl", "Ploopl", "Pstl")):
-        T = eng.get("TEMPL", (self.co.Nl, 24, self.co.Nk))
-        for n in names:
-            setattr(self, n, np.ascontiguousarray(T[:, ROWS[n]]))
+    def _templates_pending(self, names=("P11l", "Pctl", "Ploopl", "Pstl"), shape=None):
+        """The stage that just ran re-binds these attributes: they now live on the device."""
+        if shape is not None:
+            self._shape = shape
+        # attributes of the block that are NOT re-bound keep their host value if they have one; since the whole block is valid on the
+        # device, they may as well stay pending if they were
+        self._set_pending(names, "TEMPL")
         if self.co.with_NNLO:
-            self.PctNNLOl = np.ascontiguousarray(eng.get("TEMPLN", (self.co.Nl, 24, self.co.Nk))[:, 3:6])
+            self._set_pending(("PctNNLOl",), "TEMPLN")
 
     def setPsCfl(self):
         """Multipole weights, regrouping into the 12 bias groups, shot-noise subtraction, stochastic
         templates (reference pybird.py:737-866) -- regroup_kernel / regroup_cf_kernel."""
         eng, co = self._need_engine(), self.co
-        eng.put("F", np.array([self.f]))
-        eng.put("P11", self.P11)
-        eng.put("P22", self.P22)
-        eng.put("P13", self.P13)
-        eng.put("CC", np.concatenate([_s_pad(self.C22).reshape(-1), _s_pad(self.C13).reshape(-1)]))
-        eng.run(L.S_REGROUP)
-        self._templates_from_device(eng)
-        self.Cloopl = _s_get(eng, "CLOOPL", (co.Nl, co.Nloop), co.Ns)
-        # the reference also leaves the mu-weighted pieces on the bird (pybird.py:749-753)
-        self.P22l = co.l22[:, :, None] * self.P22[None]
-        self.P13l = co.l13[:, :, None] * self.P13[None]
-        self.C22 = self.C22 * co.l22[:, :, None]
-        self.C13 = self.C13 * co.l13[:, :, None]
+        claim(eng, self)
+        if not self._on_device(eng, "F"):
+            eng.put("F", np.array([self.f]))
+            self._dev.add("F")
+        for n in ("P11", "P22", "P13"):
+            if not self._on_device(eng, n):
+                eng.put(n, getattr(self, n))
+                self._dev.add(n)
+        if not self._on_device(eng, "CC"):
+            eng.put("CC", np.concatenate([_s_pad(self.C22).reshape(-1), _s_pad(self.C13).reshape(-1)]))
+            self._dev.add("CC")
+        eng.run(L.S_REGROUP, sync=False)
+        self._templates_pending(shape=(co.Nl, co.Nk))
+        self._set_pending(("Cloopl",), "CLOOPL")
+        # the reference also leaves the mu-weighted pieces on the bird (pybird.py:749-753): derived on access
+        self._set_pending(("P22l",), "P22")
+        self._set_pending(("P13l",), "P13")
+        if "C22" in self._pending or "C13" in self._pending:
+            self.__dict__["_cf_weighted"] = True
+        for n, wt in (("C22", co.l22), ("C13", co.l13)):
+            if n not in self._pending:
+                self.__dict__[n] = self.__dict__[n] * wt[:, :, None]
+
+
+    # ---- host forms of the pieces of setPsCfl (reference pybird.py:758-866), for callers that use them on their own; setPsCfl itself
+    #      runs regroup_kernel / regroup_cf_kernel
+    def reducePsCfl(self):
+        """Ploopl / Cloopl from the mu-weighted P22l, P13l / C22, C13 (reference pybird.py:758-846), then subtractShotNoise."""
+        co, f = self.co, self.f
+        Ploopl, Cloopl = np.zeros((co.Nl, co.Nloop, co.Nk)), np.zeros((co.Nl, co.Nloop, co.Ns))
+        for b in range(co.N22):
+            grp, pw = lm.GROUP_22[b]
+            Ploopl[:, grp] += f**pw * self.P22l[:, b]
+            Cloopl[:, grp] += f**pw * self.C22[:, b]
+        for b in range(co.N13):
+            grp, pw = lm.GROUP_13[b]
+            Ploopl[:, grp] += f**pw * self.P13l[:, b]
+            Cloopl[:, grp] += f**pw * self.C13[:, b]
+        self.Ploopl, self.Cloopl = Ploopl, Cloopl
+        self.subtractShotNoise()
+
+    def setPstl(self):
+        """(reference pybird.py:848-857)"""
+        co = self.co
+        Pstl = np.zeros((co.Nl, 3, co.Nk))
+        Pstl[0, 0], Pstl[0, 1] = 1.0, co.k**2
+        if co.Nl >= 2:
+            Pstl[1, 2] = co.k**2
+        self.Pstl = Pstl
+
+    def subtractShotNoise(self):
+        """(reference pybird.py:859-866)"""
+        P = np.array(self.Ploopl, dtype=np.float64, copy=True)
+        P -= P[:, :, :1]
+        self.Ploopl = P
 
 
 # ----------------------------------------------------------------------------- NonLinear
@@ -255,19 +417,19 @@ class NonLinear(HasLogger):
         if not np.array_equal(bird.kin, self.engine.kin):
             raise ValueError("bird.kin differs from the engine's input grid (reference theory.py:562 uses logspace(-5, 0, 200))")
         eng, co = self.engine, self.co
-        bird._engine = eng
+        claim(eng, bird)
+        bird.__dict__["_engine"] = eng
+        bird.__dict__["_cf_weighted"] = False
         eng.put("PIN", bird.Pin)
-        eng.run(L.S_PREP | L.S_LOOPS | L.S_CF)
-        bird.P11 = eng.get("P11", (co.Nk,))
-        bird.P22 = eng.get("P22", (co.N22, co.Nk))
-        bird.P13 = eng.get("P13", (co.N13, co.Nk))
-        bird.C11 = _s_get(eng, "C11", (co.Nl,), co.Ns)
-        bird.Cct = _s_get(eng, "CCT", (co.Nl,), co.Ns)
+        eng.put("F", np.array([bird.f]))   # the growth rate is known from the start: setPsCfl and Resum.Ps find it in place
+        bird._dev.update(("PIN", "F"))
+        eng.run(L.S_PREP | L.S_LOOPS | L.S_CF, sync=False)
+        for n in ("P11", "P22", "P13", "C11"):
+            bird._set_pending((n,), _LAZY[n])
+        bird._set_pending(("Cct",), "CCT")
         if co.with_NNLO:
-            bird.CctNNLO = _s_get(eng, "CCTN", (co.Nl,), co.Ns)
-        cc = _s_get(eng, "CC", (co.Nl * 38,), co.Ns)
-        bird.C22 = np.ascontiguousarray(cc[: co.Nl * 28].reshape(co.Nl, 28, co.Ns))
-        bird.C13 = np.ascontiguousarray(cc[co.Nl * 28 :].reshape(co.Nl, 10, co.Ns))
+            bird._set_pending(("CctNNLO",), "CCTN")
+        bird._set_pending(("C22", "C13"), "CC")
 
 
 # ----------------------------------------------------------------------------- Resum
@@ -284,7 +446,8 @@ class Resum(HasLogger):
         self.Nn = self.NIR * self.Na * 2
         self.snapshot = snapshot
         self.engine = engine_for(co)
-        self.Q = None
+        self._Q = None
+        self._Qf = None
         if co.optiresum:  # reference pybird.py:1235-1244
             self.sLow, self.sHigh = 70.0, 190.0
             self.idlow = int(np.where(co.s > self.sLow)[0][0])
@@ -297,31 +460,77 @@ class Resum(HasLogger):
             self.sr = co.s
             self._sr = slice(0, co.Ns)
 
-    def IRFilters(self, bird):
-        """X(s), Y(s) (reference pybird.py:1316-1353)."""
+    @property
+    def Q(self):
+        """Resum.Q of the last ``Ps`` / ``makeQ`` call [2, Nl, Nl, Nn] (reference pybird.py:1367-1380) -- the polynomials in f, evaluated
+        on the host when asked for (the device evaluates its own copy inside the stage)."""
+        if self._Q is None and self._Qf is not None:
+            self.makeQ(self._Qf)
+        return self._Q
+
+    @Q.setter
+    def Q(self, value):
+        self._Q = value
+
+    def makeQ(self, f):
+        """(reference pybird.py:1367-1380)  Q[a] = table[1 - a](f)"""
+        P = lm.q_polynomials(self.co.Nl)                      # [2, Nl, Nl, Nn, 15] coefficients of f^0..f^14
+        val = np.zeros(P.shape[:-1])
+        for p in range(P.shape[-1] - 1, -1, -1):
+            val = val * f + P[..., p]
+        self._Q = np.ascontiguousarray(val[::-1])
+        self._Qf = f
+
+    def _inputs(self, bird):
         eng = self.engine
-        eng.put("PIN", bird.Pin)
-        eng.put("F", np.array([bird.f]))
-        eng.run(L.S_RESUM)  # cheap at B=1; filters are a by-product
+        claim(eng, bird)
+        bird.__dict__["_engine"] = eng
+        if not bird._on_device(eng, "PIN"):
+            eng.put("PIN", bird.Pin)
+            bird._dev.add("PIN")
+        if not bird._on_device(eng, "F"):
+            eng.put("F", np.array([bird.f]))
+            bird._dev.add("F")
+        return eng
+
+    def IRFilters(self, bird, soffset=1.0, LambdaIR=None, RescaleIR=1.0, window=None):
+        """X(s), Y(s) (reference pybird.py:1316-1353); only the arguments the reference's own callers use are supported."""
+        if soffset != 1.0 or RescaleIR != 1.0 or window is not None or (LambdaIR is not None and LambdaIR != self.LambdaIR):
+            raise NotImplementedError("IRFilters: the engine's tables are built for soffset=1, RescaleIR=1, window=None and the constructor's LambdaIR")
+        eng = self._inputs(bird)
+        eng.run(L.K_IRFILTER)  # irfilter_kernel alone: X, Y, Q(f) from the inputs; nothing else on the device is touched
         xy = eng.get("XY", (2, NS_DEV))[:, self._sr]
         return np.ascontiguousarray(xy[0]), np.ascontiguousarray(xy[1])
+
+    def setXpYp(self, bird):
+        """[X^(p+1), p < NIR] then [Y X^p, p < NIR] on the resummed s range (reference pybird.py:1402-1407): [2 NIR, |sr|]"""
+        X, Y = self.IRFilters(bird)
+        return np.concatenate((np.array([X ** (p + 1) for p in range(self.NIR)]), np.array([Y * X**p for p in range(self.NIR)])))
+
+    def extractBAO(self, cf):
+        """(reference pybird.py:1382-1400) host form, for callers of the helper; the stage itself uses extract_bao_kernel"""
+        if not self.co.optiresum:
+            return cf
+        from scipy.interpolate import interp1d
+
+        cfnobao = np.concatenate([cf[..., : self.idlow], cf[..., self.idhigh :]], axis=-1)
+        nobao = interp1d(self.snobao, self.snobao**2 * cfnobao, kind="linear", axis=-1)(self.sbao) * self.sbao**-2
+        return cf[..., self.idlow : self.idhigh] - nobao
 
     def Ps(self, bird, window=None):
         """Adds the IR corrections to bird.P11l / Pctl / Ploopl in place (reference pybird.py:1413-1464)."""
         if window is not None:
             raise NotImplementedError("Resum.Ps(window=...) is not on the accelerated path")
-        eng, co = self.engine, self.co
-        eng.put("PIN", bird.Pin)
-        eng.put("F", np.array([bird.f]))
-        eng.put("C11", _s_pad(bird.C11))
-        eng.put("CCT", _s_pad(bird.Cct))
-        eng.put("CLOOPL", _s_pad(bird.Cloopl))
-        if co.with_NNLO:
-            eng.put("CCTN", _s_pad(bird.CctNNLO))
+        co = self.co
+        eng = self._inputs(bird)
+        for n, buf in (("C11", "C11"), ("Cct", "CCT"), ("Cloopl", "CLOOPL")) + ((("CctNNLO", "CCTN"),) if co.with_NNLO else ()):
+            if not bird._on_device(eng, buf):
+                eng.put(buf, _s_pad(getattr(bird, n)))
+                bird._dev.add(buf)
         bird._templates_to_device(eng)
-        eng.run(L.S_RESUM)
-        bird._templates_from_device(eng, ("P11l", "Pctl", "Ploopl"))
-        self.Q = eng.get("Q", (2, co.Nl, co.Nl, self.Nn))
+        eng.run(L.S_RESUM, sync=False)
+        bird._templates_pending(("P11l", "Pctl", "Ploopl"))
+        self._Q, self._Qf = None, bird.f
         if self.snapshot:
             bird.create_snapshot("IRresum")
 
@@ -367,16 +576,32 @@ class APeffect(HasLogger):
     def AP(self, bird, q=None):
         """Re-binds bird.P11l / Pctl / Ploopl (/ Pstl if APst) (reference pybird.py:1598-1621)."""
         eng = self.engine
+        claim(eng, bird)
+        bird.__dict__["_engine"] = eng
         qperp, qpar = self.get_AP_param(bird) if q is None else q
-        eng.set_ap_fiducial(self.DA, self.H)
-        eng.set_ap_stochastic(self.APst)
+        if getattr(eng, "_ap_state", None) != (self.DA, self.H, bool(self.APst)):  # tables of the stage: only when another plugin set them last
+            eng.set_ap_fiducial(self.DA, self.H)
+            eng.set_ap_stochastic(self.APst)
+            eng._ap_state = (self.DA, self.H, bool(self.APst))
         eng.put("DA", np.array([qperp * self.DA]))
         eng.put("H", np.array([self.H / qpar]))
         bird._templates_to_device(eng)
-        eng.run(L.S_AP)
-        bird._templates_from_device(eng)
+        eng.run(L.S_AP, sync=False)
+        bird._templates_pending(("P11l", "Pctl", "Ploopl", "Pstl") if self.APst else ("P11l", "Pctl", "Ploopl"))
         if self.snapshot:
             bird.create_snapshot("APeffect")
+
+    def integrAP(self, k, Pk, kp, arrayLegendremup, many=False):
+        """Host form of the AP integral for one set of rows (reference pybird.py:1581-1596): cubic interpolation onto kp(k, mu),
+        Legendre weights, trapezoid rule on the mu grid.  Not on the device path (``AP`` is); kept for callers of the helper."""
+        from scipy.interpolate import interp1d
+
+        mugrid = np.linspace(0.0, 1.0, self.nbinsmu)
+        _trapz = getattr(np, "trapezoid", None) or np.trapz
+        Pkint = interp1d(k, Pk, axis=-1, kind="cubic", bounds_error=False, fill_value="extrapolate")
+        if many:
+            return 2.0 * _trapz(np.einsum("lpkm,lkm->lpkm", Pkint(kp), arrayLegendremup), x=mugrid, axis=-1)
+        return 2.0 * _trapz(Pkint(kp) * arrayLegendremup, x=mugrid, axis=-1)
 
 
 class FiberCollision(HasLogger):
@@ -417,16 +642,13 @@ class FiberCollision(HasLogger):
     def fibcolWindow(self, bird):
         """P11l, Pctl, Ploopl (and Pstl if fiberst) += dPcorr, in place (reference pybird.py:1760-1810)"""
         from .tables import compose_operator
-        from .transformer import apply_operator_to_birdlike
+        from .transformer import apply_operator_in_place
 
         eng = engine_for(bird.co)
         if self._op is None or self._op[0] is not eng:
-            self._op = (eng, eng.add_operator(compose_operator(self.co.Nl, self.co.Nk, fiber=self.operator())))
-        keep = bird.Pstl
-        out = apply_operator_to_birdlike(eng, self._op[1], bird)
-        bird.P11l, bird.Pctl, bird.Ploopl = out["P11l"], out["Pctl"], out["Ploopl"]
-        bird.Pstl = out["Pstl"] if self.fiberst else keep
-        if "PctNNLOl" in out:
-            bird.PctNNLOl = out["PctNNLOl"]
+            full = compose_operator(self.co.Nl, self.co.Nk, fiber=self.operator())
+            keep = None if self.fiberst else compose_operator(self.co.Nl, self.co.Nk)  # Pstl untouched unless fiberst (pybird.py:1788-1797)
+            self._op = (eng, eng.add_operator(full, stochastic=keep))
+        apply_operator_in_place(eng, self._op[1], bird)
         if self.snapshot:
             bird.create_snapshot("fiber")

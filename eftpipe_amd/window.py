@@ -15,7 +15,7 @@ import numpy as np
 
 from ._log import HasLogger
 from .tables import spline_matrix, window_fold, window_pgrid, window_tables
-from .transformer import apply_operator_to_birdlike
+from .transformer import apply_operator_in_place, apply_operator_to_birdlike
 
 
 class MetaInfoError(Exception):
@@ -138,15 +138,29 @@ class Window(HasLogger):
 
         eng = engine_for(bird.co)
         if self._op is None or self._op[0] is not eng:
-            self._op = (eng, eng.add_operator(self.Wfold))
-        keep = bird.Pstl
-        out = apply_operator_to_birdlike(eng, self._op[1], bird)
-        bird.P11l, bird.Pctl, bird.Ploopl = out["P11l"], out["Pctl"], out["Ploopl"]
-        bird.Pstl = out["Pstl"] if self.window_st else keep
-        if "PctNNLOl" in out:
-            bird.PctNNLOl = out["PctNNLOl"]
+            Na, Nl, Nk = self.Wfold.shape[0], self.Wfold.shape[1], self.Wfold.shape[2]
+            keep = None
+            if not self.window_st and Na == Nl:  # Pstl passes through untouched: an identity matrix for the stochastic rows
+                keep = np.einsum("al,xk->alxk", np.eye(Nl), np.eye(Nk))
+            self._op = (eng, eng.add_operator(self.Wfold, stochastic=keep), keep is not None or self.window_st)
+        if self._op[2]:
+            apply_operator_in_place(eng, self._op[1], bird)
+        else:  # window_st off with Na != Nl: the reference keeps the old Pstl array as it is
+            keep = bird.Pstl
+            apply_operator_in_place(eng, self._op[1], bird)
+            bird.Pstl = keep
         if self.snapshot:
             bird.create_snapshot("window")
+
+    def integrWindow(self, P, many=False):
+        """Host form of the convolution of one array of rows (reference window.py:371-387): cubic interpolation onto the p grid, then
+        the masked dp-weighted matrix.  ``Window`` applies the same operator on the device; kept for callers of the helper."""
+        from scipy.interpolate import interp1d
+
+        Pp = interp1d(self.co.k, P, axis=-1, kind="cubic", bounds_error=False, fill_value="extrapolate")(self.p)
+        if many:
+            return np.einsum("alkp,lsp->ask", self.Waldk, Pp)
+        return np.einsum("alkp,lp->ak", self.Waldk, Pp)
 
 
 # ----------------------------------------------------------------------------- window as a ready-made matrix
@@ -240,12 +254,9 @@ class WindowMatrix(HasLogger):
         if self._op is None or self._op[0] is not eng:
             self._op = (eng, eng.add_operator(self.operator))
         keep = bird.Pstl
-        out = apply_operator_to_birdlike(eng, self._op[1], bird)
-        bird.P11l, bird.Pctl, bird.Ploopl = out["P11l"], out["Pctl"], out["Ploopl"]
-        if "PctNNLOl" in out:
-            bird.PctNNLOl = out["PctNNLOl"]
-        if self.window_st:
-            bird.Pstl = out["Pstl"]
+        apply_operator_in_place(eng, self._op[1], bird)
+        if not self.window_st:
+            bird.Pstl = keep
         bird.Picc = np.zeros((self.outpoles.nells, self.outpoles.nbin))
         if self.snapshot:
             bird.create_snapshot("window")

@@ -114,7 +114,8 @@ enum eftb_stage {
     EFTB_K_P22     = 1 << 8,  /* makeP22 alone: anti-diagonal sums + rows + synthesis */
     EFTB_K_C22     = 1 << 9,  /* makeC22 + makeC13 alone */
     EFTB_K_RESUM   = 1 << 10, /* the main kernel of Resum.Ps alone (operands of an earlier EFTB_S_RESUM run) */
-    EFTB_S_LOGP    = 1 << 11  /* Marginalizable.marginalized_logp on the current template block   marginal.py:79-140 */
+    EFTB_S_LOGP    = 1 << 11, /* Marginalizable.marginalized_logp on the current template block   marginal.py:79-140 */
+    EFTB_K_IRFILTER = 1 << 12 /* Resum.IRFilters + Resum.makeQ alone: X(s), Y(s), Q(f) from the inputs (EFTB_B_XY, EFTB_B_Q)   pybird.py:1316-1380 */
 };
 
 int  eftb_create(const eftb_config* cfg, eftb_engine** out);
@@ -220,6 +221,10 @@ int  eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f
 int  eftb_run_staged(eftb_engine* e, int stage_mask, int B);
 /* EFTB_B_PLK or EFTB_B_LOGP of the step before the one in flight (waits only for that step). */
 int  eftb_fetch_previous(eftb_engine* e, int buffer_id, double* host, size_t count);
+/* The same for the step launched `back` (1 or 2) steps before the last one.  back = 2 keeps TWO steps queued on the GPU while the host
+ * copies results out and prepares the next inputs -- the loop  stage(i); run_staged(i); fetch_back(2) [= step i - 2]  never lets the
+ * look-ahead of consecutive steps run dry; the set read here is the one the next eftb_stage_inputs refills. */
+int  eftb_fetch_back(eftb_engine* e, int back, int buffer_id, double* host, size_t count);
 
 /* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
  * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */
@@ -238,11 +243,11 @@ int  eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]);
  * if host_out != NULL (root only) the gathered block [nranks][B][Nl][Nx] is copied out after the gather. */
 int  eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out);
 /* Pipelined multi-GPU steps (eftb_stage_inputs / eftb_run_staged / eftb_gather_plk per step, nothing waits for the step in flight): the
- * gathered block alternates between two device buffers; this copies out, on the root, the block ([nranks][B][nl][nx], count elements)
- * of the exchange BEFORE the last one enqueued (which = 0) or of the last one (which = 1), waiting only for that exchange.  With a
+ * gathered block rotates through three device buffers; this copies out, on the root, the block ([nranks][B][nl][nx], count elements)
+ * of the last exchange enqueued (back = 0) or of the one `back` (1 or 2) exchanges before it, waiting only for that exchange.  With a
  * communicator (eftb_comm_init, to be called before the first eftb_stage_inputs) the staged sets keep P_l in device memory, where
  * RCCL reads it. */
-int  eftb_fetch_gathered(eftb_engine* e, int which, double* host, size_t count);
+int  eftb_fetch_gathered(eftb_engine* e, int back, double* host, size_t count);
 
 /* Window precompute (reference Window._compute_Wal / _compute_Waldk, window.py:262-359) on the device.  The caller passes
  * the k-independent tables of eftpipe_amd.tables.window_tables: x [nx] (FFTLog samples inside the tabulated window), Qt
