@@ -86,8 +86,9 @@ def executed_flops_per_launch(B):
     (one wave, 16 k x 1 s) `flops_per_wave_trip` = 2048 per v_mfma_f64_16x16x4 + 64 lanes x (2 per v_fma/v_fmac_f64, 1 per v_mul/v_add_f64),
     times waves (4 per 64 k of the resummed range, per cosmology) times 80 trips."""
     path = os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")
+    wps = int(os.environ.get("EFTB_RESUM_WPS", "2"))
     with open(path) as fh:
-        info = json.load(fh)["resum_mfma_kernel"]
+        info = json.load(fh)["resum_mfma_kernel<%d,0>" % (3 if wps >= 3 else 2)]  # the variant the engine launches (waves per SIMD, no NNLO)
     loop = max(info["loops"], key=lambda b: b["mfma"] + b["valu_f64"])
     waves = ((NK - NKLOW + 63) // 64) * 4 * B
     per_trip = {"mfma": loop["mfma"], "valu_f64": loop["valu_f64"], "f64_ops": loop["f64_ops"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
@@ -294,7 +295,7 @@ def main():
         alg_resum = 8.0 * NA * (NL * 14 * 2 * NIR) * 193 * (NK - NKLOW) * B
         alg_p22 = 8.0 * 28 * NK * NPOW**2 * B
         roofline = {
-            "bound": "mfma", "kernel": "resum_mfma_kernel (Resum.Ps on v_mfma_f64_16x16x4_f64 + FP64 VALU, which share the DP pipe)",
+            "bound": "mfma", "kernel": "resum_mfma_kernel<waves per SIMD, NNLO> (Resum.Ps on v_mfma_f64_16x16x4_f64 + FP64 VALU, which share the DP pipe)",
             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src,
             "ms_per_launch": ms_resum, "executed_flops_per_launch": exe_flops, "executed_mfma_flops_per_launch": exe_mfma_flops,

@@ -795,9 +795,26 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
                                                          const double* __restrict__ V8S, const int* __restrict__ rows,
                                                          const double* __restrict__ XY, const double* __restrict__ C11,
                                                          const double* __restrict__ Cct, const double* __restrict__ Cloopl,
-                                                         double* __restrict__ RSA, double* __restrict__ RSC) {
+                                                         double* __restrict__ RSA, double* __restrict__ RSC, const double* __restrict__ CctN,
+                                                         const double* __restrict__ CC, const double* __restrict__ fgrow,
+                                                         const double* __restrict__ l22, const double* __restrict__ l13,
+                                                         const int* __restrict__ grp) {
+    // CctN (with_nnlo, may be null): Bird.CctNNLO rides in the spare slots 44-46 of the record, for the NNLO accumulator of resum_mfma_kernel
+    // CC (may be null): the regrouping of C22 / C13 into Cloopl (Bird.setPsCfl for the xi pieces, reference pybird.py:805-846) is done
+    // here, straight into the records -- whole-pipeline runs then skip regroup_cf_kernel and the Cloopl buffer
     const int w = blockIdx.x;
     const double* q = Q + (size_t)w * 2 * NL * NL * NN;
+    __shared__ double s_cf[NL * 38];  // f^power * mu-weight per piece and multipole
+    __shared__ int s_gi[38];
+    if (CC) {
+        const double f = fgrow[w];
+        for (int e = threadIdx.x; e < NL * 38; e += blockDim.x) {
+            const int lp = e / 38, bq = e % 38;
+            s_cf[e] = ipow(f, grp[2 * bq + 1]) * (bq < 28 ? l22[lp * 28 + bq] : l13[lp * 10 + (bq - 28)]);
+        }
+        for (int e = threadIdx.x; e < 38; e += blockDim.x) s_gi[e] = grp[2 * e];
+        __syncthreads();
+    }
     for (int idx = threadIdx.x; idx < RS_ROWS * RS_NB; idx += blockDim.x) {
         const int row = idx / RS_NB, r = idx % RS_NB, off = rows[row];
         double a0 = 0.0, a1 = 0.0;
@@ -815,9 +832,18 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
             const int lp = c / 14, j = c % 14;
             if (j == 0) v = C11[((size_t)w * NL + lp) * NS + s];
             else if (j == 1) v = Cct[((size_t)w * NL + lp) * NS + s];
-            else v = Cloopl[(((size_t)w * NL + lp) * 12 + (j - 2)) * NS + s];
+            else if (!CC) v = Cloopl[(((size_t)w * NL + lp) * 12 + (j - 2)) * NS + s];
+            else {  // same sums, in the same order, as regroup_cf_kernel
+                const double* cc = CC + (size_t)w * NL * 38 * NS;
+                for (int bq = 0; bq < 28; ++bq)
+                    if (s_gi[bq] == j - 2) v += s_cf[lp * 38 + bq] * cc[(size_t)(lp * 28 + bq) * NS + s];
+                for (int bq = 0; bq < 10; ++bq)
+                    if (s_gi[28 + bq] == j - 2) v += s_cf[lp * 38 + 28 + bq] * cc[(size_t)(NL * 28 + lp * 10 + bq) * NS + s];
+            }
         } else if (c < 44) {
             v = XY[(size_t)w * 2 * NS + (c - 42) * NS + s];
+        } else if (CctN && c < 44 + NL) {
+            v = CctN[((size_t)w * NL + (c - 44)) * NS + s];
         }
         RSC[((size_t)w * NS + s) * RS_REC + c] = v;
     }
@@ -833,12 +859,16 @@ __device__ inline double estrin16(const double* __restrict__ c, double t, double
 
 // RS_WPS = waves per SIMD the kernel is built for (launch bounds): with the basis coefficients in LDS instead of 64 VGPRs the kernel fits three
 // waves per SIMD (<= 168 VGPRs); the 16-byte LDS reads of the next step's polynomials fly under this step's MFMAs.
-template <int RS_WPS>
+// NNLO: the k^4 P11 counter-terms PctNNLOl (reference pybird.py:1447-1458) take the same W as Pctl with CctNNLO in place of Cct and lctNNLO in
+// place of lct -- three more accumulators per lane (record slots 44-46) instead of a second pass over the whole stage; TN is the NNLO
+// block (rows 3-5).  Only with nsplit = 1 (the partial-sum layout of small batches has no slot for it: those run the second pass).
+template <int RS_WPS, bool NNLO>
 __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
                                                             const double* __restrict__ H, const double* __restrict__ V8,
                                                             const double* __restrict__ RSA, const double* __restrict__ RSC,
                                                             const double* __restrict__ l11, const double* __restrict__ lct,
-                                                            double* __restrict__ T, double* __restrict__ part, int nsplit) {
+                                                            double* __restrict__ T, double* __restrict__ part, int nsplit,
+                                                            const double* __restrict__ lctn, double* __restrict__ TN) {
     constexpr int NL = 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jg = lane >> 4, n = lane & 15;
@@ -884,6 +914,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
 #pragma unroll
     for (int i = 0; i < 3; ++i) accCt[i] = acc11A[i] = 0.0;
     acc11B[0] = acc11B[1] = 0.0;
+    double accN[3] = {0.0, 0.0, 0.0};  // NNLO: W CctNNLO[l']
     const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
     const double* ct = RSC + ((size_t)w * NS + s0) * RS_REC;  // wave-uniform record of the current s
     double h[3];
@@ -928,6 +959,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         const double W_ = fma(zh[tau], Dt[0], fma(yh[0], Dt[1], fma(yh[1], Dt[2], yh[2] * Dt[3])));                         \
         acc11A[tau] = fma(W_, cv[tau * 14], acc11A[tau]);                                                                   \
         accCt[tau] = fma(W_, cv[tau * 14 + 1], accCt[tau]);                                                                 \
+        if (NNLO) accN[tau] = fma(W_, cn[tau], accN[tau]);                                                                  \
         _Pragma("unroll") for (int i = 0; i < 12; ++i) accL[i] = fma(W_, cv[tau * 14 + 2 + i], accL[i]);                    \
     } while (0)
         // tiles 3 and 4: one (a = 0, l, l') block per lane, l' by lane group
@@ -938,6 +970,11 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         acc11B[which] = fma(Wx_, cx_, acc11B[which]);                                                                       \
     } while (0)
         const double c11_0 = cv[0], c11_1 = cv[14];
+        double cn[3] = {0.0, 0.0, 0.0};
+        if (NNLO) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) cn[i] = ct[44 + i];
+        }
         if (RS_WPS >= 3) {
             // tile by tile: the MFMA pair of tile tau + 1 is issued before tile tau is consumed, so only two result tiles are live (the
             // third wave of the SIMD covers what this order leaves exposed); the next step's basis polynomials sit in the middle
@@ -1005,6 +1042,11 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
             double* dst = T + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
 #pragma unroll
             for (int i = 0; i < 18; ++i) dst[(size_t)i * Nk] += o18[i];
+            if (NNLO) {  // PctNNLOl[l = jg][i] += sum_l' lctNNLO[l'][i] W Cct_NNLO[l']   (lctn is [Nl][6], zero padded)
+                double* dn = TN + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dn[(size_t)i * Nk] += lctn[i] * accN[0] + lctn[6 + i] * accN[1] + lctn[12 + i] * accN[2];
+            }
         } else {
             double* dst = T + (((size_t)w * NL + 0) * NROW) * Nk + k;
 #pragma unroll

@@ -43,7 +43,7 @@ static int fail(const char* fmt, ...) {
 struct eftb_engine {
     eftb_config c;
     hipStream_t stream = nullptr, side = nullptr;   // side: the small input-only kernels (IR filters, AP prefix sums) run beside the loop path
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJoin = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr, evJoin = nullptr, evJoinAP = nullptr;  // evJoin: X, Y, Q(f) ready; evJoinAP: AP prefix sums + knot weights ready
     bool finalized = false;
     void* tab[EFTB_T_COUNT] = {nullptr};
     size_t tab_bytes[EFTB_T_COUNT] = {0};
@@ -60,7 +60,9 @@ struct eftb_engine {
     int4 *APM = nullptr, *APM2 = nullptr;
     bool ap_fast = true;  // EFTB_AP_FAST=0: every tile through ap_apply_kernel (the pre-weights form, kept as the fallback)
     int ap_chunk = 8;     // template rows per workgroup of ap_rows_kernel (EFTB_AP_CHUNK=6|8|12)
-    int resum_wps = 3;    // waves per SIMD resum_mfma_kernel is built for (EFTB_RESUM_WPS=2: basis coefficients in registers, 205 VGPRs)
+    bool fuse_cf = true;  // EFTB_FUSE_CF=0: always through regroup_cf_kernel (A/B switch)
+    int resum_wps = 2;    // waves per SIMD resum_mfma_kernel is built for: 2 = basis coefficients in registers (201 VGPRs); EFTB_RESUM_WPS=3 = basis
+                          // coefficients in LDS, tile-by-tile consumption (166 VGPRs) -- measured 4 % slower: the kernel is bound by the DP pipe, not by latency
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
     double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
     double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of the P22 basis [B][BAS22][KSYN] and of P13 [B][10][KLIN]
@@ -471,20 +473,43 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     const bool ap_side = pre_side && e->ap_overlap && e->allow_back && (mask & EFTB_S_RESUM) && (mask & EFTB_S_AP) && (Nl == 3 || !e->generic_resum);
     if (!ap_side) join_back(e);
     const int bslot = e->back_step & 1;  // evBack[bslot] was recorded two runs ago
+    // whole-pipeline runs regroup C22 / C13 into the resummation records directly (resum_prep_kernel): no regroup_cf_kernel, no Cloopl
+    // buffer on the way (EFTB_B_CLOOPL then keeps what the last stand-alone REGROUP stage left there)
+    const bool fuse_cf = (mask & EFTB_S_REGROUP) && (mask & EFTB_S_RESUM) && c.with_resum && (Nl == 3 || !e->generic_resum) && !c.optiresum && !c.with_nnlo &&
+                         !nnlo_pass && e->fuse_cf;
     if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
         if (side_ir) launch_irfilter(e, e->side, B);
-        if (side_ap) launch_ap_prefix(e, e->side, B);
         if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
+        if (side_ap) launch_ap_prefix(e, e->side, B);
+        if (hipEventRecord(e->evJoinAP, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
     }
-    bool joined = !(side_ir || side_ap);
+    bool joined = !side_ir, joined_ap = !side_ap;
     if (mask & EFTB_S_PREP) {
         const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
         hipStream_t st0 = st;
         if (pre_side) {
             st = e->pre;
             if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            // the input-only kernels (IR filters / Q(f); AP prefix sums and knot weights) get their own low-priority stream beside the front
+            // half: X, Y, Q are free since the previous run built its resummation operands (evInFree); the AP tables alternate between two
+            // sets because the previous run's AP reads its own late (the set written here was last read two runs ago: evBack)
+            if (side_ir || side_ap) {
+                if (hipStreamWaitEvent(e->side, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+                if (side_ir) launch_irfilter(e, e->side, B);
+                if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
+                if (side_ap) {
+                    std::swap(e->APP, e->APP2);
+                    std::swap(e->APR, e->APR2);
+                    std::swap(e->APW, e->APW2);
+                    std::swap(e->API, e->API2);
+                    std::swap(e->APM, e->APM2);
+                    if (ap_side && hipStreamWaitEvent(e->side, e->evBack[bslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");  // its reader
+                    launch_ap_prefix(e, e->side, B);
+                }
+                if (hipEventRecord(e->evJoinAP, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
+            }
         }
         hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                            tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
@@ -543,19 +568,6 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     }
     if (pre_side) {
         if (hipEventRecord(e->evPrep, st) != hipSuccess || hipStreamWaitEvent(st_main, e->evPrep, 0) != hipSuccess) return fail("eftb_run: stream join failed");
-        // the input-only kernels follow on the same stream: X, Y, Q(f) are free since the previous run built its resummation operands (that
-        // is what this stream waited for); the AP prefix sums alternate between two buffers because the previous run's AP reads its own late
-        if (side_ir) launch_irfilter(e, st, B);
-        if (side_ap) {
-            std::swap(e->APP, e->APP2);
-            std::swap(e->APR, e->APR2);
-            std::swap(e->APW, e->APW2);
-            std::swap(e->API, e->API2);
-            std::swap(e->APM, e->APM2);
-            if (ap_side && hipStreamWaitEvent(st, e->evBack[bslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");  // its reader
-            launch_ap_prefix(e, st, B);
-        }
-        if ((side_ir || side_ap) && hipEventRecord(e->evJoin, st) != hipSuccess) return fail("eftb_run: stream join failed");
         st = st_main;
     }
     if (ap_side) {
@@ -570,7 +582,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (c.with_nnlo)
             hipLaunchKernelGGL(nnlo_rows_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11],
                                tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN]);
-        if (c.with_resum)
+        if (c.with_resum && !fuse_cf)
             hipLaunchKernelGGL(regroup_cf_kernel, dim3(12, Nl, B), dim3(128), 0, st, Nl, b[EFTB_B_F], b[EFTB_B_CC], tb<double>(e, EFTB_T_L22),
                                tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_CLOOPL]);
         // nothing later in this run reads the front half's outputs (P11, coefficients, P22, P13, CC; C11 / Cct only if a resummation
@@ -600,7 +612,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         }
         if (Nl == 3 || !e->generic_resum) {
             // matrix-core form: polynomials as [80 | 32 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
-#define RP_ARGS e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS), tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], c11, cct, cloopl, e->RSA, e->RSC
+            // with_nnlo, large batches: CctNNLO rides in the records and the main kernel accumulates PctNNLOl beside Pctl (no second pass)
+            const bool fused_nnlo = c.with_nnlo && !nnlo_pass && Nl == 3 && e->resum_splits == 1 && !c.optiresum;
+#define RP_ARGS e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS), tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], c11, cct, cloopl, e->RSA, e->RSC, \
+                fused_nnlo ? b[EFTB_B_CCTN] : nullptr, fuse_cf ? b[EFTB_B_CC] : nullptr, b[EFTB_B_F], tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), \
+                tb<int>(e, EFTB_T_GRP)
             if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), dim3(B), dim3(256), 0, st, RP_ARGS);
             else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), dim3(B), dim3(256), 0, st, RP_ARGS);
 #undef RP_ARGS
@@ -613,8 +629,12 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             const int schunk = (NS + nsplit - 1) / nsplit;
 #define RM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), \
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
-            if (kblocks > 0 && Nl == 3 && e->resum_wps >= 3) hipLaunchKernelGGL((resum_mfma_kernel<3>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
-            else if (kblocks > 0 && Nl == 3) hipLaunchKernelGGL((resum_mfma_kernel<2>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
+            if (kblocks > 0 && Nl == 3 && fused_nnlo)
+                hipLaunchKernelGGL((resum_mfma_kernel<2, true>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN]);
+            else if (kblocks > 0 && Nl == 3 && e->resum_wps >= 3)
+                hipLaunchKernelGGL((resum_mfma_kernel<3, false>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr);
+            else if (kblocks > 0 && Nl == 3)
+                hipLaunchKernelGGL((resum_mfma_kernel<2, false>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr);
             else if (kblocks > 0) hipLaunchKernelGGL(resum_mfma2_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
 #undef RM_ARGS
             if (nsplit > 1)
@@ -649,9 +669,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         const int nr = c.ap_stochastic && !nnlo_pass ? NROW : 21;
         const int rs = e->ap_rowsplit;
         if (!side_ap && !nnlo_pass) launch_ap_prefix(e, st, B);
-        if (!joined) {
-            if (hipStreamWaitEvent(st, e->evJoin, 0) != hipSuccess) return fail("eftb_run: stream join failed");
-            joined = true;
+        if (!joined_ap) {
+            if (hipStreamWaitEvent(st, e->evJoinAP, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+            joined_ap = true;
         }
         if (e->ap_fast) {
             // banded product of the knot weights with the spline data; rows [nr, 24) are copied through
@@ -770,7 +790,10 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     swap_in();
     e->cur_nl = in_nl;
     e->cur_nx = in_nx;
-    const int rc = launch_stages_impl(e, lin, B, true);
+    // large batches at Nl = 3 accumulate PctNNLOl inside the resummation kernel of the first pass: only AP / PROJECT are left for the block
+    const bool fused = c.with_resum && c.Nl == 3 && e->resum_splits == 1 && !c.optiresum && !e->generic_resum;
+    const int lin2 = fused ? (lin & ~EFTB_S_RESUM) : lin;
+    const int rc = lin2 ? launch_stages_impl(e, lin2, B, true) : 0;
     swap_in();  // the same swaps undo themselves
     e->cur_nl = out_nl;
     e->cur_nx = out_nx;
@@ -889,6 +912,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipEventRecord(e->evInFree, e->pre));
     HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evJoinAP, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
     for (int id = 0; id < EFTB_B_COUNT; ++id) {
@@ -933,6 +957,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AP_FAST")) e->ap_fast = atoi(f) != 0;
     if (const char* f = getenv("EFTB_AP_CHUNK")) e->ap_chunk = atoi(f);
     if (const char* f = getenv("EFTB_RESUM_WPS")) e->resum_wps = atoi(f);
+    if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 4 * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 4 * sizeof(int));
     HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
@@ -996,8 +1021,9 @@ int eftb_finalize(eftb_engine* e) {
     AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
 #undef AP_LDS
     if (c.with_ap) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // (the kernel also holds a few static words: the dynamic part must leave room for them below the 160 KB of a CU)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // third template block (engine.back)
     HIPCHK(hipDeviceSynchronize());  // null-stream zero fills (part, ZC, ZC2) are not ordered against the engine's non-blocking streams
@@ -1187,7 +1213,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1]}) if (ev) (void)hipEventDestroy(ev);
     if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->back) (void)hipStreamDestroy(e->back);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
@@ -1453,6 +1479,7 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     ++e->epoch;  // (captured graphs hold the other set's pointers)
     HIPCHK(hipStreamWaitEvent(e->stream, e->evStaged[e->cur_set], 0));  // the side stream forks from here, so it inherits the wait
     HIPCHK(hipStreamWaitEvent(e->pre, e->evStaged[e->cur_set], 0));
+    HIPCHK(hipStreamWaitEvent(e->side, e->evStaged[e->cur_set], 0));
     e->inputs_settled = e->allow_back = true;
     const int rc = run_stages(e, mask, B);
     e->inputs_settled = e->allow_back = false;

@@ -95,10 +95,22 @@ common = Common()
 _ENGINES: "weakref.WeakKeyDictionary[Common, Engine]" = weakref.WeakKeyDictionary()
 
 
-def engine_for(co, nbinsmu=200, loop_cache=None):
-    """The engine serving `co`, created on first use with the resum and AP tables resident."""
+_ENGINE_DEFAULTS = dict(nbinsmu=200, LambdaIR=0.2, NFFT_resum=192, resum_window=None)
+
+
+def engine_for(co, loop_cache=None, **opts):
+    """The engine serving `co`, created on first use with the resum and AP tables resident.  The plugin constructors record the
+    options that shape the device tables (APeffect: mu nodes; Resum: LambdaIR, NFFT, coefficient window) on `co` itself, so every
+    plugin of one tracer finds the same engine whatever the construction order; a changed option rebuilds the tables."""
+    store = co.__dict__.setdefault("_engine_opts", dict(_ENGINE_DEFAULTS))
+    for k in opts:
+        if k not in _ENGINE_DEFAULTS:
+            raise TypeError(f"unknown engine option {k!r}")
+    store.update(opts)
     eng = _ENGINES.get(co)
-    if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != nbinsmu
+    if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != store["nbinsmu"]
+                            or eng.cfg.LambdaIR != store["LambdaIR"] or eng.cfg.NFFT_resum != store["NFFT_resum"]
+                            or eng.cfg.resum_window != store["resum_window"]
                             or eng.cfg.with_NNLO != bool(co.with_NNLO) or eng.cfg.IRcutoff != co.IRcutoff or eng.cfg.kIR != co.kIR
                             or eng.cfg.optiresum != bool(co.optiresum)):
         release(eng)
@@ -106,7 +118,8 @@ def engine_for(co, nbinsmu=200, loop_cache=None):
         eng = None
     if eng is None:
         cfg = EngineConfig(Nl=co.Nl, k=np.array(co.k, dtype=np.float64), with_resum=True, with_ap=True, DA_AP=1.0, H_AP=1.0,
-                           nbinsmu=nbinsmu, with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR, optiresum=bool(co.optiresum))
+                           nbinsmu=store["nbinsmu"], LambdaIR=store["LambdaIR"], NFFT_resum=store["NFFT_resum"], resum_window=store["resum_window"],
+                           with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR, optiresum=bool(co.optiresum))
         eng = _ENGINES[co] = Engine(cfg, max_batch=1, loop_cache=loop_cache)
     return eng
 
@@ -311,8 +324,10 @@ class Bird:
     def setPsCfl(self):
         """Multipole weights, regrouping into the 12 bias groups, shot-noise subtraction, stochastic
         templates (reference pybird.py:737-866) -- regroup_kernel / regroup_cf_kernel."""
-        eng, co = self._need_engine(), self.co
+        self._need_engine()
+        eng, co = engine_for(self.co), self.co
         claim(eng, self)
+        self.__dict__["_engine"] = eng
         if not self._on_device(eng, "F"):
             eng.put("F", np.array([self.f]))
             self._dev.add("F")
@@ -395,12 +410,12 @@ class NonLinear(HasLogger):
                 self.mpi_warning("Can't load loop matrices at %s, computing new matrices.", path)
         if cache is not None:
             try:
-                self.engine = engine_for(co, loop_cache=cache)
+                engine_for(co, loop_cache=cache)
             except ValueError:
                 self.mpi_warning("Loaded loop matrices do not correspond to asked FFTLog configuration, computing new matrices.")
                 cache, save = None, save
         if cache is None:
-            self.engine = engine_for(co)
+            engine_for(co)
         self.loaded = cache is not None
         if save is True and cache is None:
             try:
@@ -408,6 +423,32 @@ class NonLinear(HasLogger):
                 np.savez(egg, **{k: mats[k] for k in PYEGG_KEYS})
             except Exception:
                 self.mpi_warning("Can't save loop matrices at %s.", path)
+
+    @property
+    def engine(self):
+        return engine_for(self.co)
+
+    def Coef(self, bird, window=None, IRcut=False):
+        """FFTLog coefficients of the linear spectrum [NFFT + 1] complex (reference pybird.py:1127-1141), host form for callers of the
+        helper (the device keeps its own real-reduced copy, EFTB_B_COEF)."""
+        from .tables import FFTLogOperator
+
+        kin, Pin = bird.kin, bird.Pin
+        if IRcut:
+            idx = int(np.searchsorted(kin, self.co.kIR))
+            op = FFTLogOperator(256, 1.5e-5, 1000.0, -1.6, kin[idx:], window, extrap=("padding", "extrap"))
+            Pin = Pin[idx:]
+            kin = kin[idx:]
+        else:
+            op = FFTLogOperator(256, 1.5e-5, 1000.0, -1.6, kin, window)
+        c = op.G @ Pin
+        if op.high_active:
+            slope = (np.log(Pin[-1]) - np.log(Pin[-2])) / (np.log(kin[-1]) - np.log(kin[-2]))
+            c = c + op.E_hi @ (Pin[-1] / kin[-1] ** slope * np.exp(slope * op.lnx_hi))
+        if op.low_active:
+            slope = (np.log(Pin[1]) - np.log(Pin[0])) / (np.log(kin[1]) - np.log(kin[0]))
+            c = c + op.E_lo @ (Pin[0] / kin[0] ** slope * np.exp(slope * op.lnx_lo))
+        return c
 
     def PsCf(self, bird, window=0.2):
         """FFTLog of P_lin + P22, P13, C11, Cct, C22, C13 (reference pybird.py:1143-1171) --
@@ -438,14 +479,15 @@ class Resum(HasLogger):
 
     def __init__(self, LambdaIR=0.2, NFFT=192, co=common, name="pybird.IRresum", snapshot=False):
         self.set_logger(name=name)
-        if LambdaIR != 0.2 or NFFT != 192:
-            raise NotImplementedError("engine tables are built for LambdaIR=0.2, NFFT=192 (reference defaults)")
-        self.co, self.LambdaIR = co, LambdaIR
+        if NFFT % 2 or NFFT < 8:
+            raise ValueError(f"expected even Nmax, instead of Nmax={NFFT}")  # reference fftlog.py:62-63
+        self.co, self.LambdaIR, self.NFFT = co, LambdaIR, NFFT
         self.NIR = 16 if co.Nl == 3 else 8
         self.Na = 3 if self.NIR == 16 else 2
         self.Nn = self.NIR * self.Na * 2
         self.snapshot = snapshot
-        self.engine = engine_for(co)
+        self._window = None
+        engine_for(co, LambdaIR=LambdaIR, NFFT_resum=NFFT, resum_window=None)
         self._Q = None
         self._Qf = None
         if co.optiresum:  # reference pybird.py:1235-1244
@@ -480,6 +522,10 @@ class Resum(HasLogger):
             val = val * f + P[..., p]
         self._Q = np.ascontiguousarray(val[::-1])
         self._Qf = f
+
+    @property
+    def engine(self):
+        return engine_for(self.co, LambdaIR=self.LambdaIR, NFFT_resum=self.NFFT, resum_window=self._window)
 
     def _inputs(self, bird):
         eng = self.engine
@@ -519,8 +565,7 @@ class Resum(HasLogger):
 
     def Ps(self, bird, window=None):
         """Adds the IR corrections to bird.P11l / Pctl / Ploopl in place (reference pybird.py:1413-1464)."""
-        if window is not None:
-            raise NotImplementedError("Resum.Ps(window=...) is not on the accelerated path")
+        self._window = window  # coefficient taper of the resummation FFTLog: part of the H table (rebuilt when it changes)
         co = self.co
         eng = self._inputs(bird)
         for n, buf in (("C11", "C11"), ("Cct", "CCT"), ("Cloopl", "CLOOPL")) + ((("CctNNLO", "CCTN"),) if co.with_NNLO else ()):
@@ -557,7 +602,11 @@ class APeffect(HasLogger):
         self._rdrag_warned = False
         self.nbinsmu = accboost * nbinsmu
         self.snapshot = snapshot
-        self.engine = engine_for(co, nbinsmu=self.nbinsmu)
+        engine_for(co, nbinsmu=self.nbinsmu)
+
+    @property
+    def engine(self):
+        return engine_for(self.co, nbinsmu=self.nbinsmu)
 
     def get_AP_param(self, bird):
         """qperp, qpar (reference pybird.py:1554-1562)."""

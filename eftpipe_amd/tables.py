@@ -222,6 +222,7 @@ class EngineConfig:
     with_resum: bool = False
     LambdaIR: float = 0.2
     NFFT_resum: int = 192
+    resum_window: Optional[float] = None    # Resum.Ps(bird, window=...): coefficient taper of the resummation FFTLog (pybird.py:1409-1411)
     with_ap: bool = False
     DA_AP: Optional[float] = None
     H_AP: Optional[float] = None
@@ -381,7 +382,7 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
         Na = 3 if Nl == 3 else 2
         kr_mask = k >= 0.02
         kr = k[kr_mask]
-        rop = FFTLogOperator(cfg.NFFT_resum, 0.1, 10000.0, -0.6, s[sr_idx], None, extrap=("padding", "padding"))
+        rop = FFTLogOperator(cfg.NFFT_resum, 0.1, 10000.0, -0.6, s[sr_idx], cfg.resum_window, extrap=("padding", "padding"))
         rM = np.stack([8.0 * np.pi**3 * lm.bessel_weight(2 * l, -0.5 * rop.Pow) for l in range(Na)])
         rk = np.exp(np.outer(-rop.Pow - 3.0, np.log(kr)))                # [193,Nkr]
         H = np.zeros((Na, Nk, NS))

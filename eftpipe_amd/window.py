@@ -61,8 +61,7 @@ class Window(HasLogger):
         self.co = pybird.common if co is None else co
         if window_fourier_file is None and window_configspace_file is None:
             raise ValueError("Window requires window_fourier_file or window_configspace_file or both")
-        if icc is not None:
-            raise NotImplementedError("integral-constraint correction is outside the accelerated hot path")
+        self.icc = icc  # an eftpipe_amd.icc.IntegralConstraint: its matrix is folded into the operator (reference window.py:393-406)
         self.window_fourier_file = Path(window_fourier_file).resolve() if window_fourier_file else None
         self.window_configspace_file = Path(window_configspace_file).resolve() if window_configspace_file else None
         self.window_st, self.withmask, self.windowk = window_st, withmask, windowk
@@ -72,8 +71,6 @@ class Window(HasLogger):
             raise ValueError(f"request Na={Na}, Nl={Nl} while bird only compute Nl up to {self.co.Nl}")
         if Na > Nl:
             raise ValueError(f"dangerous settings Na={Na}, Nl={Nl}")
-        if Nl != self.co.Nl:
-            raise NotImplementedError("Window(Nl != co.Nl) is not supported by the device operator")
         if pmax is None:
             pmax = float(self.co.k.max())
         self.p = window_pgrid(pmax, accboost)
@@ -137,18 +134,27 @@ class Window(HasLogger):
         from .pybird import engine_for
 
         eng = engine_for(bird.co)
+        if self.Wfold.shape[1] != bird.co.Nl:  # Window(Nl != co.Nl): the reference's einsum fails the same way (window.py:387)
+            raise ValueError(f"operands could not be broadcast together: window matrix has {self.Wfold.shape[1]} input multipoles, the bird {bird.co.Nl}")
         if self._op is None or self._op[0] is not eng:
             Na, Nl, Nk = self.Wfold.shape[0], self.Wfold.shape[1], self.Wfold.shape[2]
+            op = self.Wfold
+            if self.icc is not None:  # P -> W P - W_ic P as one matrix
+                if self.icc.Wfold.shape != op.shape:
+                    raise ValueError(f"icc matrix {self.icc.Wfold.shape} does not match the window matrix {op.shape}")
+                op = op - self.icc.Wfold
             keep = None
             if not self.window_st and Na == Nl:  # Pstl passes through untouched: an identity matrix for the stochastic rows
                 keep = np.einsum("al,xk->alxk", np.eye(Nl), np.eye(Nk))
-            self._op = (eng, eng.add_operator(self.Wfold, stochastic=keep), keep is not None or self.window_st)
+            self._op = (eng, eng.add_operator(op, stochastic=keep), keep is not None or self.window_st)
         if self._op[2]:
             apply_operator_in_place(eng, self._op[1], bird)
         else:  # window_st off with Na != Nl: the reference keeps the old Pstl array as it is
             keep = bird.Pstl
             apply_operator_in_place(eng, self._op[1], bird)
             bird.Pstl = keep
+        if self.icc is not None:
+            bird.Picc = bird.Picc - self.icc.PSN
         if self.snapshot:
             bird.create_snapshot("window")
 

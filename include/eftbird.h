@@ -78,7 +78,8 @@ enum eftb_buffer {
     EFTB_B_C11,       /* [B][Nl][80]          Bird.C11                            pybird.py:1090 */
     EFTB_B_CCT,       /* [B][Nl][80]          Bird.Cct                            pybird.py:1094 */
     EFTB_B_CC,        /* [B][Nl*38][80]       Bird.C22 ([Nl][28][80]) then Bird.C13 ([Nl][10][80]) */
-    EFTB_B_CLOOPL,    /* [B][Nl][12][80]      Bird.Cloopl                         pybird.py:805-846 */
+    EFTB_B_CLOOPL,    /* [B][Nl][12][80]      Bird.Cloopl                         pybird.py:805-846   (written by a REGROUP stage that is not
+                                              followed by RESUM in the same run: whole-pipeline runs regroup straight into the resummation records) */
     EFTB_B_TEMPL,     /* [B][nl][24][nx]      rows 0-2 P11l, 3-8 Pctl, 9-20 Ploopl, 21-23 Pstl; (nl, nx) = (Nl, Nk) until an
                                               operator (window / binning / chained) is applied, then that operator's output shape */
     EFTB_B_XY,        /* [B][2][80]           IR filters X(s), Y(s)               pybird.py:1316-1353 */

@@ -68,6 +68,7 @@ class OracleConfig:
     with_resum: bool = False
     LambdaIR: float = 0.2
     NFFT_resum: int = 192
+    resum_window: Optional[float] = None  # Resum.Ps(bird, window=...) (pybird.py:1409-1411, 1413)
     with_ap: bool = False
     Om_AP: Optional[float] = None
     z_AP: Optional[float] = None
@@ -297,7 +298,7 @@ class OracleEngine:
     def _ir_block(self, XpYp, C):
         """FFTLog(192) of XpYp (x) C followed by the Bessel sum (pybird.py:1361-1365, 1409-1441)."""
         inp = np.einsum("jk,...k->...jk", XpYp, C)
-        coef = self.rfft.coef(self.sr, inp, extrap="padding", window=None)
+        coef = self.rfft.coef(self.sr, inp, extrap="padding", window=self.cfg.resum_window)
         out = np.zeros(C.shape[:-1] + (self.Nn, self.Nk))
         flat_c = coef.reshape(-1, 2 * self.NIR, coef.shape[-1])
         flat_o = out.reshape(-1, self.Nn, self.Nk)

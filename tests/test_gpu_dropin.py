@@ -284,3 +284,91 @@ def test_optiresum(golden):
     for i in range(2):
         assert relerr(templ[i][:, 9:21], g["ap_Ploopl"]) < TOL and relerr(templ[i][:, 3:9], g["ap_Pctl"]) < TOL
     eng.close()
+
+
+def test_resum_nondefault_options_and_helper_methods(golden):
+    """Surface the reference offers beyond what theory.py calls: Resum(LambdaIR, NFFT), Resum.Ps(window=...), Resum.IRFilters / setXpYp /
+    makeQ, NonLinear.Coef, Bird.reducePsCfl / setPstl / subtractShotNoise and the mu-weighted by-products of setPsCfl -- against the
+    reference (tests/golden/resumopt.npz)."""
+    from eftpipe_amd import pybird
+
+    g = golden("resumopt")
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+    nl = pybird.NonLinear(load=False, save=False, co=co)
+    bird = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), 0.7, co=co)
+    c = nl.Coef(bird, window=None)
+    assert np.max(np.abs(c - g["coef_window_none"])) < 1e-12 * np.max(np.abs(g["coef_window_none"]))
+    nl.PsCf(bird)
+    bird.setPsCfl()
+    rs = pybird.Resum(LambdaIR=float(g["LambdaIR"]), NFFT=int(g["NFFT"]), co=co)
+    X, Y = rs.IRFilters(bird)
+    assert relerr(X[None], g["X"][None]) < 1e-10 and relerr(Y[None], g["Y"][None]) < 1e-10
+    assert relerr(rs.setXpYp(bird), g["XpYp"]) < 1e-10
+    rs.Ps(bird, window=float(g["window"]))
+    assert relerr(rs.Q.reshape(-1, rs.Nn), g["Q"].reshape(-1, rs.Nn)) < 1e-12
+    rs.makeQ(0.5)
+    assert rs.Q.shape == (2, 3, 3, 96)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(getattr(bird, n), g["resum_" + n]) < TOL, n
+    with pytest.raises(NotImplementedError):
+        rs.IRFilters(bird, soffset=2.0)
+    # a second bird on the default-option engine of another Common is not disturbed
+    b2 = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), co=co)
+    nl.PsCf(b2)
+    b2.setPsCfl()
+    assert relerr(b2.P22l.reshape(-1, 50), g["P22l"].reshape(-1, 50)) < TOL and relerr(b2.P13l.reshape(-1, 50), g["P13l"].reshape(-1, 50)) < TOL
+    assert relerr(b2.C22.reshape(-1, 80), g["C22w"].reshape(-1, 80)) < TOL and relerr(b2.C13.reshape(-1, 80), g["C13w"].reshape(-1, 80)) < TOL
+    assert relerr(b2.Cloopl, g["setpscfl_Cloopl"]) < TOL
+    # host helper forms
+    b2.reducePsCfl()
+    assert relerr(b2.Ploopl, g["setpscfl_Ploopl"]) < TOL and relerr(b2.Cloopl, g["setpscfl_Cloopl"]) < TOL
+    b2.setPstl()
+    assert np.array_equal(b2.Pstl, g["setpscfl_Pstl"])
+
+
+def test_lazy_bird_attributes_follow_host_mutation(golden):
+    """The stage outputs stay on the device until read; a host read, an in-place change of the array that was read, or a re-binding must all
+    be honoured by the next stage (the reference's plugins mutate the bird in place, theory.py:568-604)."""
+    from eftpipe_amd import pybird
+
+    g = golden("caseC")
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+    nl, rs = pybird.NonLinear(load=False, save=False, co=co), pybird.Resum(co=co)
+    ap = pybird.APeffect(Om_AP=synth.OM_AP, z_AP=0.7, co=co, APst=True)
+
+    def run(mutate):
+        bird = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), 0.7, co=co)
+        nl.PsCf(bird)
+        bird.setPsCfl()
+        rs.Ps(bird)
+        mutate(bird)
+        ap.AP(bird)
+        return {n: getattr(bird, n).copy() for n in ("P11l", "Pctl", "Ploopl", "Pstl")}
+
+    base = run(lambda b: None)
+    for n in base:
+        assert relerr(base[n], g["ap_" + n]) < TOL, n
+    read_only = run(lambda b: b.P11l)                              # a read alone changes nothing
+    assert all(np.array_equal(read_only[n], base[n]) for n in base)
+
+    def in_place(b):
+        b.Pctl[...] *= 2.0                                         # array handed out by the read, modified in place
+
+    doubled = run(in_place)
+    assert relerr(doubled["Pctl"], 2.0 * base["Pctl"]) < 1e-13 and np.array_equal(doubled["P11l"], base["P11l"])
+
+    def rebind(b):
+        b.Ploopl = 3.0 * b.Ploopl
+
+    tripled = run(rebind)
+    assert relerr(tripled["Ploopl"], 3.0 * base["Ploopl"]) < 1e-13 and np.array_equal(tripled["Pstl"], base["Pstl"])
+    # two birds in flight on one engine: the first one's pending results are fetched before the second one runs
+    b1 = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), 0.7, co=co)
+    nl.PsCf(b1)
+    b1.setPsCfl()
+    b2 = pybird.Bird(g["kin"], 1.1 * g["Pin"], float(g["f"]), float(g["DA"]), float(g["H"]), 0.7, co=co)
+    nl.PsCf(b2)
+    b2.setPsCfl()
+    assert relerr(b1.Ploopl, g["setpscfl_Ploopl"]) < TOL and relerr(b2.P11l, 1.1 * g["setpscfl_P11l"]) < TOL
+    rs.Ps(b1)
+    assert relerr(b1.Ploopl, g["resum_Ploopl"]) < TOL

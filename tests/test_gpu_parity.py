@@ -403,7 +403,23 @@ def test_pipelined_steps_with_changing_inputs(golden):
         assert np.array_equal(got[s], want[s]), s
     with pytest.raises(Exception):
         eng.run_staged(mask, B)  # nothing staged
-    # the same loop through the generator
+    # the same loop through the generator (which keeps two steps queued: eftb_fetch_back(2))
     for s, res in enumerate(eng.pipeline(steps)):
         assert np.array_equal(res, want[s]), s
+    assert len(list(eng.pipeline(steps[:1]))) == 1 and len(list(eng.pipeline(steps[:2]))) == 2
+    # explicit depth-2 loop: the result of step s - 2 is copied out after step s has been launched
+    got2 = []
+    for s in range(nsteps):
+        st = steps[s]
+        eng.stage_inputs(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"])
+        eng.run_staged(mask, B)
+        if s >= 2:
+            got2.append(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=2))
+    got2.append(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=1))
+    eng.sync()
+    got2.append(eng.get("PLK", (B, 3, g["k"].size)))
+    for s in range(nsteps):
+        assert np.array_equal(got2[s], want[s]), s
+    with pytest.raises(L.EftbError):
+        eng.fetch_previous("PLK", (B, 3, g["k"].size), back=3)
     eng.close()

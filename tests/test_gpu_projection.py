@@ -442,3 +442,34 @@ def test_window_precompute_rejects_bad_arguments():
         window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 2)          # Na > Nl
     with pytest.raises(L.EftbError):
         window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 3, windowk=0.0)
+
+
+def test_window_with_integral_constraint_on_device(golden, tmp_path):
+    """Window(icc=IntegralConstraint(...)).Window(bird) (reference window.py:393-406): W P - W_ic P as ONE device operator, Picc -= PSN;
+    against the oracle's restatement (PARITY UNPINNED for the ICC matrix itself, see oracle/icc.py), window_st on and off."""
+    from types import SimpleNamespace
+
+    from eftpipe_amd import pybird
+    from eftpipe_amd.icc import IntegralConstraint
+    from eftpipe_amd.window import Window
+    from icc_util import ICC_KW, make_icc_files
+    from oracle import icc as O
+
+    c = golden("caseC")
+    sn, ic, s, xi, s1 = make_icc_files(tmp_path)
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+    icc = IntegralConstraint(Pshot=1500.0, icc_configspace_SN_file=sn, icc_configspace_IC_file=ic, co=co, load=False, save=False, **ICC_KW)
+    for st in (True, False):
+        win = Window(window_configspace_file=WIN, co=co, load=False, save=False, icc=icc, window_st=st)
+        bird = SimpleNamespace(co=co, Picc=np.zeros((3, 50)), PctNNLOl=None, **{n: c["ap_" + n].copy() for n in NAMES})
+        win.Window(bird)
+        want = O.window_with_icc({n: c["ap_" + n] for n in NAMES} | {"Picc": np.zeros((3, 50))}, co.k, win.p, win.Waldk, icc.p, icc.Waldk, icc.PSN,
+                                 window_st=st)
+        for n in NAMES:
+            assert relerr(getattr(bird, n), want[n]) < TOL, (st, n)
+        assert np.array_equal(bird.Picc, -icc.PSN)
+        # the correction is visible: the plain window gives something else
+        plain = Window(window_configspace_file=WIN, co=co, load=False, save=False, window_st=st)
+        b2 = SimpleNamespace(co=co, Picc=np.zeros((3, 50)), PctNNLOl=None, **{n: c["ap_" + n].copy() for n in NAMES})
+        plain.Window(b2)
+        assert relerr(b2.Ploopl, bird.Ploopl) > 1e-6

@@ -373,3 +373,51 @@ def test_cfg3_host_tables_and_joint_rows(golden):
         rows = joint_gaussian_rows(U.bases(), fs, p, names, U.scales(g))
         V = np.einsum("tgr,tlrx->gtlx", rows, block).reshape(len(names) + 1, -1)[:, index]
         assert relerr(V[0][None], g["PNG"][None]) < 1e-13 and relerr(V[1:], g[tag + "_PG"]) < 1e-13, tag
+
+
+def test_integral_constraint_against_oracle(tmp_path):
+    """SURVEY 8(f) rank 4, PARITY UNPINNED (the reference's interp2d call no longer exists in SciPy, so it cannot produce fixtures):
+    eftpipe_amd.icc.IntegralConstraint -- PSN, the 2-D FFTLog matrix with the documented interp2d replacement, mask / dp weights, the
+    host convolution and the reference's cache format (.npz keys PSN, Wal + .json meta) -- against the oracle's line-by-line restatement
+    of reference icc.py:119-500 / fftlog2d.py:13-166."""
+    import json
+
+    from eftpipe_amd import pybird
+    from eftpipe_amd.icc import FFTLog2D, ICpannel_to_ndarray, IntegralConstraint, bessel_matrix
+    from eftpipe_amd.window import MetaInfoError
+    from icc_util import ICC_KW, make_icc_files
+    from oracle import icc as O
+
+    sn, ic, s, xi, s1 = make_icc_files(tmp_path)
+    co = pybird.Common(Nl=3, kmax=0.3)
+    cache = tmp_path / "icc_cache.npz"
+    obj = IntegralConstraint(Pshot=1500.0, icc_fourier_file=str(cache), icc_configspace_SN_file=sn, icc_configspace_IC_file=ic, co=co, load=True,
+                             save=True, **ICC_KW)
+    k, p = co.k, obj.p
+    psn = O.compute_psn(k, s, xi, 3, Nmax=ICC_KW["Nmax"])
+    assert relerr(obj.PSN, 1500.0 * psn) < 1e-12
+    panel, meta = ICpannel_to_ndarray(np.load(ic))
+    assert panel.shape == (3, 3, 36, 36) and np.array_equal(meta["s1"], s1)
+    Wal = O.compute_wal(k, p, s1, s1, panel, 3, 3, Nxmax=128, Nymax=128)
+    assert relerr(obj.Wal.reshape(9, -1), Wal.reshape(9, -1)) < 1e-11
+    assert relerr(obj.Waldk.reshape(9, -1), O.waldk(k, p, Wal).reshape(9, -1)) < 1e-11
+    rng = np.random.default_rng(5)
+    P = rng.normal(size=(3, 4, k.size)) * 1e3
+    assert relerr(obj.integrWindow(P).reshape(12, -1), O.integr_window(k, p, O.waldk(k, p, Wal), P).reshape(12, -1)) < 1e-9
+    # pieces
+    nu = -2.0 + 1.5j
+    assert np.isclose(bessel_matrix(nu, 2), O.bessel_matrix(nu, 2))
+    f2 = FFTLog2D(64, 64, 1e-3, 2500.0, 1e-3, 2500.0, -2.0, -2.0)
+    assert np.allclose(f2.window(0.5), O.taper2d(64, 64, 0.5))
+    # cache: written in the reference's format, loaded back bit-identically, meta mismatch refused
+    with np.load(cache) as z:
+        assert sorted(z.files) == ["PSN", "Wal"] and z["Wal"].shape == (3, 3, k.size, p.size)
+        assert relerr(z["PSN"], psn) < 1e-12  # stored WITHOUT the Pshot factor, as the reference does (icc.py:276-278)
+    with open(cache.with_suffix(".json")) as fh:
+        assert json.load(fh)["Nxmax"] == 128
+    again = IntegralConstraint(Pshot=2.0, icc_fourier_file=str(cache), co=co, **ICC_KW)
+    assert np.array_equal(again.Wal, obj.Wal) and relerr(again.PSN, 2.0 * psn) < 1e-12
+    with pytest.raises(MetaInfoError):
+        IntegralConstraint(Pshot=2.0, icc_fourier_file=str(cache), co=co, Nmax=512, Nxmax=128, Nymax=128)
+    with pytest.raises(ValueError):
+        IntegralConstraint(Pshot=1.0, co=co)

@@ -363,3 +363,18 @@ def test_cfg3_production_window_and_joint_likelihood(golden):
         assert np.isclose(logp, g[tag + "_logp"], rtol=1e-11) and np.isclose(fullchi2, g[tag + "_fullchi2"], rtol=1e-9), tag
         assert relerr(best[None], g[tag + "_best"][None]) < 1e-8, tag
         assert np.isclose(M.marginalized_logp(PG, PNG, g["data_vector"], g["invcov"], *flat), g[tag + "_logp_nojeffreys"], rtol=1e-11)
+
+
+def test_resum_nondefault_options(golden):
+    """Resum(LambdaIR=0.25, NFFT=128) and Resum.Ps(window=0.3) (reference pybird.py:1230-1300, 1409-1464): oracle == reference."""
+    from oracle import OracleConfig
+
+    g = golden("resumopt")
+    eng = OracleEngine(OracleConfig(Nl=3, kmA=0.7, krA=0.25, ndA=4.5e-5, with_resum=True, LambdaIR=float(g["LambdaIR"]), NFFT_resum=int(g["NFFT"]),
+                                    resum_window=float(g["window"])))
+    taps = {}
+    st = eng.evaluate(g["kin"], g["Pin"], float(g["f"]), taps=taps)
+    assert relerr(st["X"][None], g["X"][None]) < TOL and relerr(st["Y"][None], g["Y"][None]) < TOL
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(st[n], g["resum_" + n]) < TOL, n
+    assert relerr(taps["setpscfl"]["Ploopl"], g["setpscfl_Ploopl"]) < TOL and relerr(taps["setpscfl"]["Cloopl"], g["setpscfl_Cloopl"]) < TOL

@@ -44,9 +44,9 @@ def demangle(name):
     start = m.end()
     base = name[start:start + n]
     rest = name[start + n:]
-    t = re.match(r"I((?:Li\d+E)+)E", rest)
+    t = re.match(r"I((?:L[ib]\d+E)+)E", rest)
     if t:
-        base += "<" + ",".join(re.findall(r"Li(\d+)E", t.group(1))) + ">"
+        base += "<" + ",".join(re.findall(r"L[ib](\d+)E", t.group(1))) + ">"
     return base
 
 

@@ -700,10 +700,77 @@ def cfg3_fixture(ref):
     print("cfg3 written:", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+def cfg5_fixture(ref):
+    """BASELINE cfg 5 after the projection stages, from the REAL reference: the Nk = 2048 AP-stage templates of caseF through
+    Window (DR16 LRG and ELG windows, accboost 1) and Binning (kout = arange(0.025, 0.2, 0.01)), ELG also Chained.  The window precompute
+    at Nk = 2048 is the slow part (minutes, once); only the binned results and a few rows of the matrices are stored."""
+    pb = ref.pybird
+    g = dict(np.load(os.path.join(GOLD, "caseF.npz"), allow_pickle=True))
+    Nl, Nk = 3, 2048
+    co = make_common(pb, Nl, Nk)
+    kout = np.arange(0.025, 0.2, 0.01)
+    out = dict(kout=kout)
+    ddir = os.path.join(REFERENCE_ROOT, "data", "DR16_noric")
+    for t, chained in (("LRG", False), ("ELG", True)):
+        bird = ref.transformer.PlainBird(f=float(g["f"]), co=co, P11l=g["ap_P11l"].copy(), Ploopl=g["ap_Ploopl"].copy(), Pctl=g["ap_Pctl"].copy(),
+                                         Pstl=g["ap_Pstl"].copy(), Picc=np.zeros((Nl, Nk)), PctNNLOl=np.zeros((Nl, 3, Nk)))
+        win = ref.window.Window(window_configspace_file=os.path.join(ddir, f"win_NGC_{t}.txt"), co=co, load=False, save=False)
+        out["window_p"] = win.p
+        out[f"{t}_Waldk_k1000"], out[f"{t}_Waldk_k77"] = win.Waldk[:, :, 1000, :], win.Waldk[:, :, 77, :]
+        out[f"{t}_Waldk_sum_p"] = win.Waldk.sum(axis=-1)
+        win.Window(bird)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            out[f"{t}_window_{n}_k512"] = np.array(getattr(bird, n))[..., ::4]      # every 4th k of the convolved templates
+        bn = ref.binning.Binning(kout=kout, co=co)
+        out["keff"] = bn.keff
+        like = bn.transform(bird)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            out[f"{t}_binned_{n}"] = np.array(getattr(like, n), copy=True)
+        if chained:
+            like = ref.chained.Chained().transform(like)
+            for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+                out[f"{t}_chained_{n}"] = np.array(getattr(like, n), copy=True)
+        print("cfg5", t, "done")
+    np.savez_compressed(os.path.join(GOLD, "cfg5.npz"), **out)
+    print("cfg5 written:", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB raw")
+
+
+def resumopt_fixture(ref):
+    """Non-default resummation options through the REAL reference (pybird.py:1230-1300, 1316-1353, 1409-1464): Resum(LambdaIR=0.25,
+    NFFT=128) and Resum.Ps(bird, window=0.3), plus the helper methods IRFilters / setXpYp / makeQ and NonLinear.Coef on their own."""
+    pb = ref.pybird
+    Nl, z = 3, 0.7
+    cos = synth.cosmology(z=z)
+    out = dict(kin=cos["kin"], Pin=cos["Pin"], f=cos["f"], DA=cos["DA"], H=cos["H"], z=z, Nl=Nl, LambdaIR=0.25, NFFT=128, window=0.3)
+    co = make_common(pb, Nl, None)
+    out["k"] = co.k
+    nl = pb.NonLinear(load=False, save=False, co=co)
+    bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+    out["coef_window_none"] = nl.Coef(bird, window=None)
+    nl.PsCf(bird)
+    bird.setPsCfl()
+    rs = pb.Resum(LambdaIR=out["LambdaIR"], NFFT=out["NFFT"], co=co)
+    out["X"], out["Y"] = rs.IRFilters(bird)
+    out["XpYp"] = rs.setXpYp(bird)
+    rs.Ps(bird, window=out["window"])
+    out["Q"] = rs.Q.copy()
+    for n in ("P11l", "Pctl", "Ploopl"):
+        out["resum_" + n] = getattr(bird, n).copy()
+    # the helper pieces of setPsCfl on their own (pybird.py:758-866)
+    b2 = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+    nl.PsCf(b2)
+    b2.setPsCfl()
+    out["P22l"], out["P13l"] = b2.P22l.copy(), b2.P13l.copy()
+    out["C22w"], out["C13w"] = b2.C22.copy(), b2.C13.copy()
+    out["setpscfl_Ploopl"], out["setpscfl_Cloopl"], out["setpscfl_Pstl"] = b2.Ploopl.copy(), b2.Cloopl.copy(), b2.Pstl.copy()
+    np.savez_compressed(os.path.join(GOLD, "resumopt.npz"), **out)
+    print("resumopt written:", {k: np.shape(v) for k, v in out.items() if np.ndim(v) > 0})
+
+
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti", "wmat", "cfg3"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti", "wmat", "cfg3", "resumopt", "cfg5"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -725,6 +792,10 @@ def main():
             wmat_fixture(ref)
         elif name == "cfg3":
             cfg3_fixture(ref)
+        elif name == "resumopt":
+            resumopt_fixture(ref)
+        elif name == "cfg5":
+            cfg5_fixture(ref)
         else:
             run_case(ref, name, CASES[name])
 
