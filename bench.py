@@ -39,6 +39,7 @@ BS = [2.1401334, 0.77616816 / np.sqrt(2.0), 0.77003455, 0.77616816 / np.sqrt(2.0
 ES = (0.26033594, 0.0, -0.92895016)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
 NPOW, NS_DEV, NKLOW = 257, 80, 7
+DEFAULT_RESUM_WPS = 2   # engine default (eftbird.hip resum_wps); EFTB_RESUM_WPS overrides both
 
 
 def cpu_baseline(budget_s=20.0):
@@ -86,12 +87,13 @@ def executed_flops_per_launch(B):
     (one wave, 16 k x 1 s) `flops_per_wave_trip` = 2048 per v_mfma_f64_16x16x4 + 64 lanes x (2 per v_fma/v_fmac_f64, 1 per v_mul/v_add_f64),
     times waves (4 per 64 k of the resummed range, per cosmology) times 80 trips."""
     path = os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")
-    wps = int(os.environ.get("EFTB_RESUM_WPS", "2"))
+    wps = int(os.environ.get("EFTB_RESUM_WPS", str(DEFAULT_RESUM_WPS)))
+    name = "resum_mfma_lean_kernel" if wps >= 4 else "resum_mfma_kernel<%d,0>" % (3 if wps >= 3 else 2)  # the build the engine launches
     with open(path) as fh:
-        info = json.load(fh)["resum_mfma_kernel<%d,0>" % (3 if wps >= 3 else 2)]  # the variant the engine launches (waves per SIMD, no NNLO)
+        info = json.load(fh)[name]
     loop = max(info["loops"], key=lambda b: b["mfma"] + b["valu_f64"])
     waves = ((NK - NKLOW + 63) // 64) * 4 * B
-    per_trip = {"mfma": loop["mfma"], "valu_f64": loop["valu_f64"], "f64_ops": loop["f64_ops"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
+    per_trip = {"kernel_build": name, "mfma": loop["mfma"], "valu_f64": loop["valu_f64"], "f64_ops": loop["f64_ops"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
                 "vgprs": info.get("vgprs"), "scratch_bytes": info.get("scratch_bytes")}
     return float(loop["flops_per_wave_trip"]) * waves * NS_DEV, float(loop["mfma_flops_per_wave_trip"]) * waves * NS_DEV, per_trip
 

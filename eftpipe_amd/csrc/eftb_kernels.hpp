@@ -20,36 +20,21 @@ constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl)
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-// prep: P11 = spline(kin -> k) and the 129 independent FFTLog coefficients, both as pre-folded real
-// operators on Pin, plus the high-k power-law tail (reference pybird.py:694-695, fftlog.py:84-166).
-// One workgroup per cosmology.
+// First stage.  P11 = Sk Pin (cubic spline kin -> k), the 129 independent FFTLog coefficients = G Pin + E tail(slope, amp) and the IR
+// filters X, Y = B Pin + T tail'(slope', amp') are fixed real operators on the 200 input samples and on the power-law tails that continue
+// them (reference pybird.py:694-695, fftlog.py:84-166, pybird.py:1316-1353).  With the batch as the row dimension they are small GEMMs on
+// the matrix cores (synth_kernel), whose tables are read once per launch instead of once per cosmology.
+// prep_rows_kernel writes the operand rows: A1 = Pin (for P11), A2 = [Pin | tail] (coefficients; also transposed, for the
+// cosmology-contiguous copy the anti-diagonal pass reads), A3 = [Pin | tail'] (IR filters), zero padded to multiples of the GEMM's K chunk.
+// One workgroup per cosmology.  A1 / A3 may be null (only the other part is wanted).  Input guard: include/eftbird.h.
 // ------------------------------------------------------------------------------------------------
-// sum_j a[j * stride] * b[j] with eight independent chains (v_fma_f64 has a 32-cycle dependent latency; a single chain of a
-// few hundred terms is what made the small per-cosmology kernels latency-bound) and the strided loads issued in batches
-__device__ inline double dot8(const double* __restrict__ a, size_t stride, const double* b, int n) {
-    double acc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-    int j = 0;
-    for (; j + 8 <= n; j += 8) {
-        double av[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = a[(size_t)(j + u) * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = fma(av[u], b[j + u], acc[u]);
-    }
-    for (; j < n; ++j) acc[0] = fma(a[(size_t)j * stride], b[j], acc[0]);
-    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-}
-
-__global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, const double* __restrict__ Pin,
-                                                   const double* __restrict__ lnkin, const double* __restrict__ SkT,
-                                                   const double* __restrict__ GcT, const double* __restrict__ EcT,
-                                                   const double* __restrict__ lnxtail, double* __restrict__ P11,
-                                                   double* __restrict__ coef, double* __restrict__ coefT, int Bmax, int* __restrict__ status) {
+__global__ __launch_bounds__(256) void prep_rows_kernel(int Nkin, int ntail, int nxtail, int KP1, int KP2, int KP3, int Bmax,
+                                                        const double* __restrict__ Pin, const double* __restrict__ lnkin,
+                                                        const double* __restrict__ lnxtail, const double* __restrict__ lnxxtail,
+                                                        const double* __restrict__ wq2, double* __restrict__ A1, double* __restrict__ A2,
+                                                        double* __restrict__ A2T, double* __restrict__ A3, int* __restrict__ status) {
     extern __shared__ double sm[];
     double* pin = sm;
-    double* tail = sm + Nkin;
     const int w = blockIdx.x, tid = threadIdx.x;
     bool bad = false;
     for (int j = tid; j < Nkin; j += blockDim.x) {
@@ -58,22 +43,27 @@ __global__ __launch_bounds__(256) void prep_kernel(int Nk, int Nkin, int ntail, 
         bad = bad || !(fabs(v) <= 1.79769313486231570815e308) || (j >= Nkin - 2 && !(v > 0.0));  // non-finite anywhere, non-positive where the logarithm is taken
     }
     // input guard (reference fftlog.py:146-151 needs the last two samples positive): the flag sits in mapped host memory and is only written in the error case
-    if (bad && status && blockIdx.y == 0) atomicMax(status, w + 1);
+    if (bad && status) atomicMax(status, w + 1);
     __syncthreads();
-    // slope / amplitude from the last two samples (reference fftlog.py:146-151)
-    const double slope = (log(pin[Nkin - 1]) - log(pin[Nkin - 2])) / (lnkin[Nkin - 1] - lnkin[Nkin - 2]);
-    const double amp = pin[Nkin - 1] * exp(-slope * lnkin[Nkin - 1]);
-    for (int i = tid; i < ntail; i += blockDim.x) tail[i] = amp * exp(slope * lnxtail[i]);
-    __syncthreads();
-    // outputs of this cosmology: Nk values of P11 then 2 * 129 FFTLog coefficients, one per thread, blockIdx.y-th slab of 256
-    const int o = blockIdx.y * blockDim.x + tid;
-    if (o < Nk) {
-        P11[(size_t)w * Nk + o] = dot8(SkT + o, Nk, pin, Nkin);
-    } else if (o < Nk + 2 * NCH) {
-        const int idx = o - Nk, c = idx / NCH, n = idx % NCH;
-        const double v = dot8(GcT + (size_t)c * Nkin * NCH + n, NCH, pin, Nkin) + dot8(EcT + (size_t)c * ntail * NCH + n, NCH, tail, ntail);
-        coef[(size_t)w * 2 * NCH + idx] = v;
-        coefT[(size_t)idx * Bmax + w] = v;  // [2][129][Bmax]: cosmology-contiguous copy for antidiag_kernel
+    const double dln = lnkin[Nkin - 1] - lnkin[Nkin - 2];
+    if (A1) {
+        // slope / amplitude from the last two samples (reference fftlog.py:146-151)
+        const double slope = (log(pin[Nkin - 1]) - log(pin[Nkin - 2])) / dln;
+        const double amp = pin[Nkin - 1] * exp(-slope * lnkin[Nkin - 1]);
+        for (int j = tid; j < KP1; j += blockDim.x) A1[(size_t)w * KP1 + j] = j < Nkin ? pin[j] : 0.0;
+        for (int j = tid; j < KP2; j += blockDim.x) {
+            const double v = j < Nkin ? pin[j] : (j < Nkin + ntail ? amp * exp(slope * lnxtail[j - Nkin]) : 0.0);
+            A2[(size_t)w * KP2 + j] = v;
+            A2T[(size_t)j * Bmax + w] = v;
+        }
+    }
+    if (A3) {
+        // the IR filters act on q = Pin exp(-k^2 / Lambda^2) / k^2 (the weight is folded into the operator); the tail continues q's last two samples
+        const double q1 = pin[Nkin - 1] * wq2[1], q0 = pin[Nkin - 2] * wq2[0];
+        const double slope = (log(q1) - log(q0)) / dln;
+        const double amp = q1 * exp(-slope * lnkin[Nkin - 1]);
+        for (int j = tid; j < KP3; j += blockDim.x)
+            A3[(size_t)w * KP3 + j] = j < Nkin ? pin[j] : (j < Nkin + nxtail ? amp * exp(slope * lnxxtail[j - Nkin]) : 0.0);
     }
 }
 
@@ -98,7 +88,7 @@ constexpr int KLIN = 288;         // 1 + 2*128, likewise
 constexpr int SYN_KC = 48;        // K chunk of synth_kernel staged in LDS
 constexpr int BAS22 = 8, BASC = 32;  // padded basis rows per cosmology: 7 M22 matrices; Nl * (7 + 2) weighted ones
 
-// Lanes <-> cosmologies (coefficients transposed by prep_kernel: coefT[2][129][Bmax]); the matrix weights are wave-uniform
+// Lanes <-> cosmologies (transposed coefficients coefT[2][129][Bmax] come out of the first-stage GEMMs); the matrix weights are wave-uniform
 // (scalar loads), so the table is streamed once per 64 cosmologies and no cross-lane reduction is needed.
 template <int NC>
 __global__ __launch_bounds__(64) void antidiag_kernel(int B, int Bmax, const double* __restrict__ coefT,
@@ -229,45 +219,47 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int row0 = by * 32, x0 = bx * 64;
     const int rh = wave >> 1, xh = wave & 1;
-    // this thread's share of every chunk: NA elements of the A tile, NB of the Tab tile (fixed positions, pointers hoisted)
-    const double* pa[NA];
-    const double* pb[NB];
-    double ma[NA], mb[NB], va[NA], vb[NB];
-    int la[NA], lb[NB];
+    // this thread's share of every chunk: NA elements of the A tile, NB of the Tab tile at fixed positions.  Kept as 32-bit element
+    // offsets and bit masks (not pointers and multipliers): the kernel must fit beside two waves of the resummation kernel on a SIMD,
+    // i.e. in ~100 VGPRs, or its workgroups wait for a whole resummation wave to retire before they can start
+    int offa[NA];       // element offset of A[row][kk] from d.A (chunk 0)
+    unsigned amask = 0; // bit i: row of element i is inside the problem
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int e = tid + 256 * i, rr = e / SYN_KC, kk = e % SYN_KC, row = row0 + rr, rc = row < d.M ? row : d.M - 1;
-        pa[i] = d.A + (size_t)(rc / d.rpg) * d.a_group + (size_t)(rc % d.rpg) * d.K + kk;
-        ma[i] = row < d.M ? 1.0 : 0.0;
-        la[i] = rr * LDA + kk;
+        offa[i] = (int)((long long)(rc / d.rpg) * d.a_group + (long long)(rc % d.rpg) * d.K + kk);
+        amask |= (row < d.M ? 1u : 0u) << i;
     }
+    const int kb = tid >> 6, xx = tid & 63;  // Tab element i sits at row kb + 4 i of the chunk, column x0 + xx
+    const bool xlive = x0 + xx < d.X;
+    const double* tb0 = d.Tab + (size_t)kb * d.X + (xlive ? x0 + xx : d.X - 1);
+    const size_t tstep = (size_t)4 * d.X;
+    double va[NA], vb[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int e = tid + 256 * i, kk = e >> 6, xx = e & 63, x = x0 + xx;
-        pb[i] = d.Tab + (size_t)kk * d.X + (x < d.X ? x : d.X - 1);
-        mb[i] = x < d.X ? 1.0 : 0.0;
-        lb[i] = kk * LDB + xx;
-    }
+    for (int i = 0; i < NA; ++i) va[i] = d.A[offa[i]];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) va[i] = pa[i][0];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) vb[i] = pb[i][0];
+    for (int i = 0; i < NB; ++i) vb[i] = tb0[i * tstep];
     v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
     for (int k0 = 0; k0 < d.K; k0 += SYN_KC) {
         __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[la[i]] = va[i] * ma[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[lb[i]] = vb[i] * mb[i];
-        __syncthreads();
-        if (k0 + SYN_KC < d.K) {  // next chunk's global loads fly under this chunk's MFMAs
-#pragma unroll
-            for (int i = 0; i < NA; ++i) va[i] = pa[i][k0 + SYN_KC];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) vb[i] = pb[i][(size_t)(k0 + SYN_KC) * d.X];
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            As[(e / SYN_KC) * LDA + e % SYN_KC] = (amask >> i) & 1u ? va[i] : 0.0;
         }
 #pragma unroll
-        for (int t = 0; t < SYN_KC / 4; ++t) {
+        for (int i = 0; i < NB; ++i) Bs[(kb + 4 * i) * LDB + xx] = xlive ? vb[i] : 0.0;
+        __syncthreads();
+        if (k0 + SYN_KC < d.K) {  // next chunk's global loads fly under this chunk's MFMAs
+            const double* an = d.A + k0 + SYN_KC;
+            const double* tn = tb0 + (size_t)(k0 + SYN_KC) * d.X;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) va[i] = an[offa[i]];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) vb[i] = tn[i * tstep];
+        }
+#pragma unroll 4
+        for (int t = 0; t < SYN_KC / 4; ++t) {  // (four k-steps of operands in flight: a full unroll costs 40 more registers)
             const double a = As[(rh * 16 + r) * LDA + 4 * t + g];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -571,37 +563,11 @@ __global__ __launch_bounds__(128) void regroup_cf_kernel(int Nl, const double* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// IR filters X(s), Y(s) as folded operators on Pin + tail, and Q(f) by Horner
-// (reference pybird.py:1316-1353, 1367-1380).  One workgroup per cosmology.
+// Q(f) by Horner (reference pybird.py:1367-1380; the IR filters X(s), Y(s) come out of the first-stage GEMMs, see prep_rows_kernel).
+// One workgroup per cosmology; Q[a] = table[1 - a] (pybird.py:1374-1376), nq = Nl*Nl*Nn entries per table.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void irfilter_kernel(int Nkin, int nxtail, int nq, const double* __restrict__ Pin,
-                                                       const double* __restrict__ fgrow, const double* __restrict__ lnkin,
-                                                       const double* __restrict__ BXT, const double* __restrict__ BYT,
-                                                       const double* __restrict__ TXT, const double* __restrict__ TYT,
-                                                       const double* __restrict__ lnxxtail, const double* __restrict__ wq2,
-                                                       const double* __restrict__ Qpoly, double* __restrict__ XY,
-                                                       double* __restrict__ Q) {
-    extern __shared__ double sm[];
-    double* pin = sm;
-    double* tail = sm + Nkin;
-    const int w = blockIdx.x, tid = threadIdx.x;  // blockIdx.y: 0 -> X, Y filters, 1 -> Q(f) (both workgroup-uniform roles)
-    for (int j = tid; j < Nkin; j += blockDim.x) pin[j] = Pin[(size_t)w * Nkin + j];
-    __syncthreads();
-    const double q1 = pin[Nkin - 1] * wq2[1], q0 = pin[Nkin - 2] * wq2[0];
-    const double slope = (log(q1) - log(q0)) / (lnkin[Nkin - 1] - lnkin[Nkin - 2]);
-    const double amp = q1 * exp(-slope * lnkin[Nkin - 1]);
-    for (int i = tid; i < nxtail; i += blockDim.x) tail[i] = amp * exp(slope * lnxxtail[i]);
-    __syncthreads();
-    if (blockIdx.y == 0) {
-        for (int idx = tid; idx < 2 * NS; idx += blockDim.x) {
-            const int c = idx / NS, s = idx % NS;
-            const double* B = c ? BYT : BXT;
-            const double* Tt = c ? TYT : TXT;
-            XY[(size_t)w * 2 * NS + idx] = dot8(B + s, NS, pin, Nkin) + dot8(Tt + s, NS, tail, nxtail);
-        }
-        return;
-    }
-    // Q[a] = table[1 - a] (reference pybird.py:1374-1376); nq = Nl*Nl*Nn entries per table
+__global__ __launch_bounds__(256) void qf_kernel(int nq, const double* __restrict__ fgrow, const double* __restrict__ Qpoly, double* __restrict__ Q) {
+    const int w = blockIdx.x, tid = threadIdx.x;
     const double f = fgrow[w];
     for (int idx = tid; idx < 2 * nq; idx += blockDim.x) {
         const int a = idx / nq, rest = idx % nq;
@@ -815,7 +781,9 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
         for (int e = threadIdx.x; e < 38; e += blockDim.x) s_gi[e] = grp[2 * e];
         __syncthreads();
     }
-    for (int idx = threadIdx.x; idx < RS_ROWS * RS_NB; idx += blockDim.x) {
+    // blockIdx.y splits the work of one cosmology (gridDim.y = 1: all of it): part 0 also builds the A operand
+    const int part = blockIdx.y, nparts = gridDim.y;
+    for (int idx = threadIdx.x; idx < (part == 0 ? RS_ROWS * RS_NB : 0); idx += blockDim.x) {
         const int row = idx / RS_NB, r = idx % RS_NB, off = rows[row];
         double a0 = 0.0, a1 = 0.0;
         if (off >= 0)
@@ -825,7 +793,7 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
             }
         RSA[((size_t)w * RS_ROWS + row) * RS_NB + r] = a0 + a1;
     }
-    for (int idx = threadIdx.x; idx < NS * RS_REC; idx += blockDim.x) {
+    for (int idx = part * blockDim.x + threadIdx.x; idx < NS * RS_REC; idx += nparts * blockDim.x) {
         const int c = idx / NS, s = idx % NS;  // s fastest: coalesced reads of the s-major inputs
         double v = 0.0;
         if (c < 14 * NL) {
@@ -1280,7 +1248,7 @@ __device__ inline int knot_interval(const double* __restrict__ kk, int Nk, doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// AP as prefix sums over mu (ap_prefix_kernel) + interval moments by differences (ap_apply_kernel).
+// AP as prefix sums over mu (ap_prefix_kernel) + interval moments by differences (ap_weights_kernel).
 // With k' = kq (1 + rho_j), kq = k / qperp, rho_j = sqrt(1 + g mu_j^2) - 1, the offset inside knot interval i is
 //     t_j = k' - k_i = kq rho_j + delta,   delta = kq - k_i,
 // so the moments of the quadrature on the nodes [ja, jb) that fall into interval i,
@@ -1350,147 +1318,73 @@ __global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* _
     }
 }
 
-// ap_apply_kernel: workgroup = 64 k x 4 waves of one cosmology; wave <-> interval slot (s = wave, wave + 4, ...), so
-// the intervals that k'(mu) crosses are handled in parallel: slot s of a k is interval i = i_first + s dir, and its
-// node range [ja, jb) comes from the closed-form crossings of its two knots (the same function of (kq, knot) in both
-// neighbouring slots, so the ranges tile [0, nmu) exactly).  Knots and roots sit in LDS; the four waves' partial sums
-// are added through LDS in a fixed order.
-template <int NL, int NR, int RS>
-__global__ __launch_bounds__(256, 2) void ap_apply_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+// ap_direct_kernel: the stage in the reference's own form (pybird.py:1581-1621) -- per (k, row) the nmu nodes are walked in order, the
+// spline is evaluated at k'(mu_j) in the interval the comparison k_i <= k' < k_i+1 selects (end intervals extrapolate), weighted with
+// L_l'(mu'_j) and projected on (2l+1)/2 L_l(mu_j) with the trapezoid weights.  It is the FALLBACK of the two-kernel form below for tiles
+// whose distortion crosses more knot intervals than the fast path keeps (META flag), and the whole stage with EFTB_AP_FAST=0: small
+// (no LDS, few registers), so that its launch never waits for resources when every workgroup just reads its flag and leaves.
+// Workgroup = one wave = 64 k of one cosmology, the thread walks the template rows one after the other (a light launch: 1 024 waves at
+// Nk = 512, B = 128 -- the gate must not wait for resources beside the resummation kernel); rows >= nr (Pstl unless APst) are copied through.
+template <int NL>
+__global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int nr, const double* __restrict__ kk, const double* __restrict__ DAw,
                                                        const double* __restrict__ Hw, const double* __restrict__ fid,
-                                                       const double* __restrict__ mu, const double* __restrict__ PS,
-                                                       const double* __restrict__ ROOT, const double* __restrict__ T,
-                                                       const double* __restrict__ YS, double* __restrict__ Tout,
+                                                       const double* __restrict__ mu, const double* __restrict__ wmu,
+                                                       const double* __restrict__ legmu, const double* __restrict__ ROOT,
+                                                       const double* __restrict__ T, const double* __restrict__ YS, double* __restrict__ Tout,
                                                        const int4* __restrict__ META) {
-    constexpr int NS = NL * NL * 4;
-    constexpr int NRT = (NR + RS - 1) / RS;  // rows per lane: the NR rows are split over RS workgroups (blockIdx.z)
-    if (META && !META[(size_t)blockIdx.y * gridDim.x + blockIdx.x].w) return;  // fallback duty only: the tile went through ap_rows_kernel
-    constexpr int NACC = NL * NRT;
-    extern __shared__ double sm[];
-    double* s_k = sm;               // [Nk]
-    double* s_root = sm + Nk;       // [nmu]
-    double* red = sm + Nk + nmu;    // [4][NACC][64]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + lane, w = blockIdx.y, rbase = blockIdx.z * NRT;
-    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
-    for (int e = threadIdx.x; e < nmu; e += 256) s_root[e] = ROOT[(size_t)w * nmu + e];
-    __syncthreads();
-    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
-    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
-    const bool live = k < Nk;
-    const double kq = s_k[live ? k : Nk - 1] / qperp;
-    const double* ps = PS + (size_t)w * (nmu + 1) * NS;
-    const bool up = g > 0.0;  // k'(mu) rises or falls with mu
-    const int dir = up ? 1 : -1;
-    const double jscale = (nmu - 1) / mu[nmu - 1];  // node index per unit mu (uniform grid: only a first guess, see the fix-up)
-    double acc[NL][NRT];
+    const int kt = blockIdx.x, w = blockIdx.y;
+    if (META && !META[(size_t)w * gridDim.x + kt].w) return;  // fallback duty only: the tile went through ap_rows_kernel
+    const int k = kt * 64 + threadIdx.x;
+    if (k >= Nk) return;
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w], F = qpar / qperp;
+    const double kq = kk[k] / qperp, c = 2.0 / (qperp * qperp * qpar);
+    const double* root = ROOT + (size_t)w * nmu;
+    const int i_first = knot_interval(kk, Nk, kq * root[0]);
+    for (int r = 0; r < NROW; ++r) {
+        if (r >= nr) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int r = 0; r < NRT; ++r) acc[l][r] = 0.0;
-    // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling)
-    auto cross = [&](double kb) -> int {
-        const double rc = kb / kq, x = (rc * rc - 1.0) / g;  // mu^2 at the crossing
-        int j = nmu;
-        if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
-        j = max(0, min(j, nmu));
-        while (j > 0 && (up ? kq * s_root[j - 1] >= kb : kq * s_root[j - 1] < kb)) --j;
-        while (j < nmu && !(up ? kq * s_root[j] >= kb : kq * s_root[j] < kb)) ++j;
-        return j;
-    };
-    const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
-    const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
-    const int nslot = live ? (up ? i_last - i_first : i_first - i_last) + 1 : 0;
-    for (int s = wave; s < nslot; s += 4) {
-        const int i = i_first + s * dir;
-        const double klo = s_k[i], khi = s_k[i + 1];
-        const int ja = s == 0 ? 0 : cross(up ? klo : khi);
-        const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
-        if (jb <= ja) continue;
-        const double h = khi - klo, ih = 1.0 / h;
-        const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
-        const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
-        const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
-        const double* pa = ps + (size_t)ja * NS;
-        const double* pb = ps + (size_t)jb * NS;
-        const double* cw = YS + ((size_t)w * NL * NROW * Nk + i) * 2;
-        // memory round trips are what this kernel waits for (PMC: 75 % of the wave cycles): the prefix sums of all l' are
-        // fetched in one batch, and the spline data of l' + 1 is in flight while l' is being accumulated
-        double ms[NL][NL][4];
-        {
-            double4 a4[NL][NL], b4[NL][NL];
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp)
-#pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    b4[lp][l] = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
-                    a4[lp][l] = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
-                }
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp)
-#pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const double d0 = b4[lp][l].x - a4[lp][l].x, d1 = b4[lp][l].y - a4[lp][l].y;
-                    const double d2 = b4[lp][l].z - a4[lp][l].z, d3 = b4[lp][l].w - a4[lp][l].w;
-                    ms[lp][l][0] = d0;
-                    ms[lp][l][1] = fma(c10, d0, c11 * d1);
-                    ms[lp][l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
-                    ms[lp][l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
-                }
-        }
-        double2 ya[2][NRT], yb[2][NRT];
-        auto fetch = [&](int lp, int buf) {
-#pragma unroll
-            for (int r = 0; r < NRT; ++r) {
-                const double2* cp = reinterpret_cast<const double2*>(cw + ((size_t)lp * NROW + min(rbase + r, NR - 1)) * Nk * 2);
-                ya[buf][r] = cp[0];  // (y_i, s_i)
-                yb[buf][r] = cp[1];  // (y_i+1, s_i+1)
+            for (int l = 0; l < NL; ++l) {
+                const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
+                Tout[o] = T[o];
             }
-        };
-        fetch(0, 0);
+            continue;
+        }
+        const double2* ys = reinterpret_cast<const double2*>(YS) + ((size_t)w * NL * NROW + r) * Nk;
+        double acc[NL];
 #pragma unroll
-        for (int lp = 0; lp < NL; ++lp) {
-            if (lp + 1 < NL) fetch(lp + 1, (lp + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the arithmetic that consumes the previous buffer
+        for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+        int i = i_first;
+        for (int j = 0; j < nmu; ++j) {
+            const double rt = root[j], kp = kq * rt;
+            while (i < Nk - 2 && kk[i + 1] <= kp) ++i;
+            while (i > 0 && kk[i] > kp) --i;
+            const double klo = kk[i], h = kk[i + 1] - klo, ih = 1.0 / h, t = kp - klo;
+            const double m = mu[j], mp = m / (F * rt), x2 = mp * mp;
+            const double lpv[3] = {1.0, 0.5 * (3.0 * x2 - 1.0), (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125};
+            double P = 0.0;
 #pragma unroll
-            for (int r = 0; r < NRT; ++r) {
-                const double2 ca = ya[lp & 1][r], cb = yb[lp & 1][r];  // -> power form on [k_i, k_i+1]
-                const double sl = (cb.x - ca.x) * ih;
-                const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
-                const double c2 = (sl - ca.y) * ih - c3 * h;
-#pragma unroll
-                for (int l = 0; l < NL; ++l)
-                    acc[l][r] = fma(ms[lp][l][0], ca.x, fma(ms[lp][l][1], ca.y, fma(ms[lp][l][2], c2, fma(ms[lp][l][3], c3, acc[l][r]))));
+            for (int lp = 0; lp < NL; ++lp) {
+                const double2 ya = ys[(size_t)lp * NROW * Nk + i], yb = ys[(size_t)lp * NROW * Nk + i + 1];
+                const double sl = (yb.x - ya.x) * ih;
+                const double c3 = (ya.y + yb.y - 2.0 * sl) * ih * ih;
+                const double c2 = (sl - ya.y) * ih - c3 * h;
+                P = fma(fma(fma(fma(c3, t, c2), t, ya.y), t, ya.x), lpv[lp], P);
             }
-        }
-    }
-    // sum the four waves in a fixed order and write
+            const double wj = wmu[j] * P;
 #pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int r = 0; r < NRT; ++r) red[(wave * NACC + l * NRT + r) * 64 + lane] = acc[l][r];
-    __syncthreads();
-    const double c = 2.0 / (qperp * qperp * qpar);
-    for (int e = wave; e < NACC; e += 4) {
-        const int l = e / NRT, r = e % NRT;
-        const double v = (red[(0 * NACC + e) * 64 + lane] + red[(1 * NACC + e) * 64 + lane]) + (red[(2 * NACC + e) * 64 + lane] + red[(3 * NACC + e) * 64 + lane]);
-        if (live && rbase + r < NR) Tout[(((size_t)w * NL + l) * NROW + rbase + r) * Nk + k] = c * v;
-    }
-    constexpr int NCP = NROW - NR > 0 ? NROW - NR : 1;  // rows that APeffect leaves alone (Pstl unless APst)
-    if (live && NR < NROW && blockIdx.z == 0)
-        for (int e = wave; e < NCP * NL; e += 4) {
-            const int l = e / NCP, r = NR + e % NCP;
-            const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
-            Tout[o] = T[o];
+            for (int l = 0; l < NL; ++l) acc[l] = fma(wj, legmu[(size_t)l * nmu + j], acc[l]);
         }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) Tout[(((size_t)w * NL + l) * NROW + r) * Nk + k] = c * acc[l];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// AP, two-kernel form (the default path; ap_apply_kernel above stays as the fallback for distortions that cross more knot
+// AP, two-kernel form (the default path; ap_direct_kernel above is the fallback for distortions that cross more knot
 // intervals than the fast path keeps).  The stage is LINEAR in the spline data: for one cosmology and one output k
 //     out[l][row][k] = c sum_{l'} sum_{d} ( Wy[l'][l][d] y[l'][row][i0 + d] + Ws[l'][l][d] s[l'][row][i0 + d] ),
 // where (y, s) are the knot values / derivatives written by spline_kernel, i0 = i0(w, k) the lowest knot interval k'(mu) visits and
-// the knot weights follow from the interval moments of ap_apply_kernel by inserting the Hermite form of the cubic:
+// the knot weights follow from the interval moments M_i (header above ap_prefix_kernel) by inserting the Hermite form of the cubic:
 //     c0 = y_i, c1 = s_i, c2 = (3 sl - 2 s_i - s_i+1) / h, c3 = (s_i + s_i+1 - 2 sl) / h^2, sl = (y_i+1 - y_i) / h   =>
 //     left knot :  Wy += m0 - 3 m2 / h^2 + 2 m3 / h^3,   Ws += m1 - 2 m2 / h + m3 / h^2
 //     right knot:  Wy += 3 m2 / h^2 - 2 m3 / h^3,        Ws += - m2 / h + m3 / h^2            (m_p = M_i[l][l'][p]).
@@ -1500,7 +1394,7 @@ __global__ __launch_bounds__(256, 2) void ap_apply_kernel(int Nk, int nmu, const
 //   ap_weights_kernel  workgroup = 64 k x 4 waves of one cosmology; wave <-> a share of the (l', l) pairs, the thread walks its k's
 //                      intervals in mu order carrying the shared knot's contribution; writes W[w][tile][d][l][l'][{y,s}][64], i0[w][k] and
 //                      the tile's window (lowest knot, span, knots per k); tiles that need more than APW_DCAP knots per k or a window
-//                      of more than APW_WIN knots are flagged and left to ap_apply_kernel
+//                      of more than APW_WIN knots are flagged and left to ap_direct_kernel
 //   ap_rows_kernel     workgroup = (tile of 64 k, cosmology, chunk of NRC template rows); wave <-> output multipole l; the (y, s)
 //                      window of the chunk's rows (all l') sits in LDS, the weights of knot d are six coalesced loads per thread
 // ------------------------------------------------------------------------------------------------
@@ -1542,7 +1436,8 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     const bool up = g > 0.0;
     const int dir = up ? 1 : -1;
     const double jscale = (nmu - 1) / mu[nmu - 1];
-    auto cross = [&](double kb) -> int {  // first node past knot kb (as in ap_apply_kernel)
+    // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling): closed form + a one-step fix-up against the stored roots
+    auto cross = [&](double kb) -> int {
         const double rc = kb / kq, x = (rc * rc - 1.0) / g;
         int j = nmu;
         if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
@@ -1634,118 +1529,103 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     }
 }
 
-// Workgroup = (tile of 64 k, cosmology, chunk of NRC template rows) x NL multipoles x NSG row subgroups: wave (l, sg) owns output
-// multipole l of rows sg * NRC / NSG ... of the chunk.  Everything the inner loop needs is requested before the first wait: the tile's
-// window (one trip of 1 KB wave loads into LDS), the thread's lowest knot and the weights of the first APR_DP knots (registers); only
-// tiles with more knots per k than that go back to memory inside the loop (one knot ahead).
-constexpr int APR_DP = 4;
+// Workgroup = (tile of 64 k, cosmology) x NL waves, wave <-> output multipole l.  The template rows are walked in chunks of NRC: the
+// chunk's (y, s) window of all l' is staged in LDS (each byte of the spline data is read from HBM once, plus the window's halo), every
+// lane accumulates its NRC rows over the tile's knots, stores them, and the next chunk follows.  The knot weights of a tile belong to
+// this workgroup alone: they are re-read per chunk, from the cache.
 
-template <int NL, int NR, int NRC, int NSG>
-__global__ __launch_bounds__(64 * NL * NSG) void ap_rows_kernel(int Nk, const double* __restrict__ DAw, const double* __restrict__ Hw,
-                                                                const double* __restrict__ fid, const double* __restrict__ W,
-                                                                const int* __restrict__ I0, const int4* __restrict__ META,
-                                                                const double* __restrict__ T, const double* __restrict__ YS,
-                                                                double* __restrict__ Tout) {
-    constexpr int NP = NL * NL, RPT = NRC / NSG, NW = NL * NSG;  // pairs, rows per thread, waves
-    static_assert(NRC % NSG == 0, "row chunk must split evenly over the subgroups");
+template <int NL, int NRC>
+__global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int nr, const double* __restrict__ DAw, const double* __restrict__ Hw,
+                                                          const double* __restrict__ fid, const double* __restrict__ W,
+                                                          const int* __restrict__ I0, const int4* __restrict__ META,
+                                                          const double* __restrict__ T, const double* __restrict__ YS,
+                                                          double* __restrict__ Tout) {
+    constexpr int NP = NL * NL;
     __shared__ double2 win[NL * NRC * APW_WIN];  // (y, s) of series (l', row of the chunk) at knots jmin .. jmin + span
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l = wv % NL, sg = wv / NL;
-    const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, r0 = blockIdx.z * NRC, k = kt * 64 + lane;
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, k = kt * 64 + lane;
     const int i0 = I0[(size_t)w * KT * 64 + k];
     const int4 meta = META[(size_t)w * KT + kt];
-    if (meta.w) return;  // left to ap_apply_kernel
-    const int jmin = meta.x, D = meta.z;  // (meta.y, the span, is bounded by APW_WIN: flagged tiles never get here)
-    const int nrow = min(NRC, NR - r0);
-    // weights of the first knots: in flight together with the window
-    const double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + (size_t)l * NL * 128 + lane;
-    double wy[APR_DP][NL], ws[APR_DP][NL];
-#pragma unroll
-    for (int d = 0; d < APR_DP; ++d)
-#pragma unroll
-        for (int lp = 0; lp < NL; ++lp) {
-            const double* q = wt + (size_t)min(d, D - 1) * NP * 128 + lp * 128;
-            wy[d][lp] = q[0];
-            ws[d][lp] = q[64];
-        }
-    // stage the window: one series = span contiguous double2, read as two 1 KB wave loads; four series per wave
-    {
-        const double2* ys = reinterpret_cast<const double2*>(YS) + (size_t)w * NL * NROW * Nk;
-        const int nser = NL * nrow;
-        for (int e0 = wv * 4; e0 < nser; e0 += 4 * NW) {
-            double2 v[4][2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = min(e0 + u, nser - 1), lp = e / nrow, r = e - lp * nrow;
-                const double2* src = ys + ((size_t)lp * NROW + r0 + r) * Nk;
-                v[u][0] = src[min(jmin + lane, Nk - 1)];
-                v[u][1] = src[min(jmin + 64 + lane, Nk - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u;
-                if (e < nser) {
-                    const int lp = e / nrow, r = e - lp * nrow;
-                    double2* dst = win + (lp * NRC + r) * APW_WIN;
-                    dst[lane] = v[u][0];
-                    if (64 + lane < APW_WIN) dst[64 + lane] = v[u][1];
-                }
-            }
-        }
-    }
-    __syncthreads();
+    if (meta.w) return;  // left to ap_direct_kernel
+    const int jmin = meta.x, span = meta.y, D = meta.z;
     const bool live = k < Nk;
     const int o = max(i0 - jmin, 0);  // lanes past the grid (i0 = -1) carry zero weights
-    double acc[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = 0.0;
-    const double2* wrow = win + (size_t)(sg * RPT) * APW_WIN + o;
-    auto knot = [&](int d, const double* cy, const double* cs) {
-#pragma unroll
-        for (int r = 0; r < RPT; ++r)
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                const double2 v = wrow[(lp * NRC + r) * APW_WIN + d];
-                acc[r] = fma(cy[lp], v.x, fma(cs[lp], v.y, acc[r]));
-            }
-    };
-#pragma unroll
-    for (int d = 0; d < APR_DP; ++d)
-        if (d < D) knot(d, wy[d], ws[d]);  // D: workgroup-uniform
-    if (D > APR_DP) {
-        double cy[NL], cs[NL], ny[NL], ns[NL];
-#pragma unroll
-        for (int lp = 0; lp < NL; ++lp) {
-            ny[lp] = wt[(size_t)APR_DP * NP * 128 + lp * 128];
-            ns[lp] = wt[(size_t)APR_DP * NP * 128 + lp * 128 + 64];
-        }
-        for (int d = APR_DP; d < D; ++d) {
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                cy[lp] = ny[lp];
-                cs[lp] = ns[lp];
-            }
-            if (d + 1 < D) {
-                const double* wn = wt + (size_t)(d + 1) * NP * 128;
-#pragma unroll
-                for (int lp = 0; lp < NL; ++lp) {
-                    ny[lp] = wn[lp * 128];
-                    ns[lp] = wn[lp * 128 + 64];
-                }
-            }
-            knot(d, cy, cs);
-        }
-    }
-    if (!live) return;
+    const double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + (size_t)l * NL * 128 + lane;
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
     const double c = 2.0 / (qperp * qperp * qpar);
-    double* dst = Tout + (((size_t)w * NL + l) * NROW + r0 + sg * RPT) * Nk + k;
+    const double2* ys = reinterpret_cast<const double2*>(YS) + (size_t)w * NL * NROW * Nk;
+    const int j1 = jmin + lane, j2 = jmin + 64 + lane;
+    const bool two = 64 + lane < span;  // second load of a series only where the window reaches
+    for (int r0 = 0; r0 < nr; r0 += NRC) {
+        const int nrow = min(NRC, nr - r0);
+        __syncthreads();  // the previous chunk has been consumed
+        // wave l stages the series of l' = l: nrow rows, up to two 1 KB wave loads each, APR_SB rows in flight together
+        constexpr int APR_SB = 3;
+        for (int rb = 0; rb < nrow; rb += APR_SB) {
+            double2 v[APR_SB][2];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r)
-        if (sg * RPT + r < nrow) dst[(size_t)r * Nk] = c * acc[r];
-    if (NR < NROW && blockIdx.z == 0 && sg == 0) {  // rows that APeffect leaves alone (Pstl unless APst)
-        const size_t base = (((size_t)w * NL + l) * NROW + NR) * Nk + k;
+            for (int u = 0; u < APR_SB; ++u) {
+                const double2* src = ys + ((size_t)l * NROW + r0 + min(rb + u, nrow - 1)) * Nk;
+                v[u][0] = src[min(j1, Nk - 1)];
+                v[u][1] = two ? src[min(j2, Nk - 1)] : make_double2(0.0, 0.0);
+            }
 #pragma unroll
-        for (int r = 0; r < NROW - NR; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];
+            for (int u = 0; u < APR_SB; ++u)
+                if (rb + u < nrow) {
+                    double2* dst = win + (l * NRC + rb + u) * APW_WIN;
+                    dst[lane] = v[u][0];
+                    if (two) dst[64 + lane] = v[u][1];
+                }
+        }
+        __syncthreads();
+        double acc[NRC];
+#pragma unroll
+        for (int r = 0; r < NRC; ++r) acc[r] = 0.0;
+        const double2* wrow = win + o;
+        auto knot = [&](int d, const double* cy, const double* cs) {
+#pragma unroll
+            for (int r = 0; r < NRC; ++r)
+#pragma unroll
+                for (int lp = 0; lp < NL; ++lp) {
+                    const double2 v = wrow[(lp * NRC + r) * APW_WIN + d];
+                    acc[r] = fma(cy[lp], v.x, fma(cs[lp], v.y, acc[r]));
+                }
+        };
+        {  // the tile's knots, one ahead: the weights of knot d + 1 fly under the rows of knot d (re-read per chunk from the cache: they
+           // belong to this workgroup alone)
+            double cy[NL], cs[NL], ny[NL], ns[NL];
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                ny[lp] = wt[lp * 128];
+                ns[lp] = wt[lp * 128 + 64];
+            }
+            for (int d = 0; d < D; ++d) {
+#pragma unroll
+                for (int lp = 0; lp < NL; ++lp) {
+                    cy[lp] = ny[lp];
+                    cs[lp] = ns[lp];
+                }
+                if (d + 1 < D) {
+                    const double* wn = wt + (size_t)(d + 1) * NP * 128;
+#pragma unroll
+                    for (int lp = 0; lp < NL; ++lp) {
+                        ny[lp] = wn[lp * 128];
+                        ns[lp] = wn[lp * 128 + 64];
+                    }
+                }
+                knot(d, cy, cs);
+            }
+        }
+        if (live) {
+            double* dst = Tout + (((size_t)w * NL + l) * NROW + r0) * Nk + k;
+#pragma unroll
+            for (int r = 0; r < NRC; ++r)
+                if (r < nrow) dst[(size_t)r * Nk] = c * acc[r];
+        }
+    }
+    if (live) {  // rows that APeffect leaves alone (Pstl unless APst)
+        const size_t base = (((size_t)w * NL + l) * NROW) * Nk + k;
+        for (int r = nr; r < NROW; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];
     }
 }
 

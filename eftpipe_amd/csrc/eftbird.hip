@@ -58,11 +58,13 @@ struct eftb_engine {
     double *APW = nullptr, *APW2 = nullptr;
     int *API = nullptr, *API2 = nullptr;
     int4 *APM = nullptr, *APM2 = nullptr;
-    bool ap_fast = true;  // EFTB_AP_FAST=0: every tile through ap_apply_kernel (the pre-weights form, kept as the fallback)
-    int ap_chunk = 8;     // template rows per workgroup of ap_rows_kernel (EFTB_AP_CHUNK=6|8|12)
+    bool ap_fast = true;  // EFTB_AP_FAST=0: every tile through ap_direct_kernel (the reference's quadrature, otherwise the fallback)
+    int ap_chunk = 7;     // template rows per chunk of ap_rows_kernel (Nl = 3: EFTB_AP_CHUNK=7|8|12; Nl = 2: 8|12)
+    int gap_mode = 0;     // EFTB_GAP=1|2 (experiment, see launch_stages_impl)
     bool fuse_cf = true;  // EFTB_FUSE_CF=0: always through regroup_cf_kernel (A/B switch)
     int resum_wps = 2;    // waves per SIMD resum_mfma_kernel is built for: 2 = basis coefficients in registers (201 VGPRs); EFTB_RESUM_WPS=3 = basis
                           // coefficients in LDS, tile-by-tile consumption (166 VGPRs) -- measured 4 % slower: the kernel is bound by the DP pipe, not by latency
+    double *PA1 = nullptr, *PA2 = nullptr, *PA2T = nullptr, *PA3 = nullptr;  // operand rows of the first-stage GEMMs (prep_rows_kernel)
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
     double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
     double *A22 = nullptr, *A13 = nullptr;   // synthesis rows of the P22 basis [B][BAS22][KSYN] and of P13 [B][10][KLIN]
@@ -126,7 +128,6 @@ struct eftb_engine {
     int cur_set = 0, staged_B = 0;
     bool staged_plk_device = false;  // staged sets keep P_l in device memory (a communicator exists: RCCL sends from it) instead of mapped host memory
     bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
-    int ap_rowsplit = 3;  // template rows of one k are split over this many workgroups in ap_apply_kernel (EFTB_AP_ROWSPLIT=1|2|3)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
     int Nn = 0;
@@ -189,6 +190,8 @@ static int rccl_load() {
         if (_r != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(_r));   \
     } while (0)
 
+static inline size_t kpad(int n) { return (size_t)(n + SYN_KC - 1) / SYN_KC * SYN_KC; }  // K of a first-stage GEMM: padded to the chunk of synth_kernel
+
 static size_t need_table_bytes(const eftb_config& c, int id) {
     const size_t D = sizeof(double);
     const int Nn = 2 * c.NIR * c.Na;
@@ -196,9 +199,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_K: return D * c.Nk;
         case EFTB_T_S: return D * NS;
         case EFTB_T_LNKIN: return D * c.Nkin;
-        case EFTB_T_SKT: return D * c.Nkin * c.Nk;
-        case EFTB_T_GCT: return D * 2 * c.Nkin * NCH;
-        case EFTB_T_ECT: return D * 2 * c.ntail * NCH;
+        case EFTB_T_SKT: return D * kpad(c.Nkin) * c.Nk;
+        case EFTB_T_GCT: case EFTB_T_ECT: return D * kpad(c.Nkin + c.ntail) * 2 * NCH;
         case EFTB_T_LNXTAIL: return D * c.ntail;
         case EFTB_T_AD: return 2 * D * (size_t)(c.nbasis + (c.with_resum ? c.nbasis13 : 0)) * NPOW * AD_T;
         case EFTB_T_EXP22: return D * 28 * BAS22;
@@ -214,8 +216,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_L22: return D * c.Nl * 28;
         case EFTB_T_L13: return D * c.Nl * 10;
         case EFTB_T_GRP: return sizeof(int32_t) * 38 * 2;
-        case EFTB_T_BXT: case EFTB_T_BYT: return c.with_resum ? D * c.Nkin * NS : 0;
-        case EFTB_T_TXT: case EFTB_T_TYT: return c.with_resum ? D * c.nxtail * NS : 0;
+        case EFTB_T_BXT: return c.with_resum ? D * kpad(c.Nkin + c.nxtail) * 2 * NS : 0;
+        case EFTB_T_BYT: case EFTB_T_TXT: case EFTB_T_TYT: return 0;  // (folded into EFTB_T_BXT)
         case EFTB_T_LNXXTAIL: return c.with_resum ? D * c.nxtail : 0;
         case EFTB_T_WQLAST2: return c.with_resum ? D * 2 : 0;
         case EFTB_T_QPOLY: return c.with_resum ? D * 2 * c.Nl * c.Nl * Nn * 15 : 0;
@@ -228,7 +230,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
         case EFTB_T_LCTN: return c.with_nnlo ? D * c.Nl * 6 : 0;
         case EFTB_T_BAO: return c.optiresum && c.with_resum ? D * (2 * NS + 4) : 0;
-        case EFTB_T_GCT2: return c.dual_coef ? D * 2 * c.Nkin * NCH : 0;
+        case EFTB_T_GCT2: case EFTB_T_GCT2T: return c.dual_coef ? D * kpad(c.Nkin + c.ntail) * 2 * NCH : 0;
     }
     return 0;
 }
@@ -374,14 +376,29 @@ static int launch_pipeline_operator(eftb_engine* e, int B) {
     return 0;
 }
 
-static void launch_irfilter(eftb_engine* e, hipStream_t st, int B) {
+static void launch_prep_rows(eftb_engine* e, hipStream_t st, int B, bool first, bool ir) {
     const eftb_config& c = e->c;
-    double** b = e->buf;
-    const size_t lds = (size_t)(c.Nkin + c.nxtail) * sizeof(double);
-    hipLaunchKernelGGL(irfilter_kernel, dim3(B, 2), dim3(256), lds, st, c.Nkin, c.nxtail, c.Nl * c.Nl * e->Nn, b[EFTB_B_PIN], b[EFTB_B_F],
-                       tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_BXT), tb<double>(e, EFTB_T_BYT), tb<double>(e, EFTB_T_TXT),
-                       tb<double>(e, EFTB_T_TYT), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), tb<double>(e, EFTB_T_QPOLY),
-                       b[EFTB_B_XY], b[EFTB_B_Q]);
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(B), dim3(256), (size_t)c.Nkin * sizeof(double), st, c.Nkin, c.ntail, c.nxtail, (int)kpad(c.Nkin),
+                       (int)kpad(c.Nkin + c.ntail), (int)kpad(c.Nkin + c.nxtail), c.max_batch, e->buf[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
+                       tb<double>(e, EFTB_T_LNXTAIL), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), first ? e->PA1 : nullptr, e->PA2, e->PA2T,
+                       ir ? e->PA3 : nullptr, e->status);
+}
+
+static void queue_xy(eftb_engine* e, SynthBatch& sb, int B) {  // X(s), Y(s) [B][2][80] = [Pin | tail'] (BX BY ; TX TY)
+    const eftb_config& c = e->c;
+    queue_synth(sb, e->PA3, 0, 1, B, (int)kpad(c.Nkin + c.nxtail), tb<double>(e, EFTB_T_BXT), 2 * NS, e->buf[EFTB_B_XY], 0, nullptr, nullptr);
+}
+
+// Resum.IRFilters + Resum.makeQ: X, Y (operand rows + one GEMM, unless the first stage of this run already produced them) and Q(f)
+static void launch_irfilter(eftb_engine* e, hipStream_t st, int B, bool xy = true) {
+    const eftb_config& c = e->c;
+    if (xy) {
+        launch_prep_rows(e, st, B, false, true);
+        SynthBatch sb{};
+        queue_xy(e, sb, B);
+        launch_synth(st, sb);
+    }
+    hipLaunchKernelGGL(qf_kernel, dim3(B), dim3(256), 0, st, c.Nl * c.Nl * e->Nn, e->buf[EFTB_B_F], tb<double>(e, EFTB_T_QPOLY), e->buf[EFTB_B_Q]);
 }
 
 static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
@@ -473,6 +490,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     const bool ap_side = pre_side && e->ap_overlap && e->allow_back && (mask & EFTB_S_RESUM) && (mask & EFTB_S_AP) && (Nl == 3 || !e->generic_resum);
     if (!ap_side) join_back(e);
     const int bslot = e->back_step & 1;  // evBack[bslot] was recorded two runs ago
+    const bool xy_in_prep = (mask & EFTB_S_PREP) && (mask & EFTB_S_RESUM) && c.with_resum && !nnlo_pass;  // X, Y ride with the first-stage GEMMs
     // whole-pipeline runs regroup C22 / C13 into the resummation records directly (resum_prep_kernel): no regroup_cf_kernel, no Cloopl
     // buffer on the way (EFTB_B_CLOOPL then keeps what the last stand-alone REGROUP stage left there)
     const bool fuse_cf = (mask & EFTB_S_REGROUP) && (mask & EFTB_S_RESUM) && c.with_resum && (Nl == 3 || !e->generic_resum) && !c.optiresum && !c.with_nnlo &&
@@ -480,24 +498,27 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
-        if (side_ir) launch_irfilter(e, e->side, B);
+        if (side_ir) launch_irfilter(e, e->side, B, !xy_in_prep);
         if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
         if (side_ap) launch_ap_prefix(e, e->side, B);
         if (hipEventRecord(e->evJoinAP, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
     }
     bool joined = !side_ir, joined_ap = !side_ap;
     if (mask & EFTB_S_PREP) {
-        const size_t lds = (size_t)(c.Nkin + c.ntail) * sizeof(double);
         hipStream_t st0 = st;
         if (pre_side) {
             st = e->pre;
             if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            // EFTB_GAP=1 (experiment): the look-ahead only starts once the previous run's resummation kernel has finished, i.e. the
+            // latency-bound kernels of three streams overlap with each other in the gap between two resummations instead of beside one
+            if (e->gap_mode && e->back_pending && hipStreamWaitEvent(st, e->evResum, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             // the input-only kernels (IR filters / Q(f); AP prefix sums and knot weights) get their own low-priority stream beside the front
             // half: X, Y, Q are free since the previous run built its resummation operands (evInFree); the AP tables alternate between two
             // sets because the previous run's AP reads its own late (the set written here was last read two runs ago: evBack)
             if (side_ir || side_ap) {
                 if (hipStreamWaitEvent(e->side, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
-                if (side_ir) launch_irfilter(e, e->side, B);
+                if (e->gap_mode > 1 && e->back_pending && hipStreamWaitEvent(e->side, e->evResum, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+                if (side_ir) launch_irfilter(e, e->side, B, !xy_in_prep);
                 if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
                 if (side_ap) {
                     std::swap(e->APP, e->APP2);
@@ -511,13 +532,23 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
                 if (hipEventRecord(e->evJoinAP, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
             }
         }
-        hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
-                           tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT), tb<double>(e, EFTB_T_ECT), tb<double>(e, EFTB_T_LNXTAIL),
-                           b[EFTB_B_P11], b[EFTB_B_COEF], e->coefT, c.max_batch, e->status);
-        if (c.dual_coef)  // IRcutoff "loop" / "resum": a second coefficient set for the xi-space pieces (reference pybird.py:1151-1160)
-            hipLaunchKernelGGL(prep_kernel, dim3(B, (Nk + 2 * NCH + 255) / 256), dim3(256), lds, st, Nk, c.Nkin, c.ntail, b[EFTB_B_PIN],
-                               tb<double>(e, EFTB_T_LNKIN), tb<double>(e, EFTB_T_SKT), tb<double>(e, EFTB_T_GCT2), tb<double>(e, EFTB_T_ECT),
-                               tb<double>(e, EFTB_T_LNXTAIL), b[EFTB_B_P11], e->coef2, e->coefT2, c.max_batch, nullptr);
+        // operand rows, then every first-stage product in one launch on the matrix cores: P11, the FFTLog coefficients (and their
+        // cosmology-contiguous transpose for the anti-diagonal pass), the second coefficient set of IRcutoff "loop" / "resum" (reference
+        // pybird.py:1151-1160), and X(s), Y(s) when a resummation follows in this run
+        launch_prep_rows(e, st, B, true, xy_in_prep);
+        {
+            SynthBatch sb{};
+            const int KP1 = (int)kpad(c.Nkin), KP2 = (int)kpad(c.Nkin + c.ntail);
+            queue_synth(sb, e->PA1, 0, 1, B, KP1, tb<double>(e, EFTB_T_SKT), Nk, b[EFTB_B_P11], 0, nullptr, nullptr);
+            queue_synth(sb, e->PA2, 0, 1, B, KP2, tb<double>(e, EFTB_T_GCT), 2 * NCH, b[EFTB_B_COEF], 0, nullptr, nullptr);
+            queue_synth(sb, tb<double>(e, EFTB_T_ECT), KP2, 2 * NCH, 1, KP2, e->PA2T, c.max_batch, e->coefT, c.max_batch, nullptr, nullptr);
+            if (c.dual_coef) {
+                queue_synth(sb, e->PA2, 0, 1, B, KP2, tb<double>(e, EFTB_T_GCT2), 2 * NCH, e->coef2, 0, nullptr, nullptr);
+                queue_synth(sb, tb<double>(e, EFTB_T_GCT2T), KP2, 2 * NCH, 1, KP2, e->PA2T, c.max_batch, e->coefT2, c.max_batch, nullptr, nullptr);
+            }
+            if (xy_in_prep) queue_xy(e, sb, B);
+            launch_synth(st, sb);
+        }
         if (!pre_side) st = st0;
     }
     // with pre_side the whole front half (first stage, anti-diagonal sums, rows, syntheses, expansions: inputs -> P22, P13, C11, Cct, CC)
@@ -617,8 +648,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
 #define RP_ARGS e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS), tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], c11, cct, cloopl, e->RSA, e->RSC, \
                 fused_nnlo ? b[EFTB_B_CCTN] : nullptr, fuse_cf ? b[EFTB_B_CC] : nullptr, b[EFTB_B_F], tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), \
                 tb<int>(e, EFTB_T_GRP)
-            if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), dim3(B), dim3(256), 0, st, RP_ARGS);
-            else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), dim3(B), dim3(256), 0, st, RP_ARGS);
+            const dim3 rpgrid(B, fuse_cf ? 5 : 1);  // the fused regrouping is 38 conditional terms per record entry: spread over five workgroups
+            if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), rpgrid, dim3(256), 0, st, RP_ARGS);
+            else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), rpgrid, dim3(256), 0, st, RP_ARGS);
 #undef RP_ARGS
             // C11 / Cct / Cloopl now live in the per-s records: the next run's front half may overwrite its outputs (see the regrouping)
             if (full && (mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess)
@@ -667,7 +699,6 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         }
         // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
         const int nr = c.ap_stochastic && !nnlo_pass ? NROW : 21;
-        const int rs = e->ap_rowsplit;
         if (!side_ap && !nnlo_pass) launch_ap_prefix(e, st, B);
         if (!joined_ap) {
             if (hipStreamWaitEvent(st, e->evJoinAP, 0) != hipSuccess) return fail("eftb_run: stream join failed");
@@ -676,46 +707,24 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (e->ap_fast) {
             // banded product of the knot weights with the spline data; rows [nr, 24) are copied through
             const int kt = (Nk + 63) / 64;
-#define APR_ARGS Nk, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, b[EFTB_B_TEMPL], e->SD, e->Talt
-#define APR_LAUNCH(NLV, NRV, NRC, NSG) \
-    hipLaunchKernelGGL((ap_rows_kernel<NLV, NRV, NRC, NSG>), dim3(kt, B, (NRV + NRC - 1) / NRC), dim3(64 * NLV * NSG), 0, st, APR_ARGS)
-#define APR_PICK(NRC, NSG)                                  \
-    do {                                                    \
-        if (Nl == 3 && nr == 21) APR_LAUNCH(3, 21, NRC, NSG);    \
-        else if (Nl == 3) APR_LAUNCH(3, NROW, NRC, NSG);         \
-        else if (nr == 21) APR_LAUNCH(2, 21, NRC, NSG);          \
-        else APR_LAUNCH(2, NROW, NRC, NSG);                      \
-    } while (0)
-            if (e->ap_chunk == 6) APR_PICK(6, 2);
-            else if (e->ap_chunk == 12) APR_PICK(12, 2);
-            else if (e->ap_chunk == 81) APR_PICK(8, 1);
-            else if (e->ap_chunk == 84) APR_PICK(8, 4);
-            else APR_PICK(8, 2);
-#undef APR_PICK
-#undef APR_LAUNCH
+#define APR_ARGS Nk, nr, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, b[EFTB_B_TEMPL], e->SD, e->Talt
+            if (Nl == 3 && e->ap_chunk == 8) hipLaunchKernelGGL((ap_rows_kernel<3, 8>), dim3(kt, B), dim3(192), 0, st, APR_ARGS);
+            else if (Nl == 3 && e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<3, 12>), dim3(kt, B), dim3(192), 0, st, APR_ARGS);
+            else if (Nl == 3) hipLaunchKernelGGL((ap_rows_kernel<3, 7>), dim3(kt, B), dim3(192), 0, st, APR_ARGS);
+            else if (e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<2, 12>), dim3(kt, B), dim3(128), 0, st, APR_ARGS);
+            else hipLaunchKernelGGL((ap_rows_kernel<2, 8>), dim3(kt, B), dim3(128), 0, st, APR_ARGS);
 #undef APR_ARGS
         }
-        // the pre-weights form: every tile (EFTB_AP_FAST=0), or only the tiles the fast path flagged (strong distortions)
-        const int4* gate = e->ap_fast ? e->APM : nullptr;
-#define AP_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), \
-                e->APP, e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt, gate
-        const dim3 apgrid((Nk + 63) / 64, B, rs);
-        const size_t aplds = ((size_t)Nk + c.nmu + (size_t)4 * Nl * ((nr + rs - 1) / rs) * 64) * sizeof(double);
-#define AP_LAUNCH(NLV, NRV, RSV) hipLaunchKernelGGL((ap_apply_kernel<NLV, NRV, RSV>), apgrid, dim3(256), aplds, st, AP_ARGS)
-#define AP_PICK(RSV)                                 \
-    do {                                             \
-        if (Nl == 3 && nr == 21) AP_LAUNCH(3, 21, RSV);   \
-        else if (Nl == 3) AP_LAUNCH(3, NROW, RSV);        \
-        else if (nr == 21) AP_LAUNCH(2, 21, RSV);         \
-        else AP_LAUNCH(2, NROW, RSV);                     \
-    } while (0)
-        if (rs == 1) AP_PICK(1);
-        else if (rs == 2) AP_PICK(2);
-        else if (rs == 3) AP_PICK(3);
-        else AP_PICK(7);
-#undef AP_PICK
-#undef AP_LAUNCH
-#undef AP_ARGS
+        // the reference's own quadrature: every tile (EFTB_AP_FAST=0), or only the tiles the fast path flagged (strong distortions)
+        {
+            const int4* gate = e->ap_fast ? e->APM : nullptr;
+            const dim3 dgrid((Nk + 63) / 64, B);
+#define APD_ARGS Nk, c.nmu, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
+                 tb<double>(e, EFTB_T_LEGMU), e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt, gate
+            if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3>), dgrid, dim3(64), 0, st, APD_ARGS);
+            else hipLaunchKernelGGL((ap_direct_kernel<2>), dgrid, dim3(64), 0, st, APD_ARGS);
+#undef APD_ARGS
+        }
         std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
     }
     if (mask & EFTB_S_REGROUP) {
@@ -889,7 +898,6 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     e->Nn = 2 * c.NIR * c.Na;
     e->cur_nl = c.Nl;
     e->cur_nx = c.Nk;
-    if (const char* f = getenv("EFTB_AP_ROWSPLIT")) e->ap_rowsplit = std::min(7, std::max(1, atoi(f)));
     if (const char* f = getenv("EFTB_GRAPH")) e->use_graphs = atoi(f) != 0;
     if (const char* f = getenv("EFTB_GENERIC_RESUM")) e->generic_resum = atoi(f) != 0;
     if (const char* f = getenv("EFTB_PREP_OVERLAP")) e->prep_overlap = atoi(f) != 0;
@@ -934,6 +942,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
             return hipMemset(*p, 0, n * sizeof(double)) != hipSuccess ? 1 : 0;
         };
         int bad = zalloc(&e->coefT, 2 * NCH * B);
+        bad |= zalloc(&e->PA1, B * kpad(c.Nkin)) | zalloc(&e->PA2, B * kpad(c.Nkin + c.ntail)) | zalloc(&e->PA2T, B * kpad(c.Nkin + c.ntail));
+        if (c.with_resum) bad |= zalloc(&e->PA3, B * kpad(c.Nkin + c.nxtail));
         if (c.dual_coef) bad |= zalloc(&e->coef2, 2 * NCH * B) | zalloc(&e->coefT2, 2 * NCH * B);
         bad |= zalloc(reinterpret_cast<double**>(&e->SAD), 2 * (size_t)AD_CH * B * nc * NPOW);
         bad |= zalloc(&e->A22, B * BAS22 * KSYN) | zalloc(&e->A13, B * 10 * KLIN) | zalloc(&e->Y22, B * BAS22 * c.Nk);
@@ -958,6 +968,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AP_CHUNK")) e->ap_chunk = atoi(f);
     if (const char* f = getenv("EFTB_RESUM_WPS")) e->resum_wps = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_GAP")) e->gap_mode = atoi(f);
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 4 * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 4 * sizeof(int));
     HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
@@ -1016,10 +1027,6 @@ int eftb_finalize(eftb_engine* e) {
     }
     // opt in to the large dynamic LDS tiles
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#define AP_LDS(NLV, NRV, RSV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_apply_kernel<NLV, NRV, RSV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-    AP_LDS(3, 21, 1); AP_LDS(3, 21, 2); AP_LDS(3, 21, 3); AP_LDS(3, 21, 7); AP_LDS(3, NROW, 1); AP_LDS(3, NROW, 2); AP_LDS(3, NROW, 3); AP_LDS(3, NROW, 7);
-    AP_LDS(2, 21, 1); AP_LDS(2, 21, 2); AP_LDS(2, 21, 3); AP_LDS(2, 21, 7); AP_LDS(2, NROW, 1); AP_LDS(2, NROW, 2); AP_LDS(2, NROW, 3); AP_LDS(2, NROW, 7);
-#undef AP_LDS
     if (c.with_ap) {
         // (the kernel also holds a few static words: the dynamic part must leave room for them below the 160 KB of a CU)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
@@ -1203,7 +1210,7 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (int q = 0; q < 3; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);

@@ -62,9 +62,23 @@ class Engine:
         self._set("K", t["k"])
         self._set("S", t["s"])
         self._set("LNKIN", np.log(t["kin"]))
-        self._set("SKT", t["Sk"].T)
-        self._set("GCT", t["Gc"].transpose(0, 2, 1))
-        self._set("ECT", t["Ec"].transpose(0, 2, 1))
+        # first-stage operators as GEMM operands: K-major, zero padded to a multiple of 48 rows (include/eftbird.h)
+        kpad = lambda n: (n + 47) // 48 * 48
+        Nkin, ntail = t["kin"].size, t["lnx_tail"].size
+
+        def stack_gc(G):  # [2, 129, Nkin] (+ the tail operator Ec [2, 129, ntail]) -> [KP, 258]
+            out = np.zeros((kpad(Nkin + ntail), 2 * 129))
+            for c_ in range(2):
+                out[:Nkin, c_ * 129 : (c_ + 1) * 129] = G[c_].T
+                out[Nkin : Nkin + ntail, c_ * 129 : (c_ + 1) * 129] = t["Ec"][c_].T
+            return out
+
+        skt = np.zeros((kpad(Nkin), self.Nk))
+        skt[:Nkin] = t["Sk"].T
+        self._set("SKT", skt)
+        gct = stack_gc(t["Gc"])
+        self._set("GCT", gct)
+        self._set("ECT", gct.T)
         self._set("LNXTAIL", t["lnx_tail"])
         cplx = lambda z: np.stack([z.real, z.imag], axis=-1)  # complex -> (re, im) pairs (device double2)
         self._set("AD", cplx(t["ad"].transpose(1, 2, 0)))                      # [j'][t][matrix]: wave-uniform 144-byte records
@@ -82,7 +96,9 @@ class Engine:
         if "bao" in t:
             self._set("BAO", t["bao"])
         if "Gc2" in t:
-            self._set("GCT2", t["Gc2"].transpose(0, 2, 1))
+            gct2 = stack_gc(t["Gc2"])
+            self._set("GCT2", gct2)
+            self._set("GCT2T", gct2.T)
         if cfg.with_resum:
             expc = np.zeros((cfg.Nl * 38, 32))
             expc[:, : t["expand_c"].shape[1]] = t["expand_c"]
@@ -90,10 +106,11 @@ class Engine:
             self._set("MLJ", cplx(t["mlj"]))
             self._set("SYNS", t["syn_s"])
             self._set("LINS", t["lin_s"])
-            self._set("BXT", t["BX"].T)
-            self._set("BYT", t["BY"].T)
-            self._set("TXT", t["TX"].T)
-            self._set("TYT", t["TY"].T)
+            nxt = t["lnx_xtail"].size
+            bxt = np.zeros((kpad(Nkin + nxt), 2 * 80))   # X | Y = [Pin | tail'] . (BX BY ; TX TY)
+            bxt[:Nkin, :80], bxt[:Nkin, 80:] = t["BX"].T, t["BY"].T
+            bxt[Nkin : Nkin + nxt, :80], bxt[Nkin : Nkin + nxt, 80:] = t["TX"].T, t["TY"].T
+            self._set("BXT", bxt)
             self._set("LNXXTAIL", t["lnx_xtail"])
             self._set("WQLAST2", t["wq_last2"])
             self._set("QPOLY", t["Qpoly"])

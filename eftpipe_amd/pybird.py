@@ -582,7 +582,7 @@ class Resum(HasLogger):
 
 # ----------------------------------------------------------------------------- APeffect
 class APeffect(HasLogger):
-    """Alcock-Paczynski distortion (reference pybird.py:1467-1629) -- spline_kernel, ap_prefix_kernel, ap_apply_kernel."""
+    """Alcock-Paczynski distortion (reference pybird.py:1467-1629) -- spline_kernel, ap_prefix_kernel, ap_weights_kernel, ap_rows_kernel (ap_direct_kernel for extreme distortions)."""
 
     def __init__(self, Om_AP=None, z_AP=None, DA=None, H=None, rdrag_AP=None, h_AP=None, nbinsmu=200, accboost=1,
                  Nlmax=None, APst=False, co=common, name="pybird.apeffect", snapshot=False):

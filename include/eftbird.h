@@ -49,7 +49,13 @@ typedef struct eftb_config {
                               pybird.py:1151-1160  ("all" needs no switch: both operators are the cut one) */
 } eftb_config;
 
-/* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file). */
+/* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file).  The first-stage operators are stored as GEMM operands,
+ * K-major and zero padded to KP(n) = n rounded up to a multiple of 48 (the K chunk of the matrix-core kernel):
+ *   EFTB_T_SKT [KP(Nkin)][Nk]                   P11 = Pin . SKT                                        (pybird.py:694-695)
+ *   EFTB_T_GCT [KP(Nkin + ntail)][2 * 129]      FFTLog coefficients (re | im halves) = [Pin | tail] . GCT   (fftlog.py:84-166)
+ *   EFTB_T_ECT [2 * 129][KP(Nkin + ntail)]      = GCT transposed: the same product with the batch as the column dimension
+ *   EFTB_T_BXT [KP(Nkin + nxtail)][2 * 80]      IR filters X | Y = [Pin | tail'] . BXT                 (pybird.py:1316-1353)
+ * (EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT are unused ids kept for numbering.) */
 enum eftb_table {
     EFTB_T_K = 0, EFTB_T_S, EFTB_T_LNKIN, EFTB_T_SKT, EFTB_T_GCT, EFTB_T_ECT, EFTB_T_LNXTAIL,
     /* one-loop pieces in anti-diagonal form (tables.py antidiagonal_tables, synthesis_table) */
@@ -62,6 +68,7 @@ enum eftb_table {
     EFTB_T_BAO,       /* optiresum: a(s)[80], b(s)[80], then i_lo, i_hi, i_first, i_end as doubles: inside [i_first, i_end)
                          bao(s) = C(s) - a(s) C(s[i_lo]) - b(s) C(s[i_hi]), 0 elsewhere     Resum.extractBAO pybird.py:1382-1400 */
     EFTB_T_GCT2,      /* dual_coef: FFTLog operator of the xi-space coefficients (layout of EFTB_T_GCT) */
+    EFTB_T_GCT2T,     /* dual_coef: its transpose (layout of EFTB_T_ECT) */
     EFTB_T_COUNT
 };
 

@@ -473,3 +473,45 @@ def test_window_with_integral_constraint_on_device(golden, tmp_path):
         b2 = SimpleNamespace(co=co, Picc=np.zeros((3, 50)), PctNNLOl=None, **{n: c["ap_" + n].copy() for n in NAMES})
         plain.Window(b2)
         assert relerr(b2.Ploopl, bird.Ploopl) > 1e-6
+
+
+def test_cfg5_two_tracers_nk2048_against_reference(golden):
+    """BASELINE cfg 5 (Nk = 2048, IR-resummation + AP + window + binning, two tracers per point) through the batched engine: device window
+    precompute for the LRG and the ELG window, one folded operator per tracer (ELG chained, padded), eftb_set_tracers(2), against the
+    REFERENCE's binned / chained templates (tests/golden/cfg5.npz) -- replaces the self-comparison of the Nk = 2048 shape test."""
+    import cfg3_util as U
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+    from eftpipe_amd.window import window_matrix_device
+
+    g, F = golden("cfg5"), golden("caseF")
+    k, nb = F["k"], len(g["kout"])
+    Bm, _, _, _ = TB.binning_operator(k, g["kout"])
+    ops_host = []
+    for t, chained in (("LRG", False), ("ELG", True)):
+        tab = U.window_table(t + "_NGC")
+        Wal, p, Waldk, Wfold = window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+        assert relerr(Waldk[:, :, 1000, :], g[t + "_Waldk_k1000"]) < 1e-9 and relerr(Waldk.sum(axis=-1), g[t + "_Waldk_sum_p"]) < 1e-9
+        op = np.zeros((3, 3, nb, k.size))
+        o = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm, chained=chained)
+        op[: o.shape[0]] = o
+        ops_host.append(op)
+    eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(F["DA_AP"]), H_AP=float(F["H_AP"])), max_batch=4)
+    ops = [eng.add_operator(o) for o in ops_host]
+    eng.set_tracers(2, ops)
+    Pin = np.stack([F["Pin"], F["Pin"], 1.05 * F["Pin"], 1.05 * F["Pin"]])     # two likelihood points x two tracers
+    f, DA, H = float(F["f"]), float(F["DA"]), float(F["H"])
+    bias = np.stack([bias_row(f, list(F["bsA"]), None, tuple(F["es"]), kmA=0.7, krA=0.25, ndA=4.5e-5)] * 4)
+    templ, plk = eng.eval_batch(Pin, f, DA, H, bias=bias)
+    assert templ.shape == (4, 3, 24, nb)
+    rows24 = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
+    for i, (t, chained) in enumerate((("LRG", False), ("ELG", True))):
+        for n, sl in rows24.items():
+            want = g[f"{t}_{'chained' if chained else 'binned'}_{n}"]
+            assert relerr(templ[i][: want.shape[0], sl], want) < TOL, (t, n)
+        assert not np.allclose(templ[2 + i], templ[i])   # the second likelihood point (another P_lin) is its own evaluation
+    assert np.all(templ[1][2] == 0.0)                                               # padded multipole of the chained tracer
+    assert relerr(plk[0], np.einsum("r,lrx->lx", bias[0], templ[0])) < 1e-12
+    eng.close()

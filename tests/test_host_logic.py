@@ -421,3 +421,31 @@ def test_integral_constraint_against_oracle(tmp_path):
         IntegralConstraint(Pshot=2.0, icc_fourier_file=str(cache), co=co, Nmax=512, Nxmax=128, Nymax=128)
     with pytest.raises(ValueError):
         IntegralConstraint(Pshot=1.0, co=co)
+
+
+def test_cfg5_host_operators_nk2048(golden):
+    """BASELINE cfg 5 after the projection stages, host side: the window table builder + fold at Nk = 2048 and the folded
+    window -> binning [-> chained] operators against the reference's own Waldk rows, convolved templates and binned / chained results
+    (tests/golden/cfg5.npz: reference Window + Binning + Chained on the Nk = 2048 AP-stage templates of caseF, LRG and ELG windows)."""
+    import cfg3_util as U
+    from eftpipe_amd import tables as TB
+
+    g, F = golden("cfg5"), golden("caseF")
+    k = F["k"]
+    assert k.size == 2048
+    Bm, keff, _, _ = TB.binning_operator(k, g["kout"])
+    assert relerr(keff[None], g["keff"][None]) < 1e-13
+    for t, chained in (("LRG", False), ("ELG", True)):
+        tab = U.window_table(t + "_NGC")
+        Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3)
+        assert np.array_equal(p, g["window_p"])
+        Wfold, Waldk = TB.window_fold(k, Wal, p)
+        assert relerr(Waldk[:, :, 1000, :], g[t + "_Waldk_k1000"]) < 1e-9 and relerr(Waldk[:, :, 77, :], g[t + "_Waldk_k77"]) < 1e-9
+        assert relerr(Waldk.sum(axis=-1), g[t + "_Waldk_sum_p"]) < 1e-9
+        for n in U.NAMES:
+            conv = np.einsum("alxk,lnk->anx", Wfold, F["ap_" + n])
+            assert relerr(conv[..., ::4], g[f"{t}_window_{n}_k512"]) < 1e-9, (t, n)
+        op = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm, chained=chained)
+        for n in U.NAMES:
+            want = g[f"{t}_{'chained' if chained else 'binned'}_{n}"]
+            assert relerr(np.einsum("alxk,lnk->anx", op, F["ap_" + n]), want) < 1e-9, (t, n)
