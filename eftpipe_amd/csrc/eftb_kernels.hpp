@@ -18,6 +18,7 @@ constexpr int NCH = 129;     // independent complex coefficients
 constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl) + 12 (Ploopl) + 3 (Pstl)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
 // First stage.  P11 = Sk Pin (cubic spline kin -> k), the 129 independent FFTLog coefficients = G Pin + E tail(slope, amp) and the IR
@@ -885,12 +886,25 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
     double accN[3] = {0.0, 0.0, 0.0};  // NNLO: W CctNNLO[l']
     const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
     const double* ct = RSC + ((size_t)w * NS + s0) * RS_REC;  // wave-uniform record of the current s
-    double h[3];
-#pragma unroll
-    for (int v = 0; v < 3; ++v) h[v] = H[((size_t)v * NS + s0) * Nk + kc];
-    double z = k2 * ct[42], y = k2 * ct[43];
+    // H[v][s][k]: one wave-uniform base and 32-bit per-lane byte offsets (three 64-bit per-lane pointers would cost the registers that
+    // decide whether other kernels fit beside two of these waves on a SIMD)
+    const char* Hb = reinterpret_cast<const char*>(H);
+    const unsigned hrow = (unsigned)NS * (unsigned)Nk * 8u, hstep = (unsigned)Nk * 8u;
+    unsigned hoff = ((unsigned)s0 * (unsigned)Nk + (unsigned)kc) * 8u;
+    // carried from step to step: the products z H_v, y H_v of the current s (not H and z, y themselves: the next step's H is then the only
+    // other copy in flight) and the basis polynomials at z
+    double zh[3], yh[3];
     double b0, b1;
-    RS_POLY(b0, b1, z * (1.0 / RS_ZS));
+    {
+        const double z = k2 * ct[42], y = k2 * ct[43];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const double h = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
+            zh[v] = z * h;
+            yh[v] = y * h;
+        }
+        RS_POLY(b0, b1, z * (1.0 / RS_ZS));
+    }
     // keep the A operand in registers (hipcc would otherwise re-load it from memory every step)
 #pragma unroll
     for (int tau = 0; tau < RS_TILES; ++tau)
@@ -898,8 +912,9 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(aop[tau][t]));
     for (int s = s0; s < s1; ++s) {
         // memory first: this step's C columns (scalar loads, consumed after the MFMAs) and the next step's X, Y, H
-        const int sn = s + 1 < s1 ? s + 1 : s;
-        const double* ctn = RSC + ((size_t)w * NS + sn) * RS_REC;
+        const bool more = s + 1 < s1;
+        const double* ctn = more ? ct + RS_REC : ct;
+        hoff += more ? hstep : 0u;
         // (WPS >= 3: the third l' block of the record is requested only after the first tile has been consumed -- 42 doubles at once
         // overflow the scalar file and come back as v_writelane / v_readlane traffic)
         constexpr int NCV = RS_WPS >= 3 ? 28 : 42;
@@ -909,16 +924,10 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         const double xn = ctn[42], yn0 = ctn[43];
         double hn[3];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) hn[v] = H[((size_t)v * NS + sn) * Nk + kc];
+        for (int v = 0; v < 3; ++v) hn[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
         __builtin_amdgcn_sched_barrier(0);
         const double zn = k2 * xn, yn = k2 * yn0;
         double bn0, bn1;
-        double zh[3], yh[3];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            zh[v] = z * h[v];
-            yh[v] = y * h[v];
-        }
 #define RS_TILE(tau) \
     __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0), 0, 0, 0)
         // every lane accumulates both roles; the sums of the role it does not own are never read
@@ -982,15 +991,20 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
 #undef RS_USE34
         __builtin_amdgcn_sched_barrier(0);
         ct = ctn;
-        z = zn;
-        y = yn;
         b0 = bn0;
         b1 = bn1;
 #pragma unroll
-        for (int v = 0; v < 3; ++v) h[v] = hn[v];
+        for (int v = 0; v < 3; ++v) {
+            zh[v] = zn * hn[v];
+            yh[v] = yn * hn[v];
+        }
     }
     // (a, l) blocks -> output rows, mu weights applied to the s-sums.  The (a = 0, l = 1 | 2) blocks of tiles 3-4 are spread
     // over lane groups (one l' each): their l11-weighted terms are gathered into the jg = 0 lane of every k.
+    // (lane-group predicates are re-derived from an opaque copy of jg: kept alive through the loop they cost scalar pairs the records need)
+    int jgx = jg;
+    asm volatile("" : "+v"(jgx));
+#define jg jgx
     double o18[18], oA[3], o1[3], o2[3];
 #pragma unroll
     for (int i = 0; i < 6; ++i) o18[i] = lct[i] * accCt[0] + lct[6 + i] * accCt[1] + lct[12 + i] * accCt[2];
@@ -1004,7 +1018,11 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         o1[i] = t1 + __shfl(t1, n + 16) + __shfl(t1, n + 32);
         o2[i] = t2 + __shfl(t2, n + 16) + __shfl(t2, n + 48);
     }
-    if (!live) return;
+    {   // (the comparison is redone here: carried through the loop it is the one scalar pair too many -- a spill lane, i.e. one more VGPR)
+        int kx = k;
+        asm volatile("" : "+v"(kx));
+        if (kx >= Nk) return;
+    }
     if (nsplit == 1) {
         if (jg < 3) {
             double* dst = T + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
@@ -1047,12 +1065,14 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         }
     }
 }
+#undef jg
 
 // The same scheme for Nl = 2 (NIR = 8, Na = 2): the polynomials have degree 7, so the monomials of t = z / RS_ZS are the basis
 // (V8 = identity); the 8 (a, l, l') blocks x 4 slots are 32 rows = two row tiles: tile tau <-> l' = tau, lane group jg <-> (a, l) =
 // (1, 0), (1, 1), (0, 0), (0, 1); slots 0 -> (v = l', half 0), 1, 2 -> (v = slot - 1, half 1), 3 -> empty.  Four MFMAs per step, every
 // output row owned by one lane group, no cross-lane traffic.
-__global__ __launch_bounds__(256, 2) void resum_mfma2_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
+__global__ __launch_bounds__(256, 2)
+void resum_mfma2_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
                                                              const double* __restrict__ H, const double* __restrict__ V8,
                                                              const double* __restrict__ RSA, const double* __restrict__ RSC,
                                                              const double* __restrict__ l11, const double* __restrict__ lct,
@@ -1904,6 +1924,24 @@ __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(int iters, double* si
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) sink[0] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming-read calibration for the FETCH_SIZE counter: every lane reads W consecutive doubles per trip (W = 1: the 8 B/lane pattern of
+// the template kernels here; W = 2: the 16 B/lane pattern MI355X_MICROARCH.md calibrated), a known byte count per launch.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void stream_read_kernel(const double* __restrict__ src, size_t n, double* sink) {
+    double s = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * W;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i + W <= n; i += stride) {
+        if (W == 1) s += __builtin_nontemporal_load(src + i);
+        else {
+            const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(src + i));
+            s += v[0] + v[1];
+        }
+    }
     if (s == 12345.678) sink[0] = s;
 }
 

@@ -52,6 +52,18 @@ struct eftb_engine {
     // scratch
     double *SD = nullptr, *Talt = nullptr, *part = nullptr;
     double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][80][8], per-s records [B][NS][48]
+    double *RSA2 = nullptr, *RSC2 = nullptr;  // second operand set: the look-ahead builds run i+1's operands while run i's resummation reads its own
+    hipEvent_t evRsDone[2] = {nullptr, nullptr};  // the resummation that read operand set [slot] has finished
+    unsigned rs_step = 0;
+    bool prep_ahead = true;  // EFTB_PREP_AHEAD=0: regrouping and operand build stay on the main stream in front of the resummation
+    // duration of the dominant kernel inside pipelined steps (EFTB_O_TIME_DOMINANT): HIP events on the stream it is launched on
+    static constexpr int NTIMER = 8;
+    hipEvent_t evT0[NTIMER] = {}, evT1[NTIMER] = {};
+    bool timer_busy[NTIMER] = {};
+    unsigned timer_next = 0;
+    int time_dominant = 0;
+    double timer_ms = 0.0;
+    long long timer_n = 0;
     double *APP = nullptr, *APR = nullptr, *APP2 = nullptr, *APR2 = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     // AP fast path (ap_weights_kernel / ap_rows_kernel): knot weights [B][tiles][APW_DCAP][Nl][Nl][2][64], lowest knot per k [B][tiles * 64],
     // window per tile [B][tiles]; second set for the look-ahead of overlapped runs (swapped together with APP / APR)
@@ -60,7 +72,6 @@ struct eftb_engine {
     int4 *APM = nullptr, *APM2 = nullptr;
     bool ap_fast = true;  // EFTB_AP_FAST=0: every tile through ap_direct_kernel (the reference's quadrature, otherwise the fallback)
     int ap_chunk = 7;     // template rows per chunk of ap_rows_kernel (Nl = 3: EFTB_AP_CHUNK=7|8|12; Nl = 2: 8|12)
-    int gap_mode = 0;     // EFTB_GAP=1|2 (experiment, see launch_stages_impl)
     bool fuse_cf = true;  // EFTB_FUSE_CF=0: always through regroup_cf_kernel (A/B switch)
     int resum_wps = 2;    // waves per SIMD resum_mfma_kernel is built for: 2 = basis coefficients in registers (201 VGPRs); EFTB_RESUM_WPS=3 = basis
                           // coefficients in LDS, tile-by-tile consumption (166 VGPRs) -- measured 4 % slower: the kernel is bound by the DP pipe, not by latency
@@ -468,6 +479,20 @@ static int validate_inputs(const eftb_config& c, const char* who, int B, const d
     return 0;
 }
 
+// adds the finished event pairs of the dominant-kernel timer to the running sum (wait = true: after a synchronisation, all of them)
+static void collect_timer(eftb_engine* e, int slot, bool wait) {
+    for (int t = 0; t < eftb_engine::NTIMER; ++t) {
+        if ((slot >= 0 && t != slot) || !e->timer_busy[t]) continue;
+        if (wait) (void)hipEventSynchronize(e->evT1[t]);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->evT0[t], e->evT1[t]) == hipSuccess) {
+            e->timer_ms += ms;
+            ++e->timer_n;
+            e->timer_busy[t] = false;
+        }
+    }
+}
+
 static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     const eftb_config& c = e->c;
     hipStream_t st = e->stream;
@@ -509,15 +534,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (pre_side) {
             st = e->pre;
             if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
-            // EFTB_GAP=1 (experiment): the look-ahead only starts once the previous run's resummation kernel has finished, i.e. the
-            // latency-bound kernels of three streams overlap with each other in the gap between two resummations instead of beside one
-            if (e->gap_mode && e->back_pending && hipStreamWaitEvent(st, e->evResum, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             // the input-only kernels (IR filters / Q(f); AP prefix sums and knot weights) get their own low-priority stream beside the front
             // half: X, Y, Q are free since the previous run built its resummation operands (evInFree); the AP tables alternate between two
             // sets because the previous run's AP reads its own late (the set written here was last read two runs ago: evBack)
             if (side_ir || side_ap) {
                 if (hipStreamWaitEvent(e->side, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
-                if (e->gap_mode > 1 && e->back_pending && hipStreamWaitEvent(e->side, e->evResum, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
                 if (side_ir) launch_irfilter(e, e->side, B, !xy_in_prep);
                 if (hipEventRecord(e->evJoin, e->side) != hipSuccess) return fail("eftb_run: stream join failed");
                 if (side_ap) {
@@ -597,7 +618,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
                                e->YCF, c22 ? tb<double>(e, EFTB_T_EXPC) : nullptr, b[EFTB_B_CC]);
         }
     }
-    if (pre_side) {
+    // three-stream runs keep the regrouping and the operand build of the resummation on the look-ahead stream as well: the main stream
+    // then carries nothing but the resummation kernels, back to back
+    const bool ahead = ap_side && e->prep_ahead && e->RSA2;
+    if (pre_side && !ahead) {
         if (hipEventRecord(e->evPrep, st) != hipSuccess || hipStreamWaitEvent(st_main, e->evPrep, 0) != hipSuccess) return fail("eftb_run: stream join failed");
         st = st_main;
     }
@@ -649,12 +673,29 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
                 fused_nnlo ? b[EFTB_B_CCTN] : nullptr, fuse_cf ? b[EFTB_B_CC] : nullptr, b[EFTB_B_F], tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), \
                 tb<int>(e, EFTB_T_GRP)
             const dim3 rpgrid(B, fuse_cf ? 5 : 1);  // the fused regrouping is 38 conditional terms per record entry: spread over five workgroups
+            const int rslot = e->rs_step & 1;
+            if (ahead) {  // the operand set written here was last read by the resummation two runs ago
+                std::swap(e->RSA, e->RSA2);
+                std::swap(e->RSC, e->RSC2);
+                if (hipStreamWaitEvent(st, e->evRsDone[rslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            }
             if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), rpgrid, dim3(256), 0, st, RP_ARGS);
             else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), rpgrid, dim3(256), 0, st, RP_ARGS);
 #undef RP_ARGS
             // C11 / Cct / Cloopl now live in the per-s records: the next run's front half may overwrite its outputs (see the regrouping)
             if (full && (mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess)
                 return fail("eftb_run: event record failed");
+            if (ahead) {
+                if (hipEventRecord(e->evPrep, st) != hipSuccess || hipStreamWaitEvent(st_main, e->evPrep, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+                st = st_main;
+            }
+            int tslot = -1;
+            if (e->time_dominant && full && e->evT0[0]) {
+                tslot = (int)(e->timer_next++ % eftb_engine::NTIMER);
+                collect_timer(e, tslot, false);
+                if (!e->timer_busy[tslot] && hipEventRecord(e->evT0[tslot], st) != hipSuccess) return fail("eftb_run: event record failed");
+                if (e->timer_busy[tslot]) tslot = -1;  // its previous pair has not finished: skip this sample
+            }
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
@@ -671,6 +712,14 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
 #undef RM_ARGS
             if (nsplit > 1)
                 hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nsplit, e->part, b[EFTB_B_TEMPL]);
+            if (tslot >= 0) {
+                if (hipEventRecord(e->evT1[tslot], st) != hipSuccess) return fail("eftb_run: event record failed");
+                e->timer_busy[tslot] = true;
+            }
+            if (ahead) {
+                if (hipEventRecord(e->evRsDone[rslot], st) != hipSuccess) return fail("eftb_run: event record failed");
+                ++e->rs_step;
+            }
         } else {
             const int kblocks = (Nk + 255) / 256;
             // waves = kblocks*4 x (2*Nl) x (B*Nl*nsplit): split the s sum further only for small batches
@@ -901,11 +950,20 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_GRAPH")) e->use_graphs = atoi(f) != 0;
     if (const char* f = getenv("EFTB_GENERIC_RESUM")) e->generic_resum = atoi(f) != 0;
     if (const char* f = getenv("EFTB_PREP_OVERLAP")) e->prep_overlap = atoi(f) != 0;
-    int prio_lo = 0, prio_hi = 0;  // the main stream carries the critical path (resummation, AP): it gets the high priority, the
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // look-ahead stream the low one, so its kernels fill gaps instead of competing
-    HIPCHK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi));
-    HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_lo));
+    if (const char* f = getenv("EFTB_PREP_AHEAD")) e->prep_ahead = atoi(f) != 0;
+    // Stream priorities.  With the regrouping and the operand build on the look-ahead stream, the look-ahead chain (a dozen latency-bound
+    // kernels in series) is the critical path of a pipelined step and the resummation kernel the throughput work beside it: the chain gets
+    // the high priority, the main stream the low one (measured at batch 128, evaluations/s: 266-269 k; all normal 265 k; main high and
+    // look-ahead low, the round-1 assignment, 240 k; raising the wave priority of the small kernels with s_setprio lost 10 %).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    auto prio_of = [&](const char* name, int dflt) {  // EFTB_*_PRIO = 1 low, 0 normal, -1 high
+        const char* f = getenv(name);
+        return !f ? dflt : (atoi(f) > 0 ? prio_lo : (atoi(f) < 0 ? prio_hi : 0));
+    };
+    HIPCHK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_of("EFTB_MAIN_PRIO", prio_lo)));
+    HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_of("EFTB_SIDE_PRIO", 0)));
+    HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_of("EFTB_PRE_PRIO", prio_hi)));
     HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
     if (const char* f = getenv("EFTB_AP_OVERLAP")) e->ap_overlap = atoi(f) != 0;
     {
@@ -921,6 +979,11 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipEventCreateWithFlags(&e->evFork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evJoinAP, hipEventDisableTiming));
+    for (hipEvent_t& ev : e->evRsDone) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (int t = 0; t < eftb_engine::NTIMER; ++t) {
+        HIPCHK(hipEventCreate(&e->evT0[t]));
+        HIPCHK(hipEventCreate(&e->evT1[t]));
+    }
     HIPCHK(hipEventCreate(&e->ev0));
     HIPCHK(hipEventCreate(&e->ev1));
     for (int id = 0; id < EFTB_B_COUNT; ++id) {
@@ -968,7 +1031,6 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AP_CHUNK")) e->ap_chunk = atoi(f);
     if (const char* f = getenv("EFTB_RESUM_WPS")) e->resum_wps = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
-    if (const char* f = getenv("EFTB_GAP")) e->gap_mode = atoi(f);
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 4 * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 4 * sizeof(int));
     HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
@@ -1023,6 +1085,8 @@ int eftb_finalize(eftb_engine* e) {
         {
             HIPCHK(hipMalloc(&e->RSA, (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double)));
             HIPCHK(hipMalloc(&e->RSC, (size_t)c.max_batch * NS * RS_REC * sizeof(double)));
+            HIPCHK(hipMalloc(&e->RSA2, (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double)));
+            HIPCHK(hipMalloc(&e->RSC2, (size_t)c.max_batch * NS * RS_REC * sizeof(double)));
         }
     }
     // opt in to the large dynamic LDS tiles
@@ -1138,8 +1202,22 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_JEFFREYS: e->jeffreys = value ? 1 : 0; return 0;
         case EFTB_O_GRAPH: e->use_graphs = value != 0; return 0;
         case EFTB_O_CHECK_FINITE: e->check_finite = value != 0; return 0;
+        case EFTB_O_TIME_DOMINANT: e->time_dominant = value != 0; return 0;
     }
     return fail("eftb_set_option: unknown option %d", option);
+}
+
+int eftb_dominant_time(eftb_engine* e, double* ms_sum, long long* launches, int reset) {
+    if (!e || !ms_sum || !launches) return fail("eftb_dominant_time: null argument");
+    HIPCHK(hipSetDevice(e->c.device));
+    collect_timer(e, -1, true);
+    *ms_sum = e->timer_ms;
+    *launches = e->timer_n;
+    if (reset) {
+        e->timer_ms = 0.0;
+        e->timer_n = 0;
+    }
+    return 0;
 }
 
 int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov, int nG, const double* mu,
@@ -1210,7 +1288,7 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->RSA2, e->RSC2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (int q = 0; q < 3; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
@@ -1220,7 +1298,11 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1], e->evRsDone[0], e->evRsDone[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (int t = 0; t < eftb_engine::NTIMER; ++t) {
+        if (e->evT0[t]) (void)hipEventDestroy(e->evT0[t]);
+        if (e->evT1[t]) (void)hipEventDestroy(e->evT1[t]);
+    }
     if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->back) (void)hipStreamDestroy(e->back);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
@@ -1646,6 +1728,37 @@ int eftb_mfma_f64_peak(int device, double* tflops) {
     *tflops = flops / (ms * 1e-3) / 1e12;
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+    (void)hipFree(sink);
+    return 0;
+}
+
+int eftb_stream_read_probe(int device, size_t bytes, int bytes_per_lane, double* gbps) {
+    if (bytes_per_lane != 8 && bytes_per_lane != 16) return fail("eftb_stream_read_probe: bytes_per_lane must be 8 or 16");
+    if (bytes < 4096 || bytes > ((size_t)64 << 30)) return fail("eftb_stream_read_probe: bytes out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("eftb_stream_read_probe: no HIP device visible");
+    HIPCHK(hipSetDevice(device));
+    const size_t n = bytes / sizeof(double) / 2 * 2;
+    double *src = nullptr, *sink = nullptr;
+    HIPCHK(hipMalloc(&src, n * sizeof(double)));
+    HIPCHK(hipMalloc(&sink, sizeof(double)));
+    HIPCHK(hipMemset(src, 0, n * sizeof(double)));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {  // the second launch is the timed one
+        HIPCHK(hipEventRecord(a, 0));
+        if (bytes_per_lane == 8) hipLaunchKernelGGL(stream_read_kernel<1>, dim3(4096), dim3(256), 0, 0, src, n, sink);
+        else hipLaunchKernelGGL(stream_read_kernel<2>, dim3(4096), dim3(256), 0, 0, src, n, sink);
+        HIPCHK(hipEventRecord(b, 0));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+    }
+    if (gbps) *gbps = (double)n * sizeof(double) / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(src);
     (void)hipFree(sink);
     return 0;
 }

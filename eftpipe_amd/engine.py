@@ -138,6 +138,16 @@ class Engine:
         """The REDUCE stage flags non-finite P_l(k); the next synchronising call raises, naming the cosmology (off by default)."""
         L.check(self.lib.eftb_set_option(self._h, 3, int(bool(flag))))
 
+    def time_dominant(self, flag):
+        """Bracket every resummation launch with HIP events on its own stream (measurement only; see dominant_time)."""
+        L.check(self.lib.eftb_set_option(self._h, 4, int(bool(flag))))
+
+    def dominant_time(self, reset=True):
+        """(sum of the bracketed durations [ms], launches) since the last reset; waits for launches in flight."""
+        ms, n = C.c_double(), C.c_longlong()
+        L.check(self.lib.eftb_dominant_time(self._h, C.byref(ms), C.byref(n), int(bool(reset))))
+        return ms.value, n.value
+
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
 

@@ -137,10 +137,15 @@ enum eftb_option {
     EFTB_O_JEFFREYS = 1,      /* marginalized_logp(jeffreys=True): drop ln det(F2 / 2 pi)   marginal.py:118-121 */
     EFTB_O_GRAPH = 2,         /* replay whole-pipeline runs (stage masks starting at PREP) from captured HIP graphs: one host call per
                                  step; for busy hosts (no reference counterpart; off by default, also EFTB_GRAPH=1) */
-    EFTB_O_CHECK_FINITE = 3   /* the REDUCE stage flags non-finite P_l(k): the next synchronising call (eftb_sync, eftb_get, eftb_eval_*,
+    EFTB_O_CHECK_FINITE = 3,  /* the REDUCE stage flags non-finite P_l(k): the next synchronising call (eftb_sync, eftb_get, eftb_eval_*,
                                  eftb_fetch_*) then returns non-zero naming the cosmology (off by default) */
+    EFTB_O_TIME_DOMINANT = 4  /* bracket every launch of the resummation kernel with HIP events on the stream it runs on (measurement
+                                 only: bench.py's roofline; read with eftb_dominant_time) */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
+/* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for
+ * the launches still in flight. */
+int  eftb_dominant_time(eftb_engine* e, double* ms_sum, long long* launches, int reset);
 
 /* Likelihood of the EFTB_S_LOGP stage.  Replaces, for a batch of walkers on the device,
  * EFTLike.PNG / PG (likelihood.py:483-549: flatten the multipoles over the masked k bins) and
@@ -270,6 +275,10 @@ int  eftb_window_precompute(int device, int Na, int Nl, int Nk, int nx, int Np, 
 
 /* Measured FP64 MFMA issue rate (v_mfma_f64_16x16x4_f64), TFLOP/s, for the roofline denominator. */
 int  eftb_mfma_f64_peak(int device, double* tflops);
+
+/* Counter calibration: one kernel that streams `bytes` of device memory once with 8 or 16 bytes per lane (two launches; the second is
+ * timed).  Run under `rocprofv3 --pmc FETCH_SIZE` it tells how the counter tallies each access width (tools/fetch_calib.py). */
+int  eftb_stream_read_probe(int device, size_t bytes, int bytes_per_lane, double* gbps);
 
 const char* eftb_last_error(void);
 const char* eftb_version(void);

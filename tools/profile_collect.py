@@ -45,6 +45,20 @@ for f in ("pmc_fetch_counter_collection.csv", "pmc_write_counter_collection.csv"
 avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per.items() if k.startswith("eftb::")}
 json.dump(avg, open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
 
+# FETCH_SIZE calibration (tools/fetch_calib.py: 1 GiB streamed once per launch at 8 and 16 bytes per lane)
+calib = {}
+try:
+    rows = collections.defaultdict(list)
+    for r in csv.DictReader(open(find("calib_counter_collection.csv"))):
+        if "stream_read_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+            rows[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in rows.items():
+        calib[k] = {"bytes_streamed": 1 << 30, "FETCH_SIZE_KB": v, "bytes_over_counter": [(1 << 30) / (x * 1024.0) for x in v]}
+    json.dump(calib, open(os.path.join(dst, f"{tag}_fetch_calibration.json"), "w"), indent=1, sort_keys=True)
+    print("calibration", json.dumps(calib))
+except SystemExit:
+    print("no calibration pass found")
+
 bench = json.load(open(os.path.join(src, "bench.json")))
 stats = {short(r["Name"]): r for r in csv.DictReader(open(find("stats_kernel_stats.csv")))}
 dom = next(k for k in avg if k.startswith("eftb::resum_mfma_kernel"))

@@ -24,4 +24,7 @@ pmc pmc_write WRITE_SIZE
 pmc pmc_sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE
 pmc pmc_l2hit TCC_HIT_sum
 pmc pmc_l2miss TCC_MISS_sum
+# FETCH_SIZE calibration on a known byte count at 8 and 16 bytes per lane
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o calib -- python3 tools/fetch_calib.py > $OUT/calib.out 2> $OUT/calib.err
+echo "calib done"
 ls $OUT
