@@ -92,7 +92,7 @@ def executed_flops_per_launch(B):
     with open(path) as fh:
         info = json.load(fh)[name]
     loop = max(info["loops"], key=lambda b: b["mfma"] + b["valu_f64"])
-    waves = ((NK - NKLOW + 63) // 64) * 4 * B
+    waves = ((NK - (NKLOW & ~15) + 63) // 64) * 4 * B  # k tiles start at a multiple of 16
     per_trip = {"kernel_build": name, "mfma": loop["mfma"], "valu_f64": loop["valu_f64"], "f64_ops": loop["f64_ops"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
                 "vgprs": info.get("vgprs"), "scratch_bytes": info.get("scratch_bytes")}
     return float(loop["flops_per_wave_trip"]) * waves * NS_DEV, float(loop["mfma_flops_per_wave_trip"]) * waves * NS_DEV, per_trip

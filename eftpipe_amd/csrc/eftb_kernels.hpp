@@ -837,13 +837,25 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
                                                             const double* __restrict__ RSA, const double* __restrict__ RSC,
                                                             const double* __restrict__ l11, const double* __restrict__ lct,
                                                             double* __restrict__ T, double* __restrict__ part, int nsplit,
-                                                            const double* __restrict__ lctn, double* __restrict__ TN) {
+                                                            const double* __restrict__ lctn, double* __restrict__ TN, int nkb, int nB) {
     constexpr int NL = 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jg = lane >> 4, n = lane & 15;
-    const int k = Nklow + (blockIdx.x * 4 + wave) * 16 + n, w = blockIdx.y, split = blockIdx.z;
-    const bool live = k < Nk;
-    const int kc = live ? k : Nk - 1;
+    // Workgroup -> (k block, cosmology).  The k tiles start at a multiple of 16 (the 128-byte template segments of a wave are then whole
+    // cache lines; lanes below Nklow idle), and the nkb workgroups of one cosmology sit on ONE XCD (consecutive workgroup ids go round the
+    // eight XCDs): its 30 KB of per-s records and its A operand then pass through one L2 instead of eight.
+    int kb, w;
+    if ((nB & 7) == 0) {
+        const int slot = blockIdx.x >> 3;
+        kb = slot % nkb;
+        w = (blockIdx.x & 7) + 8 * (slot / nkb);
+    } else {
+        kb = blockIdx.x % nkb;
+        w = blockIdx.x / nkb;
+    }
+    const int k = (Nklow & ~15) + (kb * 4 + wave) * 16 + n, split = blockIdx.z;
+    const bool live = k < Nk && k >= Nklow;
+    const int kc = k < Nklow ? Nklow : (k < Nk ? k : Nk - 1);
     const double k2 = kk[kc] * kk[kc];
     // B operand: this lane evaluates basis polynomials jg and jg + 4 at its point; A operand: rows (16 tau + n), columns jg + 4 t
     __shared__ double s_vb[RS_WPS >= 3 ? RS_NB * 16 : 1];
@@ -1021,7 +1033,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
     {   // (the comparison is redone here: carried through the loop it is the one scalar pair too many -- a spill lane, i.e. one more VGPR)
         int kx = k;
         asm volatile("" : "+v"(kx));
-        if (kx >= Nk) return;
+        if (kx >= Nk || kx < Nklow) return;
     }
     if (nsplit == 1) {
         if (jg < 3) {

@@ -702,12 +702,13 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
             const int schunk = (NS + nsplit - 1) / nsplit;
 #define RM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), \
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
+            const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
             if (kblocks > 0 && Nl == 3 && fused_nnlo)
-                hipLaunchKernelGGL((resum_mfma_kernel<2, true>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN]);
+                hipLaunchKernelGGL((resum_mfma_kernel<2, true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb, B);
             else if (kblocks > 0 && Nl == 3 && e->resum_wps >= 3)
-                hipLaunchKernelGGL((resum_mfma_kernel<3, false>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr);
+                hipLaunchKernelGGL((resum_mfma_kernel<3, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb, B);
             else if (kblocks > 0 && Nl == 3)
-                hipLaunchKernelGGL((resum_mfma_kernel<2, false>), dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr);
+                hipLaunchKernelGGL((resum_mfma_kernel<2, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb, B);
             else if (kblocks > 0) hipLaunchKernelGGL(resum_mfma2_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
 #undef RM_ARGS
             if (nsplit > 1)

@@ -36,13 +36,30 @@ def short(name):
 for n in ("bench.json", "bench_under_rocprof.json"):
     shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 shutil.copy(find("stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+import subprocess
+tl = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), find("stats_kernel_trace.csv"), "9"], capture_output=True, text=True).stdout
+open(os.path.join(dst, f"{tag}_overlap_timeline.txt"), "w").write(
+    "One steady-state step of the pipelined loop (rocprofv3 --kernel-trace of bench.py; q = HSA queue: main / side / look-ahead / back / copy).\n" + tl)
 
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in ("pmc_fetch_counter_collection.csv", "pmc_write_counter_collection.csv", "pmc_sq_counter_collection.csv",
           "pmc_l2hit_counter_collection.csv", "pmc_l2miss_counter_collection.csv"):
-    for r in csv.DictReader(open(find(f))):
+    rows_f = list(csv.DictReader(open(find(f))))
+    # the command also launches every kernel at batch 1-2 (drop-in latency probe, parity check): keep the launches of the bench batch, i.e. the
+    # largest grid seen per kernel
+    gmax = collections.defaultdict(int)
+    for r in rows_f:
+        gmax[r["Kernel_Name"]] = max(gmax[r["Kernel_Name"]], int(r["Grid_Size"]))
+    for r in rows_f:
+        if int(r["Grid_Size"]) != gmax[r["Kernel_Name"]]:
+            continue
         per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            per[short(r["Kernel_Name"])]["duration_ns_under_pmc"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per.items() if k.startswith("eftb::")}
+for k, d in per.items():
+    if k in avg:
+        avg[k]["launches_counted"] = max(len(v) for v in d.values())
 json.dump(avg, open(os.path.join(dst, f"{tag}_pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
 
 # FETCH_SIZE calibration (tools/fetch_calib.py: 1 GiB streamed once per launch at 8 and 16 bytes per lane)
@@ -69,17 +86,39 @@ out = {
     "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
     "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
     "note": "(2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
-            "128-B requests of wide streams as 64 B). "
+            "128-B requests of wide streams as 64 B) -- calibrated here for this kernel's own 8-byte-per-lane reads as well: "
+            f"{tag}_fetch_calibration.json, 1 GiB streamed at 8 and at 16 bytes per lane both read bytes / (FETCH_SIZE*1024) = 2.000. "
             f"Algorithmic bytes per launch: H table 3*80*{NK}*8 = {3 * 80 * NK * 8 / 1e6:.1f} MB (L2-resident, re-read per cosmology) + per-s records "
             f"{B * 80 * 48 * 8 / 1e6:.1f} MB + template read-modify-write 2*{B}*63*{NK}*8 = {2 * B * 63 * NK * 8 / 1e6:.0f} MB.",
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
     "kernel_cycles_est": c["GRBM_GUI_ACTIVE"] / 8.0,
     "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
-    "effective_clock_GHz": c["GRBM_GUI_ACTIVE"] / 8.0 / float(stats[dom]["AverageNs"]),
+    "effective_clock_GHz": c["GRBM_GUI_ACTIVE"] / 8.0 / c["duration_ns_under_pmc"],
+    "duration_us_under_pmc": c["duration_ns_under_pmc"] / 1e3,
     "L2_hit": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
     "rocprof_avg_us": float(stats[dom]["AverageNs"]) / 1e3,
     "bench_hip_event_us": bench["roofline"]["ms_per_launch"] * 1e3,
+    "bench_hip_event_alone_us": bench["roofline"].get("ms_per_launch_alone", 0.0) * 1e3,
 }
+# the rocprof average mixes the pipelined launches of the timed region (other kernels beside them) with the stand-alone launches of the
+# per-stage timings that follow: split the kernel trace by whether a kernel of another queue ran during the launch
+try:
+    tr = list(csv.DictReader(open(find("stats_kernel_trace.csv"))))
+    ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], short(r["Kernel_Name"])) for r in tr]
+    gy = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): int(r["Grid_Size_Y"]) for r in tr}  # grid y = batch: bench-batch launches only
+    beside, alone = [], []
+    for s0, e0, q0, n0 in ev:
+        if not n0.startswith("eftb::resum_mfma_kernel") or gy[(s0, e0)] != B:
+            continue
+        shared = sum(max(0, min(e0, e1) - max(s0, s1)) for s1, e1, q1, n1 in ev if q1 != q0 and e1 > s0 and s1 < e0)
+        (beside if shared > 0.2 * (e0 - s0) else alone).append((e0 - s0) / 1e3)
+    out["rocprof_avg_us_pipelined_launches"] = sum(beside) / len(beside) if beside else None
+    out["rocprof_avg_us_standalone_launches"] = sum(alone) / len(alone) if alone else None
+    out["rocprof_launches_pipelined_standalone"] = [len(beside), len(alone)]
+    out["rocprof_split_note"] = ("kernel trace of the same command; 'pipelined' = a kernel of another queue ran during more than 20 % of the launch "
+                                 "(compare with bench_hip_event_us), 'standalone' = the rest (compare with bench_hip_event_alone_us)")
+except SystemExit:
+    pass
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_dominant.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print("evaluations/s", bench["value"], "ms/step", bench["ms_per_step"], "stage_ms", bench["roofline"]["stage_ms"])

@@ -9,9 +9,9 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done"
 # one derived counter per pass where the hardware cannot collect them together (FETCH_SIZE + WRITE_SIZE is refused)
 pmc() {  # name, counters...
