@@ -20,6 +20,21 @@ constexpr int NROW = 24;     // template rows per multipole: 3 (P11l) + 6 (Pctl)
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// Flat workgroup id -> (tile, group) such that the `ntile` tiles of one group (the k tiles of one cosmology / of one share of the series) run
+// on ONE XCD: consecutive workgroup ids go round the eight XCDs, each with its own L2, so with the plain (tile fastest) order every k tile of
+// a cosmology sits on a different XCD and whatever the tiles share (halo windows, per-cosmology tables) is fetched from HBM once per tile.
+__device__ __forceinline__ void xcd_decode(int ntile, int& tile, int& group) {
+    const int flat = blockIdx.x, ng = gridDim.x / ntile;
+    if ((ng & 7) == 0) {
+        const int slot = flat >> 3;
+        tile = slot % ntile;
+        group = (flat & 7) + 8 * (slot / ntile);
+    } else {
+        tile = flat % ntile;
+        group = flat / ntile;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // First stage.  P11 = Sk Pin (cubic spline kin -> k), the 129 independent FFTLog coefficients = G Pin + E tail(slope, amp) and the IR
 // filters X, Y = B Pin + T tail'(slope', amp') are fixed real operators on the 200 input samples and on the power-law tails that continue
@@ -837,7 +852,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
                                                             const double* __restrict__ RSA, const double* __restrict__ RSC,
                                                             const double* __restrict__ l11, const double* __restrict__ lct,
                                                             double* __restrict__ T, double* __restrict__ part, int nsplit,
-                                                            const double* __restrict__ lctn, double* __restrict__ TN, int nkb, int nB) {
+                                                            const double* __restrict__ lctn, double* __restrict__ TN, int nkb) {
     constexpr int NL = 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jg = lane >> 4, n = lane & 15;
@@ -845,14 +860,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
     // cache lines; lanes below Nklow idle), and the nkb workgroups of one cosmology sit on ONE XCD (consecutive workgroup ids go round the
     // eight XCDs): its 30 KB of per-s records and its A operand then pass through one L2 instead of eight.
     int kb, w;
-    if ((nB & 7) == 0) {
-        const int slot = blockIdx.x >> 3;
-        kb = slot % nkb;
-        w = (blockIdx.x & 7) + 8 * (slot / nkb);
-    } else {
-        kb = blockIdx.x % nkb;
-        w = blockIdx.x / nkb;
-    }
+    xcd_decode(nkb, kb, w);
     const int k = (Nklow & ~15) + (kb * 4 + wave) * 16 + n, split = blockIdx.z;
     const bool live = k < Nk && k >= Nklow;
     const int kc = k < Nklow ? Nklow : (k < Nk ? k : Nk - 1);
@@ -1220,12 +1228,15 @@ constexpr int SPL_HB = 32;
 // through LDS (register-prefetched one group ahead); one group of 16 series = 20 MFMAs per wave.
 constexpr int SPL_W = 128, SPL_LD = SPL_W + 2;  // staged window (64 knots + 2 x 32 halo), LDS row stride (conflict-free b64 reads)
 
-__global__ __launch_bounds__(256) void spline_kernel(int Nk, int nseries, const double* __restrict__ T, const double* __restrict__ band,
+__global__ __launch_bounds__(256) void spline_kernel(int Nk, int nseries, int rlo, int rsel, const double* __restrict__ T, const double* __restrict__ band,
                                                      double* __restrict__ YS) {
     __shared__ double ys[16 * SPL_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int w0 = blockIdx.x * 64 - SPL_HB;      // first knot of the staged window
-    const int it0 = blockIdx.x * 64 + 16 * wave;  // this wave's output tile
+    int ktile, share;  // the k tiles of one share of the series run on one XCD: their halo windows overlap by half
+    xcd_decode((Nk + 63) / 64, ktile, share);
+    const int nshare = gridDim.x / ((Nk + 63) / 64);
+    const int w0 = ktile * 64 - SPL_HB;      // first knot of the staged window
+    const int it0 = ktile * 64 + 16 * wave;  // this wave's output tile
     // B fragments: K-step t, lane (g, r): weight of input j = it0 - 32 + 4 t + g for output knot i = it0 + r, i.e. band[d][i], d = 4 t + g - r
     double bf[20];
 #pragma unroll
@@ -1234,15 +1245,17 @@ __global__ __launch_bounds__(256) void spline_kernel(int Nk, int nseries, const 
         bf[t] = (d >= 0 && d <= 2 * SPL_HB && i < Nk) ? band[(size_t)d * Nk + i] : 0.0;
     }
     const int ngroups = (nseries + 15) / 16;
-    const int per = (ngroups + gridDim.y - 1) / gridDim.y;
-    const int g0 = blockIdx.y * per, g1 = min(ngroups, g0 + per);
+    const int per = (ngroups + nshare - 1) / nshare;
+    const int g0 = share * per, g1 = min(ngroups, g0 + per);
     // staging: 16 series x 128 knots = 2048 values, 8 per thread (series = e / 128, knot = e % 128: coalesced rows)
+    // nseries counts the selected series: rows [rlo, rlo + rsel) of every (cosmology, l) block of NROW (rsel = NROW: all of them)
+    auto row_of = [&](int sp) { return rsel == NROW ? sp : (sp / rsel) * NROW + rlo + sp % rsel; };  // (uniform branch: no division on the headline path)
     double pre[8];
     auto fetch = [&](int grp) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 256 * u, sr = e >> 7, jj = w0 + (e & 127), series = grp * 16 + sr;
-            pre[u] = (series < nseries && jj >= 0 && jj < Nk) ? T[(size_t)series * Nk + jj] : 0.0;
+            pre[u] = (series < nseries && jj >= 0 && jj < Nk) ? T[(size_t)row_of(series) * Nk + jj] : 0.0;
         }
     };
     if (g0 < g1) fetch(g0);
@@ -1265,7 +1278,7 @@ __global__ __launch_bounds__(256) void spline_kernel(int Nk, int nseries, const 
         for (int q = 0; q < 4; ++q) {
             const int sr = g + 4 * q, series = grp * 16 + sr;
             if (series < nseries && i < Nk)
-                *reinterpret_cast<double2*>(YS + ((size_t)series * Nk + i) * 2) = make_double2(ys[sr * SPL_LD + 16 * wave + SPL_HB + r], acc[q]);
+                *reinterpret_cast<double2*>(YS + ((size_t)row_of(series) * Nk + i) * 2) = make_double2(ys[sr * SPL_LD + 16 * wave + SPL_HB + r], acc[q]);
         }
     }
 }
@@ -1358,14 +1371,16 @@ __global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* _
 // Workgroup = one wave = 64 k of one cosmology, the thread walks the template rows one after the other (a light launch: 1 024 waves at
 // Nk = 512, B = 128 -- the gate must not wait for resources beside the resummation kernel); rows >= nr (Pstl unless APst) are copied through.
 template <int NL>
-__global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int nr, const double* __restrict__ kk, const double* __restrict__ DAw,
+__global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo, int nr, const double* __restrict__ kk, const double* __restrict__ DAw,
                                                        const double* __restrict__ Hw, const double* __restrict__ fid,
                                                        const double* __restrict__ mu, const double* __restrict__ wmu,
                                                        const double* __restrict__ legmu, const double* __restrict__ ROOT,
                                                        const double* __restrict__ T, const double* __restrict__ YS, double* __restrict__ Tout,
                                                        const int4* __restrict__ META) {
-    const int kt = blockIdx.x, w = blockIdx.y;
-    if (META && !META[(size_t)w * gridDim.x + kt].w) return;  // fallback duty only: the tile went through ap_rows_kernel
+    const int KT = (Nk + 63) / 64;
+    int kt, w;
+    xcd_decode(KT, kt, w);
+    if (META && !META[(size_t)w * KT + kt].w) return;  // fallback duty only: the tile went through ap_rows_kernel
     const int k = kt * 64 + threadIdx.x;
     if (k >= Nk) return;
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w], F = qpar / qperp;
@@ -1373,7 +1388,7 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int nr, 
     const double* root = ROOT + (size_t)w * nmu;
     const int i_first = knot_interval(kk, Nk, kq * root[0]);
     for (int r = 0; r < NROW; ++r) {
-        if (r >= nr) {
+        if (r >= nr || r < rlo) {  // rows outside [rlo, nr) are copied through
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
@@ -1446,7 +1461,10 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     double* s_ps = sm + Nk + nmu + (nmu & 1);  // [(nmu + 1) * NS] the cosmology's prefix sums (58 KB at Nl = 3, 200 nodes): every gather below is an LDS read
     __shared__ int s_red[3];            // min i0, max i0, max knots per k over the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, k = kt * 64 + lane;
+    const int KT = (Nk + 63) / 64;
+    int kt, w;
+    xcd_decode(KT, kt, w);
+    const int k = kt * 64 + lane;
     {
         const double2* src = reinterpret_cast<const double2*>(PS + (size_t)w * (nmu + 1) * NS);
         double2* dst = reinterpret_cast<double2*>(s_ps);
@@ -1567,7 +1585,7 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
 // this workgroup alone: they are re-read per chunk, from the cache.
 
 template <int NL, int NRC>
-__global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int nr, const double* __restrict__ DAw, const double* __restrict__ Hw,
+__global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int nr, const double* __restrict__ DAw, const double* __restrict__ Hw,
                                                           const double* __restrict__ fid, const double* __restrict__ W,
                                                           const int* __restrict__ I0, const int4* __restrict__ META,
                                                           const double* __restrict__ T, const double* __restrict__ YS,
@@ -1575,7 +1593,10 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int nr, const 
     constexpr int NP = NL * NL;
     __shared__ double2 win[NL * NRC * APW_WIN];  // (y, s) of series (l', row of the chunk) at knots jmin .. jmin + span
     const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const int kt = blockIdx.x, w = blockIdx.y, KT = gridDim.x, k = kt * 64 + lane;
+    const int KT = (Nk + 63) / 64;
+    int kt, w;
+    xcd_decode(KT, kt, w);
+    const int k = kt * 64 + lane;
     const int i0 = I0[(size_t)w * KT * 64 + k];
     const int4 meta = META[(size_t)w * KT + kt];
     if (meta.w) return;  // left to ap_direct_kernel
@@ -1588,7 +1609,7 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int nr, const 
     const double2* ys = reinterpret_cast<const double2*>(YS) + (size_t)w * NL * NROW * Nk;
     const int j1 = jmin + lane, j2 = jmin + 64 + lane;
     const bool two = 64 + lane < span;  // second load of a series only where the window reaches
-    for (int r0 = 0; r0 < nr; r0 += NRC) {
+    for (int r0 = rlo; r0 < nr; r0 += NRC) {
         const int nrow = min(NRC, nr - r0);
         __syncthreads();  // the previous chunk has been consumed
         // wave l stages the series of l' = l: nrow rows, up to two 1 KB wave loads each, APR_SB rows in flight together
@@ -1655,8 +1676,9 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int nr, const 
                 if (r < nrow) dst[(size_t)r * Nk] = c * acc[r];
         }
     }
-    if (live) {  // rows that APeffect leaves alone (Pstl unless APst)
+    if (live) {  // rows that APeffect leaves alone (Pstl unless APst; everything but the counter-term rows of the NNLO block)
         const size_t base = (((size_t)w * NL + l) * NROW) * Nk + k;
+        for (int r = 0; r < rlo; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];
         for (int r = nr; r < NROW; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];
     }
 }

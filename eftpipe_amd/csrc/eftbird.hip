@@ -423,7 +423,7 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
 #undef PF_ARGS
     if (!e->ap_fast) return;
     // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
-    const dim3 wgrid((c.Nk + 63) / 64, B);
+    const dim3 wgrid(((c.Nk + 63) / 64) * B);  // flat: (k tile, cosmology) decoded XCD-aware in the kernel
     const size_t wlds = ((size_t)c.Nk + c.nmu + (c.nmu & 1) + (size_t)(c.nmu + 1) * c.Nl * c.Nl * 4) * sizeof(double);
 #define APW_ARGS c.Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, \
                  e->APW, e->API, e->APM
@@ -510,8 +510,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     const bool side_ir = !nnlo_pass && (mask & EFTB_S_RESUM) && c.with_resum && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP));
     const bool side_ap = !nnlo_pass && (mask & EFTB_S_AP) && c.with_ap && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP | EFTB_S_RESUM));
     // cross-run overlap of the front half (see engine.pre): only for asynchronous runs whose inputs are already in place
+    // with_NNLO: CctNNLO rides in the resummation records of the first pass when the batch is large enough for unsplit s sums
+    const bool nnlo_fused = c.with_nnlo && c.with_resum && Nl == 3 && e->resum_splits == 1 && !c.optiresum && !e->generic_resum;
+    // (with_NNLO steps stay on one stream: with only the front half overlapped they measured 0.66 ms per 128 against 0.64 ms in line)
     const bool pre_side = (mask & EFTB_S_PREP) && (mask & EFTB_S_REGROUP) && e->prep_overlap && e->inputs_settled && !e->use_graphs && !nnlo_pass &&
-                          !c.with_nnlo;  // (the NNLO pass of the previous run still reads CctNNLO late)
+                          !c.with_nnlo;
     const bool ap_side = pre_side && e->ap_overlap && e->allow_back && (mask & EFTB_S_RESUM) && (mask & EFTB_S_AP) && (Nl == 3 || !e->generic_resum);
     if (!ap_side) join_back(e);
     const int bslot = e->back_step & 1;  // evBack[bslot] was recorded two runs ago
@@ -668,7 +671,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (Nl == 3 || !e->generic_resum) {
             // matrix-core form: polynomials as [80 | 32 x 8] x [8 x 16 points] MFMAs, one wave = 16 k x one slice of the s sum
             // with_nnlo, large batches: CctNNLO rides in the records and the main kernel accumulates PctNNLOl beside Pctl (no second pass)
-            const bool fused_nnlo = c.with_nnlo && !nnlo_pass && Nl == 3 && e->resum_splits == 1 && !c.optiresum;
+            const bool fused_nnlo = nnlo_fused && !nnlo_pass;
 #define RP_ARGS e->Nn, c.NIR, c.Na, b[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS), tb<int>(e, EFTB_T_RSROWS), b[EFTB_B_XY], c11, cct, cloopl, e->RSA, e->RSC, \
                 fused_nnlo ? b[EFTB_B_CCTN] : nullptr, fuse_cf ? b[EFTB_B_CC] : nullptr, b[EFTB_B_F], tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), \
                 tb<int>(e, EFTB_T_GRP)
@@ -704,11 +707,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
             const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
             if (kblocks > 0 && Nl == 3 && fused_nnlo)
-                hipLaunchKernelGGL((resum_mfma_kernel<2, true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb, B);
+                hipLaunchKernelGGL((resum_mfma_kernel<2, true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
             else if (kblocks > 0 && Nl == 3 && e->resum_wps >= 3)
-                hipLaunchKernelGGL((resum_mfma_kernel<3, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb, B);
+                hipLaunchKernelGGL((resum_mfma_kernel<3, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb);
             else if (kblocks > 0 && Nl == 3)
-                hipLaunchKernelGGL((resum_mfma_kernel<2, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb, B);
+                hipLaunchKernelGGL((resum_mfma_kernel<2, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb);
             else if (kblocks > 0) hipLaunchKernelGGL(resum_mfma2_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
 #undef RM_ARGS
             if (nsplit > 1)
@@ -741,14 +744,17 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     }
     if (mask & EFTB_S_AP) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
-        const int nseries = B * Nl * NROW;
+        // the NNLO block carries only the three counter-term rows 3-5 of every multipole: spline and AP touch those alone
+        const int rlo = nnlo_pass ? 3 : 0, rsel = nnlo_pass ? 3 : NROW;
+        const int nseries = B * Nl * rsel;
         {
             const int kt = (Nk + 63) / 64;
-            const int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
-            hipLaunchKernelGGL(spline_kernel, dim3(kt, ysplit), dim3(256), 0, st, Nk, nseries, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPBAND), e->SD);
+            int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
+            if (ysplit >= 8) ysplit &= ~7;  // shares in multiples of 8: the k tiles of a share then sit on one XCD (xcd_decode)
+            hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPBAND), e->SD);
         }
         // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
-        const int nr = c.ap_stochastic && !nnlo_pass ? NROW : 21;
+        const int nr = nnlo_pass ? 6 : (c.ap_stochastic ? NROW : 21);
         if (!side_ap && !nnlo_pass) launch_ap_prefix(e, st, B);
         if (!joined_ap) {
             if (hipStreamWaitEvent(st, e->evJoinAP, 0) != hipSuccess) return fail("eftb_run: stream join failed");
@@ -757,19 +763,19 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         if (e->ap_fast) {
             // banded product of the knot weights with the spline data; rows [nr, 24) are copied through
             const int kt = (Nk + 63) / 64;
-#define APR_ARGS Nk, nr, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, b[EFTB_B_TEMPL], e->SD, e->Talt
-            if (Nl == 3 && e->ap_chunk == 8) hipLaunchKernelGGL((ap_rows_kernel<3, 8>), dim3(kt, B), dim3(192), 0, st, APR_ARGS);
-            else if (Nl == 3 && e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<3, 12>), dim3(kt, B), dim3(192), 0, st, APR_ARGS);
-            else if (Nl == 3) hipLaunchKernelGGL((ap_rows_kernel<3, 7>), dim3(kt, B), dim3(192), 0, st, APR_ARGS);
-            else if (e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<2, 12>), dim3(kt, B), dim3(128), 0, st, APR_ARGS);
-            else hipLaunchKernelGGL((ap_rows_kernel<2, 8>), dim3(kt, B), dim3(128), 0, st, APR_ARGS);
+#define APR_ARGS Nk, rlo, nr, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, b[EFTB_B_TEMPL], e->SD, e->Talt
+            if (Nl == 3 && e->ap_chunk == 8) hipLaunchKernelGGL((ap_rows_kernel<3, 8>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
+            else if (Nl == 3 && e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<3, 12>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
+            else if (Nl == 3) hipLaunchKernelGGL((ap_rows_kernel<3, 7>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
+            else if (e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<2, 12>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
+            else hipLaunchKernelGGL((ap_rows_kernel<2, 8>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
 #undef APR_ARGS
         }
         // the reference's own quadrature: every tile (EFTB_AP_FAST=0), or only the tiles the fast path flagged (strong distortions)
         {
             const int4* gate = e->ap_fast ? e->APM : nullptr;
-            const dim3 dgrid((Nk + 63) / 64, B);
-#define APD_ARGS Nk, c.nmu, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
+            const dim3 dgrid(((Nk + 63) / 64) * B);
+#define APD_ARGS Nk, c.nmu, rlo, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
                  tb<double>(e, EFTB_T_LEGMU), e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt, gate
             if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3>), dgrid, dim3(64), 0, st, APD_ARGS);
             else hipLaunchKernelGGL((ap_direct_kernel<2>), dgrid, dim3(64), 0, st, APD_ARGS);
