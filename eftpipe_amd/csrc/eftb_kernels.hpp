@@ -99,9 +99,12 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(int Nkin, int ntail, int
 // ------------------------------------------------------------------------------------------------
 constexpr int AD_T = NHALF + 2;   // anti-diagonal length (129) rounded up to even
 constexpr int AD_CH = 3, AD_TC = 44;  // the anti-diagonal is cut into AD_CH chunks of AD_TC pairs (partial sums, added by build_rows_kernel)
-constexpr int KSYN = 528;         // 1 + 2*256 synthesis coefficients, zero padded to a multiple of SYN_KC
+constexpr int KSYN = 528;         // 1 + 2*256 synthesis coefficients, zero padded to a multiple of SYN_KPAD
 constexpr int KLIN = 288;         // 1 + 2*128, likewise
-constexpr int SYN_KC = 48;        // K chunk of synth_kernel staged in LDS
+constexpr int SYN_KPAD = 48;      // every K of a synthesis / first-stage GEMM is zero padded to a multiple of this
+constexpr int SYN_KC = 24;        // K chunk of synth_kernel staged in LDS (divides SYN_KPAD); 24 rather than 48: 94 instead of 104 registers per
+                                  // lane, which is what fits beside two resummation waves on a SIMD (512 - 2 x 208 = 96)
+static_assert(SYN_KPAD % SYN_KC == 0 && (32 * SYN_KC) % 256 == 0, "chunk must divide the padding and fill the staging threads");
 constexpr int BAS22 = 8, BASC = 32;  // padded basis rows per cosmology: 7 M22 matrices; Nl * (7 + 2) weighted ones
 
 // Lanes <-> cosmologies (transposed coefficients coefT[2][129][Bmax] come out of the first-stage GEMMs); the matrix weights are wave-uniform
@@ -862,8 +865,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
     int kb, w;
     xcd_decode(nkb, kb, w);
     const int k = (Nklow & ~15) + (kb * 4 + wave) * 16 + n, split = blockIdx.z;
-    const bool live = k < Nk && k >= Nklow;
-    const int kc = k < Nklow ? Nklow : (k < Nk ? k : Nk - 1);
+    const int kc = k < Nklow ? Nklow : (k < Nk ? k : Nk - 1);  // lanes outside [Nklow, Nk) compute on a clamped k and store nothing
     const double k2 = kk[kc] * kk[kc];
     // B operand: this lane evaluates basis polynomials jg and jg + 4 at its point; A operand: rows (16 tau + n), columns jg + 4 t
     __shared__ double s_vb[RS_WPS >= 3 ? RS_NB * 16 : 1];

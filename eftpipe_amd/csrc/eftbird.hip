@@ -201,7 +201,7 @@ static int rccl_load() {
         if (_r != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(_r));   \
     } while (0)
 
-static inline size_t kpad(int n) { return (size_t)(n + SYN_KC - 1) / SYN_KC * SYN_KC; }  // K of a first-stage GEMM: padded to the chunk of synth_kernel
+static inline size_t kpad(int n) { return (size_t)(n + SYN_KPAD - 1) / SYN_KPAD * SYN_KPAD; }  // K of a first-stage GEMM: padded like the synthesis tables
 
 static size_t need_table_bytes(const eftb_config& c, int id) {
     const size_t D = sizeof(double);
