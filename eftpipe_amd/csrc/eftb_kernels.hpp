@@ -948,7 +948,8 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
 #pragma unroll
         for (int v = 0; v < 3; ++v) hn[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
         __builtin_amdgcn_sched_barrier(0);
-        const double zn = k2 * xn, yn = k2 * yn0;
+        double zn, yn;  // k^2 X, k^2 Y of the next step: formed only after this step's MFMAs have been issued -- the wait for the scalar
+                        // loads above then sits behind 640 cycles of matrix work instead of behind the first MFMA
         double bn0, bn1;
 #define RS_TILE(tau) \
     __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0), 0, 0, 0)
@@ -979,6 +980,9 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
             // third wave of the SIMD covers what this order leaves exposed); the next step's basis polynomials sit in the middle
             const v4d D0 = RS_TILE(0);
             const v4d D1 = RS_TILE(1);
+            __builtin_amdgcn_sched_barrier(0);
+            zn = k2 * xn;
+            yn = k2 * yn0;
             RS_USE012(0, D0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1000,6 +1004,8 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
 #pragma unroll
             for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            zn = k2 * xn;
+            yn = k2 * yn0;
             // ... under them the basis polynomials of the next step and the contraction of this step
             RS_POLY(bn0, bn1, zn * (1.0 / RS_ZS));
             RS_USE012(0, D[0]);
