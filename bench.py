@@ -40,6 +40,7 @@ ES = (0.26033594, 0.0, -0.92895016)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
 NPOW, NS_DEV, NKLOW = 257, 80, 7
 DEFAULT_RESUM_WPS = 2   # engine default (eftbird.hip resum_wps); EFTB_RESUM_WPS overrides both
+DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "2"))  # steps queued on the GPU ahead of the one being fetched (1..3; measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
 
 
 def cpu_baseline(budget_s=20.0):
@@ -177,29 +178,28 @@ def main():
 
     def loop(first, n, keep):
         """n pipelined steps over sets[first : first + n]; every step's output is fetched to the host before the function returns.
-        The output of step i - 2 is copied out after step i has been launched, so two steps are always queued on the GPU while the
-        host copies and prepares (the engine keeps three sets of per-step inputs / outputs)."""
+        The output of step i - DEPTH is copied out after step i has been launched, so DEPTH steps are always queued on the GPU while the
+        host copies and prepares (the engine keeps DEPTH + 1 sets of per-step inputs / outputs)."""
         for i in range(n):
             stage_and_run(sets[first + i])
             if exchange == "rccl":
                 eng.gather_plk(B, root=0)
-                if i > 1 and rank == 0:
-                    eng.fetch_gathered(B, back=2, out=gathered[i - 2] if keep else None)
+                if i >= DEPTH and rank == 0:
+                    eng.fetch_gathered(B, back=DEPTH, out=gathered[i - DEPTH] if keep else None)
             elif exchange == "host-fallback":
                 eng.sync()
                 cp.gather_host(eng.get("PLK", (B, NL, NK)))
-            elif i > 1:
-                eng.fetch_previous("PLK", (B, NL, NK), out=results[i - 2] if keep else None, back=2)
-        # drain: the last two steps
+            elif i >= DEPTH:
+                eng.fetch_previous("PLK", (B, NL, NK), out=results[i - DEPTH] if keep else None, back=DEPTH)
+        # drain: the last DEPTH steps
         if exchange == "rccl":
             eng.sync()
             if rank == 0:
-                for back in (1, 0):
-                    if n - 1 - back >= 0:
-                        eng.fetch_gathered(B, back=back, out=gathered[n - 1 - back] if keep else None)
+                for back in range(min(DEPTH, n) - 1, -1, -1):
+                    eng.fetch_gathered(B, back=back, out=gathered[n - 1 - back] if keep else None)
         elif exchange == "none":
-            if n > 1:
-                eng.fetch_previous("PLK", (B, NL, NK), out=results[n - 2] if keep else None, back=1)
+            for back in range(min(DEPTH, n) - 1, 0, -1):
+                eng.fetch_previous("PLK", (B, NL, NK), out=results[n - 1 - back] if keep else None, back=back)
             eng.sync()
             if n:
                 got = eng.get("PLK", (B, NL, NK))

@@ -126,16 +126,17 @@ struct eftb_engine {
     bool ap_overlap = true, back_pending = false, allow_back = false;  // EFTB_AP_OVERLAP=0 disables
     unsigned back_step = 0;
     hipStream_t opstream = nullptr;  // where the operator launchers put their kernels (null: the main stream)
-    // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous): three sets of the per-step inputs (PIN, F, DA,
-    // H, BIAS, GROWS) and outputs (PLK, LOGP) -- one being evaluated, one queued behind it, one whose results are being fetched / refilled
-    double* setbuf[3][EFTB_B_COUNT] = {{nullptr}};
-    double* setblock[3] = {nullptr, nullptr, nullptr};   // one contiguous input block per set (PIN, F, DA, H, BIAS, GROWS at stage_off[])
+    // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_back): four sets of the per-step inputs (PIN, F, DA,
+    // H, BIAS, GROWS) and outputs (PLK, LOGP) -- up to three launched and not yet fetched, one whose results are being fetched / refilled
+    static constexpr int NSETS = 4;  // rotating sets of per-step inputs / outputs: the host may run three steps ahead of the step it fetches
+    double* setbuf[NSETS][EFTB_B_COUNT] = {{nullptr}};
+    double* setblock[NSETS] = {};   // one contiguous input block per set (PIN, F, DA, H, BIAS, GROWS at stage_off[])
     double* orig[EFTB_B_COUNT] = {nullptr};              // the engine's own buffers, current until the first staged run
     size_t stage_off[EFTB_B_COUNT] = {0};
-    double* stage_host[3] = {nullptr, nullptr, nullptr};  // page-locked staging, one per set
+    double* stage_host[NSETS] = {};  // page-locked staging, one per set
     size_t stage_elems = 0;
     hipStream_t cpy = nullptr;
-    hipEvent_t evStaged[3] = {nullptr, nullptr, nullptr}, evSetDone[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t evStaged[NSETS] = {}, evSetDone[NSETS] = {};
     int cur_set = 0, staged_B = 0;
     bool staged_plk_device = false;  // staged sets keep P_l in device memory (a communicator exists: RCCL sends from it) instead of mapped host memory
     bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
@@ -151,8 +152,8 @@ struct eftb_engine {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     double* gathered = nullptr;
-    double* gathered2[3] = {nullptr, nullptr, nullptr};  // the gathered block rotates through three buffers: the root reads step i while steps i + 1, i + 2 are exchanged
-    hipEvent_t evGath2[3] = {nullptr, nullptr, nullptr};
+    double* gathered2[NSETS] = {};  // the gathered block rotates through three buffers: the root reads step i while steps i + 1, i + 2 are exchanged
+    hipEvent_t evGath2[NSETS] = {};
     int gather_slot = 0;
     // the gather runs on its own stream from a snapshot of P_l, so that it overlaps the next step's kernels
     hipStream_t comm_stream = nullptr;
@@ -1296,7 +1297,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
     for (double* p : {e->RSA, e->RSC, e->RSA2, e->RSC2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
     }
@@ -1313,7 +1314,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->back) (void)hipStreamDestroy(e->back);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->evStaged[q]) (void)hipEventDestroy(e->evStaged[q]);
         if (e->evSetDone[q]) (void)hipEventDestroy(e->evSetDone[q]);
         if (e->stage_host[q]) (void)hipHostFree(e->stage_host[q]);
@@ -1500,7 +1501,7 @@ static int staged_setup(eftb_engine* e) {
     e->stage_elems = (off + 1) & ~(size_t)1;  // whole double2s for the copy kernel
     for (int id : kStagedIds) e->orig[id] = e->buf[id];
     e->staged_plk_device = e->comm != nullptr;
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < eftb_engine::NSETS; ++q) {
         HIPCHK(hipMalloc(&e->setblock[q], e->stage_elems * sizeof(double)));
         HIPCHK(hipMemset(e->setblock[q], 0, e->stage_elems * sizeof(double)));
         for (int id : kStagedIn) e->setbuf[q][id] = e->buf_elems[id] ? e->setblock[q] + e->stage_off[id] : nullptr;
@@ -1523,7 +1524,7 @@ static int staged_setup(eftb_engine* e) {
         HIPCHK(hipEventRecord(e->evStaged[q], e->cpy));
         HIPCHK(hipEventRecord(e->evSetDone[q], e->cpy));
     }
-    e->cur_set = 2;  // the engine's own buffers are current until the first eftb_run_staged; sets 0, 1, 2 follow in turn
+    e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first eftb_run_staged; sets 0, 1, 2, 3 follow in turn
     HIPCHK(hipDeviceSynchronize());  // the zero fills ran on the null stream; the copy stream is about to write into these blocks
     return 0;
 }
@@ -1539,7 +1540,7 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     if (int rc = validate_inputs(c, "eftb_stage_inputs", B, Pin, f, DA, H)) return rc;
     if (int rc = staged_setup(e)) return rc;
     HIPCHK(hipSetDevice(c.device));
-    const int t = (e->cur_set + 1) % 3;  // the set after the current one: its last run was fetched two steps ago
+    const int t = (e->cur_set + 1) % eftb_engine::NSETS;  // the set after the current one: the oldest, fetched (or abandoned) by now
     HIPCHK(hipEventSynchronize(e->evStaged[t]));  // its staging block is free again (the previous upload from it has finished)
     double* h = e->stage_host[t];
     memcpy(h + e->stage_off[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double));
@@ -1568,7 +1569,7 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     if (!e->cpy || e->staged_B == 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
     if (B != e->staged_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->staged_B);
     HIPCHK(hipSetDevice(e->c.device));
-    e->cur_set = (e->cur_set + 1) % 3;
+    e->cur_set = (e->cur_set + 1) % eftb_engine::NSETS;
     for (int id : kStagedIds)
         if (e->setbuf[e->cur_set][id]) e->buf[id] = e->setbuf[e->cur_set][id];
     e->staged_B = 0;
@@ -1586,12 +1587,12 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
 
 int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_back: null argument");
-    if (back != 1 && back != 2) return fail("eftb_fetch_back: back must be 1 (the step before the one launched last) or 2 (the one before that)");
-    if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_back: only EFTB_B_PLK and EFTB_B_LOGP are triple-buffered outputs");
+    if (back < 1 || back >= eftb_engine::NSETS) return fail("eftb_fetch_back: back must be 1 (the step before the one launched last), 2 or 3");
+    if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_back: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
     if (!e->cpy) return fail("eftb_fetch_back: no staged run yet");
     if (count > e->buf_elems[id]) return fail("eftb_fetch_back: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
     HIPCHK(hipSetDevice(e->c.device));
-    const int t = (e->cur_set + 3 - back) % 3;  // back = 2 is the set that the next eftb_stage_inputs refills
+    const int t = (e->cur_set + eftb_engine::NSETS - back) % eftb_engine::NSETS;  // back = 3 is the set that the next eftb_stage_inputs refills
     // spin on the step's event instead of sleeping in a synchronize call: the sampler thread is about to enqueue the next step, and the
     // wake-up latency of a blocking wait would be paid once per step
     static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
@@ -1643,7 +1644,7 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
     HIPCHK(hipSetDevice(e->c.device));
     const size_t count = (size_t)B * e->cur_nl * e->cur_nx;
     if (e->rank == root) {
-        e->gather_slot = (e->gather_slot + 1) % 3;
+        e->gather_slot = (e->gather_slot + 1) % eftb_engine::NSETS;
         const int q = e->gather_slot;
         if (!e->gathered2[q]) {
             HIPCHK(hipMalloc(&e->gathered2[q], (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
@@ -1700,8 +1701,8 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
 
 int eftb_fetch_gathered(eftb_engine* e, int which /* = back */, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_gathered: null argument");
-    if (which < 0 || which > 2) return fail("eftb_fetch_gathered: `back` must be 0 (the last exchange enqueued), 1 or 2 (one / two exchanges before it)");
-    const int q = (e->gather_slot + 3 - which) % 3;
+    if (which < 0 || which >= eftb_engine::NSETS) return fail("eftb_fetch_gathered: `back` must be 0 (the last exchange enqueued), 1, 2 or 3 (that many exchanges before it)");
+    const int q = (e->gather_slot + eftb_engine::NSETS - which) % eftb_engine::NSETS;
     if (!e->gathered2[q]) return fail("eftb_fetch_gathered: no such exchange yet");
     if (count > (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk) return fail("eftb_fetch_gathered: asked %zu elements", count);
     HIPCHK(hipSetDevice(e->c.device));

@@ -301,8 +301,8 @@ class Engine:
             self.dims = self.out_dims()
 
     def fetch_previous(self, name, shape, out=None, back=1):
-        """PLK / LOGP of the step launched `back` (1 or 2) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
-        to fill).  back=2 keeps two steps queued while the host works (see ``pipeline``)."""
+        """PLK / LOGP of the step launched `back` (1, 2 or 3) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
+        to fill).  back=3 keeps three steps queued while the host works (see ``pipeline``)."""
         if out is None:
             out = np.empty(shape, dtype=np.float64)
         L.check(self.lib.eftb_fetch_back(self._h, int(back), L.B[name], L.dptr(out), out.size))
@@ -316,15 +316,15 @@ class Engine:
             mask = self.full_mask(reduce=(fetch == "PLK")) | (L.S_LOGP if fetch == "LOGP" else 0)
         nl, nx = self.out_dims()
         shape_of = lambda B: (B, nl, nx) if fetch == "PLK" else (B // self.ntracers, 2 + 24)
-        queued = []  # batch sizes of the steps launched and not yet fetched (at most two)
+        queued = []  # batch sizes of the steps launched and not yet fetched (at most three)
         for st in steps:
             B = self.stage_inputs(st["Pin"], st["f"], st.get("DA"), st.get("H"), bias=st.get("bias"), rows=st.get("rows"))
             self.run_staged(mask, B)
             queued.append(B)
-            if len(queued) == 3:  # two steps stay queued on the GPU while the oldest one is copied out
-                yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=2)
-        if len(queued) == 2:
-            yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=1)
+            if len(queued) == 4:  # three steps stay queued on the GPU while the oldest one is copied out
+                yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=3)
+        while len(queued) > 1:
+            yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=len(queued))
         if queued:
             self.sync()
             yield self.get(fetch, shape_of(queued.pop(0)))

@@ -403,23 +403,27 @@ def test_pipelined_steps_with_changing_inputs(golden):
         assert np.array_equal(got[s], want[s]), s
     with pytest.raises(Exception):
         eng.run_staged(mask, B)  # nothing staged
-    # the same loop through the generator (which keeps two steps queued: eftb_fetch_back(2))
+    # the same loop through the generator (which keeps three steps queued: eftb_fetch_back(3))
     for s, res in enumerate(eng.pipeline(steps)):
         assert np.array_equal(res, want[s]), s
-    assert len(list(eng.pipeline(steps[:1]))) == 1 and len(list(eng.pipeline(steps[:2]))) == 2
-    # explicit depth-2 loop: the result of step s - 2 is copied out after step s has been launched
-    got2 = []
-    for s in range(nsteps):
-        st = steps[s]
-        eng.stage_inputs(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"])
-        eng.run_staged(mask, B)
-        if s >= 2:
-            got2.append(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=2))
-    got2.append(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=1))
-    eng.sync()
-    got2.append(eng.get("PLK", (B, 3, g["k"].size)))
-    for s in range(nsteps):
-        assert np.array_equal(got2[s], want[s]), s
+    for n in (1, 2, 3, 4):
+        assert len(list(eng.pipeline(steps[:n]))) == min(n, nsteps)
+    # explicit loops of depth 2 and 3: the result of step s - depth is copied out after step s has been launched
+    for depth in (2, 3):
+        got2 = []
+        for s in range(nsteps):
+            st = steps[s]
+            eng.stage_inputs(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"])
+            eng.run_staged(mask, B)
+            if s >= depth:
+                got2.append(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=depth))
+        for back in range(min(depth, nsteps) - 1, 0, -1):
+            got2.append(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=back))
+        eng.sync()
+        got2.append(eng.get("PLK", (B, 3, g["k"].size)))
+        assert len(got2) == nsteps
+        for s in range(nsteps):
+            assert np.array_equal(got2[s], want[s]), (depth, s)
     with pytest.raises(L.EftbError):
-        eng.fetch_previous("PLK", (B, 3, g["k"].size), back=3)
+        eng.fetch_previous("PLK", (B, 3, g["k"].size), back=4)
     eng.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host time per call of the pipelined sampler loop (GPU box): is the loop bound by the host enqueueing, or by the GPU?
-stage_inputs and run_staged never wait for the GPU, so their wall time is pure host cost; fetch_previous(back=2) = wait + copy."""
+stage_inputs and run_staged never wait for the GPU, so their wall time is pure host cost; fetch_previous(back=3) = wait + copy."""
 import os
 import sys
 import time
@@ -37,8 +37,8 @@ for rep in range(2):
         b = time.perf_counter()
         eng.run_staged(mask, B)
         c = time.perf_counter()
-        if i > 1:
-            eng.fetch_previous("PLK", (B, 3, 512), out=out, back=2)
+        if i > 2:
+            eng.fetch_previous("PLK", (B, 3, 512), out=out, back=3)
         e = time.perf_counter()
         t["stage"] += b - a
         t["run"] += c - b
@@ -46,7 +46,7 @@ for rep in range(2):
     eng.sync()
     tot = time.perf_counter() - t0
 print(f"B={B}: {tot / N * 1e3:.3f} ms per step; host per step: stage_inputs {t['stage'] / N * 1e6:.0f} us, run_staged {t['run'] / N * 1e6:.0f} us, "
-      f"fetch_previous(back=2) {t['fetch'] / N * 1e6:.0f} us (wait + 1.5 MB copy)")
+      f"fetch_previous(back=3) {t['fetch'] / N * 1e6:.0f} us (wait + 1.5 MB copy)")
 # the copy alone: fetch of a step that finished long ago
 eng.sync()
 a = time.perf_counter()

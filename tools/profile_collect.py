@@ -105,10 +105,12 @@ out = {
 try:
     tr = list(csv.DictReader(open(find("stats_kernel_trace.csv"))))
     ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], short(r["Kernel_Name"])) for r in tr]
-    gy = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): int(r["Grid_Size_Y"]) for r in tr}  # grid y = batch: bench-batch launches only
+    # bench-batch launches only: the largest grid of the kernel (the command also launches it at batch 1-2)
+    gy = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) for r in tr}
+    gbig = max(g for (s_, e_), g in gy.items() if any(n.startswith("eftb::resum_mfma_kernel") and (s1, e1) == (s_, e_) for s1, e1, q1, n in ev))
     beside, alone = [], []
     for s0, e0, q0, n0 in ev:
-        if not n0.startswith("eftb::resum_mfma_kernel") or gy[(s0, e0)] != B:
+        if not n0.startswith("eftb::resum_mfma_kernel") or gy[(s0, e0)] != gbig:
             continue
         shared = sum(max(0, min(e0, e1) - max(s0, s1)) for s1, e1, q1, n1 in ev if q1 != q0 and e1 > s0 and s1 < e0)
         (beside if shared > 0.2 * (e0 - s0) else alone).append((e0 - s0) / 1e3)
