@@ -55,6 +55,7 @@ struct eftb_engine {
     double *RSA2 = nullptr, *RSC2 = nullptr;  // second operand set: the look-ahead builds run i+1's operands while run i's resummation reads its own
     hipEvent_t evRsDone[2] = {nullptr, nullptr};  // the resummation that read operand set [slot] has finished
     unsigned rs_step = 0;
+    bool nnlo_inline = true;  // EFTB_NNLO_INLINE=0: with_NNLO steps never take the three-stream layout
     bool prep_ahead = true;  // EFTB_PREP_AHEAD=0: regrouping and operand build stay on the main stream in front of the resummation
     // duration of the dominant kernel inside pipelined steps (EFTB_O_TIME_DOMINANT): HIP events on the stream it is launched on
     static constexpr int NTIMER = 8;
@@ -123,6 +124,7 @@ struct eftb_engine {
     hipStream_t back = nullptr;
     hipEvent_t evResum = nullptr, evBack[2] = {nullptr, nullptr};
     double* T3 = nullptr;
+    double *TaltN = nullptr, *T3N = nullptr;  // the same rotation for the NNLO template block (with_NNLO steps on the three-stream layout)
     bool ap_overlap = true, back_pending = false, allow_back = false;  // EFTB_AP_OVERLAP=0 disables
     unsigned back_step = 0;
     hipStream_t opstream = nullptr;  // where the operator launchers put their kernels (null: the main stream)
@@ -494,7 +496,7 @@ static void collect_timer(eftb_engine* e, int slot, bool wait) {
     }
 }
 
-static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
+static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, bool nnlo_inline = false) {
     const eftb_config& c = e->c;
     hipStream_t st = e->stream;
     const int Nk = c.Nk, Nl = c.Nl;
@@ -514,8 +516,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     // with_NNLO: CctNNLO rides in the resummation records of the first pass when the batch is large enough for unsplit s sums
     const bool nnlo_fused = c.with_nnlo && c.with_resum && Nl == 3 && e->resum_splits == 1 && !c.optiresum && !e->generic_resum;
     // (with_NNLO steps stay on one stream: with only the front half overlapped they measured 0.66 ms per 128 against 0.64 ms in line)
+    // nnlo_inline (launch_stages): this call carries the NNLO block through regrouping, resummation (fused accumulator), AP and REDUCE itself
     const bool pre_side = (mask & EFTB_S_PREP) && (mask & EFTB_S_REGROUP) && e->prep_overlap && e->inputs_settled && !e->use_graphs && !nnlo_pass &&
-                          !c.with_nnlo;
+                          (!c.with_nnlo || nnlo_inline);
     const bool ap_side = pre_side && e->ap_overlap && e->allow_back && (mask & EFTB_S_RESUM) && (mask & EFTB_S_AP) && (Nl == 3 || !e->generic_resum);
     if (!ap_side) join_back(e);
     const int bslot = e->back_step & 1;  // evBack[bslot] was recorded two runs ago
@@ -633,6 +636,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
         // regroup into the block the run before the previous one left its AP output in (its readers are done: evBack)
         if (hipStreamWaitEvent(st, e->evBack[bslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
         std::swap(b[EFTB_B_TEMPL], e->T3);
+        if (nnlo_inline) std::swap(b[EFTB_B_TEMPLN], e->T3N);
     }
     if (mask & EFTB_S_REGROUP) {
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
@@ -745,44 +749,51 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass) {
     }
     if (mask & EFTB_S_AP) {
         if (!c.with_ap) return fail("eftb_run: stage AP needs with_ap=1");
-        // the NNLO block carries only the three counter-term rows 3-5 of every multipole: spline and AP touch those alone
-        const int rlo = nnlo_pass ? 3 : 0, rsel = nnlo_pass ? 3 : NROW;
-        const int nseries = B * Nl * rsel;
-        {
-            const int kt = (Nk + 63) / 64;
-            int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
-            if (ysplit >= 8) ysplit &= ~7;  // shares in multiples of 8: the k tiles of a share then sit on one XCD (xcd_decode)
-            hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, b[EFTB_B_TEMPL], tb<double>(e, EFTB_T_SPBAND), e->SD);
-        }
-        // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
-        const int nr = nnlo_pass ? 6 : (c.ap_stochastic ? NROW : 21);
-        if (!side_ap && !nnlo_pass) launch_ap_prefix(e, st, B);
-        if (!joined_ap) {
-            if (hipStreamWaitEvent(st, e->evJoinAP, 0) != hipSuccess) return fail("eftb_run: stream join failed");
-            joined_ap = true;
-        }
-        if (e->ap_fast) {
-            // banded product of the knot weights with the spline data; rows [nr, 24) are copied through
-            const int kt = (Nk + 63) / 64;
-#define APR_ARGS Nk, rlo, nr, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, b[EFTB_B_TEMPL], e->SD, e->Talt
-            if (Nl == 3 && e->ap_chunk == 8) hipLaunchKernelGGL((ap_rows_kernel<3, 8>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
-            else if (Nl == 3 && e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<3, 12>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
-            else if (Nl == 3) hipLaunchKernelGGL((ap_rows_kernel<3, 7>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
-            else if (e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<2, 12>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
-            else hipLaunchKernelGGL((ap_rows_kernel<2, 8>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
+        // one AP pass over a template block: *pin -> *palt, then the two trade places.  nn: the NNLO block carries only the three
+        // counter-term rows 3-5 of every multipole: spline and AP touch those alone
+        auto ap_pass = [&](bool nn, double** pin, double** palt) -> int {
+            const int rlo = nn ? 3 : 0, rsel = nn ? 3 : NROW;
+            const int nseries = B * Nl * rsel;
+            {
+                const int kt = (Nk + 63) / 64;
+                int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
+                if (ysplit >= 8) ysplit &= ~7;  // shares in multiples of 8: the k tiles of a share then sit on one XCD (xcd_decode)
+                hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, EFTB_T_SPBAND), e->SD);
+            }
+            // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
+            const int nr = nn ? 6 : (c.ap_stochastic ? NROW : 21);
+            if (!side_ap && !nn) launch_ap_prefix(e, st, B);
+            if (!joined_ap) {
+                if (hipStreamWaitEvent(st, e->evJoinAP, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+                joined_ap = true;
+            }
+            if (e->ap_fast) {
+                // banded product of the knot weights with the spline data; rows outside [rlo, nr) are copied through
+                const int kt = (Nk + 63) / 64;
+#define APR_ARGS Nk, rlo, nr, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt
+                if (Nl == 3 && e->ap_chunk == 8) hipLaunchKernelGGL((ap_rows_kernel<3, 8>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
+                else if (Nl == 3 && e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<3, 12>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
+                else if (Nl == 3) hipLaunchKernelGGL((ap_rows_kernel<3, 7>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
+                else if (e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<2, 12>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
+                else hipLaunchKernelGGL((ap_rows_kernel<2, 8>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
 #undef APR_ARGS
-        }
-        // the reference's own quadrature: every tile (EFTB_AP_FAST=0), or only the tiles the fast path flagged (strong distortions)
-        {
-            const int4* gate = e->ap_fast ? e->APM : nullptr;
-            const dim3 dgrid(((Nk + 63) / 64) * B);
+            }
+            // the reference's own quadrature: every tile (EFTB_AP_FAST=0), or only the tiles the fast path flagged (strong distortions)
+            {
+                const int4* gate = e->ap_fast ? e->APM : nullptr;
+                const dim3 dgrid(((Nk + 63) / 64) * B);
 #define APD_ARGS Nk, c.nmu, rlo, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
-                 tb<double>(e, EFTB_T_LEGMU), e->APR, b[EFTB_B_TEMPL], e->SD, e->Talt, gate
-            if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3>), dgrid, dim3(64), 0, st, APD_ARGS);
-            else hipLaunchKernelGGL((ap_direct_kernel<2>), dgrid, dim3(64), 0, st, APD_ARGS);
+                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate
+                if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3>), dgrid, dim3(64), 0, st, APD_ARGS);
+                else hipLaunchKernelGGL((ap_direct_kernel<2>), dgrid, dim3(64), 0, st, APD_ARGS);
 #undef APD_ARGS
-        }
-        std::swap(e->buf[EFTB_B_TEMPL], e->Talt);
+            }
+            std::swap(*pin, *palt);
+            return 0;
+        };
+        if (int rc = ap_pass(nnlo_pass, &e->buf[EFTB_B_TEMPL], &e->Talt)) return rc;
+        if (nnlo_inline)
+            if (int rc = ap_pass(true, &e->buf[EFTB_B_TEMPLN], &e->TaltN)) return rc;
     }
     if (mask & EFTB_S_REGROUP) {
         e->cur_nl = Nl;
@@ -840,6 +851,13 @@ static int launch_stages(eftb_engine* e, int mask, int B) {
     // with_NNLO: the counter-terms k^4 P11 lctNNLO go through the same linear stages as a second template block whose Pctl
     // slots carry them (reference pybird.py:1447-1458 Resum with Q[1], CctNNLO, lctNNLO; :1615 AP; window.py:399, 410):
     // everything but the tail, then the linear stages again with the NNLO operands swapped in, then LOGP / REDUCE.
+    // whole-pipeline steps without PROJECT / LOGP take the three-stream layout: the NNLO block has its own three rotating blocks and
+    // follows the main block through every stage inside one call
+    const bool fused0 = c.with_resum && c.Nl == 3 && e->resum_splits == 1 && !c.optiresum && !e->generic_resum;
+    const int whole = EFTB_S_PREP | EFTB_S_REGROUP | EFTB_S_RESUM | EFTB_S_AP;
+    if (fused0 && c.with_ap && (mask & whole) == whole && !(mask & (EFTB_S_PROJECT | EFTB_S_LOGP)) && e->prep_overlap && e->ap_overlap && e->inputs_settled &&
+        e->allow_back && !e->use_graphs && e->T3N && e->nnlo_inline)
+        return launch_stages_impl(e, mask, B, false, true);
     const int tail = mask & (EFTB_S_LOGP | EFTB_S_REDUCE);
     const int in_nl = (mask & EFTB_S_REGROUP) ? c.Nl : e->cur_nl, in_nx = (mask & EFTB_S_REGROUP) ? c.Nk : e->cur_nx;
     if (int rc = launch_stages_impl(e, mask & ~tail, B, false)) return rc;
@@ -959,6 +977,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_GENERIC_RESUM")) e->generic_resum = atoi(f) != 0;
     if (const char* f = getenv("EFTB_PREP_OVERLAP")) e->prep_overlap = atoi(f) != 0;
     if (const char* f = getenv("EFTB_PREP_AHEAD")) e->prep_ahead = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_NNLO_INLINE")) e->nnlo_inline = atoi(f) != 0;
     // Stream priorities.  With the regrouping and the operand build on the look-ahead stream, the look-ahead chain (a dozen latency-bound
     // kernels in series) is the critical path of a pipelined step and the resummation kernel the throughput work beside it: the chain gets
     // the high priority, the main stream the low one (measured at batch 128, evaluations/s: 266-269 k; all normal 265 k; main high and
@@ -1105,6 +1124,12 @@ int eftb_finalize(eftb_engine* e) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     }
     if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // third template block (engine.back)
+    if (e->ap_overlap && e->c.with_nnlo && e->c.with_ap && !e->T3N) {
+        HIPCHK(hipMalloc(&e->T3N, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
+        HIPCHK(hipMalloc(&e->TaltN, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
+        HIPCHK(hipMemset(e->T3N, 0, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
+        HIPCHK(hipMemset(e->TaltN, 0, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
+    }
     HIPCHK(hipDeviceSynchronize());  // null-stream zero fills (part, ZC, ZC2) are not ordered against the engine's non-blocking streams
     e->finalized = true;
     return 0;
@@ -1296,7 +1321,7 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->RSA2, e->RSC2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->RSA2, e->RSC2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->TaltN, e->T3N, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);

@@ -367,6 +367,55 @@ def test_overlapped_steps_are_bit_identical(golden, monkeypatch):
     eng.close()
 
 
+def test_overlapped_nnlo_steps_are_bit_identical(golden, monkeypatch):
+    """with_NNLO steps on the three-stream layout (the NNLO block rides through regrouping, the fused accumulator of the resummation kernel,
+    its own AP pass over the three counter-term rows and REDUCE inside one call, with its own three rotating blocks): queued asynchronous
+    runs must give exactly what an engine with every overlap switched off gives, and what the two-pass path gives."""
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    B = 16  # >= 16: unsplit s sums, i.e. the fused NNLO accumulator
+    cfg = EngineConfig(Nl=3, with_resum=True, with_ap=True, with_NNLO=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"]))
+    monkeypatch.setenv("EFTB_AP_OVERLAP", "0")
+    monkeypatch.setenv("EFTB_PREP_OVERLAP", "0")
+    serial = Engine(cfg, max_batch=B)
+    monkeypatch.delenv("EFTB_AP_OVERLAP")
+    monkeypatch.delenv("EFTB_PREP_OVERLAP")
+    monkeypatch.setenv("EFTB_NNLO_INLINE", "0")
+    twopass = Engine(cfg, max_batch=B)
+    monkeypatch.delenv("EFTB_NNLO_INLINE")
+    eng = Engine(cfg, max_batch=B)
+    rng = np.random.default_rng(12)
+    f0, DA0, H0 = float(g["f"]), float(g["DA"]), float(g["H"])
+    mask = eng.full_mask(reduce=True)
+    nk = g["k"].size
+    shape_t, shape_p = (B, 3, 24, nk), (B, 3, nk)
+    for nrun in (1, 2, 3, 5):
+        scale = 1.0 + 0.1 * rng.standard_normal(B)
+        f = f0 * (1.0 + 0.05 * rng.standard_normal(B))
+        DA, H = DA0 * (1.0 + 0.03 * rng.standard_normal(B)), H0 * (1.0 + 0.03 * rng.standard_normal(B))
+        Pin = scale[:, None] * g["Pin"][None, :]
+        bias = np.stack([bias_row(float(fi), list(g["bsA"]), None, tuple(g["es"]), kmA=0.7, krA=0.25, ndA=4.5e-5) for fi in f])
+        biasn = 0.1 * rng.standard_normal((B, 3))
+        want = None
+        for e in (serial, twopass, eng):
+            e.load_inputs(Pin, f, DA, H, bias)
+            e.put("BIASN", biasn)
+            for _ in range(1 if e is serial else nrun):
+                e.run(mask, B, sync=(e is serial))
+            got = (e.get("PLK", shape_p), e.get("TEMPL", shape_t), e.get("TEMPLN", shape_t))
+            if want is None:
+                want = got
+                assert np.any(got[2][:, :, 3:6] != 0.0) and not np.any(got[2][:, :, :3]) and not np.any(got[2][:, :, 6:])
+            else:
+                for a_, w_ in zip(got, want):
+                    assert np.array_equal(a_, w_), (nrun, e is eng)
+    for e in (serial, twopass, eng):
+        e.close()
+
+
 def test_pipelined_steps_with_changing_inputs(golden):
     """eftb_stage_inputs / eftb_run_staged / eftb_fetch_previous: a sampler loop whose inputs change every step, with the next step's
     inputs staged and the previous step's results fetched while a step is in flight -- every step must equal the synchronous call."""
