@@ -55,6 +55,11 @@ struct eftb_engine {
     double *RSA2 = nullptr, *RSC2 = nullptr;  // second operand set: the look-ahead builds run i+1's operands while run i's resummation reads its own
     hipEvent_t evRsDone[2] = {nullptr, nullptr};  // the resummation that read operand set [slot] has finished
     unsigned rs_step = 0;
+    // flow control of asynchronous runs: at most RUN_DEPTH runs are in flight (a caller that never synchronises cannot grow the runtime's
+    // command queues without bound; four runs ahead is more than the three-stream layout can use)
+    static constexpr int RUN_DEPTH = 4;
+    hipEvent_t evRun[RUN_DEPTH] = {};
+    unsigned long long run_seq = 0;
     bool nnlo_inline = true;  // EFTB_NNLO_INLINE=0: with_NNLO steps never take the three-stream layout
     bool prep_ahead = true;  // EFTB_PREP_AHEAD=0: regrouping and operand build stay on the main stream in front of the resummation
     // duration of the dominant kernel inside pipelined steps (EFTB_O_TIME_DOMINANT): HIP events on the stream it is launched on
@@ -1007,6 +1012,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipEventCreateWithFlags(&e->evJoin, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evJoinAP, hipEventDisableTiming));
     for (hipEvent_t& ev : e->evRsDone) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (hipEvent_t& ev : e->evRun) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (int t = 0; t < eftb_engine::NTIMER; ++t) {
         HIPCHK(hipEventCreate(&e->evT0[t]));
         HIPCHK(hipEventCreate(&e->evT1[t]));
@@ -1332,6 +1338,7 @@ void eftb_destroy(eftb_engine* e) {
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1], e->evRsDone[0], e->evRsDone[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->evRun) if (ev) (void)hipEventDestroy(ev);
     for (int t = 0; t < eftb_engine::NTIMER; ++t) {
         if (e->evT0[t]) (void)hipEventDestroy(e->evT0[t]);
         if (e->evT1[t]) (void)hipEventDestroy(e->evT1[t]);
@@ -1389,11 +1396,22 @@ int eftb_run(eftb_engine* e, int mask, int B) {
     if (!e->finalized) return fail("eftb_run: engine not finalized");
     if (B < 1 || B > e->c.max_batch) return fail("eftb_run: batch %d outside [1, %d]", B, e->c.max_batch);
     HIPCHK(hipSetDevice(e->c.device));
+    const int slot = (int)(e->run_seq % eftb_engine::RUN_DEPTH);
+    if (e->run_seq >= eftb_engine::RUN_DEPTH) {  // the run launched RUN_DEPTH calls ago must have finished (spin: it almost always has)
+        for (;;) {
+            const hipError_t q = hipEventQuery(e->evRun[slot]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail("eftb_run: %s", hipGetErrorString(q));
+        }
+    }
     e->inputs_settled = true;  // eftb_put is synchronous: the inputs of this run are in place, its first stage may start early
     e->allow_back = true;
     const int rc = run_stages(e, mask, B);
     e->inputs_settled = e->allow_back = false;
-    return rc;
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->evRun[slot], e->back_pending ? e->back : e->stream));  // the run ends where its back half ran
+    ++e->run_seq;
+    return 0;
 }
 
 int eftb_sync(eftb_engine* e) {

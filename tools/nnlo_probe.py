@@ -19,7 +19,7 @@ BS = [2.14, 0.55, 0.77, 0.55, -1.84, -1.89, -1.49]
 d = synth.draw_batch(B, z=Z)
 bias = np.stack([bias_row(float(f), BS, None, (0.26, 0.0, -0.93), kmA=0.7, krA=0.25, ndA=4.5e-5) for f in d["f"]])
 res = {}
-for nnlo in (False, True):
+for nnlo in ((True, False) if os.environ.get("NNLO_FIRST") else (False, True)):
     cfg = EngineConfig(Nl=3, k=synth.survey_kgrid(512), with_resum=True, with_ap=True, with_NNLO=nnlo,
                        DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
     eng = Engine(cfg, max_batch=B)
