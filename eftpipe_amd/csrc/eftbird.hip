@@ -145,7 +145,11 @@ struct eftb_engine {
     hipStream_t cpy = nullptr;
     hipEvent_t evStaged[NSETS] = {}, evSetDone[NSETS] = {};
     int cur_set = 0, staged_B = 0;
-    bool staged_plk_device = false;  // staged sets keep P_l in device memory (a communicator exists: RCCL sends from it) instead of mapped host memory
+    // staged sets keep P_l in device memory: with a communicator RCCL sends from it; without one the step's last stream copies it to page-locked
+    // host memory with the DMA engine (plk_host) -- measured 0.433 ms per step against 0.458 ms with REDUCE writing mapped host memory over PCIe
+    // from its waves (EFTB_STAGED_PLK_MAPPED=1 keeps that form)
+    bool staged_plk_device = false;
+    double* plk_host[NSETS] = {};
     bool generic_resum = false;  // EFTB_GENERIC_RESUM=1: Nl = 2 on resum_kernel<2> (the pre-matrix-core kernel, kept for A/B checks)
     int cur_nl = 0, cur_nx = 0;  // shape of the template block
     int resum_splits = 1;
@@ -161,6 +165,11 @@ struct eftb_engine {
     double* gathered = nullptr;
     double* gathered2[NSETS] = {};  // the gathered block rotates through three buffers: the root reads step i while steps i + 1, i + 2 are exchanged
     hipEvent_t evGath2[NSETS] = {};
+    // the root's gathered block is copied on to page-locked host memory by the DMA engine, in line behind the exchange (no host call blocks on
+    // the transfer): eftb_fetch_gathered / eftb_gathered_view read it there
+    double* gath_host[NSETS] = {};
+    hipEvent_t evGathHost[NSETS] = {};
+    size_t gath_elems[NSETS] = {};
     int gather_slot = 0;
     // the gather runs on its own stream from a snapshot of P_l, so that it overlaps the next step's kernels
     hipStream_t comm_stream = nullptr;
@@ -1331,6 +1340,8 @@ void eftb_destroy(eftb_engine* e) {
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
+        if (e->gath_host[q]) (void)hipHostFree(e->gath_host[q]);
+        if (e->evGathHost[q]) (void)hipEventDestroy(e->evGathHost[q]);
     }
     e->gathered = nullptr;  // (one of gathered2)
     for (void* p : {(void*)e->APW, (void*)e->APW2, (void*)e->API, (void*)e->API2, (void*)e->APM, (void*)e->APM2}) if (p) (void)hipFree(p);
@@ -1353,6 +1364,7 @@ void eftb_destroy(eftb_engine* e) {
         if (e->setblock[q]) (void)hipFree(e->setblock[q]);
         for (int id : {EFTB_B_PLK, EFTB_B_LOGP})
             if (e->setbuf[q][id]) {
+                if (id == EFTB_B_PLK && e->plk_host[q]) (void)hipHostFree(e->plk_host[q]);
                 if (id == EFTB_B_PLK && e->staged_plk_device) (void)hipFree(e->setbuf[q][id]);
                 else (void)hipHostFree(e->setbuf[q][id]);
             }
@@ -1543,7 +1555,7 @@ static int staged_setup(eftb_engine* e) {
     }
     e->stage_elems = (off + 1) & ~(size_t)1;  // whole double2s for the copy kernel
     for (int id : kStagedIds) e->orig[id] = e->buf[id];
-    e->staged_plk_device = e->comm != nullptr;
+    e->staged_plk_device = e->comm != nullptr || !(getenv("EFTB_STAGED_PLK_MAPPED") && atoi(getenv("EFTB_STAGED_PLK_MAPPED")));
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
         HIPCHK(hipMalloc(&e->setblock[q], e->stage_elems * sizeof(double)));
         HIPCHK(hipMemset(e->setblock[q], 0, e->stage_elems * sizeof(double)));
@@ -1555,6 +1567,10 @@ static int staged_setup(eftb_engine* e) {
             if (id == EFTB_B_PLK && e->staged_plk_device) {
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double)));
                 HIPCHK(hipMemset(e->setbuf[q][id], 0, e->buf_elems[id] * sizeof(double)));
+                if (!e->comm) {
+                    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->plk_host[q]), e->buf_elems[id] * sizeof(double), hipHostMallocDefault));
+                    memset(e->plk_host[q], 0, e->buf_elems[id] * sizeof(double));
+                }
                 continue;
             }
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double), hipHostMallocMapped));
@@ -1624,7 +1640,12 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     const int rc = run_stages(e, mask, B);
     e->inputs_settled = e->allow_back = false;
     if (rc) return rc;
-    HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], e->back_pending ? e->back : e->stream));  // the step ends where its back half ran
+    hipStream_t last = e->back_pending ? e->back : e->stream;  // the step ends where its back half ran
+    if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE))
+        HIPCHK(hipMemcpyAsync(e->plk_host[e->cur_set], e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
+    HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], last));
+    if (e->back_pending && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE))
+        HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], last));  // whoever joins the back half also waits for the copy
     return 0;
 }
 
@@ -1647,7 +1668,9 @@ int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count
         if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
             return fail("eftb_fetch_back: the step did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", limit_s);
     }
-    if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
+    if (id == EFTB_B_PLK && e->plk_host[t])
+        memcpy(host, e->plk_host[t], count * sizeof(double));  // copied out by the DMA engine behind the step
+    else if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
         HIPCHK(hipMemcpy(host, e->setbuf[t][id], count * sizeof(double), hipMemcpyDeviceToHost));
     else
         memcpy(host, e->setbuf[t][id], count * sizeof(double));  // the results are already in (mapped) host memory
@@ -1690,8 +1713,11 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
         e->gather_slot = (e->gather_slot + 1) % eftb_engine::NSETS;
         const int q = e->gather_slot;
         if (!e->gathered2[q]) {
-            HIPCHK(hipMalloc(&e->gathered2[q], (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double)));
+            const size_t bytes = (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk * sizeof(double);
+            HIPCHK(hipMalloc(&e->gathered2[q], bytes));
             HIPCHK(hipEventCreateWithFlags(&e->evGath2[q], hipEventDisableTiming));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->gath_host[q]), bytes, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&e->evGathHost[q], hipEventDisableTiming));
         }
         e->gathered = e->gathered2[q];
     }
@@ -1733,25 +1759,59 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
         NCCLCHK(g_rccl.GroupEnd());
     }
     HIPCHK(hipEventRecord(e->evGathered, cs));
-    if (e->rank == root) HIPCHK(hipEventRecord(e->evGath2[e->gather_slot], cs));
+    if (e->rank == root) {
+        const int q = e->gather_slot;
+        HIPCHK(hipEventRecord(e->evGath2[q], cs));
+        e->gath_elems[q] = (size_t)e->nranks * count;
+        // copy-out with the DMA engine, in line behind the exchange (measured with the PCIe traffic of eight ranks, 12.6 MB per step: 0.441 ms
+        // per step; on a stream of its own 0.52 ms -- a sixth stream shares a hardware queue with the look-ahead --; a copy kernel writing
+        // mapped host memory 0.62 ms)
+        HIPCHK(hipMemcpyAsync(e->gath_host[q], e->gathered2[q], e->gath_elems[q] * sizeof(double), hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipEventRecord(e->evGathHost[q], cs));
+    }
     if (on_back) HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], cs));  // whoever joins the back half also waits for the exchange
     if (host_out && e->rank == root) {
-        HIPCHK(hipMemcpyAsync(host_out, e->gathered, (size_t)e->nranks * count * sizeof(double), hipMemcpyDeviceToHost, cs));
-        HIPCHK(hipStreamSynchronize(cs));
+        HIPCHK(hipEventSynchronize(e->evGathHost[e->gather_slot]));
+        memcpy(host_out, e->gath_host[e->gather_slot], (size_t)e->nranks * count * sizeof(double));
     }
+    return 0;
+}
+
+// waits for the copy-out of the exchange `which` exchanges back and returns where its block sits in host memory
+static int gathered_ready(eftb_engine* e, const char* who, int which, int* slot) {
+    if (which < 0 || which >= eftb_engine::NSETS) return fail("%s: `back` must be 0 (the last exchange enqueued), 1, 2 or 3 (that many exchanges before it)", who);
+    const int q = (e->gather_slot + eftb_engine::NSETS - which) % eftb_engine::NSETS;
+    if (!e->gathered2[q] || !e->gath_elems[q]) return fail("%s: no such exchange yet", who);
+    HIPCHK(hipSetDevice(e->c.device));
+    static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t r = hipEventQuery(e->evGathHost[q]);
+        if (r == hipSuccess) break;
+        if (r != hipErrorNotReady) return fail("%s: %s", who, hipGetErrorString(r));
+        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+            return fail("%s: the exchange did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", who, limit_s);
+    }
+    *slot = q;
+    return check_status(e, who);
+}
+
+int eftb_gathered_view(eftb_engine* e, int which, const double** block, size_t* count) {
+    if (!e || !block) return fail("eftb_gathered_view: null argument");
+    int q = 0;
+    if (int rc = gathered_ready(e, "eftb_gathered_view", which, &q)) return rc;
+    *block = e->gath_host[q];
+    if (count) *count = e->gath_elems[q];
     return 0;
 }
 
 int eftb_fetch_gathered(eftb_engine* e, int which /* = back */, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_gathered: null argument");
-    if (which < 0 || which >= eftb_engine::NSETS) return fail("eftb_fetch_gathered: `back` must be 0 (the last exchange enqueued), 1, 2 or 3 (that many exchanges before it)");
-    const int q = (e->gather_slot + eftb_engine::NSETS - which) % eftb_engine::NSETS;
-    if (!e->gathered2[q]) return fail("eftb_fetch_gathered: no such exchange yet");
-    if (count > (size_t)e->nranks * e->c.max_batch * e->c.Nl * e->c.Nk) return fail("eftb_fetch_gathered: asked %zu elements", count);
-    HIPCHK(hipSetDevice(e->c.device));
-    HIPCHK(hipEventSynchronize(e->evGath2[q]));
-    HIPCHK(hipMemcpy(host, e->gathered2[q], count * sizeof(double), hipMemcpyDeviceToHost));
-    return check_status(e, "eftb_fetch_gathered");
+    int q = 0;
+    if (int rc = gathered_ready(e, "eftb_fetch_gathered", which, &q)) return rc;
+    if (count > e->gath_elems[q]) return fail("eftb_fetch_gathered: the exchange holds %zu elements, asked %zu", e->gath_elems[q], count);
+    memcpy(host, e->gath_host[q], count * sizeof(double));
+    return 0;
 }
 
 int eftb_mfma_f64_peak(int device, double* tflops) {

@@ -257,12 +257,15 @@ int  eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]);
  * communication stream instead);
  * if host_out != NULL (root only) the gathered block [nranks][B][Nl][Nx] is copied out after the gather. */
 int  eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out);
-/* Pipelined multi-GPU steps (eftb_stage_inputs / eftb_run_staged / eftb_gather_plk per step, nothing waits for the step in flight): the
- * gathered block rotates through three device buffers; this copies out, on the root, the block ([nranks][B][nl][nx], count elements)
- * of the last exchange enqueued (back = 0) or of the one `back` (1 or 2) exchanges before it, waiting only for that exchange.  With a
- * communicator (eftb_comm_init, to be called before the first eftb_stage_inputs) the staged sets keep P_l in device memory, where
- * RCCL reads it. */
+/* Pipelined multi-GPU steps (eftb_stage_inputs / eftb_run_staged / eftb_gather_plk per step, nothing waits for the step in flight): on the
+ * root the gathered block rotates through four device buffers, and each is copied on to page-locked host memory by a copy kernel on its own
+ * stream as soon as its exchange has finished -- 12.6 MB per step at 8 ranks, which a blocking device-to-host copy into pageable memory would
+ * turn into the bottleneck of the whole node.  eftb_fetch_gathered copies the block ([nranks][B][nl][nx], count elements) of the last exchange
+ * enqueued (back = 0) or of the one `back` (1 ... 3) exchanges before it into `host`, waiting only for that exchange; eftb_gathered_view hands
+ * out the page-locked block itself instead (no host copy; valid until three more exchanges have been enqueued).  With a communicator
+ * (eftb_comm_init, to be called before the first eftb_stage_inputs) the staged sets keep P_l in device memory, where RCCL reads it. */
 int  eftb_fetch_gathered(eftb_engine* e, int back, double* host, size_t count);
+int  eftb_gathered_view(eftb_engine* e, int back, const double** block, size_t* count);
 
 /* Window precompute (reference Window._compute_Wal / _compute_Waldk, window.py:262-359) on the device.  The caller passes
  * the k-independent tables of eftpipe_amd.tables.window_tables: x [nx] (FFTLog samples inside the tabulated window), Qt

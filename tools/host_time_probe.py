@@ -23,9 +23,13 @@ for i in range(6):
     d = synth.draw_batch(B, z=Z, seed=100 + i)
     d["bias"] = np.stack([bias_row(float(f), BS, None, (0.26, 0.0, -0.93), kmA=0.7, krA=0.25, ndA=4.5e-5) for f in d["f"]])
     sets.append(d)
+comm = bool(os.environ.get("HP_COMM"))
+if comm:  # one-rank RCCL self exchange: the per-step host cost of the multi-GPU loop on the root
+    from eftpipe_amd.engine import comm_unique_id
+    eng.comm_init(1, 0, comm_unique_id())
 mask = eng.full_mask(reduce=True)
 out = np.empty((B, 3, 512))
-t = {"stage": 0.0, "run": 0.0, "fetch": 0.0}
+t = {"stage": 0.0, "run": 0.0, "gather": 0.0, "fetch": 0.0}
 for rep in range(2):
     for k in t:
         t[k] = 0.0
@@ -37,16 +41,26 @@ for rep in range(2):
         b = time.perf_counter()
         eng.run_staged(mask, B)
         c = time.perf_counter()
+        if comm:
+            eng.gather_plk(B, root=0)
+        g_ = time.perf_counter()
         if i > 2:
-            eng.fetch_previous("PLK", (B, 3, 512), out=out, back=3)
+            if comm:
+                out[:] = eng.fetch_gathered(B, back=2, copy=False)[0]
+            else:
+                eng.fetch_previous("PLK", (B, 3, 512), out=out, back=3)
         e = time.perf_counter()
         t["stage"] += b - a
         t["run"] += c - b
-        t["fetch"] += e - c
+        t["gather"] += g_ - c
+        t["fetch"] += e - g_
     eng.sync()
     tot = time.perf_counter() - t0
 print(f"B={B}: {tot / N * 1e3:.3f} ms per step; host per step: stage_inputs {t['stage'] / N * 1e6:.0f} us, run_staged {t['run'] / N * 1e6:.0f} us, "
-      f"fetch_previous(back=3) {t['fetch'] / N * 1e6:.0f} us (wait + 1.5 MB copy)")
+      f"gather_plk {t['gather'] / N * 1e6:.0f} us, fetch {t['fetch'] / N * 1e6:.0f} us (wait + 1.5 MB copy)")
+if comm:
+    eng.close()
+    sys.exit(0)
 # the copy alone: fetch of a step that finished long ago
 eng.sync()
 a = time.perf_counter()
