@@ -146,7 +146,7 @@ struct eftb_engine {
     hipEvent_t evStaged[NSETS] = {}, evSetDone[NSETS] = {};
     int cur_set = 0, staged_B = 0;
     // staged sets keep P_l in device memory: with a communicator RCCL sends from it; without one the step's last stream copies it to page-locked
-    // host memory with the DMA engine (plk_host) -- measured 0.433 ms per step against 0.458 ms with REDUCE writing mapped host memory over PCIe
+    // host memory with the DMA engine (plk_host) -- measured 0.447 ms per step against 0.455 ms with REDUCE writing mapped host memory over PCIe
     // from its waves (EFTB_STAGED_PLK_MAPPED=1 keeps that form)
     bool staged_plk_device = false;
     double* plk_host[NSETS] = {};
@@ -1560,9 +1560,9 @@ static int staged_setup(eftb_engine* e) {
         HIPCHK(hipMalloc(&e->setblock[q], e->stage_elems * sizeof(double)));
         HIPCHK(hipMemset(e->setblock[q], 0, e->stage_elems * sizeof(double)));
         for (int id : kStagedIn) e->setbuf[q][id] = e->buf_elems[id] ? e->setblock[q] + e->stage_off[id] : nullptr;
-        // the per-step outputs (P_l, ln P) live in page-locked host memory mapped into the device: the kernels write them over PCIe
-        // as they finish, and fetching is a wait on the step's event plus a host copy -- no D2H transfer, whose cache maintenance
-        // was measured to stall the compute queue for ~70 us per step
+        // per-step outputs: ln P (a few KB) lives in page-locked host memory mapped into the device and is written by the kernel itself;
+        // P_l stays in device memory and is copied to page-locked host memory by the DMA engine on the stream the step ends on (the back-half
+        // stream in pipelined steps: round 1 measured ~70 us of stalled compute queue per step for such a transfer on the COMPUTE stream)
         for (int id : kStagedOut) {
             if (id == EFTB_B_PLK && e->staged_plk_device) {
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double)));
@@ -1616,6 +1616,7 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     }
     hipStream_t cs = e->cpy;
     HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[t], 0));  // the last run on this set (and the fetch of its results) is over
+    // (a copy kernel reading the mapped staging block, not a DMA transfer: 0.4 MB is latency, and the DMA form measured the same or worse)
     hipLaunchKernelGGL(stage_copy_kernel, dim3(64), dim3(256), 0, cs, reinterpret_cast<const double2*>(h), reinterpret_cast<double2*>(e->setblock[t]),
                        (e->stage_elems + 1) / 2);
     HIPCHK(hipEventRecord(e->evStaged[t], cs));
