@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(int Nkin, int ntail, int
 //   expand_kernel      the 28 / 10 loop matrices per l from the synthesised basis rows
 // ------------------------------------------------------------------------------------------------
 constexpr int AD_T = NHALF + 2;   // anti-diagonal length (129) rounded up to even
-constexpr int AD_CH = 3, AD_TC = 44;  // the anti-diagonal is cut into AD_CH chunks of AD_TC pairs (partial sums, added by build_rows_kernel)
+constexpr int AD_CH = 3, AD_TC = 44;  // (measured at batch 128: 1 / 2 / 3 / 6 / 9 chunks -> 89 / 68 / 62 / 65 / 80 us for the P22 path)  // the anti-diagonal is cut into AD_CH chunks of AD_TC pairs (partial sums, added by build_rows_kernel)
 constexpr int KSYN = 528;         // 1 + 2*256 synthesis coefficients, zero padded to a multiple of SYN_KPAD
 constexpr int KLIN = 288;         // 1 + 2*128, likewise
 constexpr int SYN_KPAD = 48;      // every K of a synthesis / first-stage GEMM is zero padded to a multiple of this
