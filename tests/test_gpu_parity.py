@@ -367,6 +367,29 @@ def test_overlapped_steps_are_bit_identical(golden, monkeypatch):
     eng.close()
 
 
+def test_dominant_kernel_timer(golden):
+    """EFTB_O_TIME_DOMINANT: HIP events around every launch of the resummation kernel, on its own stream (what bench.py's roofline divides by)."""
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=16)
+    eng.load_inputs(np.stack([g["Pin"]] * 16), float(g["f"]), float(g["DA"]), float(g["H"]))
+    mask = eng.full_mask()
+    eng.run(mask, 16)
+    assert eng.dominant_time() == (0.0, 0)  # off by default
+    eng.time_dominant(True)
+    for _ in range(11):
+        eng.run(mask, 16, sync=False)
+    ms, n = eng.dominant_time(reset=False)
+    assert n == 11 and 0.0 < ms / n < 5.0
+    assert eng.dominant_time()[1] == 11 and eng.dominant_time() == (0.0, 0)
+    eng.time_dominant(False)
+    eng.run(mask, 16)
+    assert eng.dominant_time()[1] == 0
+    eng.close()
+
+
 def test_overlapped_nnlo_steps_are_bit_identical(golden, monkeypatch):
     """with_NNLO steps on the three-stream layout (the NNLO block rides through regrouping, the fused accumulator of the resummation kernel,
     its own AP pass over the three counter-term rows and REDUCE inside one call, with its own three rotating blocks): queued asynchronous

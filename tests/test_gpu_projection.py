@@ -156,6 +156,7 @@ def test_interpolation_operator_then_marginalised_logp(golden):
 def test_rccl_gather_single_rank(golden):
     """World size 1 exercises the whole RCCL code path short of the wire: lazy dlopen, unique id,
     ncclCommInitRank, gather into the root buffer, copy-out."""
+    from eftpipe_amd import _lib as L
     from eftpipe_amd.engine import Engine, comm_unique_id
     from eftpipe_amd.parambasis import bias_row
     from eftpipe_amd.tables import EngineConfig
@@ -181,6 +182,22 @@ def test_rccl_gather_single_rank(golden):
     eng.run(eng.full_mask(reduce=True), 3, sync=False)
     last = eng.gather_plk(3, root=0, to_host=True)
     assert np.array_equal(last, out)
+    # every exchange leaves its block in page-locked host memory (DMA behind the exchange): copies and zero-copy views of the last four
+    blocks = []
+    for scale in (1.0, 2.0, 3.0, 4.0):
+        eng.put("BIAS", bias * scale)
+        eng.run(eng.full_mask(reduce=True), 3, sync=False)
+        eng.gather_plk(3, root=0)
+        eng.sync()
+        blocks.append(eng.get("PLK", (3, 2, 50)))
+    for back in range(4):
+        want = blocks[3 - back]
+        view = eng.fetch_gathered(3, back=back, copy=False)
+        assert view.shape == (1, 3, 2, 50) and not view.flags.writeable
+        assert np.array_equal(view[0], want) and np.array_equal(eng.fetch_gathered(3, back=back)[0], want)
+    with pytest.raises(L.EftbError):
+        eng.fetch_gathered(3, back=4)
+    del view
     eng.close()
 
 
