@@ -1434,6 +1434,143 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
     }
 }
 
+// ap_moments_kernel (the round-1 form of the stage, kept for fine k grids: at Nk = 2048 a 2 % distortion crosses ~45 knots, more than the
+// weight tables of the fast path hold per k, and every tile would fall back to the node-by-node quadrature of ap_direct_kernel).  The interval
+// moments are binomial combinations of the mu prefix sums of ap_prefix_kernel taken at the node indices where k'(mu) crosses the knots, so a
+// (row, k, l) costs 12 FMAs per interval crossed instead of a 200-node loop.
+// Workgroup = 64 k x 4 waves of one cosmology; wave <-> interval slot (s = wave, wave + 4, ...), so
+// the intervals that k'(mu) crosses are handled in parallel: slot s of a k is interval i = i_first + s dir, and its
+// node range [ja, jb) comes from the closed-form crossings of its two knots (the same function of (kq, knot) in both
+// neighbouring slots, so the ranges tile [0, nmu) exactly).  Knots and roots sit in LDS; the four waves' partial sums
+// are added through LDS in a fixed order.
+template <int NL, int NR, int RS>
+__global__ __launch_bounds__(256, 2) void ap_moments_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+                                                       const double* __restrict__ Hw, const double* __restrict__ fid,
+                                                       const double* __restrict__ mu, const double* __restrict__ PS,
+                                                       const double* __restrict__ ROOT, const double* __restrict__ T,
+                                                       const double* __restrict__ YS, double* __restrict__ Tout) {
+    constexpr int NS = NL * NL * 4;
+    constexpr int NRT = (NR + RS - 1) / RS;  // rows per lane: the NR rows are split over RS workgroups (blockIdx.z)
+    constexpr int NACC = NL * NRT;
+    extern __shared__ double sm[];
+    double* s_k = sm;               // [Nk]
+    double* s_root = sm + Nk;       // [nmu]
+    double* red = sm + Nk + nmu;    // [4][NACC][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, w = blockIdx.y, rbase = blockIdx.z * NRT;
+    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
+    for (int e = threadIdx.x; e < nmu; e += 256) s_root[e] = ROOT[(size_t)w * nmu + e];
+    __syncthreads();
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
+    const bool live = k < Nk;
+    const double kq = s_k[live ? k : Nk - 1] / qperp;
+    const double* ps = PS + (size_t)w * (nmu + 1) * NS;
+    const bool up = g > 0.0;  // k'(mu) rises or falls with mu
+    const int dir = up ? 1 : -1;
+    const double jscale = (nmu - 1) / mu[nmu - 1];  // node index per unit mu (uniform grid: only a first guess, see the fix-up)
+    double acc[NL][NRT];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[l][r] = 0.0;
+    // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling)
+    auto cross = [&](double kb) -> int {
+        const double rc = kb / kq, x = (rc * rc - 1.0) / g;  // mu^2 at the crossing
+        int j = nmu;
+        if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
+        j = max(0, min(j, nmu));
+        while (j > 0 && (up ? kq * s_root[j - 1] >= kb : kq * s_root[j - 1] < kb)) --j;
+        while (j < nmu && !(up ? kq * s_root[j] >= kb : kq * s_root[j] < kb)) ++j;
+        return j;
+    };
+    const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
+    const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
+    const int nslot = live ? (up ? i_last - i_first : i_first - i_last) + 1 : 0;
+    for (int s = wave; s < nslot; s += 4) {
+        const int i = i_first + s * dir;
+        const double klo = s_k[i], khi = s_k[i + 1];
+        const int ja = s == 0 ? 0 : cross(up ? klo : khi);
+        const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
+        if (jb <= ja) continue;
+        const double h = khi - klo, ih = 1.0 / h;
+        const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
+        const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
+        const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
+        const double* pa = ps + (size_t)ja * NS;
+        const double* pb = ps + (size_t)jb * NS;
+        const double* cw = YS + ((size_t)w * NL * NROW * Nk + i) * 2;
+        // memory round trips are what this kernel waits for (PMC: 75 % of the wave cycles): the prefix sums of all l' are
+        // fetched in one batch, and the spline data of l' + 1 is in flight while l' is being accumulated
+        double ms[NL][NL][4];
+        {
+            double4 a4[NL][NL], b4[NL][NL];
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    b4[lp][l] = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
+                    a4[lp][l] = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
+                }
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp)
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const double d0 = b4[lp][l].x - a4[lp][l].x, d1 = b4[lp][l].y - a4[lp][l].y;
+                    const double d2 = b4[lp][l].z - a4[lp][l].z, d3 = b4[lp][l].w - a4[lp][l].w;
+                    ms[lp][l][0] = d0;
+                    ms[lp][l][1] = fma(c10, d0, c11 * d1);
+                    ms[lp][l][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
+                    ms[lp][l][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+                }
+        }
+        double2 ya[2][NRT], yb[2][NRT];
+        auto fetch = [&](int lp, int buf) {
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const double2* cp = reinterpret_cast<const double2*>(cw + ((size_t)lp * NROW + min(rbase + r, NR - 1)) * Nk * 2);
+                ya[buf][r] = cp[0];  // (y_i, s_i)
+                yb[buf][r] = cp[1];  // (y_i+1, s_i+1)
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            if (lp + 1 < NL) fetch(lp + 1, (lp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the arithmetic that consumes the previous buffer
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                const double2 ca = ya[lp & 1][r], cb = yb[lp & 1][r];  // -> power form on [k_i, k_i+1]
+                const double sl = (cb.x - ca.x) * ih;
+                const double c3 = (ca.y + cb.y - 2.0 * sl) * ih * ih;
+                const double c2 = (sl - ca.y) * ih - c3 * h;
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+                    acc[l][r] = fma(ms[lp][l][0], ca.x, fma(ms[lp][l][1], ca.y, fma(ms[lp][l][2], c2, fma(ms[lp][l][3], c3, acc[l][r]))));
+            }
+        }
+    }
+    // sum the four waves in a fixed order and write
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) red[(wave * NACC + l * NRT + r) * 64 + lane] = acc[l][r];
+    __syncthreads();
+    const double c = 2.0 / (qperp * qperp * qpar);
+    for (int e = wave; e < NACC; e += 4) {
+        const int l = e / NRT, r = e % NRT;
+        const double v = (red[(0 * NACC + e) * 64 + lane] + red[(1 * NACC + e) * 64 + lane]) + (red[(2 * NACC + e) * 64 + lane] + red[(3 * NACC + e) * 64 + lane]);
+        if (live && rbase + r < NR) Tout[(((size_t)w * NL + l) * NROW + rbase + r) * Nk + k] = c * v;
+    }
+    constexpr int NCP = NROW - NR > 0 ? NROW - NR : 1;  // rows that APeffect leaves alone (Pstl unless APst)
+    if (live && NR < NROW && blockIdx.z == 0)
+        for (int e = wave; e < NCP * NL; e += 4) {
+            const int l = e / NCP, r = NR + e % NCP;
+            const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
+            Tout[o] = T[o];
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // AP, two-kernel form (the default path; ap_direct_kernel above is the fallback for distortions that cross more knot
 // intervals than the fast path keeps).  The stage is LINEAR in the spline data: for one cosmology and one output k

@@ -77,6 +77,10 @@ struct eftb_engine {
     int *API = nullptr, *API2 = nullptr;
     int4 *APM = nullptr, *APM2 = nullptr;
     bool ap_fast = true;  // EFTB_AP_FAST=0: every tile through ap_direct_kernel (the reference's quadrature, otherwise the fallback)
+    // EFTB_AP_MODE: 0 = knot weights + banded product (ap_weights / ap_rows; tiles it cannot hold fall back to ap_direct), 1 = interval moments
+    // from the mu prefix sums (ap_moments_kernel: cost grows with the intervals crossed, not with a table size), 2 = the reference's quadrature
+    // everywhere; default: 1 for k grids so fine that a 2 % distortion at the last k crosses more than half the knots the weight tables hold
+    int ap_mode = 0;
     int ap_chunk = 7;     // template rows per chunk of ap_rows_kernel (Nl = 3: EFTB_AP_CHUNK=7|8|12; Nl = 2: 8|12)
     bool fuse_cf = true;  // EFTB_FUSE_CF=0: always through regroup_cf_kernel (A/B switch)
     int resum_wps = 2;    // waves per SIMD resum_mfma_kernel is built for: 2 = basis coefficients in registers (201 VGPRs); EFTB_RESUM_WPS=3 = basis
@@ -766,7 +770,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // one AP pass over a template block: *pin -> *palt, then the two trade places.  nn: the NNLO block carries only the three
         // counter-term rows 3-5 of every multipole: spline and AP touch those alone
         auto ap_pass = [&](bool nn, double** pin, double** palt) -> int {
-            const int rlo = nn ? 3 : 0, rsel = nn ? 3 : NROW;
+            const bool moments = e->ap_mode == 1;  // (works on whole blocks: the NNLO block's zero rows stay zero)
+            const int rlo = nn && !moments ? 3 : 0, rsel = nn && !moments ? 3 : NROW;
             const int nseries = B * Nl * rsel;
             {
                 const int kt = (Nk + 63) / 64;
@@ -775,11 +780,23 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, EFTB_T_SPBAND), e->SD);
             }
             // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
-            const int nr = nn ? 6 : (c.ap_stochastic ? NROW : 21);
+            const int nr = nn ? (moments ? 21 : 6) : (c.ap_stochastic ? NROW : 21);
             if (!side_ap && !nn) launch_ap_prefix(e, st, B);
             if (!joined_ap) {
                 if (hipStreamWaitEvent(st, e->evJoinAP, 0) != hipSuccess) return fail("eftb_run: stream join failed");
                 joined_ap = true;
+            }
+            if (moments) {
+                const dim3 apgrid((Nk + 63) / 64, B, 3);
+                const size_t aplds = ((size_t)Nk + c.nmu + (size_t)4 * Nl * ((nr + 2) / 3) * 64) * sizeof(double);
+#define APM_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, *pin, e->SD, *palt
+                if (Nl == 3 && nr == 21) hipLaunchKernelGGL((ap_moments_kernel<3, 21, 3>), apgrid, dim3(256), aplds, st, APM_ARGS);
+                else if (Nl == 3) hipLaunchKernelGGL((ap_moments_kernel<3, NROW, 3>), apgrid, dim3(256), aplds, st, APM_ARGS);
+                else if (nr == 21) hipLaunchKernelGGL((ap_moments_kernel<2, 21, 3>), apgrid, dim3(256), aplds, st, APM_ARGS);
+                else hipLaunchKernelGGL((ap_moments_kernel<2, NROW, 3>), apgrid, dim3(256), aplds, st, APM_ARGS);
+#undef APM_ARGS
+                std::swap(*pin, *palt);
+                return 0;
             }
             if (e->ap_fast) {
                 // banded product of the knot weights with the spline data; rows outside [rlo, nr) are copied through
@@ -1137,6 +1154,18 @@ int eftb_finalize(eftb_engine* e) {
         // (the kernel also holds a few static words: the dynamic part must leave room for them below the 160 KB of a CU)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        {   // which form of the AP stage (see engine.ap_mode): needs the k grid, so it is decided here
+            std::vector<double> kh(c.Nk);
+            HIPCHK(hipMemcpy(kh.data(), tb<double>(e, EFTB_T_K), c.Nk * sizeof(double), hipMemcpyDeviceToHost));
+            const double dk = kh[c.Nk - 1] - kh[c.Nk - 2];
+            e->ap_mode = dk > 0.0 && 0.02 * kh[c.Nk - 1] / dk > APW_DCAP / 2 ? 1 : 0;
+            if (const char* f = getenv("EFTB_AP_MODE")) e->ap_mode = atoi(f);
+            if (!e->ap_fast) e->ap_mode = 2;
+            e->ap_fast = e->ap_mode == 0;
+#define APM_LDS(NLV, NRV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_moments_kernel<NLV, NRV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
+            APM_LDS(3, 21); APM_LDS(3, NROW); APM_LDS(2, 21); APM_LDS(2, NROW);
+#undef APM_LDS
+        }
     }
     if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // third template block (engine.back)
     if (e->ap_overlap && e->c.with_nnlo && e->c.with_ap && !e->T3N) {

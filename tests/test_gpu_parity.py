@@ -108,12 +108,18 @@ def test_final_nk2048(golden):
     eng.close()
 
 
-@pytest.mark.parametrize("name,APst", [("caseE", False), ("caseD", False), ("caseD", True), ("caseF", False)])
-def test_ap_extreme_distortions(golden, name, APst):
+@pytest.mark.parametrize("name,APst,mode", [("caseE", False, None), ("caseD", False, None), ("caseD", True, None), ("caseF", False, None),
+                                            ("caseD", False, "1"), ("caseD", True, "1"), ("caseE", False, "1"), ("caseD", False, "2"),
+                                            ("caseF", False, "0")])
+def test_ap_extreme_distortions(golden, monkeypatch, name, APst, mode):
     """AP stage alone over a batch of strong distortions: many knot intervals crossed (rising and falling k'(mu)),
-    extrapolation past both ends of the k grid, the identity, and the isotropic F = 1 case."""
+    extrapolation past both ends of the k grid, the identity, and the isotropic F = 1 case.  mode: the engine's choice (knot weights +
+    banded product with the quadrature fallback for tiles it cannot hold; interval moments at Nk = 2048) or one form forced through
+    EFTB_AP_MODE (0 weights / fallback, 1 interval moments, 2 the reference's quadrature everywhere)."""
     from eftpipe_amd import _lib as L
 
+    if mode is not None:
+        monkeypatch.setenv("EFTB_AP_MODE", mode)
     g = golden(name)
     Nl, Nk = int(g["Nl"]), g["k"].size
     orc = oracle_engine(g, name, window_file=None, kout=None)
