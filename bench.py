@@ -162,8 +162,8 @@ def main():
         exchange = "rccl" if cp.max(1.0 - ok) == 0.0 else "host-fallback"
 
     # ---- every draw set of the run, generated before the clock starts: W + K sets of B new cosmologies per rank
-    def draw_set(i):
-        d = synth.draw_batch(B, z=Z, seed=12345 + 7919 * i + 104729 * rank)
+    def draw_set(i, nb=None):
+        d = synth.draw_batch(nb or B, z=Z, seed=12345 + 7919 * i + 104729 * rank)
         d["bias"] = np.stack([bias_row(float(f), BS, None, ES, kmA=0.7, krA=0.25, ndA=4.5e-5) for f in d["f"]])
         return d
 
@@ -257,6 +257,31 @@ def main():
                 d = sets[1 + i % (len(sets) - 1)]
                 eng.eval_batch(d["Pin"], d["f"], d["DA"], d["H"], out=pin)
             extras["templates_back_evaluations_per_s"] = B * 4 / (time.perf_counter() - t1)
+            # (2b) the batch size is a throughput knob: the same pipelined loop (new inputs staged and P_l fetched every step) at 256 per step
+            if world == 1 and not force_comm and B == 128:
+                try:
+                    B2, n2 = 256, 12
+                    eng2 = Engine(cfg, max_batch=B2, device=device)
+                    sets2 = [draw_set(1000 + i, B2) for i in range(n2 + 3)]
+                    out2 = np.empty((B2, NL, NK))
+                    for phase, cnt in (("warm", 3), ("timed", n2)):
+                        if phase == "timed":
+                            eng2.sync()
+                            t1 = time.perf_counter()
+                        for i in range(cnt):
+                            d = sets2[i if phase == "warm" else 3 + i]
+                            eng2.stage_inputs(d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"])
+                            eng2.run_staged(mask, B2)
+                            if i >= DEPTH:
+                                eng2.fetch_previous("PLK", (B2, NL, NK), out=out2, back=DEPTH)
+                        for back in range(min(DEPTH, cnt) - 1, 0, -1):
+                            eng2.fetch_previous("PLK", (B2, NL, NK), out=out2, back=back)
+                        eng2.sync()
+                        eng2.get("PLK", (B2, NL, NK))
+                    extras["value_at_batch_256"] = B2 * n2 / (time.perf_counter() - t1)
+                    eng2.close()
+                except Exception as exc:  # pragma: no cover
+                    extras["value_at_batch_256_error"] = repr(exc)
             # (3) the drop-in path as theory.py drives it (one cosmology per call through the pybird mirror classes, production grid)
             try:
                 from tools.dropin_probe import dropin_latency_ms
