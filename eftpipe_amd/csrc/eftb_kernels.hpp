@@ -143,12 +143,15 @@ __global__ __launch_bounds__(64) void antidiag_kernel(int B, int Bmax, const dou
 //   blockIdx.y = 1: the Nl*nc weighted rows Ml[l] S_c (ACF[w][BASC][KSYN]) and the nlc Nl C11 / Cct (/ CctNNLO) rows (ALC[w][nlc Nl][KLIN])
 // as real synthesis coefficients (Re Z_0, Re Z_1, Im Z_1, ...).  `sets` bit 0/1: quadratic rows of y = 0/1, bit 2/3: linear rows.
 template <int NC>
-__global__ __launch_bounds__(320) void build_rows_kernel(int sets, int Bmax, int Nl, int nlc, int nb, const double* __restrict__ coef,
+__global__ __launch_bounds__(256) void build_rows_kernel(int sets, int Bmax, int Nl, int nlc, int nb, const double* __restrict__ coef,
                                                          const double2* __restrict__ S, const double2* __restrict__ mlj,
                                                          const double2* __restrict__ linvec, double* __restrict__ A22,
                                                          double* __restrict__ A13, double* __restrict__ ACF, double* __restrict__ ALC) {
-    const int w = blockIdx.x, cf = blockIdx.y, jp = threadIdx.x;
-    if (((sets >> cf) & 1) && jp < NPOW) {
+    // 256 threads (four waves, one per SIMD): a fifth wave for the 257th harmonic would need a second free slot on one SIMD, which a CU that
+    // holds two resummation waves per SIMD does not have -- thread 0 takes j' = 256 in a second trip instead
+    const int w = blockIdx.x, cf = blockIdx.y;
+    if ((sets >> cf) & 1)
+    for (int jp = threadIdx.x; jp < NPOW; jp += 256) {
         double zr[NC], zi[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
@@ -1314,11 +1317,13 @@ __device__ inline int knot_interval(const double* __restrict__ kk, int Nk, doubl
 // (intervals crossed, ~3) x 4 NL FMAs.  No mu loop, no LDS, no divergence beyond the number of intervals crossed.
 // ------------------------------------------------------------------------------------------------
 template <int NL>
-__global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* __restrict__ DAw, const double* __restrict__ Hw,
+__global__ __launch_bounds__(256) void ap_prefix_kernel(int nmu, const double* __restrict__ DAw, const double* __restrict__ Hw,
                                                         const double* __restrict__ fid, const double* __restrict__ mu,
                                                         const double* __restrict__ wmu, const double* __restrict__ legmu,
                                                         double* __restrict__ PS, double* __restrict__ ROOT) {
-    constexpr int NS = NL * NL * 4, NCH = 8;  // sequences (l', l, q), chunks of the mu range per sequence
+    // sequences (l', l, q), chunks of the mu range per sequence: NS x NCH threads, at most 256 (four waves, one per SIMD: a fifth would need
+    // a second free slot on one SIMD of a CU that also holds two resummation waves per SIMD)
+    constexpr int NS = NL * NL * 4, NCH = NL == 3 ? 7 : 8;
     extern __shared__ double sm[];
     double* s_rho = sm;                    // [nmu]
     double* s_lp = sm + nmu;               // [NL][nmu]  L_l'(mu')

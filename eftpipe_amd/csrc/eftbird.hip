@@ -325,10 +325,10 @@ static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets,
                  e->ACF, e->ALC
     if (nc == 9) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(64), 0, st, AD_ARGS);
-        hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(320), 0, st, ROW_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(256), 0, st, ROW_ARGS);
     } else if (nc == 7) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(64), 0, st, AD_ARGS);
-        hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(320), 0, st, ROW_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(256), 0, st, ROW_ARGS);
     } else {
         return fail("loop-matrix basis of dimension %d + %d is not instantiated (expected 7 + 2)", c.nbasis, c.with_resum ? c.nbasis13 : 0);
     }
@@ -439,8 +439,8 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     const size_t pflds = ((size_t)(1 + 2 * c.Nl) * c.nmu + (size_t)c.Nl * c.Nl * 4 * 8) * sizeof(double);
 #define PF_ARGS c.nmu, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
                 tb<double>(e, EFTB_T_LEGMU), e->APP, e->APR
-    if (c.Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(320), pflds, st, PF_ARGS);
-    else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(320), pflds, st, PF_ARGS);
+    if (c.Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(256), pflds, st, PF_ARGS);
+    else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(128), pflds, st, PF_ARGS);
 #undef PF_ARGS
     if (!e->ap_fast) return;
     // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
