@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
     for (int tau = 0; tau < RS_TILES; ++tau)
 #pragma unroll
         for (int t = 0; t < 2; ++t) aop[tau][t] = RSA[((size_t)w * RS_ROWS + 16 * tau + n) * RS_NB + jg + 4 * t];
-    const int lp3 = jg < 3 ? jg : 0, lp4 = jg < 2 ? jg + 1 : 0;  // l' of this lane's block in tiles 3 and 4
+    const bool lp3hi = jg >= 2;  // tile 3: lane groups 0, 1 hold the (a = 0, l = 1 | 2, l' = 0) blocks, groups 2, 3 the l' = 1 ones; tile 4: l' = 2
     double accL[12], accCt[3], acc11A[3], acc11B[2];  // s-sums: W Cloopl[l',i] (summed over l'), W Cct[l'], W C11[l'] (tiles 0-2), tiles 3 / 4
 #pragma unroll
     for (int i = 0; i < 12; ++i) accL[i] = 0.0;
@@ -966,9 +966,9 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         _Pragma("unroll") for (int i = 0; i < 12; ++i) accL[i] = fma(W_, cv[tau * 14 + 2 + i], accL[i]);                    \
     } while (0)
         // tiles 3 and 4: one (a = 0, l, l') block per lane, l' by lane group
-#define RS_USE34(which, lpx, Dt)                                                                                            \
+#define RS_USE34(which, Dt)                                                                                                 \
     do {                                                                                                                    \
-        const double zhx_ = lpx == 0 ? zh[0] : (lpx == 1 ? zh[1] : zh[2]), cx_ = lpx == 0 ? c11_0 : (lpx == 1 ? c11_1 : cv[28]); \
+        const double zhx_ = which ? zh[2] : (lp3hi ? zh[1] : zh[0]), cx_ = which ? cv[28] : (lp3hi ? c11_1 : c11_0);        \
         const double Wx_ = fma(zhx_, Dt[0], fma(yh[0], Dt[1], fma(yh[1], Dt[2], yh[2] * Dt[3])));                           \
         acc11B[which] = fma(Wx_, cx_, acc11B[which]);                                                                       \
     } while (0)
@@ -997,8 +997,8 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
             const v4d D3 = RS_TILE(3);
             RS_USE012(2, D2);
             const v4d D4 = RS_TILE(4);
-            RS_USE34(0, lp3, D3);
-            RS_USE34(1, lp4, D4);
+            RS_USE34(0, D3);
+            RS_USE34(1, D4);
         } else {
             // all ten MFMAs of this step (five independent accumulators) ...
             v4d D[RS_TILES];
@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
             RS_USE012(0, D[0]);
             RS_USE012(1, D[1]);
             RS_USE012(2, D[2]);
-            RS_USE34(0, lp3, D[3]);
-            RS_USE34(1, lp4, D[4]);
+            RS_USE34(0, D[3]);
+            RS_USE34(1, D[4]);
         }
 #undef RS_TILE
 #undef RS_USE012
@@ -1044,10 +1044,11 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         oA[i] = l11[i] * acc11A[0] + l11[3 + i] * acc11A[1] + l11[6 + i] * acc11A[2];
-        const double t1 = jg < 3 ? l11[lp3 * 3 + i] * acc11B[0] : 0.0;                                  // (l = 1, l' = jg)
-        const double t2 = (jg == 3 ? l11[i] * acc11B[0] : 0.0) + (jg < 2 ? l11[lp4 * 3 + i] * acc11B[1] : 0.0);  // (l = 2, l' = 0 | jg + 1)
-        o1[i] = t1 + __shfl(t1, n + 16) + __shfl(t1, n + 32);
-        o2[i] = t2 + __shfl(t2, n + 16) + __shfl(t2, n + 48);
+        // tile 3: group g holds (l = 1 + g % 2, l' = g / 2); tile 4: groups 0, 1 hold (l = 1 | 2, l' = 2)
+        const double b0 = l11[(jg >> 1) * 3 + i] * acc11B[0] + (jg < 2 ? l11[6 + i] * acc11B[1] : 0.0);
+        const double t1 = (jg & 1) ? 0.0 : b0, t2 = (jg & 1) ? b0 : 0.0;  // contributions to l = 1 (groups 0, 2) and to l = 2 (groups 1, 3)
+        o1[i] = t1 + __shfl(t1, n + 32);
+        o2[i] = __shfl(t2, n + 16) + __shfl(t2, n + 48);
     }
     {   // (the comparison is redone here: carried through the loop it is the one scalar pair too many -- a spill lane, i.e. one more VGPR)
         int kx = k;

@@ -467,9 +467,9 @@ def resum_mfma_tables(Qpoly, NIR, Na):
                 lp = tau
                 a, l = (1, jg) if jg < 3 else (0, 0)
             elif tau == 3:
-                a, l, lp = ((0, 1, 0), (0, 1, 1), (0, 1, 2), (0, 2, 0))[jg]
+                a, l, lp = ((0, 1, 0), (0, 2, 0), (0, 1, 1), (0, 2, 1))[jg]
             elif jg < 2:
-                a, l, lp = 0, 2, jg + 1
+                a, l, lp = 0, 1 + jg, 2
             else:
                 continue
             v, half = (lp, 0) if slot == 0 else (slot - 1, 1)

@@ -161,9 +161,9 @@ def resum_mfma(t, f, Pin, st):
                 lp = tau
                 a, l = (1, jg) if jg < 3 else (0, 0)
             elif tau == 3:
-                a, l, lp = ((0, 1, 0), (0, 1, 1), (0, 1, 2), (0, 2, 0))[jg]
+                a, l, lp = ((0, 1, 0), (0, 2, 0), (0, 1, 1), (0, 2, 1))[jg]
             elif jg < 2:
-                a, l, lp = 0, 2, jg + 1
+                a, l, lp = 0, 1 + jg, 2
             else:
                 continue
             d = D[tau, :, jg]
