@@ -45,11 +45,12 @@ per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in ("pmc_fetch_counter_collection.csv", "pmc_write_counter_collection.csv", "pmc_sq_counter_collection.csv",
           "pmc_l2hit_counter_collection.csv", "pmc_l2miss_counter_collection.csv"):
     rows_f = list(csv.DictReader(open(find(f))))
-    # the command also launches every kernel at batch 1-2 (drop-in latency probe, parity check): keep the launches of the bench batch, i.e. the
-    # largest grid seen per kernel
-    gmax = collections.defaultdict(int)
+    # the command also launches every kernel at batch 1-2 (drop-in latency probe, parity check) and at batch 256 (side key): keep the launches
+    # of the bench batch, i.e. the most frequent grid per kernel
+    gcount = collections.defaultdict(collections.Counter)
     for r in rows_f:
-        gmax[r["Kernel_Name"]] = max(gmax[r["Kernel_Name"]], int(r["Grid_Size"]))
+        gcount[r["Kernel_Name"]][int(r["Grid_Size"])] += 1
+    gmax = {k: max(c.items(), key=lambda kv: (kv[1], kv[0]))[0] for k, c in gcount.items()}
     for r in rows_f:
         if int(r["Grid_Size"]) != gmax[r["Kernel_Name"]]:
             continue
@@ -105,9 +106,10 @@ out = {
 try:
     tr = list(csv.DictReader(open(find("stats_kernel_trace.csv"))))
     ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], short(r["Kernel_Name"])) for r in tr]
-    # bench-batch launches only: the largest grid of the kernel (the command also launches it at batch 1-2)
+    # bench-batch launches only: the most frequent grid of the kernel (the command also launches it at batch 1-2 and 256)
     gy = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) for r in tr}
-    gbig = max(g for (s_, e_), g in gy.items() if any(n.startswith("eftb::resum_mfma_kernel") and (s1, e1) == (s_, e_) for s1, e1, q1, n in ev))
+    gbig = collections.Counter(g for (s_, e_), g in gy.items()
+                               if any(n.startswith("eftb::resum_mfma_kernel") and (s1, e1) == (s_, e_) for s1, e1, q1, n in ev)).most_common(1)[0][0]
     beside, alone = [], []
     for s0, e0, q0, n0 in ev:
         if not n0.startswith("eftb::resum_mfma_kernel") or gy[(s0, e0)] != gbig:
