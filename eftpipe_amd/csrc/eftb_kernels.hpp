@@ -507,40 +507,45 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
                                                       const double* __restrict__ lct, const double* __restrict__ l22,
                                                       const double* __restrict__ l13, const int* __restrict__ grp,
                                                       double* __restrict__ T) {
-    // one lane = one k of one (cosmology, multipole): reads the 28 + 10 loop pieces and writes the 24 template rows of its l
+    // one lane = one k of one (cosmology, multipole): reads the 28 + 10 loop pieces and writes the 24 template rows of its l.  The pieces are
+    // walked group by group (each piece belongs to exactly one of the 12 bias groups; the lists are built per workgroup from the index map),
+    // loaded when they are needed: no 38-entry register array, no select per (piece, group) pair
     __shared__ double cf[38];  // f^power * mu-weight per piece
     __shared__ double p0[38];  // the pieces at the first k (shot-noise subtraction, reference pybird.py:799-800)
-    __shared__ int gi[38];
+    __shared__ int lst[12][38];
+    __shared__ int cnt[12];
     const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
     const double f = fgrow[w];
     for (int b = threadIdx.x; b < 38; b += blockDim.x) {
         cf[b] = ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
         p0[b] = b < 28 ? P22[((size_t)w * 28 + b) * Nk] : P13[((size_t)w * 10 + (b - 28)) * Nk];
-        gi[b] = grp[2 * b];
+    }
+    if (threadIdx.x < 12) {  // pieces of group threadIdx.x, in ascending order (the order the sums have always been taken in)
+        int n = 0;
+        for (int b = 0; b < 38; ++b)
+            if (grp[2 * b] == (int)threadIdx.x) lst[threadIdx.x][n++] = b;
+        cnt[threadIdx.x] = n;
     }
     __syncthreads();
     if (k >= Nk) return;
     const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
-    double d[38];
-#pragma unroll
-    for (int b = 0; b < 38; ++b) d[b] = (b < 28 ? P22[((size_t)w * 28 + b) * Nk + k] : P13[((size_t)w * 10 + (b - 28)) * Nk + k]) - p0[b];
-    double acc[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int b = 0; b < 38; ++b) {
-        const int g = gi[b];  // workgroup-uniform
-        const double v = cf[b] * d[b];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) acc[i] += g == i ? v : 0.0;
-    }
+    const double* q22 = P22 + (size_t)w * 28 * Nk + k;
+    const double* q13 = P13 + (size_t)w * 10 * Nk + k;
     double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
 #pragma unroll
     for (int r = 0; r < 3; ++r) t[(size_t)r * Nk] = l11[l * 3 + r] * p11;
 #pragma unroll
     for (int r = 0; r < 6; ++r) t[(size_t)(3 + r) * Nk] = lct[l * 6 + r] * kv * kv * p11;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) t[(size_t)(9 + i) * Nk] = acc[i];
+    for (int i = 0; i < 12; ++i) {
+        const int n = cnt[i];  // workgroup-uniform
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const int b = lst[i][j];
+            const double d = (b < 28 ? q22[(size_t)b * Nk] : q13[(size_t)(b - 28) * Nk]) - p0[b];
+            acc += cf[b] * d;
+        }
+        t[(size_t)(9 + i) * Nk] = acc;
+    }
     t[(size_t)21 * Nk] = l == 0 ? 1.0 : 0.0;
     t[(size_t)22 * Nk] = l == 0 ? kv * kv : 0.0;
     t[(size_t)23 * Nk] = l == 1 ? kv * kv : 0.0;
