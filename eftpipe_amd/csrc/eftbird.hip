@@ -325,10 +325,10 @@ static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets,
                  e->ACF, e->ALC
     if (nc == 9) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(64), 0, st, AD_ARGS);
-        hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(256), 0, st, ROW_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(320), 0, st, ROW_ARGS);
     } else if (nc == 7) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(64), 0, st, AD_ARGS);
-        hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(256), 0, st, ROW_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(320), 0, st, ROW_ARGS);
     } else {
         return fail("loop-matrix basis of dimension %d + %d is not instantiated (expected 7 + 2)", c.nbasis, c.with_resum ? c.nbasis13 : 0);
     }
