@@ -1610,16 +1610,19 @@ constexpr int APW_DCAP = 32;  // knots per k on the fast path
 constexpr int APW_WIN = 112;  // LDS window of a tile, in knots (64 k + the drift of i0 across the tile + the knots per k)
 
 template <int NL>
-__global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+__global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
                                                          const double* __restrict__ Hw, const double* __restrict__ fid,
                                                          const double* __restrict__ mu, const double* __restrict__ PS,
                                                          const double* __restrict__ ROOT, double* __restrict__ W, int* __restrict__ I0,
                                                          int4* __restrict__ META) {
-    constexpr int NS = NL * NL * 4, NP = NL * NL, PPW = (NP + 3) / 4;  // prefix sequences, (l', l) pairs, pairs per wave
+    // NL waves, NL (l', l) pairs each (wave <-> l', the order of the prefix sums): every wave walks the same interval slots, so fewer waves
+    // means fewer copies of the crossing arithmetic, and the pairs divide evenly
+    constexpr int NS = NL * NL * 4, NP = NL * NL, PPW = NL, NT = 64 * NL;  // prefix sequences, (l', l) pairs, pairs per wave, threads
     extern __shared__ double sm[];
     double* s_k = sm;                   // [Nk]
     double* s_root = sm + Nk;           // [nmu]
     double* s_ps = sm + Nk + nmu + (nmu & 1);  // [(nmu + 1) * NS] the cosmology's prefix sums (58 KB at Nl = 3, 200 nodes): every gather below is an LDS read
+    double* s_ih = s_ps + (size_t)(nmu + 1) * NS;  // [Nk] 1 / (k_i+1 - k_i): one division per knot and workgroup instead of one per (k, slot) and wave
     __shared__ int s_red[3];            // min i0, max i0, max knots per k over the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int KT = (Nk + 63) / 64;
@@ -1629,10 +1632,13 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     {
         const double2* src = reinterpret_cast<const double2*>(PS + (size_t)w * (nmu + 1) * NS);
         double2* dst = reinterpret_cast<double2*>(s_ps);
-        for (int e = threadIdx.x; e < (nmu + 1) * NS / 2; e += 256) dst[e] = src[e];
+        for (int e = threadIdx.x; e < (nmu + 1) * NS / 2; e += NT) dst[e] = src[e];
     }
-    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
-    for (int e = threadIdx.x; e < nmu; e += 256) s_root[e] = ROOT[(size_t)w * nmu + e];
+    for (int e = threadIdx.x; e < Nk; e += NT) {
+        s_k[e] = kk[e];
+        s_ih[e] = e + 1 < Nk ? 1.0 / (kk[e + 1] - kk[e]) : 0.0;
+    }
+    for (int e = threadIdx.x; e < nmu; e += NT) s_root[e] = ROOT[(size_t)w * nmu + e];
     if (threadIdx.x == 0) {
         s_red[0] = 0x7fffffff;
         s_red[1] = 0;
@@ -1643,13 +1649,14 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
     const bool live = k < Nk;
     const double kq = s_k[live ? k : Nk - 1] / qperp;
+    const double inv_kq = 1.0 / kq, inv_g = 1.0 / g;  // (the closed form only seeds the crossing: the fix-up below decides against the stored roots)
     const double* ps = s_ps;
     const bool up = g > 0.0;
     const int dir = up ? 1 : -1;
     const double jscale = (nmu - 1) / mu[nmu - 1];
     // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling): closed form + a one-step fix-up against the stored roots
     auto cross = [&](double kb) -> int {
-        const double rc = kb / kq, x = (rc * rc - 1.0) / g;
+        const double rc = kb * inv_kq, x = (rc * rc - 1.0) * inv_g;
         int j = nmu;
         if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
         j = max(0, min(j, nmu));
@@ -1687,7 +1694,7 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
         const int ja = jb_prev;
         const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
         jb_prev = jb;
-        const double h = khi - klo, ih = 1.0 / h, ih2 = ih * ih, ih3 = ih2 * ih;
+        const double ih = s_ih[i], ih2 = ih * ih, ih3 = ih2 * ih;
         const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
         const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
         const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
@@ -1697,7 +1704,7 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
         const int dk = up ? s : nslot - s;  // relative to ilo: rising k' leaves the left knot behind, falling k' the right one
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
-            const int p = wave + 4 * q;  // pair (l', l) = (p / NL, p % NL), the order of the prefix sums
+            const int p = wave * NL + q;  // pair (l', l) = (p / NL, p % NL) = (wave, q), the order of the prefix sums
             if (p < NP) {
                 double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
                 if (jb > ja) {
@@ -1723,7 +1730,7 @@ __global__ __launch_bounds__(256) void ap_weights_kernel(int Nk, int nmu, const 
     const int nk = live ? nslot + 1 : 0;
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-        const int p = wave + 4 * q;
+        const int p = wave * NL + q;
         if (p < NP) {
             const int lp = p / NL, l = p % NL;
             if (live) {
