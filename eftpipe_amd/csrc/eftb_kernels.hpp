@@ -1481,6 +1481,7 @@ __global__ __launch_bounds__(256, 2) void ap_moments_kernel(int Nk, int nmu, con
     const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
     const bool live = k < Nk;
     const double kq = s_k[live ? k : Nk - 1] / qperp;
+    const double inv_kq = 1.0 / kq, inv_g = 1.0 / g;
     const double* ps = PS + (size_t)w * (nmu + 1) * NS;
     const bool up = g > 0.0;  // k'(mu) rises or falls with mu
     const int dir = up ? 1 : -1;
@@ -1492,7 +1493,7 @@ __global__ __launch_bounds__(256, 2) void ap_moments_kernel(int Nk, int nmu, con
         for (int r = 0; r < NRT; ++r) acc[l][r] = 0.0;
     // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling)
     auto cross = [&](double kb) -> int {
-        const double rc = kb / kq, x = (rc * rc - 1.0) / g;  // mu^2 at the crossing
+        const double rc = kb * inv_kq, x = (rc * rc - 1.0) * inv_g;  // mu^2 at the crossing (a seed: the fix-up below decides)
         int j = nmu;
         if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
         j = max(0, min(j, nmu));
