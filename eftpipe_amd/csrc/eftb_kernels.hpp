@@ -1622,19 +1622,13 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
     extern __shared__ double sm[];
     double* s_k = sm;                   // [Nk]
     double* s_root = sm + Nk;           // [nmu]
-    double* s_ps = sm + Nk + nmu + (nmu & 1);  // [(nmu + 1) * NS] the cosmology's prefix sums (58 KB at Nl = 3, 200 nodes): every gather below is an LDS read
-    double* s_ih = s_ps + (size_t)(nmu + 1) * NS;  // [Nk] 1 / (k_i+1 - k_i): one division per knot and workgroup instead of one per (k, slot) and wave
+    double* s_ih = sm + Nk + nmu + (nmu & 1);  // [Nk] 1 / (k_i+1 - k_i): one division per knot and workgroup instead of one per (k, slot) and wave
     __shared__ int s_red[3];            // min i0, max i0, max knots per k over the tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
     const int k = kt * 64 + lane;
-    {
-        const double2* src = reinterpret_cast<const double2*>(PS + (size_t)w * (nmu + 1) * NS);
-        double2* dst = reinterpret_cast<double2*>(s_ps);
-        for (int e = threadIdx.x; e < (nmu + 1) * NS / 2; e += NT) dst[e] = src[e];
-    }
     for (int e = threadIdx.x; e < Nk; e += NT) {
         s_k[e] = kk[e];
         s_ih[e] = e + 1 < Nk ? 1.0 / (kk[e + 1] - kk[e]) : 0.0;
@@ -1651,7 +1645,9 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
     const bool live = k < Nk;
     const double kq = s_k[live ? k : Nk - 1] / qperp;
     const double inv_kq = 1.0 / kq, inv_g = 1.0 / g;  // (the closed form only seeds the crossing: the fix-up below decides against the stored roots)
-    const double* ps = s_ps;
+    // the cosmology's prefix sums (58 KB) are gathered from the L2 / L1: staged in LDS they left room for two workgroups per CU, and the kernel
+    // measured 80 instead of 56 us
+    const double* ps = PS + (size_t)w * (nmu + 1) * NS;
     const bool up = g > 0.0;
     const int dir = up ? 1 : -1;
     const double jscale = (nmu - 1) / mu[nmu - 1];
@@ -1699,8 +1695,8 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
         const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
         const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
         const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
-        const double* pa = ps + (size_t)ja * NS;
-        const double* pb = ps + (size_t)jb * NS;
+        const char* psb = reinterpret_cast<const char*>(ps);  // wave-uniform base + 32-bit per-lane byte offsets (one address register, not two pointers)
+        const unsigned oa = (unsigned)ja * NS * 8u, ob = (unsigned)jb * NS * 8u;
         // knot written by this step: the one this interval does NOT share with the next interval in mu order
         const int dk = up ? s : nslot - s;  // relative to ilo: rising k' leaves the left knot behind, falling k' the right one
 #pragma unroll
@@ -1709,7 +1705,7 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
             if (p < NP) {
                 double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
                 if (jb > ja) {
-                    const double4 b4 = *reinterpret_cast<const double4*>(pb + p * 4), a4 = *reinterpret_cast<const double4*>(pa + p * 4);
+                    const double4 b4 = *reinterpret_cast<const double4*>(psb + (ob + p * 32u)), a4 = *reinterpret_cast<const double4*>(psb + (oa + p * 32u));
                     const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
                     m0 = d0;
                     m1 = fma(c10, d0, c11 * d1);

@@ -445,7 +445,7 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     if (!e->ap_fast) return;
     // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
     const dim3 wgrid(((c.Nk + 63) / 64) * B);  // flat: (k tile, cosmology) decoded XCD-aware in the kernel
-    const size_t wlds = ((size_t)2 * c.Nk + c.nmu + (c.nmu & 1) + (size_t)(c.nmu + 1) * c.Nl * c.Nl * 4) * sizeof(double);
+    const size_t wlds = ((size_t)2 * c.Nk + c.nmu + (c.nmu & 1)) * sizeof(double);
 #define APW_ARGS c.Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, \
                  e->APW, e->API, e->APM
     if (c.Nl == 3) hipLaunchKernelGGL((ap_weights_kernel<3>), wgrid, dim3(192), wlds, st, APW_ARGS);
