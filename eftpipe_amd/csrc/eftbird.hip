@@ -1152,8 +1152,8 @@ int eftb_finalize(eftb_engine* e) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (c.with_ap) {
         // (the kernel also holds a few static words: the dynamic part must leave room for them below the 160 KB of a CU)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_weights_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         {   // which form of the AP stage (see engine.ap_mode): needs the k grid, so it is decided here
             std::vector<double> kh(c.Nk);
             HIPCHK(hipMemcpy(kh.data(), tb<double>(e, EFTB_T_K), c.Nk * sizeof(double), hipMemcpyDeviceToHost));
