@@ -439,7 +439,7 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     const size_t pflds = ((size_t)(1 + 2 * c.Nl) * c.nmu + (size_t)c.Nl * c.Nl * 4 * 8) * sizeof(double);
 #define PF_ARGS c.nmu, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
                 tb<double>(e, EFTB_T_LEGMU), e->APP, e->APR
-    if (c.Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(256), pflds, st, PF_ARGS);
+    if (c.Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(320), pflds, st, PF_ARGS);
     else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(128), pflds, st, PF_ARGS);
 #undef PF_ARGS
     if (!e->ap_fast) return;

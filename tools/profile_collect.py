@@ -46,11 +46,11 @@ for f in ("pmc_fetch_counter_collection.csv", "pmc_write_counter_collection.csv"
           "pmc_l2hit_counter_collection.csv", "pmc_l2miss_counter_collection.csv"):
     rows_f = list(csv.DictReader(open(find(f))))
     # the command also launches every kernel at batch 1-2 (drop-in latency probe, parity check) and at batch 256 (side key): keep the launches
-    # of the bench batch, i.e. the most frequent grid per kernel
+    # of the bench batch, i.e. the grid with the largest launches x size per kernel
     gcount = collections.defaultdict(collections.Counter)
     for r in rows_f:
         gcount[r["Kernel_Name"]][int(r["Grid_Size"])] += 1
-    gmax = {k: max(c.items(), key=lambda kv: (kv[1], kv[0]))[0] for k, c in gcount.items()}
+    gmax = {k: max(c.items(), key=lambda kv: kv[1] * kv[0])[0] for k, c in gcount.items()}  # launches x grid: batch 1 is frequent but tiny, batch 256 large but rare
     for r in rows_f:
         if int(r["Grid_Size"]) != gmax[r["Kernel_Name"]]:
             continue
@@ -108,8 +108,9 @@ try:
     ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], short(r["Kernel_Name"])) for r in tr]
     # bench-batch launches only: the most frequent grid of the kernel (the command also launches it at batch 1-2 and 256)
     gy = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) for r in tr}
-    gbig = collections.Counter(g for (s_, e_), g in gy.items()
-                               if any(n.startswith("eftb::resum_mfma_kernel") and (s1, e1) == (s_, e_) for s1, e1, q1, n in ev)).most_common(1)[0][0]
+    gcnt = collections.Counter(g for (s_, e_), g in gy.items()
+                               if any(n.startswith("eftb::resum_mfma_kernel") and (s1, e1) == (s_, e_) for s1, e1, q1, n in ev))
+    gbig = max(gcnt.items(), key=lambda kv: kv[0] * kv[1])[0]
     beside, alone = [], []
     for s0, e0, q0, n0 in ev:
         if not n0.startswith("eftb::resum_mfma_kernel") or gy[(s0, e0)] != gbig:

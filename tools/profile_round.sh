@@ -16,7 +16,7 @@ echo "stats done"
 # one derived counter per pass where the hardware cannot collect them together (FETCH_SIZE + WRITE_SIZE is refused)
 pmc() {  # name, counters...
     local name=$1; shift
-    timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/$name.err
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/$name.err
     echo "$name done"
 }
 pmc pmc_fetch FETCH_SIZE
