@@ -334,6 +334,65 @@ def test_bench_workload_against_oracle():
     eng.close()
 
 
+def test_full_size_properties_of_the_bench_workload():
+    """BASELINE cfg 2 at the bench's full size (128 cosmologies per step, Nk = 512, Nl = 3), where the oracle takes minutes: properties that
+    need no reference values.  (1) Without resummation and AP the templates are homogeneous in P_lin: P11l, Pctl scale with alpha, Ploopl
+    with alpha^2 (reference pybird.py:1074-1086, 737-866).  (2) AP at the fiducial (DA, H) is the 3 x 3 multipole
+    mixing matrix of the reference's own mu quadrature, applied row by row.  (3) A
+    permutation of the batch permutes the output, bit for bit.  (4) P_l is linear in the 24 bias coefficients."""
+    import bench
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    B, NK, NL = 128, bench.NK, bench.NL
+    k = synth.survey_kgrid(NK)
+    DAf, Hf = float(synth.da_func(synth.OM_AP, bench.Z)), float(synth.hubble(synth.OM_AP, bench.Z))
+    draws = synth.draw_batch(B, z=bench.Z, seed=2024)
+    rng = np.random.default_rng(5)
+    # (1) homogeneity, no resummation / AP
+    eng = Engine(EngineConfig(Nl=NL, k=k), max_batch=B)
+    alpha = 1.7
+    t1 = eng.eval_batch(draws["Pin"], draws["f"])
+    t2 = eng.eval_batch(alpha * draws["Pin"], draws["f"])
+    for sl, power in ((ROWS["P11l"], 1), (ROWS["Pctl"], 1), (ROWS["Ploopl"], 2)):
+        scale = np.max(np.abs(t1[:, :, sl]), axis=-1, keepdims=True) + 1e-300
+        assert np.max(np.abs(t2[:, :, sl] - alpha**power * t1[:, :, sl]) / scale) < 1e-11, power
+    assert np.array_equal(t2[:, :, ROWS["Pstl"]], t1[:, :, ROWS["Pstl"]])
+    eng.close()
+    # (2) - (4) on the full path
+    eng = Engine(EngineConfig(Nl=NL, k=k, with_resum=True, with_ap=True, DA_AP=DAf, H_AP=Hf), max_batch=B)
+    eng.load_inputs(draws["Pin"], draws["f"], np.full(B, DAf), np.full(B, Hf))
+    eng.run(eng.full_mask() & ~L.S_AP, B)
+    before = eng.get("TEMPL", (B, NL, 24, NK))
+    eng.run(L.S_AP, B)
+    after = eng.get("TEMPL", (B, NL, 24, NK))
+    # at q_perp = q_par = 1 every node of the mu quadrature sits at k' = k (a knot of the spline), so the stage reduces to the 3 x 3 matrix of
+    # the reference's trapezoid rule on 200 nodes, M[l][l'] = 2 sum_j w_j (2l+1)/2 L_l(mu_j) L_l'(mu_j) (pybird.py:1581-1596): not the identity
+    from eftpipe_amd.tables import build_tables
+    from scipy.special import eval_legendre
+
+    tb_ = build_tables(EngineConfig(Nl=NL, k=k, with_resum=True, with_ap=True, DA_AP=DAf, H_AP=Hf))
+    M = np.array([[2.0 * np.sum(tb_["wmu"] * tb_["legmu"][l] * eval_legendre(2 * lp, tb_["mu"])) for lp in range(NL)] for l in range(NL)])
+    assert np.max(np.abs(M - np.eye(NL))) < 1e-3
+    want = np.einsum("lm,bmrk->blrk", M, before[:, :, :21])
+    scale = np.max(np.abs(want), axis=-1, keepdims=True) + 1e-300
+    assert np.max(np.abs(after[:, :, :21] - want) / scale) < 1e-10
+    assert np.array_equal(after[:, :, 21:], before[:, :, 21:])  # Pstl is copied through (APst off)
+    bias = rng.normal(size=(B, 24))
+    tf, pf = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias=bias)
+    perm = rng.permutation(B)
+    tp, pp = eng.eval_batch(draws["Pin"][perm], draws["f"][perm], draws["DA"][perm], draws["H"][perm], bias=bias[perm])
+    assert np.array_equal(tp, tf[perm]) and np.array_equal(pp, pf[perm])
+    b2 = rng.normal(size=(B, 24))
+    _, p2 = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias=b2)
+    _, p3 = eng.eval_batch(draws["Pin"], draws["f"], draws["DA"], draws["H"], bias=0.5 * bias - 3.0 * b2)
+    ps = np.max(np.abs(pf) + np.abs(p2), axis=-1, keepdims=True)
+    assert np.max(np.abs(p3 - (0.5 * pf - 3.0 * p2)) / ps) < 1e-13
+    assert np.all(np.isfinite(tf)) and np.all(np.isfinite(pf))
+    eng.close()
+
+
 def test_overlapped_steps_are_bit_identical(golden, monkeypatch):
     """Asynchronous runs overlap on three streams (front half of run i+1 and back half -- spline, AP, reduce -- of run i beside the
     resummation, three template blocks rotating): any number of queued runs, and input changes in between, must give exactly what an
