@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 pat=$1; shift
 OUT=gpurun_out/pmck
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/err.log
+timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/err.log
 python3 - "$pat" <<'PY'
 import csv,glob,collections,sys
 pat=sys.argv[1]
