@@ -716,7 +716,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 st = st_main;
             }
             int tslot = -1;
-            if (e->time_dominant && full && e->evT0[0]) {
+            if (e->time_dominant && full && e->evT0[0] && !e->use_graphs) {  // (not under graph replay: the event records would be captured)
                 tslot = (int)(e->timer_next++ % eftb_engine::NTIMER);
                 collect_timer(e, tslot, false);
                 if (!e->timer_busy[tslot] && hipEventRecord(e->evT0[tslot], st) != hipSuccess) return fail("eftb_run: event record failed");

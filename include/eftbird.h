@@ -140,7 +140,7 @@ enum eftb_option {
     EFTB_O_CHECK_FINITE = 3,  /* the REDUCE stage flags non-finite P_l(k): the next synchronising call (eftb_sync, eftb_get, eftb_eval_*,
                                  eftb_fetch_*) then returns non-zero naming the cosmology (off by default) */
     EFTB_O_TIME_DOMINANT = 4  /* bracket every launch of the resummation kernel with HIP events on the stream it runs on (measurement
-                                 only: bench.py's roofline; read with eftb_dominant_time) */
+                                 only: bench.py's roofline; read with eftb_dominant_time; inactive while EFTB_O_GRAPH replays captured runs) */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 /* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for

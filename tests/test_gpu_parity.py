@@ -1,6 +1,8 @@
 """GPU parity: every stage of the HIP engine (through the C ABI) against the CPU oracle and the
 reference-generated golden fixtures.  Tolerance: 1e-6 relative is the north-star bar; we assert
 1e-8 (row-scaled) because both sides are FP64 and only summation order differs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -447,6 +449,10 @@ def test_dominant_kernel_timer(golden):
     for _ in range(11):
         eng.run(mask, 16, sync=False)
     ms, n = eng.dominant_time(reset=False)
+    if os.environ.get("EFTB_GRAPH", "0") not in ("", "0"):  # graph replay: the timer stays off (its event records would be captured)
+        assert n == 0
+        eng.close()
+        return
     assert n == 11 and 0.0 < ms / n < 5.0
     assert eng.dominant_time()[1] == 11 and eng.dominant_time() == (0.0, 0)
     eng.time_dominant(False)
