@@ -1250,7 +1250,8 @@ constexpr int SPL_HB = 32;
 // through LDS (register-prefetched one group ahead); one group of 16 series = 20 MFMAs per wave.
 constexpr int SPL_W = 128, SPL_LD = SPL_W + 2;  // staged window (64 knots + 2 x 32 halo), LDS row stride (conflict-free b64 reads)
 
-__global__ __launch_bounds__(256) void spline_kernel(int Nk, int nseries, int rlo, int rsel, const double* __restrict__ T, const double* __restrict__ band,
+// (register cap: 96 in all instead of 96 + 8 accumulator registers -- what is free beside two resummation waves on a SIMD; same speed alone)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(88))) void spline_kernel(int Nk, int nseries, int rlo, int rsel, const double* __restrict__ T, const double* __restrict__ band,
                                                      double* __restrict__ YS) {
     __shared__ double ys[16 * SPL_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
