@@ -203,13 +203,9 @@ def main():
                     if keep:
                         results[n - 1 - back] = block[rank]
         elif exchange == "none":
-            for back in range(min(DEPTH, n) - 1, 0, -1):
+            for back in range(min(DEPTH, n) - 1, -1, -1):  # (back = 0: the step launched last)
                 eng.fetch_previous("PLK", (B, NL, NK), out=results[n - 1 - back] if keep else None, back=back)
             eng.sync()
-            if n:
-                got = eng.get("PLK", (B, NL, NK))
-                if keep:
-                    results[n - 1] = got
         else:
             eng.sync()
 

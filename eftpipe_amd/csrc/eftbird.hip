@@ -1681,7 +1681,7 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
 
 int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_back: null argument");
-    if (back < 1 || back >= eftb_engine::NSETS) return fail("eftb_fetch_back: back must be 1 (the step before the one launched last), 2 or 3");
+    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_back: back must be 0 (the step launched last), 1, 2 or 3 (that many steps before it)");
     if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_back: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
     if (!e->cpy) return fail("eftb_fetch_back: no staged run yet");
     if (count > e->buf_elems[id]) return fail("eftb_fetch_back: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);

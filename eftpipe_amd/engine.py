@@ -301,7 +301,7 @@ class Engine:
             self.dims = self.out_dims()
 
     def fetch_previous(self, name, shape, out=None, back=1):
-        """PLK / LOGP of the step launched `back` (1, 2 or 3) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
+        """PLK / LOGP of the step launched `back` (0: the last one; 1, 2 or 3) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
         to fill).  back=3 keeps three steps queued while the host works (see ``pipeline``)."""
         if out is None:
             out = np.empty(shape, dtype=np.float64)
@@ -323,11 +323,8 @@ class Engine:
             queued.append(B)
             if len(queued) == 4:  # three steps stay queued on the GPU while the oldest one is copied out
                 yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=3)
-        while len(queued) > 1:
+        while queued:  # drain: back = 0 is the step launched last
             yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=len(queued))
-        if queued:
-            self.sync()
-            yield self.get(fetch, shape_of(queued.pop(0)))
 
     def pinned_empty(self, shape):
         """Page-locked float64 host array for eval_batch(out=...) / put / get."""

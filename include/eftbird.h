@@ -234,7 +234,7 @@ int  eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f
 int  eftb_run_staged(eftb_engine* e, int stage_mask, int B);
 /* EFTB_B_PLK or EFTB_B_LOGP of the step before the one in flight (waits only for that step). */
 int  eftb_fetch_previous(eftb_engine* e, int buffer_id, double* host, size_t count);
-/* The same for the step launched `back` (1, 2 or 3) steps before the last one.  The engine keeps four sets of per-step inputs / outputs, so the
+/* The same for the step launched `back` (0 = the last one itself, 1, 2 or 3) steps before the last one.  The engine keeps four sets of per-step inputs / outputs, so the
  * loop  stage(i); run_staged(i); fetch_back(3) [= step i - 3]  keeps THREE steps queued on the GPU while the host copies results out and
  * prepares the next inputs: the inputs of step i + 1 are then staged before the back half of step i - 1 has finished, and the look-ahead
  * of consecutive steps never runs dry (with back = 2 the look-ahead stream idled ~0.1 ms per step waiting for the host); the set read with

@@ -567,6 +567,7 @@ def test_pipelined_steps_with_changing_inputs(golden):
         assert len(got2) == nsteps
         for s in range(nsteps):
             assert np.array_equal(got2[s], want[s]), (depth, s)
+    assert np.array_equal(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=0), want[nsteps - 1])  # back = 0: the step launched last
     with pytest.raises(L.EftbError):
         eng.fetch_previous("PLK", (B, 3, g["k"].size), back=4)
     eng.close()
