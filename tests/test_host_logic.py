@@ -163,11 +163,123 @@ def test_control_plane_tcp_transport(tmp_path):
     script.write_text(WORKER % ROOT)
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", EFTB_CP_TCP_PORT="29562")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", EFTB_CP_TCP_PORT="29562",
+                   EFTB_CP_TOKEN="s3cret-of-this-launch")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-1500:] for o in outs)
     assert "GATHER_OK" in outs[0][0]
+
+
+def test_control_plane_tcp_needs_token_and_loopback(monkeypatch):
+    from eftpipe_amd import dist
+
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("EFTB_CP_TCP_PORT", "29563")
+    monkeypatch.delenv("EFTB_CP_TOKEN", raising=False)
+    with pytest.raises(RuntimeError, match="EFTB_CP_TOKEN"):
+        dist.ControlPlane()
+    monkeypatch.setenv("EFTB_CP_TOKEN", "t")
+    monkeypatch.setenv("MASTER_ADDR", "192.0.2.1")   # not loopback: refused unless EFTB_CP_TCP_ANY=1
+    with pytest.raises(RuntimeError, match="loopback"):
+        dist.ControlPlane()
+
+
+@pytest.mark.parametrize("transport", ["unix", "tcp"])
+def test_control_plane_rejects_foreign_connections(tmp_path, transport):
+    """nothing that arrives on the hub socket is unpickled, and a connection becomes a peer only after the handshake.
+    A foreign client that (a) sends a pickle, (b) claims a rank with the wrong token / a bad tag, (c) says nothing, is dropped; the real
+    rank 1 then joins and the collectives run.  On the Unix socket the uid check is exercised through a patched SO_PEERCRED reader."""
+    import pickle
+    import socket
+    import struct
+    import threading
+    import time
+
+    from eftpipe_amd import dist
+
+    port = 29570 if transport == "unix" else 29572
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EFTB_CP_TOKEN="right-token")
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    env.pop("TORCHELASTIC_RESTART_COUNT", None)
+    if transport == "tcp":
+        env["EFTB_CP_TCP_PORT"] = str(port + 1)
+        family, target = socket.AF_INET, ("127.0.0.1", port + 1)
+    else:
+        family, target = socket.AF_UNIX, "\0eftb-cp-127.0.0.1-%d--0" % port
+    script = tmp_path / "hub.py"
+    script.write_text("import sys\nsys.path.insert(0, %r)\nfrom eftpipe_amd import dist\ncp = dist.ControlPlane()\n"
+                      "print('REJECTED', cp.rejected, flush=True)\nassert cp.max(1.0) == 2.0\ncp.barrier()\ncp.close()\nprint('HUB_OK')\n" % ROOT)
+    hub = subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK="0", LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+    def connect():
+        t0 = time.monotonic()
+        while True:
+            s = socket.socket(family, socket.SOCK_STREAM)
+            try:
+                s.connect(target)
+                s.settimeout(30)
+                return s
+            except (ConnectionRefusedError, FileNotFoundError):
+                s.close()
+                assert time.monotonic() - t0 < 60
+                time.sleep(0.05)
+
+    def dropped(s):
+        try:
+            return s.recv(64) == b""
+        except OSError:
+            return True
+
+    # (a) a pickle instead of the handshake message
+    s = connect()
+    nonce = s.recv(16)
+    assert len(nonce) == 16
+    s.sendall(pickle.dumps({"rank": 1}) + b"\0" * 64)
+    assert dropped(s)
+    s.close()
+    # (b) the right message layout with the wrong token
+    s = connect()
+    nonce = s.recv(16)
+    s.sendall(struct.pack("<I", 1) + b"n" * 16 + dist._tag(b"wrong-token", nonce, 1))
+    assert dropped(s)
+    s.close()
+    # (c) rank out of range with a valid tag
+    s = connect()
+    nonce = s.recv(16)
+    s.sendall(struct.pack("<I", 7) + b"n" * 16 + dist._tag(b"right-token", nonce, 7))
+    assert dropped(s)
+    s.close()
+    # the real rank 1, in this process
+    for k, v in dict(env, RANK="1", LOCAL_RANK="1").items():
+        os.environ[k] = v
+    try:
+        cp = dist.ControlPlane()
+        assert cp.max(2.0) == 2.0
+        cp.barrier()
+        cp.close()
+    finally:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "EFTB_CP_TOKEN", "EFTB_CP_TCP_PORT"):
+            os.environ.pop(k, None)
+    out, err = hub.communicate(timeout=120)
+    assert hub.returncode == 0 and "HUB_OK" in out and "REJECTED 3" in out, out + err[-2000:]
+
+
+def test_control_plane_unix_socket_checks_the_peer_uid(monkeypatch):
+    """_admit drops a Unix-socket connection whose SO_PEERCRED uid is not ours (patched reader: the suite runs as one user)."""
+    import socket
+
+    from eftpipe_amd import dist
+
+    cp = dist.ControlPlane.__new__(dist.ControlPlane)
+    cp.world = 2
+    a, b = socket.socketpair()
+    assert dist._peer_uid(a) == os.getuid()
+    monkeypatch.setattr(dist, "_peer_uid", lambda sock: os.getuid() + 1)
+    assert cp._admit(a, True, b"", {}) is None
+    a.close()
+    b.close()
 
 
 @pytest.mark.parametrize("Nl", [2, 3])

@@ -45,7 +45,8 @@ CASES = {
 
 
 def make_common(pb, Nl, Nk, **kw):
-    co = pb.Common(Nl=Nl, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5, **kw)
+    kw.setdefault("ndA", 4.5e-5)
+    co = pb.Common(Nl=Nl, kmax=0.3, kmA=0.7, krA=0.25, **kw)
     if Nk is not None:
         k = synth.survey_kgrid(Nk)
         co.k, co.Nk = k, k.size
@@ -700,6 +701,71 @@ def cfg3_fixture(ref):
     print("cfg3 written:", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+def cfg3_nk512_fixture(ref):
+    """BASELINE cfg 3 at the BASELINE grid (Nl = 3, Nk = 512) with the windows the reference ships (accboost 4, windowk 0.1,
+    win_NGC_{LRG,ELG,X}.txt; yaml :6-27, :63-70): the three kernels of one likelihood point on the 512-point survey grid, APst, every
+    spectrum through its production window, binned onto its data k, ELG chained, bias contraction with the yaml's reference values.
+    Final stages only + two rows and the p-sum of each Waldk (the matrices are 174 MB each).  The reference's window precompute at
+    Nk = 512 x Np = 1540 is the slow part (minutes per tracer, once)."""
+    import time
+    pb, LK = ref.pybird, ref.likelihood
+    ddir = os.path.join(REFERENCE_ROOT, "data", "DR16_noric")
+    Nl, Nk = 3, 512
+    out = dict(Nl=Nl, km=CFG3_KM, kr=CFG3_KR, tracers=np.array(list(CFG3_TRACERS)), accboost=CFG3_WINDOW["accboost"], windowk=CFG3_WINDOW["windowk"],
+               Om_AP=CFG3_AP["Om_AP"], ng_names=np.array(list(CFG3_NG)), ng_values=np.array(list(CFG3_NG.values())))
+    ng = dict(CFG3_NG)
+    for t in ("LRG_NGC_", "ELG_NGC_"):
+        ng[t + "b2"] = (ng[t + "c2"] + ng[t + "c4"]) / np.sqrt(2.0)
+        ng[t + "b4"] = (ng[t + "c2"] - ng[t + "c4"]) / np.sqrt(2.0)
+    for t, spec in CFG3_TRACERS.items():
+        z = spec["z"]
+        if "cross" in spec:
+            A, B = (CFG3_TRACERS[x] for x in spec["cross"])
+            co = make_common(pb, Nl, Nk, No=Nl, ndA=A["nd"], kmB=CFG3_KM, krB=CFG3_KR, ndB=B["nd"])
+            basis = ref.parambasis.WestCoastBasis(prefix=t + "_", cross_prefix=[x + "_" for x in spec["cross"]])
+        else:
+            co = make_common(pb, Nl, Nk, No=Nl, ndA=spec["nd"])
+            basis = ref.parambasis.WestCoastBasis(prefix=t + "_")
+        m = LK.MultipoleInfo.load(os.path.join(ddir, spec["data"]), spec["ls"], spec["kmin"], spec["kmax"])
+        cos = synth.cosmology(z=z, A=((1.0 + 0.7) / (1.0 + z)) ** 2)
+        out.update({f"{t}_z": z, f"{t}_Pin": cos["Pin"], f"{t}_f": cos["f"], f"{t}_DA": cos["DA"], f"{t}_H": cos["H"], f"{t}_kout": m.kout,
+                    f"{t}_ls": np.array(m.ls), f"{t}_co": np.array([co.kmA, co.krA, co.ndA, co.kmB, co.krB, co.ndB])})
+        out["k"], out["kin"] = co.k, cos["kin"]
+        nl = pb.NonLinear(load=False, save=False, co=co)
+        bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+        nl.PsCf(bird)
+        bird.setPsCfl()
+        pb.Resum(co=co).Ps(bird)
+        ap = pb.APeffect(z_AP=z, co=co, **CFG3_AP)
+        out[f"{t}_DA_AP"], out[f"{t}_H_AP"] = ap.DA, ap.H
+        ap.AP(bird)
+        for n, v in stage(bird).items():
+            out[f"{t}_ap_{n}"] = v
+        t0 = time.time()
+        win = ref.window.Window(window_configspace_file=os.path.join(ddir, spec["win"]), co=co, load=False, save=False, **CFG3_WINDOW)
+        print("cfg3_nk512", t, "reference window precompute", round(time.time() - t0, 1), "s; Waldk", win.Waldk.shape, flush=True)
+        out["window_p"] = win.p
+        out[f"{t}_Waldk_sum_p"] = win.Waldk.sum(axis=-1)
+        out[f"{t}_Waldk_k100"], out[f"{t}_Waldk_k411"] = win.Waldk[:, :, 100, :], win.Waldk[:, :, 411, :]
+        win.Window(bird)
+        for n, v in stage(bird).items():
+            out[f"{t}_window_{n}"] = v
+        bn = ref.binning.Binning(kout=m.kout, co=co)
+        out[f"{t}_keff"] = bn.keff
+        like = bn.transform(bird)
+        for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+            out[f"{t}_binned_{n}"] = np.array(getattr(like, n), copy=True)
+        if spec["chained"]:
+            like = ref.chained.Chained().transform(like)
+            for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+                out[f"{t}_chained_{n}"] = np.array(getattr(like, n), copy=True)
+            like.co = pb.Common(Nl=Nl, No=Nl - 1, kmax=0.3, kmA=CFG3_KM, krA=CFG3_KR, ndA=spec["nd"])
+        like.PctNNLOl = np.zeros((Nl, 2, m.kout.size))
+        out[f"{t}_plk"] = basis.reduce_Plk(like, ng).sum()
+    np.savez_compressed(os.path.join(GOLD, "cfg3_nk512.npz"), **out)
+    print("cfg3_nk512 written:", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB raw")
+
+
 def cfg5_fixture(ref):
     """BASELINE cfg 5 after the projection stages, from the REAL reference: the Nk = 2048 AP-stage templates of caseF through
     Window (DR16 LRG and ELG windows, accboost 1) and Binning (kout = arange(0.025, 0.2, 0.01)), ELG also Chained.  The window precompute
@@ -792,6 +858,8 @@ def main():
             wmat_fixture(ref)
         elif name == "cfg3":
             cfg3_fixture(ref)
+        elif name == "cfg3_nk512":
+            cfg3_nk512_fixture(ref)
         elif name == "resumopt":
             resumopt_fixture(ref)
         elif name == "cfg5":
