@@ -92,7 +92,14 @@ def executed_flops_per_launch(B):
     wps = int(os.environ.get("EFTB_RESUM_WPS", str(DEFAULT_RESUM_WPS)))
     name = "resum_mfma_kernel<%d,0>" % (3 if wps >= 3 else 2)  # the build the engine launches
     with open(path) as fh:
-        info = json.load(fh)[name]
+        allinfo = json.load(fh)
+    info = allinfo[name]
+    from eftpipe_amd import _lib as L
+
+    lib_hash = L.load().eftb_source_hash().decode()
+    if allinfo.get("_source_hash") != lib_hash:  # e.g. EFTB_LIB points at another build: the counts do not describe the code that runs
+        raise SystemExit(f"bench.py: isa_counts.json describes sources {allinfo.get('_source_hash')}, the loaded library was built from {lib_hash}; "
+                         "run `python -c 'import __graft_entry__ as g; g.build()'` (or tools/isa_counts.py) for this build")
     loop = max(info["loops"], key=lambda b: b["mfma"] + b["valu_f64"])
     waves = ((NK - (NKLOW & ~15) + 63) // 64) * 4 * B  # k tiles start at a multiple of 16
     per_trip = {"kernel_build": name, "mfma": loop["mfma"], "valu_f64": loop["valu_f64"], "f64_ops": loop["f64_ops"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
@@ -423,7 +430,8 @@ def main():
 
 
 def _device_count():
-    """Visible HIP devices without initialising the GPU in this process: the ROCm SMI-free way is the runtime's own counter."""
+    """Visible HIP devices, from the runtime's own counter (hipGetDeviceCount: this does initialise the HIP runtime in this process, which is
+    about to create its engine anyway; no SMI tool is needed)."""
     import ctypes
 
     try:

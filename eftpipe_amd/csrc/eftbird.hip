@@ -102,7 +102,12 @@ struct eftb_engine {
     int like_nl = 0, like_nx = 0;   // template-block shape the data index was validated against (checked again when the LOGP stage launches)
     // input / output guards: kernels raise flags in mapped page-locked memory (status[0]: 1 + index of a cosmology whose P_lin is
     // non-finite or non-positive at its last two samples; status[1]: 1 + index of a cosmology with a non-finite P_l, EFTB_O_CHECK_FINITE)
+    // One pair per rotating set of the staged API (status[2 q], status[2 q + 1]: raised and cleared with step q's own results, whatever runs
+    // beside it) and one pair (slot NSETS) for runs on the engine's own buffers (eftb_put / eftb_run / eftb_eval_batch).
     int* status = nullptr;
+    int status_slot = 4;            // = NSETS: pair the kernels of the next launch raise (eftb_run_staged: the step's set)
+    int gath_set[4] = {4, 4, 4, 4};  // set whose P_l exchange `slot` carries (its flags are checked when the gathered block is handed out)
+    unsigned long long staged_launched = 0;  // eftb_run_staged calls so far: eftb_fetch_back(back) needs back < staged_launched
     bool check_finite = false;
     std::vector<double> like_host;  // eftb_eval_logp_batch: D2H landing block [B][MARG_OUT]
     int* like_index = nullptr;
@@ -413,7 +418,7 @@ static void launch_prep_rows(eftb_engine* e, hipStream_t st, int B, bool first, 
     hipLaunchKernelGGL(prep_rows_kernel, dim3(B), dim3(256), (size_t)c.Nkin * sizeof(double), st, c.Nkin, c.ntail, c.nxtail, (int)kpad(c.Nkin),
                        (int)kpad(c.Nkin + c.ntail), (int)kpad(c.Nkin + c.nxtail), c.max_batch, e->buf[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                        tb<double>(e, EFTB_T_LNXTAIL), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), first ? e->PA1 : nullptr, e->PA2, e->PA2T,
-                       ir ? e->PA3 : nullptr, e->status);
+                       ir ? e->PA3 : nullptr, e->status + 2 * e->status_slot);
 }
 
 static void queue_xy(eftb_engine* e, SynthBatch& sb, int B) {  // X(s), Y(s) [B][2][80] = [Pin | tail'] (BX BY ; TX TY)
@@ -472,17 +477,38 @@ static hipError_t sync_all(eftb_engine* e) {
     return hipSuccess;
 }
 
-// flags raised by the kernels of finished runs (call after a stream synchronisation); reported once, then cleared
-static int check_status(eftb_engine* e, const char* who) {
+// flags raised by the kernels of finished runs (call after the runs in question have finished); reported once, then cleared.
+// slot >= 0: only that pair (a staged step's own flags: the steps queued behind it keep theirs); slot < 0: every pair, after a synchronisation
+static int check_status(eftb_engine* e, const char* who, int slot = -1) {
     if (!e->status) return 0;
     volatile int* s = e->status;
-    const int bad_in = s[0], bad_out = s[1];
+    const int lo = slot < 0 ? 0 : slot, hi = slot < 0 ? eftb_engine::NSETS : slot;
+    int bad_in = 0, bad_out = 0;
+    for (int q = lo; q <= hi; ++q) {
+        if (!bad_in && !bad_out) {
+            bad_in = s[2 * q];
+            bad_out = s[2 * q + 1];
+        }
+        s[2 * q] = s[2 * q + 1] = 0;
+    }
     if (!bad_in && !bad_out) return 0;
-    s[0] = s[1] = 0;
     if (bad_in)
         return fail("%s: P_lin of cosmology %d is non-finite, or not positive at its last two samples (the FFTLog power-law extrapolation needs "
                     "them positive, reference fftlog.py:146-151); the outputs of that run are invalid", who, bad_in - 1);
     return fail("%s: non-finite P_l(k) for cosmology %d (EFTB_O_CHECK_FINITE)", who, bad_out - 1);
+}
+
+// bounded spin on an event (the sampler thread is about to enqueue the next step: the wake-up latency of a blocking wait would be paid once per step)
+static int spin_event(hipEvent_t ev, const char* who, const char* what) {
+    static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail("%s: %s", who, hipGetErrorString(q));
+        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+            return fail("%s: %s did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", who, what, limit_s);
+    }
 }
 
 // host inputs of one batch, before anything is copied: finite everywhere, P_lin positive where its logarithm is taken, distances positive
@@ -860,10 +886,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     }
     if (mask & EFTB_S_REDUCE)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],
-                           b[EFTB_B_TEMPL], b[EFTB_B_PLK], e->check_finite && !c.with_nnlo ? e->status + 1 : nullptr);
+                           b[EFTB_B_TEMPL], b[EFTB_B_PLK], e->check_finite && !c.with_nnlo ? e->status + 2 * e->status_slot + 1 : nullptr);
     if ((mask & EFTB_S_REDUCE) && c.with_nnlo)
         hipLaunchKernelGGL(reduce_nnlo_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIASN],
-                           b[EFTB_B_TEMPLN], b[EFTB_B_PLK], e->check_finite ? e->status + 1 : nullptr);
+                           b[EFTB_B_TEMPLN], b[EFTB_B_PLK], e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr);
     if (!(mask & EFTB_S_REGROUP) && !e->use_graphs && !nnlo_pass && hipEventRecord(e->evInFree, st) != hipSuccess) return fail("eftb_run: event record failed");
     if (ap_side) {
         if (hipEventRecord(e->evBack[bslot], st) != hipSuccess) return fail("eftb_run: event record failed");
@@ -983,6 +1009,10 @@ static int run_stages(eftb_engine* e, int mask, int B) {
 extern "C" {
 
 const char* eftb_last_error(void) { return g_err.c_str(); }
+#ifndef EFTB_SRC_HASH
+#define EFTB_SRC_HASH "unknown"
+#endif
+const char* eftb_source_hash(void) { return EFTB_SRC_HASH; }
 const char* eftb_version(void) { return "eftbird 0.3 (gfx950, fp64: anti-diagonal loops, mfma synthesis / resummation, overlapped steps)"; }
 
 int eftb_create(const eftb_config* cfg, eftb_engine** out) {
@@ -1090,8 +1120,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AP_CHUNK")) e->ap_chunk = atoi(f);
     if (const char* f = getenv("EFTB_RESUM_WPS")) e->resum_wps = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 4 * sizeof(int), hipHostMallocMapped));
-    memset(e->status, 0, 4 * sizeof(int));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 2 * (eftb_engine::NSETS + 1) * sizeof(int), hipHostMallocMapped));
+    memset(e->status, 0, 2 * (eftb_engine::NSETS + 1) * sizeof(int));
     HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
     *out = e;
     return 0;
@@ -1438,13 +1468,9 @@ int eftb_run(eftb_engine* e, int mask, int B) {
     if (B < 1 || B > e->c.max_batch) return fail("eftb_run: batch %d outside [1, %d]", B, e->c.max_batch);
     HIPCHK(hipSetDevice(e->c.device));
     const int slot = (int)(e->run_seq % eftb_engine::RUN_DEPTH);
-    if (e->run_seq >= eftb_engine::RUN_DEPTH) {  // the run launched RUN_DEPTH calls ago must have finished (spin: it almost always has)
-        for (;;) {
-            const hipError_t q = hipEventQuery(e->evRun[slot]);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return fail("eftb_run: %s", hipGetErrorString(q));
-        }
-    }
+    if (e->run_seq >= eftb_engine::RUN_DEPTH)  // the run launched RUN_DEPTH calls ago must have finished (spin: it almost always has)
+        if (int rc = spin_event(e->evRun[slot], "eftb_run", "the run launched RUN_DEPTH calls ago")) return rc;
+    e->status_slot = eftb_engine::NSETS;
     e->inputs_settled = true;  // eftb_put is synchronous: the inputs of this run are in place, its first stage may start early
     e->allow_back = true;
     const int rc = run_stages(e, mask, B);
@@ -1662,6 +1688,8 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     for (int id : kStagedIds)
         if (e->setbuf[e->cur_set][id]) e->buf[id] = e->setbuf[e->cur_set][id];
     e->staged_B = 0;
+    e->status_slot = e->cur_set;  // this step's kernels raise this set's flags (cleared here: whatever an abandoned step left is void)
+    e->status[2 * e->cur_set] = e->status[2 * e->cur_set + 1] = 0;
     ++e->epoch;  // (captured graphs hold the other set's pointers)
     HIPCHK(hipStreamWaitEvent(e->stream, e->evStaged[e->cur_set], 0));  // the side stream forks from here, so it inherits the wait
     HIPCHK(hipStreamWaitEvent(e->pre, e->evStaged[e->cur_set], 0));
@@ -1669,7 +1697,9 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     e->inputs_settled = e->allow_back = true;
     const int rc = run_stages(e, mask, B);
     e->inputs_settled = e->allow_back = false;
+    e->status_slot = eftb_engine::NSETS;
     if (rc) return rc;
+    ++e->staged_launched;
     hipStream_t last = e->back_pending ? e->back : e->stream;  // the step ends where its back half ran
     if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE))
         HIPCHK(hipMemcpyAsync(e->plk_host[e->cur_set], e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
@@ -1686,25 +1716,17 @@ int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count
     if (!e->cpy) return fail("eftb_fetch_back: no staged run yet");
     if (count > e->buf_elems[id]) return fail("eftb_fetch_back: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
     HIPCHK(hipSetDevice(e->c.device));
+    if ((unsigned long long)back >= e->staged_launched)
+        return fail("eftb_fetch_back: back = %d, but only %llu staged step(s) have been launched", back, e->staged_launched);
     const int t = (e->cur_set + eftb_engine::NSETS - back) % eftb_engine::NSETS;  // back = 3 is the set that the next eftb_stage_inputs refills
-    // spin on the step's event instead of sleeping in a synchronize call: the sampler thread is about to enqueue the next step, and the
-    // wake-up latency of a blocking wait would be paid once per step
-    static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; ++spins) {
-        const hipError_t q = hipEventQuery(e->evSetDone[t]);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) return fail("eftb_fetch_back: %s", hipGetErrorString(q));
-        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
-            return fail("eftb_fetch_back: the step did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", limit_s);
-    }
+    if (int rc = spin_event(e->evSetDone[t], "eftb_fetch_back", "the step")) return rc;
     if (id == EFTB_B_PLK && e->plk_host[t])
         memcpy(host, e->plk_host[t], count * sizeof(double));  // copied out by the DMA engine behind the step
     else if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
         HIPCHK(hipMemcpy(host, e->setbuf[t][id], count * sizeof(double), hipMemcpyDeviceToHost));
     else
         memcpy(host, e->setbuf[t][id], count * sizeof(double));  // the results are already in (mapped) host memory
-    return check_status(e, "eftb_fetch_back");
+    return check_status(e, "eftb_fetch_back", t);  // this step's own flags only: the steps queued behind it report with their own fetch
 }
 
 int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) { return eftb_fetch_back(e, 1, id, host, count); }
@@ -1793,6 +1815,7 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
         const int q = e->gather_slot;
         HIPCHK(hipEventRecord(e->evGath2[q], cs));
         e->gath_elems[q] = (size_t)e->nranks * count;
+        e->gath_set[q] = e->buf[EFTB_B_PLK] == e->orig[EFTB_B_PLK] || !e->cpy ? eftb_engine::NSETS : e->cur_set;
         // copy-out with the DMA engine, in line behind the exchange (measured with the PCIe traffic of eight ranks, 12.6 MB per step: 0.441 ms
         // per step; on a stream of its own 0.52 ms -- a sixth stream shares a hardware queue with the look-ahead --; a copy kernel writing
         // mapped host memory 0.62 ms)
@@ -1813,17 +1836,9 @@ static int gathered_ready(eftb_engine* e, const char* who, int which, int* slot)
     const int q = (e->gather_slot + eftb_engine::NSETS - which) % eftb_engine::NSETS;
     if (!e->gathered2[q] || !e->gath_elems[q]) return fail("%s: no such exchange yet", who);
     HIPCHK(hipSetDevice(e->c.device));
-    static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 0;; ++spins) {
-        const hipError_t r = hipEventQuery(e->evGathHost[q]);
-        if (r == hipSuccess) break;
-        if (r != hipErrorNotReady) return fail("%s: %s", who, hipGetErrorString(r));
-        if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
-            return fail("%s: the exchange did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", who, limit_s);
-    }
+    if (int rc = spin_event(e->evGathHost[q], who, "the exchange")) return rc;
     *slot = q;
-    return check_status(e, who);
+    return check_status(e, who, e->gath_set[q]);  // the flags of the step whose P_l this block carries (the root's own share)
 }
 
 int eftb_gathered_view(eftb_engine* e, int which, const double** block, size_t* count) {

@@ -158,15 +158,19 @@ class Window(HasLogger):
         if self.snapshot:
             bird.create_snapshot("window")
 
-    def integrWindow(self, P, many=False):
-        """Host form of the convolution of one array of rows (reference window.py:371-387): cubic interpolation onto the p grid, then
-        the masked dp-weighted matrix.  ``Window`` applies the same operator on the device; kept for callers of the helper."""
+    def integrWindow(self, P, interp=True):
+        """Host form of the convolution of one array of rows [Nl, n, Nk] (reference window.py:371-387, same signature): cubic interpolation
+        onto the p grid unless ``interp=False`` (P already sampled on p), then the masked dp-weighted matrix.  ``Window`` applies the same
+        operator on the device; kept for callers of the helper.  A 2-D [Nl, Nk] input is treated as one row per multipole."""
         from scipy.interpolate import interp1d
 
-        Pp = interp1d(self.co.k, P, axis=-1, kind="cubic", bounds_error=False, fill_value="extrapolate")(self.p)
-        if many:
-            return np.einsum("alkp,lsp->ask", self.Waldk, Pp)
-        return np.einsum("alkp,lp->ak", self.Waldk, Pp)
+        P = np.asarray(P)
+        flat = P.ndim == 2
+        if flat:
+            P = P[:, None]
+        Pp = interp1d(self.co.k, P, axis=-1, kind="cubic", bounds_error=False, fill_value="extrapolate")(self.p) if interp else P
+        out = np.einsum("alkp,lsp->ask", self.Waldk, Pp, optimize=True)
+        return out[:, 0] if flat else out
 
 
 # ----------------------------------------------------------------------------- window as a ready-made matrix

@@ -287,6 +287,8 @@ int  eftb_stream_read_probe(int device, size_t bytes, int bytes_per_lane, double
 
 const char* eftb_last_error(void);
 const char* eftb_version(void);
+/* first 16 hex digits of sha256(eftbird.hip + eftb_kernels.hpp) of the build (csrc/Makefile); the key of csrc/isa_counts.json */
+const char* eftb_source_hash(void);
 
 #ifdef __cplusplus
 }

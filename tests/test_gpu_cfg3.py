@@ -185,3 +185,109 @@ def test_joint_likelihood_on_the_reference_data(golden, windows, tag):
     like_nj = MarginalLikelihood(eng, index, g["data_vector"], g["invcov"], np.zeros(nG), np.full(nG, np.inf), jeffreys=False)
     assert np.isclose(like_nj.logp(rows)[0], g[tag + "_logp_nojeffreys"], rtol=1e-9)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# cfg 3 on the BASELINE grid: Nk = 512 with the production windows (tests/golden/cfg3_nk512.npz, tools/make_fixtures.py cfg3_nk512)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _co512(g, sc, No=3):
+    from eftpipe_amd import pybird
+
+    co = pybird.Common(Nl=3, No=No, kmax=0.3, **sc)
+    co.k, co.Nk = g["k"], g["k"].size
+    co.kr = co.k[0.02 <= co.k]
+    co.Nkr = co.kr.size
+    co.Nklow = co.Nk - co.Nkr
+    return co
+
+
+@pytest.fixture(scope="module")
+def windows512(golden):
+    """Window plugin objects of the three tracers on the 512-point survey grid at accboost 4 / windowk 0.1: eftb_window_precompute at
+    Np = 1540 x Nk = 512 (window_bessel_kernel, three K = 2473 GEMMs per tracer, window_maskdp_kernel, the fold GEMM)"""
+    import os
+
+    from eftpipe_amd.window import Window
+
+    g = golden("cfg3_nk512")
+    out = {}
+    for t, sc in zip(U.TRACERS, U.scales(g)):
+        co = _co512(g, sc)
+        out[t] = (co, Window(window_configspace_file=os.path.join(U.GOLD, "win_NGC_%s_sQ024.npy" % t.split("_")[0]), co=co, load=False, save=False,
+                             accboost=int(g["accboost"]), windowk=float(g["windowk"])))
+    return out
+
+
+@pytest.mark.parametrize("t", U.TRACERS)
+def test_nk512_window_precompute_at_production_settings(golden, windows512, t):
+    """the device precompute at the shipped accuracy on the BASELINE grid against the reference's own Waldk (two k rows and the p sums,
+    1e-9) and its convolved templates (reference window.py:27-33, 262-415)"""
+    from types import SimpleNamespace
+
+    g = golden("cfg3_nk512")
+    co, win = windows512[t]
+    assert np.array_equal(win.p, g["window_p"]) and win.p.size == 1540 and win.Waldk.shape == (3, 3, 512, 1540)
+    assert relerr(win.Waldk[:, :, 100, :], g[t + "_Waldk_k100"]) < 1e-9 and relerr(win.Waldk[:, :, 411, :], g[t + "_Waldk_k411"]) < 1e-9
+    assert relerr(win.Waldk.sum(axis=-1), g[t + "_Waldk_sum_p"]) < 1e-9
+    bird = SimpleNamespace(co=co, f=float(g[t + "_f"]), Picc=np.zeros((3, 512)), PctNNLOl=None, **{n: g[f"{t}_ap_{n}"].copy() for n in U.NAMES})
+    win.Window(bird)
+    for n in U.NAMES:
+        assert relerr(getattr(bird, n), g[f"{t}_window_{n}"]) < TOL, n
+
+
+def test_nk512_three_tracer_batch_against_reference(golden, windows512):
+    """BASELINE cfg 3 as one batched run: the three kernels of a likelihood point (own P_lin, own AP fiducial, own production window,
+    binning onto the data k, ELG chained) at Nl = 3, Nk = 512 through eftb_eval_batch with per-tracer folded operators; templates
+    against the reference at 1e-8, P_l pointwise at 1e-6 (yaml :6-27, 63-70; theory.py:557-609)."""
+    from eftpipe_amd import pybird
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("cfg3_nk512")
+    k = g["k"]
+    nb = max(g[t + "_kout"].size for t in U.TRACERS)
+    t0 = U.TRACERS[0]
+    eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, APst=True, DA_AP=float(g[t0 + "_DA_AP"]), H_AP=float(g[t0 + "_H_AP"])), max_batch=6)
+    ops = []
+    for t in U.TRACERS:
+        _, win = windows512[t]
+        Bm, keff, _, _ = TB.binning_operator(k, g[t + "_kout"])
+        assert relerr(keff[None], g[t + "_keff"][None]) < 1e-13
+        op = TB.compose_operator(3, k.size, Wfold=win.Wfold, binning=Bm, chained=U.CHAINED[t])
+        full = np.zeros((3, 3, nb, k.size))
+        full[: op.shape[0], :, : op.shape[2]] = op
+        ops.append(eng.add_operator(full))
+    # (a) the AP-stage templates of every tracer, before any operator
+    Pin, f, DA, H = _inputs(g)
+    templ = eng.eval_batch(Pin, f, DA, H)
+    rows24 = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
+    for i, t in enumerate(U.TRACERS):
+        for n, sl in rows24.items():
+            assert relerr(templ[i][:, sl], g[f"{t}_ap_{n}"]) < TOL, (t, n)
+    # (b) the whole chain per tracer in one batched run of two walkers, with the bias contraction
+    eng.set_tracers(3, ops)
+    p = U.params(g)
+    sc = U.scales(g)
+    bias = []
+    for i, t in enumerate(U.TRACERS):
+        A, B = U.CROSS.get(t, (t, t))
+        bsA = [p[A + "_b1"], p[A + "_b2"], 0.0, p[A + "_b4"], 0.0, 0.0, 0.0]
+        bsB = [p[B + "_b1"], p[B + "_b2"], 0.0, p[B + "_b4"], 0.0, 0.0, 0.0] if t in U.CROSS else None
+        bias.append(bias_row(float(f[i]), bsA, bsB, (0.0, 0.0, 0.0), **sc[i]))
+    bias = np.stack(bias)
+    Pin2, f2, DA2, H2 = np.concatenate([Pin, 1.02 * Pin]), np.concatenate([f, f]), np.concatenate([DA, 0.99 * DA]), np.concatenate([H, 1.01 * H])
+    templ, plk = eng.eval_batch(Pin2, f2, DA2, H2, bias=np.concatenate([bias, bias]))
+    assert templ.shape == (6, 3, 24, nb) and plk.shape == (6, 3, nb)
+    for i, t in enumerate(U.TRACERS):
+        want = U.final_templates(g, t)
+        no, nx = want["P11l"].shape[0], want["P11l"].shape[-1]
+        for n, sl in rows24.items():
+            assert relerr(templ[i][:no, sl, :nx], want[n]) < TOL, (t, n)
+        ref = g[t + "_plk"][:no]
+        assert relerr(plk[i][:no, :nx], ref) < TOL, t
+        nz = np.abs(ref) > 1e-3 * np.max(np.abs(ref), axis=-1, keepdims=True)
+        assert np.max(np.abs(plk[i][:no, :nx] / ref - 1.0)[nz]) < 1e-6, t       # the north-star bar, pointwise
+    assert not np.array_equal(plk[3], plk[0])
+    eng.close()

@@ -571,3 +571,56 @@ def test_pipelined_steps_with_changing_inputs(golden):
     with pytest.raises(L.EftbError):
         eng.fetch_previous("PLK", (B, 3, g["k"].size), back=4)
     eng.close()
+
+
+def test_pipelined_flags_belong_to_their_step(golden):
+    """the guard flags are per rotating set.  In a depth-3 pipeline one step is poisoned (huge bias coefficients overflow its
+    P_l; EFTB_O_CHECK_FINITE) -- exactly that step's fetch fails, naming the cosmology; the steps queued around it fetch clean results.  And
+    eftb_fetch_back refuses a step that was never launched instead of handing out a zero-filled block."""
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    B, nsteps, depth, poisoned = 2, 6, 3, 2
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=B)
+    eng.set_check_finite(True)
+    shape = (B, 3, g["k"].size)
+    b0 = bias_row(float(g["f"]), [2.0, 0.5, 0.3, 0.2, -1.0, -2.0, 0.5], None, (0.3, 0.1, -0.4), kmA=0.7, krA=0.25, ndA=4.5e-5)
+    steps = [dict(Pin=np.stack([g["Pin"], (1.0 + 0.01 * s) * g["Pin"]]), f=float(g["f"]), DA=float(g["DA"]), H=float(g["H"]), bias=np.stack([b0, b0]))
+             for s in range(nsteps)]
+    steps[poisoned]["bias"] = np.stack([b0, np.full(24, 1e308)])
+    want = [None if s == poisoned else eng.eval_batch(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"], templates=False) for s, st in enumerate(steps)]
+    mask = eng.full_mask(reduce=True)
+    # nothing launched yet through the staged API
+    eng.stage_inputs(steps[0]["Pin"], steps[0]["f"], steps[0]["DA"], steps[0]["H"], bias=steps[0]["bias"])
+    with pytest.raises(L.EftbError, match="no staged run yet|staged step"):
+        eng.fetch_previous("PLK", shape, back=0)
+    eng.run_staged(mask, B)
+    with pytest.raises(L.EftbError, match="only 1 staged step"):
+        eng.fetch_previous("PLK", shape, back=1)
+    assert np.array_equal(eng.fetch_previous("PLK", shape, back=0), want[0])
+    outcome = {}
+
+    def fetch(step, back):
+        try:
+            outcome[step] = eng.fetch_previous("PLK", shape, back=back)
+        except L.EftbError as exc:
+            outcome[step] = str(exc)
+
+    for s in range(1, nsteps):
+        st = steps[s]
+        eng.stage_inputs(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"])
+        eng.run_staged(mask, B)
+        if s - depth >= 1:
+            fetch(s - depth, depth)
+    for back in range(depth - 1, -1, -1):
+        fetch(nsteps - 1 - back, back)
+    for s in range(1, nsteps):
+        if s == poisoned:
+            assert isinstance(outcome[s], str) and "non-finite P_l" in outcome[s] and "cosmology 1" in outcome[s], outcome[s]
+        else:
+            assert isinstance(outcome[s], np.ndarray) and np.array_equal(outcome[s], want[s]), (s, outcome[s])
+    eng.sync()   # nothing left to report
+    eng.close()

@@ -487,6 +487,31 @@ def test_cfg3_host_tables_and_joint_rows(golden):
         assert relerr(V[0][None], g["PNG"][None]) < 1e-13 and relerr(V[1:], g[tag + "_PG"]) < 1e-13, tag
 
 
+def test_cfg3_nk512_host_tables_at_production_window(golden):
+    """BASELINE cfg 3 on the BASELINE grid (Nk = 512) with the window the reference ships (accboost 4, windowk 0.1; yaml :63-65), host side:
+    the cross-spectrum window `win_NGC_X` through the table builder against the reference's own Waldk rows / p sums at Np = 1540, the folded
+    window operator against the reference's convolved templates, window -> binning against its binned templates
+    (tests/golden/cfg3_nk512.npz, tools/make_fixtures.py cfg3_nk512; reference window.py:27-33, 262-415)."""
+    import cfg3_util as U
+    from eftpipe_amd import tables as TB
+
+    g = golden("cfg3_nk512")
+    k, t = g["k"], "X_NGC"
+    assert k.size == 512 and int(g["accboost"]) == 4 and float(g["windowk"]) == 0.1
+    assert np.array_equal(TB.window_pgrid(float(k.max()), 4), g["window_p"]) and g["window_p"].size == 1540
+    tab = U.window_table(t)
+    Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3, accboost=4)
+    Wfold, Waldk = TB.window_fold(k, Wal, p, windowk=0.1)
+    assert relerr(Waldk[:, :, 100, :], g[t + "_Waldk_k100"]) < 1e-9 and relerr(Waldk[:, :, 411, :], g[t + "_Waldk_k411"]) < 1e-9
+    assert relerr(Waldk.sum(axis=-1), g[t + "_Waldk_sum_p"]) < 1e-9
+    Bm, keff, _, _ = TB.binning_operator(k, g[t + "_kout"])
+    assert relerr(keff[None], g[t + "_keff"][None]) < 1e-13
+    op = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm)
+    for n in U.NAMES:
+        assert relerr(np.einsum("alxk,lnk->anx", Wfold, g[f"{t}_ap_{n}"]), g[f"{t}_window_{n}"]) < 1e-9, n
+        assert relerr(np.einsum("alxk,lnk->anx", op, g[f"{t}_ap_{n}"]), g[f"{t}_binned_{n}"]) < 1e-9, n
+
+
 def test_integral_constraint_against_oracle(tmp_path):
     """SURVEY 8(f) rank 4, PARITY UNPINNED (the reference's interp2d call no longer exists in SciPy, so it cannot produce fixtures):
     eftpipe_amd.icc.IntegralConstraint -- PSN, the 2-D FFTLog matrix with the documented interp2d replacement, mask / dp weights, the

@@ -378,3 +378,20 @@ def test_resum_nondefault_options(golden):
     for n in ("P11l", "Pctl", "Ploopl"):
         assert relerr(st[n], g["resum_" + n]) < TOL, n
     assert relerr(taps["setpscfl"]["Ploopl"], g["setpscfl_Ploopl"]) < TOL and relerr(taps["setpscfl"]["Cloopl"], g["setpscfl_Cloopl"]) < TOL
+
+
+def test_cfg3_nk512_oracle_ap_stage_other_redshift(golden):
+    """cfg 3 on the BASELINE grid (tests/golden/cfg3_nk512.npz): the oracle through resummation + AP (APst) for the ELG kernel (z = 0.849, its
+    own P_lin and AP fiducial) at Nk = 512 against the reference -- the Nk = 512 pin of caseD at a second redshift; the production window
+    at this grid is pinned through the host table builder (test_host_logic.py) and the device precompute (test_gpu_cfg3.py), the
+    oracle's own 4096-point precompute at Np = 1540 x Nk = 512 takes minutes."""
+    import cfg3_util as U
+    from oracle import OracleConfig
+
+    g = golden("cfg3_nk512")
+    t = "ELG_NGC"
+    sc = U.scales(g)[U.TRACERS.index(t)]
+    eng = OracleEngine(OracleConfig(Nl=3, k=g["k"], with_resum=True, with_ap=True, APst=True, DA_AP=float(g[t + "_DA_AP"]), H_AP=float(g[t + "_H_AP"]), **sc))
+    st = eng.evaluate(g["kin"], g[t + "_Pin"], float(g[t + "_f"]), float(g[t + "_DA"]), float(g[t + "_H"]), pairwise=True)
+    for n in U.NAMES:
+        assert relerr(st[n], g[f"{t}_ap_{n}"]) < TOL, n

@@ -30,6 +30,17 @@ MFMA_FLOPS = {"v_mfma_f64_16x16x4_f64": 2 * 16 * 16 * 4, "v_mfma_f64_16x16x4f64"
               "v_mfma_f64_4x4x4f64": 2 * 4 * 4 * 4 * 4}
 
 
+def source_hash():
+    """first 16 hex digits of sha256(eftbird.hip + eftb_kernels.hpp): the same value csrc/Makefile compiles into the library"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("eftbird.hip", "eftb_kernels.hpp"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def emit_asm(path):
     cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-function", "-Wno-unused-command-line-argument",
            "-S", "--cuda-device-only", "-o", path, os.path.join(CSRC, "eftbird.hip")]
@@ -149,12 +160,15 @@ def main():
             emit_asm(p)
             text = open(p).read()
     res = analyse(text)
+    res["_source_hash"] = source_hash()
     with open(a.out, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
     if a.show:
         print(json.dumps(res.get(a.show), indent=1))
     else:
         for k, v in sorted(res.items()):
+            if k.startswith("_"):
+                continue
             big = max(v["loops"], key=lambda b: b["mfma"] + b["valu_f64"], default=None)
             print(f"{k:44s} vgpr {v.get('vgprs', '?'):>4} agpr {v.get('agprs', '?'):>3} scratch {v.get('scratch_bytes', '?'):>4} lds {v.get('lds_bytes', '?'):>6}"
                   + (f"  hot loop: {big['mfma']} mfma, {big['valu_f64']} f64 valu, {big['valu_other']} other valu, {big['vmem']} vmem, {big['smem']} smem" if big else ""))
