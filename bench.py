@@ -43,6 +43,9 @@ DEFAULT_RESUM_WPS = 2   # engine default (eftbird.hip resum_wps); EFTB_RESUM_WPS
 DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "2"))  # steps queued on the GPU ahead of the one being fetched (1..3; measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
 
 
+STEP_TIMES = [] if os.environ.get("EFTB_BENCH_STEP_TIMES") else None  # diagnostics: host time at which each timed step's P_l had been fetched
+
+
 def cpu_baseline(picks, budget_s=20.0):
     """Time the oracle (NumPy restatement of the reference path) on this host, bounded sample.  `picks` = cosmologies taken from the draw
     sets of the timed loop (dicts with kin, Pin, f, DA, H): the sample cycles through them, and the oracle's templates of the first two come
@@ -177,7 +180,8 @@ def main():
 
     sets = [draw_set(i) for i in range(W + K)]
     mask = eng.full_mask(reduce=True)
-    results = np.empty((K, B, NL, NK))                                   # every timed step's P_l of this rank (N = 1) ...
+    results = np.zeros((K, B, NL, NK))                                   # every timed step's P_l of this rank (N = 1) ...
+    results.fill(0.0)                                                     # (touched: the sampler's output buffers exist before the clock starts, no first-touch page faults inside it)
     # (multi-GPU: the root takes every step's gathered block [world, B, NL, NK] as a view of the engine's page-locked host copy -- 12.6 MB per
     # step at 8 ranks, more than one host thread can copy again in a step's time -- and keeps a copy of its own rank's slice for the check below)
 
@@ -202,6 +206,8 @@ def main():
                 cp.gather_host(eng.get("PLK", (B, NL, NK)))
             elif i >= DEPTH:
                 eng.fetch_previous("PLK", (B, NL, NK), out=results[i - DEPTH] if keep else None, back=DEPTH)
+                if STEP_TIMES is not None and keep:
+                    STEP_TIMES.append(time.perf_counter())
         # drain: the last DEPTH steps
         if exchange == "rccl":
             eng.sync()
@@ -225,6 +231,8 @@ def main():
     loop(W, K, keep=True)
     cp.barrier()
     elapsed = cp.max(time.perf_counter() - t0)
+    if STEP_TIMES:
+        print("[bench] fetch-complete times since t0 (ms):", " ".join(f"{(t - t0) * 1e3:.3f}" for t in STEP_TIMES), file=sys.stderr)
     dom_ms, dom_n = eng.dominant_time(reset=True)
     eng.time_dominant(False)
 

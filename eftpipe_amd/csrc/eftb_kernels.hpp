@@ -302,6 +302,88 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
         }
 }
 
+// The same product for problems with FEW rows (the first stage: M = batch, a few hundred columns, K <= 288): one wave = one tile of 16 rows x 32
+// columns, operands straight from global memory into the MFMA lanes -- no LDS, no barriers, a 64-thread workgroup of ~70 registers that
+// starts in any free wave slot.  synth_kernel's 32 x 64 tiles give such a problem 20-50 workgroups, each walking K in 24-deep chunks behind
+// two barriers and a global -> register -> LDS hop per chunk: 35 us alone and 90 us beside the resummation for 0.08 GFLOP (round-3 trace:
+// the look-ahead chain is the critical path of a step, and this was its longest link).
+// K runs in groups of 16: lane (r = lane & 15, g = lane >> 4) holds A[row r][16 u + 4 g + j] (one 32-byte load) and multiplies it, for
+// j = 0..3, with Tab[16 u + 4 g + j][x0 + 2 r + {0, 1}] (one 16-byte load): the k order inside an MFMA is a permutation of the usual one, the
+// same on both operands.  Column tile t holds x0 + 2 r + t, so a lane stores pairs of neighbouring columns.  K is a multiple of 16 (SYN_KPAD).
+__global__ __launch_bounds__(64) void gemm_direct_kernel(SynthBatch batch) {
+    int pi = 0, wg0 = 0;
+#pragma unroll
+    for (int q = 0; q < SYN_MAXP - 1; ++q)
+        if (q + 1 < batch.n && (int)blockIdx.x >= batch.p[q].wg_end) {
+            pi = q + 1;
+            wg0 = batch.p[q].wg_end;
+        }
+    const SynthDesc& d = batch.p[pi];
+    const int wg = blockIdx.x - wg0, bx = wg % d.wgx, by = wg / d.wgx;
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const int rowa = by * 16 + r, rc = rowa < d.M ? rowa : d.M - 1;
+    const double* ap = d.A + (long long)(rc / d.rpg) * d.a_group + (long long)(rc % d.rpg) * d.K + 4 * g;
+    const int x = bx * 32 + 2 * r;
+    const bool pairs = !(d.X & 1);  // (16-byte loads of two neighbouring columns need an even row length)
+    const int x0 = x < d.X ? x : d.X - 1, x1 = x + 1 < d.X ? x + 1 : d.X - 1;
+    const double* bp = d.Tab + (size_t)(4 * g) * d.X;
+    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int ng = d.K / 16;
+    if (pairs) {
+        const double* bq = bp + (x + 1 < d.X ? x : d.X - 2);
+#pragma unroll 2
+        for (int u = 0; u < ng; ++u) {
+            const double4 a = *reinterpret_cast<const double4*>(ap + 16 * u);
+            double2 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const double2*>(bq + (size_t)(16 * u + j) * d.X);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b[0].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b[0].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[1].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[1].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, b[2].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.z, b[2].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, b[3].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.w, b[3].y, acc1, 0, 0, 0);
+        }
+    } else {
+#pragma unroll 2
+        for (int u = 0; u < ng; ++u) {
+            const double4 a = *reinterpret_cast<const double4*>(ap + 16 * u);
+            const double av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double* br = bp + (size_t)(16 * u + j) * d.X;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], br[x0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[j], br[x1], acc1, 0, 0, 0);
+            }
+        }
+    }
+    // D: rows g + 4 q, column r of each tile -> x and x + 1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = by * 16 + g + 4 * q;
+        if (row < d.M && x < d.X) {
+            const int grp = row / d.rpg, mem = row % d.rpg;
+            double v0 = acc0[q], v1 = acc1[q];
+            if (d.gscale) {
+                v0 *= d.gscale[(size_t)grp * d.X + x];
+                if (x + 1 < d.X) v1 *= d.gscale[(size_t)grp * d.X + x + 1];
+            }
+            if (d.xscale) {
+                v0 *= d.xscale[x];
+                if (x + 1 < d.X) v1 *= d.xscale[x + 1];
+            }
+            double* o = d.out + (size_t)grp * d.o_group + (size_t)mem * d.X + x;
+            if (pairs) *reinterpret_cast<double2*>(o) = make_double2(v0, v1);  // (x even, X even: x + 1 < X)
+            else {
+                o[0] = v0;
+                if (x + 1 < d.X) o[1] = v1;
+            }
+        }
+    }
+}
+
 // out[g][r][x] = sum_c comb[r][c] basis[g][c][x]: the 28 (10) loop matrices from their 7 (2) basis matrices
 // (tables.py loop_basis); one lane = one x of one cosmology and EXP_RPB output rows, the basis values stay in registers.
 constexpr int EXP_RPB = 8;
@@ -1239,8 +1321,9 @@ __global__ __launch_bounds__(256) void resum_sum_kernel(int Nk, int Nl, int nchu
 //
 // spline_kernel: the knot derivatives are  s = A^-1 R y  with A the (constant) not-a-knot tridiagonal matrix;
 // A^-1 R decays like 0.27^|i-j|, so the host ships it as a band of half-width SPL_HB (truncation < 1e-18,
-// checked in tests) and the solve becomes a banded matrix product.  Output: YS[series][i] = (y_i, s_i), the Hermite data of
-// the piecewise cubic on [k_i, k_i+1] (half the bytes of power-form coefficients).
+// checked in tests) and the solve becomes a banded matrix product.  Output: S[series][i] = s_i; together with y_i = T[series][i]
+// that is the Hermite data of the piecewise cubic on [k_i, k_i+1] (round 3: the knot values are no longer copied beside the slopes --
+// 37 MB less written per step; the consumers read y from the template block itself).
 // ------------------------------------------------------------------------------------------------
 constexpr int SPL_HB = 32;
 
@@ -1252,7 +1335,7 @@ constexpr int SPL_W = 128, SPL_LD = SPL_W + 2;  // staged window (64 knots + 2 x
 
 // (register cap: 96 in all instead of 96 + 8 accumulator registers -- what is free beside two resummation waves on a SIMD; same speed alone)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(88))) void spline_kernel(int Nk, int nseries, int rlo, int rsel, const double* __restrict__ T, const double* __restrict__ band,
-                                                     double* __restrict__ YS) {
+                                                     double* __restrict__ S) {
     __shared__ double ys[16 * SPL_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     int ktile, share;  // the k tiles of one share of the series run on one XCD: their halo windows overlap by half
@@ -1300,8 +1383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(88))) void spli
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int sr = g + 4 * q, series = grp * 16 + sr;
-            if (series < nseries && i < Nk)
-                *reinterpret_cast<double2*>(YS + ((size_t)row_of(series) * Nk + i) * 2) = make_double2(ys[sr * SPL_LD + 16 * wave + SPL_HB + r], acc[q]);
+            if (series < nseries && i < Nk) S[(size_t)row_of(series) * Nk + i] = acc[q];
         }
     }
 }
@@ -1399,28 +1481,39 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
                                                        const double* __restrict__ Hw, const double* __restrict__ fid,
                                                        const double* __restrict__ mu, const double* __restrict__ wmu,
                                                        const double* __restrict__ legmu, const double* __restrict__ ROOT,
-                                                       const double* __restrict__ T, const double* __restrict__ YS, double* __restrict__ Tout,
-                                                       const int4* __restrict__ META) {
+                                                       const double* __restrict__ T, const double* __restrict__ S, double* __restrict__ Tout,
+                                                       const int4* __restrict__ META, const double* __restrict__ bias, double* __restrict__ Plk,
+                                                       int msplit, int* __restrict__ nonfinite) {
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
-    if (META && !META[(size_t)w * KT + kt].w) return;  // fallback duty only: the tile went through ap_rows_kernel
+    // fallback duty only: the 32-k tile of this lane went through ap_rows_kernel (the gate is per half wave; no barrier below)
+    if (META && !META[(size_t)w * 2 * KT + 2 * kt + (threadIdx.x >> 5)].w) return;
     const int k = kt * 64 + threadIdx.x;
     if (k >= Nk) return;
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w], F = qpar / qperp;
     const double kq = kk[k] / qperp, c = 2.0 / (qperp * qperp * qpar);
     const double* root = ROOT + (size_t)w * nmu;
     const int i_first = knot_interval(kk, Nk, kq * root[0]);
+    // bias contraction riding along (bias != null): two FMA chains, rows [0, msplit) and [msplit, NROW), added at the end -- the order
+    // of reduce_kernel and of ap_rows_kernel's epilogue, so that a fallback tile's P_l is bit-identical to theirs
+    double ch0[NL], ch1[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ch0[l] = ch1[l] = 0.0;
+    const double* bw = bias ? bias + (size_t)w * NROW : nullptr;
     for (int r = 0; r < NROW; ++r) {
+        const double br = bw ? bw[r] : 0.0;
         if (r >= nr || r < rlo) {  // rows outside [rlo, nr) are copied through
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
-                Tout[o] = T[o];
+                const double v = T[o];
+                Tout[o] = v;
+                if (r < msplit) ch0[l] = fma(br, v, ch0[l]); else ch1[l] = fma(br, v, ch1[l]);
             }
             continue;
         }
-        const double2* ys = reinterpret_cast<const double2*>(YS) + ((size_t)w * NL * NROW + r) * Nk;
+        const size_t rbase = ((size_t)w * NL * NROW + r) * Nk;
         double acc[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] = 0.0;
@@ -1435,18 +1528,31 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
             double P = 0.0;
 #pragma unroll
             for (int lp = 0; lp < NL; ++lp) {
-                const double2 ya = ys[(size_t)lp * NROW * Nk + i], yb = ys[(size_t)lp * NROW * Nk + i + 1];
-                const double sl = (yb.x - ya.x) * ih;
-                const double c3 = (ya.y + yb.y - 2.0 * sl) * ih * ih;
-                const double c2 = (sl - ya.y) * ih - c3 * h;
-                P = fma(fma(fma(fma(c3, t, c2), t, ya.y), t, ya.x), lpv[lp], P);
+                const size_t o = rbase + (size_t)lp * NROW * Nk + i;
+                const double ya = T[o], yb = T[o + 1], sa = S[o], sb = S[o + 1];
+                const double sl = (yb - ya) * ih;
+                const double c3 = (sa + sb - 2.0 * sl) * ih * ih;
+                const double c2 = (sl - sa) * ih - c3 * h;
+                P = fma(fma(fma(fma(c3, t, c2), t, sa), t, ya), lpv[lp], P);
             }
             const double wj = wmu[j] * P;
 #pragma unroll
             for (int l = 0; l < NL; ++l) acc[l] = fma(wj, legmu[(size_t)l * nmu + j], acc[l]);
         }
 #pragma unroll
-        for (int l = 0; l < NL; ++l) Tout[(((size_t)w * NL + l) * NROW + r) * Nk + k] = c * acc[l];
+        for (int l = 0; l < NL; ++l) {
+            const double v = c * acc[l];
+            Tout[(((size_t)w * NL + l) * NROW + r) * Nk + k] = v;
+            if (r < msplit) ch0[l] = fma(br, v, ch0[l]); else ch1[l] = fma(br, v, ch1[l]);
+        }
+    }
+    if (bias) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const double a = ch0[l] + ch1[l];
+            Plk[((size_t)w * NL + l) * Nk + k] = a;
+            if (nonfinite && !(fabs(a) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
+        }
     }
 }
 
@@ -1464,7 +1570,7 @@ __global__ __launch_bounds__(256, 2) void ap_moments_kernel(int Nk, int nmu, con
                                                        const double* __restrict__ Hw, const double* __restrict__ fid,
                                                        const double* __restrict__ mu, const double* __restrict__ PS,
                                                        const double* __restrict__ ROOT, const double* __restrict__ T,
-                                                       const double* __restrict__ YS, double* __restrict__ Tout) {
+                                                       const double* __restrict__ S, double* __restrict__ Tout) {
     constexpr int NS = NL * NL * 4;
     constexpr int NRT = (NR + RS - 1) / RS;  // rows per lane: the NR rows are split over RS workgroups (blockIdx.z)
     constexpr int NACC = NL * NRT;
@@ -1516,7 +1622,7 @@ __global__ __launch_bounds__(256, 2) void ap_moments_kernel(int Nk, int nmu, con
         const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
         const double* pa = ps + (size_t)ja * NS;
         const double* pb = ps + (size_t)jb * NS;
-        const double* cw = YS + ((size_t)w * NL * NROW * Nk + i) * 2;
+        const size_t cw = (size_t)w * NL * NROW * Nk + i;  // knot i of series (l' = 0, row 0): y in T, s in S
         // memory round trips are what this kernel waits for (PMC: 75 % of the wave cycles): the prefix sums of all l' are
         // fetched in one batch, and the spline data of l' + 1 is in flight while l' is being accumulated
         double ms[NL][NL][4];
@@ -1545,9 +1651,9 @@ __global__ __launch_bounds__(256, 2) void ap_moments_kernel(int Nk, int nmu, con
         auto fetch = [&](int lp, int buf) {
 #pragma unroll
             for (int r = 0; r < NRT; ++r) {
-                const double2* cp = reinterpret_cast<const double2*>(cw + ((size_t)lp * NROW + min(rbase + r, NR - 1)) * Nk * 2);
-                ya[buf][r] = cp[0];  // (y_i, s_i)
-                yb[buf][r] = cp[1];  // (y_i+1, s_i+1)
+                const size_t o = cw + ((size_t)lp * NROW + min(rbase + r, NR - 1)) * Nk;
+                ya[buf][r] = make_double2(T[o], S[o]);          // (y_i, s_i)
+                yb[buf][r] = make_double2(T[o + 1], S[o + 1]);  // (y_i+1, s_i+1)
             }
         };
         fetch(0, 0);
@@ -1600,15 +1706,21 @@ __global__ __launch_bounds__(256, 2) void ap_moments_kernel(int Nk, int nmu, con
 // The weights depend on (DA, H) only -- inputs -- so ap_weights_kernel runs on the look-ahead stream with the prefix sums, off the
 // critical path; what is left behind the resummation is ap_rows_kernel, a banded product that streams the spline data once
 // through LDS: 66 MB in, 33 MB out, a few dozen FMAs per output.
-//   ap_weights_kernel  workgroup = 64 k x 4 waves of one cosmology; wave <-> a share of the (l', l) pairs, the thread walks its k's
-//                      intervals in mu order carrying the shared knot's contribution; writes W[w][tile][d][l][l'][{y,s}][64], i0[w][k] and
+//   ap_weights_kernel  workgroup = 64 k x NL waves of one cosmology; wave <-> l', the thread walks its k's intervals in mu order carrying
+//                      the shared knot's contribution; writes, per tile of 32 k (a half wave), W[w][tile][d][l][l'][{y,s}][32], i0[w][k] and
 //                      the tile's window (lowest knot, span, knots per k); tiles that need more than APW_DCAP knots per k or a window
 //                      of more than APW_WIN knots are flagged and left to ap_direct_kernel
-//   ap_rows_kernel     workgroup = (tile of 64 k, cosmology, chunk of NRC template rows); wave <-> output multipole l; the (y, s)
-//                      window of the chunk's rows (all l') sits in LDS, the weights of knot d are six coalesced loads per thread
+//   ap_rows_kernel     workgroup = (tile of 32 k, cosmology) x NL waves, wave <-> output multipole l, the two half waves <-> two halves of
+//                      the template rows.  The (y, s) window of ALL rows and all l' sits in LDS (two planes, filled by global_load_lds with no
+//                      register staging), so every byte of the weights, of the templates and of the slopes is read from HBM once
+//                      (round 2 walked the rows in chunks of 7 and re-read the 44 MB of weights per chunk: 199 MB fetched for 110 needed);
+//                      when REDUCE follows directly, the bias contraction P_l = sum_row b_row out[l][row] rides in the epilogue.
 // ------------------------------------------------------------------------------------------------
 constexpr int APW_DCAP = 32;  // knots per k on the fast path
-constexpr int APW_WIN = 112;  // LDS window of a tile, in knots (64 k + the drift of i0 across the tile + the knots per k)
+#ifndef APR_AHEAD
+#define APR_AHEAD 6
+#endif
+constexpr int APW_WIN = 64;   // LDS window of a 32-k tile, in knots (32 k + the drift of i0 across the tile + the knots per k)
 
 template <int NL>
 __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
@@ -1623,8 +1735,8 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
     double* s_k = sm;                   // [Nk]
     double* s_root = sm + Nk;           // [nmu]
     double* s_ih = sm + Nk + nmu + (nmu & 1);  // [Nk] 1 / (k_i+1 - k_i): one division per knot and workgroup instead of one per (k, slot) and wave
-    __shared__ int s_red[3];            // min i0, max i0, max knots per k over the tile
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_red[2][3];         // per half wave (= tile of 32 k): min i0, max i0, max knots per k
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hw = lane >> 5;
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
@@ -1634,10 +1746,10 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
         s_ih[e] = e + 1 < Nk ? 1.0 / (kk[e + 1] - kk[e]) : 0.0;
     }
     for (int e = threadIdx.x; e < nmu; e += NT) s_root[e] = ROOT[(size_t)w * nmu + e];
-    if (threadIdx.x == 0) {
-        s_red[0] = 0x7fffffff;
-        s_red[1] = 0;
-        s_red[2] = 0;
+    if (threadIdx.x < 2) {
+        s_red[threadIdx.x][0] = 0x7fffffff;
+        s_red[threadIdx.x][1] = 0;
+        s_red[threadIdx.x][2] = 0;
     }
     __syncthreads();
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
@@ -1668,19 +1780,19 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
     if (wave == 0) {
         if (live) {
             I0[(size_t)w * KT * 64 + k] = ilo;
-            atomicMin(&s_red[0], ilo);
-            atomicMax(&s_red[1], ilo);
-            atomicMax(&s_red[2], nslot + 1);
+            atomicMin(&s_red[hw][0], ilo);
+            atomicMax(&s_red[hw][1], ilo);
+            atomicMax(&s_red[hw][2], nslot + 1);
         } else {
             I0[(size_t)w * KT * 64 + k] = -1;  // resolved to the tile's lowest knot by the consumer
         }
     }
     __syncthreads();
-    const int jmin = s_red[0], D = s_red[2], span = s_red[1] - jmin + D;
-    const bool fallback = D > APW_DCAP || span > APW_WIN;
-    if (threadIdx.x == 0) META[(size_t)w * KT + kt] = make_int4(jmin, span, D, fallback ? 1 : 0);
-    if (fallback) return;
-    double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + lane;  // + ((d * NL + l) * NL + lp) * 128 (+ 64 for the s weight)
+    const int jmin = s_red[hw][0], D = s_red[hw][2], span = s_red[hw][1] - jmin + D;
+    const bool fallback = D > APW_DCAP || span > APW_WIN;  // (a tile with no k inside the grid: D = 0, never read)
+    if ((threadIdx.x & 31) == 0 && wave == 0) META[(size_t)w * 2 * KT + 2 * kt + hw] = make_int4(jmin, span, D, fallback ? 1 : 0);
+    if (fallback) return;  // (per half wave; no barrier below)
+    double* wt = W + ((size_t)w * 2 * KT + 2 * kt + hw) * APW_DCAP * NP * 2 * 32 + (lane & 31);  // + ((d * NL + l) * NL + lp) * 64 (+ 32 for the s weight)
     double cy[PPW], cs[PPW];  // contribution to the knot shared with the next interval in mu order
 #pragma unroll
     for (int q = 0; q < PPW; ++q) cy[q] = cs[q] = 0.0;
@@ -1715,9 +1827,9 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
                 const double yL = m0 - 3.0 * m2 * ih2 + 2.0 * m3 * ih3, sL = m1 - 2.0 * m2 * ih + m3 * ih2;
                 const double yR = 3.0 * m2 * ih2 - 2.0 * m3 * ih3, sR = -m2 * ih + m3 * ih2;
                 const int lp = p / NL, l = p % NL;
-                double* o = wt + (size_t)((dk * NL + l) * NL + lp) * 128;
+                double* o = wt + (size_t)((dk * NL + l) * NL + lp) * 64;
                 o[0] = cy[q] + (up ? yL : yR);
-                o[64] = cs[q] + (up ? sL : sR);
+                o[32] = cs[q] + (up ? sL : sR);
                 cy[q] = up ? yR : yL;
                 cs[q] = up ? sR : sL;
             }
@@ -1731,120 +1843,163 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
         if (p < NP) {
             const int lp = p / NL, l = p % NL;
             if (live) {
-                double* o = wt + (size_t)(((up ? nslot : 0) * NL + l) * NL + lp) * 128;
+                double* o = wt + (size_t)(((up ? nslot : 0) * NL + l) * NL + lp) * 64;
                 o[0] = cy[q];
-                o[64] = cs[q];
+                o[32] = cs[q];
             }
             for (int d = nk; d < D; ++d) {
-                double* o = wt + (size_t)((d * NL + l) * NL + lp) * 128;
+                double* o = wt + (size_t)((d * NL + l) * NL + lp) * 64;
                 o[0] = 0.0;
-                o[64] = 0.0;
+                o[32] = 0.0;
             }
         }
     }
 }
 
-// Workgroup = (tile of 64 k, cosmology) x NL waves, wave <-> output multipole l.  The template rows are walked in chunks of NRC: the
-// chunk's (y, s) window of all l' is staged in LDS (each byte of the spline data is read from HBM once, plus the window's halo), every
-// lane accumulates its NRC rows over the tile's knots, stores them, and the next chunk follows.  The knot weights of a tile belong to
-// this workgroup alone: they are re-read per chunk, from the cache.
-
-template <int NL, int NRC>
-__global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int nr, const double* __restrict__ DAw, const double* __restrict__ Hw,
+// Workgroup = (tile of 32 k, cosmology) x NL waves; wave <-> output multipole l; lane = (k in the tile, half): half 0 owns the template
+// rows [rlo, msplit), half 1 the rows [msplit, nr) (NH = the larger count, at most 12).  LDS: two planes winT / winS [l'][row][APW_WIN knots]
+// of the rows [rlo, nr) rounded up to pairs; wave l fills the series of l' = l with global_load_lds (16 B per lane: one instruction = 64 knots
+// of two consecutive rows; no registers, every load of the workgroup in flight at once).  Every lane then walks the tile's D knots once,
+// with the six weights of knot d + 1 in flight under the rows of knot d.  Rows outside [rlo, nr) are copied through.
+// bias != null: the epilogue contracts P_l(k) = sum_row bias[row] out[l][row][k] as two FMA chains -- rows [0, msplit) in half 0, rows
+// [msplit, NROW) in half 1 -- added across the half waves: the order of reduce_kernel(msplit), bit for bit.
+template <int NL, int NH, int RING>
+__global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int nr, int msplit, const double* __restrict__ DAw, const double* __restrict__ Hw,
                                                           const double* __restrict__ fid, const double* __restrict__ W,
                                                           const int* __restrict__ I0, const int4* __restrict__ META,
-                                                          const double* __restrict__ T, const double* __restrict__ YS,
-                                                          double* __restrict__ Tout) {
+                                                          const double* __restrict__ T, const double* __restrict__ S,
+                                                          double* __restrict__ Tout, const double* __restrict__ bias, double* __restrict__ Plk,
+                                                          int* __restrict__ nonfinite) {
     constexpr int NP = NL * NL;
-    __shared__ double2 win[NL * NRC * APW_WIN];  // (y, s) of series (l', row of the chunk) at knots jmin .. jmin + span
-    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
-    const int KT = (Nk + 63) / 64;
+    extern __shared__ double sm[];
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6, kl = lane & 31, half = lane >> 5;
+    const int KT = (Nk + 63) / 64, KT2 = 2 * KT;
     int kt, w;
-    xcd_decode(KT, kt, w);
-    const int k = kt * 64 + lane;
-    const int i0 = I0[(size_t)w * KT * 64 + k];
-    const int4 meta = META[(size_t)w * KT + kt];
+    xcd_decode(KT2, kt, w);
+    if (kt * 32 >= Nk) return;  // (the second half of the last 64-k tile may lie past the grid)
+    const int4 meta = META[(size_t)w * KT2 + kt];
     if (meta.w) return;  // left to ap_direct_kernel
-    const int jmin = meta.x, span = meta.y, D = meta.z;
+    const int k = kt * 32 + kl;
     const bool live = k < Nk;
-    const int o = max(i0 - jmin, 0);  // lanes past the grid (i0 = -1) carry zero weights
-    const double* wt = W + ((size_t)w * KT + kt) * APW_DCAP * NP * 2 * 64 + (size_t)l * NL * 128 + lane;
-    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
-    const double c = 2.0 / (qperp * qperp * qpar);
-    const double2* ys = reinterpret_cast<const double2*>(YS) + (size_t)w * NL * NROW * Nk;
-    const int j1 = jmin + lane, j2 = jmin + 64 + lane;
-    const bool two = 64 + lane < span;  // second load of a series only where the window reaches
-    for (int r0 = rlo; r0 < nr; r0 += NRC) {
-        const int nrow = min(NRC, nr - r0);
-        __syncthreads();  // the previous chunk has been consumed
-        // wave l stages the series of l' = l: nrow rows, up to two 1 KB wave loads each, APR_SB rows in flight together
-        constexpr int APR_SB = 3;
-        for (int rb = 0; rb < nrow; rb += APR_SB) {
-            double2 v[APR_SB][2];
-#pragma unroll
-            for (int u = 0; u < APR_SB; ++u) {
-                const double2* src = ys + ((size_t)l * NROW + r0 + min(rb + u, nrow - 1)) * Nk;
-                v[u][0] = src[min(j1, Nk - 1)];
-                v[u][1] = two ? src[min(j2, Nk - 1)] : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int u = 0; u < APR_SB; ++u)
-                if (rb + u < nrow) {
-                    double2* dst = win + (l * NRC + rb + u) * APW_WIN;
-                    dst[lane] = v[u][0];
-                    if (two) dst[64 + lane] = v[u][1];
-                }
-        }
-        __syncthreads();
-        double acc[NRC];
-#pragma unroll
-        for (int r = 0; r < NRC; ++r) acc[r] = 0.0;
-        const double2* wrow = win + o;
-        auto knot = [&](int d, const double* cy, const double* cs) {
-#pragma unroll
-            for (int r = 0; r < NRC; ++r)
-#pragma unroll
-                for (int lp = 0; lp < NL; ++lp) {
-                    const double2 v = wrow[(lp * NRC + r) * APW_WIN + d];
-                    acc[r] = fma(cy[lp], v.x, fma(cs[lp], v.y, acc[r]));
-                }
-        };
-        {  // the tile's knots, one ahead: the weights of knot d + 1 fly under the rows of knot d (re-read per chunk from the cache: they
-           // belong to this workgroup alone)
-            double cy[NL], cs[NL], ny[NL], ns[NL];
-#pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                ny[lp] = wt[lp * 128];
-                ns[lp] = wt[lp * 128 + 64];
-            }
-            for (int d = 0; d < D; ++d) {
-#pragma unroll
-                for (int lp = 0; lp < NL; ++lp) {
-                    cy[lp] = ny[lp];
-                    cs[lp] = ns[lp];
-                }
-                if (d + 1 < D) {
-                    const double* wn = wt + (size_t)(d + 1) * NP * 128;
-#pragma unroll
-                    for (int lp = 0; lp < NL; ++lp) {
-                        ny[lp] = wn[lp * 128];
-                        ns[lp] = wn[lp * 128 + 64];
-                    }
-                }
-                knot(d, cy, cs);
-            }
-        }
-        if (live) {
-            double* dst = Tout + (((size_t)w * NL + l) * NROW + r0) * Nk + k;
-#pragma unroll
-            for (int r = 0; r < NRC; ++r)
-                if (r < nrow) dst[(size_t)r * Nk] = c * acc[r];
+    const int i0 = I0[(size_t)w * KT * 64 + k];
+    const int jmin = meta.x, D = meta.z;
+    constexpr int nre = 2 * NH;  // window rows: [rlo, nr) rounded up to whole load instructions (host: nr - rlo <= nre, rlo + nre <= NROW)
+    double* winT = sm;
+    double* winS = sm + (size_t)NL * nre * APW_WIN;
+    {   // wave l stages l' = l: rows rlo .. rlo + nre - 1, knots jmin .. jmin + 63 (clamped to the row's end: knots past the span carry no weight)
+        // (a pair that starts at the last knot of a row ends one element past it -- the next row, or the two spare elements every template-
+        // shaped buffer is allocated with; clamping to Nk - 2 instead would put knot Nk - 2 where knot Nk - 1 belongs)
+        const size_t base = (((size_t)w * NL + l) * NROW + rlo + half) * Nk + min(jmin + 2 * kl, Nk - 1);
+        const double* tsrc = T + base;
+        const double* ssrc = S + base;
+        double* td = winT + (size_t)l * nre * APW_WIN;
+        double* sd = winS + (size_t)l * nre * APW_WIN;
+        for (int r = 0; r < nre; r += 2) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tsrc + (size_t)r * Nk),
+                                             (__attribute__((address_space(3))) void*)(td + r * APW_WIN), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (size_t)r * Nk),
+                                             (__attribute__((address_space(3))) void*)(sd + r * APW_WIN), 16, 0, 0);
         }
     }
-    if (live) {  // rows that APeffect leaves alone (Pstl unless APst; everything but the counter-term rows of the NNLO block)
-        const size_t base = (((size_t)w * NL + l) * NROW) * Nk + k;
-        for (int r = 0; r < rlo; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];
-        for (int r = nr; r < NROW; ++r) Tout[base + (size_t)r * Nk] = T[base + (size_t)r * Nk];
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double c = 2.0 / (qperp * qperp * qpar);
+    const int q0 = half ? msplit : rlo, q1 = half ? nr : msplit, cnt = q1 - q0;  // this half's AP rows [q0, q1)
+    const int o = max(i0 - jmin, 0);  // lanes past the grid (i0 = -1) carry zero weights
+    const double* wt = W + ((size_t)w * KT2 + kt) * APW_DCAP * NP * 2 * 32 + (size_t)l * NL * 64 + kl;
+    double acc[NH];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) acc[q] = 0.0;
+    // the weights of the first RING knots are requested together with the window: a knot's six weights come from HBM (1-2 us), its rows
+    // take ~0.15 us, so with the next knot alone in flight (RING = 2) the workgroup waits for memory once per knot (measured 53 us per launch)
+    // (branch-free: a ring slot past the tile's last knot holds zeros and re-reads the last knot's rows -- with branches around the knots the
+    // compiler speculates every LDS read of a knot above its branch and the issue-order hints below no longer see them)
+    double wy[RING][NL], ws[RING][NL];
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+        const double* wn = wt + (size_t)min(u, D - 1) * NP * 64;
+        const bool on = u < D;
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            const double a = wn[lp * 64], b = wn[lp * 64 + 32];
+            wy[u][lp] = on ? a : 0.0;
+            ws[u][lp] = on ? b : 0.0;
+        }
+    }
+    __syncthreads();  // (drains the loads above: vmcnt(0) in front of the barrier)
+    if (cnt > 0) {
+        // row q of this half sits at window row q0 - rlo + q < nre (host: both halves hold at most NH rows, half 0 exactly NH or fewer): rows
+        // past the half's count read the rows behind it (loaded, in bounds) and their sums are dropped -- every address below is one base
+        // register per plane plus an immediate
+        const double* yT = winT + (size_t)(q0 - rlo) * APW_WIN + o;
+        const double* yS = winS + (size_t)(q0 - rlo) * APW_WIN + o;
+        for (int d0 = 0; d0 < D; d0 += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                const int d = d0 + u;
+#pragma unroll
+                for (int lp = 0; lp < NL; ++lp)
+#pragma unroll
+                    for (int q = 0; q < NH; ++q)
+                        acc[q] = fma(wy[u][lp], yT[(lp * nre + q) * APW_WIN], fma(ws[u][lp], yS[(lp * nre + q) * APW_WIN], acc[q]));
+                const int step = d + 1 < D ? 1 : 0;
+                yT += step;
+                yS += step;
+                {   // this slot's next occupant: knot d + RING (zeros past the tile's last knot)
+                    const int dn = d + RING;
+                    const double* wn = wt + (size_t)min(dn, D - 1) * NP * 64;
+                    const bool on = dn < D;
+#pragma unroll
+                    for (int lp = 0; lp < NL; ++lp) {
+                        const double a = wn[lp * 64], b = wn[lp * 64 + 32];
+                        wy[u][lp] = on ? a : 0.0;
+                        ws[u][lp] = on ? b : 0.0;
+                    }
+                }
+                // issue order of this knot's NL * NH LDS reads (two rows each) and 2 NL NH FMAs: eight reads ahead, then one read per four
+                // FMAs -- left alone the scheduler puts every read of the knot in front of the first FMA: 130-230 registers
+                constexpr int AHEAD = APR_AHEAD;
+                __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+                for (int i = 0; i < NL * NH - AHEAD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * AHEAD + 16, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // results, the rows APeffect leaves alone (Pstl unless APst; everything but the counter-term rows of the NNLO block), and the contraction
+    const size_t obase = (((size_t)w * NL + l) * NROW) * Nk + k;
+    const double* bw = bias ? bias + (size_t)w * NROW : nullptr;
+    double a = 0.0;
+    if (live) {
+        const int hlo = half ? msplit : 0, hhi = half ? NROW : msplit;  // this half's share of the NROW rows in the contraction
+        for (int r = hlo; r < min(q0, hhi); ++r) {
+            const double v = T[obase + (size_t)r * Nk];
+            Tout[obase + (size_t)r * Nk] = v;
+            if (bw) a = fma(bw[r], v, a);
+        }
+#pragma unroll
+        for (int q = 0; q < NH; ++q)
+            if (q < cnt) {
+                const double v = c * acc[q];
+                Tout[obase + (size_t)(q0 + q) * Nk] = v;
+                if (bw) a = fma(bw[q0 + q], v, a);
+            }
+        for (int r = max(q1, hlo); r < hhi; ++r) {
+            const double v = T[obase + (size_t)r * Nk];
+            Tout[obase + (size_t)r * Nk] = v;
+            if (bw) a = fma(bw[r], v, a);
+        }
+    }
+    if (bias) {
+        const double other = __shfl_xor(a, 32);
+        const double tot = half ? other + a : a + other;  // rows [0, msplit) + rows [msplit, NROW)
+        if (live && half == 0) {
+            Plk[((size_t)w * NL + l) * Nk + k] = tot;
+            if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
+        }
     }
 }
 
@@ -1862,15 +2017,18 @@ __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ sr
 // ------------------------------------------------------------------------------------------------
 // reduce: P_l(k) = sum_row bias[row] * T[l][row][k]  (reference parambasis.py:128-136)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, const double* __restrict__ bias, const double* __restrict__ T,
+__global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, int msplit, const double* __restrict__ bias, const double* __restrict__ T,
                                                      double* __restrict__ Plk, int* __restrict__ nonfinite) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, w = blockIdx.z;
     if (k >= Nx) return;
     const double* b = bias + (size_t)w * NROW;
     const double* t = T + (((size_t)w * Nl + l) * NROW) * Nx + k;
-    double a = 0.0;
-#pragma unroll
-    for (int r = 0; r < NROW; ++r) a = fma(b[r], t[(size_t)r * Nx], a);
+    // two FMA chains, rows [0, msplit) and [msplit, NROW), then their sum: the order in which ap_rows_kernel's two half waves contract when
+    // REDUCE follows the AP stage directly -- a stand-alone REDUCE gives the same bits
+    double a0 = 0.0, a1 = 0.0;
+    for (int r = 0; r < msplit; ++r) a0 = fma(b[r], t[(size_t)r * Nx], a0);
+    for (int r = msplit; r < NROW; ++r) a1 = fma(b[r], t[(size_t)r * Nx], a1);
+    const double a = a0 + a1;
     Plk[((size_t)w * Nl + l) * Nx + k] = a;
     if (nonfinite && !(fabs(a) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);  // EFTB_O_CHECK_FINITE
 }

@@ -81,7 +81,7 @@ struct eftb_engine {
     // from the mu prefix sums (ap_moments_kernel: cost grows with the intervals crossed, not with a table size), 2 = the reference's quadrature
     // everywhere; default: 1 for k grids so fine that a 2 % distortion at the last k crosses more than half the knots the weight tables hold
     int ap_mode = 0;
-    int ap_chunk = 7;     // template rows per chunk of ap_rows_kernel (Nl = 3: EFTB_AP_CHUNK=7|8|12; Nl = 2: 8|12)
+    int ap_ring = 2;      // knots whose weights ap_rows_kernel keeps in flight (EFTB_AP_RING=2|4)
     bool fuse_cf = true;  // EFTB_FUSE_CF=0: always through regroup_cf_kernel (A/B switch)
     int resum_wps = 2;    // waves per SIMD resum_mfma_kernel is built for: 2 = basis coefficients in registers (201 VGPRs); EFTB_RESUM_WPS=3 = basis
                           // coefficients in LDS, tile-by-tile consumption (166 VGPRs) -- measured 4 % slower: the kernel is bound by the DP pipe, not by latency
@@ -319,6 +319,20 @@ static void launch_synth(hipStream_t st, const SynthBatch& sb) {
     if (sb.n) hipLaunchKernelGGL(synth_kernel, dim3(sb.p[sb.n - 1].wg_end), dim3(256), 0, st, sb);
 }
 
+// the same batch on gemm_direct_kernel (one wave per 16 x 32 tile, no LDS): for problems with few rows -- the first-stage products
+static int launch_gemm_direct(hipStream_t st, SynthBatch sb) {
+    int end = 0;
+    for (int i = 0; i < sb.n; ++i) {
+        SynthDesc& d = sb.p[i];
+        if (d.K % 16) return fail("eftb_run: K = %d of a first-stage product is not a multiple of 16", d.K);
+        d.wgx = (d.X + 31) / 32;
+        end += d.wgx * ((d.M + 15) / 16);
+        d.wg_end = end;
+    }
+    if (sb.n) hipLaunchKernelGGL(gemm_direct_kernel, dim3(end), dim3(64), 0, st, sb);
+    return 0;
+}
+
 // anti-diagonal sums of every loop matrix for the batch (shared by the k-space and the xi-space pieces), then the
 // synthesis rows selected by `sets` (build_rows_kernel)
 static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets, const double* coef, const double* coefT) {
@@ -433,7 +447,7 @@ static void launch_irfilter(eftb_engine* e, hipStream_t st, int B, bool xy = tru
         launch_prep_rows(e, st, B, false, true);
         SynthBatch sb{};
         queue_xy(e, sb, B);
-        launch_synth(st, sb);
+        (void)launch_gemm_direct(st, sb);
     }
     hipLaunchKernelGGL(qf_kernel, dim3(B), dim3(256), 0, st, c.Nl * c.Nl * e->Nn, e->buf[EFTB_B_F], tb<double>(e, EFTB_T_QPOLY), e->buf[EFTB_B_Q]);
 }
@@ -571,6 +585,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     // buffer on the way (EFTB_B_CLOOPL then keeps what the last stand-alone REGROUP stage left there)
     const bool fuse_cf = (mask & EFTB_S_REGROUP) && (mask & EFTB_S_RESUM) && c.with_resum && (Nl == 3 || !e->generic_resum) && !c.optiresum && !c.with_nnlo &&
                          !nnlo_pass && e->fuse_cf;
+    // P_l = sum_row b_row T[l][row]: two FMA chains split at msplit_cfg (the row split of ap_rows_kernel's half waves), everywhere
+    const int msplit_cfg = c.with_ap ? ((c.ap_stochastic ? NROW : 21) + 1) / 2 : NROW / 2;
+    const bool fuse_reduce = (mask & EFTB_S_AP) && (mask & EFTB_S_REDUCE) && !(mask & (EFTB_S_PROJECT | EFTB_S_LOGP)) && c.with_ap && e->ap_mode == 0 &&
+                             !c.with_nnlo && !nnlo_pass;
     if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
@@ -619,7 +637,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 queue_synth(sb, tb<double>(e, EFTB_T_GCT2T), KP2, 2 * NCH, 1, KP2, e->PA2T, c.max_batch, e->coefT2, c.max_batch, nullptr, nullptr);
             }
             if (xy_in_prep) queue_xy(e, sb, B);
-            launch_synth(st, sb);
+            if (int rc = launch_gemm_direct(st, sb)) return rc;
         }
         if (!pre_side) st = st0;
     }
@@ -824,15 +842,29 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 std::swap(*pin, *palt);
                 return 0;
             }
+            // REDUCE directly behind the AP stage: the bias contraction rides in the epilogue of ap_rows_kernel (and of the fallback tiles'
+            // ap_direct_kernel), in the summation order of reduce_kernel(msplit) -- no separate pass over the 33 MB of AP output
+            const bool red = fuse_reduce && !nn;
+            const int msplit = red ? msplit_cfg : (rlo + nr + 1) / 2;  // rows [rlo, msplit) / [msplit, nr) to the two half waves
+            const double* rb = red ? b[EFTB_B_BIAS] : nullptr;
+            double* rp = red ? b[EFTB_B_PLK] : nullptr;
+            int* rflag = red && e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr;
             if (e->ap_fast) {
                 // banded product of the knot weights with the spline data; rows outside [rlo, nr) are copied through
-                const int kt = (Nk + 63) / 64;
-#define APR_ARGS Nk, rlo, nr, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt
-                if (Nl == 3 && e->ap_chunk == 8) hipLaunchKernelGGL((ap_rows_kernel<3, 8>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
-                else if (Nl == 3 && e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<3, 12>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
-                else if (Nl == 3) hipLaunchKernelGGL((ap_rows_kernel<3, 7>), dim3(kt * B), dim3(192), 0, st, APR_ARGS);
-                else if (e->ap_chunk == 12) hipLaunchKernelGGL((ap_rows_kernel<2, 12>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
-                else hipLaunchKernelGGL((ap_rows_kernel<2, 8>), dim3(kt * B), dim3(128), 0, st, APR_ARGS);
+                const int kt2 = 2 * ((Nk + 63) / 64), nh = (nr - rlo + 1) / 2, nre = 2 * nh;
+                const size_t lds = (size_t)2 * Nl * nre * APW_WIN * sizeof(double);
+                if (rlo + nre > NROW || msplit - rlo > nh || nr - msplit > nh || (nh != 2 && nh != 11 && nh != 12))
+                    return fail("eftb_run: AP rows [%d, %d) split at %d do not fit the window layouts built into ap_rows_kernel", rlo, nr, msplit);
+#define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt, rb, rp, rflag
+#define APR_LAUNCH(NLV, NHV) do { if (e->ap_ring == 2) hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 2>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); \
+                                  else hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 4>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); } while (0)
+                if (Nl == 3 && nh == 11) APR_LAUNCH(3, 11);
+                else if (Nl == 3 && nh == 12) APR_LAUNCH(3, 12);
+                else if (Nl == 3) APR_LAUNCH(3, 2);
+                else if (nh == 11) APR_LAUNCH(2, 11);
+                else if (nh == 12) APR_LAUNCH(2, 12);
+                else APR_LAUNCH(2, 2);
+#undef APR_LAUNCH
 #undef APR_ARGS
             }
             // the reference's own quadrature: every tile (EFTB_AP_FAST=0), or only the tiles the fast path flagged (strong distortions)
@@ -840,7 +872,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int4* gate = e->ap_fast ? e->APM : nullptr;
                 const dim3 dgrid(((Nk + 63) / 64) * B);
 #define APD_ARGS Nk, c.nmu, rlo, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
-                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate
+                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate, rb, rp, msplit, rflag
                 if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3>), dgrid, dim3(64), 0, st, APD_ARGS);
                 else hipLaunchKernelGGL((ap_direct_kernel<2>), dgrid, dim3(64), 0, st, APD_ARGS);
 #undef APD_ARGS
@@ -884,8 +916,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         hipLaunchKernelGGL(marg_solve_kernel, dim3(nw), dim3(256), 0, st, nd, e->like_nG, e->jeffreys, e->like_mu, e->like_sinv, e->like_V, e->like_U,
                            b[EFTB_B_LOGP]);
     }
-    if (mask & EFTB_S_REDUCE)
-        hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIAS],
+    if ((mask & EFTB_S_REDUCE) && !fuse_reduce)
+        hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, msplit_cfg, b[EFTB_B_BIAS],
                            b[EFTB_B_TEMPL], b[EFTB_B_PLK], e->check_finite && !c.with_nnlo ? e->status + 2 * e->status_slot + 1 : nullptr);
     if ((mask & EFTB_S_REDUCE) && c.with_nnlo)
         hipLaunchKernelGGL(reduce_nnlo_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIASN],
@@ -1079,8 +1111,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         const size_t n = need_buffer_elems(c, id);
         e->buf_elems[id] = n;
         if (n) {
-            HIPCHK(hipMalloc(&e->buf[id], n * sizeof(double)));
-            HIPCHK(hipMemset(e->buf[id], 0, n * sizeof(double)));
+            HIPCHK(hipMalloc(&e->buf[id], (n + 2) * sizeof(double)));  // (+2: ap_rows_kernel's 16-byte window loads may end one element past a row)
+            HIPCHK(hipMemset(e->buf[id], 0, (n + 2) * sizeof(double)));
         }
     }
     const size_t B = c.max_batch;
@@ -1102,9 +1134,10 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         if (c.with_resum) bad |= zalloc(&e->ACF, B * BASC * KSYN) | zalloc(&e->ALC, B * (c.with_nnlo ? 3 : 2) * c.Nl * KLIN) | zalloc(&e->YCF, B * BASC * NS);
         if (bad) return fail("eftb_create: out of device memory for the loop scratch");
     }
-    HIPCHK(hipMalloc(&e->Talt, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));
+    HIPCHK(hipMalloc(&e->Talt, (e->buf_elems[EFTB_B_TEMPL] + 2) * sizeof(double)));
     if (c.with_ap) {
-        HIPCHK(hipMalloc(&e->SD, 2 * e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // (y, s) pairs of the splines
+        HIPCHK(hipMalloc(&e->SD, (e->buf_elems[EFTB_B_TEMPL] + 2) * sizeof(double)));  // knot slopes of the splines, laid out like the template block
+        HIPCHK(hipMemset(e->SD, 0, (e->buf_elems[EFTB_B_TEMPL] + 2) * sizeof(double)));
         HIPCHK(hipMalloc(&e->APP, (size_t)c.max_batch * (c.nmu + 1) * c.Nl * c.Nl * 4 * sizeof(double)));
         HIPCHK(hipMalloc(&e->APR, (size_t)c.max_batch * c.nmu * sizeof(double)));
         HIPCHK(hipMalloc(&e->APP2, (size_t)c.max_batch * (c.nmu + 1) * c.Nl * c.Nl * 4 * sizeof(double)));
@@ -1113,11 +1146,11 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         for (int q = 0; q < 2; ++q) {
             HIPCHK(hipMalloc(q ? &e->APW2 : &e->APW, (size_t)c.max_batch * kt * APW_DCAP * c.Nl * c.Nl * 2 * 64 * sizeof(double)));
             HIPCHK(hipMalloc(q ? &e->API2 : &e->API, (size_t)c.max_batch * kt * 64 * sizeof(int)));
-            HIPCHK(hipMalloc(q ? &e->APM2 : &e->APM, (size_t)c.max_batch * kt * sizeof(int4)));
+            HIPCHK(hipMalloc(q ? &e->APM2 : &e->APM, (size_t)c.max_batch * 2 * kt * sizeof(int4)));  // one window record per tile of 32 k
         }
     }
     if (const char* f = getenv("EFTB_AP_FAST")) e->ap_fast = atoi(f) != 0;
-    if (const char* f = getenv("EFTB_AP_CHUNK")) e->ap_chunk = atoi(f);
+    if (const char* f = getenv("EFTB_AP_RING")) e->ap_ring = atoi(f);
     if (const char* f = getenv("EFTB_RESUM_WPS")) e->resum_wps = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 2 * (eftb_engine::NSETS + 1) * sizeof(int), hipHostMallocMapped));
@@ -1192,15 +1225,22 @@ int eftb_finalize(eftb_engine* e) {
             if (const char* f = getenv("EFTB_AP_MODE")) e->ap_mode = atoi(f);
             if (!e->ap_fast) e->ap_mode = 2;
             e->ap_fast = e->ap_mode == 0;
+            // ap_rows_kernel keeps the (y, s) window of every template row of a 32-k tile in LDS: 66-72 KB per workgroup (two per CU), above
+            // the 64 KB a kernel gets without asking
+            const int lds_max = 2 * 3 * NROW * APW_WIN * (int)sizeof(double);
+#define APR_LDS(NLV, NHV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_rows_kernel<NLV, NHV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); \
+                          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_rows_kernel<NLV, NHV, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
+            APR_LDS(3, 11); APR_LDS(3, 12); APR_LDS(3, 2); APR_LDS(2, 11); APR_LDS(2, 12); APR_LDS(2, 2);
+#undef APR_LDS
 #define APM_LDS(NLV, NRV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_moments_kernel<NLV, NRV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
             APM_LDS(3, 21); APM_LDS(3, NROW); APM_LDS(2, 21); APM_LDS(2, NROW);
 #undef APM_LDS
         }
     }
-    if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, e->buf_elems[EFTB_B_TEMPL] * sizeof(double)));  // third template block (engine.back)
+    if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, (e->buf_elems[EFTB_B_TEMPL] + 2) * sizeof(double)));  // third template block (engine.back)
     if (e->ap_overlap && e->c.with_nnlo && e->c.with_ap && !e->T3N) {
-        HIPCHK(hipMalloc(&e->T3N, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
-        HIPCHK(hipMalloc(&e->TaltN, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
+        HIPCHK(hipMalloc(&e->T3N, (e->buf_elems[EFTB_B_TEMPLN] + 2) * sizeof(double)));
+        HIPCHK(hipMalloc(&e->TaltN, (e->buf_elems[EFTB_B_TEMPLN] + 2) * sizeof(double)));
         HIPCHK(hipMemset(e->T3N, 0, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
         HIPCHK(hipMemset(e->TaltN, 0, e->buf_elems[EFTB_B_TEMPLN] * sizeof(double)));
     }
