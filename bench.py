@@ -256,7 +256,7 @@ def main():
         if world == 1 and not force_comm:
             # (0) what a DEPENDENT sampler sees (reference likelihood.py:570-594 inside Model.logpost: step i + 1 needs step i's P_l): stage ->
             # run -> fetch the step just launched, nothing queued behind it.  New inputs every step, P_l back every step.
-            out1 = np.empty((B, NL, NK))
+            chi = 0.0
             for phase, cnt in (("warm", 3), ("timed", K)):
                 if phase == "timed":
                     eng.sync()
@@ -265,9 +265,12 @@ def main():
                     d = sets[(W + i) % len(sets)]
                     eng.stage_inputs(d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"])
                     eng.run_staged(mask, B)
-                    eng.fetch_previous("PLK", (B, NL, NK), out=out1, back=0)
+                    out1 = eng.fetch_previous("PLK", (B, NL, NK), back=0, copy=False)   # P_l in page-locked host memory, consumed in place
+                    chi += float(out1[0, 0, 7])                                           # (the sampler's use of it: here one element)
             dt1 = time.perf_counter() - t1
             extras["sync_step_evaluations_per_s"], extras["sync_step_ms"] = B * K / dt1, dt1 / K * 1e3
+            extras["sync_step_note"] = ("stage -> run -> P_l of the step just launched, nothing queued behind it (the engine finds the GPU idle when the step is staged and "
+                                        "runs it in latency mode: one queue, P_lin read from the staging block, P_l written to mapped host memory by the AP epilogue)")
             assert np.array_equal(out1, results[K - 1]), "dependent-sampler loop differs from the pipelined loop on the same draws"
         if not args.no_extras:
             # (1) the same kernels over inputs resident in HBM (what round 1 reported as `value`): K asynchronous runs of one batch

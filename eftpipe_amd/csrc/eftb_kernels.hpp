@@ -121,16 +121,57 @@ __global__ __launch_bounds__(64) void antidiag_kernel(int B, int Bmax, const dou
     double ar[NC], ai[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) ar[q] = ai[q] = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        const int n = jp + t, qn = n <= NHALF ? n : 2 * NHALF - n;  // c_{256-n} = conj(c_n); c_m = conj(c_t) for m = 256 - t
-        const double xr = cr[(size_t)qn * Bmax], xi = n <= NHALF ? ci[(size_t)qn * Bmax] : -ci[(size_t)qn * Bmax];
-        const double yr = cr[(size_t)t * Bmax], yi = -ci[(size_t)t * Bmax];
-        const double pr = xr * yr - xi * yi, pi = xr * yi + xi * yr;
-        const double2* m = AD + ((size_t)jp * AD_T + t) * NC;  // wave-uniform
+    // operands of pair t: the product c_n c_m (per lane = per cosmology) and the NC wave-uniform weights.  Software pipelined: the loads of pair
+    // t + 1 are issued before the 4 NC FMAs of pair t and waited for after them -- in the plain loop every one of the up to 44 trips sat through
+    // a full memory round trip (0.65 us per trip alone, 28 us per launch; the round-3 trace shows 63-83 us beside the resummation)
+    // (loads only -- the conjugations c_{256-n} = conj(c_n), c_m = conj(c_t) for m = 256 - t are applied where the values are consumed, so that
+    // nothing in the load phase waits for a load)
+    auto coef = [&](int t, double& xr, double& xi, double& yr, double& yi) {
+        const int n = jp + t, qn = n <= NHALF ? n : 2 * NHALF - n;
+        xr = cr[(size_t)qn * Bmax];
+        xi = ci[(size_t)qn * Bmax];
+        yr = cr[(size_t)t * Bmax];
+        yi = ci[(size_t)t * Bmax];
+    };
+    auto weights = [&](int t, double2* m) {
+        const double2* mp = AD + ((size_t)jp * AD_T + t) * NC;  // wave-uniform: scalar loads
+#pragma unroll
+        for (int q = 0; q < NC; ++q) m[q] = mp[q];
+    };
+    auto accumulate = [&](int t, double xr, double xi0, double yr, double yi0, const double2* m, double on) {
+        const double xi = jp + t <= NHALF ? xi0 : -xi0, yi = -yi0;
+        const double pr = (xr * yr - xi * yi) * on, pi = (xr * yi + xi * yr) * on;
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
             ar[q] = fma(m[q].x, pr, fma(-m[q].y, pi, ar[q]));
             ai[q] = fma(m[q].x, pi, fma(m[q].y, pr, ai[q]));
+        }
+    };
+    if (t0 < t1) {
+        // two register sets A / B, one pair each: while one set is being consumed the other is in flight (an odd tail re-reads the last pair
+        // with weight zero); the scheduling barriers keep each set's loads in front of the other set's arithmetic.  Scalar loads return out of
+        // order, so the only wait for them is "all of them": the set about to be consumed is touched (an empty asm) BEFORE the other set's
+        // loads go out -- its own loads are half a trip old by then
+        double axr, axi, ayr, ayi, bxr, bxi, byr, byi;
+        double2 ma[NC], mb[NC];
+        coef(t0, axr, axi, ayr, ayi);
+        weights(t0, ma);
+        for (int t = t0; t < t1; t += 2) {
+            const int tb = min(t + 1, t1 - 1), ta = min(t + 2, t1 - 1);
+            asm volatile("" ::"s"(ma[NC - 1].y), "s"(ma[0].x));
+            __builtin_amdgcn_sched_barrier(0);
+            coef(tb, bxr, bxi, byr, byi);
+            weights(tb, mb);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(t, axr, axi, ayr, ayi, ma, 1.0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"s"(mb[NC - 1].y), "s"(mb[0].x));
+            __builtin_amdgcn_sched_barrier(0);
+            coef(ta, axr, axi, ayr, ayi);
+            weights(ta, ma);
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(tb, bxr, bxi, byr, byi, mb, t + 1 < t1 ? 1.0 : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (w < B)
@@ -1483,7 +1524,7 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
                                                        const double* __restrict__ legmu, const double* __restrict__ ROOT,
                                                        const double* __restrict__ T, const double* __restrict__ S, double* __restrict__ Tout,
                                                        const int4* __restrict__ META, const double* __restrict__ bias, double* __restrict__ Plk,
-                                                       int msplit, int* __restrict__ nonfinite) {
+                                                       double* __restrict__ PlkHost, int msplit, int* __restrict__ nonfinite) {
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
@@ -1551,6 +1592,7 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
         for (int l = 0; l < NL; ++l) {
             const double a = ch0[l] + ch1[l];
             Plk[((size_t)w * NL + l) * Nk + k] = a;
+            if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = a;
             if (nonfinite && !(fabs(a) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
         }
     }
@@ -1869,7 +1911,7 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
                                                           const int* __restrict__ I0, const int4* __restrict__ META,
                                                           const double* __restrict__ T, const double* __restrict__ S,
                                                           double* __restrict__ Tout, const double* __restrict__ bias, double* __restrict__ Plk,
-                                                          int* __restrict__ nonfinite) {
+                                                          double* __restrict__ PlkHost, int* __restrict__ nonfinite) {
     constexpr int NP = NL * NL;
     extern __shared__ double sm[];
     const int lane = threadIdx.x & 63, l = threadIdx.x >> 6, kl = lane & 31, half = lane >> 5;
@@ -1998,6 +2040,7 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
         const double tot = half ? other + a : a + other;  // rows [0, msplit) + rows [msplit, NROW)
         if (live && half == 0) {
             Plk[((size_t)w * NL + l) * Nk + k] = tot;
+            if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = tot;  // latency mode: P_l lands in mapped host memory as it is formed
             if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
         }
     }
@@ -2005,9 +2048,14 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
 
 // Staged inputs: page-locked host block -> device block, as a kernel on the copy stream (a DMA transfer brings cache maintenance on the
 // compute queue with it; this one is ordinary loads from mapped host memory and ordinary stores)
-__global__ __launch_bounds__(256) void stage_copy_kernel(const double2* __restrict__ src, double2* __restrict__ dst, size_t n2) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+__global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+
+// nothing: the first dispatch after the GPU has sat idle for a few tens of microseconds takes 40-50 us to start executing (traced: a 27 KB copy
+// kernel 44 us, the 205 KB one behind it 6 us) -- eftb_stage_inputs sends this ahead of its host-side work so that the step's first real kernel
+// finds the queue awake
+__global__ void wake_kernel() {}
 
 // device-to-device snapshot as a kernel, for the same reason (P_l of a step, taken before the RCCL exchange on the communication stream)
 __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
@@ -2018,7 +2066,7 @@ __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ sr
 // reduce: P_l(k) = sum_row bias[row] * T[l][row][k]  (reference parambasis.py:128-136)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, int msplit, const double* __restrict__ bias, const double* __restrict__ T,
-                                                     double* __restrict__ Plk, int* __restrict__ nonfinite) {
+                                                     double* __restrict__ Plk, double* __restrict__ PlkHost, int* __restrict__ nonfinite) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, w = blockIdx.z;
     if (k >= Nx) return;
     const double* b = bias + (size_t)w * NROW;
@@ -2030,6 +2078,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(int Nx, int Nl, int msplit,
     for (int r = msplit; r < NROW; ++r) a1 = fma(b[r], t[(size_t)r * Nx], a1);
     const double a = a0 + a1;
     Plk[((size_t)w * Nl + l) * Nx + k] = a;
+    if (PlkHost) PlkHost[((size_t)w * Nl + l) * Nx + k] = a;
     if (nonfinite && !(fabs(a) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);  // EFTB_O_CHECK_FINITE
 }
 

@@ -153,6 +153,17 @@ struct eftb_engine {
     size_t stage_elems = 0;
     hipStream_t cpy = nullptr;
     hipEvent_t evStaged[NSETS] = {}, evSetDone[NSETS] = {};
+    // Latency mode (a sampler whose next step depends on this step's P_l: nothing is queued behind the step being staged).  eftb_stage_inputs
+    // finds the GPU idle -> this set's step runs on ONE queue (every cross-queue hand-over costs 15-18 us of dispatch latency, and there is no
+    // neighbouring step to overlap with), the first kernel reads P_lin straight from the page-locked staging block (the 0.2 MB device copy
+    // follows off the critical path; only the few KB of f / DA / H / bias are waited for, copied on the compute queue itself), and P_l is
+    // written to mapped host memory by the kernel that forms it (no DMA phase).  (Measured and dropped: the AP tables beside the resummation
+    // instead of beside the loop chain -- the chain gained 20 us, the resummation lost 39.)
+    bool latency_auto = true;           // EFTB_LATENCY_MODE=0 disables
+    bool set_latency[NSETS] = {};
+    hipEvent_t evStagedAll[NSETS] = {};  // the whole staging block of a set has been uploaded (evStaged: the part its first kernels wait for)
+    bool lat_run = false;                // the run being launched is a latency-mode step
+    double* plk_host_out = nullptr;      // latency mode: where P_l goes besides the device buffer
     int cur_set = 0, staged_B = 0;
     // staged sets keep P_l in device memory: with a communicator RCCL sends from it; without one the step's last stream copies it to page-locked
     // host memory with the DMA engine (plk_host) -- measured 0.447 ms per step against 0.455 ms with REDUCE writing mapped host memory over PCIe
@@ -848,6 +859,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             const int msplit = red ? msplit_cfg : (rlo + nr + 1) / 2;  // rows [rlo, msplit) / [msplit, nr) to the two half waves
             const double* rb = red ? b[EFTB_B_BIAS] : nullptr;
             double* rp = red ? b[EFTB_B_PLK] : nullptr;
+            double* rph = red ? e->plk_host_out : nullptr;
             int* rflag = red && e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr;
             if (e->ap_fast) {
                 // banded product of the knot weights with the spline data; rows outside [rlo, nr) are copied through
@@ -855,7 +867,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const size_t lds = (size_t)2 * Nl * nre * APW_WIN * sizeof(double);
                 if (rlo + nre > NROW || msplit - rlo > nh || nr - msplit > nh || (nh != 2 && nh != 11 && nh != 12))
                     return fail("eftb_run: AP rows [%d, %d) split at %d do not fit the window layouts built into ap_rows_kernel", rlo, nr, msplit);
-#define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt, rb, rp, rflag
+#define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt, rb, rp, rph, rflag
 #define APR_LAUNCH(NLV, NHV) do { if (e->ap_ring == 2) hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 2>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); \
                                   else hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 4>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); } while (0)
                 if (Nl == 3 && nh == 11) APR_LAUNCH(3, 11);
@@ -872,7 +884,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int4* gate = e->ap_fast ? e->APM : nullptr;
                 const dim3 dgrid(((Nk + 63) / 64) * B);
 #define APD_ARGS Nk, c.nmu, rlo, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
-                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate, rb, rp, msplit, rflag
+                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate, rb, rp, rph, msplit, rflag
                 if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3>), dgrid, dim3(64), 0, st, APD_ARGS);
                 else hipLaunchKernelGGL((ap_direct_kernel<2>), dgrid, dim3(64), 0, st, APD_ARGS);
 #undef APD_ARGS
@@ -918,7 +930,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     }
     if ((mask & EFTB_S_REDUCE) && !fuse_reduce)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, msplit_cfg, b[EFTB_B_BIAS],
-                           b[EFTB_B_TEMPL], b[EFTB_B_PLK], e->check_finite && !c.with_nnlo ? e->status + 2 * e->status_slot + 1 : nullptr);
+                           b[EFTB_B_TEMPL], b[EFTB_B_PLK], c.with_nnlo ? nullptr : e->plk_host_out, e->check_finite && !c.with_nnlo ? e->status + 2 * e->status_slot + 1 : nullptr);
     if ((mask & EFTB_S_REDUCE) && c.with_nnlo)
         hipLaunchKernelGGL(reduce_nnlo_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, b[EFTB_B_BIASN],
                            b[EFTB_B_TEMPLN], b[EFTB_B_PLK], e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr);
@@ -1458,6 +1470,7 @@ void eftb_destroy(eftb_engine* e) {
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->evStaged[q]) (void)hipEventDestroy(e->evStaged[q]);
+        if (e->evStagedAll[q]) (void)hipEventDestroy(e->evStagedAll[q]);
         if (e->evSetDone[q]) (void)hipEventDestroy(e->evSetDone[q]);
         if (e->stage_host[q]) (void)hipHostFree(e->stage_host[q]);
         if (e->setblock[q]) (void)hipFree(e->setblock[q]);
@@ -1663,7 +1676,7 @@ static int staged_setup(eftb_engine* e) {
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double)));
                 HIPCHK(hipMemset(e->setbuf[q][id], 0, e->buf_elems[id] * sizeof(double)));
                 if (!e->comm) {
-                    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->plk_host[q]), e->buf_elems[id] * sizeof(double), hipHostMallocDefault));
+                    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->plk_host[q]), e->buf_elems[id] * sizeof(double), hipHostMallocMapped));  // (mapped: latency-mode steps write it from the kernel)
                     memset(e->plk_host[q], 0, e->buf_elems[id] * sizeof(double));
                 }
                 continue;
@@ -1674,10 +1687,13 @@ static int staged_setup(eftb_engine* e) {
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->stage_host[q]), e->stage_elems * sizeof(double), hipHostMallocMapped));
         memset(e->stage_host[q], 0, e->stage_elems * sizeof(double));
         HIPCHK(hipEventCreateWithFlags(&e->evStaged[q], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->evStagedAll[q], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&e->evSetDone[q], hipEventDisableTiming));
         HIPCHK(hipEventRecord(e->evStaged[q], e->cpy));
+        HIPCHK(hipEventRecord(e->evStagedAll[q], e->cpy));
         HIPCHK(hipEventRecord(e->evSetDone[q], e->cpy));
     }
+    if (const char* f = getenv("EFTB_LATENCY_MODE")) e->latency_auto = atoi(f) != 0;
     e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first eftb_run_staged; sets 0, 1, 2, 3 follow in turn
     HIPCHK(hipDeviceSynchronize());  // the zero fills ran on the null stream; the copy stream is about to write into these blocks
     return 0;
@@ -1695,7 +1711,11 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     if (int rc = staged_setup(e)) return rc;
     HIPCHK(hipSetDevice(c.device));
     const int t = (e->cur_set + 1) % eftb_engine::NSETS;  // the set after the current one: the oldest, fetched (or abandoned) by now
-    HIPCHK(hipEventSynchronize(e->evStaged[t]));  // its staging block is free again (the previous upload from it has finished)
+    HIPCHK(hipEventSynchronize(e->evStagedAll[t]));  // its staging block is free again (the previous upload from it has finished)
+    // nothing in flight (the step launched last has finished, or none was launched): the step staged here has the GPU to itself -- see latency_auto
+    const bool lat = e->latency_auto && e->staged_B == 0 && e->stage_off[EFTB_B_PIN] == 0 && hipEventQuery(e->evSetDone[e->cur_set]) == hipSuccess;
+    e->set_latency[t] = lat;
+    if (lat) hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, e->stream);  // (see wake_kernel: its start-up runs under the host copies below)
     double* h = e->stage_host[t];
     memcpy(h + e->stage_off[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double));
     memcpy(h + e->stage_off[EFTB_B_F], f, (size_t)B * sizeof(double));
@@ -1712,9 +1732,27 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     hipStream_t cs = e->cpy;
     HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[t], 0));  // the last run on this set (and the fetch of its results) is over
     // (a copy kernel reading the mapped staging block, not a DMA transfer: 0.4 MB is latency, and the DMA form measured the same or worse)
-    hipLaunchKernelGGL(stage_copy_kernel, dim3(64), dim3(256), 0, cs, reinterpret_cast<const double2*>(h), reinterpret_cast<double2*>(e->setblock[t]),
-                       (e->stage_elems + 1) / 2);
-    HIPCHK(hipEventRecord(e->evStaged[t], cs));
+    // only what was staged travels: P_lin, f, DA, H, the bias rows -- and the likelihood rows (0.6 MB at 128 walkers) when there are any.  Reads
+    // of host memory from a kernel run at ~16 GB/s: the whole 0.85 MB block took 48-53 us, on the critical path of a dependent sampler
+    const size_t n_pin = e->stage_off[EFTB_B_F], n_small = e->stage_off[EFTB_B_GROWS] - n_pin, n_rows = rows ? (size_t)B * MARG_NG1 * NROW : 0;
+    auto copy = [&](size_t off, size_t n, int wgs, hipStream_t q) {
+        if (n) hipLaunchKernelGGL(stage_copy_kernel, dim3(wgs), dim3(256), 0, q, h + off, e->setblock[t] + off, n);
+    };
+    if (lat) {
+        // the small arrays go first and on the compute queue itself (in line in front of the step's kernels: no cross-queue hand-over; the
+        // GPU is idle, nothing of an earlier step can still be reading the set): they are all the step's first kernels wait for -- its first
+        // kernel reads P_lin from the staging block itself, whose device copy follows on the copy queue
+        copy(n_pin, n_small, 8, e->stream);
+        copy(e->stage_off[EFTB_B_GROWS], n_rows, 64, e->stream);
+        HIPCHK(hipEventRecord(e->evStaged[t], e->stream));
+        copy(0, n_pin, 48, cs);
+        HIPCHK(hipEventRecord(e->evStagedAll[t], cs));
+    } else {
+        copy(0, n_pin + n_small, 64, cs);
+        copy(e->stage_off[EFTB_B_GROWS], n_rows, 64, cs);
+        HIPCHK(hipEventRecord(e->evStaged[t], cs));
+        HIPCHK(hipEventRecord(e->evStagedAll[t], cs));
+    }
     e->staged_B = B;
     return 0;
 }
@@ -1734,14 +1772,26 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     HIPCHK(hipStreamWaitEvent(e->stream, e->evStaged[e->cur_set], 0));  // the side stream forks from here, so it inherits the wait
     HIPCHK(hipStreamWaitEvent(e->pre, e->evStaged[e->cur_set], 0));
     HIPCHK(hipStreamWaitEvent(e->side, e->evStaged[e->cur_set], 0));
-    e->inputs_settled = e->allow_back = true;
+    const bool lat = e->set_latency[e->cur_set];
+    // latency mode: one queue for the whole step; P_lin is read from the page-locked staging block (its device copy arrives behind evStagedAll);
+    // P_l goes to mapped host memory from the kernel that forms it (REDUCE, or the AP epilogue) unless the NNLO pass adds to it afterwards
+    const bool plk_direct = lat && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !e->c.with_nnlo;
+    double* pin_dev = e->buf[EFTB_B_PIN];
+    if (lat) e->buf[EFTB_B_PIN] = e->stage_host[e->cur_set] + e->stage_off[EFTB_B_PIN];
+    e->lat_run = lat;
+    e->plk_host_out = plk_direct ? e->plk_host[e->cur_set] : nullptr;
+    e->inputs_settled = e->allow_back = !lat;
     const int rc = run_stages(e, mask, B);
     e->inputs_settled = e->allow_back = false;
+    e->lat_run = false;
+    e->plk_host_out = nullptr;
+    e->buf[EFTB_B_PIN] = pin_dev;
     e->status_slot = eftb_engine::NSETS;
     if (rc) return rc;
     ++e->staged_launched;
     hipStream_t last = e->back_pending ? e->back : e->stream;  // the step ends where its back half ran
-    if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE))
+    if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAll[e->cur_set], 0));  // (the set is not "done" before its own upload is)
+    if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipMemcpyAsync(e->plk_host[e->cur_set], e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
     HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], last));
     if (e->back_pending && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE))
@@ -1770,6 +1820,23 @@ int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count
 }
 
 int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) { return eftb_fetch_back(e, 1, id, host, count); }
+
+int eftb_fetch_view(eftb_engine* e, int back, int id, const double** block, size_t* count) {
+    if (!e || !block) return fail("eftb_fetch_view: null argument");
+    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_view: back must be 0 (the step launched last), 1, 2 or 3 (that many steps before it)");
+    if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_view: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
+    if (!e->cpy) return fail("eftb_fetch_view: no staged run yet");
+    if ((unsigned long long)back >= e->staged_launched)
+        return fail("eftb_fetch_view: back = %d, but only %llu staged step(s) have been launched", back, e->staged_launched);
+    HIPCHK(hipSetDevice(e->c.device));
+    const int t = (e->cur_set + eftb_engine::NSETS - back) % eftb_engine::NSETS;
+    const double* p = id == EFTB_B_PLK ? (e->plk_host[t] ? e->plk_host[t] : (e->staged_plk_device ? nullptr : e->setbuf[t][id])) : e->setbuf[t][id];
+    if (!p) return fail("eftb_fetch_view: P_l of this engine stays in device memory for the RCCL exchange (eftb_gathered_view hands out the gathered block)");
+    if (int rc = spin_event(e->evSetDone[t], "eftb_fetch_view", "the step")) return rc;
+    *block = p;
+    if (count) *count = e->buf_elems[id];
+    return check_status(e, "eftb_fetch_view", t);
+}
 
 int eftb_comm_unique_id(char id[128]) {
     if (!id) return fail("eftb_comm_unique_id: null argument");

@@ -240,6 +240,10 @@ int  eftb_fetch_previous(eftb_engine* e, int buffer_id, double* host, size_t cou
  * of consecutive steps never runs dry (with back = 2 the look-ahead stream idled ~0.1 ms per step waiting for the host); the set read with
  * back = 3 is the one the next eftb_stage_inputs refills. */
 int  eftb_fetch_back(eftb_engine* e, int back, int buffer_id, double* host, size_t count);
+/* The same results without the host copy: *block points at the engine's page-locked host copy of the step's EFTB_B_PLK / EFTB_B_LOGP block
+ * (*count = its capacity in elements), valid until NSETS - 1 = 3 more steps have been staged.  For samplers that consume P_l in place (the
+ * dependent loop of reference likelihood.py:570-594: chi^2 from P_l, then the next proposal). */
+int  eftb_fetch_view(eftb_engine* e, int back, int buffer_id, const double** block, size_t* count);
 
 /* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
  * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */

@@ -568,6 +568,16 @@ def test_pipelined_steps_with_changing_inputs(golden):
         for s in range(nsteps):
             assert np.array_equal(got2[s], want[s]), (depth, s)
     assert np.array_equal(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=0), want[nsteps - 1])  # back = 0: the step launched last
+    view = eng.fetch_previous("PLK", (B, 3, g["k"].size), back=1, copy=False)                      # the engine's own page-locked copy, no memcpy
+    assert not view.flags.writeable and np.array_equal(view, want[nsteps - 2])
+    # the dependent-sampler loop: every step is staged with the GPU idle and runs in latency mode (one queue, P_lin read from the staging block,
+    # P_l written to mapped host memory by the kernel that forms it) -- same bits as the pipelined steps and the synchronous call
+    for s in range(nsteps):
+        st = steps[s]
+        eng.stage_inputs(st["Pin"], st["f"], st["DA"], st["H"], bias=st["bias"])
+        eng.run_staged(mask, B)
+        assert np.array_equal(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=0, copy=False), want[s]), s
+        assert np.array_equal(eng.get("PLK", (B, 3, g["k"].size)), want[s]) and np.array_equal(eng.get("PIN", (B, 200)), st["Pin"]), s   # the device copies too
     with pytest.raises(L.EftbError):
         eng.fetch_previous("PLK", (B, 3, g["k"].size), back=4)
     eng.close()
