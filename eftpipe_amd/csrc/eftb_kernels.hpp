@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(int Nkin, int ntail, int
 //   expand_kernel      the 28 / 10 loop matrices per l from the synthesised basis rows
 // ------------------------------------------------------------------------------------------------
 constexpr int AD_T = NHALF + 2;   // anti-diagonal length (129) rounded up to even
-constexpr int AD_CH = 3, AD_TC = 44;  // (measured at batch 128: 1 / 2 / 3 / 6 / 9 chunks -> 89 / 68 / 62 / 65 / 80 us for the P22 path)  // the anti-diagonal is cut into AD_CH chunks of AD_TC pairs (partial sums, added by build_rows_kernel)
+constexpr int AD_CH = 1;          // partial sums per anti-diagonal in HBM (round 2 cut it into 3 chunks of 44 pairs, summed by build_rows_kernel; round 3 sums inside the workgroup)
 constexpr int KSYN = 528;         // 1 + 2*256 synthesis coefficients, zero padded to a multiple of SYN_KPAD
 constexpr int KLIN = 288;         // 1 + 2*128, likewise
 constexpr int SYN_KPAD = 48;      // every K of a synthesis / first-stage GEMM is zero padded to a multiple of this
@@ -109,74 +109,95 @@ constexpr int BAS22 = 8, BASC = 32;  // padded basis rows per cosmology: 7 M22 m
 
 // Lanes <-> cosmologies (transposed coefficients coefT[2][129][Bmax] come out of the first-stage GEMMs); the matrix weights are wave-uniform
 // (scalar loads), so the table is streamed once per 64 cosmologies and no cross-lane reduction is needed.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: a compile-time constant after unrolling -> two v_readlane_b32 into an SGPR pair
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// Round 3.  PMC of the round-2 kernel (one wave per (j', 64 cosmologies, third of the anti-diagonal)): the waves ISSUE half of their
+// lifetime and wait a quarter of it -- not latency- but balance-bound: 1 542 waves of 0..44 trips on 1 024 SIMDs, a SIMD that draws two long
+// ones sets the launch time (26-28 us for 6 us of issue).  Now a workgroup = 4 waves = one (j', 64 cosmologies): the waves split the anti-diagonal
+// evenly, their partial sums meet in LDS in a fixed order (no partial sums in HBM any more: AD_CH = 1), and odd cosmology groups walk j'
+// backwards, so that workgroup i and workgroup 257 + i -- which the dispatcher deals to the same CU -- bring 129 - i/2 and 1 + i/2 pairs:
+// every CU gets the same work.  Inside a wave:
+//   * the weights of PB = 3 consecutive pairs (54 doubles, contiguous in the table) arrive as ONE coalesced wave-load a block ahead and are
+//     handed to the FMAs through v_readlane (SGPR operands as before, but no scalar-memory round trip and no "wait for all scalar loads");
+//   * the coefficients sit in a ring of PB slots: a slot is reloaded with the pair PB trips ahead as soon as its pair has been consumed.
 template <int NC>
-__global__ __launch_bounds__(64) void antidiag_kernel(int B, int Bmax, const double* __restrict__ coefT,
-                                                      const double2* __restrict__ AD, double2* __restrict__ S) {
-    const int jp = blockIdx.x, w = blockIdx.y * 64 + threadIdx.x, ch = blockIdx.z;
+__global__ __launch_bounds__(256) void antidiag_kernel(int B, int Bmax, const double* __restrict__ coefT,
+                                                       const double2* __restrict__ AD, double2* __restrict__ S) {
+    constexpr int PB = 3, WPP = 2 * NC;  // pairs per weight block, doubles per pair
+    static_assert(PB * WPP <= 64, "one wave-load must hold a block's weights");
+    __shared__ double red[3][2 * NC][64];  // partial sums of waves 1..3
+    const int grp = blockIdx.y, jp = (grp & 1) ? NPOW - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w = grp * 64 + lane;
     const int wl = w < B ? w : B - 1;
     const int cnt = ((2 * NHALF + jp) >> 1) - jp + 1;  // pairs (n, m) = (jp + t, 256 - t), n <= m
-    const int t0 = ch * AD_TC, t1 = min(cnt, t0 + AD_TC);
+    const int per = (cnt + 3) >> 2, t0 = wave * per, t1 = min(cnt, t0 + per);
     const double* cr = coefT + wl;
     const double* ci = coefT + (size_t)NCH * Bmax + wl;
     double ar[NC], ai[NC];
 #pragma unroll
     for (int q = 0; q < NC; ++q) ar[q] = ai[q] = 0.0;
-    // operands of pair t: the product c_n c_m (per lane = per cosmology) and the NC wave-uniform weights.  Software pipelined: the loads of pair
-    // t + 1 are issued before the 4 NC FMAs of pair t and waited for after them -- in the plain loop every one of the up to 44 trips sat through
-    // a full memory round trip (0.65 us per trip alone, 28 us per launch; the round-3 trace shows 63-83 us beside the resummation)
-    // (loads only -- the conjugations c_{256-n} = conj(c_n), c_m = conj(c_t) for m = 256 - t are applied where the values are consumed, so that
-    // nothing in the load phase waits for a load)
-    auto coef = [&](int t, double& xr, double& xi, double& yr, double& yi) {
-        const int n = jp + t, qn = n <= NHALF ? n : 2 * NHALF - n;
-        xr = cr[(size_t)qn * Bmax];
-        xi = ci[(size_t)qn * Bmax];
-        yr = cr[(size_t)t * Bmax];
-        yi = ci[(size_t)t * Bmax];
-    };
-    auto weights = [&](int t, double2* m) {
-        const double2* mp = AD + ((size_t)jp * AD_T + t) * NC;  // wave-uniform: scalar loads
-#pragma unroll
-        for (int q = 0; q < NC; ++q) m[q] = mp[q];
-    };
-    auto accumulate = [&](int t, double xr, double xi0, double yr, double yi0, const double2* m, double on) {
-        const double xi = jp + t <= NHALF ? xi0 : -xi0, yi = -yi0;
-        const double pr = (xr * yr - xi * yi) * on, pi = (xr * yi + xi * yr) * on;
-#pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            ar[q] = fma(m[q].x, pr, fma(-m[q].y, pi, ar[q]));
-            ai[q] = fma(m[q].x, pi, fma(m[q].y, pr, ai[q]));
-        }
-    };
     if (t0 < t1) {
-        // two register sets A / B, one pair each: while one set is being consumed the other is in flight (an odd tail re-reads the last pair
-        // with weight zero); the scheduling barriers keep each set's loads in front of the other set's arithmetic.  Scalar loads return out of
-        // order, so the only wait for them is "all of them": the set about to be consumed is touched (an empty asm) BEFORE the other set's
-        // loads go out -- its own loads are half a trip old by then
-        double axr, axi, ayr, ayi, bxr, bxi, byr, byi;
-        double2 ma[NC], mb[NC];
-        coef(t0, axr, axi, ayr, ayi);
-        weights(t0, ma);
-        for (int t = t0; t < t1; t += 2) {
-            const int tb = min(t + 1, t1 - 1), ta = min(t + 2, t1 - 1);
-            asm volatile("" ::"s"(ma[NC - 1].y), "s"(ma[0].x));
-            __builtin_amdgcn_sched_barrier(0);
-            coef(tb, bxr, bxi, byr, byi);
-            weights(tb, mb);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate(t, axr, axi, ayr, ayi, ma, 1.0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" ::"s"(mb[NC - 1].y), "s"(mb[0].x));
-            __builtin_amdgcn_sched_barrier(0);
-            coef(ta, axr, axi, ayr, ayi);
-            weights(ta, ma);
-            __builtin_amdgcn_sched_barrier(0);
-            accumulate(tb, bxr, bxi, byr, byi, mb, t + 1 < t1 ? 1.0 : 0.0);
-            __builtin_amdgcn_sched_barrier(0);
+        const double* adw = reinterpret_cast<const double*>(AD + ((size_t)jp * AD_T + t0) * NC);  // weights of pair t0 + i: adw[i WPP .. (i + 1) WPP)
+        const int nw = (t1 - t0) * WPP;
+        auto wload = [&](int blk) { return adw[min(blk * PB * WPP + lane, nw - 1)]; };
+        // (loads only -- the conjugations c_{256-n} = conj(c_n), c_m = conj(c_t) for m = 256 - t are applied where the values are consumed)
+        double xr[PB], xi[PB], yr[PB], yi[PB];
+        auto coef = [&](int t, int p) {
+            const int n = jp + t, qn = n <= NHALF ? n : 2 * NHALF - n;
+            xr[p] = cr[(size_t)qn * Bmax];
+            xi[p] = ci[(size_t)qn * Bmax];
+            yr[p] = cr[(size_t)t * Bmax];
+            yi[p] = ci[(size_t)t * Bmax];
+        };
+        double wc = wload(0);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) coef(min(t0 + p, t1 - 1), p);
+        const int nblk = (t1 - t0 + PB - 1) / PB;
+        for (int blk = 0; blk < nblk; ++blk) {
+            const double wn = wload(blk + 1);  // (clamped to the chunk's last weight: the block after the last one is never consumed)
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const int t = t0 + blk * PB + p;
+                const double on = t < t1 ? 1.0 : 0.0;  // pairs past the chunk's end (the last block's padding) carry no weight
+                const double xim = jp + t <= NHALF ? xi[p] : -xi[p], yim = -yi[p];
+                const double pr = (xr[p] * yr[p] - xim * yim) * on, pi = (xr[p] * yim + xim * yr[p]) * on;
+                // (scheduling barriers: left alone, the compiler gathers the reloads of all slots at the top of the trip and waits for every
+                // outstanding load before the first FMA -- no load would be in flight under the arithmetic)
+                __builtin_amdgcn_sched_barrier(0);
+                coef(min(t + PB, t1 - 1), p);  // the slot has been consumed: its next occupant is requested before this pair's FMAs
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const double mx = readlane_f64(wc, p * WPP + 2 * q), my = readlane_f64(wc, p * WPP + 2 * q + 1);
+                    ar[q] = fma(mx, pr, fma(-my, pi, ar[q]));
+                    ai[q] = fma(mx, pi, fma(my, pr, ai[q]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wc = wn;
         }
     }
-    if (w < B)
+    if (wave > 0) {
 #pragma unroll
-        for (int q = 0; q < NC; ++q) S[(((size_t)ch * Bmax + w) * NC + q) * NPOW + jp] = make_double2(ar[q], ai[q]);
+        for (int q = 0; q < NC; ++q) {
+            red[wave - 1][2 * q][lane] = ar[q];
+            red[wave - 1][2 * q + 1][lane] = ai[q];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && w < B) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {  // fixed order: wave 0 + wave 1 + wave 2 + wave 3
+                ar[q] += red[v][2 * q][lane];
+                ai[q] += red[v][2 * q + 1][lane];
+            }
+            S[((size_t)w * NC + q) * NPOW + jp] = make_double2(ar[q], ai[q]);
+        }
+    }
 }
 
 // One lane = one j' of one cosmology: sums the AD_CH partials of the nc anti-diagonal sums once, then writes

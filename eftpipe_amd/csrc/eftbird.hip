@@ -349,15 +349,15 @@ static int launch_gemm_direct(hipStream_t st, SynthBatch sb) {
 static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets, const double* coef, const double* coefT) {
     const eftb_config& c = e->c;
     const int nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
-    const dim3 grid(NPOW, (B + 63) / 64, AD_CH), rgrid(B, 2);
+    const dim3 grid(NPOW, (B + 63) / 64), rgrid(B, 2);  // antidiag: one workgroup of four waves per (j', 64 cosmologies)
 #define AD_ARGS B, c.max_batch, coefT, tb<double2>(e, EFTB_T_AD), e->SAD
 #define ROW_ARGS sets, c.max_batch, c.Nl, c.with_nnlo ? 3 : 2, c.nbasis, coef, e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
                  e->ACF, e->ALC
     if (nc == 9) {
-        if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(64), 0, st, AD_ARGS);
+        if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(256), 0, st, AD_ARGS);
         hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(320), 0, st, ROW_ARGS);
     } else if (nc == 7) {
-        if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(64), 0, st, AD_ARGS);
+        if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(256), 0, st, AD_ARGS);
         hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(320), 0, st, ROW_ARGS);
     } else {
         return fail("loop-matrix basis of dimension %d + %d is not instantiated (expected 7 + 2)", c.nbasis, c.with_resum ? c.nbasis13 : 0);
