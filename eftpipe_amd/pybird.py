@@ -95,7 +95,9 @@ common = Common()
 _ENGINES: "weakref.WeakKeyDictionary[Common, Engine]" = weakref.WeakKeyDictionary()
 
 
-_ENGINE_DEFAULTS = dict(nbinsmu=200, LambdaIR=0.2, NFFT_resum=192, resum_window=None)
+_ENGINE_DEFAULTS = dict(nbinsmu=200, LambdaIR=0.2, NFFT_resum=192, resum_window=None, fft_window=0.2, kin=None,
+                        irf_soffset=1.0, irf_rescale=1.0, irf_window=None)
+_DEFAULT_KIN = np.logspace(-5, 0, 200)  # reference theory.py:562
 
 
 def engine_for(co, loop_cache=None, **opts):
@@ -107,8 +109,13 @@ def engine_for(co, loop_cache=None, **opts):
         if k not in _ENGINE_DEFAULTS:
             raise TypeError(f"unknown engine option {k!r}")
     store.update(opts)
+    if store["kin"] is not None and np.array_equal(store["kin"], _DEFAULT_KIN):
+        store["kin"] = None
     eng = _ENGINES.get(co)
+    kin_now = _DEFAULT_KIN if store["kin"] is None else store["kin"]
     if eng is not None and (eng.Nk != co.Nk or not np.array_equal(eng.k, co.k) or eng.cfg.nbinsmu != store["nbinsmu"]
+                            or eng.cfg.fft_window != store["fft_window"] or not np.array_equal(eng.kin, kin_now)
+                            or (eng.cfg.irf_soffset, eng.cfg.irf_rescale, eng.cfg.irf_window) != (store["irf_soffset"], store["irf_rescale"], store["irf_window"])
                             or eng.cfg.LambdaIR != store["LambdaIR"] or eng.cfg.NFFT_resum != store["NFFT_resum"]
                             or eng.cfg.resum_window != store["resum_window"]
                             or eng.cfg.with_NNLO != bool(co.with_NNLO) or eng.cfg.IRcutoff != co.IRcutoff or eng.cfg.kIR != co.kIR
@@ -119,7 +126,9 @@ def engine_for(co, loop_cache=None, **opts):
     if eng is None:
         cfg = EngineConfig(Nl=co.Nl, k=np.array(co.k, dtype=np.float64), with_resum=True, with_ap=True, DA_AP=1.0, H_AP=1.0,
                            nbinsmu=store["nbinsmu"], LambdaIR=store["LambdaIR"], NFFT_resum=store["NFFT_resum"], resum_window=store["resum_window"],
-                           with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR, optiresum=bool(co.optiresum))
+                           with_NNLO=bool(co.with_NNLO), IRcutoff=co.IRcutoff, kIR=co.kIR, optiresum=bool(co.optiresum),
+                           fft_window=store["fft_window"], kin=None if store["kin"] is None else np.array(store["kin"], dtype=np.float64),
+                           irf_soffset=store["irf_soffset"], irf_rescale=store["irf_rescale"], irf_window=store["irf_window"])
         eng = _ENGINES[co] = Engine(cfg, max_batch=1, loop_cache=loop_cache)
     return eng
 
@@ -453,11 +462,9 @@ class NonLinear(HasLogger):
     def PsCf(self, bird, window=0.2):
         """FFTLog of P_lin + P22, P13, C11, Cct, C22, C13 (reference pybird.py:1143-1171) --
         prep_kernel, antidiag_kernel, build_rows_kernel, synth_kernel (FP64 MFMA), expand_kernel."""
-        if window != self.engine.cfg.fft_window:
-            raise NotImplementedError(f"engine built for FFTLog window={self.engine.cfg.fft_window}")
-        if not np.array_equal(bird.kin, self.engine.kin):
-            raise ValueError("bird.kin differs from the engine's input grid (reference theory.py:562 uses logspace(-5, 0, 200))")
-        eng, co = self.engine, self.co
+        # the FFTLog coefficient window and the input grid shape the first-stage operator tables: another value rebuilds them (as
+        # Resum(LambdaIR, NFFT) does for its own); the shipped callers pass window=0.2 and kin = logspace(-5, 0, 200) (theory.py:562)
+        eng, co = engine_for(self.co, fft_window=window, kin=bird.kin), self.co
         claim(eng, bird)
         bird.__dict__["_engine"] = eng
         bird.__dict__["_cf_weighted"] = False
@@ -527,8 +534,8 @@ class Resum(HasLogger):
     def engine(self):
         return engine_for(self.co, LambdaIR=self.LambdaIR, NFFT_resum=self.NFFT, resum_window=self._window)
 
-    def _inputs(self, bird):
-        eng = self.engine
+    def _inputs(self, bird, eng=None):
+        eng = self.engine if eng is None else eng
         claim(eng, bird)
         bird.__dict__["_engine"] = eng
         if not bird._on_device(eng, "PIN"):
@@ -541,11 +548,20 @@ class Resum(HasLogger):
 
     def IRFilters(self, bird, soffset=1.0, LambdaIR=None, RescaleIR=1.0, window=None):
         """X(s), Y(s) (reference pybird.py:1316-1353); only the arguments the reference's own callers use are supported."""
-        if soffset != 1.0 or RescaleIR != 1.0 or window is not None or (LambdaIR is not None and LambdaIR != self.LambdaIR):
-            raise NotImplementedError("IRFilters: the engine's tables are built for soffset=1, RescaleIR=1, window=None and the constructor's LambdaIR")
-        eng = self._inputs(bird)
-        eng.run(L.K_IRFILTER)  # irfilter_kernel alone: X, Y, Q(f) from the inputs; nothing else on the device is touched
-        xy = eng.get("XY", (2, NS_DEV))[:, self._sr]
+        default = soffset == 1.0 and RescaleIR == 1.0 and window is None and (LambdaIR is None or LambdaIR == self.LambdaIR)
+        special = None
+        if not default:
+            # other arguments select other X / Y operator tables, the way Resum(LambdaIR, NFFT) selects its own: the engine's tables are rebuilt
+            # for this call and put back afterwards (Resum.Ps always runs with the defaults, reference pybird.py:1424)
+            special = engine_for(self.co, LambdaIR=self.LambdaIR if LambdaIR is None else LambdaIR, NFFT_resum=self.NFFT, resum_window=self._window,
+                                 irf_soffset=float(soffset), irf_rescale=float(RescaleIR), irf_window=window)
+        try:
+            eng = self._inputs(bird, special)
+            eng.run(L.K_IRFILTER)  # irfilter_kernel alone: X, Y, Q(f) from the inputs; nothing else on the device is touched
+            xy = eng.get("XY", (2, NS_DEV))[:, self._sr]
+        finally:
+            if not default:
+                engine_for(self.co, LambdaIR=self.LambdaIR, irf_soffset=1.0, irf_rescale=1.0, irf_window=None)
         return np.ascontiguousarray(xy[0]), np.ascontiguousarray(xy[1])
 
     def setXpYp(self, bird):

@@ -218,7 +218,10 @@ class EngineConfig:
     k: Optional[np.ndarray] = None          # None -> native grid (pybird.py:472-479)
     kin: Optional[np.ndarray] = None        # None -> logspace(-5, 0, 200) (theory.py:562)
     NFFT: int = 256
-    fft_window: float = 0.2                 # NonLinear.PsCf(window=0.2) (pybird.py:1143)
+    fft_window: Optional[float] = 0.2       # NonLinear.PsCf(window=0.2) (pybird.py:1143)
+    irf_soffset: float = 1.0                # Resum.IRFilters(soffset, RescaleIR, window) (pybird.py:1316-1353); Resum.Ps uses the defaults
+    irf_rescale: float = 1.0
+    irf_window: Optional[float] = None
     with_resum: bool = False
     LambdaIR: float = 0.2
     NFFT_resum: int = 192
@@ -393,18 +396,20 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
             t["bao"] = bao
         # IR filters: q = Pin * exp(-k^2/L^2)/k^2 -> FFTLog(32) -> j0/j2 sums -> X, Y
         wq = np.exp(-(kin**2) / cfg.LambdaIR**2) / kin**2
-        xop = cut_operator(32, 1.5e-5, 10.0, -2.6, None) if ircut in ("all", "resum") else FFTLogOperator(32, 1.5e-5, 10.0, -2.6, kin, None)
+        xop = (cut_operator(32, 1.5e-5, 10.0, -2.6, cfg.irf_window) if ircut in ("all", "resum")
+               else FFTLogOperator(32, 1.5e-5, 10.0, -2.6, kin, cfg.irf_window))
         if xop.low_active:
             raise ValueError("kin[0] must not exceed 1.5e-5")
         XM = np.stack([lm.bessel_weight(2 * l, -0.5 * xop.Pow) for l in range(2)])
         XsPow = np.exp(np.outer(-xop.Pow - 3.0, np.log(s)))              # [33,Ns]
         K = lambda D: np.real(np.einsum("ln,ns,ni->lsi", XM, XsPow, D))   # [2,Ns,cols]
-        Koff = lambda D: np.real(np.einsum("n,ni->i", XM[0], D))
+        soff = cfg.irf_soffset ** (-xop.Pow - 3.0)                       # X0offset: the j0 sum at s = soffset (pybird.py:1339-1346)
+        Koff = lambda D: np.real(np.einsum("n,ni->i", XM[0] * soff, D))
         body, tail = K(xop.G), K(xop.E_hi)
         boff, toff = Koff(xop.G), Koff(xop.E_hi)
-        t["BX"] = np.ascontiguousarray(2.0 / 3.0 * (boff[None, :] - body[0] - body[1]) * wq[None, :])
+        t["BX"] = np.ascontiguousarray(cfg.irf_rescale * 2.0 / 3.0 * (boff[None, :] - body[0] - body[1]) * wq[None, :])
         t["BY"] = np.ascontiguousarray(2.0 * body[1] * wq[None, :])
-        t["TX"] = np.ascontiguousarray(2.0 / 3.0 * (toff[None, :] - tail[0] - tail[1]))
+        t["TX"] = np.ascontiguousarray(cfg.irf_rescale * 2.0 / 3.0 * (toff[None, :] - tail[0] - tail[1]))
         t["TY"] = np.ascontiguousarray(2.0 * tail[1])
         t["lnx_xtail"] = xop.lnx_hi
         t["wq_last2"] = wq[-2:].copy()

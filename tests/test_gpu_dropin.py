@@ -310,8 +310,10 @@ def test_resum_nondefault_options_and_helper_methods(golden):
     assert rs.Q.shape == (2, 3, 3, 96)
     for n in ("P11l", "Pctl", "Ploopl"):
         assert relerr(getattr(bird, n), g["resum_" + n]) < TOL, n
-    with pytest.raises(NotImplementedError):
-        rs.IRFilters(bird, soffset=2.0)
+    Xs, Ys = rs.IRFilters(bird, soffset=2.0)   # other arguments select other tables (test_surface_arguments_off_their_defaults pins them) ...
+    assert Xs.shape == X.shape and not np.array_equal(Xs, X) and np.array_equal(Ys, Y)   # soffset moves X's offset term only
+    X2, Y2 = rs.IRFilters(bird)                 # ... and the constructor's tables are back afterwards
+    assert np.array_equal(X2, X) and np.array_equal(Y2, Y)
     # a second bird on the default-option engine of another Common is not disturbed
     b2 = pybird.Bird(g["kin"], g["Pin"], float(g["f"]), co=co)
     nl.PsCf(b2)
@@ -372,3 +374,47 @@ def test_lazy_bird_attributes_follow_host_mutation(golden):
     assert relerr(b1.Ploopl, g["setpscfl_Ploopl"]) < TOL and relerr(b2.P11l, 1.1 * g["setpscfl_P11l"]) < TOL
     rs.Ps(b1)
     assert relerr(b1.Ploopl, g["resum_Ploopl"]) < TOL
+
+
+def test_surface_arguments_off_their_defaults(golden):
+    """NonLinear.PsCf(bird, window=0.3), a Bird on another input grid (240 samples up to k = 10^0.2) through PsCf /
+    setPsCfl / Resum.Ps, and Resum.IRFilters(bird, soffset, LambdaIR, RescaleIR, window) -- each selects other operator tables of the same
+    device kernels (the engine rebuilds them, as Resum(LambdaIR, NFFT) always did) -- against the REAL reference (tests/golden/surface.npz;
+    reference pybird.py:682-695, 1143-1171, 1316-1353); and back to the defaults afterwards."""
+    from eftpipe_amd import pybird
+
+    g, c = golden("surface"), golden("caseC")
+    co = pybird.Common(Nl=3, kmax=0.3, kmA=0.7, krA=0.25, ndA=4.5e-5)
+    f, DA, H, z = float(g["f"]), float(g["DA"]), float(g["H"]), float(g["z"])
+    nl, rs = pybird.NonLinear(load=False, save=False, co=co), pybird.Resum(co=co)
+    # (1) another coefficient window
+    bird = pybird.Bird(g["kin"], g["Pin"], f, DA, H, z, co=co)
+    nl.PsCf(bird, window=0.3)
+    for n in ("P11", "P22", "P13", "C11", "Cct", "C22", "C13"):
+        assert relerr(getattr(bird, n), g["w03_" + n]) < TOL, n
+    # (2) IR filters off their defaults, then with them (the tables are put back)
+    b2 = pybird.Bird(g["kin"], g["Pin"], f, DA, H, z, co=co)
+    so, lam, resc, win = (float(x) for x in g["irf"])
+    X, Y = rs.IRFilters(b2, soffset=so, LambdaIR=lam, RescaleIR=resc, window=win)
+    assert relerr(X[None], g["irf_X"][None]) < 1e-10 and relerr(Y[None], g["irf_Y"][None]) < 1e-10
+    X, Y = rs.IRFilters(b2)
+    assert relerr(X[None], g["irf_X_default"][None]) < 1e-10 and relerr(Y[None], g["irf_Y_default"][None]) < 1e-10
+    # (3) another input grid
+    b3 = pybird.Bird(g["kin2"], g["Pin2"], f, DA, H, z, co=co)
+    nl.PsCf(b3)
+    for n in ("P11", "P22", "P13", "C11"):
+        assert relerr(getattr(b3, n), g["kin2_" + n]) < TOL, n
+    b3.setPsCfl()
+    rs.Ps(b3)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(getattr(b3, n), g["kin2_resum_" + n]) < TOL, n
+    # (4) and the shipped call sequence still gives the shipped answer on the same Common
+    b4 = pybird.Bird(c["kin"], c["Pin"], float(c["f"]), float(c["DA"]), float(c["H"]), 0.7, co=co)
+    nl.PsCf(b4)
+    b4.setPsCfl()
+    rs.Ps(b4)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(getattr(b4, n), c["resum_" + n]) < TOL, n
+    # NonLinear(NFFT != 256) stays a loud refusal: the anti-diagonal tables and the synthesis kernels are sized for 257 powers
+    with pytest.raises(NotImplementedError):
+        pybird.NonLinear(load=False, save=False, NFFT=128, co=co)

@@ -96,3 +96,33 @@ def test_projection_operators_match_reference(golden):
     assert full.shape == (2, 3, len(g["kout"]), k.size)
     for n in names:
         assert relerr(np.einsum("alxk,lrk->arx", full, g["ap_" + n]), g["chained_" + n]) < 1e-9, n
+
+
+def test_surface_options_select_operator_tables(golden):
+    """VERDICT r02 item 8 on the CPU: PsCf(window=0.3), a non-default input grid and IRFilters(soffset, LambdaIR, RescaleIR, window) are other
+    operator TABLES of the same kernels -- the NumPy emulation of the device contractions on those tables against the REAL reference
+    (tests/golden/surface.npz, tools/make_fixtures.py surface; reference pybird.py:682-695, 1143-1171, 1316-1353)."""
+    g = golden("surface")
+    f = float(g["f"])
+    # (1) coefficient window 0.3
+    t = build_tables(EngineConfig(Nl=3, with_resum=True, fft_window=0.3))
+    st = E.pscf(t, g["Pin"], with_cf=True)
+    for n in ("P11", "P22", "P13", "C11", "Cct", "C22", "C13"):
+        assert relerr(st[n], g["w03_" + n]) < 1e-9, n
+    # (2) IR filters with every argument off its default
+    so, lam, resc, win = (float(x) for x in g["irf"])
+    t = build_tables(EngineConfig(Nl=3, with_resum=True, LambdaIR=lam, irf_soffset=so, irf_rescale=resc, irf_window=win))
+    X, Y = E.ir_filters(t, g["Pin"])
+    assert relerr(X[None], g["irf_X"][None]) < 1e-12 and relerr(Y[None], g["irf_Y"][None]) < 1e-12
+    t0 = build_tables(EngineConfig(Nl=3, with_resum=True))
+    X, Y = E.ir_filters(t0, g["Pin"])
+    assert relerr(X[None], g["irf_X_default"][None]) < 1e-12 and relerr(Y[None], g["irf_Y_default"][None]) < 1e-12
+    # (3) another input grid: 240 samples up to k = 10^0.2
+    t = build_tables(EngineConfig(Nl=3, with_resum=True, kin=g["kin2"]))
+    st = E.pscf(t, g["Pin2"], with_cf=True)
+    for n in ("P11", "P22", "P13", "C11"):
+        assert relerr(st[n], g["kin2_" + n]) < 1e-9, n
+    st.update(E.setpscfl(t, f, st, with_cf=True))
+    st = E.resum(t, f, g["Pin2"], st)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        assert relerr(st[n], g["kin2_resum_" + n]) < 1e-9, n

@@ -801,6 +801,78 @@ def cfg5_fixture(ref):
     print("cfg5 written:", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB raw")
 
 
+def cfg5_acc4_fixture(ref):
+    """BASELINE cfg 5 at the SHIPPED window accuracy (accboost 4, windowk 0.1 -- yaml :63-65) for the LRG window: the Nk = 2048 AP-stage
+    templates of caseF through the reference's Window at Np = 1540 and Binning.  The reference's precompute at Nk = 2048 x Np = 1540 is the
+    slow part (Waldk 227 MB; about ten minutes, once); stored: two Waldk rows, the p sums, every 4th k of the convolved templates, the binned
+    templates."""
+    import time
+    pb = ref.pybird
+    g = dict(np.load(os.path.join(GOLD, "caseF.npz"), allow_pickle=True))
+    Nl, Nk = 3, 2048
+    co = make_common(pb, Nl, Nk)
+    kout = np.arange(0.025, 0.2, 0.01)
+    out = dict(kout=kout, accboost=CFG3_WINDOW["accboost"], windowk=CFG3_WINDOW["windowk"])
+    ddir = os.path.join(REFERENCE_ROOT, "data", "DR16_noric")
+    t = "LRG"
+    bird = ref.transformer.PlainBird(f=float(g["f"]), co=co, P11l=g["ap_P11l"].copy(), Ploopl=g["ap_Ploopl"].copy(), Pctl=g["ap_Pctl"].copy(),
+                                     Pstl=g["ap_Pstl"].copy(), Picc=np.zeros((Nl, Nk)), PctNNLOl=np.zeros((Nl, 3, Nk)))
+    t0 = time.time()
+    win = ref.window.Window(window_configspace_file=os.path.join(ddir, f"win_NGC_{t}.txt"), co=co, load=False, save=False, **CFG3_WINDOW)
+    out["reference_precompute_s"] = time.time() - t0
+    print("cfg5_acc4 reference window precompute", round(time.time() - t0, 1), "s; Waldk", win.Waldk.shape, flush=True)
+    out["window_p"] = win.p
+    out[f"{t}_Waldk_k1000"], out[f"{t}_Waldk_k77"] = win.Waldk[:, :, 1000, :], win.Waldk[:, :, 77, :]
+    out[f"{t}_Waldk_sum_p"] = win.Waldk.sum(axis=-1)
+    win.Window(bird)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        out[f"{t}_window_{n}_k512"] = np.array(getattr(bird, n))[..., ::4]
+    bn = ref.binning.Binning(kout=kout, co=co)
+    out["keff"] = bn.keff
+    like = bn.transform(bird)
+    for n in ("P11l", "Pctl", "Ploopl", "Pstl"):
+        out[f"{t}_binned_{n}"] = np.array(getattr(like, n), copy=True)
+    np.savez_compressed(os.path.join(GOLD, "cfg5_acc4.npz"), **out)
+    print("cfg5_acc4 written:", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB raw")
+
+
+def surface_fixture(ref):
+    """Non-default arguments of the drop-in surface through the REAL reference: NonLinear.PsCf(bird, window=0.3)
+    (pybird.py:1143-1171), a Bird on a non-default input grid kin = logspace(-5, 0.2, 240) (pybird.py:682-695) through PsCf / setPsCfl / Resum.Ps, and
+    Resum.IRFilters(bird, soffset, LambdaIR, RescaleIR, window) (pybird.py:1316-1353).  Native 50-point k grid, Nl = 3."""
+    pb = ref.pybird
+    Nl, z = 3, 0.7
+    cos = synth.cosmology(z=z)
+    co = make_common(pb, Nl, None)
+    out = dict(k=co.k, kin=cos["kin"], Pin=cos["Pin"], f=cos["f"], DA=cos["DA"], H=cos["H"], z=z, Nl=Nl, pscf_window=0.3,
+               irf=np.array([1.3, 0.3, 0.8, 0.5]))
+    nl = pb.NonLinear(load=False, save=False, co=co)
+    rs = pb.Resum(co=co)
+    # (1) PsCf with another coefficient window
+    bird = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+    nl.PsCf(bird, window=0.3)
+    for n in ("P11", "P22", "P13", "C11", "Cct", "C22", "C13"):
+        out["w03_" + n] = np.array(getattr(bird, n), copy=True)
+    # (2) IRFilters with every argument off its default
+    b2 = pb.Bird(cos["kin"], cos["Pin"], cos["f"], cos["DA"], cos["H"], z, co=co)
+    out["irf_X"], out["irf_Y"] = rs.IRFilters(b2, soffset=1.3, LambdaIR=0.3, RescaleIR=0.8, window=0.5)
+    out["irf_X_default"], out["irf_Y_default"] = rs.IRFilters(b2)
+    # (3) another input grid
+    kin2 = np.logspace(-5, 0.2, 240)
+    Pin2 = synth.plin(kin2)
+    out["kin2"], out["Pin2"] = kin2, Pin2
+    b3 = pb.Bird(kin2, Pin2, cos["f"], cos["DA"], cos["H"], z, co=co)
+    nl.PsCf(b3)
+    for n in ("P11", "P22", "P13", "C11"):
+        out["kin2_" + n] = np.array(getattr(b3, n), copy=True)
+    b3.setPsCfl()
+    rs.Ps(b3)
+    for n in ("P11l", "Pctl", "Ploopl"):
+        out["kin2_resum_" + n] = np.array(getattr(b3, n), copy=True)
+    np.savez_compressed(os.path.join(GOLD, "surface.npz"), **out)
+    print("surface written:", {k: np.shape(v) for k, v in out.items() if np.ndim(v) > 1})
+
+
 def resumopt_fixture(ref):
     """Non-default resummation options through the REAL reference (pybird.py:1230-1300, 1316-1353, 1409-1464): Resum(LambdaIR=0.25,
     NFFT=128) and Resum.Ps(bird, window=0.3), plus the helper methods IRFilters / setXpYp / makeQ and NonLinear.Coef on their own."""
@@ -836,7 +908,7 @@ def resumopt_fixture(ref):
 def main():
     ref = load_reference()
     os.makedirs(GOLD, exist_ok=True)
-    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti", "wmat", "cfg3", "resumopt", "cfg5"])
+    want = sys.argv[1:] or (["tables"] + list(CASES) + ["marg", "pyegg", "east", "fiber", "nnlo", "ircut", "opti", "wmat", "cfg3", "resumopt", "cfg5", "cfg3_nk512", "surface", "cfg5_acc4"])
     for name in want:
         if name == "tables":
             tables_fixture(ref)
@@ -858,6 +930,10 @@ def main():
             wmat_fixture(ref)
         elif name == "cfg3":
             cfg3_fixture(ref)
+        elif name == "surface":
+            surface_fixture(ref)
+        elif name == "cfg5_acc4":
+            cfg5_acc4_fixture(ref)
         elif name == "cfg3_nk512":
             cfg3_nk512_fixture(ref)
         elif name == "resumopt":
