@@ -532,3 +532,36 @@ def test_cfg5_two_tracers_nk2048_against_reference(golden):
     assert np.all(templ[1][2] == 0.0)                                               # padded multipole of the chained tracer
     assert relerr(plk[0], np.einsum("r,lrx->lx", bias[0], templ[0])) < 1e-12
     eng.close()
+
+
+def test_cfg5_window_at_shipped_accuracy_nk2048(golden):
+    """BASELINE cfg 5 at the window accuracy the reference ships (accboost 4, windowk 0.1; yaml :63-65): eftb_window_precompute at
+    Nk = 2048 x Np = 1540 (Waldk 227 MB) against the reference's own rows and p sums (1e-9), then the Nk = 2048 engine with window -> binning
+    folded into one device operator against the reference's binned templates (tests/golden/cfg5_acc4.npz; the reference needs 11 minutes
+    for this precompute)."""
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+    from eftpipe_amd.window import window_matrix_device
+
+    g, f = golden("cfg5_acc4"), golden("caseF")
+    k = f["k"]
+    tab = np.load(WIN)
+    timing = {}
+    Wal, p, Waldk, Wfold = window_matrix_device(k, tab[:, 0], tab[:, 1:].T, 3, 3, windowk=float(g["windowk"]), accboost=int(g["accboost"]), timing=timing)
+    print("cfg5 accboost-4 window precompute:", timing)
+    del Wal
+    assert np.array_equal(p, g["window_p"]) and p.size == 1540
+    assert relerr(Waldk[:, :, 1000, :], g["LRG_Waldk_k1000"]) < 1e-9 and relerr(Waldk[:, :, 77, :], g["LRG_Waldk_k77"]) < 1e-9
+    assert relerr(Waldk.sum(axis=-1), g["LRG_Waldk_sum_p"]) < 1e-9
+    del Waldk
+    Bm, keff, _, _ = TB.binning_operator(k, g["kout"])
+    op = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm)
+    eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(f["DA_AP"]), H_AP=float(f["H_AP"])), max_batch=2)
+    eng.set_pipeline_operator(eng.add_operator(op))
+    proj = eng.eval_batch(np.stack([f["Pin"], f["Pin"]]), float(f["f"]), float(f["DA"]), float(f["H"]))
+    rows24 = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(21, 24))
+    for n, sl in rows24.items():
+        assert relerr(proj[0][:, sl], g["LRG_binned_" + n]) < TOL, n
+    assert np.array_equal(proj[0], proj[1])
+    eng.close()

@@ -512,6 +512,33 @@ def test_cfg3_nk512_host_tables_at_production_window(golden):
         assert relerr(np.einsum("alxk,lnk->anx", op, g[f"{t}_ap_{n}"]), g[f"{t}_binned_{n}"]) < 1e-9, n
 
 
+def test_cfg5_acc4_host_tables_nk2048(golden):
+    """BASELINE cfg 5 at the shipped window accuracy (accboost 4, windowk 0.1) on the Nk = 2048 grid, host side: the table builder at
+    Np = 1540 against the reference's own Waldk rows / p sums, the folded window operator against every 4th k of the reference's convolved
+    templates and window -> binning against its binned templates (tests/golden/cfg5_acc4.npz, tools/make_fixtures.py cfg5_acc4: the
+    reference's precompute takes 11 minutes here)."""
+    import cfg3_util as U
+    from eftpipe_amd import tables as TB
+
+    g, f = golden("cfg5_acc4"), golden("caseF")
+    k = f["k"]
+    assert k.size == 2048 and g["window_p"].size == 1540
+    tab = U.window_table("LRG_NGC")
+    Wal, p = TB.window_matrix(k, tab[:, 0], tab[:, 1:].T, 3, 3, accboost=4)
+    assert np.array_equal(p, g["window_p"])
+    Wfold, Waldk = TB.window_fold(k, Wal, p, windowk=0.1)
+    del Wal
+    assert relerr(Waldk[:, :, 1000, :], g["LRG_Waldk_k1000"]) < 1e-9 and relerr(Waldk[:, :, 77, :], g["LRG_Waldk_k77"]) < 1e-9
+    assert relerr(Waldk.sum(axis=-1), g["LRG_Waldk_sum_p"]) < 1e-9
+    del Waldk
+    Bm, keff, _, _ = TB.binning_operator(k, g["kout"])
+    assert relerr(keff[None], g["keff"][None]) < 1e-13
+    op = TB.compose_operator(3, k.size, Wfold=Wfold, binning=Bm)
+    for n in U.NAMES:
+        assert relerr(np.einsum("alxk,lnk->anx", Wfold[:, :, ::4], f["ap_" + n]), g[f"LRG_window_{n}_k512"]) < 1e-9, n
+        assert relerr(np.einsum("alxk,lnk->anx", op, f["ap_" + n]), g[f"LRG_binned_{n}"]) < 1e-9, n
+
+
 def test_integral_constraint_against_oracle(tmp_path):
     """SURVEY 8(f) rank 4, PARITY UNPINNED (the reference's interp2d call no longer exists in SciPy, so it cannot produce fixtures):
     eftpipe_amd.icc.IntegralConstraint -- PSN, the 2-D FFTLog matrix with the documented interp2d replacement, mask / dp weights, the
