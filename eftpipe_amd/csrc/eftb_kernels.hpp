@@ -39,7 +39,7 @@ __device__ __forceinline__ void xcd_decode(int ntile, int& tile, int& group) {
 // First stage.  P11 = Sk Pin (cubic spline kin -> k), the 129 independent FFTLog coefficients = G Pin + E tail(slope, amp) and the IR
 // filters X, Y = B Pin + T tail'(slope', amp') are fixed real operators on the 200 input samples and on the power-law tails that continue
 // them (reference pybird.py:694-695, fftlog.py:84-166, pybird.py:1316-1353).  With the batch as the row dimension they are small GEMMs on
-// the matrix cores (synth_kernel), whose tables are read once per launch instead of once per cosmology.
+// the matrix cores (gemm_direct_kernel), whose tables are read once per 16 cosmologies instead of once per cosmology.
 // prep_rows_kernel writes the operand rows: A1 = Pin (for P11), A2 = [Pin | tail] (coefficients; also transposed, for the
 // cosmology-contiguous copy the anti-diagonal pass reads), A3 = [Pin | tail'] (IR filters), zero padded to multiples of the GEMM's K chunk.
 // One workgroup per cosmology.  A1 / A3 may be null (only the other part is wanted).  Input guard: include/eftbird.h.
@@ -372,7 +372,10 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
 // K runs in groups of 16: lane (r = lane & 15, g = lane >> 4) holds A[row r][16 u + 4 g + j] (one 32-byte load) and multiplies it, for
 // j = 0..3, with Tab[16 u + 4 g + j][x0 + 2 r + {0, 1}] (one 16-byte load): the k order inside an MFMA is a permutation of the usual one, the
 // same on both operands.  Column tile t holds x0 + 2 r + t, so a lane stores pairs of neighbouring columns.  K is a multiple of 16 (SYN_KPAD).
-__global__ __launch_bounds__(64) void gemm_direct_kernel(SynthBatch batch) {
+__global__ __launch_bounds__(256) void gemm_direct_kernel(SynthBatch batch) {
+    // workgroup = 4 waves = ONE tile: the waves take a quarter of the K groups each (the serial depth of a tile is what a problem this small
+    // waits for: 18 dependent load -> MFMA trips at K = 288 became 5) and their partial tiles meet in LDS, added in wave order
+    __shared__ double red[3][8][64];
     int pi = 0, wg0 = 0;
 #pragma unroll
     for (int q = 0; q < SYN_MAXP - 1; ++q)
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(64) void gemm_direct_kernel(SynthBatch batch) {
         }
     const SynthDesc& d = batch.p[pi];
     const int wg = blockIdx.x - wg0, bx = wg % d.wgx, by = wg / d.wgx;
-    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const int rowa = by * 16 + r, rc = rowa < d.M ? rowa : d.M - 1;
     const double* ap = d.A + (long long)(rc / d.rpg) * d.a_group + (long long)(rc % d.rpg) * d.K + 4 * g;
     const int x = bx * 32 + 2 * r;
@@ -390,11 +393,11 @@ __global__ __launch_bounds__(64) void gemm_direct_kernel(SynthBatch batch) {
     const int x0 = x < d.X ? x : d.X - 1, x1 = x + 1 < d.X ? x + 1 : d.X - 1;
     const double* bp = d.Tab + (size_t)(4 * g) * d.X;
     v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int ng = d.K / 16;
+    const int ng = d.K / 16, per = (ng + 3) >> 2, u0 = wave * per, u1 = min(ng, u0 + per);
     if (pairs) {
         const double* bq = bp + (x + 1 < d.X ? x : d.X - 2);
 #pragma unroll 2
-        for (int u = 0; u < ng; ++u) {
+        for (int u = u0; u < u1; ++u) {
             const double4 a = *reinterpret_cast<const double4*>(ap + 16 * u);
             double2 b[4];
 #pragma unroll
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(64) void gemm_direct_kernel(SynthBatch batch) {
         }
     } else {
 #pragma unroll 2
-        for (int u = 0; u < ng; ++u) {
+        for (int u = u0; u < u1; ++u) {
             const double4 a = *reinterpret_cast<const double4*>(ap + 16 * u);
             const double av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
@@ -421,6 +424,22 @@ __global__ __launch_bounds__(64) void gemm_direct_kernel(SynthBatch batch) {
             }
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            red[wave - 1][q][lane] = acc0[q];
+            red[wave - 1][4 + q][lane] = acc1[q];
+        }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0[q] += red[v][q][lane];
+            acc1[q] += red[v][4 + q][lane];
+        }
     // D: rows g + 4 q, column r of each tile -> x and x + 1
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1504,14 +1523,16 @@ __global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* _
     const int q = seq & 3, l = (seq >> 2) % NL, lp = seq / (4 * NL);
     const int clen = (nmu + NCH - 1) / NCH, j0 = ch * clen, j1 = min(nmu, j0 + clen);
     double* ps = PS + (size_t)w * (nmu + 1) * NS + seq;
-    double s = 0.0;
+    // two sweeps over the chunk from LDS: totals first, then -- once the chunk offsets are known -- the running sums, written once (round 2
+    // wrote chunk-local sums to global memory and came back to add the offsets: a global read-modify-write in the middle of a 20 us kernel)
+    auto term = [&](int j) {
+        const double r = s_rho[j];
+        const double rq = q == 0 ? 1.0 : (q == 1 ? r : (q == 2 ? r * r : r * r * r));
+        return s_wl[l * nmu + j] * s_lp[lp * nmu + j] * rq;
+    };
     if (ch < NCH) {
-        for (int j = j0; j < j1; ++j) {
-            const double r = s_rho[j];
-            const double rq = q == 0 ? 1.0 : (q == 1 ? r : (q == 2 ? r * r : r * r * r));
-            s = fma(s_wl[l * nmu + j] * s_lp[lp * nmu + j], rq, s);
-            ps[(size_t)(j + 1) * NS] = s;  // chunk-local prefix
-        }
+        double s = 0.0;
+        for (int j = j0; j < j1; ++j) s += term(j);
         s_tot[seq * NCH + ch] = s;
     }
     __syncthreads();
@@ -1525,9 +1546,12 @@ __global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* _
         PS[(size_t)w * (nmu + 1) * NS + threadIdx.x] = 0.0;
     }
     __syncthreads();
-    if (ch < NCH && ch > 0) {
-        const double off = s_tot[seq * NCH + ch];
-        for (int j = j0; j < j1; ++j) ps[(size_t)(j + 1) * NS] += off;
+    if (ch < NCH) {
+        double s = s_tot[seq * NCH + ch];
+        for (int j = j0; j < j1; ++j) {
+            s += term(j);
+            ps[(size_t)(j + 1) * NS] = s;
+        }
     }
 }
 

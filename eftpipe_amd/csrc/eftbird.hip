@@ -340,7 +340,7 @@ static int launch_gemm_direct(hipStream_t st, SynthBatch sb) {
         end += d.wgx * ((d.M + 15) / 16);
         d.wg_end = end;
     }
-    if (sb.n) hipLaunchKernelGGL(gemm_direct_kernel, dim3(end), dim3(64), 0, st, sb);
+    if (sb.n) hipLaunchKernelGGL(gemm_direct_kernel, dim3(end), dim3(256), 0, st, sb);
     return 0;
 }
 
