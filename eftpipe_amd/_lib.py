@@ -29,7 +29,7 @@ class Config(C.Structure):
 
 # enum eftb_table / eftb_buffer / eftb_stage (same order as the header)
 TABLES = ("K S LNKIN SKT GCT ECT LNXTAIL AD EXP22 EXPC MLJ LINVEC SYNK SYNS LINK LINS L11 LCT L22 L13 GRP "
-          "BXT BYT TXT TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID LCTN BAO GCT2 GCT2T").split()
+          "BXT SPCBAND SPLOCAL TYT LNXXTAIL WQLAST2 QPOLY H RSBASIS RSBASISS RSROWS MU WMU LEGMU SPBAND APFID LCTN BAO GCT2 GCT2T").split()
 T = {n: i for i, n in enumerate(TABLES)}
 BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF GROWS LOGP CCTN TEMPLN BIASN GROWSN".split()
 B = {n: i for i, n in enumerate(BUFFERS)}

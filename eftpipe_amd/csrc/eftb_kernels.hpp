@@ -1469,6 +1469,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(88))) void spli
     }
 }
 
+__device__ __forceinline__ int bspl_first(int i, int Nk) { return min(max(i - 1, 0), Nk - 4); }  // J_i of tables.bspline_tables
+
 __device__ inline int knot_interval(const double* __restrict__ kk, int Nk, double x) {
     int lo = 0, hi = Nk - 1;
     while (hi - lo > 1) {
@@ -1562,14 +1564,17 @@ __global__ __launch_bounds__(320) void ap_prefix_kernel(int nmu, const double* _
 // (no LDS, few registers), so that its launch never waits for resources when every workgroup just reads its flag and leaves.
 // Workgroup = one wave = 64 k of one cosmology, the thread walks the template rows one after the other (a light launch: 1 024 waves at
 // Nk = 512, B = 128 -- the gate must not wait for resources beside the resummation kernel); rows >= nr (Pstl unless APst) are copied through.
-template <int NL>
+// BSPL: S holds the B-spline coefficients of the rows (the fast path's spline data, tables.bspline_tables; LOCAL = its per-interval matrices)
+// instead of the knot slopes of the Hermite form.
+template <int NL, bool BSPL>
 __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo, int nr, const double* __restrict__ kk, const double* __restrict__ DAw,
                                                        const double* __restrict__ Hw, const double* __restrict__ fid,
                                                        const double* __restrict__ mu, const double* __restrict__ wmu,
                                                        const double* __restrict__ legmu, const double* __restrict__ ROOT,
                                                        const double* __restrict__ T, const double* __restrict__ S, double* __restrict__ Tout,
                                                        const int4* __restrict__ META, const double* __restrict__ bias, double* __restrict__ Plk,
-                                                       double* __restrict__ PlkHost, int msplit, int* __restrict__ nonfinite) {
+                                                       double* __restrict__ PlkHost, int msplit, int* __restrict__ nonfinite,
+                                                       const double* __restrict__ LOCAL) {
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
@@ -1612,14 +1617,31 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
             const double m = mu[j], mp = m / (F * rt), x2 = mp * mp;
             const double lpv[3] = {1.0, 0.5 * (3.0 * x2 - 1.0), (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125};
             double P = 0.0;
+            if (BSPL) {
+                // value of the four basis pieces of interval i at t: sum_p local[i][e][p] t^p; the spline is their combination with c[J_i + e]
+                const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+                double be[4];
 #pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                const size_t o = rbase + (size_t)lp * NROW * Nk + i;
-                const double ya = T[o], yb = T[o + 1], sa = S[o], sb = S[o + 1];
-                const double sl = (yb - ya) * ih;
-                const double c3 = (sa + sb - 2.0 * sl) * ih * ih;
-                const double c2 = (sl - sa) * ih - c3 * h;
-                P = fma(fma(fma(fma(c3, t, c2), t, sa), t, ya), lpv[lp], P);
+                for (int e = 0; e < 4; ++e) {
+                    const double4 n4 = lc[e];
+                    be[e] = fma(fma(fma(n4.w, t, n4.z), t, n4.y), t, n4.x);
+                }
+                const int J = bspl_first(i, Nk);
+#pragma unroll
+                for (int lp = 0; lp < NL; ++lp) {
+                    const double* cp = S + rbase + (size_t)lp * NROW * Nk + J;
+                    P = fma(fma(be[0], cp[0], fma(be[1], cp[1], fma(be[2], cp[2], be[3] * cp[3]))), lpv[lp], P);
+                }
+            } else {
+#pragma unroll
+                for (int lp = 0; lp < NL; ++lp) {
+                    const size_t o = rbase + (size_t)lp * NROW * Nk + i;
+                    const double ya = T[o], yb = T[o + 1], sa = S[o], sb = S[o + 1];
+                    const double sl = (yb - ya) * ih;
+                    const double c3 = (sa + sb - 2.0 * sl) * ih * ih;
+                    const double c2 = (sl - sa) * ih - c3 * h;
+                    P = fma(fma(fma(fma(c3, t, c2), t, sa), t, ya), lpv[lp], P);
+                }
             }
             const double wj = wmu[j] * P;
 #pragma unroll
@@ -1813,25 +1835,21 @@ template <int NL>
 __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
                                                          const double* __restrict__ Hw, const double* __restrict__ fid,
                                                          const double* __restrict__ mu, const double* __restrict__ PS,
-                                                         const double* __restrict__ ROOT, double* __restrict__ W, int* __restrict__ I0,
-                                                         int4* __restrict__ META) {
+                                                         const double* __restrict__ ROOT, const double* __restrict__ LOCAL,
+                                                         double* __restrict__ W, int* __restrict__ I0, int4* __restrict__ META) {
     // NL waves, NL (l', l) pairs each (wave <-> l', the order of the prefix sums): every wave walks the same interval slots, so fewer waves
     // means fewer copies of the crossing arithmetic, and the pairs divide evenly
     constexpr int NS = NL * NL * 4, NP = NL * NL, PPW = NL, NT = 64 * NL;  // prefix sequences, (l', l) pairs, pairs per wave, threads
     extern __shared__ double sm[];
     double* s_k = sm;                   // [Nk]
     double* s_root = sm + Nk;           // [nmu]
-    double* s_ih = sm + Nk + nmu + (nmu & 1);  // [Nk] 1 / (k_i+1 - k_i): one division per knot and workgroup instead of one per (k, slot) and wave
-    __shared__ int s_red[2][3];         // per half wave (= tile of 32 k): min i0, max i0, max knots per k
+    __shared__ int s_red[2][3];         // per half wave (= tile of 32 k): min first coefficient, max first coefficient, max coefficients per k
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hw = lane >> 5;
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
     const int k = kt * 64 + lane;
-    for (int e = threadIdx.x; e < Nk; e += NT) {
-        s_k[e] = kk[e];
-        s_ih[e] = e + 1 < Nk ? 1.0 / (kk[e + 1] - kk[e]) : 0.0;
-    }
+    for (int e = threadIdx.x; e < Nk; e += NT) s_k[e] = kk[e];
     for (int e = threadIdx.x; e < nmu; e += NT) s_root[e] = ROOT[(size_t)w * nmu + e];
     if (threadIdx.x < 2) {
         s_red[threadIdx.x][0] = 0x7fffffff;
@@ -1863,15 +1881,16 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
     const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
     const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
     const int nslot = (up ? i_last - i_first : i_first - i_last) + 1;
-    const int ilo = min(i_first, i_last);
+    // B-spline coefficients this k touches: [jlow, jlow + nD), four per interval (tables.bspline_tables)
+    const int jlow = bspl_first(min(i_first, i_last), Nk), nD = live ? bspl_first(max(i_first, i_last), Nk) + 4 - jlow : 0;
     if (wave == 0) {
         if (live) {
-            I0[(size_t)w * KT * 64 + k] = ilo;
-            atomicMin(&s_red[hw][0], ilo);
-            atomicMax(&s_red[hw][1], ilo);
-            atomicMax(&s_red[hw][2], nslot + 1);
+            I0[(size_t)w * KT * 64 + k] = jlow;
+            atomicMin(&s_red[hw][0], jlow);
+            atomicMax(&s_red[hw][1], jlow);
+            atomicMax(&s_red[hw][2], nD);
         } else {
-            I0[(size_t)w * KT * 64 + k] = -1;  // resolved to the tile's lowest knot by the consumer
+            I0[(size_t)w * KT * 64 + k] = -1;  // resolved to the tile's lowest coefficient by the consumer
         }
     }
     __syncthreads();
@@ -1879,86 +1898,92 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
     const bool fallback = D > APW_DCAP || span > APW_WIN;  // (a tile with no k inside the grid: D = 0, never read)
     if ((threadIdx.x & 31) == 0 && wave == 0) META[(size_t)w * 2 * KT + 2 * kt + hw] = make_int4(jmin, span, D, fallback ? 1 : 0);
     if (fallback) return;  // (per half wave; no barrier below)
-    double* wt = W + ((size_t)w * 2 * KT + 2 * kt + hw) * APW_DCAP * NP * 2 * 32 + (lane & 31);  // + ((d * NL + l) * NL + lp) * 64 (+ 32 for the s weight)
-    double cy[PPW], cs[PPW];  // contribution to the knot shared with the next interval in mu order
+    double* wt = W + ((size_t)w * 2 * KT + 2 * kt + hw) * APW_DCAP * NP * 32 + (size_t)wave * 32 + (lane & 31);  // + (d NL + l) NL 32: pair (l' = wave, l)
+    // v[q][e]: the weights gathered so far for the four coefficients of the current interval (pair q = (l' = wave, l = q)); when the walk moves
+    // to the next interval the window slides by one coefficient and the one that leaves is final
+    double v[PPW][4];
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) cy[q] = cs[q] = 0.0;
-    int jb_prev = 0;
+    for (int q = 0; q < PPW; ++q) v[q][0] = v[q][1] = v[q][2] = v[q][3] = 0.0;
+    int Jc = 0, jb_prev = 0;
     for (int s = 0; s < (live ? nslot : 0); ++s) {
         const int i = i_first + s * dir;
         const double klo = s_k[i], khi = s_k[i + 1];
         const int ja = jb_prev;
         const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
         jb_prev = jb;
-        const double ih = s_ih[i], ih2 = ih * ih, ih3 = ih2 * ih;
         const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
         const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
         const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
         const char* psb = reinterpret_cast<const char*>(ps);  // wave-uniform base + 32-bit per-lane byte offsets (one address register, not two pointers)
         const unsigned oa = (unsigned)ja * NS * 8u, ob = (unsigned)jb * NS * 8u;
-        // knot written by this step: the one this interval does NOT share with the next interval in mu order
-        const int dk = up ? s : nslot - s;  // relative to ilo: rising k' leaves the left knot behind, falling k' the right one
+        // interval moments M_i[l'][l][p] of the nodes [ja, jb): the six prefix-sum gathers of the wave's three pairs go out together (one
+        // memory round trip per interval; pair by pair behind scheduling barriers the kernel took 78 instead of 31 us)
+        double m[PPW][4];
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
-            const int p = wave * NL + q;  // pair (l', l) = (p / NL, p % NL) = (wave, q), the order of the prefix sums
-            if (p < NP) {
-                double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
-                if (jb > ja) {
-                    const double4 b4 = *reinterpret_cast<const double4*>(psb + (ob + p * 32u)), a4 = *reinterpret_cast<const double4*>(psb + (oa + p * 32u));
-                    const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
-                    m0 = d0;
-                    m1 = fma(c10, d0, c11 * d1);
-                    m2 = fma(c20, d0, fma(c21, d1, c22 * d2));
-                    m3 = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
-                }
-                const double yL = m0 - 3.0 * m2 * ih2 + 2.0 * m3 * ih3, sL = m1 - 2.0 * m2 * ih + m3 * ih2;
-                const double yR = 3.0 * m2 * ih2 - 2.0 * m3 * ih3, sR = -m2 * ih + m3 * ih2;
-                const int lp = p / NL, l = p % NL;
-                double* o = wt + (size_t)((dk * NL + l) * NL + lp) * 64;
-                o[0] = cy[q] + (up ? yL : yR);
-                o[32] = cs[q] + (up ? sL : sR);
-                cy[q] = up ? yR : yL;
-                cs[q] = up ? sR : sL;
+            const int p = wave * NL + q;  // the order of the prefix sums
+            m[q][0] = m[q][1] = m[q][2] = m[q][3] = 0.0;
+            if (jb > ja) {
+                const double4 b4 = *reinterpret_cast<const double4*>(psb + (ob + p * 32u)), a4 = *reinterpret_cast<const double4*>(psb + (oa + p * 32u));
+                const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
+                m[q][0] = d0;
+                m[q][1] = fma(c10, d0, c11 * d1);
+                m[q][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
+                m[q][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
             }
         }
-    }
-    // the far knot of the last interval, then zeros up to the tile's knot count (lanes past the grid: zeros throughout)
-    const int nk = live ? nslot + 1 : 0;
+        const int Ji = bspl_first(i, Nk);
+        if (s > 0 && Ji != Jc) {  // the window slides (by one: the walk visits neighbouring intervals): the coefficient that leaves is final
+            const int dfin = (up ? Jc : Jc + 3) - jlow;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-        const int p = wave * NL + q;
-        if (p < NP) {
-            const int lp = p / NL, l = p % NL;
-            if (live) {
-                double* o = wt + (size_t)(((up ? nslot : 0) * NL + l) * NL + lp) * 64;
-                o[0] = cy[q];
-                o[32] = cs[q];
-            }
-            for (int d = nk; d < D; ++d) {
-                double* o = wt + (size_t)((d * NL + l) * NL + lp) * 64;
-                o[0] = 0.0;
-                o[32] = 0.0;
+            for (int q = 0; q < PPW; ++q) {
+                wt[(size_t)(dfin * NL + q) * NL * 32] = up ? v[q][0] : v[q][3];
+                if (up) {
+                    v[q][0] = v[q][1]; v[q][1] = v[q][2]; v[q][2] = v[q][3]; v[q][3] = 0.0;
+                } else {
+                    v[q][3] = v[q][2]; v[q][2] = v[q][1]; v[q][1] = v[q][0]; v[q][0] = 0.0;
+                }
             }
         }
+        Jc = Ji;
+        // coefficient e of the interval takes sum_p M[p] local[i][e][p]
+        const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double4 n4 = lc[e];
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) v[q][e] = fma(m[q][0], n4.x, fma(m[q][1], n4.y, fma(m[q][2], n4.z, fma(m[q][3], n4.w, v[q][e]))));
+        }
     }
+    // the last interval's four coefficients, then zeros up to the tile's count (lanes past the grid: zeros throughout)
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) wt[(size_t)((Jc + e - jlow) * NL + q) * NL * 32] = v[q][e];
+    }
+    for (int d = nD; d < D; ++d)
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) wt[(size_t)(d * NL + q) * NL * 32] = 0.0;
 }
 
 // Workgroup = (tile of 32 k, cosmology) x NL waves; wave <-> output multipole l; lane = (k in the tile, half): half 0 owns the template
-// rows [rlo, msplit), half 1 the rows [msplit, nr) (NH = the larger count, at most 12).  LDS: two planes winT / winS [l'][row][APW_WIN knots]
-// of the rows [rlo, nr) rounded up to pairs; wave l fills the series of l' = l with global_load_lds (16 B per lane: one instruction = 64 knots
-// of two consecutive rows; no registers, every load of the workgroup in flight at once).  Every lane then walks the tile's D knots once,
-// with the six weights of knot d + 1 in flight under the rows of knot d.  Rows outside [rlo, nr) are copied through.
+// rows [rlo, msplit), half 1 the rows [msplit, nr) (at most NH each).  LDS: the B-spline coefficients of every row in [rlo, nr) (rounded up to
+// pairs) and every l' on the tile's window of APW_WIN knots -- [l'][row][knot], filled by global_load_lds (16 B per lane: one instruction = 64
+// knots of two consecutive rows; no registers, every load of the workgroup in flight at once).  Every lane then walks the tile's D coefficients
+// once, with the NL weights of the next RING - 1 coefficients in flight.  Rows outside [rlo, nr) are copied through from T.
 // bias != null: the epilogue contracts P_l(k) = sum_row bias[row] out[l][row][k] as two FMA chains -- rows [0, msplit) in half 0, rows
 // [msplit, NROW) in half 1 -- added across the half waves: the order of reduce_kernel(msplit), bit for bit.
 template <int NL, int NH, int RING>
 __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int nr, int msplit, const double* __restrict__ DAw, const double* __restrict__ Hw,
                                                           const double* __restrict__ fid, const double* __restrict__ W,
                                                           const int* __restrict__ I0, const int4* __restrict__ META,
-                                                          const double* __restrict__ T, const double* __restrict__ S,
+                                                          const double* __restrict__ T, const double* __restrict__ C,
                                                           double* __restrict__ Tout, const double* __restrict__ bias, double* __restrict__ Plk,
                                                           double* __restrict__ PlkHost, int* __restrict__ nonfinite) {
     constexpr int NP = NL * NL;
-    extern __shared__ double sm[];
+    constexpr int nre = 2 * NH;  // window rows: [rlo, nr) rounded up to whole load instructions (host: nr - rlo <= nre, rlo + nre <= NROW)
+    __shared__ double win[NL * nre * APW_WIN];
     const int lane = threadIdx.x & 63, l = threadIdx.x >> 6, kl = lane & 31, half = lane >> 5;
     const int KT = (Nk + 63) / 64, KT2 = 2 * KT;
     int kt, w;
@@ -1970,55 +1995,42 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
     const bool live = k < Nk;
     const int i0 = I0[(size_t)w * KT * 64 + k];
     const int jmin = meta.x, D = meta.z;
-    constexpr int nre = 2 * NH;  // window rows: [rlo, nr) rounded up to whole load instructions (host: nr - rlo <= nre, rlo + nre <= NROW)
-    double* winT = sm;
-    double* winS = sm + (size_t)NL * nre * APW_WIN;
-    {   // wave l stages l' = l: rows rlo .. rlo + nre - 1, knots jmin .. jmin + 63 (clamped to the row's end: knots past the span carry no weight)
+    {   // wave l stages l' = l: rows rlo .. rlo + nre - 1, coefficients jmin .. jmin + 63 (clamped to the row's end: those past the span carry no weight)
         // (a pair that starts at the last knot of a row ends one element past it -- the next row, or the two spare elements every template-
-        // shaped buffer is allocated with; clamping to Nk - 2 instead would put knot Nk - 2 where knot Nk - 1 belongs)
-        const size_t base = (((size_t)w * NL + l) * NROW + rlo + half) * Nk + min(jmin + 2 * kl, Nk - 1);
-        const double* tsrc = T + base;
-        const double* ssrc = S + base;
-        double* td = winT + (size_t)l * nre * APW_WIN;
-        double* sd = winS + (size_t)l * nre * APW_WIN;
-        for (int r = 0; r < nre; r += 2) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tsrc + (size_t)r * Nk),
-                                             (__attribute__((address_space(3))) void*)(td + r * APW_WIN), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (size_t)r * Nk),
-                                             (__attribute__((address_space(3))) void*)(sd + r * APW_WIN), 16, 0, 0);
-        }
+        // shaped buffer is allocated with; clamping to Nk - 2 instead would put coefficient Nk - 2 where coefficient Nk - 1 belongs)
+        const double* src = C + (((size_t)w * NL + l) * NROW + rlo + half) * Nk + min(jmin + 2 * kl, Nk - 1);
+        double* dst = win + (size_t)l * nre * APW_WIN;
+#pragma unroll
+        for (int r = 0; r < nre; r += 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)r * Nk),
+                                             (__attribute__((address_space(3))) void*)(dst + r * APW_WIN), 16, 0, 0);
     }
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
     const double c = 2.0 / (qperp * qperp * qpar);
     const int q0 = half ? msplit : rlo, q1 = half ? nr : msplit, cnt = q1 - q0;  // this half's AP rows [q0, q1)
     const int o = max(i0 - jmin, 0);  // lanes past the grid (i0 = -1) carry zero weights
-    const double* wt = W + ((size_t)w * KT2 + kt) * APW_DCAP * NP * 2 * 32 + (size_t)l * NL * 64 + kl;
+    const double* wt = W + ((size_t)w * KT2 + kt) * APW_DCAP * NP * 32 + (size_t)l * NL * 32 + kl;
     double acc[NH];
 #pragma unroll
     for (int q = 0; q < NH; ++q) acc[q] = 0.0;
-    // the weights of the first RING knots are requested together with the window: a knot's six weights come from HBM (1-2 us), its rows
-    // take ~0.15 us, so with the next knot alone in flight (RING = 2) the workgroup waits for memory once per knot (measured 53 us per launch)
-    // (branch-free: a ring slot past the tile's last knot holds zeros and re-reads the last knot's rows -- with branches around the knots the
-    // compiler speculates every LDS read of a knot above its branch and the issue-order hints below no longer see them)
-    double wy[RING][NL], ws[RING][NL];
+    // (branch-free: a ring slot past the tile's last coefficient holds zeros and re-reads the last one's rows -- with branches around the steps the
+    // compiler speculates every LDS read of a step above its branch and the issue-order hints below no longer see them)
+    double wr[RING][NL];
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
-        const double* wn = wt + (size_t)min(u, D - 1) * NP * 64;
+        const double* wn = wt + (size_t)min(u, D - 1) * NP * 32;
         const bool on = u < D;
 #pragma unroll
         for (int lp = 0; lp < NL; ++lp) {
-            const double a = wn[lp * 64], b = wn[lp * 64 + 32];
-            wy[u][lp] = on ? a : 0.0;
-            ws[u][lp] = on ? b : 0.0;
+            const double a = wn[lp * 32];
+            wr[u][lp] = on ? a : 0.0;
         }
     }
     __syncthreads();  // (drains the loads above: vmcnt(0) in front of the barrier)
     if (cnt > 0) {
-        // row q of this half sits at window row q0 - rlo + q < nre (host: both halves hold at most NH rows, half 0 exactly NH or fewer): rows
-        // past the half's count read the rows behind it (loaded, in bounds) and their sums are dropped -- every address below is one base
-        // register per plane plus an immediate
-        const double* yT = winT + (size_t)(q0 - rlo) * APW_WIN + o;
-        const double* yS = winS + (size_t)(q0 - rlo) * APW_WIN + o;
+        // row q of this half sits at window row q0 - rlo + q < nre (host: both halves hold at most NH rows): rows past the half's count read the
+        // rows behind it (loaded, in bounds) and their sums are dropped -- every address below is one base register plus an immediate
+        const double* yC = win + (size_t)(q0 - rlo) * APW_WIN + o;
         for (int d0 = 0; d0 < D; d0 += RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) {
@@ -2026,32 +2038,28 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
 #pragma unroll
                 for (int lp = 0; lp < NL; ++lp)
 #pragma unroll
-                    for (int q = 0; q < NH; ++q)
-                        acc[q] = fma(wy[u][lp], yT[(lp * nre + q) * APW_WIN], fma(ws[u][lp], yS[(lp * nre + q) * APW_WIN], acc[q]));
-                const int step = d + 1 < D ? 1 : 0;
-                yT += step;
-                yS += step;
-                {   // this slot's next occupant: knot d + RING (zeros past the tile's last knot)
+                    for (int q = 0; q < NH; ++q) acc[q] = fma(wr[u][lp], yC[(lp * nre + q) * APW_WIN], acc[q]);
+                yC += d + 1 < D ? 1 : 0;
+                {   // this slot's next occupant: coefficient d + RING (zeros past the tile's last one)
                     const int dn = d + RING;
-                    const double* wn = wt + (size_t)min(dn, D - 1) * NP * 64;
+                    const double* wn = wt + (size_t)min(dn, D - 1) * NP * 32;
                     const bool on = dn < D;
 #pragma unroll
                     for (int lp = 0; lp < NL; ++lp) {
-                        const double a = wn[lp * 64], b = wn[lp * 64 + 32];
-                        wy[u][lp] = on ? a : 0.0;
-                        ws[u][lp] = on ? b : 0.0;
+                        const double a = wn[lp * 32];
+                        wr[u][lp] = on ? a : 0.0;
                     }
                 }
-                // issue order of this knot's NL * NH LDS reads (two rows each) and 2 NL NH FMAs: eight reads ahead, then one read per four
-                // FMAs -- left alone the scheduler puts every read of the knot in front of the first FMA: 130-230 registers
+                // issue order of this step's NL * NH LDS reads (one or two rows each) and FMAs: APR_AHEAD reads ahead, then one read per two
+                // FMAs -- left alone the scheduler puts every read of the step in front of the first FMA
                 constexpr int AHEAD = APR_AHEAD;
                 __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
-                for (int i = 0; i < NL * NH - AHEAD; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                for (int i = 0; i < (NL * NH) / 2 - AHEAD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x002, 4 * AHEAD + 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2 * AHEAD + 16, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -265,7 +265,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_L13: return D * c.Nl * 10;
         case EFTB_T_GRP: return sizeof(int32_t) * 38 * 2;
         case EFTB_T_BXT: return c.with_resum ? D * kpad(c.Nkin + c.nxtail) * 2 * NS : 0;
-        case EFTB_T_BYT: case EFTB_T_TXT: case EFTB_T_TYT: return 0;  // (folded into EFTB_T_BXT)
+        case EFTB_T_TYT: return 0;  // (unused id)
         case EFTB_T_LNXXTAIL: return c.with_resum ? D * c.nxtail : 0;
         case EFTB_T_WQLAST2: return c.with_resum ? D * 2 : 0;
         case EFTB_T_QPOLY: return c.with_resum ? D * 2 * c.Nl * c.Nl * Nn * 15 : 0;
@@ -275,6 +275,8 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_MU: case EFTB_T_WMU: return c.with_ap ? D * c.nmu : 0;
         case EFTB_T_LEGMU: return c.with_ap ? D * c.Nl * c.nmu : 0;
         case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
+        case EFTB_T_SPCBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
+        case EFTB_T_SPLOCAL: return c.with_ap ? D * (size_t)16 * c.Nk : 0;
         case EFTB_T_APFID: return c.with_ap ? D * 2 : 0;
         case EFTB_T_LCTN: return c.with_nnlo ? D * c.Nl * 6 : 0;
         case EFTB_T_BAO: return c.optiresum && c.with_resum ? D * (2 * NS + 4) : 0;
@@ -475,9 +477,9 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     if (!e->ap_fast) return;
     // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
     const dim3 wgrid(((c.Nk + 63) / 64) * B);  // flat: (k tile, cosmology) decoded XCD-aware in the kernel
-    const size_t wlds = ((size_t)2 * c.Nk + c.nmu + (c.nmu & 1)) * sizeof(double);
+    const size_t wlds = ((size_t)c.Nk + c.nmu) * sizeof(double);
 #define APW_ARGS c.Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, \
-                 e->APW, e->API, e->APM
+                 tb<double>(e, EFTB_T_SPLOCAL), e->APW, e->API, e->APM
     if (c.Nl == 3) hipLaunchKernelGGL((ap_weights_kernel<3>), wgrid, dim3(192), wlds, st, APW_ARGS);
     else hipLaunchKernelGGL((ap_weights_kernel<2>), wgrid, dim3(128), wlds, st, APW_ARGS);
 #undef APW_ARGS
@@ -832,7 +834,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int kt = (Nk + 63) / 64;
                 int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
                 if (ysplit >= 8) ysplit &= ~7;  // shares in multiples of 8: the k tiles of a share then sit on one XCD (xcd_decode)
-                hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, EFTB_T_SPBAND), e->SD);
+                // (the fast path keeps the splines as B-spline coefficients -- one number per knot; the moment / quadrature forms as knot slopes)
+                hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, e->ap_mode == 0 ? EFTB_T_SPCBAND : EFTB_T_SPBAND), e->SD);
             }
             // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
             const int nr = nn ? (moments ? 21 : 6) : (c.ap_stochastic ? NROW : 21);
@@ -864,7 +867,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             if (e->ap_fast) {
                 // banded product of the knot weights with the spline data; rows outside [rlo, nr) are copied through
                 const int kt2 = 2 * ((Nk + 63) / 64), nh = (nr - rlo + 1) / 2, nre = 2 * nh;
-                const size_t lds = (size_t)2 * Nl * nre * APW_WIN * sizeof(double);
+                const size_t lds = 0;  // (the window is a static array: 37 KB at most)
                 if (rlo + nre > NROW || msplit - rlo > nh || nr - msplit > nh || (nh != 2 && nh != 11 && nh != 12))
                     return fail("eftb_run: AP rows [%d, %d) split at %d do not fit the window layouts built into ap_rows_kernel", rlo, nr, msplit);
 #define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt, rb, rp, rph, rflag
@@ -884,9 +887,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int4* gate = e->ap_fast ? e->APM : nullptr;
                 const dim3 dgrid(((Nk + 63) / 64) * B);
 #define APD_ARGS Nk, c.nmu, rlo, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
-                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate, rb, rp, rph, msplit, rflag
-                if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3>), dgrid, dim3(64), 0, st, APD_ARGS);
-                else hipLaunchKernelGGL((ap_direct_kernel<2>), dgrid, dim3(64), 0, st, APD_ARGS);
+                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate, rb, rp, rph, msplit, rflag, tb<double>(e, EFTB_T_SPLOCAL)
+                if (e->ap_fast && Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3, true>), dgrid, dim3(64), 0, st, APD_ARGS);
+                else if (e->ap_fast) hipLaunchKernelGGL((ap_direct_kernel<2, true>), dgrid, dim3(64), 0, st, APD_ARGS);
+                else if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3, false>), dgrid, dim3(64), 0, st, APD_ARGS);
+                else hipLaunchKernelGGL((ap_direct_kernel<2, false>), dgrid, dim3(64), 0, st, APD_ARGS);
 #undef APD_ARGS
             }
             std::swap(*pin, *palt);
@@ -1156,7 +1161,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         HIPCHK(hipMalloc(&e->APR2, (size_t)c.max_batch * c.nmu * sizeof(double)));
         const size_t kt = (c.Nk + 63) / 64;
         for (int q = 0; q < 2; ++q) {
-            HIPCHK(hipMalloc(q ? &e->APW2 : &e->APW, (size_t)c.max_batch * kt * APW_DCAP * c.Nl * c.Nl * 2 * 64 * sizeof(double)));
+            HIPCHK(hipMalloc(q ? &e->APW2 : &e->APW, (size_t)c.max_batch * kt * APW_DCAP * c.Nl * c.Nl * 64 * sizeof(double)));
             HIPCHK(hipMalloc(q ? &e->API2 : &e->API, (size_t)c.max_batch * kt * 64 * sizeof(int)));
             HIPCHK(hipMalloc(q ? &e->APM2 : &e->APM, (size_t)c.max_batch * 2 * kt * sizeof(int4)));  // one window record per tile of 32 k
         }
@@ -1237,13 +1242,6 @@ int eftb_finalize(eftb_engine* e) {
             if (const char* f = getenv("EFTB_AP_MODE")) e->ap_mode = atoi(f);
             if (!e->ap_fast) e->ap_mode = 2;
             e->ap_fast = e->ap_mode == 0;
-            // ap_rows_kernel keeps the (y, s) window of every template row of a 32-k tile in LDS: 66-72 KB per workgroup (two per CU), above
-            // the 64 KB a kernel gets without asking
-            const int lds_max = 2 * 3 * NROW * APW_WIN * (int)sizeof(double);
-#define APR_LDS(NLV, NHV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_rows_kernel<NLV, NHV, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); \
-                          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_rows_kernel<NLV, NHV, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max))
-            APR_LDS(3, 11); APR_LDS(3, 12); APR_LDS(3, 2); APR_LDS(2, 11); APR_LDS(2, 12); APR_LDS(2, 2);
-#undef APR_LDS
 #define APM_LDS(NLV, NRV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_moments_kernel<NLV, NRV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
             APM_LDS(3, 21); APM_LDS(3, NROW); APM_LDS(2, 21); APM_LDS(2, NROW);
 #undef APM_LDS

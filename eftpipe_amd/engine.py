@@ -124,6 +124,8 @@ class Engine:
             self._set("WMU", t["wmu"])
             self._set("LEGMU", t["legmu"])
             self._set("SPBAND", t["sp_band"])
+            self._set("SPCBAND", t["sp_cband"])
+            self._set("SPLOCAL", t["sp_local"])
             self._set("APFID", t["ap_fid"])
 
     def set_ap_fiducial(self, DA, H):

@@ -203,6 +203,45 @@ def spline_derivative_band(x):
     return band
 
 
+def bspline_tables(x):
+    """The same not-a-knot cubic spline in B-spline form (round 3: ONE number per knot instead of the Hermite pair -- the AP kernels move and
+    keep half the bytes).  ``cband[d, i]``: coefficient c_i = sum_d cband[d, i] y[i + d - SPL_HB] (the inverse collocation matrix: same decay
+    as the slope operator, same band).  ``local[i, e, p]``: on the interval [x_i, x_i+1] (end pieces extrapolate) the spline is
+    sum_e c[J_i + e] sum_p local[i, e, p] (x - x_i)^p with J_i = clip(i - 1, 0, n - 4): not-a-knot removes x_1 and x_n-2 as break points, so
+    the first two and the last two intervals share a piece (scipy make_interp_spline: t = [x_0]*4 + x[2:-2] + [x_n-1]*4)."""
+    from scipy.interpolate import BSpline, make_interp_spline
+
+    x = np.asarray(x, dtype=float)
+    n = x.size
+    if n < 6:
+        raise ValueError("the B-spline form of the AP stage needs at least six k points")
+    spl = make_interp_spline(x, np.eye(n), k=3)          # coefficients [n, n]: column j = response to y = e_j
+    C = np.asarray(spl.c)                                 # c = C @ y
+    t = spl.t
+    cband = np.zeros((2 * SPL_HB + 1, n))
+    for d in range(2 * SPL_HB + 1):
+        j = np.arange(n) + d - SPL_HB
+        ok = (j >= 0) & (j < n)
+        cband[d, ok] = C[np.arange(n)[ok], j[ok]]
+    J = np.clip(np.arange(n) - 1, 0, n - 4)
+    local = np.zeros((n, 4, 4))
+    fact = (1.0, 1.0, 2.0, 6.0)
+    for i in range(n - 1):
+        xm = 0.5 * (x[i] + x[i + 1])                     # a point inside the interval: Taylor coefficients about x_i from there (exact for a cubic)
+        for e in range(4):
+            b = BSpline.basis_element(t[J[i] + e : J[i] + e + 5], extrapolate=True)
+            d = [float(b(xm, nu)) for nu in range(4)]    # value and derivatives at xm
+            h = x[i] - xm
+            # shift the expansion point from xm to x_i
+            a3 = d[3] / 6.0
+            a2 = d[2] / 2.0 + 3.0 * a3 * h
+            a1 = d[1] + d[2] * h + 3.0 * a3 * h * h
+            a0 = d[0] + d[1] * h + d[2] / 2.0 * h * h + a3 * h**3
+            local[i, e] = (a0, a1, a2, a3)
+    local[n - 1] = local[n - 2]                           # (never addressed: the last interval is n - 2)
+    return cband, local, J
+
+
 def spline_matrix(x, xe):
     """Dense operator of the same spline, end pieces extrapolated (interp1d 'extrapolate')."""
     return CubicSpline(x, np.eye(len(x)), axis=0, extrapolate=True)(xe)
@@ -425,6 +464,7 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
         t["mu"], t["wmu"] = mu, wmu
         t["legmu"] = np.ascontiguousarray(((2 * ells + 1) / 2.0)[:, None] * legendre_table(Nl, mu))
         t["sp_band"] = spline_derivative_band(k)
+        t["sp_cband"], t["sp_local"], _ = bspline_tables(k)
         t["ap_fid"] = np.array([cfg.DA_AP, cfg.H_AP], dtype=np.float64)
     return t
 

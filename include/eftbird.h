@@ -55,13 +55,14 @@ typedef struct eftb_config {
  *   EFTB_T_GCT [KP(Nkin + ntail)][2 * 129]      FFTLog coefficients (re | im halves) = [Pin | tail] . GCT   (fftlog.py:84-166)
  *   EFTB_T_ECT [2 * 129][KP(Nkin + ntail)]      = GCT transposed: the same product with the batch as the column dimension
  *   EFTB_T_BXT [KP(Nkin + nxtail)][2 * 80]      IR filters X | Y = [Pin | tail'] . BXT                 (pybird.py:1316-1353)
- * (EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT are unused ids kept for numbering.) */
+ *   EFTB_T_SPCBAND [65][Nk], EFTB_T_SPLOCAL [Nk][4][4]   the AP splines in B-spline form: coefficient operator and per-interval pieces (tables.bspline_tables)
+ * (EFTB_T_TYT is an unused id kept for numbering.) */
 enum eftb_table {
     EFTB_T_K = 0, EFTB_T_S, EFTB_T_LNKIN, EFTB_T_SKT, EFTB_T_GCT, EFTB_T_ECT, EFTB_T_LNXTAIL,
     /* one-loop pieces in anti-diagonal form (tables.py antidiagonal_tables, synthesis_table) */
     EFTB_T_AD, EFTB_T_EXP22, EFTB_T_EXPC, EFTB_T_MLJ, EFTB_T_LINVEC, EFTB_T_SYNK, EFTB_T_SYNS, EFTB_T_LINK, EFTB_T_LINS,
     EFTB_T_L11, EFTB_T_LCT, EFTB_T_L22, EFTB_T_L13, EFTB_T_GRP,
-    EFTB_T_BXT, EFTB_T_BYT, EFTB_T_TXT, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
+    EFTB_T_BXT, EFTB_T_SPCBAND, EFTB_T_SPLOCAL, EFTB_T_TYT, EFTB_T_LNXXTAIL, EFTB_T_WQLAST2, EFTB_T_QPOLY, EFTB_T_H,
     EFTB_T_RSBASIS, EFTB_T_RSBASISS, EFTB_T_RSROWS,   /* matrix-core IR-resummation (Nl = 3): tables.py resum_mfma_tables */
     EFTB_T_MU, EFTB_T_WMU, EFTB_T_LEGMU, EFTB_T_SPBAND, EFTB_T_APFID,
     EFTB_T_LCTN,      /* with_nnlo: Common.lctNNLO [Nl][3] zero padded to [Nl][6]     pybird.py:575 */

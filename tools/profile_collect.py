@@ -37,7 +37,11 @@ for n in ("bench.json", "bench_under_rocprof.json"):
     shutil.copy(os.path.join(src, n), os.path.join(dst, f"{tag}_{n}"))
 shutil.copy(find("stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 import subprocess
-tl = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), find("stats_kernel_trace.csv"), "9"], capture_output=True, text=True).stdout
+# a step in the middle of the TIMED region of the traced run: its warm-up ran `warmup_steps_run` steps before it (bench.py's own count)
+import json as _json
+_traced = _json.loads([ln for ln in open(os.path.join(src, "bench_under_rocprof.json")) if ln.startswith("{")][0])
+_idx = int(_traced.get("warmup_steps_run", _traced.get("warmup", 3))) + _traced.get("steps", 20) // 2
+tl = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), find("stats_kernel_trace.csv"), str(_idx)], capture_output=True, text=True).stdout
 open(os.path.join(dst, f"{tag}_overlap_timeline.txt"), "w").write(
     "One steady-state step of the pipelined loop (rocprofv3 --kernel-trace of bench.py; q = HSA queue: main / side / look-ahead / back / copy).\n" + tl)
 
