@@ -126,3 +126,32 @@ def test_surface_options_select_operator_tables(golden):
     st = E.resum(t, f, g["Pin2"], st)
     for n in ("P11l", "Pctl", "Ploopl"):
         assert relerr(st[n], g["kin2_resum_" + n]) < 1e-9, n
+
+
+def test_bspline_tables_reproduce_the_not_a_knot_spline():
+    """The AP stage's spline data in B-spline form (round 3; tables.bspline_tables): the banded coefficient operator (what spline_kernel applies
+    on the fast path) and the per-interval pieces (what ap_weights_kernel / ap_direct_kernel combine the interval moments / basis values with)
+    together reproduce scipy's not-a-knot CubicSpline, inside the grid and on the extrapolated end pieces (reference pybird.py:1581-1621 uses
+    interp1d(kind="cubic", fill_value="extrapolate"))."""
+    from scipy.interpolate import CubicSpline
+
+    from eftpipe_amd.loopmath import native_k
+    from eftpipe_amd.tables import SPL_HB, bspline_tables
+
+    for k in (synth.survey_kgrid(512), np.array(native_k()), synth.survey_kgrid(2048)):
+        cband, local, J = bspline_tables(k)
+        n = k.size
+        assert cband.shape == (2 * SPL_HB + 1, n) and local.shape == (n, 4, 4) and np.array_equal(J, np.clip(np.arange(n) - 1, 0, n - 4))
+        rng = np.random.default_rng(3)
+        y = rng.normal(size=n).cumsum()
+        c = np.zeros(n)
+        for d in range(2 * SPL_HB + 1):
+            j = np.arange(n) + d - SPL_HB
+            ok = (j >= 0) & (j < n)
+            c[ok] += cband[d, ok] * y[j[ok]]
+        cs = CubicSpline(k, y)
+        xe = np.concatenate([[0.5 * k[0]], rng.uniform(k[0], k[-1], 3000), k, [1.03 * k[-1]]])
+        i = np.clip(np.searchsorted(k, xe, "right") - 1, 0, n - 2)
+        t = xe - k[i]
+        val = sum(c[J[i] + e] * (local[i, e, 0] + t * (local[i, e, 1] + t * (local[i, e, 2] + t * local[i, e, 3]))) for e in range(4))
+        assert np.max(np.abs(val - cs(xe))) < 1e-12 * np.max(np.abs(cs(xe))), n
