@@ -205,13 +205,13 @@ __global__ __launch_bounds__(256) void antidiag_kernel(int B, int Bmax, const do
 //   blockIdx.y = 1: the Nl*nc weighted rows Ml[l] S_c (ACF[w][BASC][KSYN]) and the nlc Nl C11 / Cct (/ CctNNLO) rows (ALC[w][nlc Nl][KLIN])
 // as real synthesis coefficients (Re Z_0, Re Z_1, Im Z_1, ...).  `sets` bit 0/1: quadratic rows of y = 0/1, bit 2/3: linear rows.
 template <int NC>
-__global__ __launch_bounds__(320) void build_rows_kernel(int sets, int Bmax, int Nl, int nlc, int nb, const double* __restrict__ coef,
+__global__ __launch_bounds__(64) void build_rows_kernel(int sets, int Bmax, int Nl, int nlc, int nb, const double* __restrict__ coef,
                                                          const double2* __restrict__ S, const double2* __restrict__ mlj,
                                                          const double2* __restrict__ linvec, double* __restrict__ A22,
                                                          double* __restrict__ A13, double* __restrict__ ACF, double* __restrict__ ALC) {
-    // (320 threads for the 257 harmonics: with 256 and a second trip for j' = 256 the kernel measured 13.9 instead of 10.4 us alone and no
-    // better beside the resummation)
-    const int w = blockIdx.x, cf = blockIdx.y, jp = threadIdx.x;
+    // five single-wave workgroups per (cosmology, half) for the 257 harmonics (round 3: as ONE workgroup of 320 threads the kernel took 58 us
+    // beside the resummation against 9 alone -- five waves need two free wave slots on one SIMD, which two resummation waves never leave)
+    const int w = blockIdx.x, cf = blockIdx.y, jp = blockIdx.z * 64 + threadIdx.x;
     if (((sets >> cf) & 1) && jp < NPOW) {
         double zr[NC], zi[NC];
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(320) void build_rows_kernel(int sets, int Bmax, int
         const int nrows = cf == 0 ? 10 : nlc * Nl, v0 = cf == 0 ? 0 : 10;  // nlc = 2 (C11, Cct) or 3 (+ CctNNLO)
         double* out = cf == 0 ? A13 + (size_t)w * 10 * KLIN : ALC + (size_t)w * nlc * Nl * KLIN;
         const double* c = coef + (size_t)w * 2 * NCH;
-        for (int e = threadIdx.x; e < nrows * NCH; e += blockDim.x) {
+        for (int e = jp; e < nrows * NCH; e += 320) {
             const int row = e / NCH, mp = e % NCH, n = NHALF - mp;  // harmonic mp <-> coefficient n = 128 - mp
             const double2 v = linvec[(size_t)(v0 + row) * NCH + n];
             const double cr = c[n], ci = n == NHALF ? 0.0 : c[NCH + n];

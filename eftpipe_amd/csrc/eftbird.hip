@@ -67,7 +67,8 @@ struct eftb_engine {
     hipEvent_t evT0[NTIMER] = {}, evT1[NTIMER] = {};
     bool timer_busy[NTIMER] = {};
     unsigned timer_next = 0;
-    int time_dominant = 0;
+    int time_dominant = 0;          // 0 off; n: every n-th resummation launch is bracketed
+    unsigned long long time_seq = 0;
     double timer_ms = 0.0;
     long long timer_n = 0;
     double *APP = nullptr, *APR = nullptr, *APP2 = nullptr, *APR2 = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
@@ -351,16 +352,16 @@ static int launch_gemm_direct(hipStream_t st, SynthBatch sb) {
 static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets, const double* coef, const double* coefT) {
     const eftb_config& c = e->c;
     const int nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
-    const dim3 grid(NPOW, (B + 63) / 64), rgrid(B, 2);  // antidiag: one workgroup of four waves per (j', 64 cosmologies)
+    const dim3 grid(NPOW, (B + 63) / 64), rgrid(B, 2, 5);  // antidiag: one workgroup of four waves per (j', 64 cosmologies); build_rows: 5 x 64 lanes per (cosmology, half)
 #define AD_ARGS B, c.max_batch, coefT, tb<double2>(e, EFTB_T_AD), e->SAD
 #define ROW_ARGS sets, c.max_batch, c.Nl, c.with_nnlo ? 3 : 2, c.nbasis, coef, e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
                  e->ACF, e->ALC
     if (nc == 9) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9>), grid, dim3(256), 0, st, AD_ARGS);
-        hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(320), 0, st, ROW_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(64), 0, st, ROW_ARGS);
     } else if (nc == 7) {
         if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<7>), grid, dim3(256), 0, st, AD_ARGS);
-        hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(320), 0, st, ROW_ARGS);
+        hipLaunchKernelGGL((build_rows_kernel<7>), rgrid, dim3(64), 0, st, ROW_ARGS);
     } else {
         return fail("loop-matrix basis of dimension %d + %d is not instantiated (expected 7 + 2)", c.nbasis, c.with_resum ? c.nbasis13 : 0);
     }
@@ -679,8 +680,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // every synthesis of the requested pieces in one launch, then both expansions in one launch
         SynthBatch sb{};
         const bool k22 = mask & (EFTB_S_LOOPS | EFTB_K_P22), c22 = mask & (EFTB_S_CF | EFTB_K_C22);
-        if (k22) queue_synth(sb, e->A22, 0, 1, B * BAS22, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, e->Y22, 0, nullptr, nullptr);
-        if (c22) queue_synth(sb, e->ACF, 0, 1, B * BASC, KSYN, tb<double>(e, EFTB_T_SYNS), NS, e->YCF, 0, nullptr, nullptr);
+        // (only the rows in use: 7 of the 8 padded basis rows per cosmology, Nl (7 + 2) = 27 of the 32 weighted ones -- 10 % of the launch's
+        // matrix-core work was padding; the padded rows of Y22 / YCF stay at their initial zeros and meet zero columns in expand_kernel)
+        const int ncf = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
+        if (k22) queue_synth(sb, e->A22, (long long)BAS22 * KSYN, B, c.nbasis, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, e->Y22, (long long)BAS22 * Nk, nullptr, nullptr);
+        if (c22) queue_synth(sb, e->ACF, (long long)BASC * KSYN, B, Nl * ncf, KSYN, tb<double>(e, EFTB_T_SYNS), NS, e->YCF, (long long)BASC * NS, nullptr, nullptr);
         if (mask & EFTB_S_LOOPS)
             queue_synth(sb, e->A13, 10LL * KLIN, B, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], 10LL * Nk, b[EFTB_B_P11], nullptr);
         if (mask & EFTB_S_CF) {
@@ -773,7 +777,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 st = st_main;
             }
             int tslot = -1;
-            if (e->time_dominant && full && e->evT0[0] && !e->use_graphs) {  // (not under graph replay: the event records would be captured)
+            if (e->time_dominant && full && e->evT0[0] && !e->use_graphs && (e->time_seq++ % (unsigned)e->time_dominant) == 0) {  // (not under graph replay: the event records would be captured)
                 tslot = (int)(e->timer_next++ % eftb_engine::NTIMER);
                 collect_timer(e, tslot, false);
                 if (!e->timer_busy[tslot] && hipEventRecord(e->evT0[tslot], st) != hipSuccess) return fail("eftb_run: event record failed");
@@ -1359,7 +1363,7 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_JEFFREYS: e->jeffreys = value ? 1 : 0; return 0;
         case EFTB_O_GRAPH: e->use_graphs = value != 0; return 0;
         case EFTB_O_CHECK_FINITE: e->check_finite = value != 0; return 0;
-        case EFTB_O_TIME_DOMINANT: e->time_dominant = value != 0; return 0;
+        case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seq = 0; return 0;
     }
     return fail("eftb_set_option: unknown option %d", option);
 }

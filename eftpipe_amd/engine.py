@@ -140,9 +140,10 @@ class Engine:
         """The REDUCE stage flags non-finite P_l(k); the next synchronising call raises, naming the cosmology (off by default)."""
         L.check(self.lib.eftb_set_option(self._h, 3, int(bool(flag))))
 
-    def time_dominant(self, flag):
-        """Bracket every resummation launch with HIP events on its own stream (measurement only; see dominant_time)."""
-        L.check(self.lib.eftb_set_option(self._h, 4, int(bool(flag))))
+    def time_dominant(self, every):
+        """Bracket every `every`-th resummation launch with HIP events on its own stream (0 / False: off; True: every launch; measurement only,
+        see dominant_time)."""
+        L.check(self.lib.eftb_set_option(self._h, 4, int(every)))
 
     def dominant_time(self, reset=True):
         """(sum of the bracketed durations [ms], launches) since the last reset; waits for launches in flight."""

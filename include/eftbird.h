@@ -140,8 +140,9 @@ enum eftb_option {
                                  step; for busy hosts (no reference counterpart; off by default, also EFTB_GRAPH=1) */
     EFTB_O_CHECK_FINITE = 3,  /* the REDUCE stage flags non-finite P_l(k): the next synchronising call (eftb_sync, eftb_get, eftb_eval_*,
                                  eftb_fetch_*) then returns non-zero naming the cosmology (off by default) */
-    EFTB_O_TIME_DOMINANT = 4  /* bracket every launch of the resummation kernel with HIP events on the stream it runs on (measurement
-                                 only: bench.py's roofline; read with eftb_dominant_time; inactive while EFTB_O_GRAPH replays captured runs) */
+    EFTB_O_TIME_DOMINANT = 4  /* value n > 0: bracket every n-th launch of the resummation kernel with HIP events on the stream it runs on
+                                 (measurement only: bench.py's roofline; read with eftb_dominant_time; inactive while EFTB_O_GRAPH replays
+                                 captured runs).  The two event packets cost the pipelined loop about 1.5 % when every launch carries them. */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 /* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for

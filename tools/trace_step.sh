@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 OUT=$1; IDX=${2:-9}
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- python3 bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/err.log || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- python3 bench.py --steps ${STEPS:-16} --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/err.log || exit 1
 f=$(ls $OUT/*kernel_trace.csv $OUT/*/*kernel_trace.csv 2>/dev/null | head -1)
 python3 tools/timeline.py $f $IDX > $OUT/step.txt
 python3 - $f $OUT/compact.csv <<'PY'
