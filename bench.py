@@ -306,7 +306,7 @@ def main():
             # (2b) the batch size is a throughput knob: the same pipelined loop (new inputs staged and P_l fetched every step) at 256 per step
             if world == 1 and not force_comm and B == 128:
                 try:
-                    B2, n2 = 256, 12
+                    B2, n2 = 256, 20
                     eng2 = Engine(cfg, max_batch=B2, device=device)
                     sets2 = [draw_set(1000 + i, B2) for i in range(n2 + 3)]
                     out2 = np.empty((B2, NL, NK))
@@ -370,7 +370,7 @@ def main():
         except Exception:
             measured_peak = None
         traffic, traffic_src = None, None
-        for name in ("r02_pmc_dominant.json", "r01_pmc_dominant.json"):
+        for name in ("r03_pmc_dominant.json", "r02_pmc_dominant.json", "r01_pmc_dominant.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 with open(pmc) as fh:

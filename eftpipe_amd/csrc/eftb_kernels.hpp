@@ -364,11 +364,11 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
         }
 }
 
-// The same product for problems with FEW rows (the first stage: M = batch, a few hundred columns, K <= 288): one wave = one tile of 16 rows x 32
-// columns, operands straight from global memory into the MFMA lanes -- no LDS, no barriers, a 64-thread workgroup of ~70 registers that
-// starts in any free wave slot.  synth_kernel's 32 x 64 tiles give such a problem 20-50 workgroups, each walking K in 24-deep chunks behind
-// two barriers and a global -> register -> LDS hop per chunk: 35 us alone and 90 us beside the resummation for 0.08 GFLOP (round-3 trace:
-// the look-ahead chain is the critical path of a step, and this was its longest link).
+// The same product for problems with FEW rows (the first stage: M = batch, a few hundred columns, K <= 288): one workgroup = one tile of 16 rows
+// x 32 columns, operands straight from global memory into the MFMA lanes -- no LDS staging, no barrier in the K loop, ~96 registers per lane.
+// synth_kernel's 32 x 64 tiles give such a problem 20-50 workgroups, each walking K in 24-deep chunks behind two barriers and a global ->
+// register -> LDS hop per chunk: 35 us alone and 90 us beside the resummation for 0.08 GFLOP (round-3 trace: the look-ahead chain is the
+// critical path of a step, and this was its longest link).
 // K runs in groups of 16: lane (r = lane & 15, g = lane >> 4) holds A[row r][16 u + 4 g + j] (one 32-byte load) and multiplies it, for
 // j = 0..3, with Tab[16 u + 4 g + j][x0 + 2 r + {0, 1}] (one 16-byte load): the k order inside an MFMA is a permutation of the usual one, the
 // same on both operands.  Column tile t holds x0 + 2 r + t, so a lane stores pairs of neighbouring columns.  K is a multiple of 16 (SYN_KPAD).
@@ -1899,11 +1899,13 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
     if ((threadIdx.x & 31) == 0 && wave == 0) META[(size_t)w * 2 * KT + 2 * kt + hw] = make_int4(jmin, span, D, fallback ? 1 : 0);
     if (fallback) return;  // (per half wave; no barrier below)
     double* wt = W + ((size_t)w * 2 * KT + 2 * kt + hw) * APW_DCAP * NP * 32 + (size_t)wave * 32 + (lane & 31);  // + (d NL + l) NL 32: pair (l' = wave, l)
-    // v[q][e]: the weights gathered so far for the four coefficients of the current interval (pair q = (l' = wave, l = q)); when the walk moves
-    // to the next interval the window slides by one coefficient and the one that leaves is final
-    double v[PPW][4];
+    // vw[q][e][lane] (LDS, this wave's own): the weights gathered so far for the four coefficients of the current interval (pair q = (l' = wave,
+    // l = q)); when the walk moves to the next interval the window slides by one coefficient and the one that leaves is final.  In LDS rather
+    // than in 24 registers, and the pairs in a rolled loop: the kernel has to fit beside two resummation waves on a SIMD (96 registers; with the
+    // window in registers and the three pairs' gathers in flight together it needed 136)
+    double* vw = sm + Nk + nmu + (size_t)wave * PPW * 4 * 64 + lane;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) v[q][0] = v[q][1] = v[q][2] = v[q][3] = 0.0;
+    for (int i = 0; i < PPW * 4; ++i) vw[i * 64] = 0.0;
     int Jc = 0, jb_prev = 0;
     for (int s = 0; s < (live ? nslot : 0); ++s) {
         const int i = i_first + s * dir;
@@ -1911,48 +1913,41 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
         const int ja = jb_prev;
         const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
         jb_prev = jb;
-        const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
-        const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
-        const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
-        const char* psb = reinterpret_cast<const char*>(ps);  // wave-uniform base + 32-bit per-lane byte offsets (one address register, not two pointers)
-        const unsigned oa = (unsigned)ja * NS * 8u, ob = (unsigned)jb * NS * 8u;
-        // interval moments M_i[l'][l][p] of the nodes [ja, jb): the six prefix-sum gathers of the wave's three pairs go out together (one
-        // memory round trip per interval; pair by pair behind scheduling barriers the kernel took 78 instead of 31 us)
-        double m[PPW][4];
-#pragma unroll
-        for (int q = 0; q < PPW; ++q) {
-            const int p = wave * NL + q;  // the order of the prefix sums
-            m[q][0] = m[q][1] = m[q][2] = m[q][3] = 0.0;
-            if (jb > ja) {
-                const double4 b4 = *reinterpret_cast<const double4*>(psb + (ob + p * 32u)), a4 = *reinterpret_cast<const double4*>(psb + (oa + p * 32u));
-                const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
-                m[q][0] = d0;
-                m[q][1] = fma(c10, d0, c11 * d1);
-                m[q][2] = fma(c20, d0, fma(c21, d1, c22 * d2));
-                m[q][3] = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
-            }
-        }
         const int Ji = bspl_first(i, Nk);
         if (s > 0 && Ji != Jc) {  // the window slides (by one: the walk visits neighbouring intervals): the coefficient that leaves is final
             const int dfin = (up ? Jc : Jc + 3) - jlow;
 #pragma unroll
             for (int q = 0; q < PPW; ++q) {
-                wt[(size_t)(dfin * NL + q) * NL * 32] = up ? v[q][0] : v[q][3];
-                if (up) {
-                    v[q][0] = v[q][1]; v[q][1] = v[q][2]; v[q][2] = v[q][3]; v[q][3] = 0.0;
-                } else {
-                    v[q][3] = v[q][2]; v[q][2] = v[q][1]; v[q][1] = v[q][0]; v[q][0] = 0.0;
-                }
+                double* vq = vw + q * 4 * 64;
+                const double v0 = vq[0], v1 = vq[64], v2 = vq[128], v3 = vq[192];
+                wt[(size_t)(dfin * NL + q) * NL * 32] = up ? v0 : v3;
+                vq[0] = up ? v1 : 0.0;
+                vq[64] = up ? v2 : v0;
+                vq[128] = up ? v3 : v1;
+                vq[192] = up ? 0.0 : v2;
             }
         }
         Jc = Ji;
-        // coefficient e of the interval takes sum_p M[p] local[i][e][p]
-        const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+        if (jb > ja) {
+            const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
+            const char* psb = reinterpret_cast<const char*>(ps);  // wave-uniform base + 32-bit per-lane byte offsets (one address register, not two pointers)
+            const unsigned oa = (unsigned)ja * NS * 8u, ob = (unsigned)jb * NS * 8u;
+            const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+            // pair by pair: interval moments M_i[l'][l][p] of the nodes [ja, jb), then coefficient e of the interval takes sum_p M[p] local[i][e][p]
+#pragma unroll 1
+            for (int q = 0; q < PPW; ++q) {
+                const unsigned p32 = (unsigned)(wave * NL + q) * 32u;  // the order of the prefix sums
+                const double4 b4 = *reinterpret_cast<const double4*>(psb + (ob + p32)), a4 = *reinterpret_cast<const double4*>(psb + (oa + p32));
+                const double d0 = b4.x - a4.x, d1 = b4.y - a4.y, d2 = b4.z - a4.z, d3 = b4.w - a4.w;
+                const double m0 = d0, m1 = fma(dl, d0, kq * d1), m2 = fma(dl2, d0, fma(2.0 * kq * dl, d1, a2 * d2));
+                const double m3 = fma(dl2 * dl, d0, fma(3.0 * kq * dl2, d1, fma(3.0 * a2 * dl, d2, a2 * kq * d3)));
+                double* vq = vw + q * 4 * 64;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double4 n4 = lc[e];
-#pragma unroll
-            for (int q = 0; q < PPW; ++q) v[q][e] = fma(m[q][0], n4.x, fma(m[q][1], n4.y, fma(m[q][2], n4.z, fma(m[q][3], n4.w, v[q][e]))));
+                for (int e = 0; e < 4; ++e) {
+                    const double4 n4 = lc[e];
+                    vq[e * 64] = fma(m0, n4.x, fma(m1, n4.y, fma(m2, n4.z, fma(m3, n4.w, vq[e * 64]))));
+                }
+            }
         }
     }
     // the last interval's four coefficients, then zeros up to the tile's count (lanes past the grid: zeros throughout)
@@ -1960,7 +1955,7 @@ __global__ __launch_bounds__(64 * NL) void ap_weights_kernel(int Nk, int nmu, co
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int q = 0; q < PPW; ++q) wt[(size_t)((Jc + e - jlow) * NL + q) * NL * 32] = v[q][e];
+            for (int q = 0; q < PPW; ++q) wt[(size_t)((Jc + e - jlow) * NL + q) * NL * 32] = vw[(q * 4 + e) * 64];
     }
     for (int d = nD; d < D; ++d)
 #pragma unroll

@@ -478,7 +478,7 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     if (!e->ap_fast) return;
     // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
     const dim3 wgrid(((c.Nk + 63) / 64) * B);  // flat: (k tile, cosmology) decoded XCD-aware in the kernel
-    const size_t wlds = ((size_t)c.Nk + c.nmu) * sizeof(double);
+    const size_t wlds = ((size_t)c.Nk + c.nmu + (size_t)c.Nl * c.Nl * 4 * 64) * sizeof(double);  // knots, roots, the waves' coefficient windows
 #define APW_ARGS c.Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, \
                  tb<double>(e, EFTB_T_SPLOCAL), e->APW, e->API, e->APM
     if (c.Nl == 3) hipLaunchKernelGGL((ap_weights_kernel<3>), wgrid, dim3(192), wlds, st, APW_ARGS);
@@ -832,7 +832,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // counter-term rows 3-5 of every multipole: spline and AP touch those alone
         auto ap_pass = [&](bool nn, double** pin, double** palt) -> int {
             const bool moments = e->ap_mode == 1;  // (works on whole blocks: the NNLO block's zero rows stay zero)
-            const int rlo = nn && !moments ? 3 : 0, rsel = nn && !moments ? 3 : NROW;
+            const int nr = nn ? (moments ? 21 : 6) : (c.ap_stochastic ? NROW : 21);
+            // rows the spline data is needed for: [rlo, rlo + rsel) of every (cosmology, l) -- the counter-term rows of the NNLO block; on the fast
+            // path only the rows the stage distorts (Pstl passes through unless APst: 21 of 24 rows)
+            const int rlo = nn && !moments ? 3 : 0, rsel = nn && !moments ? 3 : (e->ap_mode == 0 ? nr : NROW);
             const int nseries = B * Nl * rsel;
             {
                 const int kt = (Nk + 63) / 64;
@@ -842,7 +845,6 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, e->ap_mode == 0 ? EFTB_T_SPCBAND : EFTB_T_SPBAND), e->SD);
             }
             // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
-            const int nr = nn ? (moments ? 21 : 6) : (c.ap_stochastic ? NROW : 21);
             if (!side_ap && !nn) launch_ap_prefix(e, st, B);
             if (!joined_ap) {
                 if (hipStreamWaitEvent(st, e->evJoinAP, 0) != hipSuccess) return fail("eftb_run: stream join failed");
