@@ -122,17 +122,17 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: a
 //   * the weights of PB = 3 consecutive pairs (54 doubles, contiguous in the table) arrive as ONE coalesced wave-load a block ahead and are
 //     handed to the FMAs through v_readlane (SGPR operands as before, but no scalar-memory round trip and no "wait for all scalar loads");
 //   * the coefficients sit in a ring of PB slots: a slot is reloaded with the pair PB trips ahead as soon as its pair has been consumed.
-template <int NC>
-__global__ __launch_bounds__(256) void antidiag_kernel(int B, int Bmax, const double* __restrict__ coefT,
-                                                       const double2* __restrict__ AD, double2* __restrict__ S) {
+template <int NC, int NW>
+__global__ __launch_bounds__(64 * NW) void antidiag_kernel(int B, int Bmax, const double* __restrict__ coefT,
+                                                           const double2* __restrict__ AD, double2* __restrict__ S) {
     constexpr int PB = 3, WPP = 2 * NC;  // pairs per weight block, doubles per pair
     static_assert(PB * WPP <= 64, "one wave-load must hold a block's weights");
-    __shared__ double red[3][2 * NC][64];  // partial sums of waves 1..3
+    __shared__ double red[NW - 1][2 * NC][64];  // partial sums of waves 1..NW-1
     const int grp = blockIdx.y, jp = (grp & 1) ? NPOW - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, w = grp * 64 + lane;
     const int wl = w < B ? w : B - 1;
     const int cnt = ((2 * NHALF + jp) >> 1) - jp + 1;  // pairs (n, m) = (jp + t, 256 - t), n <= m
-    const int per = (cnt + 3) >> 2, t0 = wave * per, t1 = min(cnt, t0 + per);
+    const int per = (cnt + NW - 1) / NW, t0 = wave * per, t1 = min(cnt, t0 + per);
     const double* cr = coefT + wl;
     const double* ci = coefT + (size_t)NCH * Bmax + wl;
     double ar[NC], ai[NC];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void antidiag_kernel(int B, int Bmax, const do
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {  // fixed order: wave 0 + wave 1 + wave 2 + wave 3
+            for (int v = 0; v < NW - 1; ++v) {  // fixed order: wave 0 + wave 1 + ...
                 ar[q] += red[v][2 * q][lane];
                 ai[q] += red[v][2 * q + 1][lane];
             }
@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) vb[i] = tb0[i * tstep];
     v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+    const int xw = x0 + xh * 32, ncol = xw + 16 < d.X ? 2 : (xw < d.X ? 1 : 0);  // this wave's column tiles inside the problem
     for (int k0 = 0; k0 < d.K; k0 += SYN_KC) {
         __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
@@ -341,12 +342,20 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) vb[i] = tn[i * tstep];
         }
+        // (column tiles that lie wholly past the problem's last column issue nothing: X = 80 fills 5 of the 8 tiles of its two workgroup columns,
+        // and the FP64 matrix pipe is what this kernel shares with the resummation -- beside it, its time is its MFMA count)
+        if (ncol == 2) {
 #pragma unroll 4
-        for (int t = 0; t < SYN_KC / 4; ++t) {  // (four k-steps of operands in flight: a full unroll costs 40 more registers)
-            const double a = As[(rh * 16 + r) * LDA + 4 * t + g];
+            for (int t = 0; t < SYN_KC / 4; ++t) {  // (four k-steps of operands in flight: a full unroll costs 40 more registers)
+                const double a = As[(rh * 16 + r) * LDA + 4 * t + g];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(4 * t + g) * LDB + xh * 32 + 16 * j + r], acc[j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[(4 * t + g) * LDB + xh * 32 + 16 * j + r], acc[j], 0, 0, 0);
+            }
+        } else if (ncol == 1) {
+#pragma unroll 4
+            for (int t = 0; t < SYN_KC / 4; ++t)
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(rh * 16 + r) * LDA + 4 * t + g], Bs[(4 * t + g) * LDB + xh * 32 + r], acc[0], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -372,10 +381,11 @@ __global__ __launch_bounds__(256) void synth_kernel(SynthBatch batch) {
 // K runs in groups of 16: lane (r = lane & 15, g = lane >> 4) holds A[row r][16 u + 4 g + j] (one 32-byte load) and multiplies it, for
 // j = 0..3, with Tab[16 u + 4 g + j][x0 + 2 r + {0, 1}] (one 16-byte load): the k order inside an MFMA is a permutation of the usual one, the
 // same on both operands.  Column tile t holds x0 + 2 r + t, so a lane stores pairs of neighbouring columns.  K is a multiple of 16 (SYN_KPAD).
-__global__ __launch_bounds__(256) void gemm_direct_kernel(SynthBatch batch) {
-    // workgroup = 4 waves = ONE tile: the waves take a quarter of the K groups each (the serial depth of a tile is what a problem this small
-    // waits for: 18 dependent load -> MFMA trips at K = 288 became 5) and their partial tiles meet in LDS, added in wave order
-    __shared__ double red[3][8][64];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_direct_kernel(SynthBatch batch) {
+    // workgroup = NW waves = ONE tile: the waves take an NW-th of the K groups each (the serial depth of a tile is what a problem this small
+    // waits for: 18 dependent load -> MFMA trips at K = 288 become 5 with four waves) and their partial tiles meet in LDS, added in wave order
+    __shared__ double red[NW - 1][8][64];
     int pi = 0, wg0 = 0;
 #pragma unroll
     for (int q = 0; q < SYN_MAXP - 1; ++q)
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(SynthBatch batch) {
     const int x0 = x < d.X ? x : d.X - 1, x1 = x + 1 < d.X ? x + 1 : d.X - 1;
     const double* bp = d.Tab + (size_t)(4 * g) * d.X;
     v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int ng = d.K / 16, per = (ng + 3) >> 2, u0 = wave * per, u1 = min(ng, u0 + per);
+    const int ng = d.K / 16, per = (ng + NW - 1) / NW, u0 = wave * per, u1 = min(ng, u0 + per);
     if (pairs) {
         const double* bq = bp + (x + 1 < d.X ? x : d.X - 2);
 #pragma unroll 2
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(SynthBatch batch) {
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
+    for (int v = 0; v < NW - 1; ++v)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             acc0[q] += red[v][q][lane];
