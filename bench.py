@@ -227,6 +227,7 @@ def main():
     # built tables runs its first ~10 ms of work below its sustained clocks (measured on the MI355X pool: 20 timed steps = 8 ms right behind 3 warm-up
     # steps 0.426-0.429 ms per step, behind 50 ms of the same loop 0.388-0.397, behind 500 ms 0.393; --warmup 20 alone 0.409): a chain that runs
     # for hours sees the latter.  EFTB_BENCH_PREWARM_MS=0 gives the bare W steps.
+    eng.set_latency_mode(False)  # the pipelined loop keeps DEPTH steps queued: its first step is not a dependent sampler's step
     loop(0, W, keep=False)
     warm_ms, warm_steps = float(os.environ.get("EFTB_BENCH_PREWARM_MS", "50")), W
     tw = time.perf_counter()
@@ -264,6 +265,7 @@ def main():
 
     if rank == 0:
         extras = {}
+        eng.set_latency_mode(True)
         if world == 1 and not force_comm:
             # (0) what a DEPENDENT sampler sees (reference likelihood.py:570-594 inside Model.logpost: step i + 1 needs step i's P_l): stage ->
             # run -> fetch the step just launched, nothing queued behind it.  New inputs every step, P_l back every step.

@@ -1373,6 +1373,7 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_GRAPH: e->use_graphs = value != 0; return 0;
         case EFTB_O_CHECK_FINITE: e->check_finite = value != 0; return 0;
         case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seq = 0; return 0;
+        case EFTB_O_LATENCY_MODE: e->latency_auto = value != 0; return 0;
     }
     return fail("eftb_set_option: unknown option %d", option);
 }

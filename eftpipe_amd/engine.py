@@ -151,6 +151,11 @@ class Engine:
         L.check(self.lib.eftb_dominant_time(self._h, C.byref(ms), C.byref(n), int(bool(reset))))
         return ms.value, n.value
 
+    def set_latency_mode(self, flag):
+        """True (default): a step staged while the GPU is idle runs in latency mode (one queue, zero-copy P_lin, P_l written to mapped host memory) --
+        for samplers whose next step depends on this one.  False: always the three-stream layout (loops that keep several steps queued)."""
+        L.check(self.lib.eftb_set_option(self._h, 5, int(bool(flag))))
+
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
 
@@ -330,6 +335,7 @@ class Engine:
         nl, nx = self.out_dims()
         shape_of = lambda B: (B, nl, nx) if fetch == "PLK" else (B // self.ntracers, 2 + 24)
         queued = []  # batch sizes of the steps launched and not yet fetched (at most three)
+        self.set_latency_mode(False)  # several steps stay queued: the first one must not take the single-queue form
         for st in steps:
             B = self.stage_inputs(st["Pin"], st["f"], st.get("DA"), st.get("H"), bias=st.get("bias"), rows=st.get("rows"))
             self.run_staged(mask, B)
@@ -338,6 +344,7 @@ class Engine:
                 yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=3)
         while queued:  # drain: back = 0 is the step launched last
             yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=len(queued))
+        self.set_latency_mode(True)
 
     def pinned_empty(self, shape):
         """Page-locked float64 host array for eval_batch(out=...) / put / get."""

@@ -142,7 +142,11 @@ enum eftb_option {
                                  eftb_fetch_*) then returns non-zero naming the cosmology (off by default) */
     EFTB_O_TIME_DOMINANT = 4  /* value n > 0: bracket every n-th launch of the resummation kernel with HIP events on the stream it runs on
                                  (measurement only: bench.py's roofline; read with eftb_dominant_time; inactive while EFTB_O_GRAPH replays
-                                 captured runs).  The two event packets cost the pipelined loop about 1.5 % when every launch carries them. */
+                                 captured runs).  The two event packets cost the pipelined loop about 1.5 % when every launch carries them. */,
+    EFTB_O_LATENCY_MODE = 5   /* 1 (default): a step staged (eftb_stage_inputs) while the GPU is idle runs in latency mode -- one queue, P_lin read from
+                                 the staging block, P_l written to mapped host memory by the kernel that forms it: what a sampler wants whose next
+                                 step depends on this step's result.  0: always the three-stream layout (a caller that knows more steps follow
+                                 at once: the first step of a pipelined loop then does not hold the main queue with its AP stage) */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 /* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for
