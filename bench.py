@@ -39,7 +39,6 @@ BS = [2.1401334, 0.77616816 / np.sqrt(2.0), 0.77003455, 0.77616816 / np.sqrt(2.0
 ES = (0.26033594, 0.0, -0.92895016)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
 NPOW, NS_DEV, NKLOW = 257, 80, 7
-DEFAULT_RESUM_WPS = 2   # engine default (eftbird.hip resum_wps); EFTB_RESUM_WPS overrides both
 DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "2"))  # steps queued on the GPU ahead of the one being fetched (1..3; measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
 
 
@@ -92,8 +91,7 @@ def executed_flops_per_launch(B):
     (one wave, 16 k x 1 s) `flops_per_wave_trip` = 2048 per v_mfma_f64_16x16x4 + 64 lanes x (2 per v_fma/v_fmac_f64, 1 per v_mul/v_add_f64),
     times waves (4 per 64 k of the resummed range, per cosmology) times 80 trips."""
     path = os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")
-    wps = int(os.environ.get("EFTB_RESUM_WPS", str(DEFAULT_RESUM_WPS)))
-    name = "resum_mfma_kernel<%d,0>" % (3 if wps >= 3 else 2)  # the build the engine launches
+    name = "resum_mfma_kernel<0>"  # the build the engine launches (<1>: with the NNLO accumulators)
     with open(path) as fh:
         allinfo = json.load(fh)
     info = allinfo[name]
@@ -384,7 +382,7 @@ def main():
         alg_resum = 8.0 * NA * (NL * 14 * 2 * NIR) * 193 * (NK - NKLOW) * B
         alg_p22 = 8.0 * 28 * NK * NPOW**2 * B
         roofline = {
-            "bound": "mfma", "kernel": "resum_mfma_kernel<waves per SIMD, NNLO> (Resum.Ps on v_mfma_f64_16x16x4_f64 + FP64 VALU, which share the DP pipe)",
+            "bound": "mfma", "kernel": "resum_mfma_kernel<NNLO> (Resum.Ps on v_mfma_f64_16x16x4_f64 + FP64 VALU, which share the DP pipe)",
             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src,
             "ms_per_launch": ms_resum, "launches_timed": dom_n,

@@ -935,25 +935,29 @@ __global__ __launch_bounds__(256, 2) void resum_kernel(int Nk, int Nklow, int sc
 // IR-resummation on the FP64 matrix cores (Nl = 3; tables.py resum_mfma_tables).
 // All 108 polynomials  sum_p Q_a[l,l',(half,p,v)](f) z^p  of one cosmology lie in a fixed 8-dimensional space, so with
 // an orthonormal basis beta_r(t), t = z / RS_ZS, of that space their values at 16 (k, s) points are one
-// [80 x 8] x [8 x 16] product:  rows = (tile tau, chunk, slot) as laid out by the host so that the four numbers a lane
-// receives from one v_mfma_f64_16x16x4 (rows (lane >> 4) + 4 q, column lane & 15) are the four (v, half) slots of ONE
-// (a, l, l') block at ONE k.  The lane then forms
-//     W_a[l,l'](k,s) = z H_l'(k,s) D0 + y (H_0 D1 + H_1 D2 + H_2 D3),   z = k^2 X(s), y = k^2 Y(s),
-// and contracts it with the s-dependent (wave-uniform, scalar-loaded) C11 / Cct / Cloopl columns into its own output
-// rows, accumulated over s in registers:  lanes (jg = lane >> 4, n = lane & 15) own k = k0 + n and
-//     tiles 0-2 (l' = tau):  jg < 3 -> (a = 1, l = jg): Pctl[6] + Ploopl[12];   jg = 3 -> (a = 0, l = 0): P11l[3]
-//     tile 3:                jg < 3 -> (a = 0, l = 1, l' = jg);   jg = 3 -> (a = 0, l = 2, l' = 0)
-//     tile 4:                jg < 2 -> (a = 0, l = 2, l' = jg + 1)                     (jg >= 2: zero rows)
-// The 18 (a, l, l') blocks thus fill 18 of the 20 chunks of five row tiles.  Blocks of tiles 0-2 are accumulated over s in the
-// lane that owns the output rows; the six one-number (a = 0, l >= 1) sums of tiles 3-4 are combined across lane groups once,
-// after the loop.  The loop has no branches (lane roles are applied through zeroed weights and selects), which keeps hipcc from
-// shuffling MFMA results through AGPRs.
-// resum_prep_kernel builds, per cosmology, A = Q(f) diag(RS_ZS^p) V8^T and the per-s records
-//   RSC[w][s] = { [l'][14]: C11[l'], Cct[l'], Cloopl[l',0..11] } , X, Y, pad  (48 doubles);
-// the mu weights l11 / lct multiply the s-sums once, at the end.
+// [rows x 8] x [8 x 16] product.  The weight of an (a, l, l') block is
+//     W_a[l,l'](k,s) = k^2 sum_v H_v(k,s) [ delta(v,l') X(s) D(half 0, v) + Y(s) D(half 1, v) ],
+// linear in the rows of the A operand, so the operand is built PER s (resum_as_kernel, [w][s][4 tiles][64 lanes][2]: the two
+// doubles a lane feeds the two MFMAs of a tile; a function of the inputs alone, built beside the look-ahead chain) with X(s), Y(s)
+// folded into its rows: three rows (v = 0, 1, 2) per block instead of four -- 18 blocks = 54 rows in four row tiles.  The four
+// numbers a lane receives from one v_mfma_f64_16x16x4 (rows (lane >> 4) + 4 q, column lane & 15) are, for lane (jg = lane >> 4,
+// n = lane & 15) at k = k0 + n:
+//     tiles 0-2 (l' = tau), jg < 3:  q = 0..2 -> (a = 1, l = jg), v = q;     q = 3 -> (a = 0, l = 1, l' = tau), v = jg
+//     tiles 0-2,            jg = 3:  q = 0..2 -> (a = 0, l = 0, l' = tau);   q = 3 -> zero row
+//     tile 3,               jg < 3:  q = 0..2 -> (a = 0, l = 2, l' = jg);    everything else zero
+// so every lane forms  W = H_0 D0 + H_1 D1 + H_2 D2  per tile and contracts it with the s-dependent (wave-uniform, scalar-loaded)
+// C11 / Cct / Cloopl columns into its own output rows, accumulated over s in registers (fourth slot: H_jg C11[l'] D3, summed over the
+// three lane groups after the loop; tile 3: the lane group's own C11 column, one vector load).  k^2 and the mu weights l11 / lct
+// multiply the s-sums once, at the end.  The loop has no branches and no lane-role selects (hipcc shuffles MFMA results through AGPRs
+// otherwise).  Per step: 8 MFMAs + 95 FP64 vector instructions (ten + 106, and 12 selects, with one four-slot operand per cosmology).
+// resum_prep_kernel builds the per-s records
+//   RSC[w][s] = { [l'][14]: C11[l'], Cct[l'], Cloopl[l',0..11] } , X, Y, pad  (48 doubles).
+// (Nl = 2, resum_mfma2_kernel: one operand per cosmology, A = Q(f) diag(RS_ZS^p) V8^T, four-slot blocks.)
 // ------------------------------------------------------------------------------------------------
 constexpr double RS_ZS = 8.0;  // tables.py RS_ZS
-constexpr int RS_NB = 8, RS_TILES = 5, RS_ROWS = 16 * RS_TILES, RS_REC = 48;
+constexpr int RS_NB = 8, RS_ROWS = 80, RS_REC = 48;
+constexpr int RS3_TILES = 4, RS3_ROWS = 16 * RS3_TILES, RS3_AS = RS3_ROWS * RS_NB;  // Nl = 3: rows / doubles of one per-s operand
+constexpr int RS_PF = 3;  // steps the Nl = 3 kernel prefetches its operand and records ahead (both buffers carry RS_PF spare steps)
 
 template <int NL>
 __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na, const double* __restrict__ Q,
@@ -985,9 +989,9 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
         }
         __syncthreads();
     }
-    // blockIdx.y splits the work of one cosmology (gridDim.y = 1: all of it): part 0 also builds the A operand
+    // blockIdx.y splits the work of one cosmology (gridDim.y = 1: all of it): part 0 also builds the A operand (Nl = 2; Nl = 3: resum_as_kernel)
     const int part = blockIdx.y, nparts = gridDim.y;
-    for (int idx = threadIdx.x; idx < (part == 0 ? RS_ROWS * RS_NB : 0); idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < (part == 0 && NL != 3 ? RS_ROWS * RS_NB : 0); idx += blockDim.x) {
         const int row = idx / RS_NB, r = idx % RS_NB, off = rows[row];
         double a0 = 0.0, a1 = 0.0;
         if (off >= 0)
@@ -1022,6 +1026,41 @@ __global__ __launch_bounds__(256) void resum_prep_kernel(int NN, int NIR, int Na
     }
 }
 
+// Per-s A operand of resum_mfma_kernel (Nl = 3; inputs only: Q(f), X(s), Y(s) -- off the look-ahead chain, memory-bound):
+//   RSAS[w][s][tau][lane][t] = (X(s) a_X + Y(s) a_Y)[row 16 tau + (lane & 15)][column (lane >> 4) + 4 t],   a_X | a_Y = Q rows . V8S^T,
+// rows[0 | 1][row] = offset of the row's X | Y part in the cosmology's Q block (-1: none).  Grid (cosmology, s quarter); a thread keeps its two
+// entries of a_X, a_Y in registers and walks s: every store instruction of the workgroup writes 2 KB of consecutive addresses.
+__global__ __launch_bounds__(256) void resum_as_kernel(int NN, int NIR, int Na, const double* __restrict__ Q, const double* __restrict__ V8S,
+                                                       const int* __restrict__ rows, const double* __restrict__ XY, double* __restrict__ RSAS) {
+    const int w = blockIdx.x;
+    const double* q = Q + (size_t)w * 2 * 3 * 3 * NN;
+    double ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = threadIdx.x + 256 * j, tau = e >> 7, lane = (e >> 1) & 63, t = e & 1;
+        const int row = 16 * tau + (lane & 15), r = (lane >> 4) + 4 * t;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int off = rows[which * RS3_ROWS + row];
+            double a0 = 0.0, a1 = 0.0;
+            if (off >= 0)
+                for (int p = 0; p < NIR; p += 2) {
+                    a0 = fma(q[off + p * Na], V8S[r * 16 + p], a0);
+                    a1 = fma(q[off + (p + 1) * Na], V8S[r * 16 + p + 1], a1);
+                }
+            (which ? ay : ax)[j] = a0 + a1;
+        }
+    }
+    const int ns = (NS + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * ns, s1 = min(NS, s0 + ns);
+    const double* xy = XY + (size_t)w * 2 * NS;
+    double* dst = RSAS + ((size_t)w * NS + s0) * RS3_AS + threadIdx.x;
+    for (int s = s0; s < s1; ++s, dst += RS3_AS) {
+        const double x = xy[s], y = xy[NS + s];
+        dst[0] = fma(x, ax[0], y * ay[0]);
+        dst[256] = fma(x, ax[1], y * ay[1]);
+    }
+}
+
 __device__ inline double estrin16(const double* __restrict__ c, double t, double t2, double t4, double t8) {
     const double e0 = fma(c[1], t, c[0]), e1 = fma(c[3], t, c[2]), e2 = fma(c[5], t, c[4]), e3 = fma(c[7], t, c[6]);
     const double e4 = fma(c[9], t, c[8]), e5 = fma(c[11], t, c[10]), e6 = fma(c[13], t, c[12]), e7 = fma(c[15], t, c[14]);
@@ -1030,15 +1069,13 @@ __device__ inline double estrin16(const double* __restrict__ c, double t, double
     return fma(g1, t8, g0);
 }
 
-// RS_WPS = waves per SIMD the kernel is built for (launch bounds): with the basis coefficients in LDS instead of 64 VGPRs the kernel fits three
-// waves per SIMD (<= 168 VGPRs); the 16-byte LDS reads of the next step's polynomials fly under this step's MFMAs.
 // NNLO: the k^4 P11 counter-terms PctNNLOl (reference pybird.py:1447-1458) take the same W as Pctl with CctNNLO in place of Cct and lctNNLO in
 // place of lct -- three more accumulators per lane (record slots 44-46) instead of a second pass over the whole stage; TN is the NNLO
 // block (rows 3-5).  Only with nsplit = 1 (the partial-sum layout of small batches has no slot for it: those run the second pass).
-template <int RS_WPS, bool NNLO>
-__global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
+template <bool NNLO>
+__global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, int schunk, const double* __restrict__ kk,
                                                             const double* __restrict__ H, const double* __restrict__ V8,
-                                                            const double* __restrict__ RSA, const double* __restrict__ RSC,
+                                                            const double* __restrict__ RSAS, const double* __restrict__ RSC,
                                                             const double* __restrict__ l11, const double* __restrict__ lct,
                                                             double* __restrict__ T, double* __restrict__ part, int nsplit,
                                                             const double* __restrict__ lctn, double* __restrict__ TN, int nkb) {
@@ -1047,197 +1084,144 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
     const int jg = lane >> 4, n = lane & 15;
     // Workgroup -> (k block, cosmology).  The k tiles start at a multiple of 16 (the 128-byte template segments of a wave are then whole
     // cache lines; lanes below Nklow idle), and the nkb workgroups of one cosmology sit on ONE XCD (consecutive workgroup ids go round the
-    // eight XCDs): its 30 KB of per-s records and its A operand then pass through one L2 instead of eight.
+    // eight XCDs): its per-s operands and records then pass through one L2 instead of eight.
     int kb, w;
     xcd_decode(nkb, kb, w);
     const int k = (Nklow & ~15) + (kb * 4 + wave) * 16 + n, split = blockIdx.z;
     const int kc = k < Nklow ? Nklow : (k < Nk ? k : Nk - 1);  // lanes outside [Nklow, Nk) compute on a clamped k and store nothing
-    const double k2 = kk[kc] * kk[kc];
+    const double k2 = kk[kc] * kk[kc], k2t = k2 * (1.0 / RS_ZS);
     // B operand: this lane evaluates basis polynomials jg and jg + 4 at its point; A operand: rows (16 tau + n), columns jg + 4 t
-    __shared__ double s_vb[RS_WPS >= 3 ? RS_NB * 16 : 1];
-    double vb[2][RS_WPS >= 3 ? 1 : 16];
-    int vboff = jg * 16;  // lanes of one group read the same address: broadcast, no conflicts
-    if (RS_WPS >= 3) {
-        if (threadIdx.x < RS_NB * 16) s_vb[threadIdx.x] = V8[threadIdx.x];
-        __syncthreads();
-    } else {
+    double vb[2][16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < (RS_WPS >= 3 ? 1 : 16); ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
-    }
+        for (int p = 0; p < 16; ++p) vb[t][p] = V8[(jg + 4 * t) * 16 + p];
 #define RS_POLY(out0, out1, tt)                                                        \
     do {                                                                               \
         const double t_ = (tt), t2_ = t_ * t_, t4_ = t2_ * t2_, t8_ = t4_ * t4_;       \
-        if (RS_WPS >= 3) {                                                             \
-            asm volatile("" : "+v"(vboff)); /* re-read every step: not hoisted back into registers */ \
-            const double* vp = s_vb + vboff;                                           \
-            out0 = estrin16(vp, t_, t2_, t4_, t8_);                                    \
-            out1 = estrin16(vp + 64, t_, t2_, t4_, t8_);                               \
-        } else {                                                                       \
-            out0 = estrin16(vb[0], t_, t2_, t4_, t8_);                                 \
-            out1 = estrin16(vb[1], t_, t2_, t4_, t8_);                                 \
-        }                                                                              \
+        out0 = estrin16(vb[0], t_, t2_, t4_, t8_);                                     \
+        out1 = estrin16(vb[1], t_, t2_, t4_, t8_);                                     \
     } while (0)
-    double aop[RS_TILES][2];
-#pragma unroll
-    for (int tau = 0; tau < RS_TILES; ++tau)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) aop[tau][t] = RSA[((size_t)w * RS_ROWS + 16 * tau + n) * RS_NB + jg + 4 * t];
-    const bool lp3hi = jg >= 2;  // tile 3: lane groups 0, 1 hold the (a = 0, l = 1 | 2, l' = 0) blocks, groups 2, 3 the l' = 1 ones; tile 4: l' = 2
-    double accL[12], accCt[3], acc11A[3], acc11B[2];  // s-sums: W Cloopl[l',i] (summed over l'), W Cct[l'], W C11[l'] (tiles 0-2), tiles 3 / 4
+    // s-sums: W Cloopl[l',i] (summed over l'), W Cct[l'] (jg < 3); W C11[l'] of the (a = 0, l = 0, l') block (jg = 3); H_jg D3 C11[l'] = the
+    // v = jg part of the (a = 0, l = 1, l') block; tile 3: W C11[jg] of the (a = 0, l = 2, l' = jg) block
+    double accL[12], accCt[3], accP[3], accQ[3], accP3 = 0.0;
 #pragma unroll
     for (int i = 0; i < 12; ++i) accL[i] = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) accCt[i] = acc11A[i] = 0.0;
-    acc11B[0] = acc11B[1] = 0.0;
+    for (int i = 0; i < 3; ++i) accCt[i] = accP[i] = accQ[i] = 0.0;
     double accN[3] = {0.0, 0.0, 0.0};  // NNLO: W CctNNLO[l']
     const int s0 = split * schunk, s1 = min(NS, s0 + schunk);
     const double* ct = RSC + ((size_t)w * NS + s0) * RS_REC;  // wave-uniform record of the current s
-    // H[v][s][k]: one wave-uniform base and 32-bit per-lane byte offsets (three 64-bit per-lane pointers would cost the registers that
-    // decide whether other kernels fit beside two of these waves on a SIMD)
+    // per-s A operand: one wave-uniform base and a 32-bit per-lane byte offset ([tau][lane][2]: a wave's load of a tile is 1 KB, contiguous)
+    const char* as = reinterpret_cast<const char*>(RSAS + (size_t)w * NS * RS3_AS);
+    unsigned aoff = (unsigned)s0 * (RS3_AS * 8u) + (unsigned)lane * 16u;
+    // H[v][s][k]: one wave-uniform base and 32-bit per-lane byte offsets (64-bit per-lane pointers would cost the registers that
+    // decide whether other kernels fit beside two of these waves on a SIMD); hq = H of the fourth slot's v = jg
     const char* Hb = reinterpret_cast<const char*>(H);
     const unsigned hrow = (unsigned)NS * (unsigned)Nk * 8u, hstep = (unsigned)Nk * 8u;
     unsigned hoff = ((unsigned)s0 * (unsigned)Nk + (unsigned)kc) * 8u;
-    // carried from step to step: the products z H_v, y H_v of the current s (not H and z, y themselves: the next step's H is then the only
-    // other copy in flight) and the basis polynomials at z
-    double zh[3], yh[3];
-    double b0, b1;
-    {
-        const double z = k2 * ct[42], y = k2 * ct[43];
+    const unsigned hqv = (unsigned)(jg < 3 ? jg : 0) * hrow;
+    // L2 prefetch RS_PF steps ahead: the operand of a step is first touched by the 32 waves of its cosmology together, an HBM / fabric round
+    // trip that the one step between its request and its use does not cover.  One dword per lane, 64 B apart = the whole 4 KB operand
+    // (lanes 0-5 of the second load: the 384 B record); the values are never used.
+    // (no clamp at the end of the s range: both buffers are allocated RS_PF steps longer)
+    unsigned pfoff = (unsigned)(s0 + RS_PF) * (RS3_AS * 8u) + (unsigned)lane * 64u;
+    const char* rcb = reinterpret_cast<const char*>(RSC + (size_t)w * NS * RS_REC);
+    unsigned pfroff = (unsigned)(s0 + RS_PF) * (RS_REC * 8u) + (unsigned)(lane < 6 ? lane : 0) * 64u;
+    unsigned c11off = (unsigned)s0 * (RS_REC * 8u) + (unsigned)(jg < 3 ? jg : 0) * (14u * 8u);
+    double h[3], hq, b0, b1;
+    v2d aop[RS3_TILES];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            const double h = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
-            zh[v] = z * h;
-            yh[v] = y * h;
-        }
-        RS_POLY(b0, b1, z * (1.0 / RS_ZS));
-    }
-    // keep the A operand in registers (hipcc would otherwise re-load it from memory every step)
+    for (int v = 0; v < 3; ++v) h[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
+    hq = *reinterpret_cast<const double*>(Hb + (hoff + hqv));
 #pragma unroll
-    for (int tau = 0; tau < RS_TILES; ++tau)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(aop[tau][t]));
+    for (int tau = 0; tau < RS3_TILES; ++tau) aop[tau] = *reinterpret_cast<const v2d*>((as + tau * 1024) + aoff);
+    RS_POLY(b0, b1, k2t * ct[42]);
     for (int s = s0; s < s1; ++s) {
-        // memory first: this step's C columns (scalar loads, consumed after the MFMAs) and the next step's X, Y, H
+        // memory first: the prefetches, this step's C columns of l' = 0, 1 (scalar loads, consumed after the MFMAs; those of l' = 2 follow once
+        // tile 0 has been consumed -- 42 doubles at once overflow the scalar file and come back as v_readlane traffic) and the next step's X
         const bool more = s + 1 < s1;
         const double* ctn = more ? ct + RS_REC : ct;
-        hoff += more ? hstep : 0u;
-        // (WPS >= 3: the third l' block of the record is requested only after the first tile has been consumed -- 42 doubles at once
-        // overflow the scalar file and come back as v_writelane / v_readlane traffic)
-        constexpr int NCV = RS_WPS >= 3 ? 28 : 42;
-        double cv[42];
+        const unsigned pf0 = *reinterpret_cast<const unsigned*>(as + pfoff), pf1 = *reinterpret_cast<const unsigned*>(rcb + pfroff);
+        pfoff += RS3_AS * 8u;
+        pfroff += RS_REC * 8u;
+        aoff += more ? RS3_AS * 8u : 0u;
+        asm volatile("" : "+v"(aoff));  // formed here, not behind the MFMAs (where it would land in a register they still read: 16 wait states)
+        const double c11q = *reinterpret_cast<const double*>(rcb + c11off);  // C11[l' = jg](s) of this step: the column of the lane's tile-3 block
+        c11off += more ? RS_REC * 8u : 0u;
+        double cv[3][14];  // per l': C11, Cct, Cloopl[0..11]
 #pragma unroll
-        for (int i = 0; i < NCV; ++i) cv[i] = ct[i];
-        const double xn = ctn[42], yn0 = ctn[43];
-        double hn[3];
+        for (int tau = 0; tau < 2; ++tau)
 #pragma unroll
-        for (int v = 0; v < 3; ++v) hn[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
-        __builtin_amdgcn_sched_barrier(0);
-        double zn, yn;  // k^2 X, k^2 Y of the next step: formed only after this step's MFMAs have been issued -- the wait for the scalar
-                        // loads above then sits behind 640 cycles of matrix work instead of behind the first MFMA
-        double bn0, bn1;
-#define RS_TILE(tau) \
-    __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0), 0, 0, 0)
-        // every lane accumulates both roles; the sums of the role it does not own are never read
-#define RS_USE012(tau, Dt)                                                                                                  \
-    do {                                                                                                                    \
-        const double W_ = fma(zh[tau], Dt[0], fma(yh[0], Dt[1], fma(yh[1], Dt[2], yh[2] * Dt[3])));                         \
-        acc11A[tau] = fma(W_, cv[tau * 14], acc11A[tau]);                                                                   \
-        accCt[tau] = fma(W_, cv[tau * 14 + 1], accCt[tau]);                                                                 \
-        if (NNLO) accN[tau] = fma(W_, cn[tau], accN[tau]);                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 12; ++i) accL[i] = fma(W_, cv[tau * 14 + 2 + i], accL[i]);                    \
-    } while (0)
-        // tiles 3 and 4: one (a = 0, l, l') block per lane, l' by lane group
-#define RS_USE34(which, Dt)                                                                                                 \
-    do {                                                                                                                    \
-        const double zhx_ = which ? zh[2] : (lp3hi ? zh[1] : zh[0]), cx_ = which ? cv[28] : (lp3hi ? c11_1 : c11_0);        \
-        const double Wx_ = fma(zhx_, Dt[0], fma(yh[0], Dt[1], fma(yh[1], Dt[2], yh[2] * Dt[3])));                           \
-        acc11B[which] = fma(Wx_, cx_, acc11B[which]);                                                                       \
-    } while (0)
-        const double c11_0 = cv[0], c11_1 = cv[14];
+            for (int i = 0; i < 14; ++i) cv[tau][i] = ct[tau * 14 + i];
         double cn[3] = {0.0, 0.0, 0.0};
         if (NNLO) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) cn[i] = ct[44 + i];
         }
-        if (RS_WPS >= 3) {
-            // tile by tile: the MFMA pair of tile tau + 1 is issued before tile tau is consumed, so only two result tiles are live (the
-            // third wave of the SIMD covers what this order leaves exposed); the next step's basis polynomials sit in the middle
-            const v4d D0 = RS_TILE(0);
-            const v4d D1 = RS_TILE(1);
-            __builtin_amdgcn_sched_barrier(0);
-            zn = k2 * xn;
-            yn = k2 * yn0;
-            RS_USE012(0, D0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 28; i < 42; ++i) cv[i] = ct[i];
-            const v4d D2 = RS_TILE(2);
-            RS_POLY(bn0, bn1, zn * (1.0 / RS_ZS));
-            RS_USE012(1, D1);
-            __builtin_amdgcn_sched_barrier(0);
-            const v4d D3 = RS_TILE(3);
-            RS_USE012(2, D2);
-            const v4d D4 = RS_TILE(4);
-            RS_USE34(0, D3);
-            RS_USE34(1, D4);
-        } else {
-            // all ten MFMAs of this step (five independent accumulators) ...
-            v4d D[RS_TILES];
-#pragma unroll
-            for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-#pragma unroll
-            for (int tau = 0; tau < RS_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            zn = k2 * xn;
-            yn = k2 * yn0;
-            // ... under them the basis polynomials of the next step and the contraction of this step
-            RS_POLY(bn0, bn1, zn * (1.0 / RS_ZS));
-            RS_USE012(0, D[0]);
-            RS_USE012(1, D[1]);
-            RS_USE012(2, D[2]);
-            RS_USE34(0, D[3]);
-            RS_USE34(1, D[4]);
-        }
-#undef RS_TILE
-#undef RS_USE012
-#undef RS_USE34
+        const double xn = ctn[42];
         __builtin_amdgcn_sched_barrier(0);
+        // all eight MFMAs of this step (four independent accumulators) ...
+        v4d D[RS3_TILES];
+#pragma unroll
+        for (int tau = 0; tau < RS3_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][0], b0, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+#pragma unroll
+        for (int tau = 0; tau < RS3_TILES; ++tau) D[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[tau][1], b1, D[tau], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ... the next step's operand is requested once they have been issued (same registers: the loads land while the vector work below runs)
+#pragma unroll
+        for (int tau = 0; tau < RS3_TILES; ++tau) aop[tau] = *reinterpret_cast<const v2d*>((as + tau * 1024) + aoff);
+        __builtin_amdgcn_sched_barrier(0);
+#define RS_USE(tau)                                                                                              \
+    do {                                                                                                         \
+        const double W_ = fma(h[0], D[tau][0], fma(h[1], D[tau][1], h[2] * D[tau][2]));                          \
+        accP[tau] = fma(W_, cv[tau][0], accP[tau]);                                                              \
+        accCt[tau] = fma(W_, cv[tau][1], accCt[tau]);                                                            \
+        if (NNLO) accN[tau] = fma(W_, cn[tau], accN[tau]);                                                       \
+        _Pragma("unroll") for (int i = 0; i < 12; ++i) accL[i] = fma(W_, cv[tau][2 + i], accL[i]);               \
+        accQ[tau] = fma(hq * cv[tau][0], D[tau][3], accQ[tau]);                                                  \
+    } while (0)
+        // ... under them the contraction of this step and the basis polynomials of the next (k^2 X formed only now: the wait for the scalar
+        // loads above then sits behind the matrix work instead of behind the first MFMA)
+        RS_USE(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 14; ++i) cv[2][i] = ct[28 + i];
+        double bn0, bn1;
+        RS_POLY(bn0, bn1, k2t * xn);
+        RS_USE(1);
+        __builtin_amdgcn_sched_barrier(0);
+        RS_USE(2);
+        accP3 = fma(fma(h[0], D[3][0], fma(h[1], D[3][1], h[2] * D[3][2])), c11q, accP3);
+#undef RS_USE
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::"v"(pf0), "v"(pf1));  // (the prefetches are older than the operand loads above)
+        // the next step's H into the registers this step has just read for the last time (L2-resident table: back before the MFMAs are through)
+        hoff += more ? hstep : 0u;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) h[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
+        hq = *reinterpret_cast<const double*>(Hb + (hoff + hqv));
         ct = ctn;
         b0 = bn0;
         b1 = bn1;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            zh[v] = zn * hn[v];
-            yh[v] = yn * hn[v];
-        }
     }
-    // (a, l) blocks -> output rows, mu weights applied to the s-sums.  The (a = 0, l = 1 | 2) blocks of tiles 3-4 are spread
-    // over lane groups (one l' each): their l11-weighted terms are gathered into the jg = 0 lane of every k.
-    // (lane-group predicates are re-derived from an opaque copy of jg: kept alive through the loop they cost scalar pairs the records need)
-    int jgx = jg;
-    asm volatile("" : "+v"(jgx));
-#define jg jgx
+#undef RS_POLY
+    // (a, l) blocks -> output rows: k^2 and the mu weights applied to the s-sums.  The (a = 0, l = 1 | 2) sums are spread over the lane
+    // groups jg < 3 (one v, or one l', each): gathered into the jg = 0 lane of every k.
     double o18[18], oA[3], o1[3], o2[3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o18[i] = lct[i] * accCt[0] + lct[6 + i] * accCt[1] + lct[12 + i] * accCt[2];
+    for (int i = 0; i < 6; ++i) o18[i] = k2 * (lct[i] * accCt[0] + lct[6 + i] * accCt[1] + lct[12 + i] * accCt[2]);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) o18[6 + i] = accL[i];
+    for (int i = 0; i < 12; ++i) o18[6 + i] = k2 * accL[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        oA[i] = l11[i] * acc11A[0] + l11[3 + i] * acc11A[1] + l11[6 + i] * acc11A[2];
-        // tile 3: group g holds (l = 1 + g % 2, l' = g / 2); tile 4: groups 0, 1 hold (l = 1 | 2, l' = 2)
-        const double b0 = l11[(jg >> 1) * 3 + i] * acc11B[0] + (jg < 2 ? l11[6 + i] * acc11B[1] : 0.0);
-        const double t1 = (jg & 1) ? 0.0 : b0, t2 = (jg & 1) ? b0 : 0.0;  // contributions to l = 1 (groups 0, 2) and to l = 2 (groups 1, 3)
-        o1[i] = t1 + __shfl(t1, n + 32);
-        o2[i] = __shfl(t2, n + 16) + __shfl(t2, n + 48);
+        oA[i] = k2 * (l11[i] * accP[0] + l11[3 + i] * accP[1] + l11[6 + i] * accP[2]);
+        const double t1 = jg < 3 ? l11[i] * accQ[0] + l11[3 + i] * accQ[1] + l11[6 + i] * accQ[2] : 0.0;
+        const double t2 = jg < 3 ? l11[jg * 3 + i] * accP3 : 0.0;
+        o1[i] = k2 * (t1 + __shfl(t1, (lane + 16) & 63) + __shfl(t1, (lane + 32) & 63));
+        o2[i] = k2 * (t2 + __shfl(t2, (lane + 16) & 63) + __shfl(t2, (lane + 32) & 63));
     }
-    {   // (the comparison is redone here: carried through the loop it is the one scalar pair too many -- a spill lane, i.e. one more VGPR)
-        int kx = k;
-        asm volatile("" : "+v"(kx));
-        if (kx >= Nk || kx < Nklow) return;
-    }
+    if (k >= Nk || k < Nklow) return;
     if (nsplit == 1) {
         if (jg < 3) {
             double* dst = T + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
@@ -1246,7 +1230,7 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
             if (NNLO) {  // PctNNLOl[l = jg][i] += sum_l' lctNNLO[l'][i] W Cct_NNLO[l']   (lctn is [Nl][6], zero padded)
                 double* dn = TN + (((size_t)w * NL + jg) * NROW + 3) * Nk + k;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) dn[(size_t)i * Nk] += lctn[i] * accN[0] + lctn[6 + i] * accN[1] + lctn[12 + i] * accN[2];
+                for (int i = 0; i < 3; ++i) dn[(size_t)i * Nk] += k2 * (lctn[i] * accN[0] + lctn[6 + i] * accN[1] + lctn[12 + i] * accN[2]);
             }
         } else {
             double* dst = T + (((size_t)w * NL + 0) * NROW) * Nk + k;
@@ -1280,7 +1264,6 @@ __global__ __launch_bounds__(256, RS_WPS) void resum_mfma_kernel(int Nk, int Nkl
         }
     }
 }
-#undef jg
 
 // The same scheme for Nl = 2 (NIR = 8, Na = 2): the polynomials have degree 7, so the monomials of t = z / RS_ZS are the basis
 // (V8 = identity); the 8 (a, l, l') blocks x 4 slots are 32 rows = two row tiles: tile tau <-> l' = tau, lane group jg <-> (a, l) =

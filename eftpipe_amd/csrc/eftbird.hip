@@ -51,7 +51,9 @@ struct eftb_engine {
     size_t buf_elems[EFTB_B_COUNT] = {0};
     // scratch
     double *SD = nullptr, *Talt = nullptr, *part = nullptr;
-    double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][80][8], per-s records [B][NS][48]
+    double *RSA = nullptr, *RSC = nullptr;  // matrix-core resum: A = Q V8^T [B][80][8] (Nl = 2), per-s records [B][NS][48]
+    double *RSAS = nullptr, *RSAS2 = nullptr;  // Nl = 3: the A operand per s [B][NS][4][64][2] (resum_as_kernel: inputs only), two sets like RSA / RSC
+    hipEvent_t evXY = nullptr, evAS = nullptr;  // X, Y of this run are in place (look-ahead stream); the per-s operand built beside the chain is ready
     double *RSA2 = nullptr, *RSC2 = nullptr;  // second operand set: the look-ahead builds run i+1's operands while run i's resummation reads its own
     hipEvent_t evRsDone[2] = {nullptr, nullptr};  // the resummation that read operand set [slot] has finished
     unsigned rs_step = 0;
@@ -86,8 +88,6 @@ struct eftb_engine {
     int gd_waves = 4;     // waves per workgroup (K split) of gemm_direct_kernel (EFTB_GD_WAVES=2|4)
     int ap_ring = 2;      // knots whose weights ap_rows_kernel keeps in flight (EFTB_AP_RING=2|4)
     bool fuse_cf = true;  // EFTB_FUSE_CF=0: always through regroup_cf_kernel (A/B switch)
-    int resum_wps = 2;    // waves per SIMD resum_mfma_kernel is built for: 2 = basis coefficients in registers (201 VGPRs); EFTB_RESUM_WPS=3 = basis
-                          // coefficients in LDS, tile-by-tile consumption (166 VGPRs) -- measured 4 % slower: the kernel is bound by the DP pipe, not by latency
     double *PA1 = nullptr, *PA2 = nullptr, *PA2T = nullptr, *PA3 = nullptr;  // operand rows of the first-stage GEMMs (prep_rows_kernel)
     double* coefT = nullptr;                 // FFTLog coefficients, cosmology-contiguous [2][129][B]
     double2* SAD = nullptr;                  // anti-diagonal partial sums S[AD_CH][B][nbasis + nbasis13][257]
@@ -274,7 +274,7 @@ static size_t need_table_bytes(const eftb_config& c, int id) {
         case EFTB_T_QPOLY: return c.with_resum ? D * 2 * c.Nl * c.Nl * Nn * 15 : 0;
         case EFTB_T_H: return c.with_resum ? D * c.Na * NS * c.Nk : 0;
         case EFTB_T_RSBASIS: case EFTB_T_RSBASISS: return c.with_resum ? D * RS_NB * 16 : 0;
-        case EFTB_T_RSROWS: return c.with_resum ? sizeof(int32_t) * RS_ROWS : 0;
+        case EFTB_T_RSROWS: return c.with_resum ? sizeof(int32_t) * 2 * RS3_ROWS : 0;  // Nl = 3: X part, Y part per row; Nl = 2: the first 80
         case EFTB_T_MU: case EFTB_T_WMU: return c.with_ap ? D * c.nmu : 0;
         case EFTB_T_LEGMU: return c.with_ap ? D * c.Nl * c.nmu : 0;
         case EFTB_T_SPBAND: return c.with_ap ? D * (size_t)(2 * SPL_HB + 1) * c.Nk : 0;
@@ -471,6 +471,13 @@ static void launch_irfilter(eftb_engine* e, hipStream_t st, int B, bool xy = tru
     hipLaunchKernelGGL(qf_kernel, dim3(B), dim3(256), 0, st, c.Nl * c.Nl * e->Nn, e->buf[EFTB_B_F], tb<double>(e, EFTB_T_QPOLY), e->buf[EFTB_B_Q]);
 }
 
+// per-s A operand of the Nl = 3 resummation from Q(f), X(s), Y(s) (resum_as_kernel)
+static void launch_resum_as(eftb_engine* e, hipStream_t st, int B) {
+    const eftb_config& c = e->c;
+    hipLaunchKernelGGL(resum_as_kernel, dim3(B, 4), dim3(256), 0, st, e->Nn, c.NIR, c.Na, e->buf[EFTB_B_Q], tb<double>(e, EFTB_T_RSBASISS),
+                       tb<int>(e, EFTB_T_RSROWS), e->buf[EFTB_B_XY], e->RSAS);
+}
+
 static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     const eftb_config& c = e->c;
     double** b = e->buf;
@@ -598,6 +605,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                           (!c.with_nnlo || nnlo_inline);
     const bool ap_side = pre_side && e->ap_overlap && e->allow_back && (mask & EFTB_S_RESUM) && (mask & EFTB_S_AP) && (Nl == 3 || !e->generic_resum);
     if (!ap_side) join_back(e);
+    // three-stream runs keep the regrouping and the operand build of the resummation on the look-ahead stream as well: the main stream
+    // then carries nothing but the resummation kernels, back to back
+    const bool ahead = ap_side && e->prep_ahead && e->RSA2;
+    // ... and the per-s A operand of the Nl = 3 resummation (inputs only: Q(f), X, Y) is built on the side stream, off the chain
+    const bool as_side = ahead && Nl == 3 && !e->generic_resum && e->RSAS2;
     const int bslot = e->back_step & 1;  // evBack[bslot] was recorded two runs ago
     const bool xy_in_prep = (mask & EFTB_S_PREP) && (mask & EFTB_S_RESUM) && c.with_resum && !nnlo_pass;  // X, Y ride with the first-stage GEMMs
     // whole-pipeline runs regroup C22 / C13 into the resummation records directly (resum_prep_kernel): no regroup_cf_kernel, no Cloopl
@@ -658,6 +670,14 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             if (xy_in_prep) queue_xy(e, sb, B);
             if (int rc = launch_gemm_direct(st, sb, e->gd_waves)) return rc;
         }
+        if (as_side) {  // behind the AP tables on the side stream; the set written here was last read by the resummation two runs ago
+            if (xy_in_prep && (hipEventRecord(e->evXY, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evXY, 0) != hipSuccess))
+                return fail("eftb_run: stream join failed");
+            std::swap(e->RSAS, e->RSAS2);
+            if (hipStreamWaitEvent(e->side, e->evRsDone[e->rs_step & 1], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            launch_resum_as(e, e->side, B);
+            if (hipEventRecord(e->evAS, e->side) != hipSuccess) return fail("eftb_run: event record failed");
+        }
         if (!pre_side) st = st0;
     }
     // with pre_side the whole front half (first stage, anti-diagonal sums, rows, syntheses, expansions: inputs -> P22, P13, C11, Cct, CC)
@@ -709,9 +729,6 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                                e->YCF, c22 ? tb<double>(e, EFTB_T_EXPC) : nullptr, b[EFTB_B_CC]);
         }
     }
-    // three-stream runs keep the regrouping and the operand build of the resummation on the look-ahead stream as well: the main stream
-    // then carries nothing but the resummation kernels, back to back
-    const bool ahead = ap_side && e->prep_ahead && e->RSA2;
     if (pre_side && !ahead) {
         if (hipEventRecord(e->evPrep, st) != hipSuccess || hipStreamWaitEvent(st_main, e->evPrep, 0) != hipSuccess) return fail("eftb_run: stream join failed");
         st = st_main;
@@ -771,6 +788,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 std::swap(e->RSC, e->RSC2);
                 if (hipStreamWaitEvent(st, e->evRsDone[rslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             }
+            if (full && Nl == 3 && !as_side) launch_resum_as(e, st, B);  // (in line: X, Y, Q(f) are in place behind evJoin)
             if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), rpgrid, dim3(256), 0, st, RP_ARGS);
             else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), rpgrid, dim3(256), 0, st, RP_ARGS);
 #undef RP_ARGS
@@ -779,6 +797,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 return fail("eftb_run: event record failed");
             if (ahead) {
                 if (hipEventRecord(e->evPrep, st) != hipSuccess || hipStreamWaitEvent(st_main, e->evPrep, 0) != hipSuccess) return fail("eftb_run: stream join failed");
+                if (as_side && full && hipStreamWaitEvent(st_main, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream join failed");
                 st = st_main;
             }
             int tslot = -1;
@@ -792,15 +811,13 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             int nsplit = 1;
             while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
             const int schunk = (NS + nsplit - 1) / nsplit;
-#define RM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), \
+#define RM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), Nl == 3 ? e->RSAS : e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), \
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
             const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
             if (kblocks > 0 && Nl == 3 && fused_nnlo)
-                hipLaunchKernelGGL((resum_mfma_kernel<2, true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
-            else if (kblocks > 0 && Nl == 3 && e->resum_wps >= 3)
-                hipLaunchKernelGGL((resum_mfma_kernel<3, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb);
+                hipLaunchKernelGGL((resum_mfma_kernel<true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
             else if (kblocks > 0 && Nl == 3)
-                hipLaunchKernelGGL((resum_mfma_kernel<2, false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb);
+                hipLaunchKernelGGL((resum_mfma_kernel<false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb);
             else if (kblocks > 0) hipLaunchKernelGGL(resum_mfma2_kernel, dim3(kblocks, B, nsplit), dim3(256), 0, st, RM_ARGS);
 #undef RM_ARGS
             if (nsplit > 1)
@@ -1113,6 +1130,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_of("EFTB_SIDE_PRIO", 0)));
     HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_of("EFTB_PRE_PRIO", prio_hi)));
     HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evXY, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evAS, hipEventDisableTiming));
     if (const char* f = getenv("EFTB_AP_OVERLAP")) e->ap_overlap = atoi(f) != 0;
     {
         int bp = prio_lo;  // measured: 290 k evaluations/s with the back half at low priority, 286 k at high, 278 k without the stream
@@ -1181,7 +1200,6 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AP_RING")) e->ap_ring = atoi(f);
     if (const char* f = getenv("EFTB_AD_WAVES")) e->ad_waves = atoi(f);
     if (const char* f = getenv("EFTB_GD_WAVES")) e->gd_waves = atoi(f);
-    if (const char* f = getenv("EFTB_RESUM_WPS")) e->resum_wps = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 2 * (eftb_engine::NSETS + 1) * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 2 * (eftb_engine::NSETS + 1) * sizeof(int));
@@ -1235,10 +1253,15 @@ int eftb_finalize(eftb_engine* e) {
             HIPCHK(hipMemset(e->ZC2, 0, e->buf_elems[EFTB_B_CLOOPL] * sizeof(double)));
         }
         {
-            HIPCHK(hipMalloc(&e->RSA, (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double)));
-            HIPCHK(hipMalloc(&e->RSC, (size_t)c.max_batch * NS * RS_REC * sizeof(double)));
-            HIPCHK(hipMalloc(&e->RSA2, (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double)));
-            HIPCHK(hipMalloc(&e->RSC2, (size_t)c.max_batch * NS * RS_REC * sizeof(double)));
+            const size_t abytes = (size_t)c.max_batch * RS_ROWS * RS_NB * sizeof(double);
+            HIPCHK(hipMalloc(&e->RSA, abytes));
+            HIPCHK(hipMalloc(&e->RSC, ((size_t)c.max_batch * NS + RS_PF) * RS_REC * sizeof(double)));
+            HIPCHK(hipMalloc(&e->RSA2, abytes));
+            if (c.Nl == 3) {  // one operand per s
+                HIPCHK(hipMalloc(&e->RSAS, ((size_t)c.max_batch * NS + RS_PF) * RS3_AS * sizeof(double)));
+                HIPCHK(hipMalloc(&e->RSAS2, ((size_t)c.max_batch * NS + RS_PF) * RS3_AS * sizeof(double)));
+            }
+            HIPCHK(hipMalloc(&e->RSC2, ((size_t)c.max_batch * NS + RS_PF) * RS_REC * sizeof(double)));
         }
     }
     // opt in to the large dynamic LDS tiles
@@ -1459,7 +1482,7 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->RSA2, e->RSC2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->TaltN, e->T3N, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->RSA, e->RSC, e->RSA2, e->RSC2, e->RSAS, e->RSAS2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->TaltN, e->T3N, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
@@ -1471,7 +1494,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1], e->evRsDone[0], e->evRsDone[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evXY, e->evAS, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1], e->evRsDone[0], e->evRsDone[1]}) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->evRun) if (ev) (void)hipEventDestroy(ev);
     for (int t = 0; t < eftb_engine::NTIMER; ++t) {
         if (e->evT0[t]) (void)hipEventDestroy(e->evT0[t]);

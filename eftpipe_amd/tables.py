@@ -472,7 +472,8 @@ def build_tables(cfg: EngineConfig, loop_cache=None) -> dict:
 # ----------------------------------------------------------------------------- IR-resummation on the matrix cores
 RS_ZS = 8.0     # the polynomials are evaluated in t = k^2 X / RS_ZS (must match csrc/eftb_kernels.hpp RS_ZS)
 RS_NB = 8       # dimension of the span of all resummation polynomials
-RS_ROWS = 80    # 5 MFMA row tiles x 16
+RS_ROWS = 80    # Nl = 2: row table length (two MFMA row tiles used)
+RS3_ROWS = 64   # Nl = 3: four MFMA row tiles x 16
 
 
 def resum_mfma_tables(Qpoly, NIR, Na):
@@ -481,16 +482,23 @@ def resum_mfma_tables(Qpoly, NIR, Na):
     Every polynomial  sum_p Q_a[l,l',(half,p,v)](f) z^p  of the IR-resummation (there are 108 per cosmology, degree 15)
     lies, for every f, in one fixed 8-dimensional space: q_p (p+1)! (-2)^(p+1) is a degree-7 polynomial in p.  With an
     orthonormal basis V8 of that space (in the scaled variable t = z / RS_ZS) the polynomials of all rows at 16 (k, s) points
-    become one [80 x 8] x [8 x 16] matrix product on the FP64 matrix cores, A = Q . diag(RS_ZS^p) . V8^T.
+    become one [rows x 8] x [8 x 16] matrix product on the FP64 matrix cores, A = Q . diag(RS_ZS^p) . V8^T.
 
-    Row layout (tile tau, row i):  chunk = (tau, i % 4), slot = i // 4  -- exactly the 4 values a lane holds of one
-    v_mfma_f64_16x16x4 result (rows (lane >> 4) + 4 q).  The 18 (a, l, l') blocks fill 18 of the 20 chunks of 5 tiles:
-    tau < 3: l' = tau and i % 4 = 0, 1, 2 -> (a = 1, l = i % 4), 3 -> (a = 0, l = 0);  tau = 3: i % 4 = 0, 1, 2 -> (a = 0, l = 1,
-    l' = i % 4), 3 -> (a = 0, l = 2, l' = 0);  tau = 4: i % 4 = 0, 1 -> (a = 0, l = 2, l' = 1 + i % 4), 2, 3 -> unused.
-    Slots: 0 -> (v = l', half 0) [the X^(p+1) series only couples v = l'],  1..3 -> (v = slot - 1, half 1).
+    The kernel's operand is built PER s (resum_as_kernel, from the inputs alone): the weight of an (a, l, l') block is
+        W = k^2 sum_v H_v(k,s) [ delta(v,l') X(s) D(half 0, v) + Y(s) D(half 1, v) ]
+    (the X^(p+1) series only couples v = l'), and D is linear in the rows of A, so X(s), Y(s) are folded into the rows:
+        A_s[row] = X(s) A[half 0, v = l'] delta(v,l') + Y(s) A[half 1, v]
+    THREE rows (v = 0, 1, 2) per block instead of four: 18 blocks = 54 rows fit four row tiles (ten MFMAs per step became eight, and
+    the lanes no longer form z H, y H products or select between roles).
 
-    -> rs_basis [8,16] (V8), rs_basis_scaled [8,16] (V8 diag(RS_ZS^p)), rs_rows int32[80] (offset of the row's p = 0
-       coefficient inside one cosmology's Q block [2,Nl,Nl,Nn], stride Na per p; -1 = zero row)."""
+    Row layout (tile tau, row i):  lane group jg = i % 4, slot = i // 4  -- the 4 values a lane holds of one v_mfma_f64_16x16x4
+    result (rows (lane >> 4) + 4 q).
+      tau < 3, jg < 3:  slots 0-2 -> (a = 1, l = jg, l' = tau), v = slot;   slot 3 -> (a = 0, l = 1, l' = tau), v = jg
+      tau < 3, jg = 3:  slots 0-2 -> (a = 0, l = 0, l' = tau), v = slot;   slot 3 -> zero
+      tau = 3, jg < 3:  slots 0-2 -> (a = 0, l = 2, l' = jg),  v = slot;   slot 3 -> zero;   jg = 3 -> zero
+
+    -> rs_basis [8,16] (V8), rs_basis_scaled [8,16] (V8 diag(RS_ZS^p)), rs_rows int32[2 * 64]: per row the offset of the p = 0
+       coefficient of its X part and of its Y part inside one cosmology's Q block [2,Nl,Nl,Nn] (stride Na per p; -1 = none)."""
     if NIR == 8:
         return _resum_mfma_tables_nl2(Qpoly, NIR, Na)
     Nl = 3
@@ -503,28 +511,38 @@ def resum_mfma_tables(Qpoly, NIR, Na):
     if sv[RS_NB] > 1e-13 * sv[0]:
         raise ValueError(f"resummation polynomials do not span {RS_NB} dimensions (sv ratio {sv[RS_NB] / sv[0]:.2e})")
     V8 = np.ascontiguousarray(Vt[:RS_NB])
-    rows = np.full(RS_ROWS, -1, dtype=np.int32)
+    rows = np.full((2, RS3_ROWS), -1, dtype=np.int32)
     used = np.zeros((2, Nl, Nl, 2, Na), dtype=bool)                     # a (device convention), l, l', half, v
-    for tau in range(5):
+    for tau in range(4):
         for i in range(16):
             jg, slot = i % 4, i // 4
-            if tau < 3:
-                lp = tau
-                a, l = (1, jg) if jg < 3 else (0, 0)
-            elif tau == 3:
-                a, l, lp = ((0, 1, 0), (0, 2, 0), (0, 1, 1), (0, 2, 1))[jg]
-            elif jg < 2:
-                a, l, lp = 0, 1 + jg, 2
-            else:
+            blk = resum_block(tau, jg, slot)
+            if blk is None:
                 continue
-            v, half = (lp, 0) if slot == 0 else (slot - 1, 1)
-            rows[16 * tau + i] = ((a * Nl + l) * Nl + lp) * NN + half * NIR * Na + v
-            used[a, l, lp, half, v] = True
+            a, l, lp, v = blk
+            base = ((a * Nl + l) * Nl + lp) * NN
+            r = 16 * tau + i
+            if v == lp:
+                rows[0, r] = base + v
+                used[a, l, lp, 0, v] = True
+            rows[1, r] = base + NIR * Na + v
+            used[a, l, lp, 1, v] = True
     # device Q[a] = table[1 - a] (reference pybird.py:1374-1376): every nonzero polynomial must have a row
     nz = np.abs(Qr).max(axis=(4, 6)) > 0                                 # table, l, l', half, v
     if np.any(nz[::-1] & ~used):
         raise ValueError("resummation table has entries outside the (v = l' | half 1) slot pattern")
-    return dict(rs_basis=V8, rs_basis_scaled=np.ascontiguousarray(V8 * scale[None, :]), rs_rows=rows)
+    return dict(rs_basis=V8, rs_basis_scaled=np.ascontiguousarray(V8 * scale[None, :]), rs_rows=rows.reshape(-1))
+
+
+def resum_block(tau, jg, slot):
+    """(a, l, l', v) of row (tile tau, lane group jg, slot) of the Nl = 3 resummation operand, or None for a zero row."""
+    if tau < 3 and jg < 3:
+        return (1, jg, tau, slot) if slot < 3 else (0, 1, tau, jg)
+    if tau < 3:
+        return (0, 0, tau, slot) if slot < 3 else None
+    if jg < 3 and slot < 3:
+        return (0, 2, jg, slot)
+    return None
 
 
 def _resum_mfma_tables_nl2(Qpoly, NIR, Na):
@@ -552,6 +570,7 @@ def _resum_mfma_tables_nl2(Qpoly, NIR, Na):
     nz = np.abs(Qr).max(axis=(4, 6)) > 0
     if np.any(nz[::-1] & ~used):
         raise ValueError("resummation table has entries outside the (v = l' | half 1) slot pattern")
+    rows = np.concatenate([rows, np.full(2 * RS3_ROWS - RS_ROWS, -1, dtype=np.int32)])  # one table size for both kernels
     return dict(rs_basis=V8, rs_basis_scaled=np.ascontiguousarray(V8 * scale[None, :]), rs_rows=rows)
 
 

@@ -133,8 +133,9 @@ def resum(t, f, Pin, st):
 
 def resum_mfma(t, f, Pin, st):
     """The matrix-core form of the same stage (device: resum_prep_kernel + resum_mfma_kernel / resum_mfma2_kernel): polynomials as
-    A[80 | 32 rows, 8] x beta[8, points] in t = z / RS_ZS, rows laid out as (tile, chunk, slot) -- see tables.resum_mfma_tables."""
-    from eftpipe_amd.tables import RS_ZS
+    A[rows, 8] x beta[8, points] in t = z / RS_ZS.  Nl = 3: the operand is built per s with X(s), Y(s)
+    folded into its rows, three rows per (a, l, l') block, 64 rows; Nl = 2: 32 rows of four slots -- see tables.resum_mfma_tables."""
+    from eftpipe_amd.tables import RS_ZS, resum_block
 
     NIR, Na, Nklow = t["resum_dims"]
     Nl = 3 if NIR == 16 else 2
@@ -143,36 +144,53 @@ def resum_mfma(t, f, Pin, st):
     X, Y = ir_filters(t, Pin)
     z = k[:, None] ** 2 * X[None, :]
     yk = k[:, None] ** 2 * Y[None, :]
-    rows = t["rs_rows"]
-    A = np.zeros((80, 8))
-    for r in np.nonzero(rows >= 0)[0]:
-        A[r] = t["rs_basis_scaled"][:, :NIR] @ Q[rows[r] + np.arange(NIR) * Na]
     tt = z / RS_ZS
     beta = np.einsum("rp,pks->rks", t["rs_basis"][:, :NIR], np.stack([tt**p for p in range(NIR)]))  # [8,Nk,Ns]
-    D = np.einsum("ir,rks->iks", A, beta).reshape(5, 4, 4, *z.shape)  # [tau, slot, jg, k, s]
     H = t["H"]
     out = {n: st[n].copy() for n in ("P11l", "Pctl", "Ploopl")}
-    for tau in range(5 if Nl == 3 else 2):
-        for jg in range(4):
-            if Nl == 2:
+    if Nl == 3:
+        rows = t["rs_rows"].reshape(2, 64)
+        V8S = t["rs_basis_scaled"][:, :NIR]
+        aX, aY = np.zeros((64, 8)), np.zeros((64, 8))
+        for r in range(64):
+            if rows[0, r] >= 0:
+                aX[r] = V8S @ Q[rows[0, r] + np.arange(NIR) * Na]
+            if rows[1, r] >= 0:
+                aY[r] = V8S @ Q[rows[1, r] + np.arange(NIR) * Na]
+        As = aX[:, :, None] * X[None, None, :] + aY[:, :, None] * Y[None, None, :]  # [64,8,Ns]
+        D = np.einsum("irs,rks->iks", As, beta).reshape(4, 4, 4, *z.shape)  # [tau, slot, jg, k, s]
+        k2 = k[:, None] ** 2
+        for tau in range(4):
+            for jg in range(4):
+                for slot in range(4):
+                    blk = resum_block(tau, jg, slot)
+                    if blk is None:
+                        assert not np.any(D[tau, slot, jg])
+                        continue
+                    a, l, lp, v = blk
+                    W = k2 * H[v] * D[tau, slot, jg]  # [Nk,Ns]
+                    if a == 0:
+                        out["P11l"][l] += np.einsum("ks,s,i->ik", W, st["C11"][lp], t["l11"][lp])
+                    else:
+                        out["Pctl"][l] += np.einsum("ks,s,i->ik", W, st["Cct"][lp], t["lct"][lp])
+                        out["Ploopl"][l] += np.einsum("ks,is->ik", W, st["Cloopl"][lp])
+    else:
+        rows = t["rs_rows"]
+        A = np.zeros((80, 8))
+        for r in np.nonzero(rows[:80] >= 0)[0]:
+            A[r] = t["rs_basis_scaled"][:, :NIR] @ Q[rows[r] + np.arange(NIR) * Na]
+        D = np.einsum("ir,rks->iks", A, beta).reshape(5, 4, 4, *z.shape)  # [tau, slot, jg, k, s]
+        for tau in range(2):
+            for jg in range(4):
                 lp = tau
                 a, l = ((1, 0), (1, 1), (0, 0), (0, 1))[jg]
-            elif tau < 3:
-                lp = tau
-                a, l = (1, jg) if jg < 3 else (0, 0)
-            elif tau == 3:
-                a, l, lp = ((0, 1, 0), (0, 2, 0), (0, 1, 1), (0, 2, 1))[jg]
-            elif jg < 2:
-                a, l, lp = 0, 1 + jg, 2
-            else:
-                continue
-            d = D[tau, :, jg]
-            W = z * H[lp] * d[0] + yk * (H[0] * d[1] + H[1] * d[2] + (H[2] * d[3] if Na == 3 else 0.0))  # [Nk,Ns]
-            if a == 0:
-                out["P11l"][l] += np.einsum("ks,s,i->ik", W, st["C11"][lp], t["l11"][lp])
-            else:
-                out["Pctl"][l] += np.einsum("ks,s,i->ik", W, st["Cct"][lp], t["lct"][lp])
-                out["Ploopl"][l] += np.einsum("ks,is->ik", W, st["Cloopl"][lp])
+                d = D[tau, :, jg]
+                W = z * H[lp] * d[0] + yk * (H[0] * d[1] + H[1] * d[2])  # [Nk,Ns]
+                if a == 0:
+                    out["P11l"][l] += np.einsum("ks,s,i->ik", W, st["C11"][lp], t["l11"][lp])
+                else:
+                    out["Pctl"][l] += np.einsum("ks,s,i->ik", W, st["Cct"][lp], t["lct"][lp])
+                    out["Ploopl"][l] += np.einsum("ks,is->ik", W, st["Cloopl"][lp])
     out = dict(st, **out)
     out["X"], out["Y"] = X, Y
     return out
