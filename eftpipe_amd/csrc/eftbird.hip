@@ -634,6 +634,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         if (pre_side) {
             st = e->pre;
             if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            // (X, Y of the previous run are also read by its operand build on the side stream, which evInFree does not cover)
+            if (as_side && hipStreamWaitEvent(st, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             // the input-only kernels (IR filters / Q(f); AP prefix sums and knot weights) get their own low-priority stream beside the front
             // half: X, Y, Q are free since the previous run built its resummation operands (evInFree); the AP tables alternate between two
             // sets because the previous run's AP reads its own late (the set written here was last read two runs ago: evBack)
@@ -656,8 +658,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // operand rows, then every first-stage product in one launch on the matrix cores: P11, the FFTLog coefficients (and their
         // cosmology-contiguous transpose for the anti-diagonal pass), the second coefficient set of IRcutoff "loop" / "resum" (reference
         // pybird.py:1151-1160), and X(s), Y(s) when a resummation follows in this run
-        launch_prep_rows(e, st, B, true, xy_in_prep);
-        {
+        static const int whatif = getenv("EFTB_WHATIF") ? atoi(getenv("EFTB_WHATIF")) : 0;  // timing experiments only (results are those of an earlier step)
+        if (!((whatif & 1) && pre_side && e->rs_step > 4)) launch_prep_rows(e, st, B, true, xy_in_prep);
+        if (!((whatif & 1) && pre_side && e->rs_step > 4)) {
             SynthBatch sb{};
             const int KP1 = (int)kpad(c.Nkin), KP2 = (int)kpad(c.Nkin + c.ntail);
             queue_synth(sb, e->PA1, 0, 1, B, KP1, tb<double>(e, EFTB_T_SKT), Nk, b[EFTB_B_P11], 0, nullptr, nullptr);
@@ -692,7 +695,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         if (mask & EFTB_S_LOOPS) sets |= 0x4;
         if (mask & (EFTB_S_CF | EFTB_K_C22)) sets |= 0x2;
         if (mask & EFTB_S_CF) sets |= 0x8;
-        if (!c.dual_coef) {
+        static const int whatif2 = getenv("EFTB_WHATIF") ? atoi(getenv("EFTB_WHATIF")) : 0;
+        if ((whatif2 & 2) && pre_side && e->rs_step > 4) {
+        } else if (!c.dual_coef) {
             if (int rc = launch_antidiag_rows(e, st, B, sets, b[EFTB_B_COEF], e->coefT)) return rc;
         } else {  // k-space rows from the first coefficient set, xi-space rows from the second (the sums are recomputed in between)
             if (sets & 0x5)
