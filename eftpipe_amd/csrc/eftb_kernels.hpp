@@ -724,6 +724,55 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 }
 
 
+// Direct-P_l runs (EFTB_O_PLK_DIRECT): the bias contraction P_l = sum_row b_row T[l][row] commutes with every stage behind the regrouping
+// (resummation, AP: linear maps that act on each template row alike), so it is taken FIRST: one row per multipole instead of 24 goes through
+// them.  This kernel is regroup_kernel with the contraction in its epilogue (reference pybird.py:737-866 followed by parambasis.py:42-136):
+// row 0 of the template block takes sum_row b_row T[l][row] over the rows the AP stage distorts (rows < 21, all rows when stoch0), rows
+// 21-23 the stochastic templates as always; rows 1-20 of the block are not written.
+__global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ fgrow,
+                                                          const double* __restrict__ P11, const double* __restrict__ P22,
+                                                          const double* __restrict__ P13, const double* __restrict__ l11,
+                                                          const double* __restrict__ lct, const double* __restrict__ l22,
+                                                          const double* __restrict__ l13, const int* __restrict__ grp,
+                                                          const double* __restrict__ bias, double* __restrict__ T, int stoch0) {
+    __shared__ double cf[38];  // b_group f^power mu-weight per piece
+    __shared__ double p0[38];  // the pieces at the first k (shot-noise subtraction, reference pybird.py:799-800)
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
+    const double f = fgrow[w];
+    const double* bw = bias + (size_t)w * NROW;
+    for (int b = threadIdx.x; b < 38; b += blockDim.x) {
+        cf[b] = bw[9 + grp[2 * b]] * ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
+        p0[b] = b < 28 ? P22[((size_t)w * 28 + b) * Nk] : P13[((size_t)w * 10 + (b - 28)) * Nk];
+    }
+    __syncthreads();
+    if (k >= Nk) return;
+    const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
+    const double* q22 = P22 + (size_t)w * 28 * Nk + k;
+    const double* q13 = P13 + (size_t)w * 10 * Nk + k;
+    double b11 = 0.0, bct = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) b11 = fma(bw[r], l11[l * 3 + r], b11);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) bct = fma(bw[3 + r], lct[l * 6 + r], bct);
+    double a0 = (b11 + bct * kv * kv) * p11, a1 = 0.0;  // two chains over the 38 pieces
+    for (int b = 0; b < 28; b += 2) {
+        a0 = fma(cf[b], q22[(size_t)b * Nk] - p0[b], a0);
+        a1 = fma(cf[b + 1], q22[(size_t)(b + 1) * Nk] - p0[b + 1], a1);
+    }
+    for (int b = 0; b < 10; b += 2) {
+        a0 = fma(cf[28 + b], q13[(size_t)b * Nk] - p0[28 + b], a0);
+        a1 = fma(cf[29 + b], q13[(size_t)(b + 1) * Nk] - p0[29 + b], a1);
+    }
+    const double s21 = l == 0 ? 1.0 : 0.0, s22 = l == 0 ? kv * kv : 0.0, s23 = l == 1 ? kv * kv : 0.0;
+    double tot = a0 + a1;
+    if (stoch0) tot += bw[21] * s21 + bw[22] * s22 + bw[23] * s23;  // APst: the stochastic templates are distorted with the others
+    double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
+    t[0] = tot;
+    t[(size_t)21 * Nk] = s21;
+    t[(size_t)22 * Nk] = s22;
+    t[(size_t)23 * Nk] = s23;
+}
+
 // optiresum: the BAO peak of every xi piece (one workgroup = one series of 80 s slots; reference pybird.py:1382-1400)
 __global__ __launch_bounds__(128) void extract_bao_kernel(const double* __restrict__ bao, const double* __restrict__ in, double* __restrict__ out) {
     const int s = threadIdx.x;
@@ -1265,6 +1314,157 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// IR-resummation of direct-P_l runs (EFTB_O_PLK_DIRECT; Nl = 3).  With the bias contraction taken first the correction of P_l is
+//     dP_l(k) = k^2 sum_s sum_v H_v(k,s) D_lv(k^2 X(s) / RS_ZS; s),
+//     D_lv(t; s) = sum_p t^p RS_ZS^p sum_l' sum_a g_a[l'](s) ( delta(v,l') X(s) Q_a[l,l',(0,p,v)] + Y(s) Q_a[l,l',(1,p,v)] ),
+//     g_0[l'](s) = C11[l'](s) sum_i b_i l11[l'][i],    g_1[l'](s) = Cct[l'](s) sum_i b_3+i lct[l'][i] + sum_i b_9+i Cloopl[l'][i](s)
+// (reference pybird.py:1413-1464 contracted with parambasis.py:42-136): nine polynomials of degree 15 per s whose coefficients are the same
+// for every k -- scalar operands.  resum_prep_plk_kernel builds them per cosmology (CF[w][s][160]: [l][v][p], then X(s) / RS_ZS), with
+// the regrouping of C22 / C13 into Cloopl (pybird.py:805-846) folded into g_1; resum_plk_kernel is one wave = (64 k, one l): per s three
+// Horner chains with scalar coefficients and three FMAs -- 49 FP64 vector instructions per (64 k, l, s), no matrix cores (nine rows would
+// leave a 16-row tile half empty and the basis polynomials would cost more than the Horner chains).
+// ------------------------------------------------------------------------------------------------
+constexpr int RSD_REC = 160;  // doubles per (cosmology, s): 9 x 16 coefficients, X / RS_ZS, pad
+
+__global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, int Na, const double* __restrict__ Q, const double* __restrict__ XY,
+                                                             const double* __restrict__ C11, const double* __restrict__ Cct,
+                                                             const double* __restrict__ CC, const double* __restrict__ fgrow,
+                                                             const double* __restrict__ l11, const double* __restrict__ lct,
+                                                             const double* __restrict__ l22, const double* __restrict__ l13,
+                                                             const int* __restrict__ grp, const double* __restrict__ bias, double* __restrict__ CF) {
+    constexpr int NL = 3;
+    const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+    const double* q = Q + (size_t)w * 2 * NL * NL * NN;
+    const double* bw = bias + (size_t)w * NROW;
+    __shared__ double s_cf[NL * 38];      // b_group f^power mu-weight per piece and l'
+    __shared__ double s_g[2][NL][NS];     // g_a[l'](s)
+    __shared__ double s_b[2][NL];         // sum_i b_i l11[l'][i], sum_i b_3+i lct[l'][i]
+    const double f = fgrow[w];
+    for (int e = threadIdx.x; e < NL * 38; e += blockDim.x) {
+        const int lp = e / 38, bq = e % 38;
+        s_cf[e] = bw[9 + grp[2 * bq]] * ipow(f, grp[2 * bq + 1]) * (bq < 28 ? l22[lp * 28 + bq] : l13[lp * 10 + (bq - 28)]);
+    }
+    if (threadIdx.x < 2 * NL) {
+        const int a = threadIdx.x / NL, lp = threadIdx.x % NL;
+        double v = 0.0;
+        if (a == 0)
+            for (int r = 0; r < 3; ++r) v = fma(bw[r], l11[lp * 3 + r], v);
+        else
+            for (int r = 0; r < 6; ++r) v = fma(bw[3 + r], lct[lp * 6 + r], v);
+        s_b[a][lp] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * NL * NS; e += blockDim.x) {
+        const int s = e % NS, lp = (e / NS) % NL, a = e / (NL * NS);  // s fastest: coalesced reads of the s-major inputs
+        double v;
+        if (a == 0) {
+            v = C11[((size_t)w * NL + lp) * NS + s] * s_b[0][lp];
+        } else {
+            const double* cc = CC + (size_t)w * NL * 38 * NS;
+            double v0 = Cct[((size_t)w * NL + lp) * NS + s] * s_b[1][lp], v1 = 0.0;
+            for (int b = 0; b < 28; b += 2) {
+                v0 = fma(s_cf[lp * 38 + b], cc[(size_t)(lp * 28 + b) * NS + s], v0);
+                v1 = fma(s_cf[lp * 38 + b + 1], cc[(size_t)(lp * 28 + b + 1) * NS + s], v1);
+            }
+            for (int b = 0; b < 10; b += 2) {
+                v0 = fma(s_cf[lp * 38 + 28 + b], cc[(size_t)(NL * 28 + lp * 10 + b) * NS + s], v0);
+                v1 = fma(s_cf[lp * 38 + 29 + b], cc[(size_t)(NL * 28 + lp * 10 + b + 1) * NS + s], v1);
+            }
+            v = v0 + v1;
+        }
+        s_g[a][lp][s] = v;
+    }
+    __syncthreads();
+    const double* xy = XY + (size_t)w * 2 * NS;
+    double* dst = CF + (size_t)w * NS * RSD_REC;
+    for (int idx = part * blockDim.x + threadIdx.x; idx < NS * RSD_REC; idx += nparts * blockDim.x) {
+        const int s = idx / RSD_REC, c = idx % RSD_REC;
+        double v = 0.0;
+        if (c < 144) {
+            const int l = c / 48, vv = (c / 16) % 3, p = c % 16;
+            const double x = xy[s], y = xy[NS + s];
+            if (p < NIR) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {  // device Q[a]: 0 = the C11 series, 1 = the Cct / Cloopl series
+#pragma unroll
+                    for (int lp = 0; lp < NL; ++lp) {
+                        const double* qq = q + ((a * NL + l) * NL + lp) * NN + p * Na + vv;
+                        double term = y * qq[NIR * Na];
+                        if (lp == vv) term = fma(x, qq[0], term);
+                        v = fma(s_g[a][lp][s], term, v);
+                    }
+                }
+                v = ldexp(v, 3 * p);  // RS_ZS^p, RS_ZS = 8
+            }
+        } else if (c == 144) {
+            v = xy[s] * (1.0 / RS_ZS);
+        }
+        dst[idx] = v;
+    }
+}
+
+// FP64 vector operations with one scalar (wave-uniform) operand, spelled out
+__device__ __forceinline__ double sop_fma(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double sop_mul(double a, double c) {
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double sop_add(double a, double c) {
+    double r;
+    asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void resum_plk_kernel(int Nk, int Nklow, const double* __restrict__ kk, const double* __restrict__ H,
+                                                        const double* __restrict__ CF, double* __restrict__ T, int nkb) {
+    constexpr int NL = 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // workgroup -> (k block of 256, l, cosmology); the 3 nkb workgroups of a cosmology sit on one XCD (its coefficient table passes through one L2)
+    int t3, w;
+    xcd_decode(nkb * NL, t3, w);
+    const int kb = t3 / NL, l = t3 % NL;
+    const int k = (kb * 4 + wave) * 64 + lane;
+    const int kc = k < Nklow ? Nklow : (k < Nk ? k : Nk - 1);  // lanes outside [Nklow, Nk) compute on a clamped k and store nothing
+    const double k2 = kk[kc] * kk[kc];
+    const double* cf = CF + (size_t)w * NS * RSD_REC + l * 48;  // wave-uniform: scalar loads
+    const char* Hb = reinterpret_cast<const char*>(H);
+    const unsigned hrow = (unsigned)NS * (unsigned)Nk * 8u, hstep = (unsigned)Nk * 8u;
+    unsigned hoff = (unsigned)kc * 8u;
+    double acc = 0.0;
+    double h[3];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) h[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
+    for (int s = 0; s < NS; ++s) {
+        const bool more = s + 1 < NS;
+        hoff += more ? hstep : 0u;
+        double hn[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) hn[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
+        const double t = k2 * cf[144 - l * 48];
+        // Horner with the coefficients as SCALAR addends (v_fma_f64 v, v, v, s: left to itself hipcc picks v_fmac_f64 and moves every
+        // coefficient into a vector register pair first -- 90 moves per step)
+        double d[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) d[v] = sop_add(sop_mul(t, cf[v * 16 + 15]), cf[v * 16 + 14]);
+#pragma unroll
+        for (int p = 13; p >= 0; --p)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) d[v] = sop_fma(d[v], t, cf[v * 16 + p]);
+        acc = fma(h[0], d[0], fma(h[1], d[1], fma(h[2], d[2], acc)));
+        cf += RSD_REC;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) h[v] = hn[v];
+    }
+    if (k >= Nk || k < Nklow) return;
+    T[(((size_t)w * NL + l) * NROW) * Nk + k] += k2 * acc;
+}
+
 // The same scheme for Nl = 2 (NIR = 8, Na = 2): the polynomials have degree 7, so the monomials of t = z / RS_ZS are the basis
 // (V8 = identity); the 8 (a, l, l') blocks x 4 slots are 32 rows = two row tiles: tile tau <-> l' = tau, lane group jg <-> (a, l) =
 // (1, 0), (1, 1), (0, 0), (0, 1); slots 0 -> (v = l', half 0), 1, 2 -> (v = slot - 1, half 1), 3 -> empty.  Four MFMAs per step, every
@@ -1567,7 +1767,9 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
                                                        const double* __restrict__ T, const double* __restrict__ S, double* __restrict__ Tout,
                                                        const int4* __restrict__ META, const double* __restrict__ bias, double* __restrict__ Plk,
                                                        double* __restrict__ PlkHost, int msplit, int* __restrict__ nonfinite,
-                                                       const double* __restrict__ LOCAL) {
+                                                       const double* __restrict__ LOCAL, int direct0) {
+    // direct0 >= 0 (direct-P_l runs, see regroup_plk_kernel): rows [rlo, nr) are already contracted (weight 1), of the rows outside only
+    // those from direct0 on (the stochastic templates) enter the sum, and no template block is written (Tout = null)
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
@@ -1586,13 +1788,14 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
     for (int l = 0; l < NL; ++l) ch0[l] = ch1[l] = 0.0;
     const double* bw = bias ? bias + (size_t)w * NROW : nullptr;
     for (int r = 0; r < NROW; ++r) {
-        const double br = bw ? bw[r] : 0.0;
+        const double br = bw ? (direct0 >= 0 && r >= rlo && r < nr ? 1.0 : bw[r]) : 0.0;
         if (r >= nr || r < rlo) {  // rows outside [rlo, nr) are copied through
+            if (direct0 >= 0 && r < direct0) continue;
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
                 const double v = T[o];
-                Tout[o] = v;
+                if (Tout) Tout[o] = v;
                 if (r < msplit) ch0[l] = fma(br, v, ch0[l]); else ch1[l] = fma(br, v, ch1[l]);
             }
             continue;
@@ -1643,7 +1846,7 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const double v = c * acc[l];
-            Tout[(((size_t)w * NL + l) * NROW + r) * Nk + k] = v;
+            if (Tout) Tout[(((size_t)w * NL + l) * NROW + r) * Nk + k] = v;
             if (r < msplit) ch0[l] = fma(br, v, ch0[l]); else ch1[l] = fma(br, v, ch1[l]);
         }
     }
@@ -1968,7 +2171,9 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
                                                           const int* __restrict__ I0, const int4* __restrict__ META,
                                                           const double* __restrict__ T, const double* __restrict__ C,
                                                           double* __restrict__ Tout, const double* __restrict__ bias, double* __restrict__ Plk,
-                                                          double* __restrict__ PlkHost, int* __restrict__ nonfinite) {
+                                                          double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0) {
+    // direct0 >= 0 (direct-P_l runs, see regroup_plk_kernel): rows [rlo, nr) are already contracted (weight 1), of the rows outside only
+    // those from direct0 on (the stochastic templates) enter the sum, and no template block is written (Tout = null)
     constexpr int NP = NL * NL;
     constexpr int nre = 2 * NH;  // window rows: [rlo, nr) rounded up to whole load instructions (host: nr - rlo <= nre, rlo + nre <= NROW)
     __shared__ double win[NL * nre * APW_WIN];
@@ -2058,21 +2263,21 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
     double a = 0.0;
     if (live) {
         const int hlo = half ? msplit : 0, hhi = half ? NROW : msplit;  // this half's share of the NROW rows in the contraction
-        for (int r = hlo; r < min(q0, hhi); ++r) {
+        for (int r = max(hlo, direct0); r < min(q0, hhi); ++r) {
             const double v = T[obase + (size_t)r * Nk];
-            Tout[obase + (size_t)r * Nk] = v;
+            if (Tout) Tout[obase + (size_t)r * Nk] = v;
             if (bw) a = fma(bw[r], v, a);
         }
 #pragma unroll
         for (int q = 0; q < NH; ++q)
             if (q < cnt) {
                 const double v = c * acc[q];
-                Tout[obase + (size_t)(q0 + q) * Nk] = v;
-                if (bw) a = fma(bw[q0 + q], v, a);
+                if (Tout) Tout[obase + (size_t)(q0 + q) * Nk] = v;
+                if (bw) a = fma(direct0 >= 0 ? 1.0 : bw[q0 + q], v, a);
             }
-        for (int r = max(q1, hlo); r < hhi; ++r) {
+        for (int r = max(max(q1, hlo), direct0); r < hhi; ++r) {
             const double v = T[obase + (size_t)r * Nk];
-            Tout[obase + (size_t)r * Nk] = v;
+            if (Tout) Tout[obase + (size_t)r * Nk] = v;
             if (bw) a = fma(bw[r], v, a);
         }
     }

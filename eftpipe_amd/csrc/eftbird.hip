@@ -162,6 +162,7 @@ struct eftb_engine {
     // follows off the critical path; only the few KB of f / DA / H / bias are waited for, copied on the compute queue itself), and P_l is
     // written to mapped host memory by the kernel that forms it (no DMA phase).  (Measured and dropped: the AP tables beside the resummation
     // instead of beside the loop chain -- the chain gained 20 us, the resummation lost 39.)
+    bool plk_direct = false;            // EFTB_O_PLK_DIRECT: whole-pipeline runs that end in REDUCE contract with the bias first (regroup_plk_kernel)
     bool latency_auto = true;           // EFTB_LATENCY_MODE=0 disables
     bool set_latency[NSETS] = {};
     hipEvent_t evStagedAll[NSETS] = {};  // the whole staging block of a set has been uploaded (evStaged: the part its first kernels wait for)
@@ -608,8 +609,6 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     // three-stream runs keep the regrouping and the operand build of the resummation on the look-ahead stream as well: the main stream
     // then carries nothing but the resummation kernels, back to back
     const bool ahead = ap_side && e->prep_ahead && e->RSA2;
-    // ... and the per-s A operand of the Nl = 3 resummation (inputs only: Q(f), X, Y) is built on the side stream, off the chain
-    const bool as_side = ahead && Nl == 3 && !e->generic_resum && e->RSAS2;
     const int bslot = e->back_step & 1;  // evBack[bslot] was recorded two runs ago
     const bool xy_in_prep = (mask & EFTB_S_PREP) && (mask & EFTB_S_RESUM) && c.with_resum && !nnlo_pass;  // X, Y ride with the first-stage GEMMs
     // whole-pipeline runs regroup C22 / C13 into the resummation records directly (resum_prep_kernel): no regroup_cf_kernel, no Cloopl
@@ -620,6 +619,12 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     const int msplit_cfg = c.with_ap ? ((c.ap_stochastic ? NROW : 21) + 1) / 2 : NROW / 2;
     const bool fuse_reduce = (mask & EFTB_S_AP) && (mask & EFTB_S_REDUCE) && !(mask & (EFTB_S_PROJECT | EFTB_S_LOGP)) && c.with_ap && e->ap_mode == 0 &&
                              !c.with_nnlo && !nnlo_pass;
+    // direct-P_l runs (EFTB_O_PLK_DIRECT): the bias contraction first, then resummation and AP on ONE row per multipole (regroup_plk_kernel,
+    // resum_prep_plk_kernel, resum_plk_kernel, spline / ap_rows on row 0); the template block is not produced
+    const bool direct = e->plk_direct && fuse_reduce && fuse_cf && Nl == 3 && !e->generic_resum && e->ap_fast && !c.dual_coef && !e->use_graphs &&
+                        (mask & EFTB_S_REGROUP) && e->RSAS;
+    // ... and the per-s A operand of the Nl = 3 resummation (inputs only: Q(f), X, Y) is built on the side stream, off the chain
+    const bool as_side = ahead && Nl == 3 && !e->generic_resum && e->RSAS2 && !direct;
     if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
@@ -633,9 +638,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         hipStream_t st0 = st;
         if (pre_side) {
             st = e->pre;
-            if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            static const int whatif0 = getenv("EFTB_WHATIF") ? atoi(getenv("EFTB_WHATIF")) : 0;
+            if (!(whatif0 & 4) && hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             // (X, Y of the previous run are also read by its operand build on the side stream, which evInFree does not cover)
-            if (as_side && hipStreamWaitEvent(st, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            if (!(whatif0 & 8) && as_side && hipStreamWaitEvent(st, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             // the input-only kernels (IR filters / Q(f); AP prefix sums and knot weights) get their own low-priority stream beside the front
             // half: X, Y, Q are free since the previous run built its resummation operands (evInFree); the AP tables alternate between two
             // sets because the previous run's AP reads its own late (the set written here was last read two runs ago: evBack)
@@ -745,6 +751,12 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         if (nnlo_inline) std::swap(b[EFTB_B_TEMPLN], e->T3N);
     }
     if (mask & EFTB_S_REGROUP) {
+        if (direct)
+            hipLaunchKernelGGL(regroup_plk_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
+                               b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
+                               tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], b[EFTB_B_TEMPL],
+                               c.ap_stochastic ? 1 : 0);
+        else
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
                            b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
                            tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_TEMPL]);
@@ -791,9 +803,16 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             if (ahead) {  // the operand set written here was last read by the resummation two runs ago
                 std::swap(e->RSA, e->RSA2);
                 std::swap(e->RSC, e->RSC2);
+                if (direct) std::swap(e->RSAS, e->RSAS2);  // (here the coefficient table of resum_plk_kernel)
                 if (hipStreamWaitEvent(st, e->evRsDone[rslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             }
-            if (full && Nl == 3 && !as_side) launch_resum_as(e, st, B);  // (in line: X, Y, Q(f) are in place behind evJoin)
+            if (full && direct)
+                hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, b[EFTB_B_CC],
+                                   b[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13),
+                                   tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], e->RSAS);
+            else if (full && Nl == 3 && !as_side) launch_resum_as(e, st, B);  // (in line: X, Y, Q(f) are in place behind evJoin)
+            if (full && direct) {
+            } else
             if (full && Nl == 3) hipLaunchKernelGGL((resum_prep_kernel<3>), rpgrid, dim3(256), 0, st, RP_ARGS);
             else if (full) hipLaunchKernelGGL((resum_prep_kernel<2>), rpgrid, dim3(256), 0, st, RP_ARGS);
 #undef RP_ARGS
@@ -814,12 +833,17 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             }
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
-            while (nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
+            while (!direct && nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
             const int schunk = (NS + nsplit - 1) / nsplit;
 #define RM_ARGS Nk, c.Nklow, schunk, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), tb<double>(e, EFTB_T_RSBASIS), Nl == 3 ? e->RSAS : e->RSA, e->RSC, tb<double>(e, EFTB_T_L11), \
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
             const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
-            if (kblocks > 0 && Nl == 3 && fused_nnlo)
+            if (direct) {
+                const int nkd = (Nk + 255) / 256;
+                if (kblocks > 0)
+                    hipLaunchKernelGGL(resum_plk_kernel, dim3(nkd * 3 * B), dim3(256), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), e->RSAS,
+                                       b[EFTB_B_TEMPL], nkd);
+            } else if (kblocks > 0 && Nl == 3 && fused_nnlo)
                 hipLaunchKernelGGL((resum_mfma_kernel<true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
             else if (kblocks > 0 && Nl == 3)
                 hipLaunchKernelGGL((resum_mfma_kernel<false>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, nullptr, nullptr, nkb);
@@ -859,10 +883,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // counter-term rows 3-5 of every multipole: spline and AP touch those alone
         auto ap_pass = [&](bool nn, double** pin, double** palt) -> int {
             const bool moments = e->ap_mode == 1;  // (works on whole blocks: the NNLO block's zero rows stay zero)
-            const int nr = nn ? (moments ? 21 : 6) : (c.ap_stochastic ? NROW : 21);
+            const bool dir = direct && !nn;  // direct-P_l runs: row 0 of every (cosmology, l) block is the only one that goes through the stage
+            const int nr = dir ? 1 : nn ? (moments ? 21 : 6) : (c.ap_stochastic ? NROW : 21);
             // rows the spline data is needed for: [rlo, rlo + rsel) of every (cosmology, l) -- the counter-term rows of the NNLO block; on the fast
             // path only the rows the stage distorts (Pstl passes through unless APst: 21 of 24 rows)
-            const int rlo = nn && !moments ? 3 : 0, rsel = nn && !moments ? 3 : (e->ap_mode == 0 ? nr : NROW);
+            const int rlo = nn && !moments ? 3 : 0, rsel = dir ? 1 : nn && !moments ? 3 : (e->ap_mode == 0 ? nr : NROW);
             const int nseries = B * Nl * rsel;
             {
                 const int kt = (Nk + 63) / 64;
@@ -892,18 +917,20 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             // REDUCE directly behind the AP stage: the bias contraction rides in the epilogue of ap_rows_kernel (and of the fallback tiles'
             // ap_direct_kernel), in the summation order of reduce_kernel(msplit) -- no separate pass over the 33 MB of AP output
             const bool red = fuse_reduce && !nn;
-            const int msplit = red ? msplit_cfg : (rlo + nr + 1) / 2;  // rows [rlo, msplit) / [msplit, nr) to the two half waves
+            const int msplit = dir ? 1 : red ? msplit_cfg : (rlo + nr + 1) / 2;  // rows [rlo, msplit) / [msplit, nr) to the two half waves
+            const int direct0 = dir ? (c.ap_stochastic ? NROW : 21) : -1;  // (direct-P_l: first of the rows outside [rlo, nr) that enter the contraction)
+            double* tout = dir ? nullptr : *palt;
             const double* rb = red ? b[EFTB_B_BIAS] : nullptr;
             double* rp = red ? b[EFTB_B_PLK] : nullptr;
             double* rph = red ? e->plk_host_out : nullptr;
             int* rflag = red && e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr;
             if (e->ap_fast) {
                 // banded product of the knot weights with the spline data; rows outside [rlo, nr) are copied through
-                const int kt2 = 2 * ((Nk + 63) / 64), nh = (nr - rlo + 1) / 2, nre = 2 * nh;
+                const int kt2 = 2 * ((Nk + 63) / 64), nh = dir ? 2 : (nr - rlo + 1) / 2, nre = 2 * nh;
                 const size_t lds = 0;  // (the window is a static array: 37 KB at most)
                 if (rlo + nre > NROW || msplit - rlo > nh || nr - msplit > nh || (nh != 2 && nh != 11 && nh != 12))
                     return fail("eftb_run: AP rows [%d, %d) split at %d do not fit the window layouts built into ap_rows_kernel", rlo, nr, msplit);
-#define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt, rb, rp, rph, rflag
+#define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, tout, rb, rp, rph, rflag, direct0
 #define APR_LAUNCH(NLV, NHV) do { if (e->ap_ring == 2) hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 2>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); \
                                   else hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 4>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); } while (0)
                 if (Nl == 3 && nh == 11) APR_LAUNCH(3, 11);
@@ -920,7 +947,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int4* gate = e->ap_fast ? e->APM : nullptr;
                 const dim3 dgrid(((Nk + 63) / 64) * B);
 #define APD_ARGS Nk, c.nmu, rlo, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
-                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate, rb, rp, rph, msplit, rflag, tb<double>(e, EFTB_T_SPLOCAL)
+                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, tout, gate, rb, rp, rph, msplit, rflag, tb<double>(e, EFTB_T_SPLOCAL), direct0
                 if (e->ap_fast && Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3, true>), dgrid, dim3(64), 0, st, APD_ARGS);
                 else if (e->ap_fast) hipLaunchKernelGGL((ap_direct_kernel<2, true>), dgrid, dim3(64), 0, st, APD_ARGS);
                 else if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3, false>), dgrid, dim3(64), 0, st, APD_ARGS);
@@ -1402,6 +1429,7 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_CHECK_FINITE: e->check_finite = value != 0; return 0;
         case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seq = 0; return 0;
         case EFTB_O_LATENCY_MODE: e->latency_auto = value != 0; return 0;
+        case EFTB_O_PLK_DIRECT: e->plk_direct = value != 0; return 0;
     }
     return fail("eftb_set_option: unknown option %d", option);
 }

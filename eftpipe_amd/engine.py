@@ -156,6 +156,12 @@ class Engine:
         for samplers whose next step depends on this one.  False: always the three-stream layout (loops that keep several steps queued)."""
         L.check(self.lib.eftb_set_option(self._h, 5, int(bool(flag))))
 
+    def set_plk_direct(self, flag):
+        """True: whole-pipeline runs that end in REDUCE (no PROJECT / LOGP; Nl = 3, fast AP path) take the bias contraction of reduce_Plk FIRST --
+        it commutes with the resummation and with the AP stage -- so one row per multipole instead of 24 goes through them.  Same P_l(k)
+        (summation order aside); the template block "TEMPL" does not hold the templates of such a run.  False (default): templates first."""
+        L.check(self.lib.eftb_set_option(self._h, 6, int(bool(flag))))
+
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
 

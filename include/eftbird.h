@@ -143,10 +143,15 @@ enum eftb_option {
     EFTB_O_TIME_DOMINANT = 4  /* value n > 0: bracket every n-th launch of the resummation kernel with HIP events on the stream it runs on
                                  (measurement only: bench.py's roofline; read with eftb_dominant_time; inactive while EFTB_O_GRAPH replays
                                  captured runs).  The two event packets cost the pipelined loop about 1.5 % when every launch carries them. */,
-    EFTB_O_LATENCY_MODE = 5   /* 1 (default): a step staged (eftb_stage_inputs) while the GPU is idle runs in latency mode -- one queue, P_lin read from
+    EFTB_O_LATENCY_MODE = 5,  /* 1 (default): a step staged (eftb_stage_inputs) while the GPU is idle runs in latency mode -- one queue, P_lin read from
                                  the staging block, P_l written to mapped host memory by the kernel that forms it: what a sampler wants whose next
                                  step depends on this step's result.  0: always the three-stream layout (a caller that knows more steps follow
                                  at once: the first step of a pipelined loop then does not hold the main queue with its AP stage) */
+    EFTB_O_PLK_DIRECT = 6     /* 1: whole-pipeline runs that end in REDUCE (PREP .. AP | REDUCE, no PROJECT / LOGP; Nl = 3, fast AP path) take the
+                                 bias contraction of reduce_Plk (parambasis.py:42-136) FIRST -- it commutes with Resum.Ps and APeffect.AP, linear maps
+                                 that act on every template row alike (pybird.py:1413-1464, 1581-1621) -- so one row per multipole instead of 24
+                                 goes through them: same P_l(k) (summation order aside), but EFTB_B_TEMPL does not hold the templates of such a
+                                 run.  0 (default): templates first, as the reference computes them (BirdSnapshot semantics) */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 /* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for
