@@ -730,41 +730,57 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 // row 0 of the template block takes sum_row b_row T[l][row] over the rows the AP stage distorts (rows < 21, all rows when stoch0), rows
 // 21-23 the stochastic templates as always; rows 1-20 of the block are not written.
 __global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ fgrow,
-                                                          const double* __restrict__ P11, const double* __restrict__ P22,
-                                                          const double* __restrict__ P13, const double* __restrict__ l11,
-                                                          const double* __restrict__ lct, const double* __restrict__ l22,
-                                                          const double* __restrict__ l13, const int* __restrict__ grp,
-                                                          const double* __restrict__ bias, double* __restrict__ T, int stoch0) {
-    __shared__ double cf[38];  // b_group f^power mu-weight per piece
-    __shared__ double p0[38];  // the pieces at the first k (shot-noise subtraction, reference pybird.py:799-800)
+                                                          const double* __restrict__ P11, const double* __restrict__ Y22,
+                                                          const double* __restrict__ exp22, const double* __restrict__ P13,
+                                                          const double* __restrict__ l11, const double* __restrict__ lct,
+                                                          const double* __restrict__ l22, const double* __restrict__ l13,
+                                                          const int* __restrict__ grp, const double* __restrict__ bias, double* __restrict__ T,
+                                                          int stoch0) {
+    // the 28 P22 pieces are combinations of the BAS22 synthesised basis rows (expand_kernel): contracted with their weights first, the sum
+    // runs over the basis rows themselves -- direct-P_l runs never expand them
+    __shared__ double cf[38];      // b_group f^power mu-weight per piece
+    __shared__ double w22[BAS22];  // sum_b cf[b] exp22[b][c]
+    __shared__ double z0[BAS22 + 10];  // the weighted rows at the first k (shot-noise subtraction, reference pybird.py:799-800)
     const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
     const double f = fgrow[w];
     const double* bw = bias + (size_t)w * NROW;
-    for (int b = threadIdx.x; b < 38; b += blockDim.x) {
+    const double* y22 = Y22 + (size_t)w * BAS22 * Nk;
+    const double* q13 = P13 + (size_t)w * 10 * Nk;
+    for (int b = threadIdx.x; b < 38; b += blockDim.x)
         cf[b] = bw[9 + grp[2 * b]] * ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
-        p0[b] = b < 28 ? P22[((size_t)w * 28 + b) * Nk] : P13[((size_t)w * 10 + (b - 28)) * Nk];
+    __syncthreads();
+    if (threadIdx.x < BAS22) {
+        double a = 0.0;
+        for (int b = 0; b < 28; ++b) a = fma(cf[b], exp22[b * BAS22 + threadIdx.x], a);
+        w22[threadIdx.x] = a;
+        z0[threadIdx.x] = a * y22[(size_t)threadIdx.x * Nk];
+    } else if (threadIdx.x < BAS22 + 10) {
+        const int b = threadIdx.x - BAS22;
+        z0[threadIdx.x] = cf[28 + b] * q13[(size_t)b * Nk];
     }
     __syncthreads();
     if (k >= Nk) return;
     const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
-    const double* q22 = P22 + (size_t)w * 28 * Nk + k;
-    const double* q13 = P13 + (size_t)w * 10 * Nk + k;
     double b11 = 0.0, bct = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) b11 = fma(bw[r], l11[l * 3 + r], b11);
 #pragma unroll
     for (int r = 0; r < 6; ++r) bct = fma(bw[3 + r], lct[l * 6 + r], bct);
-    double a0 = (b11 + bct * kv * kv) * p11, a1 = 0.0;  // two chains over the 38 pieces
-    for (int b = 0; b < 28; b += 2) {
-        a0 = fma(cf[b], q22[(size_t)b * Nk] - p0[b], a0);
-        a1 = fma(cf[b + 1], q22[(size_t)(b + 1) * Nk] - p0[b + 1], a1);
+    double a0 = (b11 + bct * kv * kv) * p11, a1 = 0.0, c0 = 0.0;  // two chains over the rows
+#pragma unroll
+    for (int c = 0; c < BAS22; c += 2) {
+        a0 = fma(w22[c], y22[(size_t)c * Nk + k], a0);
+        a1 = fma(w22[c + 1], y22[(size_t)(c + 1) * Nk + k], a1);
     }
+#pragma unroll
     for (int b = 0; b < 10; b += 2) {
-        a0 = fma(cf[28 + b], q13[(size_t)b * Nk] - p0[28 + b], a0);
-        a1 = fma(cf[29 + b], q13[(size_t)(b + 1) * Nk] - p0[29 + b], a1);
+        a0 = fma(cf[28 + b], q13[(size_t)b * Nk + k], a0);
+        a1 = fma(cf[29 + b], q13[(size_t)(b + 1) * Nk + k], a1);
     }
+#pragma unroll
+    for (int i = 0; i < BAS22 + 10; ++i) c0 += z0[i];
     const double s21 = l == 0 ? 1.0 : 0.0, s22 = l == 0 ? kv * kv : 0.0, s23 = l == 1 ? kv * kv : 0.0;
-    double tot = a0 + a1;
+    double tot = (a0 + a1) - c0;
     if (stoch0) tot += bw[21] * s21 + bw[22] * s22 + bw[23] * s23;  // APst: the stochastic templates are distorted with the others
     double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
     t[0] = tot;
@@ -1329,18 +1345,25 @@ constexpr int RSD_REC = 160;  // doubles per (cosmology, s): 9 x 16 coefficients
 
 __global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, int Na, const double* __restrict__ Q, const double* __restrict__ XY,
                                                              const double* __restrict__ C11, const double* __restrict__ Cct,
-                                                             const double* __restrict__ CC, const double* __restrict__ fgrow,
-                                                             const double* __restrict__ l11, const double* __restrict__ lct,
-                                                             const double* __restrict__ l22, const double* __restrict__ l13,
-                                                             const int* __restrict__ grp, const double* __restrict__ bias, double* __restrict__ CF) {
-    constexpr int NL = 3;
-    const int w = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
-    const double* q = Q + (size_t)w * 2 * NL * NL * NN;
+                                                             const double* __restrict__ YCF, const double* __restrict__ expc,
+                                                             const double* __restrict__ fgrow, const double* __restrict__ l11,
+                                                             const double* __restrict__ lct, const double* __restrict__ l22,
+                                                             const double* __restrict__ l13, const int* __restrict__ grp,
+                                                             const double* __restrict__ bias, double* __restrict__ CF) {
+    // grid (cosmology, slice of the s range); the 38 C22 / C13 pieces per l' are combinations of the BASC synthesised basis rows
+    // (expand_kernel): their weights are contracted with the combination matrix first, so g_1 is a sum over the basis rows
+    constexpr int NL = 3, NCH = 5, CPC = (BASC + NCH - 1) / NCH;  // chunks of the basis rows per g_1 entry, rows per chunk
+    const int w = blockIdx.x, ns = (NS + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * ns, s1 = min(NS, s0 + ns), nsl = s1 - s0;
     const double* bw = bias + (size_t)w * NROW;
-    __shared__ double s_cf[NL * 38];      // b_group f^power mu-weight per piece and l'
-    __shared__ double s_g[2][NL][NS];     // g_a[l'](s)
-    __shared__ double s_b[2][NL];         // sum_i b_i l11[l'][i], sum_i b_3+i lct[l'][i]
+    extern __shared__ double sm[];
+    double* s_q = sm;                        // [2 NL NL NN] the cosmology's Q(f)
+    double* s_cf = s_q + 2 * NL * NL * NN;   // [NL][38] b_group f^power mu-weight per piece and l'
+    double* s_wc = s_cf + NL * 38;           // [NL][BASC]
+    double* s_b = s_wc + NL * BASC;          // [2][NL] sum_i b_i l11[l'][i], sum_i b_3+i lct[l'][i]
+    double* s_g = s_b + 2 * NL;              // [2][NL][ns] g_a[l'](s0 + .)
+    double* s_p = s_g + 2 * NL * ns;         // [NCH][NL ns] partial sums of g_1
     const double f = fgrow[w];
+    for (int e = threadIdx.x; e < 2 * NL * NL * NN; e += blockDim.x) s_q[e] = Q[(size_t)w * 2 * NL * NL * NN + e];
     for (int e = threadIdx.x; e < NL * 38; e += blockDim.x) {
         const int lp = e / 38, bq = e % 38;
         s_cf[e] = bw[9 + grp[2 * bq]] * ipow(f, grp[2 * bq + 1]) * (bq < 28 ? l22[lp * 28 + bq] : l13[lp * 10 + (bq - 28)]);
@@ -1352,34 +1375,46 @@ __global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, in
             for (int r = 0; r < 3; ++r) v = fma(bw[r], l11[lp * 3 + r], v);
         else
             for (int r = 0; r < 6; ++r) v = fma(bw[3 + r], lct[lp * 6 + r], v);
-        s_b[a][lp] = v;
+        s_b[threadIdx.x] = v;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * NL * NS; e += blockDim.x) {
-        const int s = e % NS, lp = (e / NS) % NL, a = e / (NL * NS);  // s fastest: coalesced reads of the s-major inputs
-        double v;
-        if (a == 0) {
-            v = C11[((size_t)w * NL + lp) * NS + s] * s_b[0][lp];
-        } else {
-            const double* cc = CC + (size_t)w * NL * 38 * NS;
-            double v0 = Cct[((size_t)w * NL + lp) * NS + s] * s_b[1][lp], v1 = 0.0;
-            for (int b = 0; b < 28; b += 2) {
-                v0 = fma(s_cf[lp * 38 + b], cc[(size_t)(lp * 28 + b) * NS + s], v0);
-                v1 = fma(s_cf[lp * 38 + b + 1], cc[(size_t)(lp * 28 + b + 1) * NS + s], v1);
-            }
-            for (int b = 0; b < 10; b += 2) {
-                v0 = fma(s_cf[lp * 38 + 28 + b], cc[(size_t)(NL * 28 + lp * 10 + b) * NS + s], v0);
-                v1 = fma(s_cf[lp * 38 + 29 + b], cc[(size_t)(NL * 28 + lp * 10 + b + 1) * NS + s], v1);
-            }
-            v = v0 + v1;
+    if (threadIdx.x < NL * BASC) {
+        const int lp = threadIdx.x / BASC, c = threadIdx.x % BASC;
+        double v0 = 0.0, v1 = 0.0;
+        for (int b = 0; b < 28; b += 2) {
+            v0 = fma(s_cf[lp * 38 + b], expc[(size_t)(lp * 28 + b) * BASC + c], v0);
+            v1 = fma(s_cf[lp * 38 + b + 1], expc[(size_t)(lp * 28 + b + 1) * BASC + c], v1);
         }
-        s_g[a][lp][s] = v;
+        for (int b = 0; b < 10; b += 2) {
+            v0 = fma(s_cf[lp * 38 + 28 + b], expc[(size_t)(NL * 28 + lp * 10 + b) * BASC + c], v0);
+            v1 = fma(s_cf[lp * 38 + 29 + b], expc[(size_t)(NL * 28 + lp * 10 + b + 1) * BASC + c], v1);
+        }
+        s_wc[threadIdx.x] = v0 + v1;
+    }
+    __syncthreads();
+    {   // g_1: NCH chunks of basis rows per (l', s) entry, summed below in chunk order
+        const int ne = NL * nsl, e = threadIdx.x % (NL * ns), ch = threadIdx.x / (NL * ns);
+        if (ch < NCH && e < ne) {
+            const int lp = e / nsl, sl = e % nsl;
+            const double* y = YCF + (size_t)w * BASC * NS + s0 + sl;
+            double v = 0.0;
+            for (int c = ch * CPC; c < min(BASC, (ch + 1) * CPC); ++c) v = fma(s_wc[lp * BASC + c], y[(size_t)c * NS], v);
+            s_p[ch * NL * ns + e] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NL * nsl) {
+        const int lp = threadIdx.x / nsl, sl = threadIdx.x % nsl, s = s0 + sl;
+        double v = Cct[((size_t)w * NL + lp) * NS + s] * s_b[NL + lp];
+        for (int ch = 0; ch < NCH; ++ch) v += s_p[ch * NL * ns + threadIdx.x];
+        s_g[(NL + lp) * ns + sl] = v;
+        s_g[lp * ns + sl] = C11[((size_t)w * NL + lp) * NS + s] * s_b[lp];
     }
     __syncthreads();
     const double* xy = XY + (size_t)w * 2 * NS;
-    double* dst = CF + (size_t)w * NS * RSD_REC;
-    for (int idx = part * blockDim.x + threadIdx.x; idx < NS * RSD_REC; idx += nparts * blockDim.x) {
-        const int s = idx / RSD_REC, c = idx % RSD_REC;
+    double* dst = CF + ((size_t)w * NS + s0) * RSD_REC;
+    for (int idx = threadIdx.x; idx < nsl * RSD_REC; idx += blockDim.x) {
+        const int sl = idx / RSD_REC, c = idx % RSD_REC, s = s0 + sl;
         double v = 0.0;
         if (c < 144) {
             const int l = c / 48, vv = (c / 16) % 3, p = c % 16;
@@ -1389,10 +1424,10 @@ __global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, in
                 for (int a = 0; a < 2; ++a) {  // device Q[a]: 0 = the C11 series, 1 = the Cct / Cloopl series
 #pragma unroll
                     for (int lp = 0; lp < NL; ++lp) {
-                        const double* qq = q + ((a * NL + l) * NL + lp) * NN + p * Na + vv;
+                        const double* qq = s_q + ((a * NL + l) * NL + lp) * NN + p * Na + vv;
                         double term = y * qq[NIR * Na];
                         if (lp == vv) term = fma(x, qq[0], term);
-                        v = fma(s_g[a][lp][s], term, v);
+                        v = fma(s_g[(a * NL + lp) * ns + sl], term, v);
                     }
                 }
                 v = ldexp(v, 3 * p);  // RS_ZS^p, RS_ZS = 8
@@ -1421,48 +1456,83 @@ __device__ __forceinline__ double sop_add(double a, double c) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void resum_plk_kernel(int Nk, int Nklow, const double* __restrict__ kk, const double* __restrict__ H,
-                                                        const double* __restrict__ CF, double* __restrict__ T, int nkb) {
-    constexpr int NL = 3;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // workgroup -> (k block of 256, l, cosmology); the 3 nkb workgroups of a cosmology sit on one XCD (its coefficient table passes through one L2)
+// workgroup = 3 SH waves = (v, slice of the s range) of one (64 KPL k, l, cosmology): a lane owns KPL k (64 apart), so a wave runs KPL
+// independent Horner chains per s on ONE set of 16 scalar coefficients -- at one k per lane and with the wait for a set in front of the step
+// that requests the next one, the scalar loads, not the FP64 pipe, set the pace (66-71 us) -- sums H_v D_lv over its s in registers, and the
+// 3 SH partial sums meet in LDS at the end, added in wave order.  KPL = 2, SH = 2: 9 216 equal waves = nine per SIMD.
+template <int KPL, int SH>
+__global__ __launch_bounds__(192 * SH) void resum_plk_kernel(int Nk, int Nklow, const double* __restrict__ kk, const double* __restrict__ H,
+                                                             const double* __restrict__ CF, double* __restrict__ T, int KT) {
+    constexpr int NL = 3, NSH = NS / SH;  // (NS = 80: NSH even for SH = 1, 2, 4)
+    __shared__ double s_part[3 * SH - 1][KPL][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: the coefficient loads stay scalar)
+    const int v = wv % 3, sh = wv / 3;
+    // workgroup -> (k tile of 64 KPL, l, cosmology); the 3 KT workgroups of a cosmology sit on one XCD (its coefficient table passes through one L2)
     int t3, w;
-    xcd_decode(nkb * NL, t3, w);
-    const int kb = t3 / NL, l = t3 % NL;
-    const int k = (kb * 4 + wave) * 64 + lane;
-    const int kc = k < Nklow ? Nklow : (k < Nk ? k : Nk - 1);  // lanes outside [Nklow, Nk) compute on a clamped k and store nothing
-    const double k2 = kk[kc] * kk[kc];
-    const double* cf = CF + (size_t)w * NS * RSD_REC + l * 48;  // wave-uniform: scalar loads
-    const char* Hb = reinterpret_cast<const char*>(H);
-    const unsigned hrow = (unsigned)NS * (unsigned)Nk * 8u, hstep = (unsigned)Nk * 8u;
-    unsigned hoff = (unsigned)kc * 8u;
-    double acc = 0.0;
-    double h[3];
+    xcd_decode(KT * NL, t3, w);
+    const int kt = t3 / NL, l = t3 % NL;
+    int k[KPL];
+    double k2[KPL], acc[KPL], h[KPL];
+    const double* hp = H + ((size_t)v * NS + sh * NSH) * Nk;
+    unsigned ho[KPL];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) h[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
-    for (int s = 0; s < NS; ++s) {
-        const bool more = s + 1 < NS;
-        hoff += more ? hstep : 0u;
-        double hn[3];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) hn[v] = *reinterpret_cast<const double*>(Hb + (hoff + v * hrow));
-        const double t = k2 * cf[144 - l * 48];
-        // Horner with the coefficients as SCALAR addends (v_fma_f64 v, v, v, s: left to itself hipcc picks v_fmac_f64 and moves every
-        // coefficient into a vector register pair first -- 90 moves per step)
-        double d[3];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) d[v] = sop_add(sop_mul(t, cf[v * 16 + 15]), cf[v * 16 + 14]);
-#pragma unroll
-        for (int p = 13; p >= 0; --p)
-#pragma unroll
-            for (int v = 0; v < 3; ++v) d[v] = sop_fma(d[v], t, cf[v * 16 + p]);
-        acc = fma(h[0], d[0], fma(h[1], d[1], fma(h[2], d[2], acc)));
-        cf += RSD_REC;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) h[v] = hn[v];
+    for (int j = 0; j < KPL; ++j) {
+        k[j] = kt * 64 * KPL + 64 * j + lane;
+        const int kc = k[j] < Nklow ? Nklow : (k[j] < Nk ? k[j] : Nk - 1);  // lanes outside [Nklow, Nk) compute on a clamped k and store nothing
+        k2[j] = kk[kc] * kk[kc];
+        ho[j] = (unsigned)kc;
+        h[j] = hp[ho[j]];
+        acc[j] = 0.0;
     }
-    if (k >= Nk || k < Nklow) return;
-    T[(((size_t)w * NL + l) * NROW) * Nk + k] += k2 * acc;
+    const double* cf = CF + ((size_t)w * NS + sh * NSH) * RSD_REC + l * 48 + v * 16;  // wave-uniform: scalar loads; X / RS_ZS sits at [144] of the record
+    const int xo = 144 - l * 48 - v * 16;
+    // two steps per trip with two coefficient sets: the set a step reads was requested one step earlier and is waited for where it is first
+    // used (scalar loads return out of order: a wait is always for all of them, so it must not sit behind the requests of the next set)
+    double ca[16], cb[16], xa = cf[xo], xb;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) ca[p] = cf[p];
+#define RSD_STEP(C, X, CN, XN, MORE)                                                                        \
+    do {                                                                                                    \
+        asm volatile("" ::"s"(C[0]), "s"(X)); /* the wait for this step's set: in front of the next requests */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        cf += (MORE) ? RSD_REC : 0;                                                                         \
+        hp += (MORE) ? Nk : 0;                                                                              \
+        _Pragma("unroll") for (int p = 0; p < 16; ++p) CN[p] = cf[p];                                       \
+        XN = cf[xo];                                                                                        \
+        double hn[KPL];                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < KPL; ++j) hn[j] = hp[ho[j]];                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        /* Horner with the coefficients as SCALAR addends (v_fma_f64 v, v, v, s: left to itself hipcc picks v_fmac_f64 and moves */ \
+        /* every coefficient into a vector register pair first) */                                          \
+        double t[KPL], d[KPL];                                                                              \
+        _Pragma("unroll") for (int j = 0; j < KPL; ++j) {                                                   \
+            t[j] = sop_mul(k2[j], X);                                                                       \
+            d[j] = sop_add(sop_mul(t[j], C[15]), C[14]);                                                    \
+        }                                                                                                   \
+        _Pragma("unroll") for (int p = 13; p >= 0; --p)                                                     \
+            _Pragma("unroll") for (int j = 0; j < KPL; ++j) d[j] = sop_fma(d[j], t[j], C[p]);               \
+        _Pragma("unroll") for (int j = 0; j < KPL; ++j) acc[j] = fma(h[j], d[j], acc[j]);                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        _Pragma("unroll") for (int j = 0; j < KPL; ++j) h[j] = hn[j];                                       \
+    } while (0)
+    for (int s = 0; s < NSH; s += 2) {
+        RSD_STEP(ca, xa, cb, xb, true);
+        RSD_STEP(cb, xb, ca, xa, s + 2 < NSH);
+    }
+#undef RSD_STEP
+    if (wv > 0) {
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) s_part[wv - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        double a = acc[j];
+#pragma unroll
+        for (int q = 0; q < 3 * SH - 1; ++q) a += s_part[q][j][lane];
+        if (k[j] < Nk && k[j] >= Nklow) T[(((size_t)w * NL + l) * NROW) * Nk + k[j]] += k2[j] * a;
+    }
 }
 
 // The same scheme for Nl = 2 (NIR = 8, Na = 2): the polynomials have degree 7, so the monomials of t = z / RS_ZS are the basis

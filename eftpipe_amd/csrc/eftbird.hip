@@ -733,7 +733,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                             nullptr, e->sm4);
         }
         launch_synth(st, sb);
-        if (k22 || c22) {
+        if ((k22 || c22) && !direct) {  // (direct-P_l runs contract the basis rows themselves: regroup_plk_kernel, resum_prep_plk_kernel)
             const int n22 = k22 ? ((Nk + 63) / 64) * ((28 + EXP_RPB - 1) / EXP_RPB) * B : 0;
             const int ncf = c22 ? ((NS + 63) / 64) * ((Nl * 38 + EXP_RPB - 1) / EXP_RPB) * B : 0;
             hipLaunchKernelGGL(expand_kernel, dim3(n22 + ncf), dim3(64), 0, st, n22, Nk, B, e->Y22, tb<double>(e, EFTB_T_EXP22), b[EFTB_B_P22], Nl * 38,
@@ -753,7 +753,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     if (mask & EFTB_S_REGROUP) {
         if (direct)
             hipLaunchKernelGGL(regroup_plk_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
-                               b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
+                               b[EFTB_B_P11], e->Y22, tb<double>(e, EFTB_T_EXP22), b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
                                tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], b[EFTB_B_TEMPL],
                                c.ap_stochastic ? 1 : 0);
         else
@@ -806,10 +806,13 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 if (direct) std::swap(e->RSAS, e->RSAS2);  // (here the coefficient table of resum_plk_kernel)
                 if (hipStreamWaitEvent(st, e->evRsDone[rslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             }
-            if (full && direct)
-                hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), 0, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, b[EFTB_B_CC],
-                                   b[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13),
-                                   tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], e->RSAS);
+            if (full && direct) {
+                const int nsl = NS / 5;  // five slices of the s range per cosmology
+                const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 3 * 38 + 3 * BASC + 6 + 2 * 3 * nsl + 5 * 3 * nsl) * sizeof(double);
+                hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), plds, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF,
+                                   tb<double>(e, EFTB_T_EXPC), b[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), tb<double>(e, EFTB_T_L22),
+                                   tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], e->RSAS);
+            }
             else if (full && Nl == 3 && !as_side) launch_resum_as(e, st, B);  // (in line: X, Y, Q(f) are in place behind evJoin)
             if (full && direct) {
             } else
@@ -839,10 +842,19 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
             const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
             if (direct) {
-                const int nkd = (Nk + 255) / 256;
-                if (kblocks > 0)
-                    hipLaunchKernelGGL(resum_plk_kernel, dim3(nkd * 3 * B), dim3(256), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), e->RSAS,
-                                       b[EFTB_B_TEMPL], nkd);
+                static const int rsd_cfg = getenv("EFTB_RSD_CFG") ? atoi(getenv("EFTB_RSD_CFG")) : 42;  // k per lane, slices of the s range
+#define RSD_LAUNCH(KPLV, SHV) do { const int nkd = (Nk + 64 * KPLV - 1) / (64 * KPLV); \
+                    hipLaunchKernelGGL((resum_plk_kernel<KPLV, SHV>), dim3(nkd * 3 * B), dim3(192 * SHV), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), \
+                                       e->RSAS, b[EFTB_B_TEMPL], nkd); } while (0)
+                if (kblocks <= 0) {
+                } else if (rsd_cfg == 41) RSD_LAUNCH(4, 1);
+                else if (rsd_cfg == 42) RSD_LAUNCH(4, 2);
+                else if (rsd_cfg == 21) RSD_LAUNCH(2, 1);
+                else if (rsd_cfg == 12) RSD_LAUNCH(1, 2);
+                else if (rsd_cfg == 24) RSD_LAUNCH(2, 4);
+                else if (rsd_cfg == 22) RSD_LAUNCH(2, 2);
+                else RSD_LAUNCH(4, 2);
+#undef RSD_LAUNCH
             } else if (kblocks > 0 && Nl == 3 && fused_nnlo)
                 hipLaunchKernelGGL((resum_mfma_kernel<true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
             else if (kblocks > 0 && Nl == 3)
