@@ -741,6 +741,7 @@ __global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const 
     __shared__ double cf[38];      // b_group f^power mu-weight per piece
     __shared__ double w22[BAS22];  // sum_b cf[b] exp22[b][c]
     __shared__ double z0[BAS22 + 10];  // the weighted rows at the first k (shot-noise subtraction, reference pybird.py:799-800)
+    __shared__ double s_e[28 * BAS22];  // exp22 (one coalesced load: a thread walking its column in global memory is 28 dependent round trips)
     const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
     const double f = fgrow[w];
     const double* bw = bias + (size_t)w * NROW;
@@ -748,10 +749,11 @@ __global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const 
     const double* q13 = P13 + (size_t)w * 10 * Nk;
     for (int b = threadIdx.x; b < 38; b += blockDim.x)
         cf[b] = bw[9 + grp[2 * b]] * ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
+    for (int e = threadIdx.x; e < 28 * BAS22; e += blockDim.x) s_e[e] = exp22[e];
     __syncthreads();
     if (threadIdx.x < BAS22) {
         double a = 0.0;
-        for (int b = 0; b < 28; ++b) a = fma(cf[b], exp22[b * BAS22 + threadIdx.x], a);
+        for (int b = 0; b < 28; ++b) a = fma(cf[b], s_e[b * BAS22 + threadIdx.x], a);
         w22[threadIdx.x] = a;
         z0[threadIdx.x] = a * y22[(size_t)threadIdx.x * Nk];
     } else if (threadIdx.x < BAS22 + 10) {
@@ -1362,8 +1364,10 @@ __global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, in
     double* s_b = s_wc + NL * BASC;          // [2][NL] sum_i b_i l11[l'][i], sum_i b_3+i lct[l'][i]
     double* s_g = s_b + 2 * NL;              // [2][NL][ns] g_a[l'](s0 + .)
     double* s_p = s_g + 2 * NL * ns;         // [NCH][NL ns] partial sums of g_1
+    double* s_e = s_p + NCH * NL * ns;       // [NL 38][BASC] expc (coalesced: a thread walking its column in global memory is 38 dependent round trips)
     const double f = fgrow[w];
     for (int e = threadIdx.x; e < 2 * NL * NL * NN; e += blockDim.x) s_q[e] = Q[(size_t)w * 2 * NL * NL * NN + e];
+    for (int e = threadIdx.x; e < NL * 38 * BASC; e += blockDim.x) s_e[e] = expc[e];
     for (int e = threadIdx.x; e < NL * 38; e += blockDim.x) {
         const int lp = e / 38, bq = e % 38;
         s_cf[e] = bw[9 + grp[2 * bq]] * ipow(f, grp[2 * bq + 1]) * (bq < 28 ? l22[lp * 28 + bq] : l13[lp * 10 + (bq - 28)]);
@@ -1382,12 +1386,12 @@ __global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, in
         const int lp = threadIdx.x / BASC, c = threadIdx.x % BASC;
         double v0 = 0.0, v1 = 0.0;
         for (int b = 0; b < 28; b += 2) {
-            v0 = fma(s_cf[lp * 38 + b], expc[(size_t)(lp * 28 + b) * BASC + c], v0);
-            v1 = fma(s_cf[lp * 38 + b + 1], expc[(size_t)(lp * 28 + b + 1) * BASC + c], v1);
+            v0 = fma(s_cf[lp * 38 + b], s_e[(lp * 28 + b) * BASC + c], v0);
+            v1 = fma(s_cf[lp * 38 + b + 1], s_e[(lp * 28 + b + 1) * BASC + c], v1);
         }
         for (int b = 0; b < 10; b += 2) {
-            v0 = fma(s_cf[lp * 38 + 28 + b], expc[(size_t)(NL * 28 + lp * 10 + b) * BASC + c], v0);
-            v1 = fma(s_cf[lp * 38 + 29 + b], expc[(size_t)(NL * 28 + lp * 10 + b + 1) * BASC + c], v1);
+            v0 = fma(s_cf[lp * 38 + 28 + b], s_e[(NL * 28 + lp * 10 + b) * BASC + c], v0);
+            v1 = fma(s_cf[lp * 38 + 29 + b], s_e[(NL * 28 + lp * 10 + b + 1) * BASC + c], v1);
         }
         s_wc[threadIdx.x] = v0 + v1;
     }

@@ -808,7 +808,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             }
             if (full && direct) {
                 const int nsl = NS / 5;  // five slices of the s range per cosmology
-                const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 3 * 38 + 3 * BASC + 6 + 2 * 3 * nsl + 5 * 3 * nsl) * sizeof(double);
+                const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 3 * 38 + 3 * BASC + 6 + 2 * 3 * nsl + 5 * 3 * nsl + 3 * 38 * BASC) * sizeof(double);
                 hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), plds, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF,
                                    tb<double>(e, EFTB_T_EXPC), b[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), tb<double>(e, EFTB_T_L22),
                                    tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], e->RSAS);
