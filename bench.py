@@ -38,8 +38,10 @@ NL, NK, Z = 3, 512, 0.7
 BS = [2.1401334, 0.77616816 / np.sqrt(2.0), 0.77003455, 0.77616816 / np.sqrt(2.0), -1.8396613, -1.8918368, -1.4856405]
 ES = (0.26033594, 0.0, -0.92895016)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 NPOW, NS_DEV, NKLOW = 257, 80, 7
 DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "2"))  # steps queued on the GPU ahead of the one being fetched (1..3; measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
+DIRECT = os.environ.get("EFTB_BENCH_DIRECT", "1") != "0"   # `value` on direct-P_l runs (EFTB_O_PLK_DIRECT); 0: templates first
 
 
 STEP_TIMES = [] if os.environ.get("EFTB_BENCH_STEP_TIMES") else None  # diagnostics: host time at which each timed step's P_l had been fetched
@@ -106,6 +108,95 @@ def executed_flops_per_launch(B):
     per_trip = {"kernel_build": name, "mfma": loop["mfma"], "valu_f64": loop["valu_f64"], "f64_ops": loop["f64_ops"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
                 "vgprs": info.get("vgprs"), "scratch_bytes": info.get("scratch_bytes")}
     return float(loop["flops_per_wave_trip"]) * waves * NS_DEV, float(loop["mfma_flops_per_wave_trip"]) * waves * NS_DEV, per_trip
+
+
+def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, measured_peak):
+    """`roofline` of a direct-P_l run (EFTB_O_PLK_DIRECT).  Its step has no single dominant kernel any more: the resummation (resum_plk_kernel,
+    FP64 vector work with scalar coefficients), the synthesis GEMMs of the loop stages (synth_kernel, FP64 MFMA) and the AP knot weights
+    (ap_weights_kernel, HBM / latency) each take about a fifth of the kernel time.  All three were bracketed with HIP events on their own
+    streams inside the timed region; the one with the largest time per launch is `roofline`, the other two follow in `roofline_others`, the
+    templates-first step's dominant kernel (resum_mfma_kernel, timed alone) in `roofline_templates_first`."""
+    from eftpipe_amd import _lib as L
+
+    t = eng.tables
+    path = os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")
+    with open(path) as fh:
+        allinfo = json.load(fh)
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_per_kernel.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+
+    def traffic_of(prefix):
+        for name, v in pmc.items():
+            if name.startswith("eftb::" + prefix) and isinstance(v, dict) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                return (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "profiles/r03_pmc_per_kernel.json (2 FETCH_SIZE + WRITE_SIZE)"
+        return None, None
+
+    entries = []
+    # (0) resum_plk_kernel<4, 2>: executed FP64 vector flops from the compiled loop (two s steps per trip), waves = B x 3 l x Nk / 256 x 6, NS / 4 trips
+    info = allinfo["resum_plk_kernel<4,2>"]
+    loop = max(info["loops"], key=lambda b: b["valu_f64"])
+    waves, trips = B * 3 * ((NK + 255) // 256) * 6, NS_DEV // 4
+    flops = float(loop["flops_per_wave_trip"]) * waves * trips
+    ms, n = ktimes[0]
+    if n:
+        tr, src = traffic_of("resum_plk_kernel")
+        entries.append({"bound": "mfma", "kernel": "resum_plk_kernel<4, 2> (Resum.Ps of a direct-P_l run: nine Horner chains of degree 15 per (k, s) with scalar coefficients; FP64 vector "
+                                                   "instructions, which share the DP pipe -- and its 78.6 TFLOP/s peak -- with the matrix cores)",
+                        "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
+                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "executed_flops_per_launch": flops,
+                        "instructions_per_wave_trip": {"f64_ops": loop["f64_ops"], "valu_f64": loop["valu_f64"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
+                                                       "vgprs": info.get("vgprs")},
+                        "counts_source": "eftpipe_amd/csrc/isa_counts.json (tools/isa_counts.py, from the compiled gfx950 assembly)"})
+    # (1) synth_kernel: 2 M N K of the four products of the launch (P22 basis rows, xi basis rows, P13, C11 / Cct)
+    nb, KS, KL = t["comb22"].shape[1], t["syn_k"].shape[0], t["lin_k"].shape[0]
+    ncf = NL * (nb + t["comb13"].shape[1])
+    flops = 2.0 * B * (nb * NK * KS + ncf * NS_DEV * KS + 10 * NK * KL + 2 * NL * NS_DEV * KL)
+    ms, n = ktimes[1]
+    if n:
+        tr, src = traffic_of("synth_kernel")
+        entries.append({"bound": "mfma", "kernel": "synth_kernel (makeP22 / makeC22 / makeC13 / makeP13 / makeC11 / makeCct as four FP64-MFMA GEMMs in one launch: the synthesis of the "
+                                                   "anti-diagonal sums at every k and s)",
+                        "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
+                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_flops_per_launch": flops,
+                        "flops_note": f"2 M N K: [{B} x {nb}] x {KS} x {NK} + [{B} x {ncf}] x {KS} x {NS_DEV} + [{B} x 10] x {KL} x {NK} + [{B} x {2 * NL}] x {KL} x {NS_DEV}"})
+    # (2) ap_weights_kernel: HBM bytes it has to move = the mu prefix sums it reads + the knot weights ap_rows_kernel will read (per 32-k tile:
+    # max coefficients per k x Nl^2 x 32 k), from the AP geometry of the timed set's first batch
+    k = np.asarray(cfg.k)
+    mu = np.asarray(t["mu"])
+    qperp, qpar = np.asarray(d0["DA"]) / cfg.DA_AP, cfg.H_AP / np.asarray(d0["H"])
+    F = qpar / qperp
+    root = np.sqrt(1.0 + mu[None, :] ** 2 * (F[:, None] ** -2 - 1.0))            # [B, nmu]
+    kq = k[None, :] / qperp[:, None]
+    lo = np.minimum(kq * root[:, :1], kq * root[:, -1:])
+    hi = np.maximum(kq * root[:, :1], kq * root[:, -1:])
+    iv = lambda x: np.clip(np.searchsorted(k, x, side="right") - 1, 0, k.size - 2)
+    first = lambda i: np.clip(i - 1, 0, k.size - 4)
+    nD = first(iv(hi)) + 4 - first(iv(lo))                                          # [B, Nk] B-spline coefficients per k
+    D_tile = nD.reshape(B, -1, 32).max(axis=-1)
+    w_bytes = float(D_tile.sum()) * NL * NL * 32 * 8
+    ps_bytes = float(B) * (mu.size + 1) * NL * NL * 4 * 8
+    ms, n = ktimes[2]
+    if n:
+        tr, src = traffic_of("ap_weights_kernel")
+        gbs = (w_bytes + ps_bytes) / (ms / n * 1e-3) / 1e9
+        entries.append({"bound": "hbm", "kernel": "ap_weights_kernel<3> (APeffect.AP, inputs only: the mu quadrature of the reference collapsed into per-(k, B-spline coefficient) weights of "
+                                                  "the banded AP operator)",
+                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
+                        "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_bytes_per_launch": w_bytes + ps_bytes,
+                        "bytes_note": f"knot weights written {w_bytes / 1e6:.1f} MB (mean {D_tile.mean():.1f} coefficients per k and tile) + mu prefix sums read {ps_bytes / 1e6:.1f} MB"})
+    if not entries:
+        return templates_first
+    entries.sort(key=lambda r: -r["ms_per_launch"])
+    top = dict(entries[0])
+    top["ms_per_launch_note"] = ("HIP events on the kernel's own stream around every second of its launches inside the timed region, where the kernels of the other three "
+                                 "streams share the CUs with it; the three heaviest kernels of a direct-P_l step were timed this way, this is the one with the largest time per launch")
+    top["measured_mfma_f64_issue_peak_tflops"] = measured_peak
+    top["roofline_others"] = entries[1:]
+    top["roofline_templates_first"] = templates_first
+    return top
 
 
 def main():
@@ -226,6 +317,10 @@ def main():
     # steps 0.426-0.429 ms per step, behind 50 ms of the same loop 0.388-0.397, behind 500 ms 0.393; --warmup 20 alone 0.409): a chain that runs
     # for hours sees the latter.  EFTB_BENCH_PREWARM_MS=0 gives the bare W steps.
     eng.set_latency_mode(False)  # the pipelined loop keeps DEPTH steps queued: its first step is not a dependent sampler's step
+    # `value` is the rate of P_l(k) evaluations: the engine's direct-P_l runs (EFTB_O_PLK_DIRECT: the bias contraction taken before the
+    # resummation and the AP stage, with which it commutes) -- the templates-first rate of the same loop is the side key
+    # templates_first_evaluations_per_s, and both loops' outputs are compared below.  EFTB_BENCH_DIRECT=0: templates first as `value`.
+    eng.set_plk_direct(DIRECT)
     loop(0, W, keep=False)
     warm_ms, warm_steps = float(os.environ.get("EFTB_BENCH_PREWARM_MS", "50")), W
     tw = time.perf_counter()
@@ -234,8 +329,10 @@ def main():
         warm_steps += W
     # HIP events around every second launch of the dominant kernel inside the timed region, on the stream it runs on (every launch costs the loop
     # about 1.5 %: two more packets per step on the queue the resummation waits in)
+    eng.time_kernels(7 if DIRECT else 1)  # direct-P_l runs have three kernels of about the same weight: all three are timed, the largest is reported
     eng.time_dominant(0 if os.environ.get("EFTB_BENCH_NO_EVENTS") else int(os.environ.get("EFTB_BENCH_EVENT_EVERY", "2")))
-    eng.dominant_time(reset=True)
+    for kind in range(3):
+        eng.kernel_time(kind, reset=True)
     cp.barrier()
     t0 = time.perf_counter()
     loop(W, K, keep=True)
@@ -243,8 +340,10 @@ def main():
     elapsed = cp.max(time.perf_counter() - t0)
     if STEP_TIMES:
         print("[bench] fetch-complete times since t0 (ms):", " ".join(f"{(t - t0) * 1e3:.3f}" for t in STEP_TIMES), file=sys.stderr)
-    dom_ms, dom_n = eng.dominant_time(reset=True)
+    ktimes = [eng.kernel_time(kind, reset=True) for kind in range(3)]  # (resummation, synthesis, AP knot weights): (ms, launches) inside the timed region
+    dom_ms, dom_n = ktimes[0]
     eng.time_dominant(False)
+    eng.time_kernels(1)
 
     # ---- the timed loop's own outputs, checked: finite, and EVERY timed step bit-identical to the synchronous one-call path on the same draws
     steps_checked = 0
@@ -261,8 +360,31 @@ def main():
         assert last.shape == (world, B, NL, NK) and np.all(np.isfinite(last)), "non-finite P_l(k) in the gathered block"
         assert np.array_equal(last[rank], results[K - 1]), "the root's own slice of the gathered block differs from its P_l"
 
+    # ---- the same timed loop with the templates first (every rank takes part: the N > 1 loop exchanges); its P_l against the direct runs'
+    tf_elapsed, tf_err = None, None
+    if DIRECT:
+        direct_results = results.copy()
+        eng.set_plk_direct(False)
+        loop(0, W, keep=False)
+        cp.barrier()
+        t0 = time.perf_counter()
+        loop(W, K, keep=True)
+        cp.barrier()
+        tf_elapsed = cp.max(time.perf_counter() - t0)
+        if exchange == "none" or (exchange == "rccl" and rank == 0):
+            scale = np.max(np.abs(results), axis=-1, keepdims=True)
+            tf_err = float(np.max(np.abs(direct_results - results) / scale))
+            assert tf_err < 1e-8, f"direct-P_l runs differ from the templates-first runs of the same draws: {tf_err:.2e}"
+        results[...] = direct_results
+        eng.set_plk_direct(True)
+
     if rank == 0:
         extras = {}
+        if tf_elapsed is not None:
+            extras["templates_first_evaluations_per_s"], extras["templates_first_ms_per_step"] = B * world * K / tf_elapsed, tf_elapsed / K * 1e3
+            extras["templates_first_note"] = ("the same timed loop with EFTB_O_PLK_DIRECT off: the 24 templates per multipole go through resummation and AP and the "
+                                              "bias contraction rides in the AP epilogue (the path `value` was measured on up to round 2)"
+                                              + (f"; all {K} timed steps of the two paths agree to {tf_err:.1e} of each multipole's maximum" if tf_err is not None else ""))
         eng.set_latency_mode(True)
         if world == 1 and not force_comm:
             # (0) what a DEPENDENT sampler sees (reference likelihood.py:570-594 inside Model.logpost: step i + 1 needs step i's P_l): stage ->
@@ -335,7 +457,8 @@ def main():
                 extras.update(dropin_latency_ms(repeats=20))
             except Exception as exc:  # pragma: no cover
                 extras["dropin_error"] = repr(exc)
-        # per-kernel times, HIP events around back-to-back launches on the engine stream
+        # per-kernel times, HIP events around back-to-back launches on the engine stream (stage by stage: the templates-first kernels)
+        eng.set_plk_direct(False)
         d0 = sets[W]
         eng.load_inputs(d0["Pin"], d0["f"], d0["DA"], d0["H"], d0["bias"])
         eng.run(mask, B)
@@ -399,6 +522,8 @@ def main():
             "p22_path_ms": ms_p22, "p22_reference_algorithmic_flops_per_launch": alg_p22, "c22_path_ms": ms_c22, "stage_ms": stages,
             "stage_ms_note": "stages timed alone on the main stream (no overlap between consecutive steps)",
         }
+        if DIRECT:
+            roofline = direct_rooflines(eng, cfg, B, ktimes, sets[W], roofline, FP64_MFMA_PEAK_TFLOPS, measured_peak)
         value = B * world * K / elapsed
         valid = exchange in ("none", "rccl") and not shared_device
         out = {

@@ -69,10 +69,12 @@ struct eftb_engine {
     hipEvent_t evT0[NTIMER] = {}, evT1[NTIMER] = {};
     bool timer_busy[NTIMER] = {};
     unsigned timer_next = 0;
-    int time_dominant = 0;          // 0 off; n: every n-th resummation launch is bracketed
-    unsigned long long time_seq = 0;
-    double timer_ms = 0.0;
-    long long timer_n = 0;
+    int time_dominant = 0;          // 0 off; n: every n-th launch of the timed kernel is bracketed
+    int time_kernel = 1;            // EFTB_O_TIME_KERNEL, bits: 1 the resummation kernel, 2 the synthesis launch of the loop stages, 4 the AP knot weights
+    unsigned long long time_seqk[3] = {};
+    int timer_kind[NTIMER] = {};    // which kernel the pair of a slot brackets (see time_kernel)
+    double timer_ms[3] = {};
+    long long timer_n[3] = {};
     double *APP = nullptr, *APR = nullptr, *APP2 = nullptr, *APR2 = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     // AP fast path (ap_weights_kernel / ap_rows_kernel): knot weights [B][tiles][APW_DCAP][Nl][Nl][2][64], lowest knot per k [B][tiles * 64],
     // window per tile [B][tiles]; second set for the look-ahead of overlapped runs (swapped together with APP / APR)
@@ -472,6 +474,9 @@ static void launch_irfilter(eftb_engine* e, hipStream_t st, int B, bool xy = tru
     hipLaunchKernelGGL(qf_kernel, dim3(B), dim3(256), 0, st, c.Nl * c.Nl * e->Nn, e->buf[EFTB_B_F], tb<double>(e, EFTB_T_QPOLY), e->buf[EFTB_B_Q]);
 }
 
+static int timer_begin(eftb_engine* e, hipStream_t st, int kind);
+static void timer_end(eftb_engine* e, hipStream_t st, int tslot);
+
 // per-s A operand of the Nl = 3 resummation from Q(f), X(s), Y(s) (resum_as_kernel)
 static void launch_resum_as(eftb_engine* e, hipStream_t st, int B) {
     const eftb_config& c = e->c;
@@ -494,8 +499,10 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     const size_t wlds = ((size_t)c.Nk + c.nmu + (size_t)c.Nl * c.Nl * 4 * 64) * sizeof(double);  // knots, roots, the waves' coefficient windows
 #define APW_ARGS c.Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, \
                  tb<double>(e, EFTB_T_SPLOCAL), e->APW, e->API, e->APM
+    const int tslot = timer_begin(e, st, 2);
     if (c.Nl == 3) hipLaunchKernelGGL((ap_weights_kernel<3>), wgrid, dim3(192), wlds, st, APW_ARGS);
     else hipLaunchKernelGGL((ap_weights_kernel<2>), wgrid, dim3(128), wlds, st, APW_ARGS);
+    timer_end(e, st, tslot);
 #undef APW_ARGS
 }
 
@@ -574,11 +581,25 @@ static void collect_timer(eftb_engine* e, int slot, bool wait) {
         if (wait) (void)hipEventSynchronize(e->evT1[t]);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->evT0[t], e->evT1[t]) == hipSuccess) {
-            e->timer_ms += ms;
-            ++e->timer_n;
+            e->timer_ms[e->timer_kind[t]] += ms;
+            ++e->timer_n[e->timer_kind[t]];
             e->timer_busy[t] = false;
         }
     }
+}
+
+// EFTB_O_TIME_DOMINANT: the launch that follows on `st` is bracketed with an event pair if it is this sample's turn (-> slot, or -1)
+static int timer_begin(eftb_engine* e, hipStream_t st, int kind) {
+    if (!e->time_dominant || !(e->time_kernel & (1 << kind)) || !e->evT0[0] || e->use_graphs || (e->time_seqk[kind]++ % (unsigned)e->time_dominant) != 0)
+        return -1;  // (not under graph replay: the event records would be captured)
+    const int tslot = (int)(e->timer_next++ % eftb_engine::NTIMER);
+    collect_timer(e, tslot, false);
+    if (e->timer_busy[tslot]) return -1;  // its previous pair has not finished: skip this sample
+    e->timer_kind[tslot] = kind;
+    return hipEventRecord(e->evT0[tslot], st) == hipSuccess ? tslot : -1;
+}
+static void timer_end(eftb_engine* e, hipStream_t st, int tslot) {
+    if (tslot >= 0 && hipEventRecord(e->evT1[tslot], st) == hipSuccess) e->timer_busy[tslot] = true;
 }
 
 static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, bool nnlo_inline = false) {
@@ -732,7 +753,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 queue_synth(sb, e->ALC + (size_t)2 * Nl * KLIN, ag, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_CCTN], (long long)Nl * NS,
                             nullptr, e->sm4);
         }
-        launch_synth(st, sb);
+        {
+            const int tslot = (mask & EFTB_S_REGROUP) ? timer_begin(e, st, 1) : -1;
+            launch_synth(st, sb);
+            timer_end(e, st, tslot);
+        }
         if ((k22 || c22) && !direct) {  // (direct-P_l runs contract the basis rows themselves: regroup_plk_kernel, resum_prep_plk_kernel)
             const int n22 = k22 ? ((Nk + 63) / 64) * ((28 + EXP_RPB - 1) / EXP_RPB) * B : 0;
             const int ncf = c22 ? ((NS + 63) / 64) * ((Nl * 38 + EXP_RPB - 1) / EXP_RPB) * B : 0;
@@ -827,13 +852,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 if (as_side && full && hipStreamWaitEvent(st_main, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream join failed");
                 st = st_main;
             }
-            int tslot = -1;
-            if (e->time_dominant && full && e->evT0[0] && !e->use_graphs && (e->time_seq++ % (unsigned)e->time_dominant) == 0) {  // (not under graph replay: the event records would be captured)
-                tslot = (int)(e->timer_next++ % eftb_engine::NTIMER);
-                collect_timer(e, tslot, false);
-                if (!e->timer_busy[tslot] && hipEventRecord(e->evT0[tslot], st) != hipSuccess) return fail("eftb_run: event record failed");
-                if (e->timer_busy[tslot]) tslot = -1;  // its previous pair has not finished: skip this sample
-            }
+            const int tslot = full ? timer_begin(e, st, 0) : -1;
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
             while (!direct && nsplit < e->resum_splits && (size_t)kblocks * 4 * B * nsplit < 2048) nsplit *= 2;
@@ -863,10 +882,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
 #undef RM_ARGS
             if (nsplit > 1)
                 hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nsplit, e->part, b[EFTB_B_TEMPL]);
-            if (tslot >= 0) {
-                if (hipEventRecord(e->evT1[tslot], st) != hipSuccess) return fail("eftb_run: event record failed");
-                e->timer_busy[tslot] = true;
-            }
+            timer_end(e, st, tslot);
             if (ahead) {
                 if (hipEventRecord(e->evRsDone[rslot], st) != hipSuccess) return fail("eftb_run: event record failed");
                 ++e->rs_step;
@@ -1439,9 +1455,12 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_JEFFREYS: e->jeffreys = value ? 1 : 0; return 0;
         case EFTB_O_GRAPH: e->use_graphs = value != 0; return 0;
         case EFTB_O_CHECK_FINITE: e->check_finite = value != 0; return 0;
-        case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seq = 0; return 0;
+        case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seqk[0] = e->time_seqk[1] = e->time_seqk[2] = 0; return 0;
         case EFTB_O_LATENCY_MODE: e->latency_auto = value != 0; return 0;
         case EFTB_O_PLK_DIRECT: e->plk_direct = value != 0; return 0;
+        case EFTB_O_TIME_KERNEL:
+            if (value < 1 || value > 7) return fail("eftb_set_option: EFTB_O_TIME_KERNEL takes a set of 1 (resummation) | 2 (synthesis) | 4 (AP knot weights)");
+            e->time_kernel = value; return 0;
     }
     return fail("eftb_set_option: unknown option %d", option);
 }
@@ -1449,12 +1468,19 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
 int eftb_dominant_time(eftb_engine* e, double* ms_sum, long long* launches, int reset) {
     if (!e || !ms_sum || !launches) return fail("eftb_dominant_time: null argument");
     HIPCHK(hipSetDevice(e->c.device));
+    return eftb_kernel_time(e, 0, ms_sum, launches, reset);
+}
+
+int eftb_kernel_time(eftb_engine* e, int kind, double* ms_sum, long long* launches, int reset) {
+    if (!e || !ms_sum || !launches) return fail("eftb_kernel_time: null argument");
+    if (kind < 0 || kind > 2) return fail("eftb_kernel_time: kind %d (0 resummation, 1 synthesis, 2 AP knot weights)", kind);
+    HIPCHK(hipSetDevice(e->c.device));
     collect_timer(e, -1, true);
-    *ms_sum = e->timer_ms;
-    *launches = e->timer_n;
+    *ms_sum = e->timer_ms[kind];
+    *launches = e->timer_n[kind];
     if (reset) {
-        e->timer_ms = 0.0;
-        e->timer_n = 0;
+        e->timer_ms[kind] = 0.0;
+        e->timer_n[kind] = 0;
     }
     return 0;
 }

@@ -145,6 +145,17 @@ class Engine:
         see dominant_time)."""
         L.check(self.lib.eftb_set_option(self._h, 4, int(every)))
 
+    def time_kernels(self, which):
+        """Which launches time_dominant brackets, a set of: 1 the resummation kernel (default), 2 the synthesis launch of the loop stages, 4 the AP
+        knot weights; read each with kernel_time(kind = 0, 1, 2)."""
+        L.check(self.lib.eftb_set_option(self._h, 7, int(which)))
+
+    def kernel_time(self, kind, reset=True):
+        """(sum of the bracketed durations [ms], launches) of kind 0 resummation / 1 synthesis / 2 AP knot weights since the last reset."""
+        ms, n = C.c_double(), C.c_longlong()
+        L.check(self.lib.eftb_kernel_time(self._h, int(kind), C.byref(ms), C.byref(n), int(bool(reset))))
+        return ms.value, n.value
+
     def dominant_time(self, reset=True):
         """(sum of the bracketed durations [ms], launches) since the last reset; waits for launches in flight."""
         ms, n = C.c_double(), C.c_longlong()

@@ -147,16 +147,21 @@ enum eftb_option {
                                  the staging block, P_l written to mapped host memory by the kernel that forms it: what a sampler wants whose next
                                  step depends on this step's result.  0: always the three-stream layout (a caller that knows more steps follow
                                  at once: the first step of a pipelined loop then does not hold the main queue with its AP stage) */
-    EFTB_O_PLK_DIRECT = 6     /* 1: whole-pipeline runs that end in REDUCE (PREP .. AP | REDUCE, no PROJECT / LOGP; Nl = 3, fast AP path) take the
+    EFTB_O_PLK_DIRECT = 6,    /* 1: whole-pipeline runs that end in REDUCE (PREP .. AP | REDUCE, no PROJECT / LOGP; Nl = 3, fast AP path) take the
                                  bias contraction of reduce_Plk (parambasis.py:42-136) FIRST -- it commutes with Resum.Ps and APeffect.AP, linear maps
                                  that act on every template row alike (pybird.py:1413-1464, 1581-1621) -- so one row per multipole instead of 24
                                  goes through them: same P_l(k) (summation order aside), but EFTB_B_TEMPL does not hold the templates of such a
                                  run.  0 (default): templates first, as the reference computes them (BirdSnapshot semantics) */
+    EFTB_O_TIME_KERNEL = 7    /* which launches EFTB_O_TIME_DOMINANT brackets, a set of: 1 (default) the resummation kernel, 2 the synthesis launch of
+                                 the loop stages (synth_kernel), 4 the AP knot weights (ap_weights_kernel) -- measurement only */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 /* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for
  * the launches still in flight. */
 int  eftb_dominant_time(eftb_engine* e, double* ms_sum, long long* launches, int reset);
+/* The same for one of the launches EFTB_O_TIME_KERNEL selects: kind 0 the resummation kernel (= eftb_dominant_time), 1 the synthesis launch, 2 the AP
+ * knot weights. */
+int  eftb_kernel_time(eftb_engine* e, int kind, double* ms_sum, long long* launches, int reset);
 
 /* Likelihood of the EFTB_S_LOGP stage.  Replaces, for a batch of walkers on the device,
  * EFTLike.PNG / PG (likelihood.py:483-549: flatten the multipoles over the masked k bins) and
