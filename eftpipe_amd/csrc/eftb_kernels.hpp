@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 // (resummation, AP: linear maps that act on each template row alike), so it is taken FIRST: one row per multipole instead of 24 goes through
 // them.  This kernel is regroup_kernel with the contraction in its epilogue (reference pybird.py:737-866 followed by parambasis.py:42-136):
 // row 0 of the template block takes sum_row b_row T[l][row] over the rows the AP stage distorts (rows < 21, all rows when stoch0), rows
-// 21-23 the stochastic templates as always; rows 1-20 of the block are not written.
+// 21-23 the stochastic templates as always (ap_plk_kernel adds them with their coefficients); rows 1-20 of the block are not written.
 __global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ fgrow,
                                                           const double* __restrict__ P11, const double* __restrict__ Y22,
                                                           const double* __restrict__ exp22, const double* __restrict__ P13,
@@ -1841,9 +1841,7 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
                                                        const double* __restrict__ T, const double* __restrict__ S, double* __restrict__ Tout,
                                                        const int4* __restrict__ META, const double* __restrict__ bias, double* __restrict__ Plk,
                                                        double* __restrict__ PlkHost, int msplit, int* __restrict__ nonfinite,
-                                                       const double* __restrict__ LOCAL, int direct0) {
-    // direct0 >= 0 (direct-P_l runs, see regroup_plk_kernel): rows [rlo, nr) are already contracted (weight 1), of the rows outside only
-    // those from direct0 on (the stochastic templates) enter the sum, and no template block is written (Tout = null)
+                                                       const double* __restrict__ LOCAL) {
     const int KT = (Nk + 63) / 64;
     int kt, w;
     xcd_decode(KT, kt, w);
@@ -1862,14 +1860,13 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
     for (int l = 0; l < NL; ++l) ch0[l] = ch1[l] = 0.0;
     const double* bw = bias ? bias + (size_t)w * NROW : nullptr;
     for (int r = 0; r < NROW; ++r) {
-        const double br = bw ? (direct0 >= 0 && r >= rlo && r < nr ? 1.0 : bw[r]) : 0.0;
+        const double br = bw ? bw[r] : 0.0;
         if (r >= nr || r < rlo) {  // rows outside [rlo, nr) are copied through
-            if (direct0 >= 0 && r < direct0) continue;
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const size_t o = (((size_t)w * NL + l) * NROW + r) * Nk + k;
                 const double v = T[o];
-                if (Tout) Tout[o] = v;
+                Tout[o] = v;
                 if (r < msplit) ch0[l] = fma(br, v, ch0[l]); else ch1[l] = fma(br, v, ch1[l]);
             }
             continue;
@@ -1920,7 +1917,7 @@ __global__ __launch_bounds__(64) void ap_direct_kernel(int Nk, int nmu, int rlo,
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const double v = c * acc[l];
-            if (Tout) Tout[(((size_t)w * NL + l) * NROW + r) * Nk + k] = v;
+            Tout[(((size_t)w * NL + l) * NROW + r) * Nk + k] = v;
             if (r < msplit) ch0[l] = fma(br, v, ch0[l]); else ch1[l] = fma(br, v, ch1[l]);
         }
     }
@@ -2245,9 +2242,7 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
                                                           const int* __restrict__ I0, const int4* __restrict__ META,
                                                           const double* __restrict__ T, const double* __restrict__ C,
                                                           double* __restrict__ Tout, const double* __restrict__ bias, double* __restrict__ Plk,
-                                                          double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0) {
-    // direct0 >= 0 (direct-P_l runs, see regroup_plk_kernel): rows [rlo, nr) are already contracted (weight 1), of the rows outside only
-    // those from direct0 on (the stochastic templates) enter the sum, and no template block is written (Tout = null)
+                                                          double* __restrict__ PlkHost, int* __restrict__ nonfinite) {
     constexpr int NP = NL * NL;
     constexpr int nre = 2 * NH;  // window rows: [rlo, nr) rounded up to whole load instructions (host: nr - rlo <= nre, rlo + nre <= NROW)
     __shared__ double win[NL * nre * APW_WIN];
@@ -2337,21 +2332,21 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
     double a = 0.0;
     if (live) {
         const int hlo = half ? msplit : 0, hhi = half ? NROW : msplit;  // this half's share of the NROW rows in the contraction
-        for (int r = max(hlo, direct0); r < min(q0, hhi); ++r) {
+        for (int r = hlo; r < min(q0, hhi); ++r) {
             const double v = T[obase + (size_t)r * Nk];
-            if (Tout) Tout[obase + (size_t)r * Nk] = v;
+            Tout[obase + (size_t)r * Nk] = v;
             if (bw) a = fma(bw[r], v, a);
         }
 #pragma unroll
         for (int q = 0; q < NH; ++q)
             if (q < cnt) {
                 const double v = c * acc[q];
-                if (Tout) Tout[obase + (size_t)(q0 + q) * Nk] = v;
-                if (bw) a = fma(direct0 >= 0 ? 1.0 : bw[q0 + q], v, a);
+                Tout[obase + (size_t)(q0 + q) * Nk] = v;
+                if (bw) a = fma(bw[q0 + q], v, a);
             }
-        for (int r = max(max(q1, hlo), direct0); r < hhi; ++r) {
+        for (int r = max(q1, hlo); r < hhi; ++r) {
             const double v = T[obase + (size_t)r * Nk];
-            if (Tout) Tout[obase + (size_t)r * Nk] = v;
+            Tout[obase + (size_t)r * Nk] = v;
             if (bw) a = fma(bw[r], v, a);
         }
     }
@@ -2363,6 +2358,143 @@ __global__ __launch_bounds__(64 * NL) void ap_rows_kernel(int Nk, int rlo, int n
             if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = tot;  // latency mode: P_l lands in mapped host memory as it is formed
             if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AP of direct-P_l runs (EFTB_O_PLK_DIRECT): ONE row per multipole goes through the stage, and for one row the reference's own form
+// (pybird.py:1581-1621: the nmu-node quadrature of P_l'(k'(mu)) L_l'(mu') L_l(mu), row 0 of the block already contracted with the bias) is
+// cheaper than the knot-weight tables, which pay off over the 21 rows of a template block: no prefix sums, no weights, no banded product.
+// Workgroup = (64 k, cosmology) x 4 waves; wave <-> a quarter of the nodes, lane <-> k.  LDS: per node {root, L_2(mu'), L_4(mu'), w L_l(mu)}
+// (the cosmology's, built once per workgroup), and the spline of the three l' in piecewise-polynomial form on the window of knot intervals
+// the tile's k'(mu) can reach (from the B-spline coefficients of spline_kernel and the per-interval matrices, tables.bspline_tables): a
+// node then costs three cubics, three Legendre weights and three accumulations per lane.  Windows wider than APD_WMAX intervals (distortions
+// beyond ~20 % at the top of the grid) take the same walk with the pieces formed from global memory.  The four partial sums meet in LDS in
+// wave order; the epilogue adds the rows outside the stage (from direct0 on: the stochastic templates) times their bias coefficients.
+// ------------------------------------------------------------------------------------------------
+constexpr int APD_WMAX = 192;
+
+template <int NL>
+__global__ __launch_bounds__(256) void ap_plk_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+                                                     const double* __restrict__ Hw, const double* __restrict__ fid, const double* __restrict__ mu,
+                                                     const double* __restrict__ wmu, const double* __restrict__ legmu, const double* __restrict__ C,
+                                                     const double* __restrict__ LOCAL, const double* __restrict__ T, const double* __restrict__ bias,
+                                                     double* __restrict__ Plk, double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0) {
+    extern __shared__ double sm[];
+    double* s_k = sm;                           // [Nk] the k grid (every interval search below is an LDS walk)
+    double* s_node = s_k + Nk;                  // [nmu][8]
+    double* s_pp = s_node + (size_t)nmu * 8;    // [NL][APD_WMAX][4]
+    double* s_red = s_pp + NL * APD_WMAX * 4;   // [3][NL][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int KT = (Nk + 63) / 64;
+    int kt, w;
+    xcd_decode(KT, kt, w);
+    const int k = kt * 64 + lane, kc = min(k, Nk - 1);
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0, cnorm = 2.0 / (qperp * qperp * qpar);
+    for (int e = threadIdx.x; e < Nk; e += blockDim.x) s_k[e] = kk[e];
+    for (int j = threadIdx.x; j < nmu; j += blockDim.x) {
+        const double m = mu[j], root = sqrt(1.0 + m * m * g), mp = m / (F * root), x2 = mp * mp, wj = wmu[j];
+        double* nd = s_node + (size_t)j * 8;
+        nd[0] = root;
+        nd[1] = 0.5 * (3.0 * x2 - 1.0);
+        nd[2] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
+        nd[3] = 0.0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) nd[4 + l] = wj * legmu[(size_t)l * nmu + j];
+    }
+    __syncthreads();
+    // the window: every interval a k of this tile can reach (k'(mu) = k / q_perp root(mu), root monotonic in mu)
+    const double r0 = s_node[0], r1 = s_node[(size_t)(nmu - 1) * 8];
+    const double ka = s_k[kt * 64] / qperp, kb = s_k[min(kt * 64 + 63, Nk - 1)] / qperp;
+    const int wlo = knot_interval(s_k, Nk, ka * fmin(r0, r1)), whi = knot_interval(s_k, Nk, kb * fmax(r0, r1)), nwin = whi - wlo + 1;
+    const bool big = nwin > APD_WMAX;  // (workgroup-uniform)
+    const double* cw = C + (size_t)w * NL * NROW * Nk;  // row 0 of every l' block
+    if (!big) {
+        for (int e = threadIdx.x; e < nwin * NL; e += blockDim.x) {
+            const int iw = e % nwin, lp = e / nwin, i = wlo + iw, J = bspl_first(i, Nk);
+            const double* cp = cw + (size_t)lp * NROW * Nk + J;
+            const double c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+            const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+            const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
+            double4 pp;
+            pp.x = fma(e0.x, c0, fma(e1.x, c1, fma(e2.x, c2, e3.x * c3)));
+            pp.y = fma(e0.y, c0, fma(e1.y, c1, fma(e2.y, c2, e3.y * c3)));
+            pp.z = fma(e0.z, c0, fma(e1.z, c1, fma(e2.z, c2, e3.z * c3)));
+            pp.w = fma(e0.w, c0, fma(e1.w, c1, fma(e2.w, c2, e3.w * c3)));
+            *reinterpret_cast<double4*>(s_pp + ((size_t)lp * APD_WMAX + iw) * 4) = pp;
+        }
+    }
+    __syncthreads();
+    const int nq = (nmu + 3) / 4, j0 = wave * nq, j1 = min(nmu, j0 + nq);
+    const double kq = s_k[kc] / qperp;
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    // the pieces of the interval the lane stands in live in registers and are replaced only when k'(mu) leaves it (a few times per quarter)
+    auto piece = [&](int i, double4 (&a)[NL]) {
+        if (!big) {
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) a[lp] = *reinterpret_cast<const double4*>(s_pp + ((size_t)lp * APD_WMAX + (i - wlo)) * 4);
+        } else {
+            const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+            const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
+            const int J = bspl_first(i, Nk);
+#pragma unroll
+            for (int lp = 0; lp < NL; ++lp) {
+                const double* cp = cw + (size_t)lp * NROW * Nk + J;
+                const double c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                a[lp].x = fma(e0.x, c0, fma(e1.x, c1, fma(e2.x, c2, e3.x * c3)));
+                a[lp].y = fma(e0.y, c0, fma(e1.y, c1, fma(e2.y, c2, e3.y * c3)));
+                a[lp].z = fma(e0.z, c0, fma(e1.z, c1, fma(e2.z, c2, e3.z * c3)));
+                a[lp].w = fma(e0.w, c0, fma(e1.w, c1, fma(e2.w, c2, e3.w * c3)));
+            }
+        }
+    };
+    if (j0 < j1) {
+        int i = knot_interval(s_k, Nk, kq * s_node[(size_t)j0 * 8]);
+        double klo = s_k[i], khi = s_k[i + 1];
+        double4 a[NL];
+        piece(i, a);
+        for (int j = j0; j < j1; ++j) {
+            const double4 n0 = *reinterpret_cast<const double4*>(s_node + (size_t)j * 8), n1 = *reinterpret_cast<const double4*>(s_node + (size_t)j * 8 + 4);
+            const double kp = kq * n0.x;
+            if (kp >= khi || kp < klo) {  // (the end intervals extrapolate: the reference's comparison k_i <= k' < k_i+1)
+                const int iold = i;
+                while (i < Nk - 2 && s_k[i + 1] <= kp) ++i;
+                while (i > 0 && s_k[i] > kp) --i;
+                if (i != iold) {
+                    klo = s_k[i];
+                    khi = s_k[i + 1];
+                    piece(i, a);
+                }
+            }
+            const double t = kp - klo;
+            double P = fma(fma(fma(a[0].w, t, a[0].z), t, a[0].y), t, a[0].x);
+            P = fma(fma(fma(fma(a[1].w, t, a[1].z), t, a[1].y), t, a[1].x), n0.y, P);
+            if (NL > 2) P = fma(fma(fma(fma(a[NL - 1].w, t, a[NL - 1].z), t, a[NL - 1].y), t, a[NL - 1].x), n0.z, P);
+            acc[0] = fma(n1.x, P, acc[0]);
+            acc[1] = fma(n1.y, P, acc[1]);
+            if (NL > 2) acc[NL - 1] = fma(n1.z, P, acc[NL - 1]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) s_red[((size_t)(wave - 1) * NL + l) * 64 + lane] = acc[l];
+    }
+    __syncthreads();
+    if (wave > 0 || k >= Nk) return;
+    const double* bw = bias + (size_t)w * NROW;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        double a = acc[l];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a += s_red[((size_t)q * NL + l) * 64 + lane];
+        double tot = cnorm * a;
+        for (int r = direct0; r < NROW; ++r) tot = fma(bw[r], T[(((size_t)w * NL + l) * NROW + r) * Nk + k], tot);
+        Plk[((size_t)w * NL + l) * Nk + k] = tot;
+        if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = tot;  // latency mode: P_l lands in mapped host memory as it is formed
+        if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
     }
 }
 

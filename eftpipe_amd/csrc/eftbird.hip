@@ -617,7 +617,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     // The IR filters / Q(f) and the AP prefix sums depend on the inputs only: when they are part of a longer stage set they
     // run on a side stream beside the (latency-bound) loop path and are joined right before their consumers.
     const bool side_ir = !nnlo_pass && (mask & EFTB_S_RESUM) && c.with_resum && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP));
-    const bool side_ap = !nnlo_pass && (mask & EFTB_S_AP) && c.with_ap && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP | EFTB_S_RESUM));
+    const bool side_ap0 = !nnlo_pass && (mask & EFTB_S_AP) && c.with_ap && (mask & (EFTB_S_PREP | EFTB_S_LOOPS | EFTB_S_CF | EFTB_S_REGROUP | EFTB_S_RESUM));
     // cross-run overlap of the front half (see engine.pre): only for asynchronous runs whose inputs are already in place
     // with_NNLO: CctNNLO rides in the resummation records of the first pass when the batch is large enough for unsplit s sums
     const bool nnlo_fused = c.with_nnlo && c.with_resum && Nl == 3 && e->resum_splits == 1 && !c.optiresum && !e->generic_resum;
@@ -646,6 +646,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                         (mask & EFTB_S_REGROUP) && e->RSAS;
     // ... and the per-s A operand of the Nl = 3 resummation (inputs only: Q(f), X, Y) is built on the side stream, off the chain
     const bool as_side = ahead && Nl == 3 && !e->generic_resum && e->RSAS2 && !direct;
+    const bool side_ap = side_ap0 && !direct;  // (direct-P_l runs take the AP stage as the node quadrature on one row: no prefix sums, no knot weights)
     if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
             return fail("eftb_run: stream fork failed");
@@ -924,6 +925,15 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 // (the fast path keeps the splines as B-spline coefficients -- one number per knot; the moment / quadrature forms as knot slopes)
                 hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, e->ap_mode == 0 ? EFTB_T_SPCBAND : EFTB_T_SPBAND), e->SD);
             }
+            if (dir) {  // the node quadrature on the contracted row (ap_plk_kernel); nothing else of the stage runs
+                const size_t lds = ((size_t)Nk + (size_t)c.nmu * 8 + 3 * APD_WMAX * 4 + 3 * 3 * 64) * sizeof(double);
+                hipLaunchKernelGGL((ap_plk_kernel<3>), dim3(((Nk + 63) / 64) * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
+                                   tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), e->SD,
+                                   tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], b[EFTB_B_PLK], e->plk_host_out,
+                                   e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21);
+                std::swap(*pin, *palt);
+                return 0;
+            }
             // prefix sums over mu per cosmology (side stream when possible), then interval moments by differences x cubic coefficients
             if (!side_ap && !nn) launch_ap_prefix(e, st, B);
             if (!joined_ap) {
@@ -945,20 +955,18 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             // REDUCE directly behind the AP stage: the bias contraction rides in the epilogue of ap_rows_kernel (and of the fallback tiles'
             // ap_direct_kernel), in the summation order of reduce_kernel(msplit) -- no separate pass over the 33 MB of AP output
             const bool red = fuse_reduce && !nn;
-            const int msplit = dir ? 1 : red ? msplit_cfg : (rlo + nr + 1) / 2;  // rows [rlo, msplit) / [msplit, nr) to the two half waves
-            const int direct0 = dir ? (c.ap_stochastic ? NROW : 21) : -1;  // (direct-P_l: first of the rows outside [rlo, nr) that enter the contraction)
-            double* tout = dir ? nullptr : *palt;
+            const int msplit = red ? msplit_cfg : (rlo + nr + 1) / 2;  // rows [rlo, msplit) / [msplit, nr) to the two half waves
             const double* rb = red ? b[EFTB_B_BIAS] : nullptr;
             double* rp = red ? b[EFTB_B_PLK] : nullptr;
             double* rph = red ? e->plk_host_out : nullptr;
             int* rflag = red && e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr;
             if (e->ap_fast) {
                 // banded product of the knot weights with the spline data; rows outside [rlo, nr) are copied through
-                const int kt2 = 2 * ((Nk + 63) / 64), nh = dir ? 2 : (nr - rlo + 1) / 2, nre = 2 * nh;
+                const int kt2 = 2 * ((Nk + 63) / 64), nh = (nr - rlo + 1) / 2, nre = 2 * nh;
                 const size_t lds = 0;  // (the window is a static array: 37 KB at most)
                 if (rlo + nre > NROW || msplit - rlo > nh || nr - msplit > nh || (nh != 2 && nh != 11 && nh != 12))
                     return fail("eftb_run: AP rows [%d, %d) split at %d do not fit the window layouts built into ap_rows_kernel", rlo, nr, msplit);
-#define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, tout, rb, rp, rph, rflag, direct0
+#define APR_ARGS Nk, rlo, nr, msplit, b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), e->APW, e->API, e->APM, *pin, e->SD, *palt, rb, rp, rph, rflag
 #define APR_LAUNCH(NLV, NHV) do { if (e->ap_ring == 2) hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 2>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); \
                                   else hipLaunchKernelGGL((ap_rows_kernel<NLV, NHV, 4>), dim3(kt2 * B), dim3(64 * NLV), lds, st, APR_ARGS); } while (0)
                 if (Nl == 3 && nh == 11) APR_LAUNCH(3, 11);
@@ -975,7 +983,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int4* gate = e->ap_fast ? e->APM : nullptr;
                 const dim3 dgrid(((Nk + 63) / 64) * B);
 #define APD_ARGS Nk, c.nmu, rlo, nr, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), \
-                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, tout, gate, rb, rp, rph, msplit, rflag, tb<double>(e, EFTB_T_SPLOCAL), direct0
+                 tb<double>(e, EFTB_T_LEGMU), e->APR, *pin, e->SD, *palt, gate, rb, rp, rph, msplit, rflag, tb<double>(e, EFTB_T_SPLOCAL)
                 if (e->ap_fast && Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3, true>), dgrid, dim3(64), 0, st, APD_ARGS);
                 else if (e->ap_fast) hipLaunchKernelGGL((ap_direct_kernel<2, true>), dgrid, dim3(64), 0, st, APD_ARGS);
                 else if (Nl == 3) hipLaunchKernelGGL((ap_direct_kernel<3, false>), dgrid, dim3(64), 0, st, APD_ARGS);
