@@ -164,6 +164,17 @@ struct eftb_engine {
     // follows off the critical path; only the few KB of f / DA / H / bias are waited for, copied on the compute queue itself), and P_l is
     // written to mapped host memory by the kernel that forms it (no DMA phase).  (Measured and dropped: the AP tables beside the resummation
     // instead of beside the loop chain -- the chain gained 20 us, the resummation lost 39.)
+    // direct-P_l runs in the three-stream layout keep their FRONT (operand rows, first-stage products, anti-diagonal sums, synthesis rows, Q(f):
+    // functions of the inputs alone) on the side stream, one run ahead of the rest of the look-ahead chain (syntheses, contraction, operand
+    // build): two sets of everything the front writes, swapped per run
+    struct FrontSet {
+        double *PA1 = nullptr, *PA2 = nullptr, *PA2T = nullptr, *PA3 = nullptr, *coefT = nullptr, *A22 = nullptr, *A13 = nullptr, *ACF = nullptr, *ALC = nullptr;
+        double *P11 = nullptr, *COEF = nullptr, *XY = nullptr, *Q = nullptr;
+        double2* SAD = nullptr;
+    } alt;
+    hipEvent_t evFront = nullptr, evFrontFree[2] = {nullptr, nullptr};  // this run's front is done (side stream); the readers of front set [slot] are done
+    unsigned front_step = 0;
+    bool prev_front_side = false;
     bool plk_direct = false;            // EFTB_O_PLK_DIRECT: whole-pipeline runs that end in REDUCE contract with the bias first (regroup_plk_kernel)
     bool latency_auto = true;           // EFTB_LATENCY_MODE=0 disables
     bool set_latency[NSETS] = {};
@@ -646,6 +657,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                         (mask & EFTB_S_REGROUP) && e->RSAS;
     // ... and the per-s A operand of the Nl = 3 resummation (inputs only: Q(f), X, Y) is built on the side stream, off the chain
     const bool as_side = ahead && Nl == 3 && !e->generic_resum && e->RSAS2 && !direct;
+    // ... whose front runs a step ahead on the side stream (see FrontSet)
+    const bool front_side = direct && ahead && e->alt.A22 && (mask & EFTB_S_PREP) && (mask & (EFTB_S_LOOPS | EFTB_S_CF)) && xy_in_prep;
+    hipStream_t fst = st;  // where the front's kernels go
     const bool side_ap = side_ap0 && !direct;  // (direct-P_l runs take the AP stage as the node quadrature on one row: no prefix sums, no knot weights)
     if ((side_ir || side_ap) && !pre_side) {
         if (hipEventRecord(e->evFork, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evFork, 0) != hipSuccess)
@@ -658,12 +672,24 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     bool joined = !side_ir, joined_ap = !side_ap;
     if (mask & EFTB_S_PREP) {
         hipStream_t st0 = st;
-        if (pre_side) {
+        if (front_side) {
+            // the front of this run goes to the side stream, into the set the run before the previous one used (its readers -- syntheses,
+            // contraction, operand build -- have signalled evFrontFree); the rest of the chain (pre stream) picks up at the syntheses
             st = e->pre;
-            static const int whatif0 = getenv("EFTB_WHATIF") ? atoi(getenv("EFTB_WHATIF")) : 0;
-            if (!(whatif0 & 4) && hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            eftb_engine::FrontSet& a = e->alt;
+            std::swap(e->PA1, a.PA1); std::swap(e->PA2, a.PA2); std::swap(e->PA2T, a.PA2T); std::swap(e->PA3, a.PA3); std::swap(e->coefT, a.coefT);
+            std::swap(e->A22, a.A22); std::swap(e->A13, a.A13); std::swap(e->ACF, a.ACF); std::swap(e->ALC, a.ALC); std::swap(e->SAD, a.SAD);
+            std::swap(b[EFTB_B_P11], a.P11); std::swap(b[EFTB_B_COEF], a.COEF); std::swap(b[EFTB_B_XY], a.XY); std::swap(b[EFTB_B_Q], a.Q);
+            fst = e->side;
+            if (hipStreamWaitEvent(fst, e->evFrontFree[e->front_step & 1], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            if (!e->prev_front_side && hipStreamWaitEvent(fst, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            launch_irfilter(e, fst, B, !xy_in_prep);
+            if (hipEventRecord(e->evJoin, fst) != hipSuccess || hipEventRecord(e->evJoinAP, fst) != hipSuccess) return fail("eftb_run: stream join failed");
+        } else if (pre_side) {
+            st = e->pre;
+            if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             // (X, Y of the previous run are also read by its operand build on the side stream, which evInFree does not cover)
-            if (!(whatif0 & 8) && as_side && hipStreamWaitEvent(st, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
+            if (as_side && hipStreamWaitEvent(st, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             // the input-only kernels (IR filters / Q(f); AP prefix sums and knot weights) get their own low-priority stream beside the front
             // half: X, Y, Q are free since the previous run built its resummation operands (evInFree); the AP tables alternate between two
             // sets because the previous run's AP reads its own late (the set written here was last read two runs ago: evBack)
@@ -686,9 +712,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // operand rows, then every first-stage product in one launch on the matrix cores: P11, the FFTLog coefficients (and their
         // cosmology-contiguous transpose for the anti-diagonal pass), the second coefficient set of IRcutoff "loop" / "resum" (reference
         // pybird.py:1151-1160), and X(s), Y(s) when a resummation follows in this run
-        static const int whatif = getenv("EFTB_WHATIF") ? atoi(getenv("EFTB_WHATIF")) : 0;  // timing experiments only (results are those of an earlier step)
-        if (!((whatif & 1) && pre_side && e->rs_step > 4)) launch_prep_rows(e, st, B, true, xy_in_prep);
-        if (!((whatif & 1) && pre_side && e->rs_step > 4)) {
+        if (!front_side) fst = st;
+        launch_prep_rows(e, fst, B, true, xy_in_prep);
+        {
             SynthBatch sb{};
             const int KP1 = (int)kpad(c.Nkin), KP2 = (int)kpad(c.Nkin + c.ntail);
             queue_synth(sb, e->PA1, 0, 1, B, KP1, tb<double>(e, EFTB_T_SKT), Nk, b[EFTB_B_P11], 0, nullptr, nullptr);
@@ -699,7 +725,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 queue_synth(sb, tb<double>(e, EFTB_T_GCT2T), KP2, 2 * NCH, 1, KP2, e->PA2T, c.max_batch, e->coefT2, c.max_batch, nullptr, nullptr);
             }
             if (xy_in_prep) queue_xy(e, sb, B);
-            if (int rc = launch_gemm_direct(st, sb, e->gd_waves)) return rc;
+            if (int rc = launch_gemm_direct(fst, sb, e->gd_waves)) return rc;
         }
         if (as_side) {  // behind the AP tables on the side stream; the set written here was last read by the resummation two runs ago
             if (xy_in_prep && (hipEventRecord(e->evXY, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evXY, 0) != hipSuccess))
@@ -723,10 +749,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         if (mask & EFTB_S_LOOPS) sets |= 0x4;
         if (mask & (EFTB_S_CF | EFTB_K_C22)) sets |= 0x2;
         if (mask & EFTB_S_CF) sets |= 0x8;
-        static const int whatif2 = getenv("EFTB_WHATIF") ? atoi(getenv("EFTB_WHATIF")) : 0;
-        if ((whatif2 & 2) && pre_side && e->rs_step > 4) {
-        } else if (!c.dual_coef) {
-            if (int rc = launch_antidiag_rows(e, st, B, sets, b[EFTB_B_COEF], e->coefT)) return rc;
+        if (!c.dual_coef) {
+            if (int rc = launch_antidiag_rows(e, front_side ? fst : st, B, sets, b[EFTB_B_COEF], e->coefT)) return rc;
+            if (front_side && (hipEventRecord(e->evFront, fst) != hipSuccess || hipStreamWaitEvent(st, e->evFront, 0) != hipSuccess))
+                return fail("eftb_run: stream join failed");
         } else {  // k-space rows from the first coefficient set, xi-space rows from the second (the sums are recomputed in between)
             if (sets & 0x5)
                 if (int rc = launch_antidiag_rows(e, st, B, (sets & 0x5) | 0x10, b[EFTB_B_COEF], e->coefT)) return rc;
@@ -838,6 +864,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), plds, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF,
                                    tb<double>(e, EFTB_T_EXPC), b[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), tb<double>(e, EFTB_T_L22),
                                    tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], e->RSAS);
+                if (front_side) {  // the last reader of this run's front set
+                    if (hipEventRecord(e->evFrontFree[e->front_step & 1], st) != hipSuccess) return fail("eftb_run: event record failed");
+                    ++e->front_step;
+                }
             }
             else if (full && Nl == 3 && !as_side) launch_resum_as(e, st, B);  // (in line: X, Y, Q(f) are in place behind evJoin)
             if (full && direct) {
@@ -1041,6 +1071,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         ++e->back_step;
         e->back_pending = true;
     }
+    if (mask & EFTB_S_PREP) e->prev_front_side = front_side;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail("kernel launch failed: %s", hipGetErrorString(le));
     return 0;
@@ -1198,6 +1229,9 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_of("EFTB_SIDE_PRIO", 0)));
     HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_of("EFTB_PRE_PRIO", prio_hi)));
     HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evFront, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evFrontFree[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->evFrontFree[1], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evXY, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evAS, hipEventDisableTiming));
     if (const char* f = getenv("EFTB_AP_OVERLAP")) e->ap_overlap = atoi(f) != 0;
@@ -1248,6 +1282,15 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         bad |= zalloc(&e->A22, B * BAS22 * KSYN) | zalloc(&e->A13, B * 10 * KLIN) | zalloc(&e->Y22, B * BAS22 * c.Nk);
         if (c.with_resum) bad |= zalloc(&e->ACF, B * BASC * KSYN) | zalloc(&e->ALC, B * (c.with_nnlo ? 3 : 2) * c.Nl * KLIN) | zalloc(&e->YCF, B * BASC * NS);
         if (bad) return fail("eftb_create: out of device memory for the loop scratch");
+        if (c.with_resum && c.Nl == 3 && !c.dual_coef) {  // second set of the front's outputs (direct-P_l runs, see FrontSet)
+            eftb_engine::FrontSet& a = e->alt;
+            bad = zalloc(&a.coefT, 2 * NCH * B) | zalloc(&a.PA1, B * kpad(c.Nkin)) | zalloc(&a.PA2, B * kpad(c.Nkin + c.ntail)) | zalloc(&a.PA2T, B * kpad(c.Nkin + c.ntail)) |
+                  zalloc(&a.PA3, B * kpad(c.Nkin + c.nxtail)) | zalloc(reinterpret_cast<double**>(&a.SAD), 2 * (size_t)AD_CH * B * nc * NPOW) |
+                  zalloc(&a.A22, B * BAS22 * KSYN) | zalloc(&a.A13, B * 10 * KLIN) | zalloc(&a.ACF, B * BASC * KSYN) | zalloc(&a.ALC, B * (c.with_nnlo ? 3 : 2) * c.Nl * KLIN) |
+                  zalloc(&a.P11, e->buf_elems[EFTB_B_P11]) | zalloc(&a.COEF, e->buf_elems[EFTB_B_COEF]) | zalloc(&a.XY, e->buf_elems[EFTB_B_XY]) |
+                  zalloc(&a.Q, e->buf_elems[EFTB_B_Q]);
+            if (bad) return fail("eftb_create: out of device memory for the second front set");
+        }
     }
     HIPCHK(hipMalloc(&e->Talt, (e->buf_elems[EFTB_B_TEMPL] + 2) * sizeof(double)));
     if (c.with_ap) {
@@ -1561,7 +1604,7 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->RSA, e->RSC, e->RSA2, e->RSC2, e->RSAS, e->RSAS2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->TaltN, e->T3N, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->alt.PA1, e->alt.PA2, e->alt.PA2T, e->alt.PA3, e->alt.coefT, e->alt.A22, e->alt.A13, e->alt.ACF, e->alt.ALC, e->alt.P11, e->alt.COEF, e->alt.XY, e->alt.Q, reinterpret_cast<double*>(e->alt.SAD), e->RSA, e->RSC, e->RSA2, e->RSC2, e->RSAS, e->RSAS2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->TaltN, e->T3N, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
@@ -1573,7 +1616,7 @@ void eftb_destroy(eftb_engine* e) {
     for (auto& o : e->ops) if (o.dev) (void)hipFree(o.dev);
     for (void* p : {(void*)e->like_index, (void*)e->like_data, (void*)e->like_invcov, (void*)e->like_mu, (void*)e->like_sinv, (void*)e->like_V, (void*)e->like_U}) if (p) (void)hipFree(p);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evXY, e->evAS, e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1], e->evRsDone[0], e->evRsDone[1]}) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev0, e->ev1, e->evFork, e->evJoin, e->evJoinAP, e->evXY, e->evAS, e->evFront, e->evFrontFree[0], e->evFrontFree[1], e->evSnap, e->evGathered, e->evPrep, e->evInFree, e->evResum, e->evBack[0], e->evBack[1], e->evRsDone[0], e->evRsDone[1]}) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->evRun) if (ev) (void)hipEventDestroy(ev);
     for (int t = 0; t < eftb_engine::NTIMER; ++t) {
         if (e->evT0[t]) (void)hipEventDestroy(e->evT0[t]);
