@@ -59,7 +59,7 @@ struct eftb_engine {
     unsigned rs_step = 0;
     // flow control of asynchronous runs: at most RUN_DEPTH runs are in flight (a caller that never synchronises cannot grow the runtime's
     // command queues without bound; four runs ahead is more than the three-stream layout can use)
-    static constexpr int RUN_DEPTH = 4;
+    static constexpr int RUN_DEPTH = 8;
     hipEvent_t evRun[RUN_DEPTH] = {};
     unsigned long long run_seq = 0;
     bool nnlo_inline = true;  // EFTB_NNLO_INLINE=0: with_NNLO steps never take the three-stream layout
@@ -110,7 +110,7 @@ struct eftb_engine {
     // One pair per rotating set of the staged API (status[2 q], status[2 q + 1]: raised and cleared with step q's own results, whatever runs
     // beside it) and one pair (slot NSETS) for runs on the engine's own buffers (eftb_put / eftb_run / eftb_eval_batch).
     int* status = nullptr;
-    int status_slot = 4;            // = NSETS: pair the kernels of the next launch raise (eftb_run_staged: the step's set)
+    int status_slot = 8;            // = NSETS: pair the kernels of the next launch raise (eftb_run_staged: the step's set)
     int gath_set[4] = {4, 4, 4, 4};  // set whose P_l exchange `slot` carries (its flags are checked when the gathered block is handed out)
     unsigned long long staged_launched = 0;  // eftb_run_staged calls so far: eftb_fetch_back(back) needs back < staged_launched
     bool check_finite = false;
@@ -149,7 +149,8 @@ struct eftb_engine {
     hipStream_t opstream = nullptr;  // where the operator launchers put their kernels (null: the main stream)
     // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_back): four sets of the per-step inputs (PIN, F, DA,
     // H, BIAS, GROWS) and outputs (PLK, LOGP) -- up to three launched and not yet fetched, one whose results are being fetched / refilled
-    static constexpr int NSETS = 4;  // rotating sets of per-step inputs / outputs: the host may run three steps ahead of the step it fetches
+    static constexpr int NSETS = 8;  // rotating sets of per-step inputs / outputs: the host may run seven steps ahead of the step it fetches (a step's way from
+                                     // the staging block to the fetched P_l is four pipeline stages long since the direct-P_l runs: four sets left bubbles)
     double* setbuf[NSETS][EFTB_B_COUNT] = {{nullptr}};
     double* setblock[NSETS] = {};   // one contiguous input block per set (PIN, F, DA, H, BIAS, GROWS at stage_off[])
     double* orig[EFTB_B_COUNT] = {nullptr};              // the engine's own buffers, current until the first staged run
@@ -1958,7 +1959,7 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
 
 int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_back: null argument");
-    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_back: back must be 0 (the step launched last), 1, 2 or 3 (that many steps before it)");
+    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_back: back must be 0 (the step launched last) ... 7 (that many steps before it)");
     if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_back: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
     if (!e->cpy) return fail("eftb_fetch_back: no staged run yet");
     if (count > e->buf_elems[id]) return fail("eftb_fetch_back: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
@@ -1980,7 +1981,7 @@ int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) { re
 
 int eftb_fetch_view(eftb_engine* e, int back, int id, const double** block, size_t* count) {
     if (!e || !block) return fail("eftb_fetch_view: null argument");
-    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_view: back must be 0 (the step launched last), 1, 2 or 3 (that many steps before it)");
+    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_view: back must be 0 (the step launched last) ... 7 (that many steps before it)");
     if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_view: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
     if (!e->cpy) return fail("eftb_fetch_view: no staged run yet");
     if ((unsigned long long)back >= e->staged_launched)
@@ -2096,7 +2097,7 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
 
 // waits for the copy-out of the exchange `which` exchanges back and returns where its block sits in host memory
 static int gathered_ready(eftb_engine* e, const char* who, int which, int* slot) {
-    if (which < 0 || which >= eftb_engine::NSETS) return fail("%s: `back` must be 0 (the last exchange enqueued), 1, 2 or 3 (that many exchanges before it)", who);
+    if (which < 0 || which >= eftb_engine::NSETS) return fail("%s: `back` must be 0 (the last exchange enqueued) ... 7 (that many exchanges before it)", who);
     const int q = (e->gather_slot + eftb_engine::NSETS - which) % eftb_engine::NSETS;
     if (!e->gathered2[q] || !e->gath_elems[q]) return fail("%s: no such exchange yet", who);
     HIPCHK(hipSetDevice(e->c.device));

@@ -326,9 +326,9 @@ class Engine:
             self.dims = self.out_dims()
 
     def fetch_previous(self, name, shape, out=None, back=1, copy=True):
-        """PLK / LOGP of the step launched `back` (0: the last one; 1, 2 or 3) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
+        """PLK / LOGP of the step launched `back` (0: the last one; 1 ... 7) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
         to fill).  back=3 keeps three steps queued while the host works (see ``pipeline``).  copy=False: a read-only view of the engine's page-locked
-        host copy of the block (no 1.5 MB memcpy on the sampler's critical path), valid until three more steps have been staged."""
+        host copy of the block (no 1.5 MB memcpy on the sampler's critical path), valid until seven more steps have been staged."""
         if not copy:
             ptr, n = C.POINTER(C.c_double)(), C.c_size_t()
             L.check(self.lib.eftb_fetch_view(self._h, int(back), L.B[name], C.byref(ptr), C.byref(n)))

@@ -250,14 +250,15 @@ int  eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f
 int  eftb_run_staged(eftb_engine* e, int stage_mask, int B);
 /* EFTB_B_PLK or EFTB_B_LOGP of the step before the one in flight (waits only for that step). */
 int  eftb_fetch_previous(eftb_engine* e, int buffer_id, double* host, size_t count);
-/* The same for the step launched `back` (0 = the last one itself, 1, 2 or 3) steps before the last one.  The engine keeps four sets of per-step inputs / outputs, so the
+/* The same for the step launched `back` (0 = the last one itself, 1 ... 7) steps before the last one.  The engine keeps eight sets of per-step inputs / outputs, so the
  * loop  stage(i); run_staged(i); fetch_back(3) [= step i - 3]  keeps THREE steps queued on the GPU while the host copies results out and
  * prepares the next inputs: the inputs of step i + 1 are then staged before the back half of step i - 1 has finished, and the look-ahead
- * of consecutive steps never runs dry (with back = 2 the look-ahead stream idled ~0.1 ms per step waiting for the host); the set read with
- * back = 3 is the one the next eftb_stage_inputs refills. */
+ * of consecutive steps never runs dry (with back = 2 the look-ahead stream idled ~0.1 ms per step waiting for the host).  Direct-P_l runs
+ * (EFTB_O_PLK_DIRECT) are four pipeline stages deep -- front, syntheses + contraction, resummation, AP -- and want back = 4 or 5; the set
+ * read with back = 7 is the one the next eftb_stage_inputs refills. */
 int  eftb_fetch_back(eftb_engine* e, int back, int buffer_id, double* host, size_t count);
 /* The same results without the host copy: *block points at the engine's page-locked host copy of the step's EFTB_B_PLK / EFTB_B_LOGP block
- * (*count = its capacity in elements), valid until NSETS - 1 = 3 more steps have been staged.  For samplers that consume P_l in place (the
+ * (*count = its capacity in elements), valid until NSETS - 1 = 7 more steps have been staged.  For samplers that consume P_l in place (the
  * dependent loop of reference likelihood.py:570-594: chi^2 from P_l, then the next proposal). */
 int  eftb_fetch_view(eftb_engine* e, int back, int buffer_id, const double** block, size_t* count);
 

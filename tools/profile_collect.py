@@ -83,51 +83,75 @@ except SystemExit:
 
 bench = json.load(open(os.path.join(src, "bench.json")))
 stats = {short(r["Name"]): r for r in csv.DictReader(open(find("stats_kernel_stats.csv")))}
-dom = next(k for k in avg if k.startswith("eftb::resum_mfma_kernel"))
-c = avg[dom]
 B, NK = bench["config"]["batch_per_gpu"], 512
-out = {
-    "kernel": f"{dom} (Resum.Ps), batch {B}, Nk {NK}",
-    "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
-    "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
-    "note": "(2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
-            "128-B requests of wide streams as 64 B) -- calibrated here for this kernel's own 8-byte-per-lane reads as well: "
-            f"{tag}_fetch_calibration.json, 1 GiB streamed at 8 and at 16 bytes per lane both read bytes / (FETCH_SIZE*1024) = 2.000. "
-            f"Algorithmic bytes per launch: H table 3*80*{NK}*8 = {3 * 80 * NK * 8 / 1e6:.1f} MB (L2-resident, re-read per cosmology) + per-s records "
-            f"{B * 80 * 48 * 8 / 1e6:.1f} MB + template read-modify-write 2*{B}*63*{NK}*8 = {2 * B * 63 * NK * 8 / 1e6:.0f} MB.",
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
-    "kernel_cycles_est": c["GRBM_GUI_ACTIVE"] / 8.0,
-    "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
-    "effective_clock_GHz": c["GRBM_GUI_ACTIVE"] / 8.0 / c["duration_ns_under_pmc"],
-    "duration_us_under_pmc": c["duration_ns_under_pmc"] / 1e3,
-    "L2_hit": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
-    "rocprof_avg_us": float(stats[dom]["AverageNs"]) / 1e3,
-    "bench_hip_event_us": bench["roofline"]["ms_per_launch"] * 1e3,
-    "bench_hip_event_alone_us": bench["roofline"].get("ms_per_launch_alone", 0.0) * 1e3,
+tr = list(csv.DictReader(open(find("stats_kernel_trace.csv"))))
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], short(r["Kernel_Name"])) for r in tr]
+gy = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) for r in tr}
+
+ALGO = {
+    "eftb::resum_mfma_kernel": f"H table 3*80*{NK}*8 = {3 * 80 * NK * 8 / 1e6:.1f} MB (L2-resident, re-read per cosmology) + per-s records {B * 80 * 48 * 8 / 1e6:.1f} MB + per-s operand "
+                               f"{B * 80 * 512 * 8 / 1e6:.1f} MB + template read-modify-write 2*{B}*63*{NK}*8 = {2 * B * 63 * NK * 8 / 1e6:.0f} MB",
+    "eftb::resum_plk_kernel": f"H table {3 * 80 * NK * 8 / 1e6:.1f} MB (L2-resident) + coefficient table {B * 80 * 160 * 8 / 1e6:.1f} MB (scalar loads) + P_l read-modify-write "
+                              f"2*{B}*3*{NK}*8 = {2 * B * 3 * NK * 8 / 1e6:.1f} MB",
+    "eftb::synth_kernel": f"synthesis bases syn_k / syn_s / lin_k / lin_s ({(528 * NK + 528 * 80 + 288 * NK + 288 * 80) * 8 / 1e6:.1f} MB, re-read per row tile through the L2) + row operands "
+                          f"{B * (8 * 528 + 32 * 528 + 10 * 288 + 6 * 288) * 8 / 1e6:.1f} MB + outputs {B * (8 * NK + 32 * 80 + 10 * NK + 6 * 80) * 8 / 1e6:.1f} MB",
 }
-# the rocprof average mixes the pipelined launches of the timed region (other kernels beside them) with the stand-alone launches of the
-# per-stage timings that follow: split the kernel trace by whether a kernel of another queue ran during the launch
-try:
-    tr = list(csv.DictReader(open(find("stats_kernel_trace.csv"))))
-    ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], short(r["Kernel_Name"])) for r in tr]
-    # bench-batch launches only: the most frequent grid of the kernel (the command also launches it at batch 1-2 and 256)
-    gy = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) for r in tr}
-    gcnt = collections.Counter(g for (s_, e_), g in gy.items()
-                               if any(n.startswith("eftb::resum_mfma_kernel") and (s1, e1) == (s_, e_) for s1, e1, q1, n in ev))
+
+
+def kernel_block(prefix, hip_ms=None, hip_alone_ms=None):
+    """PMC / rocprof summary of the bench-batch launches of the kernel whose (short) name starts with `prefix`."""
+    dom = next(k for k in avg if k.startswith(prefix))
+    c = avg[dom]
+    o = {
+        "kernel": f"{dom}, batch {B}, Nk {NK}",
+        "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+        "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+        "note": "(2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of wide streams as 64 B) -- "
+                f"calibrated for 8-byte-per-lane reads as well: {tag}_fetch_calibration.json, 1 GiB streamed at 8 and at 16 bytes per lane both read bytes / (FETCH_SIZE*1024) = 2.000. "
+                "Algorithmic bytes per launch: " + next((v for k, v in ALGO.items() if dom.startswith(k)), "n/a") + ".",
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        "kernel_cycles_est": c["GRBM_GUI_ACTIVE"] / 8.0,
+        "mfma_busy_frac": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+        "valu_insts_per_simd_cycle": c["SQ_INSTS_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+        "effective_clock_GHz": c["GRBM_GUI_ACTIVE"] / 8.0 / c["duration_ns_under_pmc"],
+        "duration_us_under_pmc": c["duration_ns_under_pmc"] / 1e3,
+        "L2_hit": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
+        "rocprof_avg_us": float(stats[dom]["AverageNs"]) / 1e3,
+    }
+    if hip_ms is not None:
+        o["bench_hip_event_us"] = hip_ms * 1e3
+    if hip_alone_ms is not None:
+        o["bench_hip_event_alone_us"] = hip_alone_ms * 1e3
+    # the rocprof average mixes the pipelined launches of the timed region (other kernels beside them) with stand-alone launches (per-stage timings, PMC-free
+    # synchronous calls): split the kernel trace by whether a kernel of another queue ran during the launch; bench-batch launches only (largest launches x grid)
+    gcnt = collections.Counter(gy[(s_, e_)] for s_, e_, q_, n_ in ev if n_ == dom)
     gbig = max(gcnt.items(), key=lambda kv: kv[0] * kv[1])[0]
     beside, alone = [], []
     for s0, e0, q0, n0 in ev:
-        if not n0.startswith("eftb::resum_mfma_kernel") or gy[(s0, e0)] != gbig:
+        if n0 != dom or gy[(s0, e0)] != gbig:
             continue
         shared = sum(max(0, min(e0, e1) - max(s0, s1)) for s1, e1, q1, n1 in ev if q1 != q0 and e1 > s0 and s1 < e0)
         (beside if shared > 0.2 * (e0 - s0) else alone).append((e0 - s0) / 1e3)
-    out["rocprof_avg_us_pipelined_launches"] = sum(beside) / len(beside) if beside else None
-    out["rocprof_avg_us_standalone_launches"] = sum(alone) / len(alone) if alone else None
-    out["rocprof_launches_pipelined_standalone"] = [len(beside), len(alone)]
-    out["rocprof_split_note"] = ("kernel trace of the same command; 'pipelined' = a kernel of another queue ran during more than 20 % of the launch "
-                                 "(compare with bench_hip_event_us), 'standalone' = the rest (compare with bench_hip_event_alone_us)")
-except SystemExit:
-    pass
+    o["rocprof_avg_us_pipelined_launches"] = sum(beside) / len(beside) if beside else None
+    o["rocprof_avg_us_standalone_launches"] = sum(alone) / len(alone) if alone else None
+    o["rocprof_launches_pipelined_standalone"] = [len(beside), len(alone)]
+    o["rocprof_split_note"] = ("kernel trace of the same command; 'pipelined' = a kernel of another queue ran during more than 20 % of the launch (compare with "
+                               "bench_hip_event_us), 'standalone' = the rest")
+    return o
+
+
+roof = bench["roofline"]
+top = "eftb::" + roof["kernel"].split(" (")[0].split("<")[0]
+out = kernel_block(top, roof["ms_per_launch"], roof.get("ms_per_launch_alone"))
+out["others"] = []
+for o in roof.get("roofline_others", []):
+    try:
+        out["others"].append(kernel_block("eftb::" + o["kernel"].split(" (")[0].split("<")[0], o["ms_per_launch"]))
+    except StopIteration:
+        pass
+tf = roof.get("roofline_templates_first")
+if tf:  # the dominant kernel of the templates-first step (the step `value` was measured on up to round 2), timed alone
+    out["templates_first"] = kernel_block("eftb::resum_mfma_kernel", None, tf.get("ms_per_launch_alone"))
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_dominant.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
-print("evaluations/s", bench["value"], "ms/step", bench["ms_per_step"], "stage_ms", bench["roofline"]["stage_ms"])
+print("evaluations/s", bench["value"], "ms/step", bench["ms_per_step"], "stage_ms", (tf or roof).get("stage_ms"))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One line per run for the library in EFTB_LIB (GPU box): the resummation kernel alone (back-to-back launches, HIP events), the
+"""One line per run for the library in EFTB_LIB (GPU box; templates-first runs): the resummation kernel alone (back-to-back launches, HIP events), the
 resident pipelined loop and the staged loop at fetch depth 2 (ms per step of 128 cosmologies), and a checksum of P_l of the last
 staged step (two builds that should agree agree here to ~1e-12)."""
 import os
@@ -17,14 +17,6 @@ from eftpipe_amd.tables import EngineConfig
 
 Z, B, K = 0.7, 128, int(os.environ.get("HP_K", 40))
 BS = [2.14, 0.55, 0.77, 0.55, -1.84, -1.89, -1.49]
-if os.environ.get("EFTB_OLD_RS"):  # A/B against a library built before the per-s operand: its row table
-    import importlib.util
-    from eftpipe_amd import tables as _T
-    spec = importlib.util.spec_from_file_location("eftpipe_amd.old_tables", os.path.join(os.path.dirname(_T.__file__), "ab", "old_tables.py"))
-    _old = importlib.util.module_from_spec(spec)
-    sys.modules["eftpipe_amd.old_tables"] = _old
-    spec.loader.exec_module(_old)
-    _T.resum_mfma_tables = _old.resum_mfma_tables
 cfg = EngineConfig(Nl=3, k=synth.survey_kgrid(512), with_resum=True, with_ap=True,
                    DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
 eng = Engine(cfg, max_batch=B)

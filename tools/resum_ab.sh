@@ -7,8 +7,7 @@ for i in $(seq 1 $rounds); do
   for spec in "$@"; do
     lib=${spec%%:*}; wps=2; [[ $spec == *:* ]] && wps=${spec##*:}
     [[ $lib == "-" ]] && lib=""
-    old=""; [[ $lib == *old* ]] && old=1
-    EFTB_OLD_RS=$old EFTB_LIB=$lib EFTB_RESUM_WPS=$wps timeout -k 10 120 python3 tools/resum_ab.py 2>>gpurun_out/resum_ab.err | tail -1 >> $out || { echo "failed: $spec" >> $out; cat $out; exit 1; }
+    EFTB_LIB=$lib EFTB_RESUM_WPS=$wps timeout -k 10 120 python3 tools/resum_ab.py 2>>gpurun_out/resum_ab.err | tail -1 >> $out || { echo "failed: $spec" >> $out; cat $out; exit 1; }
   done
 done
 cat $out

@@ -18,6 +18,8 @@ BS = [2.14, 0.55, 0.77, 0.55, -1.84, -1.89, -1.49]
 cfg = EngineConfig(Nl=3, k=synth.survey_kgrid(512), with_resum=True, with_ap=True,
                    DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
 eng = Engine(cfg, max_batch=B)
+eng.set_latency_mode(False)
+eng.set_plk_direct(os.environ.get("HP_DIRECT", "1") == "1")
 sets = []
 for i in range(8):
     d = synth.draw_batch(B, z=Z, seed=100 + i)
