@@ -65,5 +65,5 @@ resident()
 alone = min(eng.run_timed(L.K_RESUM, B, 20) for _ in range(3))
 r = timeit(resident)
 s = timeit(staged)
-print(f"{os.environ.get('EFTB_LIB', 'in-tree'):28s} wps={os.environ.get('EFTB_RESUM_WPS', '2')}  resum alone {alone * 1e3:6.1f} us   resident {r:.4f}   staged {s:.4f} ms/step"
+print(f"{os.environ.get('EFTB_LIB', 'in-tree'):28s} resum alone {alone * 1e3:6.1f} us   resident {r:.4f}   staged {s:.4f} ms/step"
       f"   checksum {np.abs(out[K - 1]).sum():.12e}")
