@@ -263,6 +263,133 @@ __global__ __launch_bounds__(64) void build_rows_kernel(int sets, int Bmax, int 
     }
 }
 
+__device__ inline double ipow(double f, int p) {
+    double r = 1.0;
+    for (int i = 0; i < p; ++i) r *= f;
+    return r;
+}
+
+// Direct-P_l runs (EFTB_O_PLK_DIRECT): the bias contraction commutes with the synthesis as well -- it is linear in the rows -- so the rows are
+// contracted HERE, before the matrix-core products: per cosmology 3 rows (one per multipole) instead of 7 for the P22 basis, 3 instead of 10 for
+// P13, 3 instead of Nl (7 + 2) = 27 for the xi-space basis; the C11 / Cct rows are scaled by sum_i b_i l11[l'][i] / sum_i b_3+i lct[l'][i].
+// Weights: cf_l[b] = b_group(b) f^power(b) mu-weight_l(b) per loop piece b (regroup_kernel), contracted with the combination matrices of the
+// loop-matrix basis (tables.loop_basis: exp22 [28][BAS22], expc [Nl 38][BASC], block-diagonal in l).  Same grid and lanes as build_rows_kernel.
+template <int NC>
+__global__ __launch_bounds__(64) void build_rows_plk_kernel(int Bmax, int nb, const double* __restrict__ coef, const double2* __restrict__ S,
+                                                             const double2* __restrict__ mlj, const double2* __restrict__ linvec,
+                                                             const double* __restrict__ bias, const double* __restrict__ fgrow,
+                                                             const double* __restrict__ l11, const double* __restrict__ lct,
+                                                             const double* __restrict__ l22, const double* __restrict__ l13,
+                                                             const int* __restrict__ grp, const double* __restrict__ exp22,
+                                                             const double* __restrict__ expc, double* __restrict__ A22, double* __restrict__ A13,
+                                                             double* __restrict__ ACF, double* __restrict__ ALC) {
+    constexpr int NL = 3;
+    __shared__ double s_cf[NL * 38];   // cf_l[b]
+    __shared__ double s_w[NL * NC];    // k space: sum_b cf_l[b] exp22[b][q] (q < nb); xi space: sum_b cf_l'[b] expc[row(l', b)][l' NC + q]
+    __shared__ double s_b[2 * NL];
+    const int w = blockIdx.x, cf = blockIdx.y, jp = blockIdx.z * 64 + threadIdx.x;
+    const double* bw = bias + (size_t)w * NROW;
+    const double f = fgrow[w];
+    for (int e = threadIdx.x; e < NL * 38; e += 64) {
+        const int l = e / 38, bq = e % 38;
+        s_cf[e] = bw[9 + grp[2 * bq]] * ipow(f, grp[2 * bq + 1]) * (bq < 28 ? l22[l * 28 + bq] : l13[l * 10 + (bq - 28)]);
+    }
+    if (threadIdx.x < 2 * NL) {
+        const int a = threadIdx.x / NL, lp = threadIdx.x % NL;
+        double v = 0.0;
+        if (a == 0)
+            for (int r = 0; r < 3; ++r) v = fma(bw[r], l11[lp * 3 + r], v);
+        else
+            for (int r = 0; r < 6; ++r) v = fma(bw[3 + r], lct[lp * 6 + r], v);
+        s_b[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NL * NC) {
+        const int l = threadIdx.x / NC, q = threadIdx.x % NC;
+        double v0 = 0.0, v1 = 0.0;
+        if (cf == 0) {
+            if (q < nb)
+                for (int b = 0; b < 28; b += 2) {
+                    v0 = fma(s_cf[l * 38 + b], exp22[b * BAS22 + q], v0);
+                    v1 = fma(s_cf[l * 38 + b + 1], exp22[(b + 1) * BAS22 + q], v1);
+                }
+        } else {
+            for (int b = 0; b < 28; b += 2) {
+                v0 = fma(s_cf[l * 38 + b], expc[(size_t)(l * 28 + b) * BASC + l * NC + q], v0);
+                v1 = fma(s_cf[l * 38 + b + 1], expc[(size_t)(l * 28 + b + 1) * BASC + l * NC + q], v1);
+            }
+            for (int b = 0; b < 10; b += 2) {
+                v0 = fma(s_cf[l * 38 + 28 + b], expc[(size_t)(NL * 28 + l * 10 + b) * BASC + l * NC + q], v0);
+                v1 = fma(s_cf[l * 38 + 29 + b], expc[(size_t)(NL * 28 + l * 10 + b + 1) * BASC + l * NC + q], v1);
+            }
+        }
+        s_w[threadIdx.x] = v0 + v1;
+    }
+    __syncthreads();
+    if (jp < NPOW) {
+        double zr[NC], zi[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            zr[q] = zi[q] = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < AD_CH; ++ch) {
+                const double2 v = S[(((size_t)ch * Bmax + w) * NC + q) * NPOW + jp];
+                zr[q] += v.x;
+                zi[q] += v.y;
+            }
+        }
+        const int o0 = jp == 0 ? 0 : 2 * jp - 1;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            double cr = 0.0, ci = 0.0;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                cr = fma(s_w[l * NC + q], zr[q], cr);
+                ci = fma(s_w[l * NC + q], zi[q], ci);
+            }
+            if (cf == 0) {
+                double* o = A22 + ((size_t)w * BAS22 + l) * KSYN;
+                o[o0] = cr;
+                if (jp) o[o0 + 1] = ci;
+            } else {
+                const double2 m = mlj[l * NPOW + jp];  // Bessel weight Ml[l](n + m) (reference pybird.py:1040-1046)
+                double* o = ACF + ((size_t)w * BASC + l) * KSYN;
+                o[o0] = m.x * cr - m.y * ci;
+                if (jp) o[o0 + 1] = m.x * ci + m.y * cr;
+            }
+        }
+    }
+    {   // single-sum rows: k space -> the 10 P13 rows contracted with cf_l[28 + b] (3 rows); xi space -> C11[l'] x s_b[l'], Cct[l'] x s_b[NL + l']
+        const int nrows = cf == 0 ? NL : 2 * NL;
+        double* out = cf == 0 ? A13 + (size_t)w * 10 * KLIN : ALC + (size_t)w * 2 * NL * KLIN;
+        const double* c = coef + (size_t)w * 2 * NCH;
+        for (int e = jp; e < nrows * NCH; e += 320) {
+            const int row = e / NCH, mp = e % NCH, n = NHALF - mp;  // harmonic mp <-> coefficient n = 128 - mp
+            double vx, vy;
+            if (cf == 0) {
+                vx = vy = 0.0;
+#pragma unroll
+                for (int b = 0; b < 10; ++b) {
+                    const double2 v = linvec[(size_t)b * NCH + n];
+                    vx = fma(s_cf[row * 38 + 28 + b], v.x, vx);
+                    vy = fma(s_cf[row * 38 + 28 + b], v.y, vy);
+                }
+            } else {
+                const double2 v = linvec[(size_t)(10 + row) * NCH + n];
+                vx = s_b[row] * v.x;
+                vy = s_b[row] * v.y;
+            }
+            const double cr = c[n], ci = n == NHALF ? 0.0 : c[NCH + n];
+            double* o = out + (size_t)row * KLIN;
+            if (mp == 0) o[0] = cr * vx - ci * vy;
+            else {
+                o[2 * mp - 1] = cr * vx - ci * vy;
+                o[2 * mp] = cr * vy + ci * vx;
+            }
+        }
+    }
+}
+
 // out[row][x] = sum_q A[row][q] Tab[q][x]  (* gscale[row / rpg][x]) (* xscale[x]) on the FP64 matrix cores.  Rows are
 // addressed as (group = row / rpg, member = row % rpg): A + group a_group + member K, out + group o_group + member X.
 // Workgroup = 4 waves = 32 rows x 64 x; A and Tab chunks of SYN_KC go through LDS (strides 50 / 80: conflict-free
@@ -667,12 +794,6 @@ __global__ __launch_bounds__(256) void gemm_narrow_kernel(GemmDesc d, GemmZ z) {
 // subtraction, stochastic templates (reference pybird.py:737-866).  grp[b] = (group, power of f).
 // Writes the template block T[w][l][24][Nk].
 // ------------------------------------------------------------------------------------------------
-__device__ inline double ipow(double f, int p) {
-    double r = 1.0;
-    for (int i = 0; i < p; ++i) r *= f;
-    return r;
-}
-
 __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ fgrow,
                                                       const double* __restrict__ P11, const double* __restrict__ P22,
                                                       const double* __restrict__ P13, const double* __restrict__ l11,
@@ -726,63 +847,30 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 
 // Direct-P_l runs (EFTB_O_PLK_DIRECT): the bias contraction P_l = sum_row b_row T[l][row] commutes with every stage behind the regrouping
 // (resummation, AP: linear maps that act on each template row alike), so it is taken FIRST: one row per multipole instead of 24 goes through
-// them.  This kernel is regroup_kernel with the contraction in its epilogue (reference pybird.py:737-866 followed by parambasis.py:42-136):
-// row 0 of the template block takes sum_row b_row T[l][row] over the rows the AP stage distorts (rows < 21, all rows when stoch0), rows
-// 21-23 the stochastic templates as always (ap_plk_kernel adds them with their coefficients); rows 1-20 of the block are not written.
-__global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ fgrow,
-                                                          const double* __restrict__ P11, const double* __restrict__ Y22,
-                                                          const double* __restrict__ exp22, const double* __restrict__ P13,
+// them -- and, being linear in the rows, with the synthesis of the loop pieces before it (build_rows_plk_kernel).  This kernel is what is left of
+// regroup_kernel (reference pybird.py:737-866 followed by parambasis.py:42-136): row 0 of the template block takes sum_row b_row T[l][row] over the
+// rows the AP stage distorts (rows < 21, all rows when stoch0), rows 21-23 the stochastic templates as always (ap_plk_kernel adds them with their
+// coefficients); rows 1-20 of the block are not written.
+__global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
+                                                          const double* __restrict__ Y22, const double* __restrict__ P13,
                                                           const double* __restrict__ l11, const double* __restrict__ lct,
-                                                          const double* __restrict__ l22, const double* __restrict__ l13,
-                                                          const int* __restrict__ grp, const double* __restrict__ bias, double* __restrict__ T,
-                                                          int stoch0) {
-    // the 28 P22 pieces are combinations of the BAS22 synthesised basis rows (expand_kernel): contracted with their weights first, the sum
-    // runs over the basis rows themselves -- direct-P_l runs never expand them
-    __shared__ double cf[38];      // b_group f^power mu-weight per piece
-    __shared__ double w22[BAS22];  // sum_b cf[b] exp22[b][c]
-    __shared__ double z0[BAS22 + 10];  // the weighted rows at the first k (shot-noise subtraction, reference pybird.py:799-800)
-    __shared__ double s_e[28 * BAS22];  // exp22 (one coalesced load: a thread walking its column in global memory is 28 dependent round trips)
+                                                          const double* __restrict__ bias, double* __restrict__ T, int stoch0) {
+    // Y22[w][l][k] (row stride BAS22 Nk per cosmology), P13[w][l][k] (10 Nk per cosmology): the loop pieces already contracted with the
+    // bias (build_rows_plk_kernel) and synthesised; here the linear and counter terms join, the values at the first k are subtracted
+    // (shot-noise subtraction, reference pybird.py:799-800) and the stochastic templates are laid beside the row
     const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
-    const double f = fgrow[w];
-    const double* bw = bias + (size_t)w * NROW;
-    const double* y22 = Y22 + (size_t)w * BAS22 * Nk;
-    const double* q13 = P13 + (size_t)w * 10 * Nk;
-    for (int b = threadIdx.x; b < 38; b += blockDim.x)
-        cf[b] = bw[9 + grp[2 * b]] * ipow(f, grp[2 * b + 1]) * (b < 28 ? l22[l * 28 + b] : l13[l * 10 + (b - 28)]);
-    for (int e = threadIdx.x; e < 28 * BAS22; e += blockDim.x) s_e[e] = exp22[e];
-    __syncthreads();
-    if (threadIdx.x < BAS22) {
-        double a = 0.0;
-        for (int b = 0; b < 28; ++b) a = fma(cf[b], s_e[b * BAS22 + threadIdx.x], a);
-        w22[threadIdx.x] = a;
-        z0[threadIdx.x] = a * y22[(size_t)threadIdx.x * Nk];
-    } else if (threadIdx.x < BAS22 + 10) {
-        const int b = threadIdx.x - BAS22;
-        z0[threadIdx.x] = cf[28 + b] * q13[(size_t)b * Nk];
-    }
-    __syncthreads();
     if (k >= Nk) return;
+    const double* bw = bias + (size_t)w * NROW;
+    const double* y22 = Y22 + ((size_t)w * BAS22 + l) * Nk;
+    const double* q13 = P13 + ((size_t)w * 10 + l) * Nk;
     const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
     double b11 = 0.0, bct = 0.0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) b11 = fma(bw[r], l11[l * 3 + r], b11);
 #pragma unroll
     for (int r = 0; r < 6; ++r) bct = fma(bw[3 + r], lct[l * 6 + r], bct);
-    double a0 = (b11 + bct * kv * kv) * p11, a1 = 0.0, c0 = 0.0;  // two chains over the rows
-#pragma unroll
-    for (int c = 0; c < BAS22; c += 2) {
-        a0 = fma(w22[c], y22[(size_t)c * Nk + k], a0);
-        a1 = fma(w22[c + 1], y22[(size_t)(c + 1) * Nk + k], a1);
-    }
-#pragma unroll
-    for (int b = 0; b < 10; b += 2) {
-        a0 = fma(cf[28 + b], q13[(size_t)b * Nk + k], a0);
-        a1 = fma(cf[29 + b], q13[(size_t)(b + 1) * Nk + k], a1);
-    }
-#pragma unroll
-    for (int i = 0; i < BAS22 + 10; ++i) c0 += z0[i];
     const double s21 = l == 0 ? 1.0 : 0.0, s22 = l == 0 ? kv * kv : 0.0, s23 = l == 1 ? kv * kv : 0.0;
-    double tot = (a0 + a1) - c0;
+    double tot = (b11 + bct * kv * kv) * p11 + ((y22[k] - y22[0]) + (q13[k] - q13[0]));
     if (stoch0) tot += bw[21] * s21 + bw[22] * s22 + bw[23] * s23;  // APst: the stochastic templates are distorted with the others
     double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
     t[0] = tot;
@@ -1347,72 +1435,19 @@ constexpr int RSD_REC = 160;  // doubles per (cosmology, s): 9 x 16 coefficients
 
 __global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, int Na, const double* __restrict__ Q, const double* __restrict__ XY,
                                                              const double* __restrict__ C11, const double* __restrict__ Cct,
-                                                             const double* __restrict__ YCF, const double* __restrict__ expc,
-                                                             const double* __restrict__ fgrow, const double* __restrict__ l11,
-                                                             const double* __restrict__ lct, const double* __restrict__ l22,
-                                                             const double* __restrict__ l13, const int* __restrict__ grp,
-                                                             const double* __restrict__ bias, double* __restrict__ CF) {
-    // grid (cosmology, slice of the s range); the 38 C22 / C13 pieces per l' are combinations of the BASC synthesised basis rows
-    // (expand_kernel): their weights are contracted with the combination matrix first, so g_1 is a sum over the basis rows
-    constexpr int NL = 3, NCH = 5, CPC = (BASC + NCH - 1) / NCH;  // chunks of the basis rows per g_1 entry, rows per chunk
+                                                             const double* __restrict__ YCF, double* __restrict__ CF) {
+    // grid (cosmology, slice of the s range).  g_0[l'](s) = C11[w][l'][s], g_1[l'](s) = Cct[w][l'][s] + YCF[w][l'][s]: all three already carry their
+    // bias coefficients (build_rows_plk_kernel contracted the rows before the synthesis)
+    constexpr int NL = 3;
     const int w = blockIdx.x, ns = (NS + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * ns, s1 = min(NS, s0 + ns), nsl = s1 - s0;
-    const double* bw = bias + (size_t)w * NROW;
     extern __shared__ double sm[];
     double* s_q = sm;                        // [2 NL NL NN] the cosmology's Q(f)
-    double* s_cf = s_q + 2 * NL * NL * NN;   // [NL][38] b_group f^power mu-weight per piece and l'
-    double* s_wc = s_cf + NL * 38;           // [NL][BASC]
-    double* s_b = s_wc + NL * BASC;          // [2][NL] sum_i b_i l11[l'][i], sum_i b_3+i lct[l'][i]
-    double* s_g = s_b + 2 * NL;              // [2][NL][ns] g_a[l'](s0 + .)
-    double* s_p = s_g + 2 * NL * ns;         // [NCH][NL ns] partial sums of g_1
-    double* s_e = s_p + NCH * NL * ns;       // [NL 38][BASC] expc (coalesced: a thread walking its column in global memory is 38 dependent round trips)
-    const double f = fgrow[w];
+    double* s_g = s_q + 2 * NL * NL * NN;    // [2][NL][ns] g_a[l'](s0 + .)
     for (int e = threadIdx.x; e < 2 * NL * NL * NN; e += blockDim.x) s_q[e] = Q[(size_t)w * 2 * NL * NL * NN + e];
-    for (int e = threadIdx.x; e < NL * 38 * BASC; e += blockDim.x) s_e[e] = expc[e];
-    for (int e = threadIdx.x; e < NL * 38; e += blockDim.x) {
-        const int lp = e / 38, bq = e % 38;
-        s_cf[e] = bw[9 + grp[2 * bq]] * ipow(f, grp[2 * bq + 1]) * (bq < 28 ? l22[lp * 28 + bq] : l13[lp * 10 + (bq - 28)]);
-    }
-    if (threadIdx.x < 2 * NL) {
-        const int a = threadIdx.x / NL, lp = threadIdx.x % NL;
-        double v = 0.0;
-        if (a == 0)
-            for (int r = 0; r < 3; ++r) v = fma(bw[r], l11[lp * 3 + r], v);
-        else
-            for (int r = 0; r < 6; ++r) v = fma(bw[3 + r], lct[lp * 6 + r], v);
-        s_b[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NL * BASC) {
-        const int lp = threadIdx.x / BASC, c = threadIdx.x % BASC;
-        double v0 = 0.0, v1 = 0.0;
-        for (int b = 0; b < 28; b += 2) {
-            v0 = fma(s_cf[lp * 38 + b], s_e[(lp * 28 + b) * BASC + c], v0);
-            v1 = fma(s_cf[lp * 38 + b + 1], s_e[(lp * 28 + b + 1) * BASC + c], v1);
-        }
-        for (int b = 0; b < 10; b += 2) {
-            v0 = fma(s_cf[lp * 38 + 28 + b], s_e[(NL * 28 + lp * 10 + b) * BASC + c], v0);
-            v1 = fma(s_cf[lp * 38 + 29 + b], s_e[(NL * 28 + lp * 10 + b + 1) * BASC + c], v1);
-        }
-        s_wc[threadIdx.x] = v0 + v1;
-    }
-    __syncthreads();
-    {   // g_1: NCH chunks of basis rows per (l', s) entry, summed below in chunk order
-        const int ne = NL * nsl, e = threadIdx.x % (NL * ns), ch = threadIdx.x / (NL * ns);
-        if (ch < NCH && e < ne) {
-            const int lp = e / nsl, sl = e % nsl;
-            const double* y = YCF + (size_t)w * BASC * NS + s0 + sl;
-            double v = 0.0;
-            for (int c = ch * CPC; c < min(BASC, (ch + 1) * CPC); ++c) v = fma(s_wc[lp * BASC + c], y[(size_t)c * NS], v);
-            s_p[ch * NL * ns + e] = v;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < NL * nsl) {
-        const int lp = threadIdx.x / nsl, sl = threadIdx.x % nsl, s = s0 + sl;
-        double v = Cct[((size_t)w * NL + lp) * NS + s] * s_b[NL + lp];
-        for (int ch = 0; ch < NCH; ++ch) v += s_p[ch * NL * ns + threadIdx.x];
-        s_g[(NL + lp) * ns + sl] = v;
-        s_g[lp * ns + sl] = C11[((size_t)w * NL + lp) * NS + s] * s_b[lp];
+    for (int e = threadIdx.x; e < NL * nsl; e += blockDim.x) {
+        const int lp = e / nsl, sl = e % nsl, s = s0 + sl;
+        s_g[lp * ns + sl] = C11[((size_t)w * NL + lp) * NS + s];
+        s_g[(NL + lp) * ns + sl] = Cct[((size_t)w * NL + lp) * NS + s] + YCF[((size_t)w * BASC + lp) * NS + s];
     }
     __syncthreads();
     const double* xy = XY + (size_t)w * 2 * NS;

@@ -367,7 +367,7 @@ static int launch_gemm_direct(hipStream_t st, SynthBatch sb, int waves = 4) {
 
 // anti-diagonal sums of every loop matrix for the batch (shared by the k-space and the xi-space pieces), then the
 // synthesis rows selected by `sets` (build_rows_kernel)
-static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets, const double* coef, const double* coefT) {
+static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets, const double* coef, const double* coefT, bool contracted = false) {
     const eftb_config& c = e->c;
     const int nc = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
     const dim3 grid(NPOW, (B + 63) / 64), rgrid(B, 2, 5);  // antidiag: one workgroup of four waves per (j', 64 cosmologies); build_rows: 5 x 64 lanes per (cosmology, half)
@@ -377,6 +377,12 @@ static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets,
     if (nc == 9) {
         if ((sets & 0x10) && e->ad_waves == 2) hipLaunchKernelGGL((antidiag_kernel<9, 2>), grid, dim3(128), 0, st, AD_ARGS);
         else if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9, 4>), grid, dim3(256), 0, st, AD_ARGS);
+        if (contracted)  // direct-P_l runs: the rows contracted with the bias before the synthesis (3 per cosmology and space)
+            hipLaunchKernelGGL((build_rows_plk_kernel<9>), rgrid, dim3(64), 0, st, c.max_batch, c.nbasis, coef, e->SAD, tb<double2>(e, EFTB_T_MLJ),
+                               tb<double2>(e, EFTB_T_LINVEC), e->buf[EFTB_B_BIAS], e->buf[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
+                               tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), tb<double>(e, EFTB_T_EXP22),
+                               tb<double>(e, EFTB_T_EXPC), e->A22, e->A13, e->ACF, e->ALC);
+        else
         hipLaunchKernelGGL((build_rows_kernel<9>), rgrid, dim3(64), 0, st, ROW_ARGS);
     } else if (nc == 7) {
         if ((sets & 0x10) && e->ad_waves == 2) hipLaunchKernelGGL((antidiag_kernel<7, 2>), grid, dim3(128), 0, st, AD_ARGS);
@@ -754,7 +760,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         if (mask & (EFTB_S_CF | EFTB_K_C22)) sets |= 0x2;
         if (mask & EFTB_S_CF) sets |= 0x8;
         if (!c.dual_coef) {
-            if (int rc = launch_antidiag_rows(e, front_side ? fst : st, B, sets, b[EFTB_B_COEF], e->coefT)) return rc;
+            if (int rc = launch_antidiag_rows(e, front_side ? fst : st, B, sets, b[EFTB_B_COEF], e->coefT, direct)) return rc;
             if (front_side && (hipEventRecord(e->evFront, fst) != hipSuccess || hipStreamWaitEvent(st, e->evFront, 0) != hipSuccess))
                 return fail("eftb_run: stream join failed");
         } else {  // k-space rows from the first coefficient set, xi-space rows from the second (the sums are recomputed in between)
@@ -771,10 +777,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // (only the rows in use: 7 of the 8 padded basis rows per cosmology, Nl (7 + 2) = 27 of the 32 weighted ones -- 10 % of the launch's
         // matrix-core work was padding; the padded rows of Y22 / YCF stay at their initial zeros and meet zero columns in expand_kernel)
         const int ncf = c.nbasis + (c.with_resum ? c.nbasis13 : 0);
-        if (k22) queue_synth(sb, e->A22, (long long)BAS22 * KSYN, B, c.nbasis, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, e->Y22, (long long)BAS22 * Nk, nullptr, nullptr);
-        if (c22) queue_synth(sb, e->ACF, (long long)BASC * KSYN, B, Nl * ncf, KSYN, tb<double>(e, EFTB_T_SYNS), NS, e->YCF, (long long)BASC * NS, nullptr, nullptr);
+        // (direct-P_l runs: 3 contracted rows per cosmology in each of these three -- same strides, fewer rows)
+        if (k22) queue_synth(sb, e->A22, (long long)BAS22 * KSYN, B, direct ? 3 : c.nbasis, KSYN, tb<double>(e, EFTB_T_SYNK), Nk, e->Y22, (long long)BAS22 * Nk, nullptr, nullptr);
+        if (c22) queue_synth(sb, e->ACF, (long long)BASC * KSYN, B, direct ? 3 : Nl * ncf, KSYN, tb<double>(e, EFTB_T_SYNS), NS, e->YCF, (long long)BASC * NS, nullptr, nullptr);
         if (mask & EFTB_S_LOOPS)
-            queue_synth(sb, e->A13, 10LL * KLIN, B, 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], 10LL * Nk, b[EFTB_B_P11], nullptr);
+            queue_synth(sb, e->A13, 10LL * KLIN, B, direct ? 3 : 10, KLIN, tb<double>(e, EFTB_T_LINK), Nk, b[EFTB_B_P13], 10LL * Nk, b[EFTB_B_P11], nullptr);
         if (mask & EFTB_S_CF) {
             const long long ag = (c.with_nnlo ? 3LL : 2LL) * Nl * KLIN;
             queue_synth(sb, e->ALC, ag, B, Nl, KLIN, tb<double>(e, EFTB_T_LINS), NS, b[EFTB_B_C11], (long long)Nl * NS, nullptr, nullptr);
@@ -808,10 +815,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     }
     if (mask & EFTB_S_REGROUP) {
         if (direct)
-            hipLaunchKernelGGL(regroup_plk_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
-                               b[EFTB_B_P11], e->Y22, tb<double>(e, EFTB_T_EXP22), b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
-                               tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], b[EFTB_B_TEMPL],
-                               c.ap_stochastic ? 1 : 0);
+            hipLaunchKernelGGL(regroup_plk_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], e->Y22,
+                               b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), b[EFTB_B_BIAS], b[EFTB_B_TEMPL], c.ap_stochastic ? 1 : 0);
         else
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
                            b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
@@ -864,10 +869,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             }
             if (full && direct) {
                 const int nsl = NS / 5;  // five slices of the s range per cosmology
-                const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 3 * 38 + 3 * BASC + 6 + 2 * 3 * nsl + 5 * 3 * nsl + 3 * 38 * BASC) * sizeof(double);
-                hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), plds, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF,
-                                   tb<double>(e, EFTB_T_EXPC), b[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), tb<double>(e, EFTB_T_L22),
-                                   tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_BIAS], e->RSAS);
+                const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 2 * 3 * nsl) * sizeof(double);
+                hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), plds, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF, e->RSAS);
                 if (front_side) {  // the last reader of this run's front set
                     if (hipEventRecord(e->evFrontFree[e->front_step & 1], st) != hipSuccess) return fail("eftb_run: event record failed");
                     ++e->front_step;
