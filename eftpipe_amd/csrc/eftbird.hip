@@ -694,7 +694,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             if (hipStreamWaitEvent(fst, e->evFrontFree[e->front_step & 1], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             if (!e->prev_front_side && hipStreamWaitEvent(fst, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             launch_irfilter(e, fst, B, !xy_in_prep);
-            if (hipEventRecord(e->evJoin, fst) != hipSuccess || hipEventRecord(e->evJoinAP, fst) != hipSuccess) return fail("eftb_run: stream join failed");
+            joined = joined_ap = true;  // (X, Y, Q(f) reach the rest of the chain with evFront; no AP tables in a direct run)
         } else if (pre_side) {
             st = e->pre;
             if (hipStreamWaitEvent(st, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
@@ -1939,7 +1939,9 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     const bool lat = e->set_latency[e->cur_set];
     // latency mode: one queue for the whole step; P_lin is read from the page-locked staging block (its device copy arrives behind evStagedAll);
     // P_l goes to mapped host memory from the kernel that forms it (REDUCE, or the AP epilogue) unless the NNLO pass adds to it afterwards
-    const bool plk_direct = lat && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !e->c.with_nnlo;
+    // (pipelined direct-P_l steps too: at 0.13 ms of GPU work per step the 20 us the host spends in hipMemcpyAsync count; the kernel's stores to mapped
+    // memory cost the GPU what the DMA cost it)
+    const bool plk_direct = (lat || (e->plk_direct && !e->comm)) && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !e->c.with_nnlo;
     double* pin_dev = e->buf[EFTB_B_PIN];
     if (lat) e->buf[EFTB_B_PIN] = e->stage_host[e->cur_set] + e->stage_off[EFTB_B_PIN];
     e->lat_run = lat;
@@ -1958,7 +1960,7 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipMemcpyAsync(e->plk_host[e->cur_set], e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
     HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], last));
-    if (e->back_pending && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE))
+    if (e->back_pending && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], last));  // whoever joins the back half also waits for the copy
     return 0;
 }
