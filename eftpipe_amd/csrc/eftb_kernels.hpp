@@ -2494,16 +2494,19 @@ __global__ __launch_bounds__(256) void ap_plk_kernel(int Nk, int nmu, const doub
         for (int j = j0; j < j1; ++j) {
             const double4 n0 = *reinterpret_cast<const double4*>(s_node + (size_t)j * 8), n1 = *reinterpret_cast<const double4*>(s_node + (size_t)j * 8 + 4);
             const double kp = kq * n0.x;
-            if (kp >= khi || kp < klo) {  // (the end intervals extrapolate: the reference's comparison k_i <= k' < k_i+1)
-                const int iold = i;
-                while (i < Nk - 2 && s_k[i + 1] <= kp) ++i;
-                while (i > 0 && s_k[i] > kp) --i;
-                if (i != iold) {
-                    klo = s_k[i];
-                    khi = s_k[i + 1];
-                    piece(i, a);
-                }
+            // interval changes as WAVE-uniform steps: some lane of the wave crosses a knot at almost every node, so a per-lane branch is taken
+            // (by everybody) nearly always -- one step of every lane that has to move, the loop repeats only while some lane is still outside
+            // its interval (the end intervals extrapolate: the reference's comparison k_i <= k' < k_i+1), then one reload of the pieces
+            bool moved = false;
+            for (;;) {
+                const bool up = kp >= khi && i < Nk - 2, dn = kp < klo && i > 0;
+                if (!__any(up || dn)) break;
+                i += (up ? 1 : 0) - (dn ? 1 : 0);
+                klo = s_k[i];
+                khi = s_k[i + 1];
+                moved = true;
             }
+            if (moved) piece(i, a);  // (wave-uniform)
             const double t = kp - klo;
             double P = fma(fma(fma(a[0].w, t, a[0].z), t, a[0].y), t, a[0].x);
             P = fma(fma(fma(fma(a[1].w, t, a[1].z), t, a[1].y), t, a[1].x), n0.y, P);
