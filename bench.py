@@ -38,7 +38,6 @@ NL, NK, Z = 3, 512, 0.7
 BS = [2.1401334, 0.77616816 / np.sqrt(2.0), 0.77003455, 0.77616816 / np.sqrt(2.0), -1.8396613, -1.8918368, -1.4856405]
 ES = (0.26033594, 0.0, -0.92895016)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
-HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 NPOW, NS_DEV, NKLOW = 257, 80, 7
 DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "3"))  # steps queued on the GPU ahead of the one being fetched (1..6; direct-P_l steps are four pipeline stages deep: 618-650 k evaluations/s at 2, 660-668 k at 3, 663-695 k at 4; templates first, round 2: measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
 DIRECT = os.environ.get("EFTB_BENCH_DIRECT", "1") != "0"   # `value` on direct-P_l runs (EFTB_O_PLK_DIRECT); 0: templates first
@@ -112,8 +111,8 @@ def executed_flops_per_launch(B):
 
 def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, measured_peak):
     """`roofline` of a direct-P_l run (EFTB_O_PLK_DIRECT).  Its step has no single dominant kernel any more: the resummation (resum_plk_kernel,
-    FP64 vector work with scalar coefficients), the synthesis GEMMs of the loop stages (synth_kernel, FP64 MFMA) and the AP knot weights
-    (ap_weights_kernel, HBM / latency) each take about a fifth of the kernel time.  All three were bracketed with HIP events on their own
+    FP64 vector work with scalar coefficients), the synthesis GEMMs of the loop stages (synth_kernel, FP64 MFMA) and the AP quadrature
+    (ap_plk_kernel, FP64 vector, issue / latency bound) each take about a fifth of the kernel time.  All three were bracketed with HIP events on their own
     streams inside the timed region; the one with the largest time per launch is `roofline`, the other two follow in `roofline_others`, the
     templates-first step's dominant kernel (resum_mfma_kernel, timed alone) in `roofline_templates_first`."""
     from eftpipe_amd import _lib as L
@@ -162,31 +161,18 @@ def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, meas
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
                         "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_flops_per_launch": flops,
                         "flops_note": f"2 M N K: [{B} x {nb}] x {KS} x {NK} + [{B} x {ncf}] x {KS} x {NS_DEV} + [{B} x 10] x {KL} x {NK} + [{B} x {2 * NL}] x {KL} x {NS_DEV}"})
-    # (2) ap_weights_kernel: HBM bytes it has to move = the mu prefix sums it reads + the knot weights ap_rows_kernel will read (per 32-k tile:
-    # max coefficients per k x Nl^2 x 32 k), from the AP geometry of the timed set's first batch
-    k = np.asarray(cfg.k)
-    mu = np.asarray(t["mu"])
-    qperp, qpar = np.asarray(d0["DA"]) / cfg.DA_AP, cfg.H_AP / np.asarray(d0["H"])
-    F = qpar / qperp
-    root = np.sqrt(1.0 + mu[None, :] ** 2 * (F[:, None] ** -2 - 1.0))            # [B, nmu]
-    kq = k[None, :] / qperp[:, None]
-    lo = np.minimum(kq * root[:, :1], kq * root[:, -1:])
-    hi = np.maximum(kq * root[:, :1], kq * root[:, -1:])
-    iv = lambda x: np.clip(np.searchsorted(k, x, side="right") - 1, 0, k.size - 2)
-    first = lambda i: np.clip(i - 1, 0, k.size - 4)
-    nD = first(iv(hi)) + 4 - first(iv(lo))                                          # [B, Nk] B-spline coefficients per k
-    D_tile = nD.reshape(B, -1, 32).max(axis=-1)
-    w_bytes = float(D_tile.sum()) * NL * NL * 32 * 8
-    ps_bytes = float(B) * (mu.size + 1) * NL * NL * 4 * 8
+    # (2) ap_plk_kernel: the reference's mu quadrature on the contracted rows: per (k, node) three cubics (3 FMA each), two Legendre-weighted
+    # additions and three accumulations (14 FMA + the k' product and the offset from the knot) -- FP64 vector work
+    nmu = int(np.asarray(t["mu"]).size)
+    flops = float(B) * NK * nmu * (14 * 2 + 2)
     ms, n = ktimes[2]
     if n:
-        tr, src = traffic_of("ap_weights_kernel")
-        gbs = (w_bytes + ps_bytes) / (ms / n * 1e-3) / 1e9
-        entries.append({"bound": "hbm", "kernel": "ap_weights_kernel<3> (APeffect.AP, inputs only: the mu quadrature of the reference collapsed into per-(k, B-spline coefficient) weights of "
-                                                  "the banded AP operator)",
-                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
-                        "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_bytes_per_launch": w_bytes + ps_bytes,
-                        "bytes_note": f"knot weights written {w_bytes / 1e6:.1f} MB (mean {D_tile.mean():.1f} coefficients per k and tile) + mu prefix sums read {ps_bytes / 1e6:.1f} MB"})
+        tr, src = traffic_of("ap_plk_kernel")
+        entries.append({"bound": "mfma", "kernel": "ap_plk_kernel<3> (APeffect.AP of a direct-P_l run: the reference's own mu quadrature of P_l'(k'(mu)) L_l'(mu') L_l(mu) on one row per "
+                                                   "multipole, splines as piecewise polynomials in LDS; FP64 vector instructions, bound by issue and LDS latency rather than by arithmetic)",
+                        "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
+                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_flops_per_launch": flops,
+                        "flops_note": f"{B} x {NK} k x {nmu} nodes x 30 flop"})
     if not entries:
         return templates_first
     entries.sort(key=lambda r: -r["ms_per_launch"])

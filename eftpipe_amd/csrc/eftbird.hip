@@ -70,7 +70,7 @@ struct eftb_engine {
     bool timer_busy[NTIMER] = {};
     unsigned timer_next = 0;
     int time_dominant = 0;          // 0 off; n: every n-th launch of the timed kernel is bracketed
-    int time_kernel = 1;            // EFTB_O_TIME_KERNEL, bits: 1 the resummation kernel, 2 the synthesis launch of the loop stages, 4 the AP knot weights
+    int time_kernel = 1;            // EFTB_O_TIME_KERNEL, bits: 1 the resummation kernel, 2 the synthesis launch of the loop stages, 4 the AP kernel (knot weights; direct-P_l runs: ap_plk_kernel)
     unsigned long long time_seqk[3] = {};
     int timer_kind[NTIMER] = {};    // which kernel the pair of a slot brackets (see time_kernel)
     double timer_ms[3] = {};
@@ -964,10 +964,12 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             }
             if (dir) {  // the node quadrature on the contracted row (ap_plk_kernel); nothing else of the stage runs
                 const size_t lds = ((size_t)Nk + (size_t)c.nmu * 8 + 3 * APD_WMAX * 4 + 3 * 3 * 64) * sizeof(double);
+                const int tslot = timer_begin(e, st, 2);
                 hipLaunchKernelGGL((ap_plk_kernel<3>), dim3(((Nk + 63) / 64) * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
                                    tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), e->SD,
                                    tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], b[EFTB_B_PLK], e->plk_host_out,
                                    e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21);
+                timer_end(e, st, tslot);
                 std::swap(*pin, *palt);
                 return 0;
             }

@@ -153,14 +153,14 @@ enum eftb_option {
                                  goes through them: same P_l(k) (summation order aside), but EFTB_B_TEMPL does not hold the templates of such a
                                  run.  0 (default): templates first, as the reference computes them (BirdSnapshot semantics) */
     EFTB_O_TIME_KERNEL = 7    /* which launches EFTB_O_TIME_DOMINANT brackets, a set of: 1 (default) the resummation kernel, 2 the synthesis launch of
-                                 the loop stages (synth_kernel), 4 the AP knot weights (ap_weights_kernel) -- measurement only */
+                                 the loop stages (synth_kernel), 4 the heaviest AP kernel (ap_weights_kernel; direct-P_l runs: ap_plk_kernel) -- measurement only */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 /* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for
  * the launches still in flight. */
 int  eftb_dominant_time(eftb_engine* e, double* ms_sum, long long* launches, int reset);
 /* The same for one of the launches EFTB_O_TIME_KERNEL selects: kind 0 the resummation kernel (= eftb_dominant_time), 1 the synthesis launch, 2 the AP
- * knot weights. */
+ * kernel. */
 int  eftb_kernel_time(eftb_engine* e, int kind, double* ms_sum, long long* launches, int reset);
 
 /* Likelihood of the EFTB_S_LOGP stage.  Replaces, for a batch of walkers on the device,

@@ -93,6 +93,8 @@ ALGO = {
                                f"{B * 80 * 512 * 8 / 1e6:.1f} MB + template read-modify-write 2*{B}*63*{NK}*8 = {2 * B * 63 * NK * 8 / 1e6:.0f} MB",
     "eftb::resum_plk_kernel": f"H table {3 * 80 * NK * 8 / 1e6:.1f} MB (L2-resident) + coefficient table {B * 80 * 160 * 8 / 1e6:.1f} MB (scalar loads) + P_l read-modify-write "
                               f"2*{B}*3*{NK}*8 = {2 * B * 3 * NK * 8 / 1e6:.1f} MB",
+    "eftb::ap_plk_kernel": f"B-spline coefficients of the contracted rows {B * 3 * NK * 8 / 1e6:.1f} MB + per-interval matrices {NK * 16 * 8 / 1e6:.2f} MB (L2) + stochastic rows and P_l "
+                           f"{B * 3 * 4 * NK * 8 / 1e6:.1f} MB (P_l to mapped host memory)",
     "eftb::synth_kernel": f"synthesis bases syn_k / syn_s / lin_k / lin_s ({(528 * NK + 528 * 80 + 288 * NK + 288 * 80) * 8 / 1e6:.1f} MB, re-read per row tile through the L2) + row operands "
                           f"{B * (8 * 528 + 32 * 528 + 10 * 288 + 6 * 288) * 8 / 1e6:.1f} MB + outputs {B * (8 * NK + 32 * 80 + 10 * NK + 6 * 80) * 8 / 1e6:.1f} MB",
 }
