@@ -41,9 +41,10 @@ import subprocess
 import json as _json
 _traced = _json.loads([ln for ln in open(os.path.join(src, "bench_under_rocprof.json")) if ln.startswith("{")][0])
 _idx = int(_traced.get("warmup_steps_run", _traced.get("warmup", 3))) + _traced.get("steps", 20) // 2
-tl = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), find("stats_kernel_trace.csv"), str(_idx)], capture_output=True, text=True).stdout
+_mark = "resum_plk" if "roofline_templates_first" in _traced.get("roofline", {}) else "resum_mfma"  # the timed loop runs direct-P_l steps when it reports both
+tl = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), find("stats_kernel_trace.csv"), str(_idx), _mark], capture_output=True, text=True).stdout
 open(os.path.join(dst, f"{tag}_overlap_timeline.txt"), "w").write(
-    "One steady-state step of the pipelined loop (rocprofv3 --kernel-trace of bench.py; q = HSA queue: main / side / look-ahead / back / copy).\n" + tl)
+    "One steady-state step of the pipelined timed loop (rocprofv3 --kernel-trace of bench.py; q = HSA queue: main / side / look-ahead / back / copy; under the tracer the host, not the GPU, sets the pace of direct-P_l steps).\n" + tl)
 
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in ("pmc_fetch_counter_collection.csv", "pmc_write_counter_collection.csv", "pmc_sq_counter_collection.csv",
