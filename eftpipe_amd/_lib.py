@@ -76,7 +76,7 @@ def load():
     lib.eftb_run_timed.argtypes, lib.eftb_run_timed.restype = [vp, i32, i32, i32, C.POINTER(C.c_float)], i32
     lib.eftb_eval_batch.argtypes, lib.eftb_eval_batch.restype = [vp, i32, dp, dp, dp, dp, dp, dp, dp], i32
     lib.eftb_eval_logp_batch.argtypes, lib.eftb_eval_logp_batch.restype = [vp, i32, dp, dp, dp, dp, dp, dp, dp, dp], i32
-    lib.eftb_stage_inputs.argtypes, lib.eftb_stage_inputs.restype = [vp, i32, dp, dp, dp, dp, dp, dp], i32
+    lib.eftb_stage_inputs.argtypes, lib.eftb_stage_inputs.restype = [vp, i32, vp, vp, vp, vp, vp, vp], i32  # (const double* parameters declared void*: engine.stage_inputs passes plain addresses)
     lib.eftb_run_staged.argtypes, lib.eftb_run_staged.restype = [vp, i32, i32], i32
     lib.eftb_fetch_previous.argtypes, lib.eftb_fetch_previous.restype = [vp, i32, dp, sz], i32
     lib.eftb_fetch_back.argtypes, lib.eftb_fetch_back.restype = [vp, i32, i32, dp, sz], i32
@@ -115,6 +115,15 @@ def pinned_empty(shape):
     raw = (C.c_double * max(n, 1)).from_address(p)
     weakref.finalize(raw, lib.eftb_host_free, p)
     return np.frombuffer(raw, dtype=np.float64, count=n).reshape(shape)  # the ndarray keeps `raw` alive as its base
+
+
+def vptr(a):
+    """float64 C-contiguous ndarray -> its address as an integer for a `const double*` parameter declared void* (None -> NULL): half the cost of
+    dptr's typed pointer object, for the calls a sampler makes every step"""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
 
 
 def dptr(a):

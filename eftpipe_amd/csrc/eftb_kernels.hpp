@@ -44,7 +44,7 @@ __device__ __forceinline__ void xcd_decode(int ntile, int& tile, int& group) {
 // cosmology-contiguous copy the anti-diagonal pass reads), A3 = [Pin | tail'] (IR filters), zero padded to multiples of the GEMM's K chunk.
 // One workgroup per cosmology.  A1 / A3 may be null (only the other part is wanted).  Input guard: include/eftbird.h.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_rows_kernel(int Nkin, int ntail, int nxtail, int KP1, int KP2, int KP3, int Bmax,
+__device__ __forceinline__ void prep_rows_body(int Nkin, int ntail, int nxtail, int KP1, int KP2, int KP3, int Bmax,
                                                         const double* __restrict__ Pin, const double* __restrict__ lnkin,
                                                         const double* __restrict__ lnxtail, const double* __restrict__ lnxxtail,
                                                         const double* __restrict__ wq2, double* __restrict__ A1, double* __restrict__ A2,
@@ -81,6 +81,50 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(int Nkin, int ntail, int
         for (int j = tid; j < KP3; j += blockDim.x)
             A3[(size_t)w * KP3 + j] = j < Nkin ? pin[j] : (j < Nkin + nxtail ? amp * exp(slope * lnxxtail[j - Nkin]) : 0.0);
     }
+}
+
+__global__ __launch_bounds__(256) void prep_rows_kernel(int Nkin, int ntail, int nxtail, int KP1, int KP2, int KP3, int Bmax,
+                                                        const double* __restrict__ Pin, const double* __restrict__ lnkin,
+                                                        const double* __restrict__ lnxtail, const double* __restrict__ lnxxtail,
+                                                        const double* __restrict__ wq2, double* __restrict__ A1, double* __restrict__ A2,
+                                                        double* __restrict__ A2T, double* __restrict__ A3, int* __restrict__ status) {
+    prep_rows_body(Nkin, ntail, nxtail, KP1, KP2, KP3, Bmax, Pin, lnkin, lnxtail, lnxxtail, wq2, A1, A2, A2T, A3, status);
+}
+
+// Q(f) of Resum.makeQ for one cosmology (qf_kernel's body; declared here for the merged front launch below)
+__device__ __forceinline__ void qf_body(int w, int nq, const double* __restrict__ fgrow, const double* __restrict__ Qpoly, double* __restrict__ Q) {
+    const int tid = threadIdx.x;
+    const double f = fgrow[w];
+    for (int idx = tid; idx < 2 * nq; idx += blockDim.x) {
+        const int a = idx / nq, rest = idx % nq;
+        const double* c = Qpoly + ((size_t)(1 - a) * nq + rest) * 15;
+        double cv[15];
+#pragma unroll
+        for (int p = 0; p < 15; ++p) cv[p] = c[p];
+        const double f2 = f * f;
+        double ev = cv[14], od = cv[13];  // even / odd powers: two chains
+#pragma unroll
+        for (int p = 12; p >= 0; p -= 2) {
+            ev = fma(ev, f2, cv[p]);
+            if (p >= 1) od = fma(od, f2, cv[p - 1]);
+        }
+        Q[(size_t)w * 2 * nq + idx] = fma(od, f, ev);
+    }
+}
+
+// operand rows and Q(f) in one launch (direct-P_l runs: both are the first kernels of the front on the side stream; a launch costs the host
+// 4 us and the step is bounded by the host): workgroups [0, B) = prep_rows, [B, 2 B) = Q(f)
+__global__ __launch_bounds__(256) void prep_rows_qf_kernel(int B, int Nkin, int ntail, int nxtail, int KP1, int KP2, int KP3, int Bmax,
+                                                           const double* __restrict__ Pin, const double* __restrict__ lnkin,
+                                                           const double* __restrict__ lnxtail, const double* __restrict__ lnxxtail,
+                                                           const double* __restrict__ wq2, double* __restrict__ A1, double* __restrict__ A2,
+                                                           double* __restrict__ A2T, double* __restrict__ A3, int* __restrict__ status, int nq,
+                                                           const double* __restrict__ fgrow, const double* __restrict__ Qpoly, double* __restrict__ Q) {
+    if ((int)blockIdx.x >= B) {
+        qf_body(blockIdx.x - B, nq, fgrow, Qpoly, Q);
+        return;
+    }
+    prep_rows_body(Nkin, ntail, nxtail, KP1, KP2, KP3, Bmax, Pin, lnkin, lnxtail, lnxxtail, wq2, A1, A2, A2T, A3, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -851,14 +895,14 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 // regroup_kernel (reference pybird.py:737-866 followed by parambasis.py:42-136): row 0 of the template block takes sum_row b_row T[l][row] over the
 // rows the AP stage distorts (rows < 21, all rows when stoch0), rows 21-23 the stochastic templates as always (ap_plk_kernel adds them with their
 // coefficients); rows 1-20 of the block are not written.
-__global__ __launch_bounds__(256) void regroup_plk_kernel(int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
-                                                          const double* __restrict__ Y22, const double* __restrict__ P13,
-                                                          const double* __restrict__ l11, const double* __restrict__ lct,
-                                                          const double* __restrict__ bias, double* __restrict__ T, int stoch0) {
+__device__ __forceinline__ void regroup_plk_body(int kx, int w, int l, int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
+                                                 const double* __restrict__ Y22, const double* __restrict__ P13,
+                                                 const double* __restrict__ l11, const double* __restrict__ lct,
+                                                 const double* __restrict__ bias, double* __restrict__ T, int stoch0) {
     // Y22[w][l][k] (row stride BAS22 Nk per cosmology), P13[w][l][k] (10 Nk per cosmology): the loop pieces already contracted with the
     // bias (build_rows_plk_kernel) and synthesised; here the linear and counter terms join, the values at the first k are subtracted
     // (shot-noise subtraction, reference pybird.py:799-800) and the stochastic templates are laid beside the row
-    const int k = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y, l = blockIdx.z;
+    const int k = kx * blockDim.x + threadIdx.x;
     if (k >= Nk) return;
     const double* bw = bias + (size_t)w * NROW;
     const double* y22 = Y22 + ((size_t)w * BAS22 + l) * Nk;
@@ -921,23 +965,7 @@ __global__ __launch_bounds__(128) void regroup_cf_kernel(int Nl, const double* _
 // One workgroup per cosmology; Q[a] = table[1 - a] (pybird.py:1374-1376), nq = Nl*Nl*Nn entries per table.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qf_kernel(int nq, const double* __restrict__ fgrow, const double* __restrict__ Qpoly, double* __restrict__ Q) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    const double f = fgrow[w];
-    for (int idx = tid; idx < 2 * nq; idx += blockDim.x) {
-        const int a = idx / nq, rest = idx % nq;
-        const double* c = Qpoly + ((size_t)(1 - a) * nq + rest) * 15;
-        double cv[15];
-#pragma unroll
-        for (int p = 0; p < 15; ++p) cv[p] = c[p];
-        const double f2 = f * f;
-        double ev = cv[14], od = cv[13];  // even / odd powers: two chains
-#pragma unroll
-        for (int p = 12; p >= 0; p -= 2) {
-            ev = fma(ev, f2, cv[p]);
-            if (p >= 1) od = fma(od, f2, cv[p - 1]);
-        }
-        Q[(size_t)w * 2 * nq + idx] = fma(od, f, ev);
-    }
+    qf_body(blockIdx.x, nq, fgrow, Qpoly, Q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1433,13 +1461,13 @@ __global__ __launch_bounds__(256, 2) void resum_mfma_kernel(int Nk, int Nklow, i
 // ------------------------------------------------------------------------------------------------
 constexpr int RSD_REC = 160;  // doubles per (cosmology, s): 9 x 16 coefficients, X / RS_ZS, pad
 
-__global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, int Na, const double* __restrict__ Q, const double* __restrict__ XY,
-                                                             const double* __restrict__ C11, const double* __restrict__ Cct,
-                                                             const double* __restrict__ YCF, double* __restrict__ CF) {
+__device__ __forceinline__ void resum_prep_plk_body(int w, int part, int nparts, int NN, int NIR, int Na, const double* __restrict__ Q,
+                                                    const double* __restrict__ XY, const double* __restrict__ C11, const double* __restrict__ Cct,
+                                                    const double* __restrict__ YCF, double* __restrict__ CF) {
     // grid (cosmology, slice of the s range).  g_0[l'](s) = C11[w][l'][s], g_1[l'](s) = Cct[w][l'][s] + YCF[w][l'][s]: all three already carry their
     // bias coefficients (build_rows_plk_kernel contracted the rows before the synthesis)
     constexpr int NL = 3;
-    const int w = blockIdx.x, ns = (NS + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * ns, s1 = min(NS, s0 + ns), nsl = s1 - s0;
+    const int ns = (NS + nparts - 1) / nparts, s0 = part * ns, s1 = min(NS, s0 + ns), nsl = s1 - s0;
     extern __shared__ double sm[];
     double* s_q = sm;                        // [2 NL NL NN] the cosmology's Q(f)
     double* s_g = s_q + 2 * NL * NL * NN;    // [2][NL][ns] g_a[l'](s0 + .)
@@ -1475,6 +1503,24 @@ __global__ __launch_bounds__(256) void resum_prep_plk_kernel(int NN, int NIR, in
             v = xy[s] * (1.0 / RS_ZS);
         }
         dst[idx] = v;
+    }
+}
+
+// One launch for the two light kernels between the syntheses and the resummation of a direct-P_l run (a launch costs the host 4 us and the step is
+// bounded by the host): workgroups [0, nreg) = regroup_plk (k tile, cosmology, l), the rest = resum_prep_plk (cosmology, slice of the s range)
+__global__ __launch_bounds__(256) void back_prep_plk_kernel(int nreg, int nkx, int B, int nparts, int Nk, int Nl, const double* __restrict__ kk,
+                                                            const double* __restrict__ P11, const double* __restrict__ Y22,
+                                                            const double* __restrict__ P13, const double* __restrict__ l11,
+                                                            const double* __restrict__ lct, const double* __restrict__ bias, double* __restrict__ T,
+                                                            int stoch0, int NN, int NIR, int Na, const double* __restrict__ Q,
+                                                            const double* __restrict__ XY, const double* __restrict__ C11,
+                                                            const double* __restrict__ Cct, const double* __restrict__ YCF, double* __restrict__ CF) {
+    const int id = blockIdx.x;
+    if (id < nreg) {
+        regroup_plk_body(id % nkx, (id / nkx) % B, id / (nkx * B), Nk, Nl, kk, P11, Y22, P13, l11, lct, bias, T, stoch0);
+    } else {
+        const int j = id - nreg;
+        resum_prep_plk_body(j % B, j / B, nparts, NN, NIR, Na, Q, XY, C11, Cct, YCF, CF);
     }
 }
 

@@ -693,7 +693,6 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             fst = e->side;
             if (hipStreamWaitEvent(fst, e->evFrontFree[e->front_step & 1], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             if (!e->prev_front_side && hipStreamWaitEvent(fst, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
-            launch_irfilter(e, fst, B, !xy_in_prep);
             joined = joined_ap = true;  // (X, Y, Q(f) reach the rest of the chain with evFront; no AP tables in a direct run)
         } else if (pre_side) {
             st = e->pre;
@@ -723,6 +722,12 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // cosmology-contiguous transpose for the anti-diagonal pass), the second coefficient set of IRcutoff "loop" / "resum" (reference
         // pybird.py:1151-1160), and X(s), Y(s) when a resummation follows in this run
         if (!front_side) fst = st;
+        if (front_side)  // operand rows and Q(f) in one launch
+            hipLaunchKernelGGL(prep_rows_qf_kernel, dim3(2 * B), dim3(256), (size_t)c.Nkin * sizeof(double), fst, B, c.Nkin, c.ntail, c.nxtail, (int)kpad(c.Nkin),
+                               (int)kpad(c.Nkin + c.ntail), (int)kpad(c.Nkin + c.nxtail), c.max_batch, e->buf[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
+                               tb<double>(e, EFTB_T_LNXTAIL), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), e->PA1, e->PA2, e->PA2T, e->PA3,
+                               e->status + 2 * e->status_slot, c.Nl * c.Nl * e->Nn, e->buf[EFTB_B_F], tb<double>(e, EFTB_T_QPOLY), e->buf[EFTB_B_Q]);
+        else
         launch_prep_rows(e, fst, B, true, xy_in_prep);
         {
             SynthBatch sb{};
@@ -814,10 +819,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         if (nnlo_inline) std::swap(b[EFTB_B_TEMPLN], e->T3N);
     }
     if (mask & EFTB_S_REGROUP) {
-        if (direct)
-            hipLaunchKernelGGL(regroup_plk_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], e->Y22,
-                               b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), b[EFTB_B_BIAS], b[EFTB_B_TEMPL], c.ap_stochastic ? 1 : 0);
-        else
+        if (direct) {  // (regroup_plk rides in the launch of the operand build below: back_prep_plk_kernel)
+        } else
         hipLaunchKernelGGL(regroup_kernel, dim3((Nk + 255) / 256, B, Nl), dim3(256), 0, st, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_F],
                            b[EFTB_B_P11], b[EFTB_B_P22], b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
                            tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), b[EFTB_B_TEMPL]);
@@ -870,7 +873,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             if (full && direct) {
                 const int nsl = NS / 5;  // five slices of the s range per cosmology
                 const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 2 * 3 * nsl) * sizeof(double);
-                hipLaunchKernelGGL(resum_prep_plk_kernel, dim3(B, 5), dim3(256), plds, st, e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF, e->RSAS);
+                const int nkx = (Nk + 255) / 256, nreg = nkx * B * Nl;
+                hipLaunchKernelGGL(back_prep_plk_kernel, dim3(nreg + 5 * B), dim3(256), plds, st, nreg, nkx, B, 5, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], e->Y22,
+                                   b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), b[EFTB_B_BIAS], b[EFTB_B_TEMPL], c.ap_stochastic ? 1 : 0,
+                                   e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF, e->RSAS);
                 if (front_side) {  // the last reader of this run's front set
                     if (hipEventRecord(e->evFrontFree[e->front_step & 1], st) != hipSuccess) return fail("eftb_run: event record failed");
                     ++e->front_step;
