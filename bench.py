@@ -558,7 +558,10 @@ def main():
             "config": {"workload": "cfg2: single-tracer LRG z=0.7, Nl=3 (l=0,2,4), Nk=512, IR-resum + AP, P_l via west-coast bias contraction; "
                                    "H2D+D2H inclusive: every step stages new inputs from host memory and its P_l is fetched to host memory inside the timed region; "
                                    f"`value` pipelines INDEPENDENT batches at depth {DEPTH} (step i's P_l is copied out after step i + {DEPTH} has been launched); the rate a "
-                                   "sampler sees whose next step depends on this step's P_l is the side key sync_step_evaluations_per_s",
+                                   "sampler sees whose next step depends on this step's P_l is the side key sync_step_evaluations_per_s"
+                                   + ("; `value` is measured on direct-P_l runs (EFTB_O_PLK_DIRECT: the bias contraction is taken before the synthesis of the loop pieces, the "
+                                      "resummation and the AP stage, with which it commutes -- same P_l, no template block); the templates-first rate of the same loop (rounds 1-2) is "
+                                      "the side key templates_first_evaluations_per_s, and every timed step of the two is compared" if DIRECT else ""),
                        "batch_per_gpu": B,
                        "parallelism": (f"batch-sharded x{world}, per-step gather of P_l to rank 0 via {exchange}, rank 0 receives every step's gathered block in page-locked host memory"
                                        if world > 1 or force_comm else "single GPU")},
