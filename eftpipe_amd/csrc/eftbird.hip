@@ -905,19 +905,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
             const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
             if (direct) {
-                static const int rsd_cfg = getenv("EFTB_RSD_CFG") ? atoi(getenv("EFTB_RSD_CFG")) : 42;  // k per lane, slices of the s range
-#define RSD_LAUNCH(KPLV, SHV) do { const int nkd = (Nk + 64 * KPLV - 1) / (64 * KPLV); \
-                    hipLaunchKernelGGL((resum_plk_kernel<KPLV, SHV>), dim3(nkd * 3 * B), dim3(192 * SHV), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H), \
-                                       e->RSAS, b[EFTB_B_TEMPL], nkd); } while (0)
-                if (kblocks <= 0) {
-                } else if (rsd_cfg == 41) RSD_LAUNCH(4, 1);
-                else if (rsd_cfg == 42) RSD_LAUNCH(4, 2);
-                else if (rsd_cfg == 21) RSD_LAUNCH(2, 1);
-                else if (rsd_cfg == 12) RSD_LAUNCH(1, 2);
-                else if (rsd_cfg == 24) RSD_LAUNCH(2, 4);
-                else if (rsd_cfg == 22) RSD_LAUNCH(2, 2);
-                else RSD_LAUNCH(4, 2);
-#undef RSD_LAUNCH
+                // four k per lane, two slices of the s range (measured on the pool: 38-41 us; 4 x 1: 45, 2 x 1: 42, 2 x 2: 44, 1 x 2: 56, 2 x 4: 38)
+                const int nkd = (Nk + 64 * 4 - 1) / (64 * 4);
+                if (kblocks > 0)
+                    hipLaunchKernelGGL((resum_plk_kernel<4, 2>), dim3(nkd * 3 * B), dim3(192 * 2), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H),
+                                       e->RSAS, b[EFTB_B_TEMPL], nkd);
             } else if (kblocks > 0 && Nl == 3 && fused_nnlo)
                 hipLaunchKernelGGL((resum_mfma_kernel<true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
             else if (kblocks > 0 && Nl == 3)
