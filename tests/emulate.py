@@ -196,6 +196,31 @@ def resum_mfma(t, f, Pin, st):
     return out
 
 
+def resum_plk(t, f, Pin, st, bias):
+    """The resummation correction of a direct-P_l run (device: resum_prep_plk / resum_plk kernels, Nl = 3): with the bias contraction taken first,
+    dP_l(k) = k^2 sum_s sum_v H_v(k,s) D_lv(k^2 X(s) / RS_ZS; s),  D_lv = sum_p t^p RS_ZS^p sum_l' sum_a g_a[l'](s) (delta(v,l') X(s) Q_a[l,l',(0,p,v)] +
+    Y(s) Q_a[l,l',(1,p,v)]),  g_0 = C11 (b . l11),  g_1 = Cct (b . lct) + b . Cloopl.   -> [Nl, Nk]"""
+    from eftpipe_amd.tables import RS_ZS
+
+    NIR, Na, _ = t["resum_dims"]
+    Nl = 3
+    k = t["k"]
+    Qd = (t["Qpoly"] @ f ** np.arange(15))[::-1].reshape(2, Nl, Nl, 2, NIR, Na)  # device a (0: the C11 series), l, l', half, p, v
+    X, Y = ir_filters(t, Pin)
+    b = np.asarray(bias)
+    g = np.stack([st["C11"] * (t["l11"] @ b[0:3])[:, None],
+                  st["Cct"] * (t["lct"] @ b[3:9])[:, None] + np.einsum("i,lis->ls", b[9:21], st["Cloopl"])])  # [a, l', s]
+    term = Y[None, None, None, None, None, :] * Qd[:, :, :, 1, :, :, None]  # [a, l, l', p, v, s]
+    for lp in range(Nl):
+        term[:, :, lp, :, lp, :] += X[None, None, None, :] * Qd[:, :, lp, 0, :, lp, None]
+    coef = np.einsum("aps,alpqvs->lvqs", g, term) * (RS_ZS ** np.arange(NIR))[None, None, :, None]  # [l, v, p, s]
+    tt = k[:, None] ** 2 * X[None, :] / RS_ZS
+    D = np.zeros((Nl, Na) + tt.shape)
+    for p in range(NIR - 1, -1, -1):  # Horner, as the kernel does
+        D = D * tt + coef[:, :, p, None, :]
+    return k[None, :] ** 2 * np.einsum("vks,lvks->lk", t["H"], D)
+
+
 def spline_derivs(t, y):
     """y [..., Nk] -> knot derivatives via the banded operator (device: spline_kernel)."""
     band = t["sp_band"]

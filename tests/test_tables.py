@@ -46,6 +46,14 @@ def test_device_algebra_matches_oracle(golden, name, resum, ap):
                 assert relerr(alt[n], taps["resum"][n]) < 1e-9, n
             z = t["k"][:, None] ** 2 * alt["X"][None, :]
             assert z.max() < 2 * 8.0  # the scaled variable of the polynomial basis stays O(1)
+            if t["l11"].shape[0] == 3:
+                # direct-P_l runs: the bias contraction commutes with the stage -- the contracted correction (nine scalar-coefficient polynomials per s)
+                # against the reference's template corrections contracted afterwards
+                rng = np.random.default_rng(3)
+                bias = rng.normal(size=24)
+                dref = sum(np.einsum("i,lik->lk", bias[sl], taps["resum"][n] - taps["setpscfl"][n])
+                           for n, sl in (("P11l", slice(0, 3)), ("Pctl", slice(3, 9)), ("Ploopl", slice(9, 21))))
+                assert relerr(E.resum_plk(t, f, g["Pin"], pre, bias), dref) < 1e-9
     if ap:
         names = ("P11l", "Pctl", "Ploopl") + (("Pstl",) if name == "caseC" else ())
         st = E.ap(t, float(g["DA"]), float(g["H"]), st, names)
