@@ -94,7 +94,7 @@ def test_direct_pipelined_steps_are_bit_identical_to_synchronous_runs():
     the bits of one synchronous direct run per input set; switching the option between steps of one engine is safe."""
     import bench
 
-    B, K = 32, 9
+    B, K = 32, 13
     eng, _ = _engine(B)
     sets = [_draws(B, 500 + i) for i in range(3)]
     ref = [_plk(eng, s, B, True) for s in sets]
@@ -110,9 +110,9 @@ def test_direct_pipelined_steps_are_bit_identical_to_synchronous_runs():
         want.append((ref if direct else tm)[i % 3])
         eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
         eng.run_staged(mask, B)
-        if i >= 2:
-            eng.fetch_previous("PLK", (B, bench.NL, bench.NK), out=out[i - 2], back=2)
-    for back in (1, 0):
+        if i >= 5:  # five steps stay queued (the engine rotates eight sets: back <= 7)
+            eng.fetch_previous("PLK", (B, bench.NL, bench.NK), out=out[i - 5], back=5)
+    for back in (4, 3, 2, 1, 0):
         eng.fetch_previous("PLK", (B, bench.NL, bench.NK), out=out[K - 1 - back], back=back)
     eng.sync()
     for i in range(K):

@@ -583,8 +583,9 @@ def test_pipelined_steps_with_changing_inputs(golden):
     eng.close()
 
 
-def test_pipelined_flags_belong_to_their_step(golden):
-    """the guard flags are per rotating set.  In a depth-3 pipeline one step is poisoned (huge bias coefficients overflow its
+@pytest.mark.parametrize("direct", [False, True])
+def test_pipelined_flags_belong_to_their_step(golden, direct):
+    """the guard flags are per rotating set (direct: the same on direct-P_l runs, where the AP quadrature kernel raises the flag).  In a depth-3 pipeline one step is poisoned (huge bias coefficients overflow its
     P_l; EFTB_O_CHECK_FINITE) -- exactly that step's fetch fails, naming the cosmology; the steps queued around it fetch clean results.  And
     eftb_fetch_back refuses a step that was never launched instead of handing out a zero-filled block."""
     from eftpipe_amd import _lib as L
@@ -596,6 +597,7 @@ def test_pipelined_flags_belong_to_their_step(golden):
     B, nsteps, depth, poisoned = 2, 6, 3, 2
     eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=B)
     eng.set_check_finite(True)
+    eng.set_plk_direct(direct)
     shape = (B, 3, g["k"].size)
     b0 = bias_row(float(g["f"]), [2.0, 0.5, 0.3, 0.2, -1.0, -2.0, 0.5], None, (0.3, 0.1, -0.4), kmA=0.7, krA=0.25, ndA=4.5e-5)
     steps = [dict(Pin=np.stack([g["Pin"], (1.0 + 0.01 * s) * g["Pin"]]), f=float(g["f"]), DA=float(g["DA"]), H=float(g["H"]), bias=np.stack([b0, b0]))
