@@ -72,8 +72,9 @@ def test_direct_plk_against_oracle_and_template_path(APst):
 
 
 def test_direct_plk_with_fallback_tiles():
-    """Strong distortions: tiles whose k'(mu) crosses more knots than the weight tables hold go through ap_direct_kernel (the reference's own
-    quadrature) -- in direct runs on the contracted row.  Against the template path of the same engine."""
+    """Strong distortions: on the template path the tiles whose k'(mu) crosses more knots than the weight tables hold go through
+    ap_direct_kernel; in direct runs ap_plk_kernel's window of piecewise polynomials overflows (more than 192 intervals) and the pieces are
+    formed from global memory.  Against the template path of the same engine."""
     B = 8
     eng, _ = _engine(B)
     d = _draws(B, 31)
