@@ -2512,27 +2512,29 @@ __global__ __launch_bounds__(256) void ap_plk_kernel(int Nk, int nmu, const doub
     double acc[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) acc[l] = 0.0;
-    // the pieces of the interval the lane stands in live in registers and are replaced only when k'(mu) leaves it (a few times per quarter)
-    auto piece = [&](int i, double4 (&a)[NL]) {
-        if (!big) {
+    // the pieces of the interval the lane stands in live in registers and are replaced only when k'(mu) leaves it; the walk is compiled twice
+    // (window in LDS / pieces from global memory: workgroup-uniform choice) so that the common form carries none of the other's code
+    auto walk = [&](auto bigc) {
+        constexpr bool BIG = decltype(bigc)::value;
+        auto piece = [&](int i, double4 (&a)[NL]) {
+            if constexpr (!BIG) {
 #pragma unroll
-            for (int lp = 0; lp < NL; ++lp) a[lp] = *reinterpret_cast<const double4*>(s_pp + ((size_t)lp * APD_WMAX + (i - wlo)) * 4);
-        } else {
-            const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
-            const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
-            const int J = bspl_first(i, Nk);
+                for (int lp = 0; lp < NL; ++lp) a[lp] = *reinterpret_cast<const double4*>(s_pp + ((size_t)lp * APD_WMAX + (i - wlo)) * 4);
+            } else {
+                const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+                const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
+                const int J = bspl_first(i, Nk);
 #pragma unroll
-            for (int lp = 0; lp < NL; ++lp) {
-                const double* cp = cw + (size_t)lp * NROW * Nk + J;
-                const double c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
-                a[lp].x = fma(e0.x, c0, fma(e1.x, c1, fma(e2.x, c2, e3.x * c3)));
-                a[lp].y = fma(e0.y, c0, fma(e1.y, c1, fma(e2.y, c2, e3.y * c3)));
-                a[lp].z = fma(e0.z, c0, fma(e1.z, c1, fma(e2.z, c2, e3.z * c3)));
-                a[lp].w = fma(e0.w, c0, fma(e1.w, c1, fma(e2.w, c2, e3.w * c3)));
+                for (int lp = 0; lp < NL; ++lp) {
+                    const double* cp = cw + (size_t)lp * NROW * Nk + J;
+                    const double c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3];
+                    a[lp].x = fma(e0.x, c0, fma(e1.x, c1, fma(e2.x, c2, e3.x * c3)));
+                    a[lp].y = fma(e0.y, c0, fma(e1.y, c1, fma(e2.y, c2, e3.y * c3)));
+                    a[lp].z = fma(e0.z, c0, fma(e1.z, c1, fma(e2.z, c2, e3.z * c3)));
+                    a[lp].w = fma(e0.w, c0, fma(e1.w, c1, fma(e2.w, c2, e3.w * c3)));
+                }
             }
-        }
-    };
-    if (j0 < j1) {
+        };
         int i = knot_interval(s_k, Nk, kq * s_node[(size_t)j0 * 8]);
         double klo = s_k[i], khi = s_k[i + 1];
         double4 a[NL];
@@ -2561,6 +2563,10 @@ __global__ __launch_bounds__(256) void ap_plk_kernel(int Nk, int nmu, const doub
             acc[1] = fma(n1.y, P, acc[1]);
             if (NL > 2) acc[NL - 1] = fma(n1.z, P, acc[NL - 1]);
         }
+    };
+    if (j0 < j1) {
+        if (big) walk(std::true_type{});
+        else walk(std::false_type{});
     }
     if (wave > 0) {
 #pragma unroll
