@@ -690,6 +690,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             std::swap(e->PA1, a.PA1); std::swap(e->PA2, a.PA2); std::swap(e->PA2T, a.PA2T); std::swap(e->PA3, a.PA3); std::swap(e->coefT, a.coefT);
             std::swap(e->A22, a.A22); std::swap(e->A13, a.A13); std::swap(e->ACF, a.ACF); std::swap(e->ALC, a.ALC); std::swap(e->SAD, a.SAD);
             std::swap(b[EFTB_B_P11], a.P11); std::swap(b[EFTB_B_COEF], a.COEF); std::swap(b[EFTB_B_XY], a.XY); std::swap(b[EFTB_B_Q], a.Q);
+            ++e->epoch;  // (graphs captured earlier hold the other set's pointers)
             fst = e->side;
             if (hipStreamWaitEvent(fst, e->evFrontFree[e->front_step & 1], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             if (!e->prev_front_side && hipStreamWaitEvent(fst, e->evInFree, 0) != hipSuccess) return fail("eftb_run: stream wait failed");
