@@ -939,7 +939,11 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         }
     }
     if (ap_side) {
-        if (hipEventRecord(e->evResum, st) != hipSuccess || hipStreamWaitEvent(e->back, e->evResum, 0) != hipSuccess) return fail("eftb_run: stream fork failed");
+        // (with the operands built ahead the resummation's own event -- recorded right behind it on this stream -- is the fork point: one
+        // event record less on the host's path)
+        if (ahead && (mask & EFTB_S_RESUM)) {
+            if (hipStreamWaitEvent(e->back, e->evRsDone[(e->rs_step + 1) & 1], 0) != hipSuccess) return fail("eftb_run: stream fork failed");
+        } else if (hipEventRecord(e->evResum, st) != hipSuccess || hipStreamWaitEvent(e->back, e->evResum, 0) != hipSuccess) return fail("eftb_run: stream fork failed");
         st = e->back;
     }
     if (mask & EFTB_S_AP) {
@@ -1876,7 +1880,7 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     if (int rc = staged_setup(e)) return rc;
     HIPCHK(hipSetDevice(c.device));
     const int t = (e->cur_set + 1) % eftb_engine::NSETS;  // the set after the current one: the oldest, fetched (or abandoned) by now
-    HIPCHK(hipEventSynchronize(e->evStagedAll[t]));  // its staging block is free again (the previous upload from it has finished)
+    HIPCHK(hipEventSynchronize(e->set_latency[t] ? e->evStagedAll[t] : e->evStaged[t]));  // its staging block is free again (the previous upload from it has finished)
     // nothing in flight (the step launched last has finished, or none was launched): the step staged here has the GPU to itself -- see latency_auto
     const bool lat = e->latency_auto && e->staged_B == 0 && e->stage_off[EFTB_B_PIN] == 0 && hipEventQuery(e->evSetDone[e->cur_set]) == hipSuccess;
     e->set_latency[t] = lat;
@@ -1915,8 +1919,7 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     } else {
         copy(0, n_pin + n_small, 64, cs);
         copy(e->stage_off[EFTB_B_GROWS], n_rows, 64, cs);
-        HIPCHK(hipEventRecord(e->evStaged[t], cs));
-        HIPCHK(hipEventRecord(e->evStagedAll[t], cs));
+        HIPCHK(hipEventRecord(e->evStaged[t], cs));  // (= "all of it": evStagedAll is only recorded for latency-mode sets)
     }
     e->staged_B = B;
     return 0;
