@@ -109,6 +109,39 @@ def executed_flops_per_launch(B):
     return float(loop["flops_per_wave_trip"]) * waves * NS_DEV, float(loop["mfma_flops_per_wave_trip"]) * waves * NS_DEV, per_trip
 
 
+def synth_flops(t, B, direct):
+    """2 M N K of the products ONE synth_kernel launch of a whole-pipeline step carries, with the rows the engine queues (eftbird.hip, the
+    queue_synth calls of launch_stages_impl): templates first 7 basis rows of P22, Nl (7 + 2) weighted xi rows, 10 of P13, Nl + Nl of C11 / Cct per
+    cosmology; a direct-P_l run queues 3 contracted rows in each of the first three."""
+    nb, KS, KL = t["comb22"].shape[1], t["syn_k"].shape[0], t["lin_k"].shape[0]
+    ncf = NL * (nb + t["comb13"].shape[1])
+    r22, rcf, r13 = (3, 3, 3) if direct else (nb, ncf, 10)
+    flops = 2.0 * B * (r22 * NK * KS + rcf * NS_DEV * KS + r13 * NK * KL + 2 * NL * NS_DEV * KL)
+    note = f"2 M N K: [{B} x {r22}] x {KS} x {NK} + [{B} x {rcf}] x {KS} x {NS_DEV} + [{B} x {r13}] x {KL} x {NK} + [{B} x {2 * NL}] x {KL} x {NS_DEV}"
+    return flops, note
+
+
+def direct_step_flops(eng, B, allinfo):
+    """FP64 flops the launches of ONE direct-P_l step execute (what `roofline_step` divides by the step time): per kernel, from the compiled loops
+    (tools/isa_counts.py) where the kernel is a counted loop, else from the shape of its sums."""
+    t = eng.tables
+    kp = lambda n: (n + 47) // 48 * 48
+    Nkin, ntail, nxt = t["kin"].size, t["lnx_tail"].size, t["lnx_xtail"].size
+    out = {}
+    info = allinfo["resum_plk_kernel<4,2>"]
+    loop = max(info["loops"], key=lambda b: b["valu_f64"])
+    out["resum_plk_kernel"] = float(loop["flops_per_wave_trip"]) * B * 3 * ((NK + 255) // 256) * 6 * (NS_DEV // 4)
+    out["synth_kernel"] = synth_flops(t, B, direct=True)[0]
+    out["ap_plk_kernel"] = float(B) * NK * int(np.asarray(t["mu"]).size) * 30
+    nb = t["comb22"].shape[1] + t["comb13"].shape[1]
+    out["antidiag_kernel"] = 8.0 * B * nb * (NPOW * (NPOW + 1) // 2)     # one complex multiply-add per (matrix, pair n <= m) and cosmology
+    out["gemm_direct_kernel"] = 2.0 * B * (kp(Nkin) * NK + 2 * kp(Nkin + ntail) * 2 * 129 + kp(Nkin + nxt) * 2 * NS_DEV)  # P11, coefficients (+ transpose), X / Y
+    out["spline_kernel"] = 2.0 * B * NL * NK * 65                         # banded operator, half-width 32
+    out["build_rows_plk_kernel"] = 8.0 * B * NPOW * (3 * nb + 3 * NL * nb + 3 + 2 * NL)  # contraction of the anti-diagonal sums into 3 + 3 rows, the single-sum rows
+    out["back_prep_plk_kernel"] = 2.0 * B * (NL * NK * 12 + NS_DEV * 160 * 6)             # regrouping of the contracted rows; coefficient table (6 products per entry)
+    return out
+
+
 def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, measured_peak):
     """`roofline` of a direct-P_l run (EFTB_O_PLK_DIRECT).  Its step has no single dominant kernel any more: the resummation (resum_plk_kernel,
     FP64 vector work with scalar coefficients), the synthesis GEMMs of the loop stages (synth_kernel, FP64 MFMA) and the AP quadrature
@@ -142,7 +175,7 @@ def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, meas
     ms, n = ktimes[0]
     if n:
         tr, src = traffic_of("resum_plk_kernel")
-        entries.append({"bound": "mfma", "kernel": "resum_plk_kernel<4, 2> (Resum.Ps of a direct-P_l run: nine Horner chains of degree 15 per (k, s) with scalar coefficients; FP64 vector "
+        entries.append({"bound": "valu_f64", "kernel": "resum_plk_kernel<4, 2> (Resum.Ps of a direct-P_l run: nine Horner chains of degree 15 per (k, s) with scalar coefficients; FP64 vector "
                                                    "instructions, which share the DP pipe -- and its 78.6 TFLOP/s peak -- with the matrix cores)",
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
                         "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "executed_flops_per_launch": flops,
@@ -150,17 +183,15 @@ def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, meas
                                                        "vgprs": info.get("vgprs")},
                         "counts_source": "eftpipe_amd/csrc/isa_counts.json (tools/isa_counts.py, from the compiled gfx950 assembly)"})
     # (1) synth_kernel: 2 M N K of the four products of the launch (P22 basis rows, xi basis rows, P13, C11 / Cct)
-    nb, KS, KL = t["comb22"].shape[1], t["syn_k"].shape[0], t["lin_k"].shape[0]
-    ncf = NL * (nb + t["comb13"].shape[1])
-    flops = 2.0 * B * (nb * NK * KS + ncf * NS_DEV * KS + 10 * NK * KL + 2 * NL * NS_DEV * KL)
+    flops, note = synth_flops(t, B, direct=True)
     ms, n = ktimes[1]
     if n:
         tr, src = traffic_of("synth_kernel")
-        entries.append({"bound": "mfma", "kernel": "synth_kernel (makeP22 / makeC22 / makeC13 / makeP13 / makeC11 / makeCct as four FP64-MFMA GEMMs in one launch: the synthesis of the "
-                                                   "anti-diagonal sums at every k and s)",
+        entries.append({"bound": "mfma", "kernel": "synth_kernel (makeP22 / makeC22 / makeC13 / makeP13 / makeC11 / makeCct as FP64-MFMA GEMMs in one launch: the synthesis of the "
+                                                   "anti-diagonal sums at every k and s; in a direct-P_l run the rows arrive contracted with the bias: 3 per cosmology and product)",
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
                         "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_flops_per_launch": flops,
-                        "flops_note": f"2 M N K: [{B} x {nb}] x {KS} x {NK} + [{B} x {ncf}] x {KS} x {NS_DEV} + [{B} x 10] x {KL} x {NK} + [{B} x {2 * NL}] x {KL} x {NS_DEV}"})
+                        "flops_note": note})
     # (2) ap_plk_kernel: the reference's mu quadrature on the contracted rows: per (k, node) three cubics (3 FMA each), two Legendre-weighted
     # additions and three accumulations (14 FMA + the k' product and the offset from the knot) -- FP64 vector work
     nmu = int(np.asarray(t["mu"]).size)
@@ -168,7 +199,7 @@ def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, meas
     ms, n = ktimes[2]
     if n:
         tr, src = traffic_of("ap_plk_kernel")
-        entries.append({"bound": "mfma", "kernel": "ap_plk_kernel<3> (APeffect.AP of a direct-P_l run: the reference's own mu quadrature of P_l'(k'(mu)) L_l'(mu') L_l(mu) on one row per "
+        entries.append({"bound": "valu_f64", "kernel": "ap_plk_kernel<3> (APeffect.AP of a direct-P_l run: the reference's own mu quadrature of P_l'(k'(mu)) L_l'(mu') L_l(mu) on one row per "
                                                    "multipole, splines as piecewise polynomials in LDS; FP64 vector instructions, bound by issue and LDS latency rather than by arithmetic)",
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
                         "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_flops_per_launch": flops,
@@ -195,6 +226,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra rates (resident loop, templates back, drop-in latency)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): this process becomes the launcher -- N FRESH child processes, one rank per GPU, with the
+        # environment torch.distributed.run would have set.  Nothing here has touched HIP yet, and nothing is exec'ed: children are spawned.
+        raise SystemExit(spawn_ranks(args.gpus))
+
     from eftpipe_amd import _lib as L
     from eftpipe_amd import dist, synth
     from eftpipe_amd.engine import Engine, comm_unique_id, mfma_f64_peak
@@ -205,6 +241,14 @@ def main():
     rank, world = cp.rank, cp.world
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("EFTB_BENCH_RENDEZVOUS_ONLY"):  # launch-path check for boxes without a GPU (tests/test_host_logic.py): every rank joins, rank 0 reports
+        cp.barrier()
+        ranks = cp.max(float(rank)) + 1
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": world, "highest_rank_seen": int(ranks) - 1}))
+        cp.barrier()
+        cp.close()
+        return
     B, K, W = args.batch, args.steps, args.warmup
     cfg = EngineConfig(Nl=NL, k=synth.survey_kgrid(NK), with_resum=True, with_ap=True,
                        DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
@@ -303,6 +347,15 @@ def main():
         The output of step i - DEPTH is copied out after step i has been launched, so DEPTH steps are always queued on the GPU while the
         host copies and prepares (the engine keeps DEPTH + 1 sets of per-step inputs / outputs)."""
         for i in range(n):
+            if exchange == "none":  # one library call per step: stage + launch + the view of the step DEPTH back (eftb_step)
+                d = sets[first + i]
+                view = eng.step(mask, d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"], back=DEPTH, shape=(B, NL, NK))
+                if view is not None:
+                    if keep:
+                        keeper.put(view, i - DEPTH)
+                        if STEP_TIMES is not None:
+                            STEP_TIMES.append(time.perf_counter())
+                continue
             stage_and_run(sets[first + i])
             if exchange == "rccl":
                 eng.gather_plk(B, root=0)
@@ -313,10 +366,6 @@ def main():
             elif exchange == "host-fallback":
                 eng.sync()
                 cp.gather_host(eng.get("PLK", (B, NL, NK)))
-            elif i >= DEPTH:
-                take(i - DEPTH, DEPTH, keep)
-                if STEP_TIMES is not None and keep:
-                    STEP_TIMES.append(time.perf_counter())
         # drain: the last DEPTH steps
         if exchange == "rccl":
             eng.sync()
@@ -382,16 +431,21 @@ def main():
         assert np.array_equal(last[rank], results[K - 1]), "the root's own slice of the gathered block differs from its P_l"
 
     # ---- the same timed loop with the templates first (every rank takes part: the N > 1 loop exchanges); its P_l against the direct runs'
-    tf_elapsed, tf_err = None, None
+    tf_elapsed, tf_err, tf_dom_ms, tf_dom_n = None, None, 0.0, 0
     if DIRECT:
         direct_results = results.copy()
         eng.set_plk_direct(False)
         loop(0, W, keep=False)
+        eng.time_kernels(1)   # resum_mfma_kernel inside THIS loop: the in-pipeline time `roofline_templates_first` is priced with
+        eng.time_dominant(0 if os.environ.get("EFTB_BENCH_NO_EVENTS") else int(os.environ.get("EFTB_BENCH_EVENT_EVERY", "2")))
+        eng.kernel_time(0, reset=True)
         cp.barrier()
         t0 = time.perf_counter()
         loop(W, K, keep=True)
         cp.barrier()
         tf_elapsed = cp.max(time.perf_counter() - t0)
+        tf_dom_ms, tf_dom_n = eng.kernel_time(0, reset=True)
+        eng.time_dominant(False)
         if exchange == "none" or (exchange == "rccl" and rank == 0):
             scale = np.max(np.abs(results), axis=-1, keepdims=True)
             tf_err = float(np.max(np.abs(direct_results - results) / scale))
@@ -509,7 +563,13 @@ def main():
         # ---- roofline of the dominant kernel: EXECUTED FP64 work / live-measured time / FP64 matrix peak
         exe_flops, exe_mfma_flops, per_trip = executed_flops_per_launch(B)
         ms_alone = ms_resum
-        ms_resum = dom_ms / dom_n if dom_n else ms_alone  # average over the launches of the timed region (beside the look-ahead / back-half kernels)
+        # average over the launches of the timed region (beside the look-ahead / back-half kernels).  In a direct-P_l bench the timed region's kind-0
+        # timer bracketed resum_plk_kernel, not this kernel: its own in-pipeline time comes from the templates-first loop above
+        if DIRECT:
+            dom_tf_ms, dom_tf_n = tf_dom_ms, tf_dom_n
+        else:
+            dom_tf_ms, dom_tf_n = dom_ms, dom_n
+        ms_resum = dom_tf_ms / dom_tf_n if dom_tf_n else ms_alone
         achieved = exe_flops / (ms_resum * 1e-3) / 1e12
         try:
             measured_peak = mfma_f64_peak(device)
@@ -532,9 +592,9 @@ def main():
             "bound": "mfma", "kernel": "resum_mfma_kernel<NNLO> (Resum.Ps on v_mfma_f64_16x16x4_f64 + FP64 VALU, which share the DP pipe)",
             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src,
-            "ms_per_launch": ms_resum, "launches_timed": dom_n,
-            "ms_per_launch_note": "HIP events on the kernel's own stream around every second of its launches inside the timed region, where the look-ahead and "
-                                  "back-half kernels of the neighbouring steps share the CUs (and the FP64 pipe) with it",
+            "ms_per_launch": ms_resum, "launches_timed": dom_tf_n,
+            "ms_per_launch_note": "HIP events on the kernel's own stream around every second of its launches inside the timed templates-first loop, where the look-ahead and "
+                                  "back-half kernels of the neighbouring steps share the CUs (and the FP64 pipe) with it" + ("" if dom_tf_n else " -- NOT AVAILABLE in this run: the stand-alone time is used"),
             "ms_per_launch_alone": ms_alone, "frac_alone": exe_flops / (ms_alone * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "executed_flops_per_launch": exe_flops, "executed_mfma_flops_per_launch": exe_mfma_flops,
             "mfma_only_frac": exe_mfma_flops / (ms_resum * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
@@ -548,6 +608,32 @@ def main():
         }
         if DIRECT:
             roofline = direct_rooflines(eng, cfg, B, ktimes, sets[W], roofline, FP64_MFMA_PEAK_TFLOPS, measured_peak)
+            # the step as a whole: executed FP64 flops of all its launches over the step time (a direct step has no dominant kernel)
+            with open(os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")) as fh:
+                per_kernel = direct_step_flops(eng, B, json.load(fh))
+            step_flops = sum(per_kernel.values())
+            ms_step = elapsed / K * 1e3
+            res = extras.get("resident_evaluations_per_s")
+            roofline["roofline_step"] = {
+                "bound": "valu_f64 + mfma (one DP pipe)", "executed_flops_per_step": step_flops, "flops_per_kernel": per_kernel,
+                "achieved": step_flops / (ms_step * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": step_flops / (ms_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms_per_step": ms_step,
+                "frac_resident_inputs": (step_flops / (B / res) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if res else None,
+                "note": "sum over the launches of one direct-P_l step of the FP64 flops they execute (compiled-loop counts for the resummation, 2 M N K for the matrix-core "
+                        "products, sums' shapes for the rest) / ms_per_step of the timed loop / FP64 peak; frac_resident_inputs: the same over the step time of the resident loop"}
+
+        def check_fracs(node, path="roofline"):
+            # no utilisation above 1 leaves this program: such a number is a pricing error, not a measurement
+            if isinstance(node, dict):
+                for k_, v in node.items():
+                    if k_.startswith("frac") or k_ == "mfma_only_frac":
+                        assert v is None or 0.0 <= v <= 1.0, f"{path}.{k_} = {v}: outside [0, 1]"
+                    check_fracs(v, path + "." + k_)
+            elif isinstance(node, list):
+                for i_, v in enumerate(node):
+                    check_fracs(v, f"{path}[{i_}]")
+
+        check_fracs(roofline)
         value = B * world * K / elapsed
         valid = exchange in ("none", "rccl") and not shared_device
         out = {
@@ -604,6 +690,32 @@ def main():
     cp.barrier()
     eng.close()
     cp.close()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set as torch.distributed.run sets them), let rank 0's stdout (the JSON line) through, and return the worst child status."""
+    import socket
+    import subprocess
+    import uuid
+
+    with socket.socket() as sk:  # a free port for the rendezvous name (the control plane is a Unix socket named from it unless EFTB_CP_TCP_PORT is set)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    run_id = uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TORCHELASTIC_RUN_ID=run_id)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    for r, pr in enumerate(procs):
+        rc = pr.wait()
+        if rc:
+            print(f"[bench] rank {r} exited with status {rc}", file=sys.stderr)
+            worst = max(worst, rc if rc > 0 else 128 - rc)
+    return worst
 
 
 def _device_count():

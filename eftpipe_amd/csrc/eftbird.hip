@@ -6,8 +6,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -111,8 +115,6 @@ struct eftb_engine {
     // beside it) and one pair (slot NSETS) for runs on the engine's own buffers (eftb_put / eftb_run / eftb_eval_batch).
     int* status = nullptr;
     int status_slot = 8;            // = NSETS: pair the kernels of the next launch raise (eftb_run_staged: the step's set)
-    int gath_set[4] = {4, 4, 4, 4};  // set whose P_l exchange `slot` carries (its flags are checked when the gathered block is handed out)
-    unsigned long long staged_launched = 0;  // eftb_run_staged calls so far: eftb_fetch_back(back) needs back < staged_launched
     bool check_finite = false;
     std::vector<double> like_host;  // eftb_eval_logp_batch: D2H landing block [B][MARG_OUT]
     int* like_index = nullptr;
@@ -208,12 +210,43 @@ struct eftb_engine {
     double* gath_host[NSETS] = {};
     hipEvent_t evGathHost[NSETS] = {};
     size_t gath_elems[NSETS] = {};
+    int gath_set[NSETS] = {NSETS, NSETS, NSETS, NSETS, NSETS, NSETS, NSETS, NSETS};  // set whose P_l exchange `slot` carries (its flags are checked when the gathered block is handed out; NSETS: the engine's own buffers)
+    static_assert(NSETS == 8, "gath_set's initialiser and status_slot's default name NSETS entries");
     int gather_slot = 0;
     // the gather runs on its own stream from a snapshot of P_l, so that it overlaps the next step's kernels
     hipStream_t comm_stream = nullptr;
     hipEvent_t evSnap = nullptr, evGathered = nullptr;
     double* plk_snap = nullptr;
+    // Submission thread (EFTB_O_SUBMIT_THREAD, default on).  A staged step costs the host 50-95 us of HIP calls (nine kernel launches, ~20 event
+    // records / waits) on top of ~30 us of validation and copies into the staging block -- more than the 0.12 ms the GPU needs for a direct-P_l
+    // step of 128.  So while earlier steps are still in flight, eftb_stage_inputs only fills the staging block and eftb_run_staged only QUEUES the
+    // step: this thread issues the upload kernel and every launch of the step (exactly the code the caller's thread runs otherwise), and the
+    // caller goes on to the next step's inputs.  A step that finds the engine quiescent and the GPU idle (a dependent sampler's step) is issued by the
+    // caller itself, as before: no hand-over latency.  Every other entry point waits until the queue is empty (sub_drain), so the engine's state
+    // is only ever touched by one thread at a time; the queue and the per-step completion records are the only shared data.
+    struct SubCmd { int set, mask, B, has_rows; unsigned long long step; };
+    static constexpr int SUBQ = 16;          // ring of queued steps (at most NSETS - 1 can be pending: every step owns a staging set)
+    SubCmd sub_ring[SUBQ];
+    std::atomic<unsigned long long> sub_tail{0};   // commands pushed (caller's thread)
+    std::atomic<unsigned long long> sub_head{0};   // commands completed (submission thread)
+    std::atomic<bool> sub_sleeping{false}, sub_stop{false};
+    std::mutex sub_mx;
+    std::condition_variable sub_cv;
+    std::thread sub_thread;
+    int sub_mode = 1;   // 0: the caller issues every step; 1: queued unless the engine is quiescent and the GPU idle; 2: always queued (tests)
+    bool sub_started = false;
+    static constexpr int SUBREC = 32;        // completion records of the last steps: rc + message of the launch (surface when the step is fetched)
+    int sub_rc[SUBREC] = {};
+    char sub_err[SUBREC][256] = {};
+    std::atomic<unsigned long long> steps_launched{0};  // staged steps whose launch has been issued (by either thread), in order
+    unsigned long long steps_submitted = 0;   // staged steps handed in so far (caller's thread) = what eftb_fetch_back counts `back` from
+    int p_set = NSETS - 1;                    // caller's view of the set rotation: the set of the step submitted last
+    int dfr_set = -1, dfr_B = 0, dfr_rows = 0;   // inputs staged into set dfr_set, waiting for eftb_run_staged to queue them
+    unsigned long long set_step[NSETS] = {};  // 1 + the step that used the set last (0: never used): its launch must be over before the set is refilled
 };
+
+static void sub_stop_thread(eftb_engine* e);
+static inline void sub_drain(eftb_engine* e);   // every entry point but the staged-step calls first lets the submission thread finish its queue
 
 // RCCL is resolved lazily so that single-GPU users never load it
 struct RcclApi {
@@ -663,8 +696,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                              !c.with_nnlo && !nnlo_pass;
     // direct-P_l runs (EFTB_O_PLK_DIRECT): the bias contraction first, then resummation and AP on ONE row per multipole (regroup_plk_kernel,
     // resum_prep_plk_kernel, resum_plk_kernel, spline / ap_rows on row 0); the template block is not produced
+    // (only runs that also hold PREP, LOOPS and CF: the front of a direct run leaves CONTRACTED rows in Y22 / P13 / YCF / C11 / CCT, which is what
+    // back_prep_plk_kernel reads -- a run split in front of REGROUP finds un-contracted rows there and takes the template path)
     const bool direct = e->plk_direct && fuse_reduce && fuse_cf && Nl == 3 && !e->generic_resum && e->ap_fast && !c.dual_coef && !e->use_graphs &&
-                        (mask & EFTB_S_REGROUP) && e->RSAS;
+                        (mask & EFTB_S_PREP) && (mask & EFTB_S_LOOPS) && (mask & EFTB_S_CF) && (mask & EFTB_S_REGROUP) && e->RSAS;
     // ... and the per-s A operand of the Nl = 3 resummation (inputs only: Q(f), X, Y) is built on the side stream, off the chain
     const bool as_side = ahead && Nl == 3 && !e->generic_resum && e->RSAS2 && !direct;
     // ... whose front runs a step ahead on the side stream (see FrontSet)
@@ -1324,6 +1359,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AD_WAVES")) e->ad_waves = atoi(f);
     if (const char* f = getenv("EFTB_GD_WAVES")) e->gd_waves = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_SUBMIT_THREAD")) e->sub_mode = std::max(0, std::min(2, atoi(f)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 2 * (eftb_engine::NSETS + 1) * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 2 * (eftb_engine::NSETS + 1) * sizeof(int));
     HIPCHK(hipDeviceSynchronize());  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
@@ -1332,6 +1368,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
 }
 
 int eftb_set_table(eftb_engine* e, int id, const void* host, size_t nbytes) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e || !host) return fail("eftb_set_table: null argument");
     if (id < 0 || id >= EFTB_T_COUNT) return fail("eftb_set_table: bad table id %d", id);
@@ -1355,6 +1392,7 @@ int eftb_set_table(eftb_engine* e, int id, const void* host, size_t nbytes) {
 }
 
 int eftb_finalize(eftb_engine* e) {
+    if (e) sub_drain(e);
     if (!e) return fail("eftb_finalize: null engine");
     for (int id = 0; id < EFTB_T_COUNT; ++id)
         if (need_table_bytes(e->c, id) && !e->tab[id]) return fail("eftb_finalize: table %d was never set", id);
@@ -1419,6 +1457,7 @@ int eftb_finalize(eftb_engine* e) {
 }
 
 int eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx_in, const double* op, int* op_id) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e || !op || !op_id) return fail("eftb_add_operator: null argument");
     if (nl_out < 1 || nx_out < 1 || nl_in < 1 || nx_in < 1) return fail("eftb_add_operator: bad shape");
@@ -1442,6 +1481,7 @@ int eftb_add_operator(eftb_engine* e, int nl_out, int nx_out, int nl_in, int nx_
 }
 
 int eftb_set_operator_stochastic(eftb_engine* e, int op_id, int st_op_id) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e) return fail("eftb_set_operator_stochastic: null engine");
     const int n = (int)e->ops.size();
@@ -1456,6 +1496,7 @@ int eftb_set_operator_stochastic(eftb_engine* e, int op_id, int st_op_id) {
 }
 
 int eftb_set_tracers(eftb_engine* e, int ntr) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e) return fail("eftb_set_tracers: null engine");
     if (ntr < 1 || ntr > e->c.max_batch) return fail("eftb_set_tracers: %d tracers outside [1, max_batch]", ntr);
@@ -1466,6 +1507,7 @@ int eftb_set_tracers(eftb_engine* e, int ntr) {
 }
 
 int eftb_set_pipeline_operator_tracer(eftb_engine* e, int tracer, int op_id) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e) return fail("eftb_set_pipeline_operator_tracer: null engine");
     const int n = (int)e->ops.size();
@@ -1482,6 +1524,7 @@ int eftb_set_pipeline_operator_tracer(eftb_engine* e, int tracer, int op_id) {
 }
 
 int eftb_apply_operator(eftb_engine* e, int op_id, int B) {
+    if (e) sub_drain(e);
     if (!e) return fail("eftb_apply_operator: null engine");
     if (!e->finalized) return fail("eftb_apply_operator: engine not finalized");
     if (B < 1 || B > e->c.max_batch) return fail("eftb_apply_operator: batch %d outside [1, %d]", B, e->c.max_batch);
@@ -1494,6 +1537,7 @@ int eftb_apply_operator(eftb_engine* e, int op_id, int B) {
 }
 
 int eftb_set_pipeline_operator(eftb_engine* e, int op_id) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e) return fail("eftb_set_pipeline_operator: null engine");
     if (op_id >= (int)e->ops.size()) return fail("eftb_set_pipeline_operator: operator id %d out of range", op_id);
@@ -1502,6 +1546,7 @@ int eftb_set_pipeline_operator(eftb_engine* e, int op_id) {
 }
 
 int eftb_set_template_dims(eftb_engine* e, int nl, int nx) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e) return fail("eftb_set_template_dims: null engine");
     if (nl < 1 || nx < 1 || (size_t)nl * nx > (size_t)e->c.Nl * e->c.Nk) return fail("eftb_set_template_dims: bad shape [%d][24][%d]", nl, nx);
@@ -1511,6 +1556,7 @@ int eftb_set_template_dims(eftb_engine* e, int nl, int nx) {
 }
 
 int eftb_set_option(eftb_engine* e, int option, int value) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e) return fail("eftb_set_option: null engine");
     switch (option) {
@@ -1521,6 +1567,9 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seqk[0] = e->time_seqk[1] = e->time_seqk[2] = 0; return 0;
         case EFTB_O_LATENCY_MODE: e->latency_auto = value != 0; return 0;
         case EFTB_O_PLK_DIRECT: e->plk_direct = value != 0; return 0;
+        case EFTB_O_SUBMIT_THREAD:
+            if (value < 0 || value > 2) return fail("eftb_set_option: EFTB_O_SUBMIT_THREAD takes 0, 1 or 2");
+            e->sub_mode = value; return 0;
         case EFTB_O_TIME_KERNEL:
             if (value < 1 || value > 7) return fail("eftb_set_option: EFTB_O_TIME_KERNEL takes a set of 1 (resummation) | 2 (synthesis) | 4 (AP knot weights)");
             e->time_kernel = value; return 0;
@@ -1529,12 +1578,14 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
 }
 
 int eftb_dominant_time(eftb_engine* e, double* ms_sum, long long* launches, int reset) {
+    if (e) sub_drain(e);
     if (!e || !ms_sum || !launches) return fail("eftb_dominant_time: null argument");
     HIPCHK(hipSetDevice(e->c.device));
     return eftb_kernel_time(e, 0, ms_sum, launches, reset);
 }
 
 int eftb_kernel_time(eftb_engine* e, int kind, double* ms_sum, long long* launches, int reset) {
+    if (e) sub_drain(e);
     if (!e || !ms_sum || !launches) return fail("eftb_kernel_time: null argument");
     if (kind < 0 || kind > 2) return fail("eftb_kernel_time: kind %d (0 resummation, 1 synthesis, 2 AP knot weights)", kind);
     HIPCHK(hipSetDevice(e->c.device));
@@ -1550,6 +1601,7 @@ int eftb_kernel_time(eftb_engine* e, int kind, double* ms_sum, long long* launch
 
 int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov, int nG, const double* mu,
                         const double* sigma_inv) {
+    if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e || !index || !data || !invcov || (nG > 0 && (!mu || !sigma_inv))) return fail("eftb_set_likelihood: null argument");
     if (nG < 0 || nG > MARG_MAXG) return fail("eftb_set_likelihood: nG=%d outside [0, %d]", nG, MARG_MAXG);  // nG = 0: plain -chi2 / 2
@@ -1606,6 +1658,7 @@ int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const d
 
 void eftb_destroy(eftb_engine* e) {
     if (!e) return;
+    sub_stop_thread(e);
     (void)hipSetDevice(e->c.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
@@ -1663,6 +1716,7 @@ size_t eftb_buffer_size(const eftb_engine* e, int id) {
 }
 
 int eftb_put(eftb_engine* e, int id, size_t offset, const double* host, size_t count) {
+    if (e) sub_drain(e);
     if (!e || !host) return fail("eftb_put: null argument");
     if (id < 0 || id >= EFTB_B_COUNT || !e->buf[id]) return fail("eftb_put: buffer %d not available in this configuration", id);
     if (offset + count > e->buf_elems[id]) return fail("eftb_put: buffer %d holds %zu elements, asked [%zu, %zu)", id, e->buf_elems[id], offset, offset + count);
@@ -1674,6 +1728,7 @@ int eftb_put(eftb_engine* e, int id, size_t offset, const double* host, size_t c
 }
 
 int eftb_get(eftb_engine* e, int id, size_t offset, double* host, size_t count) {
+    if (e) sub_drain(e);
     if (!e || !host) return fail("eftb_get: null argument");
     if (id < 0 || id >= EFTB_B_COUNT || !e->buf[id]) return fail("eftb_get: buffer %d not available in this configuration", id);
     if (offset + count > e->buf_elems[id]) return fail("eftb_get: buffer %d holds %zu elements, asked [%zu, %zu)", id, e->buf_elems[id], offset, offset + count);
@@ -1685,6 +1740,7 @@ int eftb_get(eftb_engine* e, int id, size_t offset, double* host, size_t count) 
 }
 
 int eftb_run(eftb_engine* e, int mask, int B) {
+    if (e) sub_drain(e);
     if (!e) return fail("eftb_run: null engine");
     if (!e->finalized) return fail("eftb_run: engine not finalized");
     if (B < 1 || B > e->c.max_batch) return fail("eftb_run: batch %d outside [1, %d]", B, e->c.max_batch);
@@ -1704,6 +1760,7 @@ int eftb_run(eftb_engine* e, int mask, int B) {
 }
 
 int eftb_sync(eftb_engine* e) {
+    if (e) sub_drain(e);
     if (!e) return fail("eftb_sync: null engine");
     join_back(e);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1712,6 +1769,7 @@ int eftb_sync(eftb_engine* e) {
 }
 
 int eftb_run_timed(eftb_engine* e, int mask, int B, int repeats, float* ms) {
+    if (e) sub_drain(e);
     if (!e || !ms) return fail("eftb_run_timed: null argument");
     if (!e->finalized) return fail("eftb_run_timed: engine not finalized");
     if (B < 1 || B > e->c.max_batch) return fail("eftb_run_timed: batch %d outside [1, %d]", B, e->c.max_batch);
@@ -1753,6 +1811,7 @@ static int upload_and_launch(eftb_engine* e, const char* who, int B, const doubl
 
 int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, double* templ,
                     const double* bias, double* plk) {
+    if (e) sub_drain(e);
     if (!e || !Pin || !f || (!templ && !plk)) return fail("eftb_eval_batch: null argument");
     if (plk && !bias) return fail("eftb_eval_batch: bias is required when plk is requested");
     if (plk && B >= 1 && B <= e->c.max_batch) {
@@ -1771,6 +1830,7 @@ int eftb_eval_batch(eftb_engine* e, int B, const double* Pin, const double* f, c
 
 int eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* rows,
                          double* logp, double* fullchi2, double* best) {
+    if (e) sub_drain(e);
     if (!e || !Pin || !f || !rows || !logp) return fail("eftb_eval_logp_batch: null argument");
     if (!e->finalized) return fail("eftb_eval_logp_batch: engine not finalized");
     if (!e->like_ndata) return fail("eftb_eval_logp_batch: needs eftb_set_likelihood");
@@ -1868,23 +1928,10 @@ static int staged_setup(eftb_engine* e) {
     return 0;
 }
 
-int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
-                      const double* rows) {
-    if (!e || !Pin || !f) return fail("eftb_stage_inputs: null argument");
-    if (!e->finalized) return fail("eftb_stage_inputs: engine not finalized");
+// ---- staged steps: the host part (inputs -> page-locked block of set t) ...
+static void stage_fill(eftb_engine* e, int t, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
+                       const double* rows) {
     const eftb_config& c = e->c;
-    if (B < 1 || B > c.max_batch) return fail("eftb_stage_inputs: batch %d outside [1, %d]", B, c.max_batch);
-    if (c.with_ap && (!DA || !H)) return fail("eftb_stage_inputs: DA and H are required when with_ap=1");
-    if (rows && !e->like_ndata) return fail("eftb_stage_inputs: rows need eftb_set_likelihood");
-    if (int rc = validate_inputs(c, "eftb_stage_inputs", B, Pin, f, DA, H)) return rc;
-    if (int rc = staged_setup(e)) return rc;
-    HIPCHK(hipSetDevice(c.device));
-    const int t = (e->cur_set + 1) % eftb_engine::NSETS;  // the set after the current one: the oldest, fetched (or abandoned) by now
-    HIPCHK(hipEventSynchronize(e->set_latency[t] ? e->evStagedAll[t] : e->evStaged[t]));  // its staging block is free again (the previous upload from it has finished)
-    // nothing in flight (the step launched last has finished, or none was launched): the step staged here has the GPU to itself -- see latency_auto
-    const bool lat = e->latency_auto && e->staged_B == 0 && e->stage_off[EFTB_B_PIN] == 0 && hipEventQuery(e->evSetDone[e->cur_set]) == hipSuccess;
-    e->set_latency[t] = lat;
-    if (lat) hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, e->stream);  // (see wake_kernel: its start-up runs under the host copies below)
     double* h = e->stage_host[t];
     memcpy(h + e->stage_off[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double));
     memcpy(h + e->stage_off[EFTB_B_F], f, (size_t)B * sizeof(double));
@@ -1898,12 +1945,17 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
         for (int w = 0; w < B; ++w)
             memcpy(h + e->stage_off[EFTB_B_GROWS] + (size_t)w * MARG_NG1 * NROW, rows + (size_t)w * ng1 * NROW, (size_t)ng1 * NROW * sizeof(double));
     }
+}
+
+// ... and the device part (issued by the caller's thread or by the submission thread): the upload kernels of set t and their events
+static int stage_issue(eftb_engine* e, int t, int B, bool has_rows, bool lat) {
+    double* h = e->stage_host[t];
     hipStream_t cs = e->cpy;
     HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[t], 0));  // the last run on this set (and the fetch of its results) is over
     // (a copy kernel reading the mapped staging block, not a DMA transfer: 0.4 MB is latency, and the DMA form measured the same or worse)
     // only what was staged travels: P_lin, f, DA, H, the bias rows -- and the likelihood rows (0.6 MB at 128 walkers) when there are any.  Reads
     // of host memory from a kernel run at ~16 GB/s: the whole 0.85 MB block took 48-53 us, on the critical path of a dependent sampler
-    const size_t n_pin = e->stage_off[EFTB_B_F], n_small = e->stage_off[EFTB_B_GROWS] - n_pin, n_rows = rows ? (size_t)B * MARG_NG1 * NROW : 0;
+    const size_t n_pin = e->stage_off[EFTB_B_F], n_small = e->stage_off[EFTB_B_GROWS] - n_pin, n_rows = has_rows ? (size_t)B * MARG_NG1 * NROW : 0;
     auto copy = [&](size_t off, size_t n, int wgs, hipStream_t q) {
         if (n) hipLaunchKernelGGL(stage_copy_kernel, dim3(wgs), dim3(256), 0, q, h + off, e->setblock[t] + off, n);
     };
@@ -1921,19 +1973,14 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
         copy(e->stage_off[EFTB_B_GROWS], n_rows, 64, cs);
         HIPCHK(hipEventRecord(e->evStaged[t], cs));  // (= "all of it": evStagedAll is only recorded for latency-mode sets)
     }
-    e->staged_B = B;
     return 0;
 }
 
-int eftb_run_staged(eftb_engine* e, int mask, int B) {
-    if (!e) return fail("eftb_run_staged: null engine");
-    if (!e->cpy || e->staged_B == 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
-    if (B != e->staged_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->staged_B);
-    HIPCHK(hipSetDevice(e->c.device));
+// the staged set becomes current and the step is launched (either thread)
+static int run_staged_issue(eftb_engine* e, int mask, int B) {
     e->cur_set = (e->cur_set + 1) % eftb_engine::NSETS;
     for (int id : kStagedIds)
         if (e->setbuf[e->cur_set][id]) e->buf[id] = e->setbuf[e->cur_set][id];
-    e->staged_B = 0;
     e->status_slot = e->cur_set;  // this step's kernels raise this set's flags (cleared here: whatever an abandoned step left is void)
     e->status[2 * e->cur_set] = e->status[2 * e->cur_set + 1] = 0;
     ++e->epoch;  // (captured graphs hold the other set's pointers)
@@ -1958,7 +2005,6 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     e->buf[EFTB_B_PIN] = pin_dev;
     e->status_slot = eftb_engine::NSETS;
     if (rc) return rc;
-    ++e->staged_launched;
     hipStream_t last = e->back_pending ? e->back : e->stream;  // the step ends where its back half ran
     if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAll[e->cur_set], 0));  // (the set is not "done" before its own upload is)
     if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
@@ -1969,16 +2015,180 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     return 0;
 }
 
+static inline void cpu_pause() { __builtin_ia32_pause(); }
+
+// ---- submission thread (see eftb_engine::SubCmd)
+static void sub_main(eftb_engine* e) {
+    (void)hipSetDevice(e->c.device);
+    unsigned long long head = e->sub_head.load(std::memory_order_relaxed);
+    for (;;) {
+        // wait for a command: spin for a while (a pipelined loop delivers one every ~0.1 ms), then sleep
+        unsigned spins = 0;
+        while (e->sub_tail.load(std::memory_order_acquire) == head) {
+            if (e->sub_stop.load(std::memory_order_acquire)) return;
+            if (++spins < 200000) { cpu_pause(); continue; }   // ~ a few ms
+            std::unique_lock<std::mutex> lk(e->sub_mx);
+            e->sub_sleeping.store(true, std::memory_order_seq_cst);
+            e->sub_cv.wait(lk, [&] { return e->sub_tail.load(std::memory_order_acquire) != head || e->sub_stop.load(std::memory_order_acquire); });
+            e->sub_sleeping.store(false, std::memory_order_seq_cst);
+            spins = 0;
+        }
+        const eftb_engine::SubCmd c = e->sub_ring[head % eftb_engine::SUBQ];
+        e->set_latency[c.set] = false;   // a queued step has company on the GPU: three-stream layout
+        int rc = stage_issue(e, c.set, c.B, c.has_rows != 0, false);
+        if (!rc) {
+            e->cur_set = (c.set + eftb_engine::NSETS - 1) % eftb_engine::NSETS;   // (= what it is anyway, unless an earlier launch failed half way)
+            rc = run_staged_issue(e, c.mask, c.B);
+        }
+        e->cur_set = c.set;
+        const int r = (int)(c.step % eftb_engine::SUBREC);
+        e->sub_rc[r] = rc;
+        if (rc) snprintf(e->sub_err[r], sizeof e->sub_err[r], "%s", g_err.c_str());
+        ++head;
+        e->steps_launched.store(c.step + 1, std::memory_order_release);
+        e->sub_head.store(head, std::memory_order_release);
+    }
+}
+
+// nothing queued and the submission thread between commands: the engine's state belongs to the caller's thread
+static inline bool sub_quiescent(const eftb_engine* e) {
+    return e->sub_head.load(std::memory_order_acquire) == e->sub_tail.load(std::memory_order_relaxed);
+}
+
+static inline void sub_drain(eftb_engine* e) {
+    if (!e->sub_started) return;
+    while (!sub_quiescent(e)) cpu_pause();
+}
+
+static void sub_stop_thread(eftb_engine* e) {
+    if (!e->sub_started) return;
+    sub_drain(e);
+    {
+        std::lock_guard<std::mutex> lk(e->sub_mx);
+        e->sub_stop.store(true, std::memory_order_release);
+    }
+    e->sub_cv.notify_all();
+    if (e->sub_thread.joinable()) e->sub_thread.join();
+    e->sub_started = false;
+}
+
+// waits until the launch of staged step `step` has been issued, and reports its launch error (if any) as this call's
+static int sub_wait_launched(eftb_engine* e, unsigned long long step, const char* who) {
+    static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
+    if (e->steps_launched.load(std::memory_order_acquire) <= step) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; e->steps_launched.load(std::memory_order_acquire) <= step; ++spins) {
+            cpu_pause();
+            if ((spins & 0xffff) == 0xffff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+                return fail("%s: the submission thread did not issue the step within %.0f s (EFTB_FETCH_TIMEOUT_S)", who, limit_s);
+        }
+    }
+    const int r = (int)(step % eftb_engine::SUBREC);
+    if (e->sub_rc[r]) return fail("%s: the launch of this step failed: %s", who, e->sub_err[r]);
+    return 0;
+}
+
+int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
+                      const double* rows) {
+    if (!e || !Pin || !f) return fail("eftb_stage_inputs: null argument");
+    if (!e->finalized) return fail("eftb_stage_inputs: engine not finalized");
+    const eftb_config& c = e->c;
+    if (B < 1 || B > c.max_batch) return fail("eftb_stage_inputs: batch %d outside [1, %d]", B, c.max_batch);
+    if (c.with_ap && (!DA || !H)) return fail("eftb_stage_inputs: DA and H are required when with_ap=1");
+    if (rows && !e->like_ndata) return fail("eftb_stage_inputs: rows need eftb_set_likelihood");
+    if (int rc = validate_inputs(c, "eftb_stage_inputs", B, Pin, f, DA, H)) return rc;
+    if (!e->cpy) {
+        sub_drain(e);
+        if (int rc = staged_setup(e)) return rc;
+        e->p_set = e->cur_set;
+    }
+    HIPCHK(hipSetDevice(c.device));
+    const int t = (e->p_set + 1) % eftb_engine::NSETS;  // the set after the current one: the oldest, fetched (or abandoned) by now
+    // the step that used this set last has been issued (its events exist) ...
+    if (e->set_step[t])
+        if (int rc = sub_wait_launched(e, e->set_step[t] - 1, "eftb_stage_inputs")) (void)rc;  // (a failed launch left nothing to wait for; its fetch reports it)
+    HIPCHK(hipEventSynchronize(e->set_latency[t] ? e->evStagedAll[t] : e->evStaged[t]));  // ... and its staging block is free again (the previous upload from it has finished)
+    // (a latency-mode step's first kernel read P_lin from the staging block itself: that step must be over too -- it almost always is)
+    if (e->set_latency[t])
+        if (int rc = spin_event(e->evSetDone[t], "eftb_stage_inputs", "the latency-mode step that read this staging block")) return rc;
+    // Who issues the step?  With earlier steps still queued or in flight, the submission thread (this call only fills the staging block).  With
+    // the engine quiescent and the GPU idle -- a sampler whose next step depends on this step's result -- this thread, at once, as a latency-mode
+    // step if that is enabled (see latency_auto)
+    const bool quiet = sub_quiescent(e);
+    const bool gpu_idle = quiet && hipEventQuery(e->evSetDone[e->cur_set]) == hipSuccess;
+    if (e->sub_mode == 2 || (e->sub_mode == 1 && !gpu_idle)) {
+        stage_fill(e, t, B, Pin, f, DA, H, bias, rows);
+        e->dfr_set = t; e->dfr_B = B; e->dfr_rows = rows ? 1 : 0;
+        e->staged_B = B;
+        return 0;
+    }
+    sub_drain(e);
+    // nothing in flight (the step launched last has finished, or none was launched): the step staged here has the GPU to itself -- see latency_auto
+    const bool lat = e->latency_auto && e->staged_B == 0 && e->stage_off[EFTB_B_PIN] == 0 && gpu_idle;
+    e->set_latency[t] = lat;
+    if (lat) hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, e->stream);  // (see wake_kernel: its start-up runs under the host copies below)
+    stage_fill(e, t, B, Pin, f, DA, H, bias, rows);
+    if (int rc = stage_issue(e, t, B, rows != nullptr, lat)) return rc;
+    e->dfr_set = -1;
+    e->staged_B = B;
+    return 0;
+}
+
+int eftb_run_staged(eftb_engine* e, int mask, int B) {
+    if (!e) return fail("eftb_run_staged: null engine");
+    if (!e->cpy || e->staged_B == 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
+    if (B != e->staged_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->staged_B);
+    HIPCHK(hipSetDevice(e->c.device));
+    e->staged_B = 0;
+    const unsigned long long step = e->steps_submitted;
+    if (e->dfr_set >= 0) {  // queued: the submission thread uploads the staging block and launches the step
+        if (!e->sub_started) {
+            e->sub_stop.store(false);
+            e->sub_thread = std::thread(sub_main, e);
+            e->sub_started = true;
+        }
+        // (never more than NSETS - 1 pending: each owns a set, and eftb_stage_inputs has waited for the set's previous user)
+        const unsigned long long tail = e->sub_tail.load(std::memory_order_relaxed);
+        e->sub_ring[tail % eftb_engine::SUBQ] = eftb_engine::SubCmd{e->dfr_set, mask, B, e->dfr_rows, step};
+        e->sub_tail.store(tail + 1, std::memory_order_release);
+        if (e->sub_sleeping.load(std::memory_order_seq_cst)) {
+            std::lock_guard<std::mutex> lk(e->sub_mx);
+            e->sub_cv.notify_one();
+        }
+        e->p_set = e->dfr_set;
+        e->set_step[e->p_set] = step + 1;
+        e->dfr_set = -1;
+        ++e->steps_submitted;
+        return 0;
+    }
+    sub_drain(e);
+    const int rc = run_staged_issue(e, mask, B);
+    e->p_set = e->cur_set;
+    if (rc) return rc;
+    e->sub_rc[step % eftb_engine::SUBREC] = 0;
+    e->set_step[e->p_set] = step + 1;
+    ++e->steps_submitted;
+    e->steps_launched.store(step + 1, std::memory_order_release);
+    return 0;
+}
+
+// set and step of the staged step `back` steps before the one submitted last, once its launch has been issued
+static int staged_step(eftb_engine* e, const char* who, int back, int* set) {
+    if (back < 0 || back >= eftb_engine::NSETS) return fail("%s: back must be 0 (the step launched last) ... 7 (that many steps before it)", who);
+    if (!e->cpy) return fail("%s: no staged run yet", who);
+    if ((unsigned long long)back >= e->steps_submitted)
+        return fail("%s: back = %d, but only %llu staged step(s) have been launched", who, back, e->steps_submitted);
+    *set = (e->p_set + eftb_engine::NSETS - back) % eftb_engine::NSETS;  // back = 7 is the set that the next eftb_stage_inputs refills
+    return sub_wait_launched(e, e->steps_submitted - 1 - back, who);
+}
+
 int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_back: null argument");
-    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_back: back must be 0 (the step launched last) ... 7 (that many steps before it)");
     if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_back: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
-    if (!e->cpy) return fail("eftb_fetch_back: no staged run yet");
     if (count > e->buf_elems[id]) return fail("eftb_fetch_back: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
+    int t = 0;
+    if (int rc = staged_step(e, "eftb_fetch_back", back, &t)) return rc;
     HIPCHK(hipSetDevice(e->c.device));
-    if ((unsigned long long)back >= e->staged_launched)
-        return fail("eftb_fetch_back: back = %d, but only %llu staged step(s) have been launched", back, e->staged_launched);
-    const int t = (e->cur_set + eftb_engine::NSETS - back) % eftb_engine::NSETS;  // back = 3 is the set that the next eftb_stage_inputs refills
     if (int rc = spin_event(e->evSetDone[t], "eftb_fetch_back", "the step")) return rc;
     if (id == EFTB_B_PLK && e->plk_host[t])
         memcpy(host, e->plk_host[t], count * sizeof(double));  // copied out by the DMA engine behind the step
@@ -1993,19 +2203,25 @@ int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) { re
 
 int eftb_fetch_view(eftb_engine* e, int back, int id, const double** block, size_t* count) {
     if (!e || !block) return fail("eftb_fetch_view: null argument");
-    if (back < 0 || back >= eftb_engine::NSETS) return fail("eftb_fetch_view: back must be 0 (the step launched last) ... 7 (that many steps before it)");
     if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_view: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
-    if (!e->cpy) return fail("eftb_fetch_view: no staged run yet");
-    if ((unsigned long long)back >= e->staged_launched)
-        return fail("eftb_fetch_view: back = %d, but only %llu staged step(s) have been launched", back, e->staged_launched);
+    int t = 0;
+    if (int rc = staged_step(e, "eftb_fetch_view", back, &t)) return rc;
     HIPCHK(hipSetDevice(e->c.device));
-    const int t = (e->cur_set + eftb_engine::NSETS - back) % eftb_engine::NSETS;
     const double* p = id == EFTB_B_PLK ? (e->plk_host[t] ? e->plk_host[t] : (e->staged_plk_device ? nullptr : e->setbuf[t][id])) : e->setbuf[t][id];
     if (!p) return fail("eftb_fetch_view: P_l of this engine stays in device memory for the RCCL exchange (eftb_gathered_view hands out the gathered block)");
     if (int rc = spin_event(e->evSetDone[t], "eftb_fetch_view", "the step")) return rc;
     *block = p;
     if (count) *count = e->buf_elems[id];
     return check_status(e, "eftb_fetch_view", t);
+}
+
+int eftb_step(eftb_engine* e, int mask, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
+              const double* rows, int back, int id, const double** block, size_t* count) {
+    if (int rc = eftb_stage_inputs(e, B, Pin, f, DA, H, bias, rows)) return rc;
+    if (int rc = eftb_run_staged(e, mask, B)) return rc;
+    if (block) *block = nullptr;
+    if (back < 0 || !block || (unsigned long long)back >= e->steps_submitted) return 0;  // (the pipeline is still filling: nothing to hand out yet)
+    return eftb_fetch_view(e, back, id, block, count);
 }
 
 int eftb_comm_unique_id(char id[128]) {
@@ -2019,6 +2235,7 @@ int eftb_comm_unique_id(char id[128]) {
 }
 
 int eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]) {
+    if (e) sub_drain(e);
     if (!e || !id) return fail("eftb_comm_init: null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("eftb_comm_init: bad rank %d of %d", rank, nranks);
     if (e->cpy) return fail("eftb_comm_init: call it before the first eftb_stage_inputs (the staged sets place P_l where the exchange can read it)");
@@ -2033,6 +2250,7 @@ int eftb_comm_init(eftb_engine* e, int nranks, int rank, const char id[128]) {
 }
 
 int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
+    if (e) sub_drain(e);
     if (!e) return fail("eftb_gather_plk: null engine");
     if (B < 1 || B > e->c.max_batch) return fail("eftb_gather_plk: batch %d outside [1, %d]", B, e->c.max_batch);
     if (root < 0 || root >= e->nranks) return fail("eftb_gather_plk: bad root %d", root);

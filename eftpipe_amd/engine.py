@@ -32,6 +32,9 @@ class Engine:
         self._pipeline_op = -1
         self.ntracers = 1
         self._tracer_ops = []
+        self._latency_mode = os.environ.get("EFTB_LATENCY_MODE", "1") != "0"  # the library's default (eftb_set_option(EFTB_O_LATENCY_MODE))
+        self._plk_direct = False
+        self._step_ptr, self._step_n, self._views = C.c_void_p(), C.c_size_t(), {}
         c = L.Config()
         c.device, c.Nl, c.Nk, c.Nkin, c.max_batch = device, cfg.Nl, self.Nk, self.Nkin, self.max_batch
         c.with_resum, c.with_ap, c.ap_stochastic = int(cfg.with_resum), int(cfg.with_ap), int(cfg.APst)
@@ -166,12 +169,20 @@ class Engine:
         """True (default): a step staged while the GPU is idle runs in latency mode (one queue, zero-copy P_lin, P_l written to mapped host memory) --
         for samplers whose next step depends on this one.  False: always the three-stream layout (loops that keep several steps queued)."""
         L.check(self.lib.eftb_set_option(self._h, 5, int(bool(flag))))
+        self._latency_mode = bool(flag)
 
     def set_plk_direct(self, flag):
         """True: whole-pipeline runs that end in REDUCE (no PROJECT / LOGP; Nl = 3, fast AP path) take the bias contraction of reduce_Plk FIRST --
         it commutes with the resummation and with the AP stage -- so one row per multipole instead of 24 goes through them.  Same P_l(k)
         (summation order aside); the template block "TEMPL" does not hold the templates of such a run.  False (default): templates first."""
         L.check(self.lib.eftb_set_option(self._h, 6, int(bool(flag))))
+        self._plk_direct = bool(flag)
+
+    def set_submit_thread(self, flag):
+        """True (default): staged steps handed in while earlier ones are still queued or running are issued by the library's submission thread
+        (the sampler's thread only fills the staging block and queues the step).  False: the calling thread issues every launch itself.
+        2: every step is queued, also one that finds the GPU idle (tests)."""
+        L.check(self.lib.eftb_set_option(self._h, 8, int(flag)))
 
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
@@ -330,6 +341,35 @@ class Engine:
         if mask & L.S_PROJECT:
             self.dims = self.out_dims()
 
+    def step(self, mask, Pin, f, DA=None, H=None, bias=None, rows=None, back=-1, fetch="PLK", shape=None):
+        """One sampler step in one library call (``eftb_step``): stage these inputs, launch the step, and -- with back >= 0 -- hand out a read-only
+        view of the PLK / LOGP block of the step `back` steps before this one (None while fewer than back + 1 steps are behind it).  Arrays that
+        already are C-contiguous float64 of the right shape are passed as they are."""
+        B, Pin, f, DA, H = self._inputs(Pin, f, DA, H)
+        if bias is not None and not (type(bias) is np.ndarray and bias.dtype == np.float64 and bias.flags["C_CONTIGUOUS"]):
+            bias = np.ascontiguousarray(bias, dtype=np.float64)
+        if rows is not None and not (type(rows) is np.ndarray and rows.dtype == np.float64 and rows.flags["C_CONTIGUOUS"]):
+            rows = np.ascontiguousarray(rows, dtype=np.float64)
+        ptr, n = self._step_ptr, self._step_n
+        L.check(self.lib.eftb_step(self._h, mask, B, L.vptr(Pin), L.vptr(f), L.vptr(DA), L.vptr(H), L.vptr(bias), L.vptr(rows), int(back), L.B[fetch],
+                                   C.byref(ptr), C.byref(n)))
+        if mask & L.S_REGROUP:
+            self.dims = (self.Nl, self.Nk)
+        if mask & L.S_PROJECT:
+            self.dims = self.out_dims()
+        if back < 0 or not ptr.value:
+            return None
+        key = (ptr.value, shape)
+        view = self._views.get(key)   # (the engine rotates a handful of page-locked blocks: the ndarray wrappers are made once)
+        if view is None:
+            size = int(np.prod(shape))
+            if n.value < size:
+                raise L.EftbError(f"step: the block holds {n.value} elements, asked {size}")
+            view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(size,)).reshape(shape)
+            view.flags.writeable = False
+            self._views[key] = view
+        return view
+
     def fetch_previous(self, name, shape, out=None, back=1, copy=True):
         """PLK / LOGP of the step launched `back` (0: the last one; 1 ... 7) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
         to fill).  back=3 keeps three steps queued while the host works (see ``pipeline``).  copy=False: a read-only view of the engine's page-locked
@@ -348,25 +388,35 @@ class Engine:
         L.check(self.lib.eftb_fetch_back(self._h, int(back), L.B[name], L.dptr(out), out.size))
         return out
 
-    def pipeline(self, steps, mask=None, fetch="PLK"):
+    def pipeline(self, steps, mask=None, fetch="PLK", depth=None):
         """Generator over a stream of steps (dicts with Pin, f, DA, H and bias and/or rows): stages step i + 1 and launches it
         before fetching the results of step i, so the GPU never waits for the host.  Yields one result per step, in order:
-        P_l [B, nl, nx] (fetch="PLK", needs bias) or the raw LOGP block [walkers, 26] (fetch="LOGP", needs rows + a likelihood)."""
+        P_l [B, nl, nx] (fetch="PLK", needs bias) or the raw LOGP block [walkers, 26] (fetch="LOGP", needs rows + a likelihood).
+        depth: steps kept queued on the GPU while the oldest one is copied out (1 ... 7; default 3, 4 for direct-P_l runs, whose
+        steps are four pipeline stages deep)."""
         if mask is None:
             mask = self.full_mask(reduce=(fetch == "PLK")) | (L.S_LOGP if fetch == "LOGP" else 0)
+        if depth is None:
+            depth = 4 if self._plk_direct else 3
+        if not 1 <= int(depth) <= 7:
+            raise ValueError("depth must be 1 ... 7 (the engine rotates eight sets of per-step inputs / outputs)")
+        depth = int(depth)
         nl, nx = self.out_dims()
         shape_of = lambda B: (B, nl, nx) if fetch == "PLK" else (B // self.ntracers, 2 + 24)
-        queued = []  # batch sizes of the steps launched and not yet fetched (at most three)
+        queued = []  # batch sizes of the steps launched and not yet fetched (at most `depth`)
+        latency_before = self._latency_mode
         self.set_latency_mode(False)  # several steps stay queued: the first one must not take the single-queue form
-        for st in steps:
-            B = self.stage_inputs(st["Pin"], st["f"], st.get("DA"), st.get("H"), bias=st.get("bias"), rows=st.get("rows"))
-            self.run_staged(mask, B)
-            queued.append(B)
-            if len(queued) == 4:  # three steps stay queued on the GPU while the oldest one is copied out
-                yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=3)
-        while queued:  # drain: back = 0 is the step launched last
-            yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=len(queued))
-        self.set_latency_mode(True)
+        try:
+            for st in steps:
+                B = self.stage_inputs(st["Pin"], st["f"], st.get("DA"), st.get("H"), bias=st.get("bias"), rows=st.get("rows"))
+                self.run_staged(mask, B)
+                queued.append(B)
+                if len(queued) == depth + 1:  # `depth` steps stay queued on the GPU while the oldest one is copied out
+                    yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=depth)
+            while queued:  # drain: back = 0 is the step launched last
+                yield self.fetch_previous(fetch, shape_of(queued.pop(0)), back=len(queued))
+        finally:  # (also when the consumer abandons the generator or a step raises: the caller's setting comes back)
+            self.set_latency_mode(latency_before)
 
     def pinned_empty(self, shape):
         """Page-locked float64 host array for eval_batch(out=...) / put / get."""

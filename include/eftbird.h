@@ -151,9 +151,18 @@ enum eftb_option {
                                  bias contraction of reduce_Plk (parambasis.py:42-136) FIRST -- it commutes with Resum.Ps and APeffect.AP, linear maps
                                  that act on every template row alike (pybird.py:1413-1464, 1581-1621) -- so one row per multipole instead of 24
                                  goes through them: same P_l(k) (summation order aside), but EFTB_B_TEMPL does not hold the templates of such a
-                                 run.  0 (default): templates first, as the reference computes them (BirdSnapshot semantics) */
-    EFTB_O_TIME_KERNEL = 7    /* which launches EFTB_O_TIME_DOMINANT brackets, a set of: 1 (default) the resummation kernel, 2 the synthesis launch of
+                                 run, and the stage taps EFTB_B_P13 / C11 / CCT (and the synthesised basis rows behind P22 / CC) hold rows already
+                                 CONTRACTED with the bias.  Only a run whose mask holds PREP, LOOPS, CF, REGROUP, RESUM, AP and REDUCE together is
+                                 taken this way: a sequence split into several eftb_run calls always takes the template path.
+                                 0 (default): templates first, as the reference computes them (BirdSnapshot semantics) */
+    EFTB_O_TIME_KERNEL = 7,   /* which launches EFTB_O_TIME_DOMINANT brackets, a set of: 1 (default) the resummation kernel, 2 the synthesis launch of
                                  the loop stages (synth_kernel), 4 the heaviest AP kernel (ap_weights_kernel; direct-P_l runs: ap_plk_kernel) -- measurement only */
+    EFTB_O_SUBMIT_THREAD = 8  /* 1 (default; also EFTB_SUBMIT_THREAD=0/1): staged steps handed in while earlier ones are still queued or running are
+                                 issued by a submission thread inside the library -- eftb_stage_inputs fills the page-locked block, eftb_run_staged
+                                 queues the step and returns; the thread uploads the block and launches the kernels (50-95 us of HIP calls per step
+                                 that the sampler's thread no longer pays).  A step staged while the engine is quiescent and the GPU idle is issued by
+                                 the caller as before.  Same bits either way.  0: the caller's thread issues every step; 2: every step is queued, whatever the
+                                 GPU is doing (tests).  No reference counterpart. */
 };
 int  eftb_set_option(eftb_engine* e, int option, int value);
 /* Sum of the event-bracketed durations [ms] and number of resummation launches since the last reset (EFTB_O_TIME_DOMINANT); waits for
@@ -261,6 +270,11 @@ int  eftb_fetch_back(eftb_engine* e, int back, int buffer_id, double* host, size
  * (*count = its capacity in elements), valid until NSETS - 1 = 7 more steps have been staged.  For samplers that consume P_l in place (the
  * dependent loop of reference likelihood.py:570-594: chi^2 from P_l, then the next proposal). */
 int  eftb_fetch_view(eftb_engine* e, int back, int buffer_id, const double** block, size_t* count);
+/* One sampler step in one call: eftb_stage_inputs + eftb_run_staged + (back >= 0 and that many steps already behind this one)
+ * eftb_fetch_view(back, buffer_id).  *block stays NULL while the pipeline is still filling.  Replaces, per step of a batched sampler, what
+ * EFTLeafKernel.calculate_power_spectrum + reduce_Plk do per point (theory.py:557-609, parambasis.py:42-136). */
+int  eftb_step(eftb_engine* e, int stage_mask, int B, const double* Pin, const double* f, const double* DA, const double* H,
+               const double* bias, const double* rows, int back, int buffer_id, const double** block, size_t* count);
 
 /* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
  * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */

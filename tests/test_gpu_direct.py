@@ -144,3 +144,163 @@ def test_direct_option_leaves_other_runs_alone():
     b = _plk(eng2, d2, B, True)
     assert np.array_equal(a, b)
     eng2.close()
+
+
+def test_direct_plk_against_the_reference_golden_file(golden):
+    """Direct runs against REFERENCE outputs: caseD.npz is the cfg-2 shape (Nl = 3, Nk = 512, resum + AP) pushed through the real reference by
+    tools/make_fixtures.py; `plk_auto` / `plk_cross` are its reduce_Plk (parambasis.py:42-136) of the AP-stage templates for an auto spectrum
+    and for an A x B contraction with the second tracer's own km / kr / nd."""
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.parambasis import bias_row
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseD")
+    Nl, Nk, z = int(g["Nl"]), g["k"].size, float(g["z"])
+    f, DA, H = float(g["f"]), float(g["DA"]), float(g["H"])
+    cfg = EngineConfig(Nl=Nl, k=g["k"], with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, z)), H_AP=float(synth.hubble(synth.OM_AP, z)))
+    eng = Engine(cfg, max_batch=2)
+    bsA, bsB, es = list(g["bsA"]), list(g["bsB"]), tuple(g["es"])
+    bias = np.stack([bias_row(f, bsA, None, es, kmA=0.7, krA=0.25, ndA=4.5e-5),
+                     bias_row(f, bsA, bsB, es, kmA=0.7, krA=0.25, ndA=4.5e-5, kmB=0.6, krB=0.3, ndB=2.3e-4)])
+    Pin = np.stack([g["Pin"], g["Pin"]])
+    out = {}
+    for direct in (False, True):
+        eng.set_plk_direct(direct)
+        eng.load_inputs(Pin, f, DA, H, bias)
+        eng.run(eng.full_mask(reduce=True), 2, sync=True)
+        out[direct] = eng.get("PLK", (2, Nl, Nk)).copy()
+    assert not np.array_equal(out[True], out[False])  # the option took effect
+    for direct in (False, True):
+        for i, name in enumerate(("plk_auto", "plk_cross")):
+            want = g[name]
+            assert relerr(out[direct][i], want) < TOL, (direct, name)
+            big = np.abs(want) > 1e-3 * np.abs(want).max(axis=-1, keepdims=True)
+            assert np.max(np.abs(out[direct][i] - want)[big] / np.abs(want)[big]) < 1e-6, (direct, name)
+    eng.close()
+
+
+def test_direct_option_with_split_stage_masks():
+    """The option on, the pipeline split over several eftb_run calls (the stage-wise use of the drop-in classes): the front of the first call is
+    not a direct run's front (un-contracted rows), so the second call must take the template path -- same bits as with the option off."""
+    import bench
+    from eftpipe_amd import _lib as L
+
+    B = 4
+    eng, _ = _engine(B)
+    d = _draws(B, 91)
+    want = _plk(eng, d, B, False)
+    whole = _plk(eng, d, B, True)
+    eng.set_plk_direct(True)
+    for first, second in ((L.S_PREP | L.S_LOOPS | L.S_CF, L.S_REGROUP | L.S_RESUM | L.S_AP | L.S_REDUCE),
+                          (L.S_PREP, L.S_LOOPS | L.S_CF | L.S_REGROUP | L.S_RESUM | L.S_AP | L.S_REDUCE),
+                          (L.S_PREP | L.S_LOOPS, L.S_CF | L.S_REGROUP | L.S_RESUM | L.S_AP | L.S_REDUCE)):
+        eng.load_inputs(d["Pin"], d["f"], d["DA"], d["H"], d["bias"])
+        eng.run(first, B, sync=True)
+        eng.run(second, B, sync=True)
+        assert np.array_equal(eng.get("PLK", (B, 3, bench.NK)), want), (first, second)
+    # and a whole-pipeline run right behind the split ones is a direct run again
+    eng.run(eng.full_mask(reduce=True), B, sync=True)
+    assert np.array_equal(eng.get("PLK", (B, 3, bench.NK)), whole)
+    eng.close()
+
+
+def test_many_exchanges_then_fetch():
+    """More exchanges than the engine has rotating sets (the per-exchange bookkeeping was sized for four), then the per-step fetches:
+    the launch counter and the CHECK_FINITE option must be what they were, and every gathered block must carry its own step."""
+    import bench
+
+    B, K = 8, 19
+    eng, _ = _engine(B)
+    eng.set_check_finite(True)
+    eng.set_latency_mode(False)
+    sets = [_draws(B, 900 + i) for i in range(3)]
+    ref = [_plk(eng, s, B, False) for s in sets]
+    mask = eng.full_mask(reduce=True)
+    shape = (B, bench.NL, bench.NK)
+    for i in range(K):
+        s = sets[i % 3]
+        eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
+        eng.run_staged(mask, B)
+        eng.gather_plk(B, root=0)
+        if i >= 2:
+            assert np.array_equal(eng.fetch_gathered(B, back=2)[0], ref[(i - 2) % 3]), i
+    eng.sync()
+    for back in range(0, 8):
+        assert np.array_equal(eng.fetch_previous("PLK", shape, back=back), ref[(K - 1 - back) % 3]), back
+        assert np.array_equal(eng.fetch_previous("PLK", shape, back=back, copy=False), ref[(K - 1 - back) % 3]), back
+        assert np.array_equal(eng.fetch_gathered(B, back=back)[0], ref[(K - 1 - back) % 3]), back
+    # CHECK_FINITE is still on: a NaN bias row is reported by the fetch of its own step
+    s = dict(sets[0])
+    bad = s["bias"].copy()
+    bad[3, 0] = np.nan
+    eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=bad)
+    eng.run_staged(mask, B)
+    with pytest.raises(Exception, match="non-finite P_l"):
+        eng.fetch_previous("PLK", shape, back=0)
+    eng.close()
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_submission_thread_returns_the_bits_of_the_callers_thread(direct):
+    """Staged steps issued by the library's submission thread (EFTB_O_SUBMIT_THREAD, the default: every step handed in while earlier ones are in
+    flight) against the same loop with every launch issued by the calling thread, and against synchronous runs; through eftb_step (one call per
+    step) and through the three-call form."""
+    import bench
+
+    B, K, depth = 32, 23, 4
+    eng, _ = _engine(B)
+    sets = [_draws(B, 700 + i) for i in range(4)]
+    ref = [_plk(eng, s, B, direct) for s in sets]
+    eng.set_plk_direct(direct)
+    eng.set_latency_mode(False)
+    mask = eng.full_mask(reduce=True)
+    shape = (B, bench.NL, bench.NK)
+    for thread in (True, False, 2, True):
+        eng.set_submit_thread(thread)
+        got = []
+        for i in range(K):
+            s = sets[i % 4]
+            if i % 2:  # one call per step ...
+                view = eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], back=depth, shape=shape)
+            else:      # ... or three
+                eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
+                eng.run_staged(mask, B)
+                view = eng.fetch_previous("PLK", shape, back=depth, copy=False) if i >= depth else None
+            assert (view is None) == (i < depth)
+            if view is not None:
+                got.append(view.copy())
+        for back in range(depth - 1, -1, -1):
+            got.append(eng.fetch_previous("PLK", shape, back=back))
+        eng.sync()
+        for i in range(K):
+            assert np.array_equal(got[i], ref[i % 4]), (thread, i)
+        # stage-wise calls right behind queued steps wait for the queue to drain
+        assert np.array_equal(_plk(eng, sets[1], B, direct), ref[1])
+        eng.set_plk_direct(direct)
+    eng.close()
+
+
+def test_submission_thread_reports_a_failed_launch_with_its_step():
+    """A step whose launch fails on the submission thread (here: a stage mask the configuration cannot run) is reported by the fetch of THAT step;
+    the steps around it are not affected."""
+    import bench
+    from eftpipe_amd import _lib as L
+
+    B = 8
+    eng, _ = _engine(B)
+    eng.set_latency_mode(False)
+    eng.set_submit_thread(2)   # every step through the queue, whatever the GPU is doing
+    s = _draws(B, 41)
+    ref = _plk(eng, s, B, False)
+    mask = eng.full_mask(reduce=True)
+    shape = (B, bench.NL, bench.NK)
+    for i in range(6):
+        eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
+        eng.run_staged(mask | (L.S_PROJECT if i == 3 else 0), B)   # no pipeline operator is set: step 3 cannot be launched
+    for back, ok in ((5, True), (4, True), (3, True), (2, False), (1, True), (0, True)):
+        if ok:
+            assert np.array_equal(eng.fetch_previous("PLK", shape, back=back), ref), back
+        else:
+            with pytest.raises(Exception, match="PROJECT needs"):
+                eng.fetch_previous("PLK", shape, back=back)
+    eng.close()

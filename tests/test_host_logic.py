@@ -1,4 +1,5 @@
 """Host logic on the CPU: Common mirror, bias vectors, wave plan, sharding, socket control plane."""
+import json
 import os
 import subprocess
 import sys
@@ -613,3 +614,21 @@ def test_cfg5_host_operators_nk2048(golden):
         for n in U.NAMES:
             want = g[f"{t}_{'chained' if chained else 'binned'}_{n}"]
             assert relerr(np.einsum("alxk,lnk->anx", op, F["ap_" + n]), want) < 1e-9, (t, n)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's recorded command shape): the script spawns two fresh rank
+    processes itself and they meet on the control plane (EFTB_BENCH_RENDEZVOUS_ONLY stops them there: this box has no GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["EFTB_BENCH_RENDEZVOUS_ONLY"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line == {"rendezvous": "ok", "world": 2, "highest_rank_seen": 1}
+    # a rank that fails makes the launcher fail
+    env["EFTB_BENCH_RENDEZVOUS_ONLY"] = ""
+    env["EFTB_LIB"] = "/nonexistent/libeftbird.so"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
