@@ -403,11 +403,13 @@ def main():
     eng.time_dominant(0 if os.environ.get("EFTB_BENCH_NO_EVENTS") else int(os.environ.get("EFTB_BENCH_EVENT_EVERY", "2")))
     for kind in range(3):
         eng.kernel_time(kind, reset=True)
+    eng.submit_stats(enable=True, reset=True)   # host clocks of the staged steps (two steady_clock reads per call: ~50 ns)
     cp.barrier()
     t0 = time.perf_counter()
     loop(W, K, keep=True)
     cp.barrier()
     elapsed = cp.max(time.perf_counter() - t0)
+    host_stats = eng.submit_stats(enable=False, reset=True)
     if STEP_TIMES:
         print("[bench] fetch-complete times since t0 (ms):", " ".join(f"{(t - t0) * 1e3:.3f}" for t in STEP_TIMES), file=sys.stderr)
     ktimes = [eng.kernel_time(kind, reset=True) for kind in range(3)]  # (resummation, synthesis, AP knot weights): (ms, launches) inside the timed region
@@ -652,6 +654,7 @@ def main():
                        "parallelism": (f"batch-sharded x{world}, per-step gather of P_l to rank 0 via {exchange}, rank 0 receives every step's gathered block in page-locked host memory"
                                        if world > 1 or force_comm else "single GPU")},
             "valid": bool(valid), "timed_steps_checked_against_sync_path": steps_checked,
+            "host_us_per_step": host_stats,
             "warmup_steps_run": warm_steps,
             "warmup_note": f"{W} untimed pipelined steps as asked, then the same untimed loop repeated until {warm_ms:.0f} ms had passed ({warm_steps} steps in all): "
                            "the timed region (a few ms) otherwise runs at the clocks of a GPU that has just left idle; EFTB_BENCH_PREWARM_MS=0 switches the extension off",

@@ -2588,6 +2588,133 @@ __global__ __launch_bounds__(256) void ap_plk_kernel(int Nk, int nmu, const doub
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// AP of direct-P_l runs, moment form (round 4; ap_plk_kernel above is kept for A/B runs, EFTB_AP_PLK_NODES=1).  The node quadrature of one
+// contracted row costs ~50 instructions per (k, node) in dependent LDS chains and fills every SIMD with waiting waves for 40-60 us.  But P_l' is a
+// piecewise cubic, so the nmu-node sum over the nodes that fall into knot interval i is a combination of four interval moments,
+//     sum_{j in [ja, jb)} wl[l][j] lp[l'][j] P_l'(k'_j) = sum_p a_i[l'][p] M_i[l][l'][p],
+// and the moments are binomial combinations of the k-independent mu prefix sums of ap_prefix_kernel (header above it): per (k, interval
+// crossed) 36 prefix differences, 90 FMAs for the binomials, 36 for the contraction -- no node loop.  A k crosses 1 ... ~10 intervals at the
+// distortions a chain visits (cost grows with the distortion; any number is handled).  Same sum as the reference's quadrature
+// (pybird.py:1581-1621) in another order.
+// Workgroup = (64 k, cosmology) x 4 waves; wave <-> interval slot (s = wave, wave + 4, ...) exactly as in ap_moments_kernel; the pieces of
+// interval i come from the B-spline coefficients of spline_kernel (row 0 of each l' block) and the per-interval matrices
+// (tables.bspline_tables); the four partial sums meet in LDS in wave order; the epilogue adds the rows outside the stage (from direct0 on:
+// the stochastic templates) times their bias coefficients.
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(256) void ap_plk_mom_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+                                                         const double* __restrict__ Hw, const double* __restrict__ fid, const double* __restrict__ mu,
+                                                         const double* __restrict__ PS, const double* __restrict__ ROOT, const double* __restrict__ C,
+                                                         const double* __restrict__ LOCAL, const double* __restrict__ T, const double* __restrict__ bias,
+                                                         double* __restrict__ Plk, double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0) {
+    constexpr int NSQ = NL * NL * 4;
+    extern __shared__ double sm[];
+    double* s_k = sm;               // [Nk]
+    double* s_root = sm + Nk;       // [nmu]
+    double* red = sm + Nk + nmu;    // [3][NL][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int KT = (Nk + 63) / 64;
+    int kt, w;
+    xcd_decode(KT, kt, w);
+    const int k = kt * 64 + lane;
+    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
+    for (int e = threadIdx.x; e < nmu; e += 256) s_root[e] = ROOT[(size_t)w * nmu + e];
+    __syncthreads();
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
+    const bool live = k < Nk;
+    const double kq = s_k[live ? k : Nk - 1] / qperp;
+    const double inv_kq = 1.0 / kq, inv_g = 1.0 / g;
+    const double* ps = PS + (size_t)w * (nmu + 1) * NSQ;
+    const double* cw = C + (size_t)w * NL * NROW * Nk;  // row 0 of every l' block
+    const bool up = g > 0.0;  // k'(mu) rises or falls with mu
+    const int dir = up ? 1 : -1;
+    const double jscale = (nmu - 1) / mu[nmu - 1];  // node index per unit mu (uniform grid: only a first guess, see the fix-up)
+    double acc[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+    // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling)
+    auto cross = [&](double kb) -> int {
+        const double rc = kb * inv_kq, x = (rc * rc - 1.0) * inv_g;  // mu^2 at the crossing (a seed: the fix-up below decides)
+        int j = nmu;
+        if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
+        j = max(0, min(j, nmu));
+        while (j > 0 && (up ? kq * s_root[j - 1] >= kb : kq * s_root[j - 1] < kb)) --j;
+        while (j < nmu && !(up ? kq * s_root[j] >= kb : kq * s_root[j] < kb)) ++j;
+        return j;
+    };
+    const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
+    const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
+    const int nslot = live ? (up ? i_last - i_first : i_first - i_last) + 1 : 0;
+    for (int s = wave; s < nslot; s += 4) {
+        const int i = i_first + s * dir;
+        const double klo = s_k[i], khi = s_k[i + 1];
+        const int ja = s == 0 ? 0 : cross(up ? klo : khi);
+        const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
+        if (jb <= ja) continue;
+        // everything this slot reads is requested before anything is used: prefix sums at both ends, the interval's matrices, the coefficients
+        const double* pa = ps + (size_t)ja * NSQ;
+        const double* pb = ps + (size_t)jb * NSQ;
+        double4 a4[NL][NL], b4[NL][NL];
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                b4[lp][l] = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
+                a4[lp][l] = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
+            }
+        const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+        const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
+        const int J = bspl_first(i, Nk);
+        double cc[NL][4];
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            const double* cp = cw + (size_t)lp * NROW * Nk + J;
+            cc[lp][0] = cp[0]; cc[lp][1] = cp[1]; cc[lp][2] = cp[2]; cc[lp][3] = cp[3];
+        }
+        const double dl = kq - klo, dl2 = dl * dl, a2 = kq * kq;
+        const double c10 = dl, c11 = kq, c20 = dl2, c21 = 2.0 * kq * dl, c22 = a2;
+        const double c30 = dl2 * dl, c31 = 3.0 * kq * dl2, c32 = 3.0 * a2 * dl, c33 = a2 * kq;
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            // power form of P_l' on [k_i, k_i+1] in t = k' - k_i
+            const double p0 = fma(e0.x, cc[lp][0], fma(e1.x, cc[lp][1], fma(e2.x, cc[lp][2], e3.x * cc[lp][3])));
+            const double p1 = fma(e0.y, cc[lp][0], fma(e1.y, cc[lp][1], fma(e2.y, cc[lp][2], e3.y * cc[lp][3])));
+            const double p2 = fma(e0.z, cc[lp][0], fma(e1.z, cc[lp][1], fma(e2.z, cc[lp][2], e3.z * cc[lp][3])));
+            const double p3 = fma(e0.w, cc[lp][0], fma(e1.w, cc[lp][1], fma(e2.w, cc[lp][2], e3.w * cc[lp][3])));
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const double d0 = b4[lp][l].x - a4[lp][l].x, d1 = b4[lp][l].y - a4[lp][l].y;
+                const double d2 = b4[lp][l].z - a4[lp][l].z, d3 = b4[lp][l].w - a4[lp][l].w;
+                const double m1 = fma(c10, d0, c11 * d1);
+                const double m2 = fma(c20, d0, fma(c21, d1, c22 * d2));
+                const double m3 = fma(c30, d0, fma(c31, d1, fma(c32, d2, c33 * d3)));
+                acc[l] = fma(d0, p0, fma(m1, p1, fma(m2, p2, fma(m3, p3, acc[l]))));
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) red[((size_t)(wave - 1) * NL + l) * 64 + lane] = acc[l];
+    }
+    __syncthreads();
+    if (wave > 0 || !live) return;
+    const double cnorm = 2.0 / (qperp * qperp * qpar);
+    const double* bw = bias + (size_t)w * NROW;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        double a = acc[l];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a += red[((size_t)q * NL + l) * 64 + lane];
+        double tot = cnorm * a;
+        for (int r = direct0; r < NROW; ++r) tot = fma(bw[r], T[(((size_t)w * NL + l) * NROW + r) * Nk + k], tot);
+        Plk[((size_t)w * NL + l) * Nk + k] = tot;
+        if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = tot;  // latency mode: P_l lands in mapped host memory as it is formed
+        if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
+    }
+}
+
 // Staged inputs: page-locked host block -> device block, as a kernel on the copy stream (a DMA transfer brings cache maintenance on the
 // compute queue with it; this one is ordinary loads from mapped host memory and ordinary stores)
 __global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
@@ -2598,6 +2725,16 @@ __global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restric
 // kernel 44 us, the 205 KB one behind it 6 us) -- eftb_stage_inputs sends this ahead of its host-side work so that the step's first real kernel
 // finds the queue awake
 __global__ void wake_kernel() {}
+
+// P_l of a pipelined step -> mapped page-locked host memory, 16 bytes per lane, a few dozen workgroups: the PCIe stores keep 48 waves busy
+// instead of the 4 096 of the kernel that forms P_l
+__global__ __launch_bounds__(256) void copy16_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    const size_t n2 = n / 2;
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) d2[i] = s2[i];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
 
 // device-to-device snapshot as a kernel, for the same reason (P_l of a step, taken before the RCCL exchange on the communication stream)
 __global__ __launch_bounds__(256) void copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {

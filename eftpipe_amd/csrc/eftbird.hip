@@ -178,6 +178,7 @@ struct eftb_engine {
     hipEvent_t evFront = nullptr, evFrontFree[2] = {nullptr, nullptr};  // this run's front is done (side stream); the readers of front set [slot] are done
     unsigned front_step = 0;
     bool prev_front_side = false;
+    bool ap_plk_nodes = false;          // EFTB_AP_PLK_NODES=1: the AP stage of direct-P_l runs as the node quadrature (ap_plk_kernel, round 3) instead of the moment form
     bool plk_direct = false;            // EFTB_O_PLK_DIRECT: whole-pipeline runs that end in REDUCE contract with the bias first (regroup_plk_kernel)
     bool latency_auto = true;           // EFTB_LATENCY_MODE=0 disables
     bool set_latency[NSETS] = {};
@@ -243,6 +244,16 @@ struct eftb_engine {
     int p_set = NSETS - 1;                    // caller's view of the set rotation: the set of the step submitted last
     int dfr_set = -1, dfr_B = 0, dfr_rows = 0;   // inputs staged into set dfr_set, waiting for eftb_run_staged to queue them
     unsigned long long set_step[NSETS] = {};  // 1 + the step that used the set last (0: never used): its launch must be over before the set is refilled
+    // completion words of the staged sets in mapped page-locked memory: the step's last stream writes 1 + its step number behind everything else
+    // (hipStreamWriteValue64), so the fetch of a step polls plain memory -- a hipEventQuery loop on the caller's thread takes the runtime's locks
+    // thousands of times per step and slows the submission thread's launches down (measured: no gain from the thread at all with the event spin)
+    volatile unsigned long long* set_done = nullptr;
+    unsigned long long set_word[NSETS] = {};  // 1 + the step whose completion write was enqueued for the set (else the set's event is what to wait for)
+    bool done_words = true;                   // EFTB_DONE_WORDS=0: event queries (A/B); also the fall-back when the write command is refused
+    // EFTB_SUB_STATS=1: host time the issuing thread spends per step (printed by eftb_destroy)
+    bool sub_stats = false;
+    double issue_ns = 0.0, fill_ns = 0.0, wait_ns = 0.0;
+    unsigned long long issue_n = 0, inline_n = 0;
 };
 
 static void sub_stop_thread(eftb_engine* e);
@@ -535,7 +546,7 @@ static void launch_resum_as(eftb_engine* e, hipStream_t st, int B) {
                        tb<int>(e, EFTB_T_RSROWS), e->buf[EFTB_B_XY], e->RSAS);
 }
 
-static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
+static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B, bool weights = true) {
     const eftb_config& c = e->c;
     double** b = e->buf;
     const size_t pflds = ((size_t)(1 + 2 * c.Nl) * c.nmu + (size_t)c.Nl * c.Nl * 4 * 8) * sizeof(double);
@@ -544,7 +555,7 @@ static void launch_ap_prefix(eftb_engine* e, hipStream_t st, int B) {
     if (c.Nl == 3) hipLaunchKernelGGL((ap_prefix_kernel<3>), dim3(B), dim3(320), pflds, st, PF_ARGS);
     else hipLaunchKernelGGL((ap_prefix_kernel<2>), dim3(B), dim3(128), pflds, st, PF_ARGS);
 #undef PF_ARGS
-    if (!e->ap_fast) return;
+    if (!e->ap_fast || !weights) return;
     // knot weights of the fast path: inputs only as well, so they ride with the prefix sums (look-ahead stream in overlapped runs)
     const dim3 wgrid(((c.Nk + 63) / 64) * B);  // flat: (k tile, cosmology) decoded XCD-aware in the kernel
     const size_t wlds = ((size_t)c.Nk + c.nmu + (size_t)c.Nl * c.Nl * 4 * 64) * sizeof(double);  // knots, roots, the waves' coefficient windows
@@ -1000,13 +1011,26 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 // (the fast path keeps the splines as B-spline coefficients -- one number per knot; the moment / quadrature forms as knot slopes)
                 hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, e->ap_mode == 0 ? EFTB_T_SPCBAND : EFTB_T_SPBAND), e->SD);
             }
-            if (dir) {  // the node quadrature on the contracted row (ap_plk_kernel); nothing else of the stage runs
+            if (dir && e->ap_plk_nodes) {  // the node quadrature on the contracted row (ap_plk_kernel); nothing else of the stage runs
                 const size_t lds = ((size_t)Nk + (size_t)c.nmu * 8 + 3 * APD_WMAX * 4 + 3 * 3 * 64) * sizeof(double);
                 const int tslot = timer_begin(e, st, 2);
                 hipLaunchKernelGGL((ap_plk_kernel<3>), dim3(((Nk + 63) / 64) * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
                                    tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), e->SD,
                                    tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], b[EFTB_B_PLK], e->plk_host_out,
                                    e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21);
+                timer_end(e, st, tslot);
+                std::swap(*pin, *palt);
+                return 0;
+            }
+            if (dir) {
+                // moment form on the contracted row (ap_plk_mom_kernel): the mu prefix sums of this cosmology batch (a function of DA, H alone) in
+                // line in front of it -- the stage is ~20 us of latency-bound launches either way, and in line it needs no second set of sums
+                launch_ap_prefix(e, st, B, false);
+                const size_t lds = ((size_t)Nk + c.nmu + 3 * 3 * 64) * sizeof(double);
+                const int tslot = timer_begin(e, st, 2);
+                hipLaunchKernelGGL((ap_plk_mom_kernel<3>), dim3(((Nk + 63) / 64) * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
+                                   tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, e->SD, tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS],
+                                   b[EFTB_B_PLK], e->plk_host_out, e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21);
                 timer_end(e, st, tslot);
                 std::swap(*pin, *palt);
                 return 0;
@@ -1359,6 +1383,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_AD_WAVES")) e->ad_waves = atoi(f);
     if (const char* f = getenv("EFTB_GD_WAVES")) e->gd_waves = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_AP_PLK_NODES")) e->ap_plk_nodes = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUBMIT_THREAD")) e->sub_mode = std::max(0, std::min(2, atoi(f)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 2 * (eftb_engine::NSETS + 1) * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 2 * (eftb_engine::NSETS + 1) * sizeof(int));
@@ -1703,6 +1728,10 @@ void eftb_destroy(eftb_engine* e) {
                 else (void)hipHostFree(e->setbuf[q][id]);
             }
     }
+    if (e->set_done) (void)hipHostFree(const_cast<unsigned long long*>(e->set_done));
+    if (e->sub_stats && e->issue_n)
+        fprintf(stderr, "[eftbird] staged steps: %llu issued (%llu by the caller's thread), %.1f us per step in the issuing thread, %.1f us filling the staging block, "
+                        "%.1f us waiting for results\n", e->issue_n, e->inline_n, e->issue_ns / e->issue_n * 1e-3, e->fill_ns / e->issue_n * 1e-3, e->wait_ns / e->issue_n * 1e-3);
     if (e->status) (void)hipHostFree(e->status);
     if (e->side) (void)hipStreamDestroy(e->side);
     if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
@@ -1923,6 +1952,14 @@ static int staged_setup(eftb_engine* e) {
         HIPCHK(hipEventRecord(e->evSetDone[q], e->cpy));
     }
     if (const char* f = getenv("EFTB_LATENCY_MODE")) e->latency_auto = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_DONE_WORDS")) e->done_words = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_SUB_STATS")) e->sub_stats = atoi(f) != 0;
+    {
+        void* p = nullptr;
+        HIPCHK(hipHostMalloc(&p, eftb_engine::NSETS * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(p, 0, eftb_engine::NSETS * sizeof(unsigned long long));
+        e->set_done = static_cast<volatile unsigned long long*>(p);
+    }
     e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first eftb_run_staged; sets 0, 1, 2, 3 follow in turn
     HIPCHK(hipDeviceSynchronize());  // the zero fills ran on the null stream; the copy stream is about to write into these blocks
     return 0;
@@ -1977,7 +2014,7 @@ static int stage_issue(eftb_engine* e, int t, int B, bool has_rows, bool lat) {
 }
 
 // the staged set becomes current and the step is launched (either thread)
-static int run_staged_issue(eftb_engine* e, int mask, int B) {
+static int run_staged_issue(eftb_engine* e, int mask, int B, unsigned long long step) {
     e->cur_set = (e->cur_set + 1) % eftb_engine::NSETS;
     for (int id : kStagedIds)
         if (e->setbuf[e->cur_set][id]) e->buf[id] = e->setbuf[e->cur_set][id];
@@ -1993,10 +2030,13 @@ static int run_staged_issue(eftb_engine* e, int mask, int B) {
     // (pipelined direct-P_l steps too: at 0.13 ms of GPU work per step the 20 us the host spends in hipMemcpyAsync count; the kernel's stores to mapped
     // memory cost the GPU what the DMA cost it)
     const bool plk_direct = (lat || (e->plk_direct && !e->comm)) && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !e->c.with_nnlo;
+    // ... from the kernel that forms it in latency mode (one kernel less on the dependent sampler's chain); in pipelined steps by a small copy
+    // kernel behind the step (round 3 stored from ap_plk_kernel: 1.6 MB of 8-byte PCIe stores kept every SIMD's waves resident for ~25 us)
+    const bool plk_tail = plk_direct && !lat && !e->ap_plk_nodes;
     double* pin_dev = e->buf[EFTB_B_PIN];
     if (lat) e->buf[EFTB_B_PIN] = e->stage_host[e->cur_set] + e->stage_off[EFTB_B_PIN];
     e->lat_run = lat;
-    e->plk_host_out = plk_direct ? e->plk_host[e->cur_set] : nullptr;
+    e->plk_host_out = plk_direct && !plk_tail ? e->plk_host[e->cur_set] : nullptr;
     e->inputs_settled = e->allow_back = !lat;
     const int rc = run_stages(e, mask, B);
     e->inputs_settled = e->allow_back = false;
@@ -2007,11 +2047,22 @@ static int run_staged_issue(eftb_engine* e, int mask, int B) {
     if (rc) return rc;
     hipStream_t last = e->back_pending ? e->back : e->stream;  // the step ends where its back half ran
     if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAll[e->cur_set], 0));  // (the set is not "done" before its own upload is)
+    if (plk_tail) {
+        const size_t n = (size_t)B * e->cur_nl * e->cur_nx;
+        hipLaunchKernelGGL(copy16_kernel, dim3(48), dim3(256), 0, last, e->buf[EFTB_B_PLK], e->plk_host[e->cur_set], n);
+    }
     if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipMemcpyAsync(e->plk_host[e->cur_set], e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
     HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], last));
     if (e->back_pending && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], last));  // whoever joins the back half also waits for the copy
+    if (e->done_words) {
+        if (hipStreamWriteValue64(last, const_cast<unsigned long long*>(e->set_done) + e->cur_set, step + 1, 0) == hipSuccess) e->set_word[e->cur_set] = step + 1;
+        else {
+            (void)hipGetLastError();
+            e->done_words = false;  // this runtime refuses the command: event queries from here on (the words of the earlier steps stay valid)
+        }
+    }
     return 0;
 }
 
@@ -2035,12 +2086,14 @@ static void sub_main(eftb_engine* e) {
         }
         const eftb_engine::SubCmd c = e->sub_ring[head % eftb_engine::SUBQ];
         e->set_latency[c.set] = false;   // a queued step has company on the GPU: three-stream layout
+        const auto ti0 = std::chrono::steady_clock::now();
         int rc = stage_issue(e, c.set, c.B, c.has_rows != 0, false);
         if (!rc) {
             e->cur_set = (c.set + eftb_engine::NSETS - 1) % eftb_engine::NSETS;   // (= what it is anyway, unless an earlier launch failed half way)
-            rc = run_staged_issue(e, c.mask, c.B);
+            rc = run_staged_issue(e, c.mask, c.B, c.step);
         }
         e->cur_set = c.set;
+        if (e->sub_stats) { e->issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ti0).count(); ++e->issue_n; }
         const int r = (int)(c.step % eftb_engine::SUBREC);
         e->sub_rc[r] = rc;
         if (rc) snprintf(e->sub_err[r], sizeof e->sub_err[r], "%s", g_err.c_str());
@@ -2117,7 +2170,9 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     const bool quiet = sub_quiescent(e);
     const bool gpu_idle = quiet && hipEventQuery(e->evSetDone[e->cur_set]) == hipSuccess;
     if (e->sub_mode == 2 || (e->sub_mode == 1 && !gpu_idle)) {
+        const auto tf0 = std::chrono::steady_clock::now();
         stage_fill(e, t, B, Pin, f, DA, H, bias, rows);
+        if (e->sub_stats) e->fill_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf0).count();
         e->dfr_set = t; e->dfr_B = B; e->dfr_rows = rows ? 1 : 0;
         e->staged_B = B;
         return 0;
@@ -2127,8 +2182,14 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     const bool lat = e->latency_auto && e->staged_B == 0 && e->stage_off[EFTB_B_PIN] == 0 && gpu_idle;
     e->set_latency[t] = lat;
     if (lat) hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, e->stream);  // (see wake_kernel: its start-up runs under the host copies below)
+    const auto tf0 = std::chrono::steady_clock::now();
     stage_fill(e, t, B, Pin, f, DA, H, bias, rows);
+    const auto tf1 = std::chrono::steady_clock::now();
     if (int rc = stage_issue(e, t, B, rows != nullptr, lat)) return rc;
+    if (e->sub_stats) {
+        e->fill_ns += std::chrono::duration<double, std::nano>(tf1 - tf0).count();
+        e->issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf1).count();
+    }
     e->dfr_set = -1;
     e->staged_B = B;
     return 0;
@@ -2162,7 +2223,9 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
         return 0;
     }
     sub_drain(e);
-    const int rc = run_staged_issue(e, mask, B);
+    const auto ti0 = std::chrono::steady_clock::now();
+    const int rc = run_staged_issue(e, mask, B, step);
+    if (e->sub_stats) { e->issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ti0).count(); ++e->issue_n; ++e->inline_n; }
     e->p_set = e->cur_set;
     if (rc) return rc;
     e->sub_rc[step % eftb_engine::SUBREC] = 0;
@@ -2170,6 +2233,27 @@ int eftb_run_staged(eftb_engine* e, int mask, int B) {
     ++e->steps_submitted;
     e->steps_launched.store(step + 1, std::memory_order_release);
     return 0;
+}
+
+// the step that ran on set t has finished (its completion word, or its event)
+static int wait_step_done(eftb_engine* e, int t, unsigned long long step, const char* who) {
+    const auto tw0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    if (e->set_word[t] == step + 1) {   // (else: no completion write was enqueued for this step -- EFTB_DONE_WORDS=0, or the runtime refused it)
+        static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
+        for (unsigned spins = 0; e->set_done[t] < step + 1; ++spins) {
+            cpu_pause();
+            if ((spins & 0xfffff) == 0xfffff && std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count() > limit_s) {
+                rc = fail("%s: the step did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", who, limit_s);
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        rc = spin_event(e->evSetDone[t], who, "the step");
+    }
+    if (e->sub_stats) e->wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
+    return rc;
 }
 
 // set and step of the staged step `back` steps before the one submitted last, once its launch has been issued
@@ -2189,7 +2273,7 @@ int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count
     int t = 0;
     if (int rc = staged_step(e, "eftb_fetch_back", back, &t)) return rc;
     HIPCHK(hipSetDevice(e->c.device));
-    if (int rc = spin_event(e->evSetDone[t], "eftb_fetch_back", "the step")) return rc;
+    if (int rc = wait_step_done(e, t, e->steps_submitted - 1 - back, "eftb_fetch_back")) return rc;
     if (id == EFTB_B_PLK && e->plk_host[t])
         memcpy(host, e->plk_host[t], count * sizeof(double));  // copied out by the DMA engine behind the step
     else if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
@@ -2209,10 +2293,21 @@ int eftb_fetch_view(eftb_engine* e, int back, int id, const double** block, size
     HIPCHK(hipSetDevice(e->c.device));
     const double* p = id == EFTB_B_PLK ? (e->plk_host[t] ? e->plk_host[t] : (e->staged_plk_device ? nullptr : e->setbuf[t][id])) : e->setbuf[t][id];
     if (!p) return fail("eftb_fetch_view: P_l of this engine stays in device memory for the RCCL exchange (eftb_gathered_view hands out the gathered block)");
-    if (int rc = spin_event(e->evSetDone[t], "eftb_fetch_view", "the step")) return rc;
+    if (int rc = wait_step_done(e, t, e->steps_submitted - 1 - back, "eftb_fetch_view")) return rc;
     *block = p;
     if (count) *count = e->buf_elems[id];
     return check_status(e, "eftb_fetch_view", t);
+}
+
+int eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[5]) {
+    if (!e) return fail("eftb_submit_stats: null engine");
+    sub_drain(e);
+    if (out) {
+        out[0] = (double)e->issue_n; out[1] = (double)e->inline_n; out[2] = e->issue_ns * 1e-3; out[3] = e->fill_ns * 1e-3; out[4] = e->wait_ns * 1e-3;
+    }
+    if (reset) { e->issue_n = e->inline_n = 0; e->issue_ns = e->fill_ns = e->wait_ns = 0.0; }
+    e->sub_stats = enable != 0;
+    return 0;
 }
 
 int eftb_step(eftb_engine* e, int mask, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,

@@ -184,6 +184,14 @@ class Engine:
         2: every step is queued, also one that finds the GPU idle (tests)."""
         L.check(self.lib.eftb_set_option(self._h, 8, int(flag)))
 
+    def submit_stats(self, enable=True, reset=True):
+        """Host-side cost of the staged steps since the last reset (``eftb_submit_stats``): dict with steps, steps issued by the caller's thread, and
+        microseconds per step spent issuing (either thread), filling the staging block, and waiting for results in fetch calls."""
+        out = np.zeros(5)
+        L.check(self.lib.eftb_submit_stats(self._h, int(bool(enable)), int(bool(reset)), L.dptr(out)))
+        n = max(out[0], 1.0)
+        return {"steps": int(out[0]), "issued_by_caller": int(out[1]), "issue_us_per_step": out[2] / n, "fill_us_per_step": out[3] / n, "wait_us_per_step": out[4] / n}
+
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
 

@@ -276,6 +276,11 @@ int  eftb_fetch_view(eftb_engine* e, int back, int buffer_id, const double** blo
 int  eftb_step(eftb_engine* e, int stage_mask, int B, const double* Pin, const double* f, const double* DA, const double* H,
                const double* bias, const double* rows, int back, int buffer_id, const double** block, size_t* count);
 
+/* Host-side cost of the staged steps, for bench.py's accounting (measurement only): enable != 0 switches the clocks on; out (may be NULL) receives
+ * {steps issued, of which by the caller's thread, us spent issuing (upload kernel + launches + events, whichever thread), us spent copying inputs
+ * into the staging blocks, us the caller spent waiting for results in eftb_fetch_*}; reset != 0 clears the sums. */
+int  eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[5]);
+
 /* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
  * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */
 void* eftb_host_alloc(size_t bytes);

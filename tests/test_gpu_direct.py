@@ -266,8 +266,7 @@ def test_submission_thread_returns_the_bits_of_the_callers_thread(direct):
                 eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
                 eng.run_staged(mask, B)
                 view = eng.fetch_previous("PLK", shape, back=depth, copy=False) if i >= depth else None
-            assert (view is None) == (i < depth)
-            if view is not None:
+            if i >= depth:  # (before that the view, if any, is a step of the previous pass)
                 got.append(view.copy())
         for back in range(depth - 1, -1, -1):
             got.append(eng.fetch_previous("PLK", shape, back=back))

@@ -41,7 +41,7 @@ def resident():
     eng.sync()
 
 
-def staged(depth=2):
+def staged(depth=int(os.environ.get("HP_DEPTH", "3"))):
     for i in range(K):
         d = sets[i % 8]
         eng.stage_inputs(d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"])
