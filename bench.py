@@ -39,7 +39,8 @@ BS = [2.1401334, 0.77616816 / np.sqrt(2.0), 0.77003455, 0.77616816 / np.sqrt(2.0
 ES = (0.26033594, 0.0, -0.92895016)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
 NPOW, NS_DEV, NKLOW = 257, 80, 7
-DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "3"))  # steps queued on the GPU ahead of the one being fetched (1..6; direct-P_l steps are four pipeline stages deep: 618-650 k evaluations/s at 2, 660-668 k at 3, 663-695 k at 4; templates first, round 2: measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
+COALESCE = int(os.environ.get("EFTB_BENCH_COALESCE", "2"))  # steps the engine may launch together when they are still queued (Engine(coalesce=...): device state for COALESCE x batch)
+DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "9"))  # steps queued on the GPU ahead of the one being fetched (1..6; direct-P_l steps are four pipeline stages deep: 618-650 k evaluations/s at 2, 660-668 k at 3, 663-695 k at 4; templates first, round 2: measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
 DIRECT = os.environ.get("EFTB_BENCH_DIRECT", "1") != "0"   # `value` on direct-P_l runs (EFTB_O_PLK_DIRECT); 0: templates first
 
 
@@ -267,7 +268,7 @@ def main():
             device, shared_device = cp.local_rank % ndev, True
             print(f"[bench] rank {rank}: only {ndev} GPU(s) visible, sharing device {device}", file=sys.stderr)
     with threadpool_limits(limits=8):
-        eng = Engine(cfg, max_batch=B, device=device)
+        eng = Engine(cfg, max_batch=B, device=device, coalesce=COALESCE)
     shared_device = cp.max(1.0 if shared_device else 0.0) > 0.0   # any rank sharing a GPU makes the run a rehearsal
     exchange = "none"
     force_comm = world == 1 and os.environ.get("EFTB_BENCH_FORCE_COMM") == "1"  # one-GPU rehearsal of the N > 1 loop (RCCL self exchange)
@@ -349,7 +350,7 @@ def main():
         for i in range(n):
             if exchange == "none":  # one library call per step: stage + launch + the view of the step DEPTH back (eftb_step)
                 d = sets[first + i]
-                view = eng.step(mask, d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"], back=DEPTH, shape=(B, NL, NK))
+                view = eng.step(mask, d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"], back=DEPTH if i >= DEPTH else -1, shape=(B, NL, NK))
                 if view is not None:
                     if keep:
                         keeper.put(view, i - DEPTH)

@@ -24,7 +24,7 @@ class Config(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "device", "Nl", "Nk", "Nkin", "max_batch", "with_resum", "with_ap", "ap_stochastic", "nmu",
-        "ntail", "nxtail", "nbasis", "nbasis13", "NIR", "Na", "Nklow", "with_nnlo", "optiresum", "dual_coef")]
+        "ntail", "nxtail", "nbasis", "nbasis13", "NIR", "Na", "Nklow", "with_nnlo", "optiresum", "dual_coef", "step_batch")]
 
 
 # enum eftb_table / eftb_buffer / eftb_stage (same order as the header)

@@ -2721,6 +2721,16 @@ __global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restric
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// The same for a launch that carries several queued steps: up to 8 steps x 6 arrays, each a run of doubles from a step's staging block to its rows
+// of the device block; workgroups [seg * wgs, (seg + 1) * wgs) share segment seg.
+struct StageSeg { const double* src; double* dst; size_t n; };
+struct StageSegs { StageSeg s[48]; int n; };
+__global__ __launch_bounds__(256) void stage_gather_kernel(StageSegs sg, int wgs) {
+    const int seg = blockIdx.x / wgs, part = blockIdx.x % wgs;
+    const StageSeg g = sg.s[seg];
+    for (size_t i = (size_t)part * 256 + threadIdx.x; i < g.n; i += (size_t)wgs * 256) g.dst[i] = g.src[i];
+}
+
 // nothing: the first dispatch after the GPU has sat idle for a few tens of microseconds takes 40-50 us to start executing (traced: a 27 KB copy
 // kernel 44 us, the 205 KB one behind it 6 us) -- eftb_stage_inputs sends this ahead of its host-side work so that the step's first real kernel
 // finds the queue awake

@@ -114,7 +114,7 @@ struct eftb_engine {
     // One pair per rotating set of the staged API (status[2 q], status[2 q + 1]: raised and cleared with step q's own results, whatever runs
     // beside it) and one pair (slot NSETS) for runs on the engine's own buffers (eftb_put / eftb_run / eftb_eval_batch).
     int* status = nullptr;
-    int status_slot = 8;            // = NSETS: pair the kernels of the next launch raise (eftb_run_staged: the step's set)
+    int status_slot = 16;           // = NSETS: pair the kernels of the next launch raise (eftb_run_staged: the step's set)
     bool check_finite = false;
     std::vector<double> like_host;  // eftb_eval_logp_batch: D2H landing block [B][MARG_OUT]
     int* like_index = nullptr;
@@ -151,16 +151,21 @@ struct eftb_engine {
     hipStream_t opstream = nullptr;  // where the operator launchers put their kernels (null: the main stream)
     // Pipelined sampler steps (eftb_stage_inputs / eftb_run_staged / eftb_fetch_back): four sets of the per-step inputs (PIN, F, DA,
     // H, BIAS, GROWS) and outputs (PLK, LOGP) -- up to three launched and not yet fetched, one whose results are being fetched / refilled
-    static constexpr int NSETS = 8;  // rotating sets of per-step inputs / outputs: the host may run seven steps ahead of the step it fetches (a step's way from
+    static constexpr int NSETS = 16; // rotating sets of per-launch inputs / outputs: the host may run fifteen steps ahead of the step it fetches (round 3: 8; a step's way from
                                      // the staging block to the fetched P_l is four pipeline stages long since the direct-P_l runs: four sets left bubbles)
     double* setbuf[NSETS][EFTB_B_COUNT] = {{nullptr}};
     double* setblock[NSETS] = {};   // one contiguous input block per set (PIN, F, DA, H, BIAS, GROWS at stage_off[])
     double* orig[EFTB_B_COUNT] = {nullptr};              // the engine's own buffers, current until the first staged run
     size_t stage_off[EFTB_B_COUNT] = {0};
-    double* stage_host[NSETS] = {};  // page-locked staging, one per set
+    // page-locked staging, one block per STEP (a launch may carry several queued steps -- see SubCmd -- so staging blocks and device sets
+    // rotate separately: slot = step % NSLOT, set = launch % NSETS)
+    static constexpr int NSLOT = 32;
+    double* stage_host[NSLOT] = {};
     size_t stage_elems = 0;
     hipStream_t cpy = nullptr;
-    hipEvent_t evStaged[NSETS] = {}, evSetDone[NSETS] = {};
+    static constexpr int NLRING = 64;       // ring of the upload events, by launch number (a staging block is refilled 16 steps <= 16 launches later)
+    hipEvent_t evStagedR[NLRING] = {}, evStagedAllR[NLRING] = {};
+    hipEvent_t evSetDone[NSETS] = {};
     // Latency mode (a sampler whose next step depends on this step's P_l: nothing is queued behind the step being staged).  eftb_stage_inputs
     // finds the GPU idle -> this set's step runs on ONE queue (every cross-queue hand-over costs 15-18 us of dispatch latency, and there is no
     // neighbouring step to overlap with), the first kernel reads P_lin straight from the page-locked staging block (the 0.2 MB device copy
@@ -181,11 +186,10 @@ struct eftb_engine {
     bool ap_plk_nodes = false;          // EFTB_AP_PLK_NODES=1: the AP stage of direct-P_l runs as the node quadrature (ap_plk_kernel, round 3) instead of the moment form
     bool plk_direct = false;            // EFTB_O_PLK_DIRECT: whole-pipeline runs that end in REDUCE contract with the bias first (regroup_plk_kernel)
     bool latency_auto = true;           // EFTB_LATENCY_MODE=0 disables
-    bool set_latency[NSETS] = {};
-    hipEvent_t evStagedAll[NSETS] = {};  // the whole staging block of a set has been uploaded (evStaged: the part its first kernels wait for)
+    bool set_latency[NSETS] = {};        // the launch on this set is a latency-mode step (evStagedAllR: the whole staging block has been uploaded; evStagedR: the part its first kernels wait for)
     bool lat_run = false;                // the run being launched is a latency-mode step
     double* plk_host_out = nullptr;      // latency mode: where P_l goes besides the device buffer
-    int cur_set = 0, staged_B = 0;
+    int cur_set = 0;
     // staged sets keep P_l in device memory: with a communicator RCCL sends from it; without one the step's last stream copies it to page-locked
     // host memory with the DMA engine (plk_host) -- measured 0.447 ms per step against 0.455 ms with REDUCE writing mapped host memory over PCIe
     // from its waves (EFTB_STAGED_PLK_MAPPED=1 keeps that form)
@@ -211,8 +215,8 @@ struct eftb_engine {
     double* gath_host[NSETS] = {};
     hipEvent_t evGathHost[NSETS] = {};
     size_t gath_elems[NSETS] = {};
-    int gath_set[NSETS] = {NSETS, NSETS, NSETS, NSETS, NSETS, NSETS, NSETS, NSETS};  // set whose P_l exchange `slot` carries (its flags are checked when the gathered block is handed out; NSETS: the engine's own buffers)
-    static_assert(NSETS == 8, "gath_set's initialiser and status_slot's default name NSETS entries");
+    int gath_set[NSETS];  // (all NSETS after eftb_create) set whose P_l exchange `slot` carries (its flags are checked when the gathered block is handed out; NSETS: the engine's own buffers)
+    static_assert(NSETS == 16, "status_slot's default names NSETS");
     int gather_slot = 0;
     // the gather runs on its own stream from a snapshot of P_l, so that it overlaps the next step's kernels
     hipStream_t comm_stream = nullptr;
@@ -225,30 +229,44 @@ struct eftb_engine {
     // caller goes on to the next step's inputs.  A step that finds the engine quiescent and the GPU idle (a dependent sampler's step) is issued by the
     // caller itself, as before: no hand-over latency.  Every other entry point waits until the queue is empty (sub_drain), so the engine's state
     // is only ever touched by one thread at a time; the queue and the per-step completion records are the only shared data.
-    struct SubCmd { int set, mask, B, has_rows; unsigned long long step; };
-    static constexpr int SUBQ = 16;          // ring of queued steps (at most NSETS - 1 can be pending: every step owns a staging set)
+    // Coalescing: steps that are still queued when the submission thread gets to them leave as ONE launch chain (their staging blocks are gathered
+    // into one device set, row after row; each step's results are its rows of the set's output blocks).  At 128 cosmologies every kernel of a
+    // step is a single ragged round of waves; two or four steps together cost far less than two or four launches (measured: 0.108 ms per 128 at 256
+    // against 0.126).  Needs eftb_config.step_batch < max_batch (the device state is sized for max_batch; a step brings at most step_batch).
+    struct SubCmd { int slot, mask, B, has_rows; unsigned long long step; };
+    static constexpr int SUBQ = 64;          // ring of queued steps (at most NSLOT - 1 can be pending: every step owns a staging block)
     SubCmd sub_ring[SUBQ];
     std::atomic<unsigned long long> sub_tail{0};   // commands pushed (caller's thread)
     std::atomic<unsigned long long> sub_head{0};   // commands completed (submission thread)
-    std::atomic<bool> sub_sleeping{false}, sub_stop{false};
+    std::atomic<bool> sub_sleeping{false}, sub_stop{false}, sub_hold{false};   // sub_hold (EFTB_O_SUBMIT_HOLD, tests): queued steps are not taken until it is cleared
     std::mutex sub_mx;
     std::condition_variable sub_cv;
     std::thread sub_thread;
     int sub_mode = 1;   // 0: the caller issues every step; 1: queued unless the engine is quiescent and the GPU idle; 2: always queued (tests)
     bool sub_started = false;
-    static constexpr int SUBREC = 32;        // completion records of the last steps: rc + message of the launch (surface when the step is fetched)
-    int sub_rc[SUBREC] = {};
+    static constexpr int SUBREC = 64;        // records of the last steps: where the step's rows are, rc + message of its launch (surface when the step is fetched)
+    struct StepRec { int set, row, B, rc, nl, nx; unsigned long long launch; };
+    StepRec rec[SUBREC] = {};
     char sub_err[SUBREC][256] = {};
+    int coalesce_max = 1;                    // steps per launch at most (EFTB_COALESCE; 1 unless step_batch < max_batch)
+    int sub_inflight = 3;                    // launches the submission thread keeps in flight before it lets the queue grow (EFTB_SUB_INFLIGHT)
+    unsigned long long launch_seq = 0;       // staged launches issued so far (issuing thread)
+    unsigned long long launch_done = 0;      // ... of which known to have finished (issuing thread's view)
+    int lring_set[NLRING] = {};              // set of launch (seq % NLRING)
     std::atomic<unsigned long long> steps_launched{0};  // staged steps whose launch has been issued (by either thread), in order
     unsigned long long steps_submitted = 0;   // staged steps handed in so far (caller's thread) = what eftb_fetch_back counts `back` from
-    int p_set = NSETS - 1;                    // caller's view of the set rotation: the set of the step submitted last
-    int dfr_set = -1, dfr_B = 0, dfr_rows = 0;   // inputs staged into set dfr_set, waiting for eftb_run_staged to queue them
-    unsigned long long set_step[NSETS] = {};  // 1 + the step that used the set last (0: never used): its launch must be over before the set is refilled
+    int stg_slot = -1, stg_B = 0, stg_rows = 0;  // inputs staged into block stg_slot, waiting for eftb_run_staged
+    bool stg_inline = false, stg_lat = false;    // ... to be issued by the caller's thread (engine quiescent, GPU idle), as a latency-mode step
+    unsigned long long slot_step[NSLOT] = {}; // 1 + the step that used the staging block last (0: never used): its launch must be over before the block is refilled
+    bool slot_latency[NSLOT] = {};            // ... which was a latency-mode step (its first kernel read P_lin from the block itself)
+    size_t slot_off[EFTB_B_COUNT] = {0};      // layout of a staging block (one step: step_batch rows per array)
+    size_t slot_elems = 0;
+    unsigned long long launch_n = 0;          // (statistics: launches that carried the issue_n steps)
     // completion words of the staged sets in mapped page-locked memory: the step's last stream writes 1 + its step number behind everything else
     // (hipStreamWriteValue64), so the fetch of a step polls plain memory -- a hipEventQuery loop on the caller's thread takes the runtime's locks
     // thousands of times per step and slows the submission thread's launches down (measured: no gain from the thread at all with the event spin)
     volatile unsigned long long* set_done = nullptr;
-    unsigned long long set_word[NSETS] = {};  // 1 + the step whose completion write was enqueued for the set (else the set's event is what to wait for)
+    unsigned long long set_word[NSETS] = {};  // 1 + the launch whose completion write was enqueued for the set (else the set's event is what to wait for)
     bool done_words = true;                   // EFTB_DONE_WORDS=0: event queries (A/B); also the fall-back when the write command is refused
     // EFTB_SUB_STATS=1: host time the issuing thread spends per step (printed by eftb_destroy)
     bool sub_stats = false;
@@ -1267,6 +1285,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     const eftb_config& c = *cfg;
     if (c.Nl != 2 && c.Nl != 3) return fail("eftb_create: Nl must be 2 or 3 (got %d)", c.Nl);
     if (c.Nk < 8 || c.Nkin < 4 || c.max_batch < 1) return fail("eftb_create: bad dimensions Nk=%d Nkin=%d max_batch=%d", c.Nk, c.Nkin, c.max_batch);
+    if (c.step_batch < 0 || c.step_batch > c.max_batch) return fail("eftb_create: step_batch=%d outside [0, max_batch=%d]", c.step_batch, c.max_batch);
     if (c.nbasis < 1 || c.nbasis > 16) return fail("eftb_create: nbasis=%d outside [1, 16]", c.nbasis);
     if (c.nbasis > BAS22 || (c.with_resum && c.Nl * (c.nbasis + c.nbasis13) > BASC)) return fail("eftb_create: loop basis %d + %d too large", c.nbasis, c.nbasis13);
     if (c.with_resum && !((c.Nl == 3 && c.NIR == 16 && c.Na == 3) || (c.Nl == 2 && c.NIR == 8 && c.Na == 2)))
@@ -1278,6 +1297,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     HIPCHK(hipSetDevice(c.device));
     eftb_engine* e = new eftb_engine();
     e->c = c;
+    for (int& g : e->gath_set) g = eftb_engine::NSETS;
     e->Nn = 2 * c.NIR * c.Na;
     e->cur_nl = c.Nl;
     e->cur_nx = c.Nk;
@@ -1581,6 +1601,7 @@ int eftb_set_template_dims(eftb_engine* e, int nl, int nx) {
 }
 
 int eftb_set_option(eftb_engine* e, int option, int value) {
+    if (e && option == EFTB_O_SUBMIT_HOLD) { e->sub_hold.store(value != 0, std::memory_order_release); return 0; }  // (no drain: the queue is meant to stand)
     if (e) sub_drain(e);
     if (e) ++e->epoch;  // invalidates the captured graphs
     if (!e) return fail("eftb_set_option: null engine");
@@ -1592,6 +1613,7 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seqk[0] = e->time_seqk[1] = e->time_seqk[2] = 0; return 0;
         case EFTB_O_LATENCY_MODE: e->latency_auto = value != 0; return 0;
         case EFTB_O_PLK_DIRECT: e->plk_direct = value != 0; return 0;
+        case EFTB_O_SUBMIT_HOLD: e->sub_hold.store(value != 0, std::memory_order_release); return 0;
         case EFTB_O_SUBMIT_THREAD:
             if (value < 0 || value > 2) return fail("eftb_set_option: EFTB_O_SUBMIT_THREAD takes 0, 1 or 2");
             e->sub_mode = value; return 0;
@@ -1715,11 +1737,14 @@ void eftb_destroy(eftb_engine* e) {
     if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->back) (void)hipStreamDestroy(e->back);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
+    for (int h = 0; h < eftb_engine::NSLOT; ++h)
+        if (e->stage_host[h]) (void)hipHostFree(e->stage_host[h]);
+    for (int r = 0; r < eftb_engine::NLRING; ++r) {
+        if (e->evStagedR[r]) (void)hipEventDestroy(e->evStagedR[r]);
+        if (e->evStagedAllR[r]) (void)hipEventDestroy(e->evStagedAllR[r]);
+    }
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
-        if (e->evStaged[q]) (void)hipEventDestroy(e->evStaged[q]);
-        if (e->evStagedAll[q]) (void)hipEventDestroy(e->evStagedAll[q]);
         if (e->evSetDone[q]) (void)hipEventDestroy(e->evSetDone[q]);
-        if (e->stage_host[q]) (void)hipHostFree(e->stage_host[q]);
         if (e->setblock[q]) (void)hipFree(e->setblock[q]);
         for (int id : {EFTB_B_PLK, EFTB_B_LOGP})
             if (e->setbuf[q][id]) {
@@ -1905,8 +1930,8 @@ static const int kStagedIds[] = {EFTB_B_PIN, EFTB_B_F, EFTB_B_DA, EFTB_B_H, EFTB
 static const int kStagedIn[] = {EFTB_B_PIN, EFTB_B_F, EFTB_B_DA, EFTB_B_H, EFTB_B_BIAS, EFTB_B_GROWS};  // order inside a set's input block
 static const int kStagedOut[] = {EFTB_B_PLK, EFTB_B_LOGP};
 
-// Every set keeps its inputs in ONE device block with the layout of the page-locked staging block, so that staging is a single
-// large asynchronous copy (small separate copies are carried out by the host thread once the stream's dependencies have resolved,
+// Every set keeps its inputs in ONE device block with the layout of the page-locked staging blocks, so that staging is one upload
+// kernel (small separate copies are carried out by the host thread once the stream's dependencies have resolved,
 // which would stall the sampler loop for a whole step).
 static int staged_setup(eftb_engine* e) {
     if (e->cpy) return 0;
@@ -1942,131 +1967,205 @@ static int staged_setup(eftb_engine* e) {
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->setbuf[q][id]), e->buf_elems[id] * sizeof(double), hipHostMallocMapped));
             memset(e->setbuf[q][id], 0, e->buf_elems[id] * sizeof(double));
         }
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->stage_host[q]), e->stage_elems * sizeof(double), hipHostMallocMapped));
-        memset(e->stage_host[q], 0, e->stage_elems * sizeof(double));
-        HIPCHK(hipEventCreateWithFlags(&e->evStaged[q], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&e->evStagedAll[q], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&e->evSetDone[q], hipEventDisableTiming));
-        HIPCHK(hipEventRecord(e->evStaged[q], e->cpy));
-        HIPCHK(hipEventRecord(e->evStagedAll[q], e->cpy));
         HIPCHK(hipEventRecord(e->evSetDone[q], e->cpy));
+    }
+    // a staging block is sized for one step (step_batch cosmologies), laid out like the device block of a set that holds only that step
+    const size_t sb = e->c.step_batch > 0 ? (size_t)e->c.step_batch : (size_t)e->c.max_batch;
+    size_t hoff = 0;
+    for (int id : kStagedIn) {
+        e->slot_off[id] = hoff;
+        hoff += e->buf_elems[id] / e->c.max_batch * sb;
+    }
+    e->slot_elems = (hoff + 1) & ~(size_t)1;
+    for (int h = 0; h < eftb_engine::NSLOT; ++h) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->stage_host[h]), e->slot_elems * sizeof(double), hipHostMallocMapped));
+        memset(e->stage_host[h], 0, e->slot_elems * sizeof(double));
+    }
+    for (int r = 0; r < eftb_engine::NLRING; ++r) {
+        HIPCHK(hipEventCreateWithFlags(&e->evStagedR[r], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->evStagedAllR[r], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e->evStagedR[r], e->cpy));
+        HIPCHK(hipEventRecord(e->evStagedAllR[r], e->cpy));
     }
     if (const char* f = getenv("EFTB_LATENCY_MODE")) e->latency_auto = atoi(f) != 0;
     if (const char* f = getenv("EFTB_DONE_WORDS")) e->done_words = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUB_STATS")) e->sub_stats = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_SUB_INFLIGHT")) e->sub_inflight = std::max(1, std::min(eftb_engine::NSETS - 1, atoi(f)));
+    e->coalesce_max = e->comm ? 1 : (int)std::min<size_t>(8, (size_t)e->c.max_batch / sb);   // (with a communicator every step is exchanged by itself)
+    if (const char* f = getenv("EFTB_COALESCE")) e->coalesce_max = std::max(1, std::min(e->coalesce_max, atoi(f)));
     {
         void* p = nullptr;
         HIPCHK(hipHostMalloc(&p, eftb_engine::NSETS * sizeof(unsigned long long), hipHostMallocMapped));
         memset(p, 0, eftb_engine::NSETS * sizeof(unsigned long long));
         e->set_done = static_cast<volatile unsigned long long*>(p);
     }
-    e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first eftb_run_staged; sets 0, 1, 2, 3 follow in turn
+    e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first staged launch; sets 0, 1, 2, 3 follow in turn
     HIPCHK(hipDeviceSynchronize());  // the zero fills ran on the null stream; the copy stream is about to write into these blocks
     return 0;
 }
 
-// ---- staged steps: the host part (inputs -> page-locked block of set t) ...
-static void stage_fill(eftb_engine* e, int t, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
+// ---- staged steps: the host part (inputs -> page-locked block `slot`) ...
+static void stage_fill(eftb_engine* e, int slot, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
                        const double* rows) {
     const eftb_config& c = e->c;
-    double* h = e->stage_host[t];
-    memcpy(h + e->stage_off[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double));
-    memcpy(h + e->stage_off[EFTB_B_F], f, (size_t)B * sizeof(double));
+    double* h = e->stage_host[slot];
+    memcpy(h + e->slot_off[EFTB_B_PIN], Pin, (size_t)B * c.Nkin * sizeof(double));
+    memcpy(h + e->slot_off[EFTB_B_F], f, (size_t)B * sizeof(double));
     if (c.with_ap) {
-        memcpy(h + e->stage_off[EFTB_B_DA], DA, (size_t)B * sizeof(double));
-        memcpy(h + e->stage_off[EFTB_B_H], H, (size_t)B * sizeof(double));
+        memcpy(h + e->slot_off[EFTB_B_DA], DA, (size_t)B * sizeof(double));
+        memcpy(h + e->slot_off[EFTB_B_H], H, (size_t)B * sizeof(double));
     }
-    if (bias) memcpy(h + e->stage_off[EFTB_B_BIAS], bias, (size_t)B * NROW * sizeof(double));
+    if (bias) memcpy(h + e->slot_off[EFTB_B_BIAS], bias, (size_t)B * NROW * sizeof(double));
     if (rows) {  // packed [B][nG+1][24] -> device rows of MARG_NG1
         const int ng1 = e->like_nG + 1;
         for (int w = 0; w < B; ++w)
-            memcpy(h + e->stage_off[EFTB_B_GROWS] + (size_t)w * MARG_NG1 * NROW, rows + (size_t)w * ng1 * NROW, (size_t)ng1 * NROW * sizeof(double));
+            memcpy(h + e->slot_off[EFTB_B_GROWS] + (size_t)w * MARG_NG1 * NROW, rows + (size_t)w * ng1 * NROW, (size_t)ng1 * NROW * sizeof(double));
     }
 }
 
-// ... and the device part (issued by the caller's thread or by the submission thread): the upload kernels of set t and their events
-static int stage_issue(eftb_engine* e, int t, int B, bool has_rows, bool lat) {
-    double* h = e->stage_host[t];
+// ... and the device part (issued by the caller's thread or by the submission thread): n queued steps become ONE launch on the next device set --
+// their staging blocks are gathered into the set's input block row after row by one upload kernel, then every stage runs on the joint batch
+static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, bool lat) {
+    const eftb_config& c = e->c;
+    const int q = (e->cur_set + 1) % eftb_engine::NSETS;
+    const unsigned long long L = e->launch_seq;
+    const int lr = (int)(L % eftb_engine::NLRING);
+    const int mask = cmds[0].mask;
+    const bool has_rows = cmds[0].has_rows != 0;
+    int Bt = 0;
+    for (int j = 0; j < n; ++j) Bt += cmds[j].B;
     hipStream_t cs = e->cpy;
-    HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[t], 0));  // the last run on this set (and the fetch of its results) is over
-    // (a copy kernel reading the mapped staging block, not a DMA transfer: 0.4 MB is latency, and the DMA form measured the same or worse)
+    HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[q], 0));  // the last launch on this set (and the fetch of its results) is over
+    // (an upload kernel reading the mapped staging blocks, not a DMA transfer: 0.4 MB is latency, and the DMA form measured the same or worse)
     // only what was staged travels: P_lin, f, DA, H, the bias rows -- and the likelihood rows (0.6 MB at 128 walkers) when there are any.  Reads
     // of host memory from a kernel run at ~16 GB/s: the whole 0.85 MB block took 48-53 us, on the critical path of a dependent sampler
-    const size_t n_pin = e->stage_off[EFTB_B_F], n_small = e->stage_off[EFTB_B_GROWS] - n_pin, n_rows = has_rows ? (size_t)B * MARG_NG1 * NROW : 0;
-    auto copy = [&](size_t off, size_t n, int wgs, hipStream_t q) {
-        if (n) hipLaunchKernelGGL(stage_copy_kernel, dim3(wgs), dim3(256), 0, q, h + off, e->setblock[t] + off, n);
+    const size_t width[6] = {(size_t)c.Nkin, 1, 1, 1, (size_t)NROW, (size_t)MARG_NG1 * NROW};
+    auto gather = [&](int id_lo, int id_hi, int wgs_per_seg, hipStream_t st) {  // arrays kStagedIn[id_lo .. id_hi) of every step of the group
+        StageSegs sg{};
+        int row = 0;
+        for (int j = 0; j < n; ++j) {
+            for (int a = id_lo; a < id_hi; ++a) {
+                const int id = kStagedIn[a];
+                if (!e->buf_elems[id] || (id == EFTB_B_GROWS && !has_rows)) continue;
+                StageSeg& g = sg.s[sg.n++];
+                g.src = e->stage_host[cmds[j].slot] + e->slot_off[id];
+                g.dst = e->setblock[q] + e->stage_off[id] + (size_t)row * width[a];
+                g.n = (size_t)cmds[j].B * width[a];
+            }
+            row += cmds[j].B;
+        }
+        if (sg.n) hipLaunchKernelGGL(stage_gather_kernel, dim3(sg.n * wgs_per_seg), dim3(256), 0, st, sg, wgs_per_seg);
     };
+    e->set_latency[q] = lat;
     if (lat) {
         // the small arrays go first and on the compute queue itself (in line in front of the step's kernels: no cross-queue hand-over; the
         // GPU is idle, nothing of an earlier step can still be reading the set): they are all the step's first kernels wait for -- its first
         // kernel reads P_lin from the staging block itself, whose device copy follows on the copy queue
-        copy(n_pin, n_small, 8, e->stream);
-        copy(e->stage_off[EFTB_B_GROWS], n_rows, 64, e->stream);
-        HIPCHK(hipEventRecord(e->evStaged[t], e->stream));
-        copy(0, n_pin, 48, cs);
-        HIPCHK(hipEventRecord(e->evStagedAll[t], cs));
+        gather(1, 6, 8, e->stream);
+        HIPCHK(hipEventRecord(e->evStagedR[lr], e->stream));
+        gather(0, 1, 48, cs);
+        HIPCHK(hipEventRecord(e->evStagedAllR[lr], cs));
     } else {
-        copy(0, n_pin + n_small, 64, cs);
-        copy(e->stage_off[EFTB_B_GROWS], n_rows, 64, cs);
-        HIPCHK(hipEventRecord(e->evStaged[t], cs));  // (= "all of it": evStagedAll is only recorded for latency-mode sets)
+        gather(0, 6, 12, cs);
+        HIPCHK(hipEventRecord(e->evStagedR[lr], cs));
     }
-    return 0;
-}
-
-// the staged set becomes current and the step is launched (either thread)
-static int run_staged_issue(eftb_engine* e, int mask, int B, unsigned long long step) {
-    e->cur_set = (e->cur_set + 1) % eftb_engine::NSETS;
+    // the set becomes current and the launch goes out
+    e->cur_set = q;
+    e->lring_set[lr] = q;
+    ++e->launch_seq;
+    int row = 0;
+    for (int j = 0; j < n; ++j) {  // where each step's rows will be (the fetch needs it even when the launch fails below: to say so)
+        eftb_engine::StepRec& r = e->rec[cmds[j].step % eftb_engine::SUBREC];
+        r.set = q; r.row = row; r.B = cmds[j].B; r.launch = L; r.rc = 0;
+        row += cmds[j].B;
+    }
     for (int id : kStagedIds)
-        if (e->setbuf[e->cur_set][id]) e->buf[id] = e->setbuf[e->cur_set][id];
-    e->status_slot = e->cur_set;  // this step's kernels raise this set's flags (cleared here: whatever an abandoned step left is void)
-    e->status[2 * e->cur_set] = e->status[2 * e->cur_set + 1] = 0;
+        if (e->setbuf[q][id]) e->buf[id] = e->setbuf[q][id];
+    e->status_slot = q;  // this launch's kernels raise this set's flags (cleared here: whatever an abandoned step left is void)
+    e->status[2 * q] = e->status[2 * q + 1] = 0;
     ++e->epoch;  // (captured graphs hold the other set's pointers)
-    HIPCHK(hipStreamWaitEvent(e->stream, e->evStaged[e->cur_set], 0));  // the side stream forks from here, so it inherits the wait
-    HIPCHK(hipStreamWaitEvent(e->pre, e->evStaged[e->cur_set], 0));
-    HIPCHK(hipStreamWaitEvent(e->side, e->evStaged[e->cur_set], 0));
-    const bool lat = e->set_latency[e->cur_set];
-    // latency mode: one queue for the whole step; P_lin is read from the page-locked staging block (its device copy arrives behind evStagedAll);
+    HIPCHK(hipStreamWaitEvent(e->stream, e->evStagedR[lr], 0));  // the side stream forks from here, so it inherits the wait
+    HIPCHK(hipStreamWaitEvent(e->pre, e->evStagedR[lr], 0));
+    HIPCHK(hipStreamWaitEvent(e->side, e->evStagedR[lr], 0));
+    // latency mode: one queue for the whole step; P_lin is read from the page-locked staging block (its device copy arrives behind evStagedAllR);
     // P_l goes to mapped host memory from the kernel that forms it (REDUCE, or the AP epilogue) unless the NNLO pass adds to it afterwards
-    // (pipelined direct-P_l steps too: at 0.13 ms of GPU work per step the 20 us the host spends in hipMemcpyAsync count; the kernel's stores to mapped
-    // memory cost the GPU what the DMA cost it)
-    const bool plk_direct = (lat || (e->plk_direct && !e->comm)) && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !e->c.with_nnlo;
+    const bool plk_direct = (lat || (e->plk_direct && !e->comm)) && e->plk_host[q] && (mask & EFTB_S_REDUCE) && !c.with_nnlo;
     // ... from the kernel that forms it in latency mode (one kernel less on the dependent sampler's chain); in pipelined steps by a small copy
     // kernel behind the step (round 3 stored from ap_plk_kernel: 1.6 MB of 8-byte PCIe stores kept every SIMD's waves resident for ~25 us)
     const bool plk_tail = plk_direct && !lat && !e->ap_plk_nodes;
     double* pin_dev = e->buf[EFTB_B_PIN];
-    if (lat) e->buf[EFTB_B_PIN] = e->stage_host[e->cur_set] + e->stage_off[EFTB_B_PIN];
+    if (lat) e->buf[EFTB_B_PIN] = e->stage_host[cmds[0].slot] + e->slot_off[EFTB_B_PIN];
     e->lat_run = lat;
-    e->plk_host_out = plk_direct && !plk_tail ? e->plk_host[e->cur_set] : nullptr;
+    e->plk_host_out = plk_direct && !plk_tail ? e->plk_host[q] : nullptr;
     e->inputs_settled = e->allow_back = !lat;
-    const int rc = run_stages(e, mask, B);
+    const int rc = run_stages(e, mask, Bt);
     e->inputs_settled = e->allow_back = false;
     e->lat_run = false;
     e->plk_host_out = nullptr;
     e->buf[EFTB_B_PIN] = pin_dev;
     e->status_slot = eftb_engine::NSETS;
     if (rc) return rc;
-    hipStream_t last = e->back_pending ? e->back : e->stream;  // the step ends where its back half ran
-    if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAll[e->cur_set], 0));  // (the set is not "done" before its own upload is)
-    if (plk_tail) {
-        const size_t n = (size_t)B * e->cur_nl * e->cur_nx;
-        hipLaunchKernelGGL(copy16_kernel, dim3(48), dim3(256), 0, last, e->buf[EFTB_B_PLK], e->plk_host[e->cur_set], n);
+    for (int j = 0; j < n; ++j) {  // shape of the output rows (after the pipeline operator, if the mask has one)
+        eftb_engine::StepRec& r = e->rec[cmds[j].step % eftb_engine::SUBREC];
+        r.nl = e->cur_nl; r.nx = e->cur_nx;
     }
-    if (e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
-        HIPCHK(hipMemcpyAsync(e->plk_host[e->cur_set], e->buf[EFTB_B_PLK], (size_t)B * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
-    HIPCHK(hipEventRecord(e->evSetDone[e->cur_set], last));
-    if (e->back_pending && e->plk_host[e->cur_set] && (mask & EFTB_S_REDUCE) && !plk_direct)
+    hipStream_t last = e->back_pending ? e->back : e->stream;  // the launch ends where its back half ran
+    if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAllR[lr], 0));  // (the set is not "done" before its own upload is)
+    if (plk_tail) {
+        const size_t cnt = (size_t)Bt * e->cur_nl * e->cur_nx;
+        hipLaunchKernelGGL(copy16_kernel, dim3(48), dim3(256), 0, last, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
+    }
+    if (e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
+        HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], (size_t)Bt * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
+    HIPCHK(hipEventRecord(e->evSetDone[q], last));
+    if (e->back_pending && e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], last));  // whoever joins the back half also waits for the copy
     if (e->done_words) {
-        if (hipStreamWriteValue64(last, const_cast<unsigned long long*>(e->set_done) + e->cur_set, step + 1, 0) == hipSuccess) e->set_word[e->cur_set] = step + 1;
+        if (hipStreamWriteValue64(last, const_cast<unsigned long long*>(e->set_done) + q, L + 1, 0) == hipSuccess) e->set_word[q] = L + 1;
         else {
             (void)hipGetLastError();
-            e->done_words = false;  // this runtime refuses the command: event queries from here on (the words of the earlier steps stay valid)
+            e->done_words = false;  // this runtime refuses the command: event queries from here on (the words of the earlier launches stay valid)
         }
     }
     return 0;
 }
 
+// issue_group + bookkeeping shared by both issuing threads: the steps' records, the clocks, the publication of "issued"
+static int issue_and_publish(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, bool lat, bool by_caller) {
+    const auto ti0 = std::chrono::steady_clock::now();
+    const int q_before = e->cur_set;
+    const unsigned long long L_before = e->launch_seq;
+    const int rc = issue_group(e, cmds, n, lat);
+    if (rc && e->launch_seq == L_before) {  // failed before the set was taken: the steps still need records that say so
+        for (int j = 0; j < n; ++j) {
+            eftb_engine::StepRec& r = e->rec[cmds[j].step % eftb_engine::SUBREC];
+            r.set = q_before; r.row = 0; r.B = cmds[j].B; r.launch = ~0ull;
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        const int ri = (int)(cmds[j].step % eftb_engine::SUBREC);
+        e->rec[ri].rc = rc;
+        if (rc) snprintf(e->sub_err[ri], sizeof e->sub_err[ri], "%s", g_err.c_str());
+    }
+    if (e->sub_stats) {
+        e->issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ti0).count();
+        e->issue_n += n;
+        ++e->launch_n;
+        if (by_caller) e->inline_n += n;
+    }
+    e->steps_launched.store(cmds[n - 1].step + 1, std::memory_order_release);
+    return rc;
+}
+
 static inline void cpu_pause() { __builtin_ia32_pause(); }
+
+// has staged launch L finished?  (issuing thread; its completion word if one was enqueued, else its set's event)
+static bool launch_finished(eftb_engine* e, unsigned long long L) {
+    const int q = e->lring_set[L % eftb_engine::NLRING];
+    if (e->set_word[q] >= L + 1) return e->set_done[q] >= L + 1;   // (words grow with the launch number: a later launch on the set says it too)
+    return hipEventQuery(e->evSetDone[q]) == hipSuccess;
+}
 
 // ---- submission thread (see eftb_engine::SubCmd)
 static void sub_main(eftb_engine* e) {
@@ -2084,21 +2183,26 @@ static void sub_main(eftb_engine* e) {
             e->sub_sleeping.store(false, std::memory_order_seq_cst);
             spins = 0;
         }
-        const eftb_engine::SubCmd c = e->sub_ring[head % eftb_engine::SUBQ];
-        e->set_latency[c.set] = false;   // a queued step has company on the GPU: three-stream layout
-        const auto ti0 = std::chrono::steady_clock::now();
-        int rc = stage_issue(e, c.set, c.B, c.has_rows != 0, false);
-        if (!rc) {
-            e->cur_set = (c.set + eftb_engine::NSETS - 1) % eftb_engine::NSETS;   // (= what it is anyway, unless an earlier launch failed half way)
-            rc = run_staged_issue(e, c.mask, c.B, c.step);
+        while (e->sub_hold.load(std::memory_order_acquire) && !e->sub_stop.load(std::memory_order_acquire)) cpu_pause();
+        // flow control: with sub_inflight launches still running the queue is left to grow -- what has piled up by the time one of them finishes
+        // leaves as one launch (coalesce_max steps at most)
+        while (e->launch_done < e->launch_seq && launch_finished(e, e->launch_done)) ++e->launch_done;
+        for (unsigned wspins = 0; (long long)(e->launch_seq - e->launch_done) >= e->sub_inflight;) {
+            if (launch_finished(e, e->launch_done)) { ++e->launch_done; continue; }
+            for (int i = 0; i < 16; ++i) cpu_pause();
+            if ((++wspins & 0xfffff) == 0 && e->sub_stop.load(std::memory_order_acquire)) break;
         }
-        e->cur_set = c.set;
-        if (e->sub_stats) { e->issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ti0).count(); ++e->issue_n; }
-        const int r = (int)(c.step % eftb_engine::SUBREC);
-        e->sub_rc[r] = rc;
-        if (rc) snprintf(e->sub_err[r], sizeof e->sub_err[r], "%s", g_err.c_str());
-        ++head;
-        e->steps_launched.store(c.step + 1, std::memory_order_release);
+        eftb_engine::SubCmd grp[8];
+        int n = 0, Bt = 0;
+        const unsigned long long tail = e->sub_tail.load(std::memory_order_acquire);
+        while (head + n < tail && n < e->coalesce_max) {
+            const eftb_engine::SubCmd& c = e->sub_ring[(head + n) % eftb_engine::SUBQ];
+            if (n && (c.mask != grp[0].mask || c.has_rows != grp[0].has_rows || Bt + c.B > e->c.max_batch || e->check_finite)) break;
+            grp[n++] = c;
+            Bt += c.B;
+        }
+        (void)issue_and_publish(e, grp, n, false, false);
+        head += n;
         e->sub_head.store(head, std::memory_order_release);
     }
 }
@@ -2110,6 +2214,7 @@ static inline bool sub_quiescent(const eftb_engine* e) {
 
 static inline void sub_drain(eftb_engine* e) {
     if (!e->sub_started) return;
+    e->sub_hold.store(false, std::memory_order_release);   // (an entry point that needs the queue empty ends a test's hold)
     while (!sub_quiescent(e)) cpu_pause();
 }
 
@@ -2137,7 +2242,7 @@ static int sub_wait_launched(eftb_engine* e, unsigned long long step, const char
         }
     }
     const int r = (int)(step % eftb_engine::SUBREC);
-    if (e->sub_rc[r]) return fail("%s: the launch of this step failed: %s", who, e->sub_err[r]);
+    if (e->rec[r].rc) return fail("%s: the launch of this step failed: %s", who, e->sub_err[r]);
     return 0;
 }
 
@@ -2146,102 +2251,94 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     if (!e || !Pin || !f) return fail("eftb_stage_inputs: null argument");
     if (!e->finalized) return fail("eftb_stage_inputs: engine not finalized");
     const eftb_config& c = e->c;
-    if (B < 1 || B > c.max_batch) return fail("eftb_stage_inputs: batch %d outside [1, %d]", B, c.max_batch);
+    const int step_max = c.step_batch > 0 ? c.step_batch : c.max_batch;
+    if (B < 1 || B > step_max) return fail("eftb_stage_inputs: batch %d outside [1, %d]", B, step_max);
     if (c.with_ap && (!DA || !H)) return fail("eftb_stage_inputs: DA and H are required when with_ap=1");
     if (rows && !e->like_ndata) return fail("eftb_stage_inputs: rows need eftb_set_likelihood");
     if (int rc = validate_inputs(c, "eftb_stage_inputs", B, Pin, f, DA, H)) return rc;
     if (!e->cpy) {
         sub_drain(e);
         if (int rc = staged_setup(e)) return rc;
-        e->p_set = e->cur_set;
     }
     HIPCHK(hipSetDevice(c.device));
-    const int t = (e->p_set + 1) % eftb_engine::NSETS;  // the set after the current one: the oldest, fetched (or abandoned) by now
-    // the step that used this set last has been issued (its events exist) ...
-    if (e->set_step[t])
-        if (int rc = sub_wait_launched(e, e->set_step[t] - 1, "eftb_stage_inputs")) (void)rc;  // (a failed launch left nothing to wait for; its fetch reports it)
-    HIPCHK(hipEventSynchronize(e->set_latency[t] ? e->evStagedAll[t] : e->evStaged[t]));  // ... and its staging block is free again (the previous upload from it has finished)
-    // (a latency-mode step's first kernel read P_lin from the staging block itself: that step must be over too -- it almost always is)
-    if (e->set_latency[t])
-        if (int rc = spin_event(e->evSetDone[t], "eftb_stage_inputs", "the latency-mode step that read this staging block")) return rc;
+    const int slot = (int)(e->steps_submitted % eftb_engine::NSLOT);  // the oldest staging block: its step was fetched (or abandoned) long ago
+    // the step that used this block last has been issued (its events exist) ...
+    if (e->slot_step[slot]) {
+        (void)sub_wait_launched(e, e->slot_step[slot] - 1, "eftb_stage_inputs");  // (a failed launch left nothing to wait for; its fetch reports it)
+        const eftb_engine::StepRec& r = e->rec[(e->slot_step[slot] - 1) % eftb_engine::SUBREC];
+        if (r.launch != ~0ull) {
+            const int lr = (int)(r.launch % eftb_engine::NLRING);
+            // ... and the block is free again (the upload from it has finished; a latency-mode step's first kernel read P_lin from the block itself:
+            // that step must be over too -- it almost always is)
+            HIPCHK(hipEventSynchronize(e->slot_latency[slot] ? e->evStagedAllR[lr] : e->evStagedR[lr]));
+            if (e->slot_latency[slot])
+                if (int rc = spin_event(e->evSetDone[r.set], "eftb_stage_inputs", "the latency-mode step that read this staging block")) return rc;
+        }
+    }
     // Who issues the step?  With earlier steps still queued or in flight, the submission thread (this call only fills the staging block).  With
     // the engine quiescent and the GPU idle -- a sampler whose next step depends on this step's result -- this thread, at once, as a latency-mode
     // step if that is enabled (see latency_auto)
     const bool quiet = sub_quiescent(e);
     const bool gpu_idle = quiet && hipEventQuery(e->evSetDone[e->cur_set]) == hipSuccess;
-    if (e->sub_mode == 2 || (e->sub_mode == 1 && !gpu_idle)) {
-        const auto tf0 = std::chrono::steady_clock::now();
-        stage_fill(e, t, B, Pin, f, DA, H, bias, rows);
-        if (e->sub_stats) e->fill_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf0).count();
-        e->dfr_set = t; e->dfr_B = B; e->dfr_rows = rows ? 1 : 0;
-        e->staged_B = B;
-        return 0;
-    }
-    sub_drain(e);
+    e->stg_inline = !(e->sub_mode == 2 || (e->sub_mode == 1 && !gpu_idle));
     // nothing in flight (the step launched last has finished, or none was launched): the step staged here has the GPU to itself -- see latency_auto
-    const bool lat = e->latency_auto && e->staged_B == 0 && e->stage_off[EFTB_B_PIN] == 0 && gpu_idle;
-    e->set_latency[t] = lat;
-    if (lat) hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, e->stream);  // (see wake_kernel: its start-up runs under the host copies below)
-    const auto tf0 = std::chrono::steady_clock::now();
-    stage_fill(e, t, B, Pin, f, DA, H, bias, rows);
-    const auto tf1 = std::chrono::steady_clock::now();
-    if (int rc = stage_issue(e, t, B, rows != nullptr, lat)) return rc;
-    if (e->sub_stats) {
-        e->fill_ns += std::chrono::duration<double, std::nano>(tf1 - tf0).count();
-        e->issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf1).count();
+    e->stg_lat = e->stg_inline && e->latency_auto && gpu_idle && e->slot_off[EFTB_B_PIN] == 0;
+    e->slot_latency[slot] = e->stg_lat;
+    if (e->stg_lat) {
+        sub_drain(e);
+        hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, e->stream);  // (see wake_kernel: its start-up runs under the host copies below)
     }
-    e->dfr_set = -1;
-    e->staged_B = B;
+    const auto tf0 = std::chrono::steady_clock::now();
+    stage_fill(e, slot, B, Pin, f, DA, H, bias, rows);
+    if (e->sub_stats) e->fill_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf0).count();
+    e->stg_slot = slot; e->stg_B = B; e->stg_rows = rows ? 1 : 0;
     return 0;
 }
 
 int eftb_run_staged(eftb_engine* e, int mask, int B) {
     if (!e) return fail("eftb_run_staged: null engine");
-    if (!e->cpy || e->staged_B == 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
-    if (B != e->staged_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->staged_B);
+    if (!e->cpy || e->stg_slot < 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
+    if (B != e->stg_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->stg_B);
     HIPCHK(hipSetDevice(e->c.device));
-    e->staged_B = 0;
     const unsigned long long step = e->steps_submitted;
-    if (e->dfr_set >= 0) {  // queued: the submission thread uploads the staging block and launches the step
+    const eftb_engine::SubCmd cmd{e->stg_slot, mask, B, e->stg_rows, step};
+    if (!e->stg_inline) {  // queued: the submission thread uploads the staging block and launches the step (with whatever else is queued by then)
         if (!e->sub_started) {
             e->sub_stop.store(false);
             e->sub_thread = std::thread(sub_main, e);
             e->sub_started = true;
         }
-        // (never more than NSETS - 1 pending: each owns a set, and eftb_stage_inputs has waited for the set's previous user)
+        // (never more than NSLOT - 1 pending: each owns a staging block, and eftb_stage_inputs has waited for the block's previous user)
         const unsigned long long tail = e->sub_tail.load(std::memory_order_relaxed);
-        e->sub_ring[tail % eftb_engine::SUBQ] = eftb_engine::SubCmd{e->dfr_set, mask, B, e->dfr_rows, step};
+        e->sub_ring[tail % eftb_engine::SUBQ] = cmd;
         e->sub_tail.store(tail + 1, std::memory_order_release);
         if (e->sub_sleeping.load(std::memory_order_seq_cst)) {
             std::lock_guard<std::mutex> lk(e->sub_mx);
             e->sub_cv.notify_one();
         }
-        e->p_set = e->dfr_set;
-        e->set_step[e->p_set] = step + 1;
-        e->dfr_set = -1;
+        e->slot_step[e->stg_slot] = step + 1;
+        e->stg_slot = -1;
         ++e->steps_submitted;
         return 0;
     }
     sub_drain(e);
-    const auto ti0 = std::chrono::steady_clock::now();
-    const int rc = run_staged_issue(e, mask, B, step);
-    if (e->sub_stats) { e->issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ti0).count(); ++e->issue_n; ++e->inline_n; }
-    e->p_set = e->cur_set;
-    if (rc) return rc;
-    e->sub_rc[step % eftb_engine::SUBREC] = 0;
-    e->set_step[e->p_set] = step + 1;
+    // (launch bookkeeping of the issuing thread: bring "finished" up to date, as the submission thread does before its launches)
+    while (e->launch_done < e->launch_seq && launch_finished(e, e->launch_done)) ++e->launch_done;
+    const int rc = issue_and_publish(e, &cmd, 1, e->stg_lat, true);
+    e->slot_step[e->stg_slot] = step + 1;
+    e->stg_slot = -1;
     ++e->steps_submitted;
-    e->steps_launched.store(step + 1, std::memory_order_release);
-    return 0;
+    return rc;
 }
 
-// the step that ran on set t has finished (its completion word, or its event)
-static int wait_step_done(eftb_engine* e, int t, unsigned long long step, const char* who) {
+// the launch that carried a step has finished (its completion word, or its set's event)
+static int wait_step_done(eftb_engine* e, const eftb_engine::StepRec& r, const char* who) {
     const auto tw0 = std::chrono::steady_clock::now();
     int rc = 0;
-    if (e->set_word[t] == step + 1) {   // (else: no completion write was enqueued for this step -- EFTB_DONE_WORDS=0, or the runtime refused it)
+    const int t = r.set;
+    if (e->set_word[t] >= r.launch + 1) {   // (else: no completion write was enqueued for this launch -- EFTB_DONE_WORDS=0, or the runtime refused it)
         static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
-        for (unsigned spins = 0; e->set_done[t] < step + 1; ++spins) {
+        for (unsigned spins = 0; e->set_done[t] < r.launch + 1; ++spins) {
             cpu_pause();
             if ((spins & 0xfffff) == 0xfffff && std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count() > limit_s) {
                 rc = fail("%s: the step did not finish within %.0f s (EFTB_FETCH_TIMEOUT_S)", who, limit_s);
@@ -2256,31 +2353,41 @@ static int wait_step_done(eftb_engine* e, int t, unsigned long long step, const 
     return rc;
 }
 
-// set and step of the staged step `back` steps before the one submitted last, once its launch has been issued
-static int staged_step(eftb_engine* e, const char* who, int back, int* set) {
-    if (back < 0 || back >= eftb_engine::NSETS) return fail("%s: back must be 0 (the step launched last) ... 7 (that many steps before it)", who);
+// record of the staged step `back` steps before the one submitted last, once its launch has been issued
+static int staged_step(eftb_engine* e, const char* who, int back, const eftb_engine::StepRec** rec) {
+    if (back < 0 || back >= eftb_engine::NSETS) return fail("%s: back must be 0 (the step launched last) ... %d (that many steps before it)", who, eftb_engine::NSETS - 1);
     if (!e->cpy) return fail("%s: no staged run yet", who);
     if ((unsigned long long)back >= e->steps_submitted)
         return fail("%s: back = %d, but only %llu staged step(s) have been launched", who, back, e->steps_submitted);
-    *set = (e->p_set + eftb_engine::NSETS - back) % eftb_engine::NSETS;  // back = 7 is the set that the next eftb_stage_inputs refills
-    return sub_wait_launched(e, e->steps_submitted - 1 - back, who);
+    const unsigned long long step = e->steps_submitted - 1 - back;
+    if (int rc = sub_wait_launched(e, step, who)) return rc;
+    *rec = &e->rec[step % eftb_engine::SUBREC];
+    return 0;
+}
+
+// where a step's rows of a per-set output block start: P_l [row][nl][nx]; ln P per likelihood point [row / ntr][MARG_OUT]
+static inline size_t step_offset(const eftb_engine* e, const eftb_engine::StepRec& r, int id) {
+    return id == EFTB_B_PLK ? (size_t)r.row * r.nl * r.nx : (size_t)(r.row / e->ntr) * MARG_OUT;
 }
 
 int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count) {
     if (!e || !host) return fail("eftb_fetch_back: null argument");
     if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_back: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
     if (count > e->buf_elems[id]) return fail("eftb_fetch_back: buffer %d holds %zu elements, asked %zu", id, e->buf_elems[id], count);
-    int t = 0;
-    if (int rc = staged_step(e, "eftb_fetch_back", back, &t)) return rc;
+    const eftb_engine::StepRec* r = nullptr;
+    if (int rc = staged_step(e, "eftb_fetch_back", back, &r)) return rc;
     HIPCHK(hipSetDevice(e->c.device));
-    if (int rc = wait_step_done(e, t, e->steps_submitted - 1 - back, "eftb_fetch_back")) return rc;
+    const int t = r->set;
+    if (int rc = wait_step_done(e, *r, "eftb_fetch_back")) return rc;
+    const size_t off = step_offset(e, *r, id);
+    if (off + count > e->buf_elems[id]) return fail("eftb_fetch_back: the step's rows start at element %zu of %zu, asked %zu", off, e->buf_elems[id], count);
     if (id == EFTB_B_PLK && e->plk_host[t])
-        memcpy(host, e->plk_host[t], count * sizeof(double));  // copied out by the DMA engine behind the step
+        memcpy(host, e->plk_host[t] + off, count * sizeof(double));  // copied out behind the step
     else if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
-        HIPCHK(hipMemcpy(host, e->setbuf[t][id], count * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(host, e->setbuf[t][id] + off, count * sizeof(double), hipMemcpyDeviceToHost));
     else
-        memcpy(host, e->setbuf[t][id], count * sizeof(double));  // the results are already in (mapped) host memory
-    return check_status(e, "eftb_fetch_back", t);  // this step's own flags only: the steps queued behind it report with their own fetch
+        memcpy(host, e->setbuf[t][id] + off, count * sizeof(double));  // the results are already in (mapped) host memory
+    return check_status(e, "eftb_fetch_back", t);  // this launch's own flags only: the steps queued behind it report with their own fetch
 }
 
 int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) { return eftb_fetch_back(e, 1, id, host, count); }
@@ -2288,24 +2395,27 @@ int eftb_fetch_previous(eftb_engine* e, int id, double* host, size_t count) { re
 int eftb_fetch_view(eftb_engine* e, int back, int id, const double** block, size_t* count) {
     if (!e || !block) return fail("eftb_fetch_view: null argument");
     if (id != EFTB_B_PLK && id != EFTB_B_LOGP) return fail("eftb_fetch_view: only EFTB_B_PLK and EFTB_B_LOGP are per-set outputs");
-    int t = 0;
-    if (int rc = staged_step(e, "eftb_fetch_view", back, &t)) return rc;
+    const eftb_engine::StepRec* r = nullptr;
+    if (int rc = staged_step(e, "eftb_fetch_view", back, &r)) return rc;
     HIPCHK(hipSetDevice(e->c.device));
+    const int t = r->set;
     const double* p = id == EFTB_B_PLK ? (e->plk_host[t] ? e->plk_host[t] : (e->staged_plk_device ? nullptr : e->setbuf[t][id])) : e->setbuf[t][id];
     if (!p) return fail("eftb_fetch_view: P_l of this engine stays in device memory for the RCCL exchange (eftb_gathered_view hands out the gathered block)");
-    if (int rc = wait_step_done(e, t, e->steps_submitted - 1 - back, "eftb_fetch_view")) return rc;
-    *block = p;
-    if (count) *count = e->buf_elems[id];
+    if (int rc = wait_step_done(e, *r, "eftb_fetch_view")) return rc;
+    const size_t off = step_offset(e, *r, id);
+    *block = p + off;
+    if (count) *count = e->buf_elems[id] - off;
     return check_status(e, "eftb_fetch_view", t);
 }
 
-int eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[5]) {
+int eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[6]) {
     if (!e) return fail("eftb_submit_stats: null engine");
     sub_drain(e);
     if (out) {
         out[0] = (double)e->issue_n; out[1] = (double)e->inline_n; out[2] = e->issue_ns * 1e-3; out[3] = e->fill_ns * 1e-3; out[4] = e->wait_ns * 1e-3;
+        out[5] = (double)e->launch_n;
     }
-    if (reset) { e->issue_n = e->inline_n = 0; e->issue_ns = e->fill_ns = e->wait_ns = 0.0; }
+    if (reset) { e->issue_n = e->inline_n = e->launch_n = 0; e->issue_ns = e->fill_ns = e->wait_ns = 0.0; }
     e->sub_stats = enable != 0;
     return 0;
 }
@@ -2422,7 +2532,7 @@ int eftb_gather_plk(eftb_engine* e, int B, int root, double* host_out) {
 
 // waits for the copy-out of the exchange `which` exchanges back and returns where its block sits in host memory
 static int gathered_ready(eftb_engine* e, const char* who, int which, int* slot) {
-    if (which < 0 || which >= eftb_engine::NSETS) return fail("%s: `back` must be 0 (the last exchange enqueued) ... 7 (that many exchanges before it)", who);
+    if (which < 0 || which >= eftb_engine::NSETS) return fail("%s: `back` must be 0 (the last exchange enqueued) ... %d (that many exchanges before it)", who, eftb_engine::NSETS - 1);
     const int q = (e->gather_slot + eftb_engine::NSETS - which) % eftb_engine::NSETS;
     if (!e->gathered2[q] || !e->gath_elems[q]) return fail("%s: no such exchange yet", who);
     HIPCHK(hipSetDevice(e->c.device));

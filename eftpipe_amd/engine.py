@@ -20,7 +20,10 @@ ROWS = dict(P11l=slice(0, 3), Pctl=slice(3, 9), Ploopl=slice(9, 21), Pstl=slice(
 
 
 class Engine:
-    def __init__(self, cfg: EngineConfig, max_batch: int = 1, device: int = 0, loop_cache=None):
+    def __init__(self, cfg: EngineConfig, max_batch: int = 1, device: int = 0, loop_cache=None, coalesce: int = 1):
+        """max_batch: cosmologies per call / per staged step.  coalesce > 1: the device state is sized for coalesce x max_batch, and staged steps
+        that are still queued when the library's submission thread reaches them leave as one launch of up to that many cosmologies (every step is
+        still fetched by itself; same bits per cosmology)."""
         self.lib = L.load()
         self.cfg = cfg
         t = self.tables = build_tables(cfg, loop_cache)
@@ -36,7 +39,8 @@ class Engine:
         self._plk_direct = False
         self._step_ptr, self._step_n, self._views = C.c_void_p(), C.c_size_t(), {}
         c = L.Config()
-        c.device, c.Nl, c.Nk, c.Nkin, c.max_batch = device, cfg.Nl, self.Nk, self.Nkin, self.max_batch
+        c.device, c.Nl, c.Nk, c.Nkin, c.max_batch = device, cfg.Nl, self.Nk, self.Nkin, self.max_batch * max(1, int(coalesce))
+        c.step_batch = self.max_batch if coalesce > 1 else 0
         c.with_resum, c.with_ap, c.ap_stochastic = int(cfg.with_resum), int(cfg.with_ap), int(cfg.APst)
         c.nmu = cfg.nbinsmu
         c.ntail = t["lnx_tail"].size
@@ -184,13 +188,18 @@ class Engine:
         2: every step is queued, also one that finds the GPU idle (tests)."""
         L.check(self.lib.eftb_set_option(self._h, 8, int(flag)))
 
+    def hold_submissions(self, flag):
+        """Tests: True makes the submission thread leave queued steps in the queue until hold_submissions(False) (so that they leave together)."""
+        L.check(self.lib.eftb_set_option(self._h, 9, int(bool(flag))))
+
     def submit_stats(self, enable=True, reset=True):
         """Host-side cost of the staged steps since the last reset (``eftb_submit_stats``): dict with steps, steps issued by the caller's thread, and
         microseconds per step spent issuing (either thread), filling the staging block, and waiting for results in fetch calls."""
-        out = np.zeros(5)
+        out = np.zeros(6)
         L.check(self.lib.eftb_submit_stats(self._h, int(bool(enable)), int(bool(reset)), L.dptr(out)))
         n = max(out[0], 1.0)
-        return {"steps": int(out[0]), "issued_by_caller": int(out[1]), "issue_us_per_step": out[2] / n, "fill_us_per_step": out[3] / n, "wait_us_per_step": out[4] / n}
+        return {"steps": int(out[0]), "launches": int(out[5]), "issued_by_caller": int(out[1]), "issue_us_per_step": out[2] / n, "fill_us_per_step": out[3] / n,
+                "wait_us_per_step": out[4] / n}
 
     def set_ap_stochastic(self, flag):
         L.check(self.lib.eftb_set_option(self._h, 0, int(bool(flag))))
@@ -379,9 +388,9 @@ class Engine:
         return view
 
     def fetch_previous(self, name, shape, out=None, back=1, copy=True):
-        """PLK / LOGP of the step launched `back` (0: the last one; 1 ... 7) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
+        """PLK / LOGP of the step launched `back` (0: the last one; 1 ... 15) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
         to fill).  back=3 keeps three steps queued while the host works (see ``pipeline``).  copy=False: a read-only view of the engine's page-locked
-        host copy of the block (no 1.5 MB memcpy on the sampler's critical path), valid until seven more steps have been staged."""
+        host copy of the block (no 1.5 MB memcpy on the sampler's critical path), valid until fifteen more steps have been staged."""
         if not copy:
             ptr, n = C.POINTER(C.c_double)(), C.c_size_t()
             L.check(self.lib.eftb_fetch_view(self._h, int(back), L.B[name], C.byref(ptr), C.byref(n)))
@@ -400,14 +409,14 @@ class Engine:
         """Generator over a stream of steps (dicts with Pin, f, DA, H and bias and/or rows): stages step i + 1 and launches it
         before fetching the results of step i, so the GPU never waits for the host.  Yields one result per step, in order:
         P_l [B, nl, nx] (fetch="PLK", needs bias) or the raw LOGP block [walkers, 26] (fetch="LOGP", needs rows + a likelihood).
-        depth: steps kept queued on the GPU while the oldest one is copied out (1 ... 7; default 3, 4 for direct-P_l runs, whose
+        depth: steps kept queued on the GPU while the oldest one is copied out (1 ... 15; default 3, 4 for direct-P_l runs, whose
         steps are four pipeline stages deep)."""
         if mask is None:
             mask = self.full_mask(reduce=(fetch == "PLK")) | (L.S_LOGP if fetch == "LOGP" else 0)
         if depth is None:
             depth = 4 if self._plk_direct else 3
-        if not 1 <= int(depth) <= 7:
-            raise ValueError("depth must be 1 ... 7 (the engine rotates eight sets of per-step inputs / outputs)")
+        if not 1 <= int(depth) <= 15:
+            raise ValueError("depth must be 1 ... 15 (the engine rotates sixteen sets of per-launch inputs / outputs)")
         depth = int(depth)
         nl, nx = self.out_dims()
         shape_of = lambda B: (B, nl, nx) if fetch == "PLK" else (B // self.ntracers, 2 + 24)

@@ -47,6 +47,9 @@ typedef struct eftb_config {
                               hold arange(70, 200, 2.5), the rest repeat the last value and carry no weight   pybird.py:553-556, 1382-1400 */
     int32_t dual_coef;     /* Common.IRcutoff = "loop" | "resum": the xi-space pieces use a second FFTLog operator (EFTB_T_GCT2)
                               pybird.py:1151-1160  ("all" needs no switch: both operators are the cut one) */
+    int32_t step_batch;    /* largest batch of ONE staged step (0 = max_batch).  With step_batch < max_batch, staged steps that are still queued
+                              when the submission thread reaches them are launched TOGETHER, as one batch of up to max_batch cosmologies (same
+                              bits per cosmology; each step is still fetched by itself).  No reference counterpart. */
 } eftb_config;
 
 /* Constant tables (built on the host by eftpipe_amd/tables.py; shapes in that file).  The first-stage operators are stored as GEMM operands,
@@ -157,6 +160,8 @@ enum eftb_option {
                                  0 (default): templates first, as the reference computes them (BirdSnapshot semantics) */
     EFTB_O_TIME_KERNEL = 7,   /* which launches EFTB_O_TIME_DOMINANT brackets, a set of: 1 (default) the resummation kernel, 2 the synthesis launch of
                                  the loop stages (synth_kernel), 4 the heaviest AP kernel (ap_weights_kernel; direct-P_l runs: ap_plk_kernel) -- measurement only */
+    EFTB_O_SUBMIT_HOLD = 9,   /* tests: 1 makes the submission thread leave queued steps where they are until the option is cleared (or any entry point
+                                 that needs the queue empty is called) -- the steps queued meanwhile then leave together, as eftb_config.step_batch allows */
     EFTB_O_SUBMIT_THREAD = 8  /* 1 (default; also EFTB_SUBMIT_THREAD=0/1): staged steps handed in while earlier ones are still queued or running are
                                  issued by a submission thread inside the library -- eftb_stage_inputs fills the page-locked block, eftb_run_staged
                                  queues the step and returns; the thread uploads the block and launches the kernels (50-95 us of HIP calls per step
@@ -259,15 +264,15 @@ int  eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f
 int  eftb_run_staged(eftb_engine* e, int stage_mask, int B);
 /* EFTB_B_PLK or EFTB_B_LOGP of the step before the one in flight (waits only for that step). */
 int  eftb_fetch_previous(eftb_engine* e, int buffer_id, double* host, size_t count);
-/* The same for the step launched `back` (0 = the last one itself, 1 ... 7) steps before the last one.  The engine keeps eight sets of per-step inputs / outputs, so the
+/* The same for the step launched `back` (0 = the last one itself, 1 ... 15) steps before the last one.  The engine keeps sixteen sets of per-launch inputs / outputs, so the
  * loop  stage(i); run_staged(i); fetch_back(3) [= step i - 3]  keeps THREE steps queued on the GPU while the host copies results out and
  * prepares the next inputs: the inputs of step i + 1 are then staged before the back half of step i - 1 has finished, and the look-ahead
  * of consecutive steps never runs dry (with back = 2 the look-ahead stream idled ~0.1 ms per step waiting for the host).  Direct-P_l runs
- * (EFTB_O_PLK_DIRECT) are four pipeline stages deep -- front, syntheses + contraction, resummation, AP -- and want back = 4 or 5; the set
- * read with back = 7 is the one the next eftb_stage_inputs refills. */
+ * (EFTB_O_PLK_DIRECT) are four pipeline stages deep -- front, syntheses + contraction, resummation, AP -- and want back = 4 or more; the set
+ * read with back = 15 is the one the sixteenth launch from there refills. */
 int  eftb_fetch_back(eftb_engine* e, int back, int buffer_id, double* host, size_t count);
 /* The same results without the host copy: *block points at the engine's page-locked host copy of the step's EFTB_B_PLK / EFTB_B_LOGP block
- * (*count = its capacity in elements), valid until NSETS - 1 = 7 more steps have been staged.  For samplers that consume P_l in place (the
+ * (*count = its capacity in elements), valid until NSETS - 1 = 15 more steps have been staged.  For samplers that consume P_l in place (the
  * dependent loop of reference likelihood.py:570-594: chi^2 from P_l, then the next proposal). */
 int  eftb_fetch_view(eftb_engine* e, int back, int buffer_id, const double** block, size_t* count);
 /* One sampler step in one call: eftb_stage_inputs + eftb_run_staged + (back >= 0 and that many steps already behind this one)
@@ -278,8 +283,8 @@ int  eftb_step(eftb_engine* e, int stage_mask, int B, const double* Pin, const d
 
 /* Host-side cost of the staged steps, for bench.py's accounting (measurement only): enable != 0 switches the clocks on; out (may be NULL) receives
  * {steps issued, of which by the caller's thread, us spent issuing (upload kernel + launches + events, whichever thread), us spent copying inputs
- * into the staging blocks, us the caller spent waiting for results in eftb_fetch_*}; reset != 0 clears the sums. */
-int  eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[5]);
+ * into the staging blocks, us the caller spent waiting for results in eftb_fetch_*, launches that carried those steps}; reset != 0 clears the sums. */
+int  eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[6]);
 
 /* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
  * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */

@@ -209,7 +209,7 @@ def test_many_exchanges_then_fetch():
     the launch counter and the CHECK_FINITE option must be what they were, and every gathered block must carry its own step."""
     import bench
 
-    B, K = 8, 19
+    B, K = 8, 37
     eng, _ = _engine(B)
     eng.set_check_finite(True)
     eng.set_latency_mode(False)
@@ -225,7 +225,7 @@ def test_many_exchanges_then_fetch():
         if i >= 2:
             assert np.array_equal(eng.fetch_gathered(B, back=2)[0], ref[(i - 2) % 3]), i
     eng.sync()
-    for back in range(0, 8):
+    for back in range(0, 16):
         assert np.array_equal(eng.fetch_previous("PLK", shape, back=back), ref[(K - 1 - back) % 3]), back
         assert np.array_equal(eng.fetch_previous("PLK", shape, back=back, copy=False), ref[(K - 1 - back) % 3]), back
         assert np.array_equal(eng.fetch_gathered(B, back=back)[0], ref[(K - 1 - back) % 3]), back
@@ -302,4 +302,52 @@ def test_submission_thread_reports_a_failed_launch_with_its_step():
         else:
             with pytest.raises(Exception, match="PROJECT needs"):
                 eng.fetch_previous("PLK", shape, back=back)
+    eng.close()
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_coalesced_steps_return_the_bits_of_separate_steps(direct):
+    """Engine(coalesce=4): steps that are still queued when the submission thread reaches them leave as one launch (their staging blocks gathered
+    into one device set).  Held in the queue on purpose here, so that groups of 4, 3, 2 and 1 steps -- with different batch sizes -- are launched
+    together; every step's P_l must be the bits of the same step run by itself."""
+    import bench
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    B = 16
+    k = synth.survey_kgrid(bench.NK)
+    cfg = EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, bench.Z)), H_AP=float(synth.hubble(synth.OM_AP, bench.Z)))
+    eng = Engine(cfg, max_batch=B, coalesce=4)
+    sizes = [16, 16, 16, 16, 16, 9, 16, 5, 16, 16]
+    sets = [_draws(n, 300 + i) for i, n in enumerate(sizes)]
+    ref = [_plk(eng, s, n, direct) for s, n in zip(sets, sizes)]
+    eng.set_plk_direct(direct)
+    eng.set_latency_mode(False)
+    eng.set_submit_thread(2)   # every step through the queue
+    mask = eng.full_mask(reduce=True)
+    eng.submit_stats(enable=True, reset=True)
+    groups = [(0, 4), (4, 7), (7, 9), (9, 10)]   # steps [a, b) queued while the thread is held
+    for a, b in groups:
+        eng.hold_submissions(True)
+        for i in range(a, b):
+            s = sets[i]
+            eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
+            eng.run_staged(mask, sizes[i])
+        eng.hold_submissions(False)
+        for i in range(a, b):
+            got = eng.fetch_previous("PLK", (sizes[i], bench.NL, bench.NK), back=b - 1 - i)
+            assert np.array_equal(got, ref[i]), (a, b, i)
+            view = eng.fetch_previous("PLK", (sizes[i], bench.NL, bench.NK), back=b - 1 - i, copy=False)
+            assert np.array_equal(view, ref[i]), (a, b, i)
+    st = eng.submit_stats(enable=False)
+    assert st["steps"] == 10 and st["launches"] == 4, st
+    # a free-running loop (whatever grouping the timing produces) returns the same bits
+    K, depth = 24, 6
+    for i in range(K):
+        s = sets[i % 5]
+        view = eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], back=depth, shape=(B, bench.NL, bench.NK))
+        if i >= depth:
+            assert np.array_equal(view, ref[(i - depth) % 5]), i
+    for back in range(depth - 1, -1, -1):
+        assert np.array_equal(eng.fetch_previous("PLK", (B, bench.NL, bench.NK), back=back), ref[(K - 1 - back) % 5]), back
     eng.close()

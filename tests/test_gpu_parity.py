@@ -579,7 +579,7 @@ def test_pipelined_steps_with_changing_inputs(golden):
         assert np.array_equal(eng.fetch_previous("PLK", (B, 3, g["k"].size), back=0, copy=False), want[s]), s
         assert np.array_equal(eng.get("PLK", (B, 3, g["k"].size)), want[s]) and np.array_equal(eng.get("PIN", (B, 200)), st["Pin"]), s   # the device copies too
     with pytest.raises(L.EftbError):
-        eng.fetch_previous("PLK", (B, 3, g["k"].size), back=8)
+        eng.fetch_previous("PLK", (B, 3, g["k"].size), back=16)
     eng.close()
 
 

@@ -196,7 +196,7 @@ def test_rccl_gather_single_rank(golden):
         assert view.shape == (1, 3, 2, 50) and not view.flags.writeable
         assert np.array_equal(view[0], want) and np.array_equal(eng.fetch_gathered(3, back=back)[0], want)
     with pytest.raises(L.EftbError):
-        eng.fetch_gathered(3, back=8)
+        eng.fetch_gathered(3, back=16)
     del view
     eng.close()
 
