@@ -2715,6 +2715,187 @@ __global__ __launch_bounds__(256) void ap_plk_mom_kernel(int Nk, int nmu, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ap_plk_fused_kernel: the whole AP stage of a direct-P_l run behind the spline coefficients in ONE launch, one workgroup per (cosmology, half of
+// the k tiles), everything it gathers from in LDS:
+//   1. the mu tables of the cosmology (rho_j, L_l'(mu'_j), w_j L_l(mu_j)) and their prefix sums PS[j][l'][l][q] (what ap_prefix_kernel writes to
+//      global memory: 58 KB that every (k, interval) of ap_plk_mom_kernel gathers 2 x 288 bytes from, one HBM / L2 round trip per interval),
+//   2. the power-form pieces of the three contracted splines on every knot interval (B-spline coefficients x per-interval matrices: 48 KB),
+//   3. per k the walk over the intervals k'(mu) crosses, moments by differences of the prefix sums (header of ap_plk_mom_kernel), all reads LDS.
+// 256 workgroups of four waves at B = 128: one wave per SIMD for ~8 us instead of 4 096 waves of 156 registers for 25 us (+ 10 us of
+// ap_prefix_kernel) -- beside it the rest of the machine stays free for the other streams' kernels.  Needs (nmu + 1) 36 + Nk 12 + ... doubles
+// of LDS: k grids up to 768 points; finer grids keep ap_prefix_kernel + ap_plk_mom_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(256) void ap_plk_fused_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+                                                           const double* __restrict__ Hw, const double* __restrict__ fid, const double* __restrict__ mu,
+                                                           const double* __restrict__ wmu, const double* __restrict__ legmu, const double* __restrict__ C,
+                                                           const double* __restrict__ LOCAL, const double* __restrict__ T, const double* __restrict__ bias,
+                                                           double* __restrict__ Plk, double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0, int dbg) {
+    constexpr int NSQ = NL * NL * 4, NCHK = 7;   // 36 sequences x 7 chunks of the mu range = 252 threads
+    extern __shared__ double sm[];
+    double* s_k = sm;                                   // [Nk] (+ 1 if odd)
+    double* s_root = s_k + ((Nk + 1) & ~1);             // [nmu]
+    double* s_rho = s_root + nmu;                       // [nmu]
+    double* s_lp = s_rho + nmu;                         // [NL][nmu]  L_l'(mu')
+    double* s_wl = s_lp + NL * nmu;                     // [NL][nmu]  wmu (2l+1)/2 L_l(mu)
+    double* s_tot = s_wl + NL * nmu;                    // [NSQ][NCHK + 1]
+    double* s_ps = s_tot + NSQ * (NCHK + 1);            // [nmu + 1][NSQ]
+    double* s_pp = s_ps + (size_t)(nmu + 1) * NSQ;      // [Nk - 1][NL][4]  (16-byte aligned: every block above has an even length)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = blockIdx.x & 1, w = blockIdx.x >> 1;
+    const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
+    const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
+    // ---- 1. tables
+    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
+    for (int j = threadIdx.x; j < nmu; j += 256) {
+        const double m = mu[j];
+        const double root = sqrt(1.0 + m * m * g);
+        const double mp = m / (F * root), x2 = mp * mp, wj = wmu[j];
+        s_root[j] = root;
+        s_rho[j] = g * m * m / (1.0 + root);
+        s_lp[j] = 1.0;
+        s_lp[nmu + j] = 0.5 * (3.0 * x2 - 1.0);
+        if (NL > 2) s_lp[2 * nmu + j] = (35.0 * x2 * x2 - 30.0 * x2 + 3.0) * 0.125;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) s_wl[l * nmu + j] = wj * legmu[(size_t)l * nmu + j];
+    }
+    // ---- 2. pieces: interval i of spline l' in power form (t = k' - k_i)
+    const double* cw = C + (size_t)w * NL * NROW * Nk;  // row 0 of every l' block
+    for (int i = threadIdx.x; i < ((dbg & 4) ? 0 : Nk - 1); i += 256) {
+        const int J = bspl_first(i, Nk);
+        const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
+        const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
+        double cc[NL][4];
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            const double* cp = cw + (size_t)lp * NROW * Nk + J;
+            cc[lp][0] = cp[0]; cc[lp][1] = cp[1]; cc[lp][2] = cp[2]; cc[lp][3] = cp[3];
+        }
+#pragma unroll
+        for (int lp = 0; lp < NL; ++lp) {
+            const double c0 = cc[lp][0], c1 = cc[lp][1], c2 = cc[lp][2], c3 = cc[lp][3];
+            double4 pp;
+            pp.x = fma(e0.x, c0, fma(e1.x, c1, fma(e2.x, c2, e3.x * c3)));
+            pp.y = fma(e0.y, c0, fma(e1.y, c1, fma(e2.y, c2, e3.y * c3)));
+            pp.z = fma(e0.z, c0, fma(e1.z, c1, fma(e2.z, c2, e3.z * c3)));
+            pp.w = fma(e0.w, c0, fma(e1.w, c1, fma(e2.w, c2, e3.w * c3)));
+            *reinterpret_cast<double4*>(s_pp + ((size_t)i * NL + lp) * 4) = pp;
+        }
+    }
+    __syncthreads();
+    // ---- prefix sums over mu, PS[j][l'][l][q] = sum_{j' < j} wl[l][j'] lp[l'][j'] rho_j'^q: thread <-> (sequence, chunk of <= 32 nodes).  The chunk's
+    // terms are formed in registers (independent LDS reads, all in flight at once), summed there, and written once behind the chunk offsets --
+    // ap_prefix_kernel's two sweeps with their LDS round trip per node were 6 us of this kernel's 25
+    {
+        constexpr int CL = 32;
+        const int seq = threadIdx.x % NSQ, ch = threadIdx.x / NSQ;
+        const int q = seq & 3, l = (seq >> 2) % NL, lp = seq / (4 * NL);
+        const int clen = (nmu + NCHK - 1) / NCHK, j0 = ch * clen, nj = ch < NCHK && !(dbg & 2) ? max(0, min(nmu - j0, clen)) : 0;  // (host: clen <= CL)
+        double v[CL];
+#pragma unroll
+        for (int u = 0; u < CL; ++u) {
+            const int j = min(j0 + u, nmu - 1);
+            const double r = s_rho[j];
+            const double rq = q == 0 ? 1.0 : (q == 1 ? r : (q == 2 ? r * r : r * r * r));
+            v[u] = u < nj ? s_wl[l * nmu + j] * s_lp[lp * nmu + j] * rq : 0.0;
+        }
+#pragma unroll
+        for (int u = 1; u < CL; ++u) v[u] += v[u - 1];
+        if (ch < NCHK) s_tot[seq * (NCHK + 1) + ch] = v[CL - 1];
+        __syncthreads();
+        if (threadIdx.x < NSQ) {  // exclusive scan of the chunk totals
+            double run = 0.0;
+            for (int c = 0; c < NCHK; ++c) {
+                const double t = s_tot[threadIdx.x * (NCHK + 1) + c];
+                s_tot[threadIdx.x * (NCHK + 1) + c] = run;
+                run += t;
+            }
+            s_ps[threadIdx.x] = 0.0;
+        }
+        __syncthreads();
+        if (ch < NCHK) {
+            const double off = s_tot[seq * (NCHK + 1) + ch];
+#pragma unroll
+            for (int u = 0; u < CL; ++u)
+                if (u < nj) s_ps[(size_t)(j0 + u + 1) * NSQ + seq] = off + v[u];
+        }
+    }
+    __syncthreads();
+    // ---- 3. the k tiles of this half, one per wave at a time (tiles interleave between the two halves: the high-k tiles cross more intervals)
+    const int KT = (Nk + 63) / 64;
+    const bool up = g > 0.0;  // k'(mu) rises or falls with mu
+    const int dir = up ? 1 : -1;
+    const double inv_g = 1.0 / g, jscale = (nmu - 1) / mu[nmu - 1];
+    const double cnorm = 2.0 / (qperp * qperp * qpar);
+    const double* bw = bias + (size_t)w * NROW;
+    for (int kt = 2 * wave + half; kt < KT; kt += 8) {
+        const int k = kt * 64 + lane;
+        const bool live = k < Nk;
+        const double kq = s_k[live ? k : Nk - 1] / qperp, inv_kq = 1.0 / kq;
+        // (the rows outside the stage: requested now, consumed behind the walk)
+        double tst[NL][3];
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tst[l][r] = live && NROW - 3 + r >= direct0 ? T[(((size_t)w * NL + l) * NROW + NROW - 3 + r) * Nk + k] : 0.0;
+        auto cross = [&](double kb) -> int {  // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling)
+            const double rc = kb * inv_kq, x = (rc * rc - 1.0) * inv_g;  // mu^2 at the crossing (a seed: the fix-up below decides)
+            int j = nmu;
+            if (x >= 0.0 && x < 1.0) j = (int)(sqrt(x) * jscale) + 1;
+            j = max(0, min(j, nmu));
+            while (j > 0 && (up ? kq * s_root[j - 1] >= kb : kq * s_root[j - 1] < kb)) --j;
+            while (j < nmu && !(up ? kq * s_root[j] >= kb : kq * s_root[j] < kb)) ++j;
+            return j;
+        };
+        const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
+        const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
+        const int nslot = live && !(dbg & 1) ? (up ? i_last - i_first : i_first - i_last) + 1 : 0;
+        double acc[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+        int ja = 0;
+        for (int s = 0; s < nslot; ++s) {
+            const int i = i_first + s * dir;
+            const double klo = s_k[i], khi = s_k[i + 1];
+            const int jb = s == nslot - 1 ? nmu : cross(up ? khi : klo);
+            if (jb > ja) {
+                // P_l'(k') on this interval as a cubic in rho (k' - k_i = kq rho + dl): sum_j W_j P(k'_j) = sum_q w_q (PS_q[jb] - PS_q[ja])
+                const double dl = kq - klo, kq2 = kq * kq;
+                const double* pa = s_ps + (size_t)ja * NSQ;
+                const double* pb = s_ps + (size_t)jb * NSQ;
+                const double* pi = s_pp + (size_t)i * NL * 4;
+#pragma unroll
+                for (int lp = 0; lp < NL; ++lp) {
+                    const double4 p = *reinterpret_cast<const double4*>(pi + lp * 4);
+                    const double w0 = fma(fma(fma(p.w, dl, p.z), dl, p.y), dl, p.x);
+                    const double w1 = kq * fma(fma(3.0 * p.w, dl, 2.0 * p.z), dl, p.y);
+                    const double w2 = kq2 * fma(3.0 * p.w, dl, p.z);
+                    const double w3 = kq2 * kq * p.w;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) {
+                        const double4 b4 = *reinterpret_cast<const double4*>(pb + (lp * NL + l) * 4);
+                        const double4 a4 = *reinterpret_cast<const double4*>(pa + (lp * NL + l) * 4);
+                        acc[l] = fma(b4.x - a4.x, w0, fma(b4.y - a4.y, w1, fma(b4.z - a4.z, w2, fma(b4.w - a4.w, w3, acc[l]))));
+                    }
+                }
+                ja = jb;
+            }
+        }
+        if (!live) continue;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            double tot = cnorm * acc[l];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (NROW - 3 + r >= direct0) tot = fma(bw[NROW - 3 + r], tst[l][r], tot);
+            Plk[((size_t)w * NL + l) * Nk + k] = tot;
+            if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = tot;  // latency mode: P_l lands in mapped host memory as it is formed
+            if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
+        }
+    }
+}
+
 // Staged inputs: page-locked host block -> device block, as a kernel on the copy stream (a DMA transfer brings cache maintenance on the
 // compute queue with it; this one is ordinary loads from mapped host memory and ordinary stores)
 __global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {

@@ -183,6 +183,7 @@ struct eftb_engine {
     hipEvent_t evFront = nullptr, evFrontFree[2] = {nullptr, nullptr};  // this run's front is done (side stream); the readers of front set [slot] are done
     unsigned front_step = 0;
     bool prev_front_side = false;
+    bool ap_plk_fused = false;          // the AP stage of direct-P_l runs as ap_plk_fused_kernel (k grids whose tables fit the LDS; EFTB_AP_PLK_FUSED=0: ap_prefix + ap_plk_mom)
     bool ap_plk_nodes = false;          // EFTB_AP_PLK_NODES=1: the AP stage of direct-P_l runs as the node quadrature (ap_plk_kernel, round 3) instead of the moment form
     bool plk_direct = false;            // EFTB_O_PLK_DIRECT: whole-pipeline runs that end in REDUCE contract with the bias first (regroup_plk_kernel)
     bool latency_auto = true;           // EFTB_LATENCY_MODE=0 disables
@@ -1040,6 +1041,19 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 std::swap(*pin, *palt);
                 return 0;
             }
+            if (dir && e->ap_plk_fused) {
+                // moment form with everything in LDS (ap_plk_fused_kernel): prefix sums, pieces and the walk in one launch, two workgroups per cosmology
+                const size_t lds = ((size_t)((Nk + 1) & ~1) + (size_t)c.nmu * (2 + 2 * 3) + 36 * 8 + (size_t)(c.nmu + 1) * 36 + (size_t)(Nk - 1) * 3 * 4) * sizeof(double);
+                const int tslot = timer_begin(e, st, 2);
+                hipLaunchKernelGGL((ap_plk_fused_kernel<3>), dim3(2 * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
+                                   tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), e->SD,
+                                   tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], b[EFTB_B_PLK], e->plk_host_out,
+                                   e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21,
+                                   getenv("EFTB_APF_DBG") ? atoi(getenv("EFTB_APF_DBG")) : 0);
+                timer_end(e, st, tslot);
+                std::swap(*pin, *palt);
+                return 0;
+            }
             if (dir) {
                 // moment form on the contracted row (ap_plk_mom_kernel): the mu prefix sums of this cosmology batch (a function of DA, H alone) in
                 // line in front of it -- the stage is ~20 us of latency-bound launches either way, and in line it needs no second set of sums
@@ -1484,6 +1498,12 @@ int eftb_finalize(eftb_engine* e) {
             if (const char* f = getenv("EFTB_AP_MODE")) e->ap_mode = atoi(f);
             if (!e->ap_fast) e->ap_mode = 2;
             e->ap_fast = e->ap_mode == 0;
+            {   // the all-in-LDS form of the direct-P_l AP stage, where its tables fit
+                const size_t lds = ((size_t)((c.Nk + 1) & ~1) + (size_t)c.nmu * 8 + 36 * 8 + (size_t)(c.nmu + 1) * 36 + (size_t)(c.Nk - 1) * 12) * sizeof(double);
+                e->ap_plk_fused = c.Nl == 3 && lds <= 150 * 1024 && c.nmu >= 2 && c.nmu <= 7 * 32 && !(getenv("EFTB_AP_PLK_FUSED") && !atoi(getenv("EFTB_AP_PLK_FUSED")));
+                if (e->ap_plk_fused)
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_plk_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            }
 #define APM_LDS(NLV, NRV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_moments_kernel<NLV, NRV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
             APM_LDS(3, 21); APM_LDS(3, NROW); APM_LDS(2, 21); APM_LDS(2, NROW);
 #undef APM_LDS
