@@ -185,6 +185,8 @@ struct eftb_engine {
     bool prev_front_side = false;
     bool ap_plk_fused = false;          // the AP stage of direct-P_l runs as ap_plk_fused_kernel (k grids whose tables fit the LDS; EFTB_AP_PLK_FUSED=0: ap_prefix + ap_plk_mom)
     bool ap_plk_nodes = false;          // EFTB_AP_PLK_NODES=1: the AP stage of direct-P_l runs as the node quadrature (ap_plk_kernel, round 3) instead of the moment form
+    double* PLK0 = nullptr;             // direct-P_l runs with a PROJECT stage: P_l [B][Nl][Nk] as the AP stage leaves it (the operator then takes ONE row per cosmology)
+    bool plk_host_written = false;      // the kernel that formed the final P_l of the last launch also stored it to plk_host_out
     bool plk_direct = false;            // EFTB_O_PLK_DIRECT: whole-pipeline runs that end in REDUCE contract with the bias first (regroup_plk_kernel)
     bool latency_auto = true;           // EFTB_LATENCY_MODE=0 disables
     bool set_latency[NSETS] = {};        // the launch on this set is a latency-mode step (evStagedAllR: the whole staging block has been uploaded; evStagedR: the part its first kernels wait for)
@@ -530,6 +532,39 @@ static int launch_pipeline_operator(eftb_engine* e, int B) {
     return 0;
 }
 
+// PROJECT stage of a direct-P_l run: the same operators on ONE row per cosmology, P_l [B][Nl][Nk] (PLK0) -> EFTB_B_PLK [B][nl_out][nx_out]
+static int launch_pipeline_operator_plk(eftb_engine* e, int B, hipStream_t st) {
+    const bool per_tracer = !e->tracer_ops.empty();
+    if (per_tracer && (B % e->ntr)) return fail("eftb_run: batch %d is not a multiple of the %d tracers per likelihood point", B, e->ntr);
+    const int nz = per_tracer ? e->ntr : 1;
+    const eftb_engine::Op& o = e->ops[per_tracer ? e->tracer_ops[0] : e->pipeline_op];
+    GemmDesc g{};
+    GemmZ z{};
+    const long long bin = (long long)o.nl_in * o.nx_in, bout = (long long)o.nl_out * o.nx_out;
+    g.A = e->PLK0; g.a_group = bin * nz; g.a_row = 0; g.a_seg = o.nx_in;
+    g.rows = B / nz; g.rows_per_group = 1; g.nseg = o.nl_in; g.kseg = o.nx_in;
+    g.B = o.dev; g.ldb = o.ld; g.ncols = o.nl_out * o.nx_out;
+    g.C = e->buf[EFTB_B_PLK]; g.c_group = bout * nz; g.c_row = 0; g.c_colgroup = o.nx_out; g.cols_per_group = o.nx_out;
+    if (g.ncols <= 16 * GN_MAXT && nz <= GN_MAXZ) {  // few output columns: K split over the waves, 16-row workgroups; the tracers are the z dimension
+        for (int t = 0; t < nz; ++t) z.B[t] = e->ops[per_tracer ? e->tracer_ops[t] : e->pipeline_op].dev;
+        z.a_off = bin;
+        z.c_off = bout;
+        hipLaunchKernelGGL(gemm_narrow_kernel, dim3((g.rows + 15) / 16, 1, nz), dim3(256), 0, st, g, z);
+    } else {
+        for (int t = 0; t < nz; ++t) {
+            GemmDesc gt = g;
+            gt.A = g.A + (size_t)t * bin;
+            gt.C = g.C + (size_t)t * bout;
+            gt.B = e->ops[per_tracer ? e->tracer_ops[t] : e->pipeline_op].dev;
+            if (gt.ncols <= 16 * GN_MAXT) hipLaunchKernelGGL(gemm_narrow_kernel, dim3((gt.rows + 15) / 16, 1), dim3(256), 0, st, gt, GemmZ{});
+            else hipLaunchKernelGGL(gemm_rows_kernel, dim3((gt.rows + 63) / 64, (gt.ncols + 255) / 256), dim3(256), GEMM_LDS, st, gt);
+        }
+    }
+    e->cur_nl = o.nl_out;
+    e->cur_nx = o.nx_out;
+    return 0;
+}
+
 static void launch_prep_rows(eftb_engine* e, hipStream_t st, int B, bool first, bool ir) {
     const eftb_config& c = e->c;
     hipLaunchKernelGGL(prep_rows_kernel, dim3(B), dim3(256), (size_t)c.Nkin * sizeof(double), st, c.Nkin, c.ntail, c.nxtail, (int)kpad(c.Nkin),
@@ -728,8 +763,23 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
     // resum_prep_plk_kernel, resum_plk_kernel, spline / ap_rows on row 0); the template block is not produced
     // (only runs that also hold PREP, LOOPS and CF: the front of a direct run leaves CONTRACTED rows in Y22 / P13 / YCF / C11 / CCT, which is what
     // back_prep_plk_kernel reads -- a run split in front of REGROUP finds un-contracted rows there and takes the template path)
-    const bool direct = e->plk_direct && fuse_reduce && fuse_cf && Nl == 3 && !e->generic_resum && e->ap_fast && !c.dual_coef && !e->use_graphs &&
+    // Round 4: also with a PROJECT stage behind AP (window / binning / chained are linear maps of the k and multipole axes that act on every row
+    // alike: reference window.py:371-415, binning.py:131-162, chained.py:56-68 -- the operator takes ONE row per cosmology instead of 24) unless an
+    // operator keeps a second matrix for the stochastic rows; and on every k grid (the AP stage of a direct run is the moment form on B-spline
+    // pieces, which needs neither the knot-weight tables nor their grid limit).  LOGP runs stay templates-first: they need 1 + n_G contracted rows.
+    bool proj_plk = true;  // every operator of the PROJECT stage can act on the contracted row
+    if (mask & EFTB_S_PROJECT) {
+        auto one = [&](int id) { return id >= 0 && id < (int)e->ops.size() && e->ops[id].st_op < 0 && e->ops[id].nl_in == Nl && e->ops[id].nx_in == Nk; };
+        if (e->tracer_ops.empty()) proj_plk = one(e->pipeline_op);
+        else
+            for (int t = 0; t < e->ntr; ++t) proj_plk = proj_plk && one(e->tracer_ops[t]) && e->ops[e->tracer_ops[t]].nl_out == e->ops[e->tracer_ops[0]].nl_out &&
+                                                        e->ops[e->tracer_ops[t]].nx_out == e->ops[e->tracer_ops[0]].nx_out;
+    }
+    const bool direct_tail = (mask & EFTB_S_AP) && (mask & EFTB_S_REDUCE) && !(mask & EFTB_S_LOGP) && c.with_ap && !c.with_nnlo && !nnlo_pass && proj_plk && e->PLK0;
+    const bool direct = e->plk_direct && direct_tail && fuse_cf && Nl == 3 && !e->generic_resum && !c.dual_coef && !e->use_graphs &&
                         (mask & EFTB_S_PREP) && (mask & EFTB_S_LOOPS) && (mask & EFTB_S_CF) && (mask & EFTB_S_REGROUP) && e->RSAS;
+    const bool direct_proj = direct && (mask & EFTB_S_PROJECT);
+    e->plk_host_written = true;
     // ... and the per-s A operand of the Nl = 3 resummation (inputs only: Q(f), X, Y) is built on the side stream, off the chain
     const bool as_side = ahead && Nl == 3 && !e->generic_resum && e->RSAS2 && !direct;
     // ... whose front runs a step ahead on the side stream (see FrontSet)
@@ -1028,14 +1078,17 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
                 if (ysplit >= 8) ysplit &= ~7;  // shares in multiples of 8: the k tiles of a share then sit on one XCD (xcd_decode)
                 // (the fast path keeps the splines as B-spline coefficients -- one number per knot; the moment / quadrature forms as knot slopes)
-                hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, e->ap_mode == 0 ? EFTB_T_SPCBAND : EFTB_T_SPBAND), e->SD);
+                hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, e->ap_mode == 0 || dir ? EFTB_T_SPCBAND : EFTB_T_SPBAND), e->SD);
             }
+            // (a PROJECT stage follows: the stage leaves P_l in PLK0 and the operator writes the final block)
+            double* const plk_dst = direct_proj ? e->PLK0 : b[EFTB_B_PLK];
+            double* const plk_hst = direct_proj ? nullptr : e->plk_host_out;
             if (dir && e->ap_plk_nodes) {  // the node quadrature on the contracted row (ap_plk_kernel); nothing else of the stage runs
                 const size_t lds = ((size_t)Nk + (size_t)c.nmu * 8 + 3 * APD_WMAX * 4 + 3 * 3 * 64) * sizeof(double);
                 const int tslot = timer_begin(e, st, 2);
                 hipLaunchKernelGGL((ap_plk_kernel<3>), dim3(((Nk + 63) / 64) * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
                                    tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), e->SD,
-                                   tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], b[EFTB_B_PLK], e->plk_host_out,
+                                   tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], plk_dst, plk_hst,
                                    e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21);
                 timer_end(e, st, tslot);
                 std::swap(*pin, *palt);
@@ -1047,7 +1100,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int tslot = timer_begin(e, st, 2);
                 hipLaunchKernelGGL((ap_plk_fused_kernel<3>), dim3(2 * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
                                    tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), e->SD,
-                                   tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], b[EFTB_B_PLK], e->plk_host_out,
+                                   tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], plk_dst, plk_hst,
                                    e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21,
                                    getenv("EFTB_APF_DBG") ? atoi(getenv("EFTB_APF_DBG")) : 0);
                 timer_end(e, st, tslot);
@@ -1062,7 +1115,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int tslot = timer_begin(e, st, 2);
                 hipLaunchKernelGGL((ap_plk_mom_kernel<3>), dim3(((Nk + 63) / 64) * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
                                    tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), e->APP, e->APR, e->SD, tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS],
-                                   b[EFTB_B_PLK], e->plk_host_out, e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21);
+                                   plk_dst, plk_hst, e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21);
                 timer_end(e, st, tslot);
                 std::swap(*pin, *palt);
                 return 0;
@@ -1134,7 +1187,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         e->cur_nl = Nl;
         e->cur_nx = Nk;
     }
-    if (mask & EFTB_S_PROJECT) {
+    if (direct_proj) {
+        if (int rc = launch_pipeline_operator_plk(e, B, st)) return rc;
+        e->plk_host_written = false;  // (the operator writes device memory only: whoever wants P_l in host memory copies it behind the launch)
+    } else if (mask & EFTB_S_PROJECT) {
         e->opstream = st;
         const int rc = launch_pipeline_operator(e, B);
         e->opstream = nullptr;
@@ -1162,7 +1218,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         hipLaunchKernelGGL(marg_solve_kernel, dim3(nw), dim3(256), 0, st, nd, e->like_nG, e->jeffreys, e->like_mu, e->like_sinv, e->like_V, e->like_U,
                            b[EFTB_B_LOGP]);
     }
-    if ((mask & EFTB_S_REDUCE) && !fuse_reduce)
+    if ((mask & EFTB_S_REDUCE) && !fuse_reduce && !direct)
         hipLaunchKernelGGL(reduce_kernel, dim3((e->cur_nx + 255) / 256, e->cur_nl, B), dim3(256), 0, st, e->cur_nx, e->cur_nl, msplit_cfg, b[EFTB_B_BIAS],
                            b[EFTB_B_TEMPL], b[EFTB_B_PLK], c.with_nnlo ? nullptr : e->plk_host_out, e->check_finite && !c.with_nnlo ? e->status + 2 * e->status_slot + 1 : nullptr);
     if ((mask & EFTB_S_REDUCE) && c.with_nnlo)
@@ -1509,6 +1565,10 @@ int eftb_finalize(eftb_engine* e) {
 #undef APM_LDS
         }
     }
+    if (c.with_ap && c.Nl == 3 && !e->PLK0) {
+        HIPCHK(hipMalloc(&e->PLK0, e->buf_elems[EFTB_B_PLK] * sizeof(double)));
+        HIPCHK(hipMemset(e->PLK0, 0, e->buf_elems[EFTB_B_PLK] * sizeof(double)));
+    }
     if (e->ap_overlap && !e->T3) HIPCHK(hipMalloc(&e->T3, (e->buf_elems[EFTB_B_TEMPL] + 2) * sizeof(double)));  // third template block (engine.back)
     if (e->ap_overlap && e->c.with_nnlo && e->c.with_ap && !e->T3N) {
         HIPCHK(hipMalloc(&e->T3N, (e->buf_elems[EFTB_B_TEMPLN] + 2) * sizeof(double)));
@@ -1736,7 +1796,7 @@ void eftb_destroy(eftb_engine* e) {
             if (e->orig[id]) e->buf[id] = e->orig[id];  // the staged sets are freed below, the engine's own buffers with e->buf
     for (auto& p : e->tab) if (p) (void)hipFree(p);
     for (auto& p : e->buf) if (p) (void)hipFree(p);
-    for (double* p : {e->alt.PA1, e->alt.PA2, e->alt.PA2T, e->alt.PA3, e->alt.coefT, e->alt.A22, e->alt.A13, e->alt.ACF, e->alt.ALC, e->alt.P11, e->alt.COEF, e->alt.XY, e->alt.Q, reinterpret_cast<double*>(e->alt.SAD), e->RSA, e->RSC, e->RSA2, e->RSC2, e->RSAS, e->RSAS2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->TaltN, e->T3N, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
+    for (double* p : {e->alt.PA1, e->alt.PA2, e->alt.PA2T, e->alt.PA3, e->alt.coefT, e->alt.A22, e->alt.A13, e->alt.ACF, e->alt.ALC, e->alt.P11, e->alt.COEF, e->alt.XY, e->alt.Q, reinterpret_cast<double*>(e->alt.SAD), e->PLK0, e->RSA, e->RSC, e->RSA2, e->RSC2, e->RSAS, e->RSAS2, e->APP, e->APR, e->APP2, e->APR2, e->SD, e->Talt, e->T3, e->TaltN, e->T3N, e->part, e->plk_snap, e->PA1, e->PA2, e->PA2T, e->PA3, e->A22, e->A13, e->ACF, e->ALC, e->Y22, e->YCF, e->coefT, e->sm2, e->sm4, e->ZC, e->ZC2, e->coef2, e->coefT2, e->XB, reinterpret_cast<double*>(e->SAD)}) if (p) (void)hipFree(p);
     for (int q = 0; q < eftb_engine::NSETS; ++q) {
         if (e->gathered2[q]) (void)hipFree(e->gathered2[q]);
         if (e->evGath2[q]) (void)hipEventDestroy(e->evGath2[q]);
@@ -2132,7 +2192,7 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     }
     hipStream_t last = e->back_pending ? e->back : e->stream;  // the launch ends where its back half ran
     if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAllR[lr], 0));  // (the set is not "done" before its own upload is)
-    if (plk_tail) {
+    if (plk_tail || (plk_direct && !e->plk_host_written)) {
         const size_t cnt = (size_t)Bt * e->cur_nl * e->cur_nx;
         hipLaunchKernelGGL(copy16_kernel, dim3(48), dim3(256), 0, last, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
     }

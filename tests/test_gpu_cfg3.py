@@ -290,4 +290,18 @@ def test_nk512_three_tracer_batch_against_reference(golden, windows512):
         nz = np.abs(ref) > 1e-3 * np.max(np.abs(ref), axis=-1, keepdims=True)
         assert np.max(np.abs(plk[i][:no, :nx] / ref - 1.0)[nz]) < 1e-6, t       # the north-star bar, pointwise
     assert not np.array_equal(plk[3], plk[0])
+    # (c) the same batched run as a direct-P_l run (round 4: the bias contraction first, ONE row per multipole through resummation, AP and the
+    # per-tracer window -> binning -> chained operators): the reference's P_l again, and the template path's to summation order
+    eng.set_plk_direct(True)
+    plk_d = eng.eval_batch(Pin2, f2, DA2, H2, bias=np.concatenate([bias, bias]), templates=False)
+    eng.set_plk_direct(False)
+    assert plk_d.shape == plk.shape and not np.array_equal(plk_d, plk)   # (the option took effect)
+    for i, t in enumerate(U.TRACERS):
+        ref = g[t + "_plk"]
+        no, nx = ref.shape[0] if ref.shape[0] < 3 else U.final_templates(g, t)["P11l"].shape[0], U.final_templates(g, t)["P11l"].shape[-1]
+        ref = ref[:no]
+        assert relerr(plk_d[i][:no, :nx], ref) < TOL, t
+        nz = np.abs(ref) > 1e-3 * np.max(np.abs(ref), axis=-1, keepdims=True)
+        assert np.max(np.abs(plk_d[i][:no, :nx] / ref - 1.0)[nz]) < 1e-6, t
+    assert relerr(plk_d, plk) < 1e-9
     eng.close()

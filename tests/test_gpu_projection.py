@@ -564,4 +564,21 @@ def test_cfg5_window_at_shipped_accuracy_nk2048(golden):
     for n, sl in rows24.items():
         assert relerr(proj[0][:, sl], g["LRG_binned_" + n]) < TOL, n
     assert np.array_equal(proj[0], proj[1])
+    # the same engine on direct-P_l runs (round 4: any k grid -- the moment-form AP kernel on B-spline pieces -- and the PROJECT stage on one row per
+    # cosmology): P_l against the reference's binned templates contracted with the bias (reduce_Plk, parambasis.py:42-136)
+    from eftpipe_amd.parambasis import bias_row
+
+    bs = [[2.1, 0.6, 0.8, 0.5, -1.8, -1.9, -1.5], [1.3, 0.2, 0.4, 0.9, 0.7, -0.6, 1.1]]
+    bias = np.stack([bias_row(float(f["f"]), b_, None, (0.3, 0.1, -0.9), kmA=0.7, krA=0.25, ndA=4.5e-5) for b_ in bs])
+    T = np.concatenate([g["LRG_binned_" + n] for n in ("P11l", "Pctl", "Ploopl", "Pstl")], axis=1)   # [Nl][24][nbins], the engine's row order
+    want = np.einsum("wr,lrx->wlx", bias, T)
+    args = (np.stack([f["Pin"], f["Pin"]]), float(f["f"]), float(f["DA"]), float(f["H"]))
+    plk_t = eng.eval_batch(*args, bias=bias, templates=False)
+    eng.set_plk_direct(True)
+    plk_d = eng.eval_batch(*args, bias=bias, templates=False)
+    assert not np.array_equal(plk_d, plk_t)   # (the option took effect at Nk = 2048, behind a PROJECT stage)
+    for got in (plk_t, plk_d):
+        assert relerr(got, want) < TOL
+        big = np.abs(want) > 1e-3 * np.abs(want).max(axis=-1, keepdims=True)
+        assert np.max(np.abs(got - want)[big] / np.abs(want)[big]) < 1e-6
     eng.close()
