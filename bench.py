@@ -530,6 +530,16 @@ def main():
                     eng2.close()
                 except Exception as exc:  # pragma: no cover
                     extras["value_at_batch_256_error"] = repr(exc)
+            # (2c) BASELINE cfg 3 (three tracers per likelihood point, production windows, marginalised ln P) and the single-GPU half of cfg 5
+            # (Nk = 2048, window + binning, two tracers), each checked inside its loop against the reference's own outputs (tests/golden)
+            if world == 1 and not force_comm:
+                try:
+                    from tools.cfg_rates import cfg3_rates, cfg5_rate
+
+                    extras.update(cfg3_rates(device))
+                    extras.update(cfg5_rate(device))
+                except Exception as exc:  # pragma: no cover
+                    extras["cfg_rates_error"] = repr(exc)
             # (3) the drop-in path as theory.py drives it (one cosmology per call through the pybird mirror classes, production grid)
             try:
                 from tools.dropin_probe import dropin_latency_ms
