@@ -122,18 +122,37 @@ def synth_flops(t, B, direct):
     return flops, note
 
 
-def direct_step_flops(eng, B, allinfo):
-    """FP64 flops the launches of ONE direct-P_l step execute (what `roofline_step` divides by the step time): per kernel, from the compiled loops
-    (tools/isa_counts.py) where the kernel is a counted loop, else from the shape of its sums."""
+def ap_slots_per_k(d, k, DA_fid, H_fid, nmu=200):
+    """mean number of knot intervals k'(mu) = k / q_perp sqrt(1 + mu^2 (1 / F^2 - 1)) crosses per (cosmology, k) of draw set d: what the moment-form AP
+    kernel of a direct-P_l run does its work per (the executed flops of ap_plk_fused_kernel scale with it)"""
+    qperp, qpar = d["DA"] / DA_fid, H_fid / d["H"]
+    g = 1.0 / (qpar / qperp) ** 2 - 1.0
+    mu = np.linspace(0.0, 1.0, nmu)
+    root = np.sqrt(1.0 + mu[None, :] ** 2 * g[:, None])
+    lo, hi = root.min(axis=1), root.max(axis=1)
+    kq = k[None, :] / qperp[:, None]
+    i0 = np.clip(np.searchsorted(k, kq * lo[:, None], side="right") - 1, 0, k.size - 2)
+    i1 = np.clip(np.searchsorted(k, kq * hi[:, None], side="right") - 1, 0, k.size - 2)
+    return float(np.mean(i1 - i0 + 1))
+
+
+AP_FLOPS_PER_SLOT = 3 * 20 + 9 * 12   # per (k, interval): the cubic of each l' re-expanded in rho (10 FMAs), 9 x (4 differences + 4 FMAs)
+
+
+def direct_step_flops(eng, B, allinfo, slots_per_k):
+    """FP64 flops the launches of ONE direct-P_l step of B cosmologies execute (what `roofline_step` divides by the step time): per kernel, from the
+    compiled loops (tools/isa_counts.py) where the kernel is a counted loop, else from the shape of its sums."""
     t = eng.tables
     kp = lambda n: (n + 47) // 48 * 48
     Nkin, ntail, nxt = t["kin"].size, t["lnx_tail"].size, t["lnx_xtail"].size
+    nmu = int(np.asarray(t["mu"]).size)
     out = {}
     info = allinfo["resum_plk_kernel<4,2>"]
     loop = max(info["loops"], key=lambda b: b["valu_f64"])
     out["resum_plk_kernel"] = float(loop["flops_per_wave_trip"]) * B * 3 * ((NK + 255) // 256) * 6 * (NS_DEV // 4)
     out["synth_kernel"] = synth_flops(t, B, direct=True)[0]
-    out["ap_plk_kernel"] = float(B) * NK * int(np.asarray(t["mu"]).size) * 30
+    # moment-form AP stage in one launch: prefix sums (36 sequences x nmu nodes, 3 flop, twice per cosmology), pieces (3 x (Nk - 1) x 32 flop, twice), the walk
+    out["ap_plk_fused_kernel"] = float(B) * (2 * 36 * nmu * 3 + 2 * 3 * (NK - 1) * 32 + NK * slots_per_k * AP_FLOPS_PER_SLOT)
     nb = t["comb22"].shape[1] + t["comb13"].shape[1]
     out["antidiag_kernel"] = 8.0 * B * nb * (NPOW * (NPOW + 1) // 2)     # one complex multiply-add per (matrix, pair n <= m) and cosmology
     out["gemm_direct_kernel"] = 2.0 * B * (kp(Nkin) * NK + 2 * kp(Nkin + ntail) * 2 * 129 + kp(Nkin + nxt) * 2 * NS_DEV)  # P11, coefficients (+ transpose), X / Y
@@ -155,56 +174,64 @@ def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, meas
     path = os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")
     with open(path) as fh:
         allinfo = json.load(fh)
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_per_kernel.json")
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as fh:
-            pmc = json.load(fh)
+    pmc, pmc_name = {}, None
+    for name in ("r04_pmc_per_kernel.json", "r03_pmc_per_kernel.json"):
+        pmc_path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                pmc, pmc_name = json.load(fh), name
+            break
 
-    def traffic_of(prefix):
+    def traffic_of(prefix, Bl=None):
+        # HBM bytes per launch from the committed counter runs (separate --pmc passes at 128 cosmologies per launch), scaled to this launch's batch
         for name, v in pmc.items():
             if name.startswith("eftb::" + prefix) and isinstance(v, dict) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                return (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0, "profiles/r03_pmc_per_kernel.json (2 FETCH_SIZE + WRITE_SIZE)"
+                scale = (Bl / float(pmc.get("_batch", 128))) if Bl else 1.0
+                return (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 * scale, f"profiles/{pmc_name} (2 FETCH_SIZE + WRITE_SIZE, x {scale:.2f} for the batch of this launch)"
         return None, None
 
     entries = []
     # (0) resum_plk_kernel<4, 2>: executed FP64 vector flops from the compiled loop (two s steps per trip), waves = B x 3 l x Nk / 256 x 6, NS / 4 trips
     info = allinfo["resum_plk_kernel<4,2>"]
     loop = max(info["loops"], key=lambda b: b["valu_f64"])
-    waves, trips = B * 3 * ((NK + 255) // 256) * 6, NS_DEV // 4
+    ms, n, nc = ktimes[0]
+    Bl = nc / n if n else B   # cosmologies per timed launch (coalesced staged steps leave as one launch)
+    waves, trips = Bl * 3 * ((NK + 255) // 256) * 6, NS_DEV // 4
     flops = float(loop["flops_per_wave_trip"]) * waves * trips
-    ms, n = ktimes[0]
     if n:
-        tr, src = traffic_of("resum_plk_kernel")
+        tr, src = traffic_of("resum_plk_kernel", Bl)
         entries.append({"bound": "valu_f64", "kernel": "resum_plk_kernel<4, 2> (Resum.Ps of a direct-P_l run: nine Horner chains of degree 15 per (k, s) with scalar coefficients; FP64 vector "
                                                    "instructions, which share the DP pipe -- and its 78.6 TFLOP/s peak -- with the matrix cores)",
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
-                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "executed_flops_per_launch": flops,
+                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "cosmologies_per_launch": Bl, "executed_flops_per_launch": flops,
                         "instructions_per_wave_trip": {"f64_ops": loop["f64_ops"], "valu_f64": loop["valu_f64"], "flops_per_wave_trip": loop["flops_per_wave_trip"],
                                                        "vgprs": info.get("vgprs")},
                         "counts_source": "eftpipe_amd/csrc/isa_counts.json (tools/isa_counts.py, from the compiled gfx950 assembly)"})
     # (1) synth_kernel: 2 M N K of the four products of the launch (P22 basis rows, xi basis rows, P13, C11 / Cct)
-    flops, note = synth_flops(t, B, direct=True)
-    ms, n = ktimes[1]
+    ms, n, nc = ktimes[1]
+    Bl = nc / n if n else B
+    flops, note = synth_flops(t, Bl, direct=True)
     if n:
-        tr, src = traffic_of("synth_kernel")
+        tr, src = traffic_of("synth_kernel", Bl)
         entries.append({"bound": "mfma", "kernel": "synth_kernel (makeP22 / makeC22 / makeC13 / makeP13 / makeC11 / makeCct as FP64-MFMA GEMMs in one launch: the synthesis of the "
                                                    "anti-diagonal sums at every k and s; in a direct-P_l run the rows arrive contracted with the bias: 3 per cosmology and product)",
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
-                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_flops_per_launch": flops,
+                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "cosmologies_per_launch": Bl, "algorithmic_flops_per_launch": flops,
                         "flops_note": note})
-    # (2) ap_plk_kernel: the reference's mu quadrature on the contracted rows: per (k, node) three cubics (3 FMA each), two Legendre-weighted
-    # additions and three accumulations (14 FMA + the k' product and the offset from the knot) -- FP64 vector work
+    # (2) the AP stage of a direct-P_l run: ap_plk_fused_kernel (moment form: prefix sums over mu, spline pieces and the interval walk in LDS); its
+    # executed FP64 work is a few dozen flops per (k, interval crossed) -- the kernel is bound by LDS round trips, not by arithmetic
     nmu = int(np.asarray(t["mu"]).size)
-    flops = float(B) * NK * nmu * (14 * 2 + 2)
-    ms, n = ktimes[2]
+    ms, n, nc = ktimes[2]
+    Bl = nc / n if n else B
+    slots = ap_slots_per_k(d0, np.asarray(cfg.k), cfg.DA_AP, cfg.H_AP, nmu)
+    flops = float(Bl) * (2 * 36 * nmu * 3 + 2 * 3 * (NK - 1) * 32 + NK * slots * AP_FLOPS_PER_SLOT)
     if n:
-        tr, src = traffic_of("ap_plk_kernel")
-        entries.append({"bound": "valu_f64", "kernel": "ap_plk_kernel<3> (APeffect.AP of a direct-P_l run: the reference's own mu quadrature of P_l'(k'(mu)) L_l'(mu') L_l(mu) on one row per "
-                                                   "multipole, splines as piecewise polynomials in LDS; FP64 vector instructions, bound by issue and LDS latency rather than by arithmetic)",
+        tr, src = traffic_of("ap_plk_fused_kernel", Bl)
+        entries.append({"bound": "valu_f64", "kernel": "ap_plk_fused_kernel<3> (APeffect.AP of a direct-P_l run in moment form: the mu quadrature of P_l'(k'(mu)) L_l'(mu') L_l(mu) on one row "
+                                                       "per multipole as prefix sums over mu x the cubic pieces of the intervals k'(mu) crosses, all tables in LDS; latency-bound, not arithmetic-bound)",
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
-                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "algorithmic_flops_per_launch": flops,
-                        "flops_note": f"{B} x {NK} k x {nmu} nodes x 30 flop"})
+                        "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "cosmologies_per_launch": Bl, "executed_flops_per_launch": flops,
+                        "flops_note": f"{Bl:.0f} x ({NK} k x {slots:.2f} intervals x {AP_FLOPS_PER_SLOT} flop + 2 x 36 x {nmu} x 3 prefix terms + 2 x 3 x {NK - 1} x 32 for the pieces)"})
     if not entries:
         return templates_first
     entries.sort(key=lambda r: -r["ms_per_launch"])
@@ -413,8 +440,8 @@ def main():
     host_stats = eng.submit_stats(enable=False, reset=True)
     if STEP_TIMES:
         print("[bench] fetch-complete times since t0 (ms):", " ".join(f"{(t - t0) * 1e3:.3f}" for t in STEP_TIMES), file=sys.stderr)
-    ktimes = [eng.kernel_time(kind, reset=True) for kind in range(3)]  # (resummation, synthesis, AP knot weights): (ms, launches) inside the timed region
-    dom_ms, dom_n = ktimes[0]
+    ktimes = [eng.kernel_time(kind, reset=True, cosmologies=True) for kind in range(3)]  # (resummation, synthesis, AP kernel): (ms, launches, cosmologies carried) inside the timed region
+    dom_ms, dom_n = ktimes[0][:2]
     eng.time_dominant(False)
     eng.time_kernels(1)
 
@@ -533,11 +560,13 @@ def main():
             # (2c) BASELINE cfg 3 (three tracers per likelihood point, production windows, marginalised ln P) and the single-GPU half of cfg 5
             # (Nk = 2048, window + binning, two tracers), each checked inside its loop against the reference's own outputs (tests/golden)
             if world == 1 and not force_comm:
-                try:
-                    from tools.cfg_rates import cfg3_rates, cfg5_rate
+                try:  # (a fresh child process: its own engines, queues and thread pools -- this process idles meanwhile)
+                    import subprocess
 
-                    extras.update(cfg3_rates(device))
-                    extras.update(cfg5_rate(device))
+                    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cfg_rates.py"), "--json", str(device)], capture_output=True, text=True, timeout=600)
+                    if res.returncode:
+                        raise RuntimeError(res.stderr[-1500:])
+                    extras.update(json.loads(res.stdout.strip().splitlines()[-1]))
                 except Exception as exc:  # pragma: no cover
                     extras["cfg_rates_error"] = repr(exc)
             # (3) the drop-in path as theory.py drives it (one cosmology per call through the pybird mirror classes, production grid)
@@ -623,7 +652,7 @@ def main():
             roofline = direct_rooflines(eng, cfg, B, ktimes, sets[W], roofline, FP64_MFMA_PEAK_TFLOPS, measured_peak)
             # the step as a whole: executed FP64 flops of all its launches over the step time (a direct step has no dominant kernel)
             with open(os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")) as fh:
-                per_kernel = direct_step_flops(eng, B, json.load(fh))
+                per_kernel = direct_step_flops(eng, B, json.load(fh), ap_slots_per_k(sets[W], np.asarray(cfg.k), cfg.DA_AP, cfg.H_AP))
             step_flops = sum(per_kernel.values())
             ms_step = elapsed / K * 1e3
             res = extras.get("resident_evaluations_per_s")

@@ -35,7 +35,7 @@ BUFFERS = "PIN F DA H P11 P22 P13 C11 CCT CC CLOOPL TEMPL XY Q BIAS PLK COEF GRO
 B = {n: i for i, n in enumerate(BUFFERS)}
 S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C22, K_RESUM, S_LOGP, K_IRFILTER = (1 << i for i in range(13))
 
-EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_dominant_time eftb_kernel_time eftb_set_likelihood eftb_destroy eftb_add_operator eftb_apply_operator "
+EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_dominant_time eftb_kernel_time eftb_kernel_time_ex eftb_set_likelihood eftb_destroy eftb_add_operator eftb_apply_operator "
            "eftb_set_operator_stochastic eftb_set_tracers eftb_set_pipeline_operator_tracer eftb_set_pipeline_operator eftb_set_template_dims eftb_put eftb_get eftb_buffer_size eftb_run "
            "eftb_sync eftb_run_timed eftb_stage_inputs eftb_run_staged eftb_fetch_previous eftb_fetch_back eftb_fetch_view eftb_step eftb_submit_stats eftb_eval_batch eftb_eval_logp_batch eftb_host_alloc eftb_host_free eftb_comm_unique_id eftb_comm_init eftb_gather_plk eftb_fetch_gathered eftb_gathered_view "
            "eftb_window_precompute eftb_mfma_f64_peak eftb_stream_read_probe eftb_last_error eftb_version eftb_source_hash").split()
@@ -59,6 +59,7 @@ def load():
     lib.eftb_set_option.argtypes, lib.eftb_set_option.restype = [vp, i32, i32], i32
     lib.eftb_dominant_time.argtypes, lib.eftb_dominant_time.restype = [vp, dp, C.POINTER(C.c_longlong), i32], i32
     lib.eftb_kernel_time.argtypes, lib.eftb_kernel_time.restype = [vp, i32, dp, C.POINTER(C.c_longlong), i32], i32
+    lib.eftb_kernel_time_ex.argtypes, lib.eftb_kernel_time_ex.restype = [vp, i32, dp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), i32], i32
     lib.eftb_set_likelihood.argtypes, lib.eftb_set_likelihood.restype = [vp, i32, C.POINTER(C.c_int32), dp, dp, i32, dp, dp], i32
     lib.eftb_add_operator.argtypes, lib.eftb_add_operator.restype = [vp, i32, i32, i32, i32, dp, C.POINTER(C.c_int)], i32
     lib.eftb_set_operator_stochastic.argtypes, lib.eftb_set_operator_stochastic.restype = [vp, i32, i32], i32

@@ -79,6 +79,9 @@ struct eftb_engine {
     int timer_kind[NTIMER] = {};    // which kernel the pair of a slot brackets (see time_kernel)
     double timer_ms[3] = {};
     long long timer_n[3] = {};
+    long long timer_cosmo[3] = {};   // cosmologies the timed launches carried (a launch of coalesced steps carries several steps' worth)
+    int timer_B[8] = {};             // batch of the launch slot t brackets (NTIMER = 8)
+    int launch_B = 0;                // batch of the launch being issued (launch_stages_impl)
     double *APP = nullptr, *APR = nullptr, *APP2 = nullptr, *APR2 = nullptr;  // AP: prefix sums over mu [B][nmu+1][Nl*Nl*4], roots [B][nmu]
     // AP fast path (ap_weights_kernel / ap_rows_kernel): knot weights [B][tiles][APW_DCAP][Nl][Nl][2][64], lowest knot per k [B][tiles * 64],
     // window per tile [B][tiles]; second set for the look-ahead of overlapped runs (swapped together with APP / APR)
@@ -702,6 +705,7 @@ static void collect_timer(eftb_engine* e, int slot, bool wait) {
         if (hipEventElapsedTime(&ms, e->evT0[t], e->evT1[t]) == hipSuccess) {
             e->timer_ms[e->timer_kind[t]] += ms;
             ++e->timer_n[e->timer_kind[t]];
+            e->timer_cosmo[e->timer_kind[t]] += e->timer_B[t];
             e->timer_busy[t] = false;
         }
     }
@@ -715,6 +719,7 @@ static int timer_begin(eftb_engine* e, hipStream_t st, int kind) {
     collect_timer(e, tslot, false);
     if (e->timer_busy[tslot]) return -1;  // its previous pair has not finished: skip this sample
     e->timer_kind[tslot] = kind;
+    e->timer_B[tslot] = e->launch_B;
     return hipEventRecord(e->evT0[tslot], st) == hipSuccess ? tslot : -1;
 }
 static void timer_end(eftb_engine* e, hipStream_t st, int tslot) {
@@ -723,6 +728,7 @@ static void timer_end(eftb_engine* e, hipStream_t st, int tslot) {
 
 static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, bool nnlo_inline = false) {
     const eftb_config& c = e->c;
+    e->launch_B = B;
     hipStream_t st = e->stream;
     const int Nk = c.Nk, Nl = c.Nl;
     double** b = e->buf;
@@ -1722,8 +1728,20 @@ int eftb_kernel_time(eftb_engine* e, int kind, double* ms_sum, long long* launch
     if (reset) {
         e->timer_ms[kind] = 0.0;
         e->timer_n[kind] = 0;
+        e->timer_cosmo[kind] = 0;
     }
     return 0;
+}
+
+int eftb_kernel_time_ex(eftb_engine* e, int kind, double* ms_sum, long long* launches, long long* cosmologies, int reset) {
+    if (!cosmologies) return fail("eftb_kernel_time_ex: null argument");
+    if (e && kind >= 0 && kind <= 2) {
+        sub_drain(e);
+        (void)hipSetDevice(e->c.device);
+        collect_timer(e, -1, true);
+        *cosmologies = e->timer_cosmo[kind];
+    }
+    return eftb_kernel_time(e, kind, ms_sum, launches, reset);
 }
 
 int eftb_set_likelihood(eftb_engine* e, int ndata, const int32_t* index, const double* data, const double* invcov, int nG, const double* mu,

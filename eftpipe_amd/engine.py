@@ -157,11 +157,12 @@ class Engine:
         knot weights; read each with kernel_time(kind = 0, 1, 2)."""
         L.check(self.lib.eftb_set_option(self._h, 7, int(which)))
 
-    def kernel_time(self, kind, reset=True):
-        """(sum of the bracketed durations [ms], launches) of kind 0 resummation / 1 synthesis / 2 AP knot weights since the last reset."""
-        ms, n = C.c_double(), C.c_longlong()
-        L.check(self.lib.eftb_kernel_time(self._h, int(kind), C.byref(ms), C.byref(n), int(bool(reset))))
-        return ms.value, n.value
+    def kernel_time(self, kind, reset=True, cosmologies=False):
+        """(sum of the bracketed durations [ms], launches) of kind 0 resummation / 1 synthesis / 2 AP kernel since the last reset; cosmologies=True:
+        (ms, launches, cosmologies those launches carried) -- a launch of coalesced staged steps carries several steps' batches."""
+        ms, n, nc = C.c_double(), C.c_longlong(), C.c_longlong()
+        L.check(self.lib.eftb_kernel_time_ex(self._h, int(kind), C.byref(ms), C.byref(n), C.byref(nc), int(bool(reset))))
+        return (ms.value, n.value, nc.value) if cosmologies else (ms.value, n.value)
 
     def dominant_time(self, reset=True):
         """(sum of the bracketed durations [ms], launches) since the last reset; waits for launches in flight."""

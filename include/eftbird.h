@@ -176,6 +176,8 @@ int  eftb_dominant_time(eftb_engine* e, double* ms_sum, long long* launches, int
 /* The same for one of the launches EFTB_O_TIME_KERNEL selects: kind 0 the resummation kernel (= eftb_dominant_time), 1 the synthesis launch, 2 the AP
  * kernel. */
 int  eftb_kernel_time(eftb_engine* e, int kind, double* ms_sum, long long* launches, int reset);
+/* ... and the cosmologies those launches carried: a launch of coalesced staged steps (eftb_config.step_batch) carries several steps' batches. */
+int  eftb_kernel_time_ex(eftb_engine* e, int kind, double* ms_sum, long long* launches, long long* cosmologies, int reset);
 
 /* Likelihood of the EFTB_S_LOGP stage.  Replaces, for a batch of walkers on the device,
  * EFTLike.PNG / PG (likelihood.py:483-549: flatten the multipoles over the masked k bins) and

@@ -239,5 +239,11 @@ def cfg5_rate(device=0, walkers=64, steps=10, depth=4):
 if __name__ == "__main__":
     import json
 
-    print(json.dumps(cfg3_rates(), indent=1))
-    print(json.dumps(cfg5_rate(), indent=1))
+    if len(sys.argv) > 1 and sys.argv[1] == "--json":   # bench.py's child process: one JSON line with both
+        dev = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+        out = cfg3_rates(dev)
+        out.update(cfg5_rate(dev))
+        print(json.dumps(out))
+    else:
+        print(json.dumps(cfg3_rates(), indent=1))
+        print(json.dumps(cfg5_rate(), indent=1))
