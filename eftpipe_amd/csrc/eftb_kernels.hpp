@@ -2903,13 +2903,18 @@ __global__ __launch_bounds__(256) void stage_copy_kernel(const double* __restric
 }
 
 // The same for a launch that carries several queued steps: up to 8 steps x 6 arrays, each a run of doubles from a step's staging block to its rows
-// of the device block; workgroups [seg * wgs, (seg + 1) * wgs) share segment seg.
-struct StageSeg { const double* src; double* dst; size_t n; };
+// of the device block.  One double per lane and every load of the launch in flight at once: the reads cross PCIe (1.5-2 us each way), so the
+// kernel's time is one round trip + the transfer, not a chain of them (12 workgroups per run walking it in 8 passes took 45-56 us for 0.23 MB).
+struct StageSeg { const double* src; double* dst; unsigned n, first; };   // first: index of the run's first element in the launch's flat numbering (multiples of 64)
 struct StageSegs { StageSeg s[48]; int n; };
-__global__ __launch_bounds__(256) void stage_gather_kernel(StageSegs sg, int wgs) {
-    const int seg = blockIdx.x / wgs, part = blockIdx.x % wgs;
+__global__ __launch_bounds__(256) void stage_gather_kernel(StageSegs sg) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    int seg = 0;
+    for (int q = 1; q < sg.n; ++q)
+        if (i >= sg.s[q].first) seg = q;   // (runs start at multiples of 64: the choice is wave-uniform)
     const StageSeg g = sg.s[seg];
-    for (size_t i = (size_t)part * 256 + threadIdx.x; i < g.n; i += (size_t)wgs * 256) g.dst[i] = g.src[i];
+    const unsigned j = i - g.first;
+    if (j < g.n) g.dst[j] = g.src[j];
 }
 
 // nothing: the first dispatch after the GPU has sat idle for a few tens of microseconds takes 40-50 us to start executing (traced: a 27 KB copy

@@ -186,6 +186,8 @@ struct eftb_engine {
     hipEvent_t evFront = nullptr, evFrontFree[2] = {nullptr, nullptr};  // this run's front is done (side stream); the readers of front set [slot] are done
     unsigned front_step = 0;
     bool prev_front_side = false;
+    bool upload_on_side = true;         // EFTB_UPLOAD_ON_SIDE=0: staged uploads always on the copy stream
+    bool synth_direct = false;          // EFTB_SYNTH_DIRECT=1: the syntheses of direct-P_l runs on gemm_direct_kernel
     bool ap_plk_fused = false;          // the AP stage of direct-P_l runs as ap_plk_fused_kernel (k grids whose tables fit the LDS; EFTB_AP_PLK_FUSED=0: ap_prefix + ap_plk_mom)
     bool ap_plk_nodes = false;          // EFTB_AP_PLK_NODES=1: the AP stage of direct-P_l runs as the node quadrature (ap_plk_kernel, round 3) instead of the moment form
     double* PLK0 = nullptr;             // direct-P_l runs with a PROJECT stage: P_l [B][Nl][Nk] as the AP stage leaves it (the operator then takes ONE row per cosmology)
@@ -920,7 +922,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         }
         {
             const int tslot = (mask & EFTB_S_REGROUP) ? timer_begin(e, st, 1) : -1;
-            launch_synth(st, sb);
+            // (direct-P_l runs: three rows per cosmology and product -- problems with few rows per column tile, the shape gemm_direct_kernel was
+            // written for: one 16 x 32 tile per workgroup, K split over its four waves, no LDS staging and no barrier in the K loop)
+            if (direct && e->synth_direct) { if (int rc = launch_gemm_direct(st, sb, 4)) return rc; }
+            else launch_synth(st, sb);
             timer_end(e, st, tslot);
         }
         if ((k22 || c22) && !direct) {  // (direct-P_l runs contract the basis rows themselves: regroup_plk_kernel, resum_prep_plk_kernel)
@@ -1480,6 +1485,8 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_GD_WAVES")) e->gd_waves = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
     if (const char* f = getenv("EFTB_AP_PLK_NODES")) e->ap_plk_nodes = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_SYNTH_DIRECT")) e->synth_direct = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_UPLOAD_ON_SIDE")) e->upload_on_side = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUBMIT_THREAD")) e->sub_mode = std::max(0, std::min(2, atoi(f)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 2 * (eftb_engine::NSETS + 1) * sizeof(int), hipHostMallocMapped));
     memset(e->status, 0, 2 * (eftb_engine::NSETS + 1) * sizeof(int));
@@ -2133,14 +2140,17 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     const bool has_rows = cmds[0].has_rows != 0;
     int Bt = 0;
     for (int j = 0; j < n; ++j) Bt += cmds[j].B;
-    hipStream_t cs = e->cpy;
+    // the upload goes where the launch's first kernels go: direct-P_l launches start on the side stream (their front), so the upload in front of
+    // them on the same queue needs no cross-queue hand-over (20-35 us each on this runtime, and the chain of a launch has four more)
+    hipStream_t cs = (e->plk_direct && !lat && e->upload_on_side) ? e->side : e->cpy;
     HIPCHK(hipStreamWaitEvent(cs, e->evSetDone[q], 0));  // the last launch on this set (and the fetch of its results) is over
     // (an upload kernel reading the mapped staging blocks, not a DMA transfer: 0.4 MB is latency, and the DMA form measured the same or worse)
     // only what was staged travels: P_lin, f, DA, H, the bias rows -- and the likelihood rows (0.6 MB at 128 walkers) when there are any.  Reads
     // of host memory from a kernel run at ~16 GB/s: the whole 0.85 MB block took 48-53 us, on the critical path of a dependent sampler
     const size_t width[6] = {(size_t)c.Nkin, 1, 1, 1, (size_t)NROW, (size_t)MARG_NG1 * NROW};
-    auto gather = [&](int id_lo, int id_hi, int wgs_per_seg, hipStream_t st) {  // arrays kStagedIn[id_lo .. id_hi) of every step of the group
+    auto gather = [&](int id_lo, int id_hi, hipStream_t st) {  // arrays kStagedIn[id_lo .. id_hi) of every step of the group
         StageSegs sg{};
+        unsigned total = 0;
         int row = 0;
         for (int j = 0; j < n; ++j) {
             for (int a = id_lo; a < id_hi; ++a) {
@@ -2149,23 +2159,25 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
                 StageSeg& g = sg.s[sg.n++];
                 g.src = e->stage_host[cmds[j].slot] + e->slot_off[id];
                 g.dst = e->setblock[q] + e->stage_off[id] + (size_t)row * width[a];
-                g.n = (size_t)cmds[j].B * width[a];
+                g.n = (unsigned)((size_t)cmds[j].B * width[a]);
+                g.first = total;
+                total += (g.n + 63u) & ~63u;
             }
             row += cmds[j].B;
         }
-        if (sg.n) hipLaunchKernelGGL(stage_gather_kernel, dim3(sg.n * wgs_per_seg), dim3(256), 0, st, sg, wgs_per_seg);
+        if (sg.n) hipLaunchKernelGGL(stage_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sg);
     };
     e->set_latency[q] = lat;
     if (lat) {
         // the small arrays go first and on the compute queue itself (in line in front of the step's kernels: no cross-queue hand-over; the
         // GPU is idle, nothing of an earlier step can still be reading the set): they are all the step's first kernels wait for -- its first
         // kernel reads P_lin from the staging block itself, whose device copy follows on the copy queue
-        gather(1, 6, 8, e->stream);
+        gather(1, 6, e->stream);
         HIPCHK(hipEventRecord(e->evStagedR[lr], e->stream));
-        gather(0, 1, 48, cs);
+        gather(0, 1, cs);
         HIPCHK(hipEventRecord(e->evStagedAllR[lr], cs));
     } else {
-        gather(0, 6, 12, cs);
+        gather(0, 6, cs);
         HIPCHK(hipEventRecord(e->evStagedR[lr], cs));
     }
     // the set becomes current and the launch goes out

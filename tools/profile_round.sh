@@ -16,7 +16,8 @@ echo "stats done"
 # one derived counter per pass where the hardware cannot collect them together (FETCH_SIZE + WRITE_SIZE is refused)
 pmc() {  # name, counters...
     local name=$1; shift
-    timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/$name.err
+    # (one step per launch in the counter passes: EFTB_BENCH_COALESCE=1 -- the counters are then per launch of 128 cosmologies)
+    EFTB_BENCH_COALESCE=1 timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/$name.err
     echo "$name done"
 }
 pmc pmc_fetch FETCH_SIZE
