@@ -147,9 +147,9 @@ def direct_step_flops(eng, B, allinfo, slots_per_k):
     Nkin, ntail, nxt = t["kin"].size, t["lnx_tail"].size, t["lnx_xtail"].size
     nmu = int(np.asarray(t["mu"]).size)
     out = {}
-    info = allinfo["resum_plk_kernel<4,2>"]
+    info = allinfo["resum_plk_kernel<4,4>"]
     loop = max(info["loops"], key=lambda b: b["valu_f64"])
-    out["resum_plk_kernel"] = float(loop["flops_per_wave_trip"]) * B * 3 * ((NK + 255) // 256) * 6 * (NS_DEV // 4)
+    out["resum_plk_kernel"] = float(loop["flops_per_wave_trip"]) * B * 3 * ((NK + 255) // 256) * 12 * (NS_DEV // 8)   # 3 v x 4 slices of s = 12 waves per (256 k, l, cosmology), two s per trip
     out["synth_kernel"] = synth_flops(t, B, direct=True)[0]
     # moment-form AP stage in one launch: prefix sums (36 sequences x nmu nodes, 3 flop, twice per cosmology), pieces (3 x (Nk - 1) x 32 flop, twice), the walk
     out["ap_plk_fused_kernel"] = float(B) * (2 * 36 * nmu * 3 + 2 * 3 * (NK - 1) * 32 + NK * slots_per_k * AP_FLOPS_PER_SLOT)
@@ -191,16 +191,16 @@ def direct_rooflines(eng, cfg, B, ktimes, d0, templates_first, peak_tflops, meas
         return None, None
 
     entries = []
-    # (0) resum_plk_kernel<4, 2>: executed FP64 vector flops from the compiled loop (two s steps per trip), waves = B x 3 l x Nk / 256 x 6, NS / 4 trips
-    info = allinfo["resum_plk_kernel<4,2>"]
+    # (0) resum_plk_kernel<4, 4>: executed FP64 vector flops from the compiled loop (two s steps per trip), waves = B x 3 l x Nk / 256 x 12, NS / 8 trips
+    info = allinfo["resum_plk_kernel<4,4>"]
     loop = max(info["loops"], key=lambda b: b["valu_f64"])
     ms, n, nc = ktimes[0]
     Bl = nc / n if n else B   # cosmologies per timed launch (coalesced staged steps leave as one launch)
-    waves, trips = Bl * 3 * ((NK + 255) // 256) * 6, NS_DEV // 4
+    waves, trips = Bl * 3 * ((NK + 255) // 256) * 12, NS_DEV // 8
     flops = float(loop["flops_per_wave_trip"]) * waves * trips
     if n:
         tr, src = traffic_of("resum_plk_kernel", Bl)
-        entries.append({"bound": "valu_f64", "kernel": "resum_plk_kernel<4, 2> (Resum.Ps of a direct-P_l run: nine Horner chains of degree 15 per (k, s) with scalar coefficients; FP64 vector "
+        entries.append({"bound": "valu_f64", "kernel": "resum_plk_kernel<4, 4> (Resum.Ps of a direct-P_l run: nine Horner chains of degree 15 per (k, s) with scalar coefficients; FP64 vector "
                                                    "instructions, which share the DP pipe -- and its 78.6 TFLOP/s peak -- with the matrix cores)",
                         "achieved": flops / (ms / n * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s", "frac": flops / (ms / n * 1e-3) / 1e12 / peak_tflops,
                         "traffic": tr, "traffic_source": src, "ms_per_launch": ms / n, "launches_timed": n, "cosmologies_per_launch": Bl, "executed_flops_per_launch": flops,

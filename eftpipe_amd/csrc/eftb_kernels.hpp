@@ -2722,17 +2722,17 @@ __global__ __launch_bounds__(256) void ap_plk_mom_kernel(int Nk, int nmu, const 
 //      global memory: 58 KB that every (k, interval) of ap_plk_mom_kernel gathers 2 x 288 bytes from, one HBM / L2 round trip per interval),
 //   2. the power-form pieces of the three contracted splines on every knot interval (B-spline coefficients x per-interval matrices: 48 KB),
 //   3. per k the walk over the intervals k'(mu) crosses, moments by differences of the prefix sums (header of ap_plk_mom_kernel), all reads LDS.
-// 256 workgroups of four waves at B = 128: one wave per SIMD for ~8 us instead of 4 096 waves of 156 registers for 25 us (+ 10 us of
-// ap_prefix_kernel) -- beside it the rest of the machine stays free for the other streams' kernels.  Needs (nmu + 1) 36 + Nk 12 + ... doubles
+// One workgroup of eight waves per cosmology (NW = 8; or two of four, NW = 4): 23 us alone at B = 128 for spline-to-P_l against 35 (4 096 waves of
+// 156 registers gathering from global memory + ap_prefix_kernel) -- beside it the rest of the machine stays free for the other streams' kernels.  Needs (nmu + 1) 36 + Nk 12 + ... doubles
 // of LDS: k grids up to 768 points; finer grids keep ap_prefix_kernel + ap_plk_mom_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int NL>
-__global__ __launch_bounds__(256) void ap_plk_fused_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
+template <int NL, int NW>
+__global__ __launch_bounds__(64 * NW) void ap_plk_fused_kernel(int Nk, int nmu, const double* __restrict__ kk, const double* __restrict__ DAw,
                                                            const double* __restrict__ Hw, const double* __restrict__ fid, const double* __restrict__ mu,
                                                            const double* __restrict__ wmu, const double* __restrict__ legmu, const double* __restrict__ C,
                                                            const double* __restrict__ LOCAL, const double* __restrict__ T, const double* __restrict__ bias,
                                                            double* __restrict__ Plk, double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0, int dbg) {
-    constexpr int NSQ = NL * NL * 4, NCHK = 7;   // 36 sequences x 7 chunks of the mu range = 252 threads
+    constexpr int NSQ = NL * NL * 4, NT = 64 * NW, NCHK = NT / NSQ;   // 36 sequences x 7 (14) chunks of the mu range = 252 (504) threads
     extern __shared__ double sm[];
     double* s_k = sm;                                   // [Nk] (+ 1 if odd)
     double* s_root = s_k + ((Nk + 1) & ~1);             // [nmu]
@@ -2743,12 +2743,13 @@ __global__ __launch_bounds__(256) void ap_plk_fused_kernel(int Nk, int nmu, cons
     double* s_ps = s_tot + NSQ * (NCHK + 1);            // [nmu + 1][NSQ]
     double* s_pp = s_ps + (size_t)(nmu + 1) * NSQ;      // [Nk - 1][NL][4]  (16-byte aligned: every block above has an even length)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = blockIdx.x & 1, w = blockIdx.x >> 1;
+    constexpr int SPLIT = NW == 8 ? 1 : 2;   // workgroups per cosmology: eight waves take every tile of a cosmology, four waves every other one
+    const int half = blockIdx.x % SPLIT, w = blockIdx.x / SPLIT;
     const double qperp = DAw[w] / fid[0], qpar = fid[1] / Hw[w];
     const double F = qpar / qperp, g = 1.0 / (F * F) - 1.0;
     // ---- 1. tables
-    for (int e = threadIdx.x; e < Nk; e += 256) s_k[e] = kk[e];
-    for (int j = threadIdx.x; j < nmu; j += 256) {
+    for (int e = threadIdx.x; e < Nk; e += NT) s_k[e] = kk[e];
+    for (int j = threadIdx.x; j < nmu; j += NT) {
         const double m = mu[j];
         const double root = sqrt(1.0 + m * m * g);
         const double mp = m / (F * root), x2 = mp * mp, wj = wmu[j];
@@ -2762,7 +2763,7 @@ __global__ __launch_bounds__(256) void ap_plk_fused_kernel(int Nk, int nmu, cons
     }
     // ---- 2. pieces: interval i of spline l' in power form (t = k' - k_i)
     const double* cw = C + (size_t)w * NL * NROW * Nk;  // row 0 of every l' block
-    for (int i = threadIdx.x; i < ((dbg & 4) ? 0 : Nk - 1); i += 256) {
+    for (int i = threadIdx.x; i < ((dbg & 4) ? 0 : Nk - 1); i += NT) {
         const int J = bspl_first(i, Nk);
         const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
         const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
@@ -2788,7 +2789,7 @@ __global__ __launch_bounds__(256) void ap_plk_fused_kernel(int Nk, int nmu, cons
     // terms are formed in registers (independent LDS reads, all in flight at once), summed there, and written once behind the chunk offsets --
     // ap_prefix_kernel's two sweeps with their LDS round trip per node were 6 us of this kernel's 25
     {
-        constexpr int CL = 32;
+        constexpr int CL = NW == 8 ? 16 : 32;
         const int seq = threadIdx.x % NSQ, ch = threadIdx.x / NSQ;
         const int q = seq & 3, l = (seq >> 2) % NL, lp = seq / (4 * NL);
         const int clen = (nmu + NCHK - 1) / NCHK, j0 = ch * clen, nj = ch < NCHK && !(dbg & 2) ? max(0, min(nmu - j0, clen)) : 0;  // (host: clen <= CL)
@@ -2829,7 +2830,7 @@ __global__ __launch_bounds__(256) void ap_plk_fused_kernel(int Nk, int nmu, cons
     const double inv_g = 1.0 / g, jscale = (nmu - 1) / mu[nmu - 1];
     const double cnorm = 2.0 / (qperp * qperp * qpar);
     const double* bw = bias + (size_t)w * NROW;
-    for (int kt = 2 * wave + half; kt < KT; kt += 8) {
+    for (int kt = SPLIT * wave + half; kt < KT; kt += SPLIT * NW) {
         const int k = kt * 64 + lane;
         const bool live = k < Nk;
         const double kq = s_k[live ? k : Nk - 1] / qperp, inv_kq = 1.0 / kq;

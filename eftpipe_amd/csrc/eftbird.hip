@@ -1032,11 +1032,25 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
             const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
             if (direct) {
-                // four k per lane, two slices of the s range (measured on the pool: 38-41 us; 4 x 1: 45, 2 x 1: 42, 2 x 2: 44, 1 x 2: 56, 2 x 4: 38)
-                const int nkd = (Nk + 64 * 4 - 1) / (64 * 4);
-                if (kblocks > 0)
-                    hipLaunchKernelGGL((resum_plk_kernel<4, 2>), dim3(nkd * 3 * B), dim3(192 * 2), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H),
-                                       e->RSAS, b[EFTB_B_TEMPL], nkd);
+                // four k per lane, four slices of the s range (round 3 measured 4 x 2: 38-41 us; 4 x 1: 45, 2 x 1: 42, 2 x 2: 44, 1 x 2: 56, 2 x 4: 38)
+                static const int shape = getenv("EFTB_RPLK") ? atoi(getenv("EFTB_RPLK")) : 44;   // (KPL, SH) as two digits: A/B runs of the wave shape
+#define RPLK_LAUNCH(KPLV, SHV)                                                                                                                        \
+    do {                                                                                                                                              \
+        const int nkd = (Nk + 64 * KPLV - 1) / (64 * KPLV);                                                                                           \
+        hipLaunchKernelGGL((resum_plk_kernel<KPLV, SHV>), dim3(nkd * 3 * B), dim3(192 * SHV), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K),           \
+                           tb<double>(e, EFTB_T_H), e->RSAS, b[EFTB_B_TEMPL], nkd);                                                                   \
+    } while (0)
+                if (kblocks > 0) {
+                    if (shape == 81) RPLK_LAUNCH(8, 1);
+                    else if (shape == 82) RPLK_LAUNCH(8, 2);
+                    else if (shape == 84) RPLK_LAUNCH(8, 4);
+                    else if (shape == 44) RPLK_LAUNCH(4, 4);
+                    else if (shape == 41) RPLK_LAUNCH(4, 1);
+                    else if (shape == 24) RPLK_LAUNCH(2, 4);
+                    else if (shape == 42) RPLK_LAUNCH(4, 2);
+                    else RPLK_LAUNCH(4, 4);   // (round 4, same-box sweep tools/rplk_sweep.sh: 34.9 us alone at B = 128 / 105 at 384; 4 x 2: 39.0 / 120; 2 x 4: 38.6 / 117; 8 x 1: 57 / 117)
+                }
+#undef RPLK_LAUNCH
             } else if (kblocks > 0 && Nl == 3 && fused_nnlo)
                 hipLaunchKernelGGL((resum_mfma_kernel<true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
             else if (kblocks > 0 && Nl == 3)
@@ -1107,13 +1121,18 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             }
             if (dir && e->ap_plk_fused) {
                 // moment form with everything in LDS (ap_plk_fused_kernel): prefix sums, pieces and the walk in one launch, two workgroups per cosmology
-                const size_t lds = ((size_t)((Nk + 1) & ~1) + (size_t)c.nmu * (2 + 2 * 3) + 36 * 8 + (size_t)(c.nmu + 1) * 36 + (size_t)(Nk - 1) * 3 * 4) * sizeof(double);
+                const size_t lds = ((size_t)((Nk + 1) & ~1) + (size_t)c.nmu * (2 + 2 * 3) + 36 * 16 + (size_t)(c.nmu + 1) * 36 + (size_t)(Nk - 1) * 3 * 4) * sizeof(double);
                 const int tslot = timer_begin(e, st, 2);
-                hipLaunchKernelGGL((ap_plk_fused_kernel<3>), dim3(2 * B), dim3(256), lds, st, Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H],
-                                   tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU), tb<double>(e, EFTB_T_LEGMU), e->SD,
-                                   tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], plk_dst, plk_hst,
-                                   e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21,
-                                   getenv("EFTB_APF_DBG") ? atoi(getenv("EFTB_APF_DBG")) : 0);
+#define APF_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU),   \
+                 tb<double>(e, EFTB_T_LEGMU), e->SD, tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], plk_dst, plk_hst,                                      \
+                 e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21, getenv("EFTB_APF_DBG") ? atoi(getenv("EFTB_APF_DBG")) : 0
+                // one workgroup of eight waves per cosmology (22.3 us alone at B = 128, 40 at 384; two workgroups of four waves: 22.7 / 61 -- the LDS
+                // tables allow one workgroup per CU either way).  One shape for every batch size: the two sum the mu prefix in different chunks, and
+                // a cosmology's bits must not depend on the batch it travels in (EFTB_APF_WAVES=4 for A/B runs)
+                static const int apf_nw = getenv("EFTB_APF_WAVES") ? atoi(getenv("EFTB_APF_WAVES")) : 8;
+                if (apf_nw == 4) hipLaunchKernelGGL((ap_plk_fused_kernel<3, 4>), dim3(2 * B), dim3(256), lds, st, APF_ARGS);
+                else hipLaunchKernelGGL((ap_plk_fused_kernel<3, 8>), dim3(B), dim3(512), lds, st, APF_ARGS);
+#undef APF_ARGS
                 timer_end(e, st, tslot);
                 std::swap(*pin, *palt);
                 return 0;
@@ -1568,10 +1587,11 @@ int eftb_finalize(eftb_engine* e) {
             if (!e->ap_fast) e->ap_mode = 2;
             e->ap_fast = e->ap_mode == 0;
             {   // the all-in-LDS form of the direct-P_l AP stage, where its tables fit
-                const size_t lds = ((size_t)((c.Nk + 1) & ~1) + (size_t)c.nmu * 8 + 36 * 8 + (size_t)(c.nmu + 1) * 36 + (size_t)(c.Nk - 1) * 12) * sizeof(double);
+                const size_t lds = ((size_t)((c.Nk + 1) & ~1) + (size_t)c.nmu * 8 + 36 * 16 + (size_t)(c.nmu + 1) * 36 + (size_t)(c.Nk - 1) * 12) * sizeof(double);
                 e->ap_plk_fused = c.Nl == 3 && lds <= 150 * 1024 && c.nmu >= 2 && c.nmu <= 7 * 32 && !(getenv("EFTB_AP_PLK_FUSED") && !atoi(getenv("EFTB_AP_PLK_FUSED")));
                 if (e->ap_plk_fused)
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_plk_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                    for (const void* fn : {reinterpret_cast<const void*>(&ap_plk_fused_kernel<3, 4>), reinterpret_cast<const void*>(&ap_plk_fused_kernel<3, 8>)})
+                        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             }
 #define APM_LDS(NLV, NRV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_moments_kernel<NLV, NRV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
             APM_LDS(3, 21); APM_LDS(3, NROW); APM_LDS(2, 21); APM_LDS(2, NROW);
