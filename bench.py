@@ -5,9 +5,9 @@ Workload = BASELINE.json configs[1]: LRG z=0.7, Nl=3, Nk=512, IR-resummation + A
 per step.  A step = one pass of the hot path (reference theory.py:557-609: FFTLog coefficients -> anti-diagonal sums ->
 P22/P13/C11/Cct/C22/C13 -> regroup -> resum -> AP -> bias contraction) over one batch of NEW inputs:
 
-    timed region, per step:  eftb_stage_inputs (H2D of Pin, f, DA, H, bias rows of a draw set never seen before)
-                             eftb_run_staged   (all stages)
-                             eftb_fetch_back     (P_l of the step two back, D2H)          [N > 1: RCCL gather to rank 0, rank 0 copies out]
+    timed region, per step:  eftb_step = eftb_stage_inputs (Pin, f, DA, H, bias rows of a draw set never seen before -> page-locked block)
+                                         eftb_run_staged   (all stages; issued by the library's submission thread, queued steps leave as one launch)
+                                         eftb_fetch_view   (P_l of the step DEPTH back, in page-locked host memory)   [N > 1: RCCL gather to rank 0]
 
 so `value` is the input-to-output rate a sampler sees (H2D + D2H inclusive, every step's P_l lands in host memory inside the timed
 region; pipeline fill and drain are inside it too).  All draws are generated before the clock starts.  The rate of the same kernels
@@ -16,10 +16,11 @@ over inputs that stay resident in HBM, and the rate with the full template block
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel: the FP64-MFMA IR-resummation kernel, timed live with HIP events on
-the engine stream; `frac` = EXECUTED FP64 flops / time / peak, the executed count derived from the compiled kernel's instruction
-counts -- eftpipe_amd/csrc/isa_counts.json, written by tools/isa_counts.py at build time) and `cpu_baseline` (the NumPy oracle,
-"port", timed on this host on a bounded sample).
+Rank 0 prints ONE JSON line carrying `roofline` (the kernel with the largest time per launch inside the timed region -- on direct-P_l runs the
+resummation kernel resum_plk_kernel -- timed live with HIP events on its own stream; `frac` = EXECUTED FP64 flops / time / peak, the executed count
+derived from the compiled kernel's instruction counts -- eftpipe_amd/csrc/isa_counts.json, written by tools/isa_counts.py at build time -- and from
+the batch each bracketed launch carried; `frac_alone`: the same kernel with nothing beside it; `roofline_step`: all launches of a step) and
+`cpu_baseline` (the NumPy oracle, "port", timed on this host on a bounded sample).
 """
 from __future__ import annotations
 
@@ -461,7 +462,7 @@ def main():
         assert np.array_equal(last[rank], results[K - 1]), "the root's own slice of the gathered block differs from its P_l"
 
     # ---- the same timed loop with the templates first (every rank takes part: the N > 1 loop exchanges); its P_l against the direct runs'
-    tf_elapsed, tf_err, tf_dom_ms, tf_dom_n = None, None, 0.0, 0
+    tf_elapsed, tf_err, tf_dom_ms, tf_dom_n, tf_dom_nc = None, None, 0.0, 0, 0
     if DIRECT:
         direct_results = results.copy()
         eng.set_plk_direct(False)
@@ -474,7 +475,7 @@ def main():
         loop(W, K, keep=True)
         cp.barrier()
         tf_elapsed = cp.max(time.perf_counter() - t0)
-        tf_dom_ms, tf_dom_n = eng.kernel_time(0, reset=True)
+        tf_dom_ms, tf_dom_n, tf_dom_nc = eng.kernel_time(0, reset=True, cosmologies=True)
         eng.time_dominant(False)
         if exchange == "none" or (exchange == "rccl" and rank == 0):
             scale = np.max(np.abs(results), axis=-1, keepdims=True)
@@ -608,10 +609,13 @@ def main():
         # average over the launches of the timed region (beside the look-ahead / back-half kernels).  In a direct-P_l bench the timed region's kind-0
         # timer bracketed resum_plk_kernel, not this kernel: its own in-pipeline time comes from the templates-first loop above
         if DIRECT:
-            dom_tf_ms, dom_tf_n = tf_dom_ms, tf_dom_n
+            dom_tf_ms, dom_tf_n, dom_tf_nc = tf_dom_ms, tf_dom_n, tf_dom_nc
         else:
-            dom_tf_ms, dom_tf_n = dom_ms, dom_n
+            dom_tf_ms, dom_tf_n, dom_tf_nc = dom_ms, dom_n, ktimes[0][2]
         ms_resum = dom_tf_ms / dom_tf_n if dom_tf_n else ms_alone
+        # (coalesced staged steps leave as one launch: the in-pipeline launches carried dom_tf_nc / dom_tf_n cosmologies each, the stand-alone one B)
+        bl_tf = dom_tf_nc / dom_tf_n if dom_tf_n else B
+        exe_flops_alone, exe_flops, exe_mfma_flops = exe_flops, exe_flops * bl_tf / B, exe_mfma_flops * bl_tf / B
         achieved = exe_flops / (ms_resum * 1e-3) / 1e12
         try:
             measured_peak = mfma_f64_peak(device)
@@ -637,7 +641,8 @@ def main():
             "ms_per_launch": ms_resum, "launches_timed": dom_tf_n,
             "ms_per_launch_note": "HIP events on the kernel's own stream around every second of its launches inside the timed templates-first loop, where the look-ahead and "
                                   "back-half kernels of the neighbouring steps share the CUs (and the FP64 pipe) with it" + ("" if dom_tf_n else " -- NOT AVAILABLE in this run: the stand-alone time is used"),
-            "ms_per_launch_alone": ms_alone, "frac_alone": exe_flops / (ms_alone * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "cosmologies_per_launch": bl_tf,
+            "ms_per_launch_alone": ms_alone, "frac_alone": exe_flops_alone / (ms_alone * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "executed_flops_per_launch": exe_flops, "executed_mfma_flops_per_launch": exe_mfma_flops,
             "mfma_only_frac": exe_mfma_flops / (ms_resum * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "instructions_per_wave_trip": per_trip, "counts_source": "eftpipe_amd/csrc/isa_counts.json (tools/isa_counts.py, from the compiled gfx950 assembly)",
@@ -650,6 +655,25 @@ def main():
         }
         if DIRECT:
             roofline = direct_rooflines(eng, cfg, B, ktimes, sets[W], roofline, FP64_MFMA_PEAK_TFLOPS, measured_peak)
+            # the same three kernels with nothing beside them: synchronous direct-P_l runs of one batch, every launch bracketed
+            eng.set_plk_direct(True)
+            eng.time_kernels(7)
+            eng.time_dominant(1)
+            for kind in range(3):
+                eng.kernel_time(kind, reset=True)
+            for _ in range(6):
+                eng.run(mask, B, sync=True)
+            alone = [eng.kernel_time(kind, reset=True, cosmologies=True) for kind in range(3)]
+            eng.time_dominant(False)
+            eng.time_kernels(1)
+            tag = {"resum_plk": 0, "synth_kernel": 1, "ap_plk_fused": 2}
+            for ent in [roofline] + roofline.get("roofline_others", []):
+                for name, kind in tag.items():
+                    if ent["kernel"].startswith(name) and alone[kind][1]:
+                        ms_a = alone[kind][0] / alone[kind][1]
+                        fl = ent.get("executed_flops_per_launch", ent.get("algorithmic_flops_per_launch")) * B / ent["cosmologies_per_launch"]
+                        ent["ms_per_launch_alone"], ent["frac_alone"] = ms_a, fl / (ms_a * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
+                        ent["alone_note"] = f"synchronous direct-P_l runs of {B} cosmologies, nothing of another step beside the kernel (HIP events on its stream)" 
             # the step as a whole: executed FP64 flops of all its launches over the step time (a direct step has no dominant kernel)
             with open(os.path.join(ROOT, "eftpipe_amd", "csrc", "isa_counts.json")) as fh:
                 per_kernel = direct_step_flops(eng, B, json.load(fh), ap_slots_per_k(sets[W], np.asarray(cfg.k), cfg.DA_AP, cfg.H_AP))
@@ -685,7 +709,8 @@ def main():
             "dtype": "f64", "data": "synthetic (SYNTH-PLIN v1; a new draw set of `batch_per_gpu` cosmologies every step, seeds 12345 + 7919 step + 104729 rank)",
             "config": {"workload": "cfg2: single-tracer LRG z=0.7, Nl=3 (l=0,2,4), Nk=512, IR-resum + AP, P_l via west-coast bias contraction; "
                                    "H2D+D2H inclusive: every step stages new inputs from host memory and its P_l is fetched to host memory inside the timed region; "
-                                   f"`value` pipelines INDEPENDENT batches at depth {DEPTH} (step i's P_l is copied out after step i + {DEPTH} has been launched); the rate a "
+                                   f"`value` pipelines INDEPENDENT batches at depth {DEPTH} (step i's P_l is taken after step i + {DEPTH} has been handed in; steps still queued when "
+                                   f"the library's submission thread reaches them leave as one launch of up to {COALESCE} steps -- Engine(coalesce={COALESCE}) --, each fetched by itself); the rate a "
                                    "sampler sees whose next step depends on this step's P_l is the side key sync_step_evaluations_per_s"
                                    + ("; `value` is measured on direct-P_l runs (EFTB_O_PLK_DIRECT: the bias contraction is taken before the synthesis of the loop pieces, the "
                                       "resummation and the AP stage, with which it commutes -- same P_l, no template block); the templates-first rate of the same loop (rounds 1-2) is "

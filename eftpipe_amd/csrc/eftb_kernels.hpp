@@ -2731,7 +2731,7 @@ __global__ __launch_bounds__(64 * NW) void ap_plk_fused_kernel(int Nk, int nmu, 
                                                            const double* __restrict__ Hw, const double* __restrict__ fid, const double* __restrict__ mu,
                                                            const double* __restrict__ wmu, const double* __restrict__ legmu, const double* __restrict__ C,
                                                            const double* __restrict__ LOCAL, const double* __restrict__ T, const double* __restrict__ bias,
-                                                           double* __restrict__ Plk, double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0, int dbg) {
+                                                           double* __restrict__ Plk, double* __restrict__ PlkHost, int* __restrict__ nonfinite, int direct0) {
     constexpr int NSQ = NL * NL * 4, NT = 64 * NW, NCHK = NT / NSQ;   // 36 sequences x 7 (14) chunks of the mu range = 252 (504) threads
     extern __shared__ double sm[];
     double* s_k = sm;                                   // [Nk] (+ 1 if odd)
@@ -2763,7 +2763,7 @@ __global__ __launch_bounds__(64 * NW) void ap_plk_fused_kernel(int Nk, int nmu, 
     }
     // ---- 2. pieces: interval i of spline l' in power form (t = k' - k_i)
     const double* cw = C + (size_t)w * NL * NROW * Nk;  // row 0 of every l' block
-    for (int i = threadIdx.x; i < ((dbg & 4) ? 0 : Nk - 1); i += NT) {
+    for (int i = threadIdx.x; i < Nk - 1; i += NT) {
         const int J = bspl_first(i, Nk);
         const double4* lc = reinterpret_cast<const double4*>(LOCAL + (size_t)i * 16);
         const double4 e0 = lc[0], e1 = lc[1], e2 = lc[2], e3 = lc[3];
@@ -2792,7 +2792,7 @@ __global__ __launch_bounds__(64 * NW) void ap_plk_fused_kernel(int Nk, int nmu, 
         constexpr int CL = NW == 8 ? 16 : 32;
         const int seq = threadIdx.x % NSQ, ch = threadIdx.x / NSQ;
         const int q = seq & 3, l = (seq >> 2) % NL, lp = seq / (4 * NL);
-        const int clen = (nmu + NCHK - 1) / NCHK, j0 = ch * clen, nj = ch < NCHK && !(dbg & 2) ? max(0, min(nmu - j0, clen)) : 0;  // (host: clen <= CL)
+        const int clen = (nmu + NCHK - 1) / NCHK, j0 = ch * clen, nj = ch < NCHK ? max(0, min(nmu - j0, clen)) : 0;  // (host: clen <= CL)
         double v[CL];
 #pragma unroll
         for (int u = 0; u < CL; ++u) {
@@ -2851,7 +2851,7 @@ __global__ __launch_bounds__(64 * NW) void ap_plk_fused_kernel(int Nk, int nmu, 
         };
         const int i_first = knot_interval(s_k, Nk, kq * s_root[0]);
         const int i_last = knot_interval(s_k, Nk, kq * s_root[nmu - 1]);
-        const int nslot = live && !(dbg & 1) ? (up ? i_last - i_first : i_first - i_last) + 1 : 0;
+        const int nslot = live ? (up ? i_last - i_first : i_first - i_last) + 1 : 0;
         double acc[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) acc[l] = 0.0;

@@ -1125,7 +1125,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int tslot = timer_begin(e, st, 2);
 #define APF_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU),   \
                  tb<double>(e, EFTB_T_LEGMU), e->SD, tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], plk_dst, plk_hst,                                      \
-                 e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21, getenv("EFTB_APF_DBG") ? atoi(getenv("EFTB_APF_DBG")) : 0
+                 e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21
                 // one workgroup of eight waves per cosmology (22.3 us alone at B = 128, 40 at 384; two workgroups of four waves: 22.7 / 61 -- the LDS
                 // tables allow one workgroup per CU either way).  One shape for every batch size: the two sum the mu prefix in different chunks, and
                 // a cosmology's bits must not depend on the batch it travels in (EFTB_APF_WAVES=4 for A/B runs)
