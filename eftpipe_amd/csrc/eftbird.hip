@@ -2317,10 +2317,17 @@ static void sub_main(eftb_engine* e) {
         // flow control: with sub_inflight launches still running the queue is left to grow -- what has piled up by the time one of them finishes
         // leaves as one launch (coalesce_max steps at most)
         while (e->launch_done < e->launch_seq && launch_finished(e, e->launch_done)) ++e->launch_done;
-        for (unsigned wspins = 0; (long long)(e->launch_seq - e->launch_done) >= e->sub_inflight;) {
-            if (launch_finished(e, e->launch_done)) { ++e->launch_done; continue; }
-            for (int i = 0; i < 16; ++i) cpu_pause();
-            if ((++wspins & 0xfffff) == 0 && e->sub_stop.load(std::memory_order_acquire)) break;
+        {
+            static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
+            const auto tw0 = std::chrono::steady_clock::now();
+            for (unsigned wspins = 0; (long long)(e->launch_seq - e->launch_done) >= e->sub_inflight;) {
+                if (launch_finished(e, e->launch_done)) { ++e->launch_done; continue; }
+                for (int i = 0; i < 16; ++i) cpu_pause();
+                // (a launch that never finishes must not hold the queue -- and with it every entry point that drains it -- for ever: the steps go
+                // out anyway and their fetches report the time-out)
+                if ((++wspins & 0xffff) == 0 && (e->sub_stop.load(std::memory_order_acquire) ||
+                                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count() > limit_s)) break;
+            }
         }
         eftb_engine::SubCmd grp[8];
         int n = 0, Bt = 0;
@@ -2410,7 +2417,9 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     // step if that is enabled (see latency_auto)
     const bool quiet = sub_quiescent(e);
     const bool gpu_idle = quiet && hipEventQuery(e->evSetDone[e->cur_set]) == hipSuccess;
-    e->stg_inline = !(e->sub_mode == 2 || (e->sub_mode == 1 && !gpu_idle));
+    // (with latency mode off the caller has said that more steps follow at once: queued from the first step on -- the caller goes on staging
+    // while the thread issues; 2-3 % of a 20-step loop)
+    e->stg_inline = !(e->sub_mode == 2 || (e->sub_mode == 1 && (!gpu_idle || !e->latency_auto)));
     // nothing in flight (the step launched last has finished, or none was launched): the step staged here has the GPU to itself -- see latency_auto
     e->stg_lat = e->stg_inline && e->latency_auto && gpu_idle && e->slot_off[EFTB_B_PIN] == 0;
     e->slot_latency[slot] = e->stg_lat;
