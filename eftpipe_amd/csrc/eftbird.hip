@@ -26,6 +26,15 @@ using namespace eftb;
 
 constexpr size_t GEMM_LDS = (size_t)64 * 258 * sizeof(double);  // A tile of gemm_rows_kernel
 
+// What-if builds only (make whatif -> libeftbird_whatif.so, tools/whatif_probe.py): EFTB_WHATIF_SKIP is a set of direct-P_l kernels that are NOT
+// launched, to see what each one costs the pipelined step (the results of such a run are garbage).  The product library has no such switch.
+#ifdef EFTB_WHATIF
+static const int g_whatif = getenv("EFTB_WHATIF_SKIP") ? atoi(getenv("EFTB_WHATIF_SKIP")) : 0;
+#define WHATIF_SKIP(bit) ((g_whatif & (bit)) != 0)
+#else
+#define WHATIF_SKIP(bit) false
+#endif
+
 static thread_local std::string g_err;
 
 static int fail(const char* fmt, ...) {
@@ -257,6 +266,7 @@ struct eftb_engine {
     StepRec rec[SUBREC] = {};
     char sub_err[SUBREC][256] = {};
     int coalesce_max = 1;                    // steps per launch at most (EFTB_COALESCE; 1 unless step_batch < max_batch)
+    int sub_low = 2;                         // ... and below which it launches whatever is queued at once (EFTB_SUB_LOW); between the two it waits for a full group
     int sub_inflight = 3;                    // launches the submission thread keeps in flight before it lets the queue grow (EFTB_SUB_INFLIGHT)
     unsigned long long launch_seq = 0;       // staged launches issued so far (issuing thread)
     unsigned long long launch_done = 0;      // ... of which known to have finished (issuing thread's view)
@@ -273,8 +283,16 @@ struct eftb_engine {
     // completion words of the staged sets in mapped page-locked memory: the step's last stream writes 1 + its step number behind everything else
     // (hipStreamWriteValue64), so the fetch of a step polls plain memory -- a hipEventQuery loop on the caller's thread takes the runtime's locks
     // thousands of times per step and slows the submission thread's launches down (measured: no gain from the thread at all with the event spin)
+    // P_l of a pipelined launch leaves on a stream of its own (copy16_kernel behind an event on the launch's last stream): on the back stream the
+    // 1.6 MB per 128 cosmologies of PCIe stores (27 us) sat in front of the next launch's spline / AP kernels and inside the launch's completion --
+    // what-if runs (tools/whatif_probe.py) priced it at 22.7 us of a 101 us step, more than the resummation kernel.  The flow control of the
+    // submission thread counts a launch as finished when its COMPUTE is (second word per set), the fetch when the copy is
+    hipStream_t outq = nullptr;
+    int out_mode = 0;
+    hipEvent_t evOut[NSETS] = {};
     volatile unsigned long long* set_done = nullptr;
     unsigned long long set_word[NSETS] = {};  // 1 + the launch whose completion write was enqueued for the set (else the set's event is what to wait for)
+    unsigned long long set_cword[NSETS] = {}; // ... whose compute-done write was (set_done[NSETS + q])
     bool done_words = true;                   // EFTB_DONE_WORDS=0: event queries (A/B); also the fall-back when the write command is refused
     // EFTB_SUB_STATS=1: host time the issuing thread spends per step (printed by eftb_destroy)
     bool sub_stats = false;
@@ -445,9 +463,11 @@ static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets,
 #define ROW_ARGS sets, c.max_batch, c.Nl, c.with_nnlo ? 3 : 2, c.nbasis, coef, e->SAD, tb<double2>(e, EFTB_T_MLJ), tb<double2>(e, EFTB_T_LINVEC), e->A22, e->A13, \
                  e->ACF, e->ALC
     if (nc == 9) {
-        if ((sets & 0x10) && e->ad_waves == 2) hipLaunchKernelGGL((antidiag_kernel<9, 2>), grid, dim3(128), 0, st, AD_ARGS);
+        if (contracted && WHATIF_SKIP(4)) {
+        } else if ((sets & 0x10) && e->ad_waves == 2) hipLaunchKernelGGL((antidiag_kernel<9, 2>), grid, dim3(128), 0, st, AD_ARGS);
         else if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9, 4>), grid, dim3(256), 0, st, AD_ARGS);
-        if (contracted)  // direct-P_l runs: the rows contracted with the bias before the synthesis (3 per cosmology and space)
+        if (contracted && WHATIF_SKIP(8)) {
+        } else if (contracted)  // direct-P_l runs: the rows contracted with the bias before the synthesis (3 per cosmology and space)
             hipLaunchKernelGGL((build_rows_plk_kernel<9>), rgrid, dim3(64), 0, st, c.max_batch, c.nbasis, coef, e->SAD, tb<double2>(e, EFTB_T_MLJ),
                                tb<double2>(e, EFTB_T_LINVEC), e->buf[EFTB_B_BIAS], e->buf[EFTB_B_F], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT),
                                tb<double>(e, EFTB_T_L22), tb<double>(e, EFTB_T_L13), tb<int>(e, EFTB_T_GRP), tb<double>(e, EFTB_T_EXP22),
@@ -638,7 +658,7 @@ static inline void join_back(eftb_engine* e) {
 // every stream of the engine drained (setters that replace resident tables / likelihood data)
 static hipError_t sync_all(eftb_engine* e) {
     join_back(e);
-    for (hipStream_t q : {e->stream, e->side, e->pre, e->back, e->cpy, e->comm_stream})
+    for (hipStream_t q : {e->stream, e->side, e->pre, e->back, e->cpy, e->outq, e->comm_stream})
         if (q) {
             const hipError_t rc = hipStreamSynchronize(q);
             if (rc != hipSuccess) return rc;
@@ -846,7 +866,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         // cosmology-contiguous transpose for the anti-diagonal pass), the second coefficient set of IRcutoff "loop" / "resum" (reference
         // pybird.py:1151-1160), and X(s), Y(s) when a resummation follows in this run
         if (!front_side) fst = st;
-        if (front_side)  // operand rows and Q(f) in one launch
+        if (front_side && WHATIF_SKIP(1)) {
+        } else if (front_side)  // operand rows and Q(f) in one launch
             hipLaunchKernelGGL(prep_rows_qf_kernel, dim3(2 * B), dim3(256), (size_t)c.Nkin * sizeof(double), fst, B, c.Nkin, c.ntail, c.nxtail, (int)kpad(c.Nkin),
                                (int)kpad(c.Nkin + c.ntail), (int)kpad(c.Nkin + c.nxtail), c.max_batch, e->buf[EFTB_B_PIN], tb<double>(e, EFTB_T_LNKIN),
                                tb<double>(e, EFTB_T_LNXTAIL), tb<double>(e, EFTB_T_LNXXTAIL), tb<double>(e, EFTB_T_WQLAST2), e->PA1, e->PA2, e->PA2T, e->PA3,
@@ -864,7 +885,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 queue_synth(sb, tb<double>(e, EFTB_T_GCT2T), KP2, 2 * NCH, 1, KP2, e->PA2T, c.max_batch, e->coefT2, c.max_batch, nullptr, nullptr);
             }
             if (xy_in_prep) queue_xy(e, sb, B);
-            if (int rc = launch_gemm_direct(fst, sb, e->gd_waves)) return rc;
+            if (!(front_side && WHATIF_SKIP(2)))
+                if (int rc = launch_gemm_direct(fst, sb, e->gd_waves)) return rc;
         }
         if (as_side) {  // behind the AP tables on the side stream; the set written here was last read by the resummation two runs ago
             if (xy_in_prep && (hipEventRecord(e->evXY, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evXY, 0) != hipSuccess))
@@ -924,7 +946,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             const int tslot = (mask & EFTB_S_REGROUP) ? timer_begin(e, st, 1) : -1;
             // (direct-P_l runs: three rows per cosmology and product -- problems with few rows per column tile, the shape gemm_direct_kernel was
             // written for: one 16 x 32 tile per workgroup, K split over its four waves, no LDS staging and no barrier in the K loop)
-            if (direct && e->synth_direct) { if (int rc = launch_gemm_direct(st, sb, 4)) return rc; }
+            if (direct && WHATIF_SKIP(16)) {
+            } else if (direct && e->synth_direct) { if (int rc = launch_gemm_direct(st, sb, 4)) return rc; }
             else launch_synth(st, sb);
             timer_end(e, st, tslot);
         }
@@ -1001,6 +1024,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 const int nsl = NS / 5;  // five slices of the s range per cosmology
                 const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 2 * 3 * nsl) * sizeof(double);
                 const int nkx = (Nk + 255) / 256, nreg = nkx * B * Nl;
+                if (!WHATIF_SKIP(32))
                 hipLaunchKernelGGL(back_prep_plk_kernel, dim3(nreg + 5 * B), dim3(256), plds, st, nreg, nkx, B, 5, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], e->Y22,
                                    b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), b[EFTB_B_BIAS], b[EFTB_B_TEMPL], c.ap_stochastic ? 1 : 0,
                                    e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF, e->RSAS);
@@ -1040,7 +1064,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         hipLaunchKernelGGL((resum_plk_kernel<KPLV, SHV>), dim3(nkd * 3 * B), dim3(192 * SHV), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K),           \
                            tb<double>(e, EFTB_T_H), e->RSAS, b[EFTB_B_TEMPL], nkd);                                                                   \
     } while (0)
-                if (kblocks > 0) {
+                if (kblocks > 0 && !WHATIF_SKIP(64)) {
                     if (shape == 81) RPLK_LAUNCH(8, 1);
                     else if (shape == 82) RPLK_LAUNCH(8, 2);
                     else if (shape == 84) RPLK_LAUNCH(8, 4);
@@ -1103,6 +1127,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
                 if (ysplit >= 8) ysplit &= ~7;  // shares in multiples of 8: the k tiles of a share then sit on one XCD (xcd_decode)
                 // (the fast path keeps the splines as B-spline coefficients -- one number per knot; the moment / quadrature forms as knot slopes)
+                if (!(dir && WHATIF_SKIP(128)))
                 hipLaunchKernelGGL(spline_kernel, dim3(kt * ysplit), dim3(256), 0, st, Nk, nseries, rlo, rsel, *pin, tb<double>(e, e->ap_mode == 0 || dir ? EFTB_T_SPCBAND : EFTB_T_SPBAND), e->SD);
             }
             // (a PROJECT stage follows: the stage leaves P_l in PLK0 and the operator writes the final block)
@@ -1130,7 +1155,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 // tables allow one workgroup per CU either way).  One shape for every batch size: the two sum the mu prefix in different chunks, and
                 // a cosmology's bits must not depend on the batch it travels in (EFTB_APF_WAVES=4 for A/B runs)
                 static const int apf_nw = getenv("EFTB_APF_WAVES") ? atoi(getenv("EFTB_APF_WAVES")) : 8;
-                if (apf_nw == 4) hipLaunchKernelGGL((ap_plk_fused_kernel<3, 4>), dim3(2 * B), dim3(256), lds, st, APF_ARGS);
+                if (WHATIF_SKIP(256)) {
+                } else if (apf_nw == 4) hipLaunchKernelGGL((ap_plk_fused_kernel<3, 4>), dim3(2 * B), dim3(256), lds, st, APF_ARGS);
                 else hipLaunchKernelGGL((ap_plk_fused_kernel<3, 8>), dim3(B), dim3(512), lds, st, APF_ARGS);
 #undef APF_ARGS
                 timer_end(e, st, tslot);
@@ -1834,7 +1860,7 @@ void eftb_destroy(eftb_engine* e) {
     (void)hipSetDevice(e->c.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
-    for (hipStream_t q : {e->pre, e->side, e->cpy, e->back}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work and staged uploads still in flight
+    for (hipStream_t q : {e->pre, e->side, e->cpy, e->back, e->outq}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work, staged uploads and copy-outs still in flight
     drop_graphs(e);
     if (e->cpy)
         for (int id = 0; id < EFTB_B_COUNT; ++id)
@@ -1862,6 +1888,8 @@ void eftb_destroy(eftb_engine* e) {
     if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->back) (void)hipStreamDestroy(e->back);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
+    if (e->outq) (void)hipStreamDestroy(e->outq);
+    for (hipEvent_t ev : e->evOut) if (ev) (void)hipEventDestroy(ev);
     for (int h = 0; h < eftb_engine::NSLOT; ++h)
         if (e->stage_host[h]) (void)hipHostFree(e->stage_host[h]);
     for (int r = 0; r < eftb_engine::NLRING; ++r) {
@@ -1943,6 +1971,7 @@ int eftb_sync(eftb_engine* e) {
     if (!e) return fail("eftb_sync: null engine");
     join_back(e);
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->outq) HIPCHK(hipStreamSynchronize(e->outq));                // the copy-out of the last staged launch's P_l
     if (e->comm_stream) HIPCHK(hipStreamSynchronize(e->comm_stream));  // an asynchronous gather may still be in flight
     return check_status(e, "eftb_sync");
 }
@@ -2117,13 +2146,24 @@ static int staged_setup(eftb_engine* e) {
     if (const char* f = getenv("EFTB_DONE_WORDS")) e->done_words = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUB_STATS")) e->sub_stats = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUB_INFLIGHT")) e->sub_inflight = std::max(1, std::min(eftb_engine::NSETS - 1, atoi(f)));
+    if (const char* f = getenv("EFTB_SUB_LOW")) e->sub_low = std::max(1, atoi(f));
+    e->sub_low = std::min(e->sub_low, e->sub_inflight);
     e->coalesce_max = e->comm ? 1 : (int)std::min<size_t>(8, (size_t)e->c.max_batch / sb);   // (with a communicator every step is exchanged by itself)
     if (const char* f = getenv("EFTB_COALESCE")) e->coalesce_max = std::max(1, std::min(e->coalesce_max, atoi(f)));
     {
         void* p = nullptr;
-        HIPCHK(hipHostMalloc(&p, eftb_engine::NSETS * sizeof(unsigned long long), hipHostMallocMapped));
-        memset(p, 0, eftb_engine::NSETS * sizeof(unsigned long long));
+        HIPCHK(hipHostMalloc(&p, 2 * eftb_engine::NSETS * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(p, 0, 2 * eftb_engine::NSETS * sizeof(unsigned long long));
         e->set_done = static_cast<volatile unsigned long long*>(p);
+    }
+    // EFTB_OUT_STREAM: 0 (default) the copy-out of P_l stays in line on the launch's last stream; 1: on a stream of its own; 2: on the copy stream
+    // (idle in direct-P_l loops, whose uploads ride on the side stream).  Measured (200 steps, same box): in line 0.101-0.103 ms per step, own
+    // stream 0.16-0.19 whatever its priority and GPU_MAX_HW_QUEUES -- kept for A/B runs
+    e->out_mode = getenv("EFTB_OUT_STREAM") ? atoi(getenv("EFTB_OUT_STREAM")) : 0;
+    if (e->out_mode) {
+        const int oprio = getenv("EFTB_OUT_PRIO") ? atoi(getenv("EFTB_OUT_PRIO")) : 1;   // 1 low, 0 normal, -1 high
+        if (e->out_mode == 1) HIPCHK(hipStreamCreateWithPriority(&e->outq, hipStreamNonBlocking, oprio > 0 ? prio_lo : (oprio < 0 ? prio_hi : 0)));
+        for (int q = 0; q < eftb_engine::NSETS; ++q) HIPCHK(hipEventCreateWithFlags(&e->evOut[q], hipEventDisableTiming));
     }
     e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first staged launch; sets 0, 1, 2, 3 follow in turn
     HIPCHK(hipDeviceSynchronize());  // the zero fills ran on the null stream; the copy stream is about to write into these blocks
@@ -2185,7 +2225,7 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
             }
             row += cmds[j].B;
         }
-        if (sg.n) hipLaunchKernelGGL(stage_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sg);
+        if (sg.n && !WHATIF_SKIP(1024)) hipLaunchKernelGGL(stage_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sg);
     };
     e->set_latency[q] = lat;
     if (lat) {
@@ -2242,17 +2282,30 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     }
     hipStream_t last = e->back_pending ? e->back : e->stream;  // the launch ends where its back half ran
     if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAllR[lr], 0));  // (the set is not "done" before its own upload is)
+    hipStream_t done_on = last;  // where the launch's LAST work runs: what the set's event and completion word follow
+    static const bool flow_cword = !(getenv("EFTB_FLOW_CWORD") && !atoi(getenv("EFTB_FLOW_CWORD")));
+    if (e->done_words && !lat && flow_cword) {   // compute finished: what the submission thread's flow control counts (the copy-out below is not part of it)
+        if (hipStreamWriteValue64(last, const_cast<unsigned long long*>(e->set_done) + eftb_engine::NSETS + q, L + 1, 0) == hipSuccess) e->set_cword[q] = L + 1;
+        else (void)hipGetLastError();
+    }
     if (plk_tail || (plk_direct && !e->plk_host_written)) {
         const size_t cnt = (size_t)Bt * e->cur_nl * e->cur_nx;
-        hipLaunchKernelGGL(copy16_kernel, dim3(48), dim3(256), 0, last, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
+        hipStream_t oq = e->out_mode == 1 ? e->outq : (e->out_mode == 2 && cs != e->cpy ? e->cpy : nullptr);
+        if (oq && !lat) {
+            HIPCHK(hipEventRecord(e->evOut[q], last));
+            HIPCHK(hipStreamWaitEvent(oq, e->evOut[q], 0));
+            done_on = oq;
+        }
+        if (!WHATIF_SKIP(512))
+        hipLaunchKernelGGL(copy16_kernel, dim3(48), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
     }
     if (e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], (size_t)Bt * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
-    HIPCHK(hipEventRecord(e->evSetDone[q], last));
+    HIPCHK(hipEventRecord(e->evSetDone[q], done_on));
     if (e->back_pending && e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], last));  // whoever joins the back half also waits for the copy
     if (e->done_words) {
-        if (hipStreamWriteValue64(last, const_cast<unsigned long long*>(e->set_done) + q, L + 1, 0) == hipSuccess) e->set_word[q] = L + 1;
+        if (hipStreamWriteValue64(done_on, const_cast<unsigned long long*>(e->set_done) + q, L + 1, 0) == hipSuccess) e->set_word[q] = L + 1;
         else {
             (void)hipGetLastError();
             e->done_words = false;  // this runtime refuses the command: event queries from here on (the words of the earlier launches stay valid)
@@ -2293,6 +2346,7 @@ static inline void cpu_pause() { __builtin_ia32_pause(); }
 // has staged launch L finished?  (issuing thread; its completion word if one was enqueued, else its set's event)
 static bool launch_finished(eftb_engine* e, unsigned long long L) {
     const int q = e->lring_set[L % eftb_engine::NLRING];
+    if (e->set_cword[q] >= L + 1) return e->set_done[eftb_engine::NSETS + q] >= L + 1;   // its compute has finished (the copy-out of P_l may still run)
     if (e->set_word[q] >= L + 1) return e->set_done[q] >= L + 1;   // (words grow with the launch number: a later launch on the set says it too)
     return hipEventQuery(e->evSetDone[q]) == hipSuccess;
 }
@@ -2320,8 +2374,12 @@ static void sub_main(eftb_engine* e) {
         {
             static const double limit_s = getenv("EFTB_FETCH_TIMEOUT_S") ? atof(getenv("EFTB_FETCH_TIMEOUT_S")) : 60.0;
             const auto tw0 = std::chrono::steady_clock::now();
-            for (unsigned wspins = 0; (long long)(e->launch_seq - e->launch_done) >= e->sub_inflight;) {
-                if (launch_finished(e, e->launch_done)) { ++e->launch_done; continue; }
+            for (unsigned wspins = 0;;) {
+                const long long inflight = (long long)(e->launch_seq - e->launch_done);
+                // go: below the in-flight limit AND (a full group is waiting, or the GPU is about to run dry: fewer than sub_low launches left)
+                if (inflight < e->sub_inflight &&
+                    (inflight < e->sub_low || (long long)(e->sub_tail.load(std::memory_order_acquire) - head) >= e->coalesce_max)) break;
+                if (inflight > 0 && launch_finished(e, e->launch_done)) { ++e->launch_done; continue; }
                 for (int i = 0; i < 16; ++i) cpu_pause();
                 // (a launch that never finishes must not hold the queue -- and with it every entry point that drains it -- for ever: the steps go
                 // out anyway and their fetches report the time-out)
