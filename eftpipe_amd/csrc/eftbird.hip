@@ -294,6 +294,17 @@ struct eftb_engine {
     unsigned long long set_word[NSETS] = {};  // 1 + the launch whose completion write was enqueued for the set (else the set's event is what to wait for)
     unsigned long long set_cword[NSETS] = {}; // ... whose compute-done write was (set_done[NSETS + q])
     bool done_words = true;                   // EFTB_DONE_WORDS=0: event queries (A/B); also the fall-back when the write command is refused
+    // EFTB_O_STEP_TRACE: GPU timestamps (timing events) at nine points of every staged direct-P_l launch -- upload start, front end, synthesis
+    // start, operand build end, resummation start / end, spline start, AP end, copy-out end -- on their own streams: an undistorted timeline of
+    // the pipelined loop (rocprofv3 doubles the host's launch cost, and under it the host, not the GPU, sets the pace); tools/step_trace.py
+    static constexpr int NTP = 12, NTRACE = 64;   // (points 9-11: inside the front -- upload end, first-stage products end, anti-diagonal sums end)
+    hipEvent_t evTrace[NTRACE][NTP] = {};
+    hipEvent_t evTraceBase = nullptr;
+    int trace_B[NTRACE] = {};
+    unsigned long long trace_launch[NTRACE] = {};
+    bool trace_on = false;
+    int trace_slot = -1;      // ring slot of the launch being issued (-1: not traced)
+    unsigned long long trace_n = 0;
     // EFTB_SUB_STATS=1: host time the issuing thread spends per step (printed by eftb_destroy)
     bool sub_stats = false;
     double issue_ns = 0.0, fill_ns = 0.0, wait_ns = 0.0;
@@ -343,6 +354,10 @@ static int rccl_load() {
         ncclResult_t _r = (expr);                                                                \
         if (_r != ncclSuccess) return fail("%s failed: %s", #expr, g_rccl.GetErrorString(_r));   \
     } while (0)
+
+static inline void trace_point(eftb_engine* e, int p, hipStream_t st) {
+    if (e->trace_slot >= 0) (void)hipEventRecord(e->evTrace[e->trace_slot][p], st);
+}
 
 static inline size_t kpad(int n) { return (size_t)(n + SYN_KPAD - 1) / SYN_KPAD * SYN_KPAD; }  // K of a first-stage GEMM: padded like the synthesis tables
 
@@ -466,6 +481,7 @@ static int launch_antidiag_rows(eftb_engine* e, hipStream_t st, int B, int sets,
         if (contracted && WHATIF_SKIP(4)) {
         } else if ((sets & 0x10) && e->ad_waves == 2) hipLaunchKernelGGL((antidiag_kernel<9, 2>), grid, dim3(128), 0, st, AD_ARGS);
         else if (sets & 0x10) hipLaunchKernelGGL((antidiag_kernel<9, 4>), grid, dim3(256), 0, st, AD_ARGS);
+        if (contracted) trace_point(e, 11, st);
         if (contracted && WHATIF_SKIP(8)) {
         } else if (contracted)  // direct-P_l runs: the rows contracted with the bias before the synthesis (3 per cosmology and space)
             hipLaunchKernelGGL((build_rows_plk_kernel<9>), rgrid, dim3(64), 0, st, c.max_batch, c.nbasis, coef, e->SAD, tb<double2>(e, EFTB_T_MLJ),
@@ -887,6 +903,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             if (xy_in_prep) queue_xy(e, sb, B);
             if (!(front_side && WHATIF_SKIP(2)))
                 if (int rc = launch_gemm_direct(fst, sb, e->gd_waves)) return rc;
+            if (front_side) trace_point(e, 10, fst);
         }
         if (as_side) {  // behind the AP tables on the side stream; the set written here was last read by the resummation two runs ago
             if (xy_in_prep && (hipEventRecord(e->evXY, st) != hipSuccess || hipStreamWaitEvent(e->side, e->evXY, 0) != hipSuccess))
@@ -912,8 +929,10 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         if (mask & EFTB_S_CF) sets |= 0x8;
         if (!c.dual_coef) {
             if (int rc = launch_antidiag_rows(e, front_side ? fst : st, B, sets, b[EFTB_B_COEF], e->coefT, direct)) return rc;
+            if (front_side) trace_point(e, 1, fst);
             if (front_side && (hipEventRecord(e->evFront, fst) != hipSuccess || hipStreamWaitEvent(st, e->evFront, 0) != hipSuccess))
                 return fail("eftb_run: stream join failed");
+            if (front_side) trace_point(e, 2, st);
         } else {  // k-space rows from the first coefficient set, xi-space rows from the second (the sums are recomputed in between)
             if (sets & 0x5)
                 if (int rc = launch_antidiag_rows(e, st, B, (sets & 0x5) | 0x10, b[EFTB_B_COEF], e->coefT)) return rc;
@@ -1028,6 +1047,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 hipLaunchKernelGGL(back_prep_plk_kernel, dim3(nreg + 5 * B), dim3(256), plds, st, nreg, nkx, B, 5, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], e->Y22,
                                    b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), b[EFTB_B_BIAS], b[EFTB_B_TEMPL], c.ap_stochastic ? 1 : 0,
                                    e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF, e->RSAS);
+                trace_point(e, 3, st);
                 if (front_side) {  // the last reader of this run's front set
                     if (hipEventRecord(e->evFrontFree[e->front_step & 1], st) != hipSuccess) return fail("eftb_run: event record failed");
                     ++e->front_step;
@@ -1047,6 +1067,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 if (as_side && full && hipStreamWaitEvent(st_main, e->evAS, 0) != hipSuccess) return fail("eftb_run: stream join failed");
                 st = st_main;
             }
+            if (direct) trace_point(e, 4, st);
             const int tslot = full ? timer_begin(e, st, 0) : -1;
             const int kblocks = (Nk - c.Nklow + 63) / 64;
             int nsplit = 1;
@@ -1084,6 +1105,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             if (nsplit > 1)
                 hipLaunchKernelGGL(resum_sum_kernel, dim3((Nk + 255) / 256, 21 * Nl, B), dim3(256), 0, st, Nk, Nl, nsplit, e->part, b[EFTB_B_TEMPL]);
             timer_end(e, st, tslot);
+            if (direct) trace_point(e, 5, st);
             if (ahead) {
                 if (hipEventRecord(e->evRsDone[rslot], st) != hipSuccess) return fail("eftb_run: event record failed");
                 ++e->rs_step;
@@ -1122,6 +1144,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
             // path only the rows the stage distorts (Pstl passes through unless APst: 21 of 24 rows)
             const int rlo = nn && !moments ? 3 : 0, rsel = dir ? 1 : nn && !moments ? 3 : (e->ap_mode == 0 ? nr : NROW);
             const int nseries = B * Nl * rsel;
+            if (dir) trace_point(e, 6, st);
             {
                 const int kt = (Nk + 63) / 64;
                 int ysplit = std::max(1, std::min((nseries + 15) / 16, 1024 / kt));  // ~4 workgroups per CU, each sweeping its share of the series
@@ -1159,6 +1182,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 } else if (apf_nw == 4) hipLaunchKernelGGL((ap_plk_fused_kernel<3, 4>), dim3(2 * B), dim3(256), lds, st, APF_ARGS);
                 else hipLaunchKernelGGL((ap_plk_fused_kernel<3, 8>), dim3(B), dim3(512), lds, st, APF_ARGS);
 #undef APF_ARGS
+                trace_point(e, 7, st);
                 timer_end(e, st, tslot);
                 std::swap(*pin, *palt);
                 return 0;
@@ -1397,6 +1421,23 @@ static int run_stages(eftb_engine* e, int mask, int B) {
     return 0;
 }
 
+// Measurement: EFTB_STREAM_PAD="a,b,c,d,e" creates (and keeps) that many extra streams of the same priority in front of the main / side / look-ahead /
+// back / copy stream, each touched once so that its hardware queue exists.  Which hardware queue a stream lands on decides which other streams'
+// barrier packets its kernels wait behind (round 4: the copy-out of P_l on a stream of its own ran at 0.16 or 0.103 ms per step depending on how
+// many streams were created before it) -- a sweep of the placement of the engine's own five streams, tools/pad_sweep.sh.
+static int pad_streams(int which, int prio) {
+    const char* f = getenv("EFTB_STREAM_PAD");
+    if (!f) return 0;
+    int v[5] = {0, 0, 0, 0, 0};
+    sscanf(f, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+    for (int i = 0; i < v[which]; ++i) {
+        hipStream_t dummy = nullptr;
+        HIPCHK(hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, prio));
+        hipLaunchKernelGGL(wake_kernel, dim3(1), dim3(64), 0, dummy);
+    }
+    return 0;
+}
+
 extern "C" {
 
 const char* eftb_last_error(void) { return g_err.c_str(); }
@@ -1442,8 +1483,11 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
         const char* f = getenv(name);
         return !f ? dflt : (atoi(f) > 0 ? prio_lo : (atoi(f) < 0 ? prio_hi : 0));
     };
+    if (int rc = pad_streams(0, prio_of("EFTB_MAIN_PRIO", prio_lo))) return rc;
     HIPCHK(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_of("EFTB_MAIN_PRIO", prio_lo)));
+    if (int rc = pad_streams(1, prio_of("EFTB_SIDE_PRIO", 0))) return rc;
     HIPCHK(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio_of("EFTB_SIDE_PRIO", 0)));
+    if (int rc = pad_streams(2, prio_of("EFTB_PRE_PRIO", prio_hi))) return rc;
     HIPCHK(hipStreamCreateWithPriority(&e->pre, hipStreamNonBlocking, prio_of("EFTB_PRE_PRIO", prio_hi)));
     HIPCHK(hipEventCreateWithFlags(&e->evPrep, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->evFront, hipEventDisableTiming));
@@ -1455,6 +1499,7 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     {
         int bp = prio_lo;  // measured: 290 k evaluations/s with the back half at low priority, 286 k at high, 278 k without the stream
         if (const char* f = getenv("EFTB_BACK_PRIO")) bp = atoi(f) > 0 ? prio_lo : (atoi(f) < 0 ? prio_hi : 0);
+        if (int rc = pad_streams(3, bp)) return rc;
         HIPCHK(hipStreamCreateWithPriority(&e->back, hipStreamNonBlocking, bp));
     }
     HIPCHK(hipEventCreateWithFlags(&e->evResum, hipEventDisableTiming));
@@ -1752,6 +1797,19 @@ int eftb_set_option(eftb_engine* e, int option, int value) {
         case EFTB_O_TIME_DOMINANT: e->time_dominant = value < 0 ? 0 : value; e->time_seqk[0] = e->time_seqk[1] = e->time_seqk[2] = 0; return 0;
         case EFTB_O_LATENCY_MODE: e->latency_auto = value != 0; return 0;
         case EFTB_O_PLK_DIRECT: e->plk_direct = value != 0; return 0;
+        case EFTB_O_STEP_TRACE:
+            if (value && !e->evTraceBase) {
+                HIPCHK(hipSetDevice(e->c.device));
+                HIPCHK(hipEventCreate(&e->evTraceBase));
+                for (auto& row : e->evTrace)
+                    for (hipEvent_t& ev : row) HIPCHK(hipEventCreate(&ev));
+            }
+            if (value) {
+                HIPCHK(hipEventRecord(e->evTraceBase, e->stream));
+                e->trace_n = 0;
+            }
+            e->trace_on = value != 0;
+            return 0;
         case EFTB_O_SUBMIT_HOLD: e->sub_hold.store(value != 0, std::memory_order_release); return 0;
         case EFTB_O_SUBMIT_THREAD:
             if (value < 0 || value > 2) return fail("eftb_set_option: EFTB_O_SUBMIT_THREAD takes 0, 1 or 2");
@@ -1905,6 +1963,11 @@ void eftb_destroy(eftb_engine* e) {
                 if (id == EFTB_B_PLK && e->staged_plk_device) (void)hipFree(e->setbuf[q][id]);
                 else (void)hipHostFree(e->setbuf[q][id]);
             }
+    }
+    if (e->evTraceBase) {
+        (void)hipEventDestroy(e->evTraceBase);
+        for (auto& row : e->evTrace)
+            for (hipEvent_t ev : row) if (ev) (void)hipEventDestroy(ev);
     }
     if (e->set_done) (void)hipHostFree(const_cast<unsigned long long*>(e->set_done));
     if (e->sub_stats && e->issue_n)
@@ -2092,6 +2155,7 @@ static int staged_setup(eftb_engine* e) {
     HIPCHK(hipSetDevice(e->c.device));
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (int rc = pad_streams(4, prio_hi)) return rc;
     HIPCHK(hipStreamCreateWithPriority(&e->cpy, hipStreamNonBlocking, prio_hi));
     size_t off = 0;
     for (int id : kStagedIn) {
@@ -2162,7 +2226,9 @@ static int staged_setup(eftb_engine* e) {
     e->out_mode = getenv("EFTB_OUT_STREAM") ? atoi(getenv("EFTB_OUT_STREAM")) : 0;
     if (e->out_mode) {
         const int oprio = getenv("EFTB_OUT_PRIO") ? atoi(getenv("EFTB_OUT_PRIO")) : 1;   // 1 low, 0 normal, -1 high
-        if (e->out_mode == 1) HIPCHK(hipStreamCreateWithPriority(&e->outq, hipStreamNonBlocking, oprio > 0 ? prio_lo : (oprio < 0 ? prio_hi : 0)));
+        if (e->out_mode == 1) {
+            HIPCHK(hipStreamCreateWithPriority(&e->outq, hipStreamNonBlocking, oprio > 0 ? prio_lo : (oprio < 0 ? prio_hi : 0)));
+        }
         for (int q = 0; q < eftb_engine::NSETS; ++q) HIPCHK(hipEventCreateWithFlags(&e->evOut[q], hipEventDisableTiming));
     }
     e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first staged launch; sets 0, 1, 2, 3 follow in turn
@@ -2227,6 +2293,13 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
         }
         if (sg.n && !WHATIF_SKIP(1024)) hipLaunchKernelGGL(stage_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sg);
     };
+    e->trace_slot = -1;
+    if (e->trace_on && !lat && e->evTraceBase) {
+        e->trace_slot = (int)(e->trace_n++ % eftb_engine::NTRACE);
+        e->trace_B[e->trace_slot] = Bt;
+        e->trace_launch[e->trace_slot] = L;
+        trace_point(e, 0, cs);
+    }
     e->set_latency[q] = lat;
     if (lat) {
         // the small arrays go first and on the compute queue itself (in line in front of the step's kernels: no cross-queue hand-over; the
@@ -2238,6 +2311,7 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
         HIPCHK(hipEventRecord(e->evStagedAllR[lr], cs));
     } else {
         gather(0, 6, cs);
+        trace_point(e, 9, cs);
         HIPCHK(hipEventRecord(e->evStagedR[lr], cs));
     }
     // the set becomes current and the launch goes out
@@ -2275,13 +2349,14 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     e->plk_host_out = nullptr;
     e->buf[EFTB_B_PIN] = pin_dev;
     e->status_slot = eftb_engine::NSETS;
-    if (rc) return rc;
+    if (rc) { e->trace_slot = -1; return rc; }
     for (int j = 0; j < n; ++j) {  // shape of the output rows (after the pipeline operator, if the mask has one)
         eftb_engine::StepRec& r = e->rec[cmds[j].step % eftb_engine::SUBREC];
         r.nl = e->cur_nl; r.nx = e->cur_nx;
     }
     hipStream_t last = e->back_pending ? e->back : e->stream;  // the launch ends where its back half ran
     if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAllR[lr], 0));  // (the set is not "done" before its own upload is)
+    constexpr int copy_wgs = 48;   // (8 ... 512 workgroups measured the same: the kernel's time is the PCIe transfer)
     hipStream_t done_on = last;  // where the launch's LAST work runs: what the set's event and completion word follow
     static const bool flow_cword = !(getenv("EFTB_FLOW_CWORD") && !atoi(getenv("EFTB_FLOW_CWORD")));
     if (e->done_words && !lat && flow_cword) {   // compute finished: what the submission thread's flow control counts (the copy-out below is not part of it)
@@ -2297,10 +2372,12 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
             done_on = oq;
         }
         if (!WHATIF_SKIP(512))
-        hipLaunchKernelGGL(copy16_kernel, dim3(48), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
+        hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
     }
     if (e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], (size_t)Bt * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
+    trace_point(e, 8, done_on);
+    e->trace_slot = -1;
     HIPCHK(hipEventRecord(e->evSetDone[q], done_on));
     if (e->back_pending && e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipEventRecord(e->evBack[(e->back_step + 1) & 1], last));  // whoever joins the back half also waits for the copy
@@ -2614,6 +2691,32 @@ int eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[6]) {
     }
     if (reset) { e->issue_n = e->inline_n = e->launch_n = 0; e->issue_ns = e->fill_ns = e->wait_ns = 0.0; }
     e->sub_stats = enable != 0;
+    return 0;
+}
+
+int eftb_step_trace(eftb_engine* e, double* out, int max_launches, int* n_out) {
+    if (!e || !out || !n_out) return fail("eftb_step_trace: null argument");
+    sub_drain(e);
+    HIPCHK(hipSetDevice(e->c.device));
+    if (!e->evTraceBase) return fail("eftb_step_trace: EFTB_O_STEP_TRACE was never switched on");
+    HIPCHK(sync_all(e));
+    const unsigned long long total = e->trace_n, first = total > (unsigned long long)eftb_engine::NTRACE ? total - eftb_engine::NTRACE : 0;
+    int n = 0;
+    for (unsigned long long i = first; i < total && n < max_launches; ++i) {
+        const int sl = (int)(i % eftb_engine::NTRACE);
+        double* row = out + (size_t)n * (eftb_engine::NTP + 2);
+        row[0] = (double)e->trace_launch[sl];
+        row[1] = (double)e->trace_B[sl];
+        bool ok = true;
+        for (int p = 0; p < eftb_engine::NTP; ++p) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e->evTraceBase, e->evTrace[sl][p]) != hipSuccess) { (void)hipGetLastError(); ok = false; ms = -1.f; }
+            row[2 + p] = ms * 1e3;
+        }
+        (void)ok;
+        ++n;
+    }
+    *n_out = n;
     return 0;
 }
 

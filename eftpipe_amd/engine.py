@@ -189,6 +189,17 @@ class Engine:
         2: every step is queued, also one that finds the GPU idle (tests)."""
         L.check(self.lib.eftb_set_option(self._h, 8, int(flag)))
 
+    def step_trace(self, flag=None):
+        """Measurement: step_trace(True) starts recording GPU timestamps at nine points of every staged direct-P_l launch; step_trace() returns
+        the last (up to 64) launches as an array [n, 14] (columns 11-13: upload end, first-stage products end, anti-diagonal sums end): launch number, cosmologies, then upload start, front end, synthesis start, operand build
+        end, resummation start, resummation end, spline start, AP end, copy-out end in microseconds since the recording started."""
+        if flag is not None:
+            L.check(self.lib.eftb_set_option(self._h, 10, int(bool(flag))))
+            return None
+        out, n = np.zeros((64, 14)), C.c_int()
+        L.check(self.lib.eftb_step_trace(self._h, L.dptr(out), 64, C.byref(n)))
+        return out[: n.value]
+
     def hold_submissions(self, flag):
         """Tests: True makes the submission thread leave queued steps in the queue until hold_submissions(False) (so that they leave together)."""
         L.check(self.lib.eftb_set_option(self._h, 9, int(bool(flag))))

@@ -160,6 +160,9 @@ enum eftb_option {
                                  0 (default): templates first, as the reference computes them (BirdSnapshot semantics) */
     EFTB_O_TIME_KERNEL = 7,   /* which launches EFTB_O_TIME_DOMINANT brackets, a set of: 1 (default) the resummation kernel, 2 the synthesis launch of
                                  the loop stages (synth_kernel), 4 the heaviest AP kernel (ap_weights_kernel; direct-P_l runs: ap_plk_kernel) -- measurement only */
+    EFTB_O_STEP_TRACE = 10,   /* measurement: timing events at nine points of every staged direct-P_l launch (upload start, front end, synthesis start,
+                                 operand build end, resummation start / end, spline start, AP end, copy-out end), each on its own stream; read with
+                                 eftb_step_trace.  Switching it on (again) restarts the clock. */
     EFTB_O_SUBMIT_HOLD = 9,   /* tests: 1 makes the submission thread leave queued steps where they are until the option is cleared (or any entry point
                                  that needs the queue empty is called) -- the steps queued meanwhile then leave together, as eftb_config.step_batch allows */
     EFTB_O_SUBMIT_THREAD = 8  /* 1 (default; also EFTB_SUBMIT_THREAD=0/1): staged steps handed in while earlier ones are still queued or running are
@@ -287,6 +290,10 @@ int  eftb_step(eftb_engine* e, int stage_mask, int B, const double* Pin, const d
  * {steps issued, of which by the caller's thread, us spent issuing (upload kernel + launches + events, whichever thread), us spent copying inputs
  * into the staging blocks, us the caller spent waiting for results in eftb_fetch_*, launches that carried those steps}; reset != 0 clears the sums. */
 int  eftb_submit_stats(eftb_engine* e, int enable, int reset, double out[6]);
+
+/* The last (up to 64) traced launches (EFTB_O_STEP_TRACE), oldest first: out[i][0] = launch number, out[i][1] = cosmologies it carried, out[i][2..13] = the
+ * twelve timestamps (the nine of EFTB_O_STEP_TRACE, then upload end, first-stage products end, anti-diagonal sums end) in microseconds since the option was switched on (-1000: point not recorded).  Waits for everything in flight. */
+int  eftb_step_trace(eftb_engine* e, double* out, int max_launches, int* n_out);
 
 /* Page-locked host memory for the I/O buffers of eftb_eval_batch / eftb_put / eftb_get: D2H of the template block runs at
  * the PCIe rate instead of through the driver's pageable staging copy.  NULL on failure (eftb_last_error). */
