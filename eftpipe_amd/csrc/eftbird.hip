@@ -2371,7 +2371,9 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
             HIPCHK(hipStreamWaitEvent(oq, e->evOut[q], 0));
             done_on = oq;
         }
-        if (!WHATIF_SKIP(512))
+        if (WHATIF_SKIP(2048) && e->PLK0)   // (what-if: the same kernel with a device destination -- the stream holds it, PCIe does not)
+            hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->PLK0, cnt);
+        else if (!WHATIF_SKIP(512))
         hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
     }
     if (e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)

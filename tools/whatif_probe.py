@@ -11,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {1: "prep_rows_qf", 2: "gemm_direct (first stage)", 4: "antidiag", 8: "build_rows_plk", 16: "synth", 32: "back_prep_plk", 64: "resum_plk", 128: "spline",
-         256: "ap_plk_fused", 512: "copy16", 1024: "stage_gather"}
+         256: "ap_plk_fused", 512: "copy16", 1024: "stage_gather", 2048: "the PCIe leg of copy16 (device destination)"}
 
 
 def child():
@@ -57,7 +57,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child()
         sys.exit(0)
-    skips = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 1 | 2 | 4 | 8, 16 | 32, 128 | 256, 0]
+    skips = [int(x) for x in os.environ["WI_SKIPS"].split(",")] if os.environ.get("WI_SKIPS") else [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 2048, 1 | 2 | 4 | 8, 16 | 32, 128 | 256, 0]
     base = None
     for sk in skips:
         env = dict(os.environ, EFTB_LIB=os.path.join(ROOT, "eftpipe_amd", "libeftbird_whatif.so"), EFTB_WHATIF_SKIP=str(sk))
