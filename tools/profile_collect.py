@@ -42,6 +42,11 @@ import json as _json
 _traced = _json.loads([ln for ln in open(os.path.join(src, "bench_under_rocprof.json")) if ln.startswith("{")][0])
 _idx = int(_traced.get("warmup_steps_run", _traced.get("warmup", 3))) + _traced.get("steps", 20) // 2
 _mark = "resum_plk" if "roofline_templates_first" in _traced.get("roofline", {}) else "resum_mfma"  # the timed loop runs direct-P_l steps when it reports both
+# (coalesced launches: fewer resummation launches than steps -- take the index as the same FRACTION of the launches the trace holds)
+import csv as _csv
+_nres = sum(1 for r in _csv.DictReader(open(find("stats_kernel_trace.csv"))) if _mark in r["Kernel_Name"])
+_nsteps_total = int(_traced.get("warmup_steps_run", 3)) + 3 * _traced.get("steps", 20) + 40   # warm-up + timed + templates-first + checks (rough: only the fraction matters)
+_idx = max(2, min(_nres - 3, int(_nres * (int(_traced.get("warmup_steps_run", 3)) + _traced.get("steps", 20) // 2) / max(_nsteps_total, 1))))
 tl = subprocess.run([sys.executable, os.path.join(root, "tools", "timeline.py"), find("stats_kernel_trace.csv"), str(_idx), _mark], capture_output=True, text=True).stdout
 open(os.path.join(dst, f"{tag}_overlap_timeline.txt"), "w").write(
     "One steady-state step of the pipelined timed loop (rocprofv3 --kernel-trace of bench.py; q = HSA queue: main / side / look-ahead / back / copy; under the tracer the host, not the GPU, sets the pace of direct-P_l steps).\n" + tl)
