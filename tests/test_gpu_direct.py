@@ -351,3 +351,49 @@ def test_coalesced_steps_return_the_bits_of_separate_steps(direct):
     for back in range(depth - 1, -1, -1):
         assert np.array_equal(eng.fetch_previous("PLK", (B, bench.NL, bench.NK), back=back), ref[(K - 1 - back) % 5]), back
     eng.close()
+
+
+def test_measurement_taps_of_the_staged_loop():
+    """The measurement interfaces bench.py and tools/step_trace.py read: host clocks of the staged steps (eftb_submit_stats), the batch the kernel
+    timers saw (eftb_kernel_time_ex) and the per-launch timeline (EFTB_O_STEP_TRACE) -- consistent with what was submitted, and without touching the results."""
+    import bench
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    B, K, depth = 16, 18, 5
+    k = synth.survey_kgrid(bench.NK)
+    cfg = EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, bench.Z)), H_AP=float(synth.hubble(synth.OM_AP, bench.Z)))
+    eng = Engine(cfg, max_batch=B, coalesce=3)
+    s = _draws(B, 61)
+    ref = _plk(eng, s, B, True)
+    eng.set_plk_direct(True)
+    eng.set_latency_mode(False)
+    mask = eng.full_mask(reduce=True)
+    eng.submit_stats(enable=True, reset=True)
+    eng.time_kernels(7)
+    eng.time_dominant(1)
+    for kind in range(3):
+        eng.kernel_time(kind, reset=True)
+    eng.step_trace(True)
+    for i in range(K):
+        view = eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], back=depth if i >= depth else -1, shape=(B, bench.NL, bench.NK))
+        if i >= depth:
+            assert np.array_equal(view, ref), i
+    for back in range(depth - 1, -1, -1):
+        assert np.array_equal(eng.fetch_previous("PLK", (B, bench.NL, bench.NK), back=back), ref)
+    eng.sync()
+    st = eng.submit_stats(enable=False)
+    assert st["steps"] == K and 1 <= st["launches"] <= K and st["issue_us_per_step"] > 0.0
+    tr = eng.step_trace()
+    eng.step_trace(False)
+    assert len(tr) == st["launches"] and tr[:, 1].sum() == K * B        # every launch traced, every cosmology counted once
+    pts = tr[:, 2:]
+    assert np.all(pts >= 0.0)
+    for a, b in ((0, 9), (9, 10), (10, 11), (11, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8)):   # the order of a launch's dependency chain
+        assert np.all(pts[:, b] >= pts[:, a]), (a, b)
+    assert np.all(np.diff(pts[:, 8]) > 0)                                # launches complete in order
+    for kind in range(3):
+        ms, n, nc = eng.kernel_time(kind, reset=True, cosmologies=True)
+        assert n == st["launches"] and nc == K * B and ms > 0.0, kind
+    eng.time_dominant(False)
+    eng.close()
