@@ -40,7 +40,7 @@ BS = [2.1401334, 0.77616816 / np.sqrt(2.0), 0.77003455, 0.77616816 / np.sqrt(2.0
 ES = (0.26033594, 0.0, -0.92895016)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix peak (not in the local guide; measured issue rate reported beside it)
 NPOW, NS_DEV, NKLOW = 257, 80, 7
-COALESCE = int(os.environ.get("EFTB_BENCH_COALESCE", "3"))  # steps the engine may launch together when they are still queued (Engine(coalesce=...): device state for COALESCE x batch)
+COALESCE = int(os.environ.get("EFTB_BENCH_COALESCE", "4"))  # steps the engine may launch together when they are still queued (Engine(coalesce=...): device state for COALESCE x batch)
 DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "12"))  # steps queued on the GPU ahead of the one being fetched (1..6; direct-P_l steps are four pipeline stages deep: 618-650 k evaluations/s at 2, 660-668 k at 3, 663-695 k at 4; templates first, round 2: measured 276-279 k evaluations/s at 2, 279 k at 3 over 40 steps, and 273 k vs 266 k over 20: the drain is longer)
 DIRECT = os.environ.get("EFTB_BENCH_DIRECT", "1") != "0"   # `value` on direct-P_l runs (EFTB_O_PLK_DIRECT); 0: templates first
 

@@ -267,7 +267,7 @@ struct eftb_engine {
     char sub_err[SUBREC][256] = {};
     int coalesce_max = 1;                    // steps per launch at most (EFTB_COALESCE; 1 unless step_batch < max_batch)
     int sub_low = 2;                         // ... and below which it launches whatever is queued at once (EFTB_SUB_LOW); between the two it waits for a full group
-    int sub_inflight = 3;                    // launches the submission thread keeps in flight before it lets the queue grow (EFTB_SUB_INFLIGHT)
+    int sub_inflight = 4;                    // launches the submission thread keeps in flight before it lets the queue grow (EFTB_SUB_INFLIGHT)
     unsigned long long launch_seq = 0;       // staged launches issued so far (issuing thread)
     unsigned long long launch_done = 0;      // ... of which known to have finished (issuing thread's view)
     int lring_set[NLRING] = {};              // set of launch (seq % NLRING)
@@ -2371,7 +2371,11 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
             HIPCHK(hipStreamWaitEvent(oq, e->evOut[q], 0));
             done_on = oq;
         }
-        if (WHATIF_SKIP(2048) && e->PLK0)   // (what-if: the same kernel with a device destination -- the stream holds it, PCIe does not)
+        // the DMA engine, in line behind the launch's last kernel (same-box A/B over 200 steps: 0.091-0.096 ms per step against 0.102-0.104 with
+        // copy16_kernel -- the what-if runs priced the kernel's PCIe stores at a fifth of the step; EFTB_PLK_DMA=0 brings the kernel back)
+        static const bool plk_dma = !(getenv("EFTB_PLK_DMA") && !atoi(getenv("EFTB_PLK_DMA")));
+        if (plk_dma) HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], cnt * sizeof(double), hipMemcpyDeviceToHost, done_on));
+        else if (WHATIF_SKIP(2048) && e->PLK0)   // (what-if: the same kernel with a device destination -- the stream holds it, PCIe does not)
             hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->PLK0, cnt);
         else if (!WHATIF_SKIP(512))
         hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
