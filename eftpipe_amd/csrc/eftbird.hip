@@ -2374,11 +2374,11 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
         // the DMA engine, in line behind the launch's last kernel (same-box A/B over 200 steps: 0.091-0.096 ms per step against 0.102-0.104 with
         // copy16_kernel -- the what-if runs priced the kernel's PCIe stores at a fifth of the step; EFTB_PLK_DMA=0 brings the kernel back)
         static const bool plk_dma = !(getenv("EFTB_PLK_DMA") && !atoi(getenv("EFTB_PLK_DMA")));
-        if (plk_dma) HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], cnt * sizeof(double), hipMemcpyDeviceToHost, done_on));
-        else if (WHATIF_SKIP(2048) && e->PLK0)   // (what-if: the same kernel with a device destination -- the stream holds it, PCIe does not)
+        if (WHATIF_SKIP(512)) {   // (what-if: P_l stays on the device)
+        } else if (WHATIF_SKIP(2048) && e->PLK0)   // (what-if: the copy kernel with a device destination -- the stream holds it, PCIe does not)
             hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->PLK0, cnt);
-        else if (!WHATIF_SKIP(512))
-        hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
+        else if (plk_dma) HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], cnt * sizeof(double), hipMemcpyDeviceToHost, done_on));
+        else hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
     }
     if (e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
         HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], (size_t)Bt * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));

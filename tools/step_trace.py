@@ -14,7 +14,7 @@ from eftpipe_amd.engine import Engine
 from eftpipe_amd.parambasis import bias_row
 from eftpipe_amd.tables import EngineConfig
 
-Z, B, K, DEPTH, CO = 0.7, 128, int(os.environ.get("ST_K", 90)), int(os.environ.get("ST_DEPTH", 12)), int(os.environ.get("ST_COALESCE", 3))
+Z, B, K, DEPTH, CO = 0.7, 128, int(os.environ.get("ST_K", 90)), int(os.environ.get("ST_DEPTH", 12)), int(os.environ.get("ST_COALESCE", 4))
 cfg = EngineConfig(Nl=3, k=synth.survey_kgrid(512), with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
 eng = Engine(cfg, max_batch=B, coalesce=CO)
 eng.set_latency_mode(False)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What does each kernel of a direct-P_l step cost the pipelined, coalescing loop?  (GPU box; needs `make -C eftpipe_amd/csrc whatif`.)
-Runs the staged loop of bench.py (depth 12, coalesce 3, 128 per step) once per entry of SKIPS in a fresh child process with
+Runs the staged loop of bench.py (depth 12, coalesce 4, 128 per step) once per entry of SKIPS in a fresh child process with
 EFTB_LIB=libeftbird_whatif.so and EFTB_WHATIF_SKIP set: the named kernels are not launched (the results of those runs are garbage; only the time
 per step is read).  The difference to the full run is what the kernel costs the step -- against its stand-alone duration (tools/kstat_direct.sh)."""
 import json
@@ -11,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {1: "prep_rows_qf", 2: "gemm_direct (first stage)", 4: "antidiag", 8: "build_rows_plk", 16: "synth", 32: "back_prep_plk", 64: "resum_plk", 128: "spline",
-         256: "ap_plk_fused", 512: "copy16", 1024: "stage_gather", 2048: "the PCIe leg of copy16 (device destination)"}
+         256: "ap_plk_fused", 512: "the copy-out of P_l (DMA; EFTB_PLK_DMA=0: copy16_kernel)", 1024: "stage_gather", 2048: "the PCIe leg of copy16_kernel (device destination)"}
 
 
 def child():
@@ -25,7 +25,7 @@ def child():
 
     Z, B, K, DEPTH = 0.7, 128, int(os.environ.get("WI_K", 200)), 12
     cfg = EngineConfig(Nl=3, k=synth.survey_kgrid(512), with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, Z)), H_AP=float(synth.hubble(synth.OM_AP, Z)))
-    eng = Engine(cfg, max_batch=B, coalesce=3)
+    eng = Engine(cfg, max_batch=B, coalesce=4)
     eng.set_latency_mode(False)
     eng.set_plk_direct(True)
     sets = []
