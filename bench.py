@@ -433,11 +433,16 @@ def main():
     for kind in range(3):
         eng.kernel_time(kind, reset=True)
     eng.submit_stats(enable=True, reset=True)   # host clocks of the staged steps (two steady_clock reads per call: ~50 ns)
+    import gc
+
+    gc.collect()
+    gc.disable()   # (a generation-2 collection inside a 2.5 ms timed region is a 20 % outlier; the loop allocates next to nothing)
     cp.barrier()
     t0 = time.perf_counter()
     loop(W, K, keep=True)
     cp.barrier()
     elapsed = cp.max(time.perf_counter() - t0)
+    gc.enable()
     host_stats = eng.submit_stats(enable=False, reset=True)
     if STEP_TIMES:
         print("[bench] fetch-complete times since t0 (ms):", " ".join(f"{(t - t0) * 1e3:.3f}" for t in STEP_TIMES), file=sys.stderr)

@@ -895,32 +895,43 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 // regroup_kernel (reference pybird.py:737-866 followed by parambasis.py:42-136): row 0 of the template block takes sum_row b_row T[l][row] over the
 // rows the AP stage distorts (rows < 21, all rows when stoch0), rows 21-23 the stochastic templates as always (ap_plk_kernel adds them with their
 // coefficients); rows 1-20 of the block are not written.
-__device__ __forceinline__ void regroup_plk_body(int kx, int w, int l, int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
+__device__ __forceinline__ void regroup_plk_body(int kx, int w, int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
                                                  const double* __restrict__ Y22, const double* __restrict__ P13,
                                                  const double* __restrict__ l11, const double* __restrict__ lct,
                                                  const double* __restrict__ bias, double* __restrict__ T, int stoch0) {
     // Y22[w][l][k] (row stride BAS22 Nk per cosmology), P13[w][l][k] (10 Nk per cosmology): the loop pieces already contracted with the
     // bias (build_rows_plk_kernel) and synthesised; here the linear and counter terms join, the values at the first k are subtracted
-    // (shot-noise subtraction, reference pybird.py:799-800) and the stochastic templates are laid beside the row
+    // (shot-noise subtraction, reference pybird.py:799-800) and the stochastic templates are laid beside the row.  A thread takes its k for
+    // every l (round 4: a third of the waves of the per-(k, l) form, the same arithmetic per output)
     const int k = kx * blockDim.x + threadIdx.x;
     if (k >= Nk) return;
     const double* bw = bias + (size_t)w * NROW;
-    const double* y22 = Y22 + ((size_t)w * BAS22 + l) * Nk;
-    const double* q13 = P13 + ((size_t)w * 10 + l) * Nk;
     const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
-    double b11 = 0.0, bct = 0.0;
+    double y22[3], q13[3], y0[3], q0[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) b11 = fma(bw[r], l11[l * 3 + r], b11);
+    for (int l = 0; l < 3; ++l)
+        if (l < Nl) {
+            const double* yr = Y22 + ((size_t)w * BAS22 + l) * Nk;
+            const double* qr = P13 + ((size_t)w * 10 + l) * Nk;
+            y22[l] = yr[k]; y0[l] = yr[0]; q13[l] = qr[k]; q0[l] = qr[0];
+        }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) bct = fma(bw[3 + r], lct[l * 6 + r], bct);
-    const double s21 = l == 0 ? 1.0 : 0.0, s22 = l == 0 ? kv * kv : 0.0, s23 = l == 1 ? kv * kv : 0.0;
-    double tot = (b11 + bct * kv * kv) * p11 + ((y22[k] - y22[0]) + (q13[k] - q13[0]));
-    if (stoch0) tot += bw[21] * s21 + bw[22] * s22 + bw[23] * s23;  // APst: the stochastic templates are distorted with the others
-    double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
-    t[0] = tot;
-    t[(size_t)21 * Nk] = s21;
-    t[(size_t)22 * Nk] = s22;
-    t[(size_t)23 * Nk] = s23;
+    for (int l = 0; l < 3; ++l) {
+        if (l >= Nl) break;
+        double b11 = 0.0, bct = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) b11 = fma(bw[r], l11[l * 3 + r], b11);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) bct = fma(bw[3 + r], lct[l * 6 + r], bct);
+        const double s21 = l == 0 ? 1.0 : 0.0, s22 = l == 0 ? kv * kv : 0.0, s23 = l == 1 ? kv * kv : 0.0;
+        double tot = (b11 + bct * kv * kv) * p11 + ((y22[l] - y0[l]) + (q13[l] - q0[l]));
+        if (stoch0) tot += bw[21] * s21 + bw[22] * s22 + bw[23] * s23;  // APst: the stochastic templates are distorted with the others
+        double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
+        t[0] = tot;
+        t[(size_t)21 * Nk] = s21;
+        t[(size_t)22 * Nk] = s22;
+        t[(size_t)23 * Nk] = s23;
+    }
 }
 
 // optiresum: the BAO peak of every xi piece (one workgroup = one series of 80 s slots; reference pybird.py:1382-1400)
@@ -1517,7 +1528,7 @@ __global__ __launch_bounds__(256) void back_prep_plk_kernel(int nreg, int nkx, i
                                                             const double* __restrict__ Cct, const double* __restrict__ YCF, double* __restrict__ CF) {
     const int id = blockIdx.x;
     if (id < nreg) {
-        regroup_plk_body(id % nkx, (id / nkx) % B, id / (nkx * B), Nk, Nl, kk, P11, Y22, P13, l11, lct, bias, T, stoch0);
+        regroup_plk_body(id % nkx, id / nkx, Nk, Nl, kk, P11, Y22, P13, l11, lct, bias, T, stoch0);
     } else {
         const int j = id - nreg;
         resum_prep_plk_body(j % B, j / B, nparts, NN, NIR, Na, Q, XY, C11, Cct, YCF, CF);

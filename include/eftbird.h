@@ -267,6 +267,10 @@ int  eftb_eval_logp_batch(eftb_engine* e, int B, const double* Pin, const double
 int  eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H,
                        const double* bias, const double* rows);
 int  eftb_run_staged(eftb_engine* e, int stage_mask, int B);
+/* (Round 4.)  A staged step handed in while earlier ones are still queued or running is only QUEUED by eftb_run_staged: the library's submission
+ * thread issues it (EFTB_O_SUBMIT_THREAD), together with whatever else is queued by then if eftb_config.step_batch allows.  A launch error of such
+ * a step cannot be returned by eftb_run_staged any more: the step still counts (`back` indices are positions in the sequence of steps handed in) and
+ * the eftb_fetch_* call of THAT step returns the error; the same holds for a step the calling thread issued itself. */
 /* EFTB_B_PLK or EFTB_B_LOGP of the step before the one in flight (waits only for that step). */
 int  eftb_fetch_previous(eftb_engine* e, int buffer_id, double* host, size_t count);
 /* The same for the step launched `back` (0 = the last one itself, 1 ... 15) steps before the last one.  The engine keeps sixteen sets of per-launch inputs / outputs, so the
