@@ -196,7 +196,6 @@ struct eftb_engine {
     unsigned front_step = 0;
     bool prev_front_side = false;
     bool upload_on_side = true;         // EFTB_UPLOAD_ON_SIDE=0: staged uploads always on the copy stream
-    bool synth_direct = false;          // EFTB_SYNTH_DIRECT=1: the syntheses of direct-P_l runs on gemm_direct_kernel
     bool ap_plk_fused = false;          // the AP stage of direct-P_l runs as ap_plk_fused_kernel (k grids whose tables fit the LDS; EFTB_AP_PLK_FUSED=0: ap_prefix + ap_plk_mom)
     bool ap_plk_nodes = false;          // EFTB_AP_PLK_NODES=1: the AP stage of direct-P_l runs as the node quadrature (ap_plk_kernel, round 3) instead of the moment form
     double* PLK0 = nullptr;             // direct-P_l runs with a PROJECT stage: P_l [B][Nl][Nk] as the AP stage leaves it (the operator then takes ONE row per cosmology)
@@ -283,16 +282,10 @@ struct eftb_engine {
     // completion words of the staged sets in mapped page-locked memory: the step's last stream writes 1 + its step number behind everything else
     // (hipStreamWriteValue64), so the fetch of a step polls plain memory -- a hipEventQuery loop on the caller's thread takes the runtime's locks
     // thousands of times per step and slows the submission thread's launches down (measured: no gain from the thread at all with the event spin)
-    // P_l of a pipelined launch leaves on a stream of its own (copy16_kernel behind an event on the launch's last stream): on the back stream the
-    // 1.6 MB per 128 cosmologies of PCIe stores (27 us) sat in front of the next launch's spline / AP kernels and inside the launch's completion --
-    // what-if runs (tools/whatif_probe.py) priced it at 22.7 us of a 101 us step, more than the resummation kernel.  The flow control of the
-    // submission thread counts a launch as finished when its COMPUTE is (second word per set), the fetch when the copy is
-    hipStream_t outq = nullptr;
-    int out_mode = 0;
-    hipEvent_t evOut[NSETS] = {};
     volatile unsigned long long* set_done = nullptr;
     unsigned long long set_word[NSETS] = {};  // 1 + the launch whose completion write was enqueued for the set (else the set's event is what to wait for)
     unsigned long long set_cword[NSETS] = {}; // ... whose compute-done write was (set_done[NSETS + q])
+    bool plk_dma = true;                      // EFTB_PLK_DMA=0: P_l of a pipelined launch through copy16_kernel instead of the DMA engine
     bool done_words = true;                   // EFTB_DONE_WORDS=0: event queries (A/B); also the fall-back when the write command is refused
     // EFTB_O_STEP_TRACE: GPU timestamps (timing events) at nine points of every staged direct-P_l launch -- upload start, front end, synthesis
     // start, operand build end, resummation start / end, spline start, AP end, copy-out end -- on their own streams: an undistorted timeline of
@@ -674,7 +667,7 @@ static inline void join_back(eftb_engine* e) {
 // every stream of the engine drained (setters that replace resident tables / likelihood data)
 static hipError_t sync_all(eftb_engine* e) {
     join_back(e);
-    for (hipStream_t q : {e->stream, e->side, e->pre, e->back, e->cpy, e->outq, e->comm_stream})
+    for (hipStream_t q : {e->stream, e->side, e->pre, e->back, e->cpy, e->comm_stream})
         if (q) {
             const hipError_t rc = hipStreamSynchronize(q);
             if (rc != hipSuccess) return rc;
@@ -963,11 +956,8 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
         }
         {
             const int tslot = (mask & EFTB_S_REGROUP) ? timer_begin(e, st, 1) : -1;
-            // (direct-P_l runs: three rows per cosmology and product -- problems with few rows per column tile, the shape gemm_direct_kernel was
-            // written for: one 16 x 32 tile per workgroup, K split over its four waves, no LDS staging and no barrier in the K loop)
             if (direct && WHATIF_SKIP(16)) {
-            } else if (direct && e->synth_direct) { if (int rc = launch_gemm_direct(st, sb, 4)) return rc; }
-            else launch_synth(st, sb);
+            } else launch_synth(st, sb);
             timer_end(e, st, tslot);
         }
         if ((k22 || c22) && !direct) {  // (direct-P_l runs contract the basis rows themselves: regroup_plk_kernel, resum_prep_plk_kernel)
@@ -1040,7 +1030,7 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 if (hipStreamWaitEvent(st, e->evRsDone[rslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             }
             if (full && direct) {
-                static const int nparts = getenv("EFTB_BPP_PARTS") ? std::max(1, std::min(NS, atoi(getenv("EFTB_BPP_PARTS")))) : 5;  // slices of the s range per cosmology
+                constexpr int nparts = 5;  // slices of the s range per cosmology (3 / 2 / 1 measured 17 / 21 / 37 us alone at B = 128 against 12.6)
                 const int nsl = (NS + nparts - 1) / nparts;
                 const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 2 * 3 * nsl) * sizeof(double);
                 const int nkx = (Nk + 255) / 256, nreg = nkx * B;   // (regroup: one workgroup per (256 k, cosmology), all three l)
@@ -1078,25 +1068,12 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 tb<double>(e, nnlo_pass ? EFTB_T_LCTN : EFTB_T_LCT), b[EFTB_B_TEMPL], e->part, nsplit
             const int nkb = (Nk - (c.Nklow & ~15) + 63) / 64;  // Nl = 3: k tiles aligned to 16, (k block, cosmology) decoded from a flat index
             if (direct) {
-                // four k per lane, four slices of the s range (round 3 measured 4 x 2: 38-41 us; 4 x 1: 45, 2 x 1: 42, 2 x 2: 44, 1 x 2: 56, 2 x 4: 38)
-                static const int shape = getenv("EFTB_RPLK") ? atoi(getenv("EFTB_RPLK")) : 44;   // (KPL, SH) as two digits: A/B runs of the wave shape
-#define RPLK_LAUNCH(KPLV, SHV)                                                                                                                        \
-    do {                                                                                                                                              \
-        const int nkd = (Nk + 64 * KPLV - 1) / (64 * KPLV);                                                                                           \
-        hipLaunchKernelGGL((resum_plk_kernel<KPLV, SHV>), dim3(nkd * 3 * B), dim3(192 * SHV), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K),           \
-                           tb<double>(e, EFTB_T_H), e->RSAS, b[EFTB_B_TEMPL], nkd);                                                                   \
-    } while (0)
-                if (kblocks > 0 && !WHATIF_SKIP(64)) {
-                    if (shape == 81) RPLK_LAUNCH(8, 1);
-                    else if (shape == 82) RPLK_LAUNCH(8, 2);
-                    else if (shape == 84) RPLK_LAUNCH(8, 4);
-                    else if (shape == 44) RPLK_LAUNCH(4, 4);
-                    else if (shape == 41) RPLK_LAUNCH(4, 1);
-                    else if (shape == 24) RPLK_LAUNCH(2, 4);
-                    else if (shape == 42) RPLK_LAUNCH(4, 2);
-                    else RPLK_LAUNCH(4, 4);   // (round 4, same-box sweep tools/rplk_sweep.sh: 34.9 us alone at B = 128 / 105 at 384; 4 x 2: 39.0 / 120; 2 x 4: 38.6 / 117; 8 x 1: 57 / 117)
-                }
-#undef RPLK_LAUNCH
+                // four k per lane, four slices of the s range (round 4, same-box sweep of six shapes: 34.9 us alone at B = 128 / 105 at 384; 4 x 2, the
+                // round-3 shape: 39.0 / 120; 2 x 4: 38.6 / 117; 8 x 1: 57 / 117; 8 x 2: 58 / 153; 8 x 4: 49 / 134)
+                const int nkd = (Nk + 64 * 4 - 1) / (64 * 4);
+                if (kblocks > 0 && !WHATIF_SKIP(64))
+                    hipLaunchKernelGGL((resum_plk_kernel<4, 4>), dim3(nkd * 3 * B), dim3(192 * 4), 0, st, Nk, c.Nklow, tb<double>(e, EFTB_T_K), tb<double>(e, EFTB_T_H),
+                                       e->RSAS, b[EFTB_B_TEMPL], nkd);
             } else if (kblocks > 0 && Nl == 3 && fused_nnlo)
                 hipLaunchKernelGGL((resum_mfma_kernel<true>), dim3(nkb * B, 1, nsplit), dim3(256), 0, st, RM_ARGS, tb<double>(e, EFTB_T_LCTN), b[EFTB_B_TEMPLN], nkb);
             else if (kblocks > 0 && Nl == 3)
@@ -1175,13 +1152,9 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
 #define APF_ARGS Nk, c.nmu, tb<double>(e, EFTB_T_K), b[EFTB_B_DA], b[EFTB_B_H], tb<double>(e, EFTB_T_APFID), tb<double>(e, EFTB_T_MU), tb<double>(e, EFTB_T_WMU),   \
                  tb<double>(e, EFTB_T_LEGMU), e->SD, tb<double>(e, EFTB_T_SPLOCAL), *pin, b[EFTB_B_BIAS], plk_dst, plk_hst,                                      \
                  e->check_finite ? e->status + 2 * e->status_slot + 1 : nullptr, c.ap_stochastic ? NROW : 21
-                // one workgroup of eight waves per cosmology (22.3 us alone at B = 128, 40 at 384; two workgroups of four waves: 22.7 / 61 -- the LDS
-                // tables allow one workgroup per CU either way).  One shape for every batch size: the two sum the mu prefix in different chunks, and
-                // a cosmology's bits must not depend on the batch it travels in (EFTB_APF_WAVES=4 for A/B runs)
-                static const int apf_nw = getenv("EFTB_APF_WAVES") ? atoi(getenv("EFTB_APF_WAVES")) : 8;
-                if (WHATIF_SKIP(256)) {
-                } else if (apf_nw == 4) hipLaunchKernelGGL((ap_plk_fused_kernel<3, 4>), dim3(2 * B), dim3(256), lds, st, APF_ARGS);
-                else hipLaunchKernelGGL((ap_plk_fused_kernel<3, 8>), dim3(B), dim3(512), lds, st, APF_ARGS);
+                // one workgroup of eight waves per cosmology (22.3 us alone at B = 128, 40 at 384; two workgroups of four waves measured 22.7 / 61 -- the
+                // LDS tables allow one workgroup per CU either way)
+                if (!WHATIF_SKIP(256)) hipLaunchKernelGGL((ap_plk_fused_kernel<3, 8>), dim3(B), dim3(512), lds, st, APF_ARGS);
 #undef APF_ARGS
                 trace_point(e, 7, st);
                 timer_end(e, st, tslot);
@@ -1576,7 +1549,6 @@ int eftb_create(const eftb_config* cfg, eftb_engine** out) {
     if (const char* f = getenv("EFTB_GD_WAVES")) e->gd_waves = atoi(f);
     if (const char* f = getenv("EFTB_FUSE_CF")) e->fuse_cf = atoi(f) != 0;
     if (const char* f = getenv("EFTB_AP_PLK_NODES")) e->ap_plk_nodes = atoi(f) != 0;
-    if (const char* f = getenv("EFTB_SYNTH_DIRECT")) e->synth_direct = atoi(f) != 0;
     if (const char* f = getenv("EFTB_UPLOAD_ON_SIDE")) e->upload_on_side = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUBMIT_THREAD")) e->sub_mode = std::max(0, std::min(2, atoi(f)));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->status), 2 * (eftb_engine::NSETS + 1) * sizeof(int), hipHostMallocMapped));
@@ -1662,8 +1634,7 @@ int eftb_finalize(eftb_engine* e) {
                 const size_t lds = ((size_t)((c.Nk + 1) & ~1) + (size_t)c.nmu * 8 + 36 * 16 + (size_t)(c.nmu + 1) * 36 + (size_t)(c.Nk - 1) * 12) * sizeof(double);
                 e->ap_plk_fused = c.Nl == 3 && lds <= 150 * 1024 && c.nmu >= 2 && c.nmu <= 7 * 32 && !(getenv("EFTB_AP_PLK_FUSED") && !atoi(getenv("EFTB_AP_PLK_FUSED")));
                 if (e->ap_plk_fused)
-                    for (const void* fn : {reinterpret_cast<const void*>(&ap_plk_fused_kernel<3, 4>), reinterpret_cast<const void*>(&ap_plk_fused_kernel<3, 8>)})
-                        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_plk_fused_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             }
 #define APM_LDS(NLV, NRV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ap_moments_kernel<NLV, NRV, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256))
             APM_LDS(3, 21); APM_LDS(3, NROW); APM_LDS(2, 21); APM_LDS(2, NROW);
@@ -1919,7 +1890,7 @@ void eftb_destroy(eftb_engine* e) {
     (void)hipSetDevice(e->c.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
-    for (hipStream_t q : {e->pre, e->side, e->cpy, e->back, e->outq}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work, staged uploads and copy-outs still in flight
+    for (hipStream_t q : {e->pre, e->side, e->cpy, e->back}) if (q) (void)hipStreamSynchronize(q);  // look-ahead work and staged uploads still in flight
     drop_graphs(e);
     if (e->cpy)
         for (int id = 0; id < EFTB_B_COUNT; ++id)
@@ -1947,8 +1918,6 @@ void eftb_destroy(eftb_engine* e) {
     if (e->pre) (void)hipStreamDestroy(e->pre);
     if (e->back) (void)hipStreamDestroy(e->back);
     if (e->cpy) (void)hipStreamDestroy(e->cpy);
-    if (e->outq) (void)hipStreamDestroy(e->outq);
-    for (hipEvent_t ev : e->evOut) if (ev) (void)hipEventDestroy(ev);
     for (int h = 0; h < eftb_engine::NSLOT; ++h)
         if (e->stage_host[h]) (void)hipHostFree(e->stage_host[h]);
     for (int r = 0; r < eftb_engine::NLRING; ++r) {
@@ -2035,7 +2004,6 @@ int eftb_sync(eftb_engine* e) {
     if (!e) return fail("eftb_sync: null engine");
     join_back(e);
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->outq) HIPCHK(hipStreamSynchronize(e->outq));                // the copy-out of the last staged launch's P_l
     if (e->comm_stream) HIPCHK(hipStreamSynchronize(e->comm_stream));  // an asynchronous gather may still be in flight
     return check_status(e, "eftb_sync");
 }
@@ -2209,6 +2177,7 @@ static int staged_setup(eftb_engine* e) {
     }
     if (const char* f = getenv("EFTB_LATENCY_MODE")) e->latency_auto = atoi(f) != 0;
     if (const char* f = getenv("EFTB_DONE_WORDS")) e->done_words = atoi(f) != 0;
+    if (const char* f = getenv("EFTB_PLK_DMA")) e->plk_dma = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUB_STATS")) e->sub_stats = atoi(f) != 0;
     if (const char* f = getenv("EFTB_SUB_INFLIGHT")) e->sub_inflight = std::max(1, std::min(eftb_engine::NSETS - 1, atoi(f)));
     if (const char* f = getenv("EFTB_SUB_LOW")) e->sub_low = std::max(1, atoi(f));
@@ -2220,17 +2189,6 @@ static int staged_setup(eftb_engine* e) {
         HIPCHK(hipHostMalloc(&p, 2 * eftb_engine::NSETS * sizeof(unsigned long long), hipHostMallocMapped));
         memset(p, 0, 2 * eftb_engine::NSETS * sizeof(unsigned long long));
         e->set_done = static_cast<volatile unsigned long long*>(p);
-    }
-    // EFTB_OUT_STREAM: 0 (default) the copy-out of P_l stays in line on the launch's last stream; 1: on a stream of its own; 2: on the copy stream
-    // (idle in direct-P_l loops, whose uploads ride on the side stream).  Measured (200 steps, same box): in line 0.101-0.103 ms per step, own
-    // stream 0.16-0.19 whatever its priority and GPU_MAX_HW_QUEUES -- kept for A/B runs
-    e->out_mode = getenv("EFTB_OUT_STREAM") ? atoi(getenv("EFTB_OUT_STREAM")) : 0;
-    if (e->out_mode) {
-        const int oprio = getenv("EFTB_OUT_PRIO") ? atoi(getenv("EFTB_OUT_PRIO")) : 1;   // 1 low, 0 normal, -1 high
-        if (e->out_mode == 1) {
-            HIPCHK(hipStreamCreateWithPriority(&e->outq, hipStreamNonBlocking, oprio > 0 ? prio_lo : (oprio < 0 ? prio_hi : 0)));
-        }
-        for (int q = 0; q < eftb_engine::NSETS; ++q) HIPCHK(hipEventCreateWithFlags(&e->evOut[q], hipEventDisableTiming));
     }
     e->cur_set = eftb_engine::NSETS - 1;  // the engine's own buffers are current until the first staged launch; sets 0, 1, 2, 3 follow in turn
     HIPCHK(hipDeviceSynchronize());  // the zero fills ran on the null stream; the copy stream is about to write into these blocks
@@ -2359,22 +2317,15 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     if (lat) HIPCHK(hipStreamWaitEvent(last, e->evStagedAllR[lr], 0));  // (the set is not "done" before its own upload is)
     constexpr int copy_wgs = 48;   // (8 ... 512 workgroups measured the same: the kernel's time is the PCIe transfer)
     hipStream_t done_on = last;  // where the launch's LAST work runs: what the set's event and completion word follow
-    static const bool flow_cword = !(getenv("EFTB_FLOW_CWORD") && !atoi(getenv("EFTB_FLOW_CWORD")));
-    if (e->done_words && !lat && flow_cword) {   // compute finished: what the submission thread's flow control counts (the copy-out below is not part of it)
+    if (e->done_words && !lat) {   // compute finished: what the submission thread's flow control counts (the copy-out below is not part of it)
         if (hipStreamWriteValue64(last, const_cast<unsigned long long*>(e->set_done) + eftb_engine::NSETS + q, L + 1, 0) == hipSuccess) e->set_cword[q] = L + 1;
         else (void)hipGetLastError();
     }
     if (plk_tail || (plk_direct && !e->plk_host_written)) {
         const size_t cnt = (size_t)Bt * e->cur_nl * e->cur_nx;
-        hipStream_t oq = e->out_mode == 1 ? e->outq : (e->out_mode == 2 && cs != e->cpy ? e->cpy : nullptr);
-        if (oq && !lat) {
-            HIPCHK(hipEventRecord(e->evOut[q], last));
-            HIPCHK(hipStreamWaitEvent(oq, e->evOut[q], 0));
-            done_on = oq;
-        }
         // the DMA engine, in line behind the launch's last kernel (same-box A/B over 200 steps: 0.091-0.096 ms per step against 0.102-0.104 with
         // copy16_kernel -- the what-if runs priced the kernel's PCIe stores at a fifth of the step; EFTB_PLK_DMA=0 brings the kernel back)
-        static const bool plk_dma = !(getenv("EFTB_PLK_DMA") && !atoi(getenv("EFTB_PLK_DMA")));
+        const bool plk_dma = e->plk_dma;
         if (WHATIF_SKIP(512)) {   // (what-if: P_l stays on the device)
         } else if (WHATIF_SKIP(2048) && e->PLK0)   // (what-if: the copy kernel with a device destination -- the stream holds it, PCIe does not)
             hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->PLK0, cnt);

@@ -398,3 +398,55 @@ def test_measurement_taps_of_the_staged_loop():
         assert 1 <= n <= st["launches"] and nc % B == 0 and n * B <= nc <= K * B and ms > 0.0, kind
     eng.time_dominant(False)
     eng.close()
+
+
+@pytest.mark.parametrize("env,exact", [({"EFTB_PLK_DMA": "0"}, True), ({"EFTB_DONE_WORDS": "0"}, True), ({"EFTB_UPLOAD_ON_SIDE": "0"}, True),
+                                        ({"EFTB_SUBMIT_THREAD": "0"}, True), ({"EFTB_COALESCE": "1"}, True), ({"EFTB_SUB_INFLIGHT": "1"}, True),
+                                        ({"EFTB_AP_PLK_FUSED": "0"}, False), ({"EFTB_AP_PLK_NODES": "1"}, False)])
+def test_staged_direct_loop_under_each_switch(monkeypatch, env, exact):
+    """Every run-time switch of the staged direct-P_l path off its default: the fall-backs (event completion, the copy kernel, the
+    caller issuing every step, uploads on the copy stream, no coalescing, one launch in flight) return the default build's bits; the other
+    forms of the AP stage (ap_prefix + ap_plk_mom, the node quadrature) the same P_l to summation order."""
+    import bench
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    B, K, depth = 16, 14, 6
+    k = synth.survey_kgrid(bench.NK)
+    cfg = EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, bench.Z)), H_AP=float(synth.hubble(synth.OM_AP, bench.Z)))
+    sets = [_draws(B, 820 + i) for i in range(3)]
+
+    def run():
+        eng = Engine(cfg, max_batch=B, coalesce=3)
+        eng.set_plk_direct(True)
+        eng.set_latency_mode(False)
+        mask = eng.full_mask(reduce=True)
+        got = []
+        for i in range(K):
+            s = sets[i % 3]
+            view = eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], back=depth if i >= depth else -1, shape=(B, bench.NL, bench.NK))
+            if i >= depth:
+                got.append(view.copy())
+        for back in range(depth - 1, -1, -1):
+            got.append(eng.fetch_previous("PLK", (B, bench.NL, bench.NK), back=back))
+        # the dependent-sampler form too (latency mode: P_l stored by the kernel that forms it)
+        eng.set_latency_mode(True)
+        eng.sync()
+        s = sets[0]
+        eng.stage_inputs(s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
+        eng.run_staged(mask, B)
+        got.append(eng.fetch_previous("PLK", (B, bench.NL, bench.NK), back=0))
+        eng.close()
+        return got
+
+    want = run()
+    for name, value in env.items():
+        monkeypatch.setenv(name, value)
+    got = run()
+    assert len(got) == len(want) == K + 1
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert np.isfinite(a).all()
+        if exact:
+            assert np.array_equal(a, b), (env, i)
+        else:
+            assert relerr(a, b) < 1e-9 and not np.array_equal(a, b), (env, i)
