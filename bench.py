@@ -45,7 +45,8 @@ DEPTH = int(os.environ.get("EFTB_BENCH_DEPTH", "12"))  # steps queued on the GPU
 DIRECT = os.environ.get("EFTB_BENCH_DIRECT", "1") != "0"   # `value` on direct-P_l runs (EFTB_O_PLK_DIRECT); 0: templates first
 
 
-STEP_TIMES = [] if os.environ.get("EFTB_BENCH_STEP_TIMES") else None  # diagnostics: host time at which each timed step's P_l had been fetched
+STEP_TIMES = [] if os.environ.get("EFTB_BENCH_STEP_TIMES") else None
+HOST_PROFILE = [0.0, 0.0] if os.environ.get("EFTB_BENCH_HOST_PROFILE") else None  # diagnostics: seconds of the timed loop inside eng.step() / inside keeper.put()  # diagnostics: host time at which each timed step's P_l had been fetched
 
 
 def cpu_baseline(picks, budget_s=20.0):
@@ -378,12 +379,19 @@ def main():
         for i in range(n):
             if exchange == "none":  # one library call per step: stage + launch + the view of the step DEPTH back (eftb_step)
                 d = sets[first + i]
+                if HOST_PROFILE is not None:
+                    ta = time.perf_counter()
                 view = eng.step(mask, d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"], back=DEPTH if i >= DEPTH else -1, shape=(B, NL, NK))
+                if HOST_PROFILE is not None:
+                    tb = time.perf_counter()
                 if view is not None:
                     if keep:
                         keeper.put(view, i - DEPTH)
                         if STEP_TIMES is not None:
                             STEP_TIMES.append(time.perf_counter())
+                if HOST_PROFILE is not None and keep:
+                    HOST_PROFILE[0] += tb - ta
+                    HOST_PROFILE[1] += time.perf_counter() - tb
                 continue
             stage_and_run(sets[first + i])
             if exchange == "rccl":
@@ -444,6 +452,9 @@ def main():
     elapsed = cp.max(time.perf_counter() - t0)
     gc.enable()
     host_stats = eng.submit_stats(enable=False, reset=True)
+    if HOST_PROFILE is not None:
+        print(f"[bench] main thread, per timed step: eng.step {HOST_PROFILE[0] / K * 1e6:.1f} us (of which waiting for results {host_stats['wait_us_per_step']:.1f}, filling the staging "
+              f"block {host_stats['fill_us_per_step']:.1f}), keeper.put {HOST_PROFILE[1] / K * 1e6:.1f} us; wall {elapsed / K * 1e6:.1f} us", file=sys.stderr)
     if STEP_TIMES:
         print("[bench] fetch-complete times since t0 (ms):", " ".join(f"{(t - t0) * 1e3:.3f}" for t in STEP_TIMES), file=sys.stderr)
     ktimes = [eng.kernel_time(kind, reset=True, cosmologies=True) for kind in range(3)]  # (resummation, synthesis, AP kernel): (ms, launches, cosmologies carried) inside the timed region
