@@ -47,13 +47,17 @@ traced = (time.perf_counter() - t0) / K
 tr = eng.step_trace()
 print(f"ms per step: {plain * 1e3:.4f} without the trace events, {traced * 1e3:.4f} with them; {len(tr)} launches kept")
 names = ["upload", "front>", "synth<", "prep>", "resum<", "resum>", "spline<", "AP>", "copy>"]
-sel = tr[len(tr) // 2 - 6: len(tr) // 2 + 6] if len(tr) > 14 else tr
+sel = tr[len(tr) // 2 - 6: len(tr) // 2 + 6] if len(tr) > 14 else tr   # (a short loop, ST_K=20: every launch, i.e. fill and drain)
 base = sel[0][2]
 print("launch  B " + " ".join(f"{n:>8s}" for n in names) + "   | front synth+prep resum  AP  copy | gaps: front->synth prep->resum resum->spline")
 for r in sel:
     t = r[2:] - base
     print(f"{int(r[0]):5d} {int(r[1]):4d} " + " ".join(f"{x:8.1f}" for x in t[:9]) + f" [front: upload {t[9] - t[0]:4.0f} rows+gemm {t[10] - t[9]:4.0f} antidiag {t[11] - t[10]:4.0f} build {t[1] - t[11]:4.0f}]" +
           f"   | {t[1] - t[0]:5.0f} {t[3] - t[2]:5.0f} {t[5] - t[4]:5.0f} {t[7] - t[6]:5.0f} {t[8] - t[7]:5.0f} | {t[2] - t[1]:6.0f} {t[4] - t[3]:6.0f} {t[6] - t[5]:6.0f}")
+if len(tr) < 8:
+    print("first upload to last copy-out: %.0f us for %d steps" % (tr[-1, 10] - tr[0, 2], K))
+    eng.close()
+    sys.exit(0)
 per = np.diff(tr[:, 10])  # copy-out end
 print("launch period (copy-out end to copy-out end), us: mean %.0f, steps per launch %.2f" % (per[5:].mean(), tr[5:, 1].mean() / B))
 eng.close()
