@@ -249,7 +249,7 @@ struct eftb_engine {
     // into one device set, row after row; each step's results are its rows of the set's output blocks).  At 128 cosmologies every kernel of a
     // step is a single ragged round of waves; two or four steps together cost far less than two or four launches (measured: 0.108 ms per 128 at 256
     // against 0.126).  Needs eftb_config.step_batch < max_batch (the device state is sized for max_batch; a step brings at most step_batch).
-    struct SubCmd { int slot, mask, B, has_rows; unsigned long long step; };
+    struct SubCmd { int slot, mask, B, has_rows; unsigned long long step; double* out; size_t out_count; };  // out: the caller's page-locked destination of this step's P_l (eftb_set_step_output), or null
     static constexpr int SUBQ = 64;          // ring of queued steps (at most NSLOT - 1 can be pending: every step owns a staging block)
     SubCmd sub_ring[SUBQ];
     std::atomic<unsigned long long> sub_tail{0};   // commands pushed (caller's thread)
@@ -261,7 +261,7 @@ struct eftb_engine {
     int sub_mode = 1;   // 0: the caller issues every step; 1: queued unless the engine is quiescent and the GPU idle; 2: always queued (tests)
     bool sub_started = false;
     static constexpr int SUBREC = 64;        // records of the last steps: where the step's rows are, rc + message of its launch (surface when the step is fetched)
-    struct StepRec { int set, row, B, rc, nl, nx; unsigned long long launch; };
+    struct StepRec { int set, row, B, rc, nl, nx; unsigned long long launch; double* out; };
     StepRec rec[SUBREC] = {};
     char sub_err[SUBREC][256] = {};
     int coalesce_max = 1;                    // steps per launch at most (EFTB_COALESCE; 1 unless step_batch < max_batch)
@@ -273,6 +273,8 @@ struct eftb_engine {
     std::atomic<unsigned long long> steps_launched{0};  // staged steps whose launch has been issued (by either thread), in order
     unsigned long long steps_submitted = 0;   // staged steps handed in so far (caller's thread) = what eftb_fetch_back counts `back` from
     int stg_slot = -1, stg_B = 0, stg_rows = 0;  // inputs staged into block stg_slot, waiting for eftb_run_staged
+    double* stg_out = nullptr;                   // eftb_set_step_output: where the P_l of the step launched NEXT goes (the caller's page-locked array), ...
+    size_t stg_out_count = 0;                    // ... which holds this many doubles
     bool stg_inline = false, stg_lat = false;    // ... to be issued by the caller's thread (engine quiescent, GPU idle), as a latency-mode step
     unsigned long long slot_step[NSLOT] = {}; // 1 + the step that used the staging block last (0: never used): its launch must be over before the block is refilled
     bool slot_latency[NSLOT] = {};            // ... which was a latency-mode step (its first kernel read P_lin from the block itself)
@@ -2280,7 +2282,7 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     int row = 0;
     for (int j = 0; j < n; ++j) {  // where each step's rows will be (the fetch needs it even when the launch fails below: to say so)
         eftb_engine::StepRec& r = e->rec[cmds[j].step % eftb_engine::SUBREC];
-        r.set = q; r.row = row; r.B = cmds[j].B; r.launch = L; r.rc = 0;
+        r.set = q; r.row = row; r.B = cmds[j].B; r.launch = L; r.rc = 0; r.out = cmds[j].out;
         row += cmds[j].B;
     }
     for (int id : kStagedIds)
@@ -2300,7 +2302,10 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     double* pin_dev = e->buf[EFTB_B_PIN];
     if (lat) e->buf[EFTB_B_PIN] = e->stage_host[cmds[0].slot] + e->slot_off[EFTB_B_PIN];
     e->lat_run = lat;
-    e->plk_host_out = plk_direct && !plk_tail ? e->plk_host[q] : nullptr;
+    // steps with a destination of their own (eftb_set_step_output): P_l always leaves through the copy-out below, one transfer per destination
+    bool any_out = false;
+    for (int j = 0; j < n; ++j) any_out = any_out || cmds[j].out != nullptr;
+    e->plk_host_out = plk_direct && !plk_tail && !any_out ? e->plk_host[q] : nullptr;
     e->inputs_settled = e->allow_back = !lat;
     const int rc = run_stages(e, mask, Bt);
     e->inputs_settled = e->allow_back = false;
@@ -2321,19 +2326,42 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
         if (hipStreamWriteValue64(last, const_cast<unsigned long long*>(e->set_done) + eftb_engine::NSETS + q, L + 1, 0) == hipSuccess) e->set_cword[q] = L + 1;
         else (void)hipGetLastError();
     }
-    if (plk_tail || (plk_direct && !e->plk_host_written)) {
-        const size_t cnt = (size_t)Bt * e->cur_nl * e->cur_nx;
+    // P_l [rows of the launch][nl][nx] to host memory: the set's own page-locked block, or -- per step -- the caller's page-locked array; steps next to
+    // each other that go to the set's block travel as one transfer
+    auto copy_out = [&](hipStream_t st) -> int {
+        const size_t per = (size_t)e->cur_nl * e->cur_nx;
         // the DMA engine, in line behind the launch's last kernel (same-box A/B over 200 steps: 0.091-0.096 ms per step against 0.102-0.104 with
         // copy16_kernel -- the what-if runs priced the kernel's PCIe stores at a fifth of the step; EFTB_PLK_DMA=0 brings the kernel back)
-        const bool plk_dma = e->plk_dma;
-        if (WHATIF_SKIP(512)) {   // (what-if: P_l stays on the device)
-        } else if (WHATIF_SKIP(2048) && e->PLK0)   // (what-if: the copy kernel with a device destination -- the stream holds it, PCIe does not)
-            hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->PLK0, cnt);
-        else if (plk_dma) HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], cnt * sizeof(double), hipMemcpyDeviceToHost, done_on));
-        else hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, done_on, e->buf[EFTB_B_PLK], e->plk_host[q], cnt);
+        const bool dma = e->plk_dma || !plk_direct;
+        if (WHATIF_SKIP(512)) return 0;   // (what-if: P_l stays on the device)
+        if (WHATIF_SKIP(2048) && e->PLK0) {   // (what-if: the copy kernel with a device destination -- the stream holds it, PCIe does not)
+            hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, st, e->buf[EFTB_B_PLK], e->PLK0, (size_t)Bt * per);
+            return 0;
+        }
+        for (int j = 0; j < n; ++j)
+            if (cmds[j].out && cmds[j].out_count < (size_t)cmds[j].B * per)
+                return fail("eftb_run_staged: the step's P_l has %zu elements, the destination of eftb_set_step_output holds %zu", (size_t)cmds[j].B * per, cmds[j].out_count);
+        int row = 0;
+        for (int j = 0; j < n;) {
+            int j1 = j + 1, rows = cmds[j].B;
+            if (!cmds[j].out)
+                for (; j1 < n && !cmds[j1].out; ++j1) rows += cmds[j1].B;
+            const double* src = e->buf[EFTB_B_PLK] + (size_t)row * per;
+            double* dst = cmds[j].out ? cmds[j].out : e->plk_host[q] + (size_t)row * per;
+            if (dma) HIPCHK(hipMemcpyAsync(dst, src, (size_t)rows * per * sizeof(double), hipMemcpyDeviceToHost, st));
+            else hipLaunchKernelGGL(copy16_kernel, dim3(copy_wgs), dim3(256), 0, st, src, dst, (size_t)rows * per);
+            row += rows;
+            j = j1;
+        }
+        return 0;
+    };
+    const bool kernel_stored = plk_direct && !plk_tail && !any_out && e->plk_host_written;  // the kernel that formed P_l wrote it to the set's host block too
+    if (plk_direct && !kernel_stored) {
+        if (int crc = copy_out(done_on)) return crc;
     }
-    if (e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct)
-        HIPCHK(hipMemcpyAsync(e->plk_host[q], e->buf[EFTB_B_PLK], (size_t)Bt * e->cur_nl * e->cur_nx * sizeof(double), hipMemcpyDeviceToHost, last));
+    if (e->plk_host[q] && (mask & EFTB_S_REDUCE) && !plk_direct) {
+        if (int crc = copy_out(last)) return crc;
+    }
     trace_point(e, 8, done_on);
     e->trace_slot = -1;
     HIPCHK(hipEventRecord(e->evSetDone[q], done_on));
@@ -2358,7 +2386,7 @@ static int issue_and_publish(eftb_engine* e, const eftb_engine::SubCmd* cmds, in
     if (rc && e->launch_seq == L_before) {  // failed before the set was taken: the steps still need records that say so
         for (int j = 0; j < n; ++j) {
             eftb_engine::StepRec& r = e->rec[cmds[j].step % eftb_engine::SUBREC];
-            r.set = q_before; r.row = 0; r.B = cmds[j].B; r.launch = ~0ull;
+            r.set = q_before; r.row = 0; r.B = cmds[j].B; r.launch = ~0ull; r.out = cmds[j].out;
         }
     }
     for (int j = 0; j < n; ++j) {
@@ -2527,13 +2555,36 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     return 0;
 }
 
+int eftb_set_step_output(eftb_engine* e, double* dst, size_t count) {
+    if (!e) return fail("eftb_set_step_output: null engine");
+    if (!dst) { e->stg_out = nullptr; e->stg_out_count = 0; return 0; }
+    if (e->comm) return fail("eftb_set_step_output: P_l of an engine with a communicator stays in device memory for the exchange (eftb_gathered_view)");
+    HIPCHK(hipSetDevice(e->c.device));
+    // the DMA engine writes the array behind the step: it must be page-locked (eftb_host_alloc, hipHostMalloc, hipHostRegister) -- pageable memory would
+    // turn every transfer into a synchronous staged copy on the issuing thread
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, dst) != hipSuccess || at.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return fail("eftb_set_step_output: the destination is not page-locked host memory (allocate it with eftb_host_alloc / Engine.pinned_empty)");
+    }
+    e->stg_out = dst;
+    e->stg_out_count = count;
+    return 0;
+}
+
 int eftb_run_staged(eftb_engine* e, int mask, int B) {
     if (!e) return fail("eftb_run_staged: null engine");
     if (!e->cpy || e->stg_slot < 0) return fail("eftb_run_staged: nothing staged (eftb_stage_inputs first)");
     if (B != e->stg_B) return fail("eftb_run_staged: batch %d, but %d cosmologies were staged", B, e->stg_B);
     HIPCHK(hipSetDevice(e->c.device));
     const unsigned long long step = e->steps_submitted;
-    const eftb_engine::SubCmd cmd{e->stg_slot, mask, B, e->stg_rows, step};
+    double* out = e->stg_out;
+    e->stg_out = nullptr;   // (one step only, launched or not)
+    if (out) {
+        if (!(mask & EFTB_S_REDUCE) || (mask & EFTB_S_LOGP)) return fail("eftb_run_staged: eftb_set_step_output names a destination for P_l, but this run forms none (mask 0x%x)", mask);
+        if (!e->plk_host[0]) return fail("eftb_run_staged: eftb_set_step_output needs an engine whose P_l leaves through the copy-out (no communicator, no EFTB_STAGED_PLK_MAPPED)");
+    }
+    const eftb_engine::SubCmd cmd{e->stg_slot, mask, B, e->stg_rows, step, out, e->stg_out_count};
     if (!e->stg_inline) {  // queued: the submission thread uploads the staging block and launches the step (with whatever else is queued by then)
         if (!e->sub_started) {
             e->sub_stop.store(false);
@@ -2613,7 +2664,10 @@ int eftb_fetch_back(eftb_engine* e, int back, int id, double* host, size_t count
     if (int rc = wait_step_done(e, *r, "eftb_fetch_back")) return rc;
     const size_t off = step_offset(e, *r, id);
     if (off + count > e->buf_elems[id]) return fail("eftb_fetch_back: the step's rows start at element %zu of %zu, asked %zu", off, e->buf_elems[id], count);
-    if (id == EFTB_B_PLK && e->plk_host[t])
+    if (id == EFTB_B_PLK && r->out) {
+        if (count > (size_t)r->B * r->nl * r->nx) return fail("eftb_fetch_back: the step's P_l has %zu elements, asked %zu", (size_t)r->B * r->nl * r->nx, count);
+        if (host != r->out) memcpy(host, r->out, count * sizeof(double));  // (it went to the caller's own array: eftb_set_step_output)
+    } else if (id == EFTB_B_PLK && e->plk_host[t])
         memcpy(host, e->plk_host[t] + off, count * sizeof(double));  // copied out behind the step
     else if (e->staged_plk_device && id == EFTB_B_PLK)  // multi-GPU runs keep P_l on the device for the RCCL exchange
         HIPCHK(hipMemcpy(host, e->setbuf[t][id] + off, count * sizeof(double), hipMemcpyDeviceToHost));
@@ -2635,6 +2689,11 @@ int eftb_fetch_view(eftb_engine* e, int back, int id, const double** block, size
     if (!p) return fail("eftb_fetch_view: P_l of this engine stays in device memory for the RCCL exchange (eftb_gathered_view hands out the gathered block)");
     if (int rc = wait_step_done(e, *r, "eftb_fetch_view")) return rc;
     const size_t off = step_offset(e, *r, id);
+    if (id == EFTB_B_PLK && r->out) {   // the step's P_l went to the caller's own array (eftb_set_step_output): that is the block
+        *block = r->out;
+        if (count) *count = (size_t)r->B * r->nl * r->nx;
+        return check_status(e, "eftb_fetch_view", t);
+    }
     *block = p + off;
     if (count) *count = e->buf_elems[id] - off;
     return check_status(e, "eftb_fetch_view", t);

@@ -370,10 +370,16 @@ class Engine:
         if mask & L.S_PROJECT:
             self.dims = self.out_dims()
 
-    def step(self, mask, Pin, f, DA=None, H=None, bias=None, rows=None, back=-1, fetch="PLK", shape=None):
+    def step(self, mask, Pin, f, DA=None, H=None, bias=None, rows=None, back=-1, fetch="PLK", shape=None, out=None):
         """One sampler step in one library call (``eftb_step``): stage these inputs, launch the step, and -- with back >= 0 -- hand out a read-only
         view of the PLK / LOGP block of the step `back` steps before this one (None while fewer than back + 1 steps are behind it).  Arrays that
-        already are C-contiguous float64 of the right shape are passed as they are."""
+        already are C-contiguous float64 of the right shape are passed as they are.  ``out``: a writable C-contiguous float64 array in page-locked
+        memory (``pinned_empty``, or a slice of one) that receives THIS step's P_l straight from the copy-out behind the step
+        (``eftb_set_step_output``) -- it is complete once a later call has handed out this step (the view returned then IS that memory)."""
+        if out is not None:
+            if not (type(out) is np.ndarray and out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]):
+                raise L.EftbError("step: out must be a writable C-contiguous float64 ndarray (in page-locked memory: Engine.pinned_empty)")
+            L.check(self.lib.eftb_set_step_output(self._h, out.ctypes.data, out.size))
         B, Pin, f, DA, H = self._inputs(Pin, f, DA, H)
         if bias is not None and not (type(bias) is np.ndarray and bias.dtype == np.float64 and bias.flags["C_CONTIGUOUS"]):
             bias = np.ascontiguousarray(bias, dtype=np.float64)
@@ -396,6 +402,8 @@ class Engine:
                 raise L.EftbError(f"step: the block holds {n.value} elements, asked {size}")
             view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(size,)).reshape(shape)
             view.flags.writeable = False
+            if len(self._views) >= 64:  # (steps with destinations of their own bring a new address every time: the cache is for the engine's few blocks)
+                self._views.clear()
             self._views[key] = view
         return view
 

@@ -284,6 +284,14 @@ int  eftb_fetch_back(eftb_engine* e, int back, int buffer_id, double* host, size
  * (*count = its capacity in elements), valid until NSETS - 1 = 15 more steps have been staged.  For samplers that consume P_l in place (the
  * dependent loop of reference likelihood.py:570-594: chi^2 from P_l, then the next proposal). */
 int  eftb_fetch_view(eftb_engine* e, int back, int buffer_id, const double** block, size_t* count);
+/* Where the P_l of the staged step launched NEXT goes: the caller's own page-locked array (eftb_host_alloc / hipHostMalloc / hipHostRegister;
+ * `count` doubles, at least B x Nl x Nx of the step's output) instead of the engine's host block -- the copy-out behind the step writes it with
+ * the DMA engine, so a sampler that keeps every step's P_l (emulator training sets, the chains' derived output of cobaya's `output_params`,
+ * reference theory.py:557-609 per point) pays no second host copy.  One step only; dst = NULL withdraws it.  eftb_fetch_view of that step
+ * hands out dst once the step has finished (eftb_fetch_back copies from it); the array must stay allocated and untouched until then.  Refused:
+ * pageable memory, engines with a communicator, runs that form no P_l (LOGP); an array that turns out too small for the step's rows fails the
+ * launch, reported by the step's fetch.  May be called while earlier steps are queued (it does not wait for them). */
+int  eftb_set_step_output(eftb_engine* e, double* dst, size_t count);
 /* One sampler step in one call: eftb_stage_inputs + eftb_run_staged + (back >= 0 and that many steps already behind this one)
  * eftb_fetch_view(back, buffer_id).  *block stays NULL while the pipeline is still filling.  Replaces, per step of a batched sampler, what
  * EFTLeafKernel.calculate_power_spectrum + reduce_Plk do per point (theory.py:557-609, parambasis.py:42-136). */

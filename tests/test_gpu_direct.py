@@ -353,6 +353,88 @@ def test_coalesced_steps_return_the_bits_of_separate_steps(direct):
     eng.close()
 
 
+@pytest.mark.parametrize("direct", [True, False])
+def test_steps_deliver_into_the_callers_own_array(direct):
+    """eftb_set_step_output (Engine.step(out=...)): the copy-out behind a step writes the caller's page-locked array instead of the engine's host
+    block -- same bits as the step run by itself, whether the step leaves alone (caller's thread, latency mode), in a group of queued steps, or next
+    to steps WITHOUT a destination of their own in the same launch; the view handed out for such a step is that array."""
+    import bench
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.tables import EngineConfig
+
+    B = 16
+    k = synth.survey_kgrid(bench.NK)
+    cfg = EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(synth.da_func(synth.OM_AP, bench.Z)), H_AP=float(synth.hubble(synth.OM_AP, bench.Z)))
+    eng = Engine(cfg, max_batch=B, coalesce=4)
+    sizes = [16, 9, 16, 5, 16, 16, 16]
+    sets = [_draws(n, 700 + i) for i, n in enumerate(sizes)]
+    ref = [_plk(eng, s, n, direct) for s, n in zip(sets, sizes)]
+    eng.set_plk_direct(direct)
+    mask = eng.full_mask(reduce=True)
+    shape = lambda i: (sizes[i], bench.NL, bench.NK)
+    dest = eng.pinned_empty((len(sizes), B, bench.NL, bench.NK))
+    # (a) a dependent sampler's step: engine idle -> issued by the caller, latency mode
+    dest.fill(-1.0)
+    eng.set_latency_mode(True)
+    s = sets[0]
+    eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=dest[0])
+    view = eng.fetch_previous("PLK", shape(0), back=0, copy=False)
+    assert view.ctypes.data == dest[0].ctypes.data, "the view of a step with its own destination is that destination"
+    assert np.array_equal(dest[0], ref[0])
+    assert np.array_equal(eng.fetch_previous("PLK", shape(0), back=0), ref[0])
+    # (b) one launch of four queued steps, two of them with destinations (the second and the last), ragged batch sizes
+    dest.fill(-1.0)
+    eng.set_latency_mode(False)
+    eng.set_submit_thread(2)
+    eng.submit_stats(enable=True, reset=True)
+    eng.hold_submissions(True)
+    own = {1, 3}
+    for i in range(4):
+        s = sets[i]
+        eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=dest[i].reshape(-1)[: int(np.prod(shape(i)))].reshape(shape(i)) if i in own else None)
+    eng.hold_submissions(False)
+    for i in range(4):
+        view = eng.fetch_previous("PLK", shape(i), back=3 - i, copy=False)
+        assert np.array_equal(view, ref[i]), i
+        got = dest[i].reshape(-1)[: int(np.prod(shape(i)))].reshape(shape(i))
+        if i in own:
+            assert view.ctypes.data == dest[i].ctypes.data and np.array_equal(got, ref[i]), i
+            assert np.all(dest[i].reshape(-1)[int(np.prod(shape(i))):] == -1.0), "nothing beyond the step's own rows is written"
+        else:
+            assert np.all(dest[i] == -1.0), i
+    assert eng.submit_stats(enable=False)["launches"] == 1
+    # (c) a free-running loop, every step into its own slice
+    dest.fill(-1.0)
+    eng.set_submit_thread(1)
+    K, depth = len(sizes), 3
+    for i in range(K):
+        s = sets[i]
+        eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], back=depth if i >= depth else -1, shape=shape(max(i - depth, 0)),
+                 out=dest[i].reshape(-1)[: int(np.prod(shape(i)))].reshape(shape(i)))
+        if i >= depth:
+            j = i - depth
+            assert np.array_equal(dest[j].reshape(-1)[: int(np.prod(shape(j)))].reshape(shape(j)), ref[j]), j
+    for back in range(depth - 1, -1, -1):
+        j = K - 1 - back
+        eng.fetch_previous("PLK", shape(j), back=back, copy=False)
+        assert np.array_equal(dest[j].reshape(-1)[: int(np.prod(shape(j)))].reshape(shape(j)), ref[j]), j
+    # refusals: pageable memory at once; an array too small for the step's rows fails the launch and the step's fetch says so
+    s = sets[0]
+    with pytest.raises(L.EftbError, match="page-locked"):
+        eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=np.zeros(shape(0)))
+    small = eng.pinned_empty((sizes[0] - 1, bench.NL, bench.NK))
+    eng.set_submit_thread(2)
+    eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=small)
+    with pytest.raises(L.EftbError, match="destination of eftb_set_step_output holds"):
+        eng.fetch_previous("PLK", shape(0), back=0)
+    # ... and the engine goes on
+    eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=dest[0])
+    eng.fetch_previous("PLK", shape(0), back=0, copy=False)
+    assert np.array_equal(dest[0], ref[0])
+    eng.close()
+
+
 def test_measurement_taps_of_the_staged_loop():
     """The measurement interfaces bench.py and tools/step_trace.py read: host clocks of the staged steps (eftb_submit_stats), the batch the kernel
     timers saw (eftb_kernel_time_ex) and the per-launch timeline (EFTB_O_STEP_TRACE) -- consistent with what was submitted, and without touching the results."""
