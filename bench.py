@@ -8,6 +8,8 @@ P22/P13/C11/Cct/C22/C13 -> regroup -> resum -> AP -> bias contraction) over one 
     timed region, per step:  eftb_step = eftb_stage_inputs (Pin, f, DA, H, bias rows of a draw set never seen before -> page-locked block)
                                          eftb_run_staged   (all stages; issued by the library's submission thread, queued steps leave as one launch)
                                          eftb_fetch_view   (P_l of the step DEPTH back, in page-locked host memory)   [N > 1: RCCL gather to rank 0]
+                             N = 1: every step names its slice of the sampler's own page-locked results array as the destination of its P_l
+                             (eftb_set_step_output): the copy-out behind the step writes it, the fetch only waits for it
 
 so `value` is the input-to-output rate a sampler sees (H2D + D2H inclusive, every step's P_l lands in host memory inside the timed
 region; pipeline fill and drain are inside it too).  All draws are generated before the clock starts.  The rate of the same kernels
@@ -406,7 +408,7 @@ def main():
                 if i >= DEPTH and rank == 0:
                     block = eng.fetch_gathered(B, back=DEPTH, copy=False)
                     if keep:
-                        results[i - DEPTH] = block[rank]
+                        keeper.put(block[rank], i - DEPTH)   # (the root's own slice, copied by the second host thread: 1.6 MB per step would hold the launching thread ~0.1 ms)
             elif exchange == "host-fallback":
                 eng.sync()
                 cp.gather_host(eng.get("PLK", (B, NL, NK)))
@@ -417,7 +419,8 @@ def main():
                 for back in range(min(DEPTH, n) - 1, -1, -1):
                     block = eng.fetch_gathered(B, back=back, copy=False)
                     if keep:
-                        results[n - 1 - back] = block[rank]
+                        keeper.put(block[rank], n - 1 - back)
+                keeper.join()
         elif exchange == "none":
             for back in range(min(DEPTH, n) - 1, -1, -1):  # (back = 0: the step launched last)
                 take(n - 1 - back, back, keep)
@@ -736,6 +739,8 @@ def main():
                                    f"`value` pipelines INDEPENDENT batches at depth {DEPTH} (step i's P_l is taken after step i + {DEPTH} has been handed in; steps still queued when "
                                    f"the library's submission thread reaches them leave as one launch of up to {COALESCE} steps -- Engine(coalesce={COALESCE}) --, each fetched by itself); the rate a "
                                    "sampler sees whose next step depends on this step's P_l is the side key sync_step_evaluations_per_s"
+                                   + ("; every step's P_l is delivered into the sampler's own page-locked results array by the copy-out behind the step (eftb_set_step_output), "
+                                      "where it is compared with the synchronous path afterwards" if OWN_OUT else "")
                                    + ("; `value` is measured on direct-P_l runs (EFTB_O_PLK_DIRECT: the bias contraction is taken before the synthesis of the loop pieces, the "
                                       "resummation and the AP stage, with which it commutes -- same P_l, no template block); the templates-first rate of the same loop (rounds 1-2) is "
                                       "the side key templates_first_evaluations_per_s, and every timed step of the two is compared" if DIRECT else ""),
