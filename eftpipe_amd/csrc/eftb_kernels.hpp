@@ -889,12 +889,17 @@ __global__ __launch_bounds__(256) void regroup_kernel(int Nk, int Nl, const doub
 }
 
 
+// rows 21, 22, 23 of a template block (the stochastic templates Pstl; reference pybird.py:779-786): 1, k^2 at l = 0, k^2 at l = 2 -- functions of (l, k) alone
+__device__ __forceinline__ double stoch_template(int l, int r, double kv) {
+    return r == 0 ? (l == 0 ? 1.0 : 0.0) : r == 1 ? (l == 0 ? kv * kv : 0.0) : (l == 1 ? kv * kv : 0.0);
+}
+
 // Direct-P_l runs (EFTB_O_PLK_DIRECT): the bias contraction P_l = sum_row b_row T[l][row] commutes with every stage behind the regrouping
 // (resummation, AP: linear maps that act on each template row alike), so it is taken FIRST: one row per multipole instead of 24 goes through
 // them -- and, being linear in the rows, with the synthesis of the loop pieces before it (build_rows_plk_kernel).  This kernel is what is left of
 // regroup_kernel (reference pybird.py:737-866 followed by parambasis.py:42-136): row 0 of the template block takes sum_row b_row T[l][row] over the
-// rows the AP stage distorts (rows < 21, all rows when stoch0), rows 21-23 the stochastic templates as always (ap_plk_kernel adds them with their
-// coefficients); rows 1-20 of the block are not written.
+// rows the AP stage distorts (rows < 21, all rows when stoch0); rows 1-23 of the block are not written (the AP kernels of direct runs add the
+// stochastic templates, stoch_template(), with their coefficients: round 4 -- they used to be stored here and read back there, 19 MB each way per 512 cosmologies).
 __device__ __forceinline__ void regroup_plk_body(int kx, int w, int Nk, int Nl, const double* __restrict__ kk, const double* __restrict__ P11,
                                                  const double* __restrict__ Y22, const double* __restrict__ P13,
                                                  const double* __restrict__ l11, const double* __restrict__ lct,
@@ -903,8 +908,8 @@ __device__ __forceinline__ void regroup_plk_body(int kx, int w, int Nk, int Nl, 
     // bias (build_rows_plk_kernel) and synthesised; here the linear and counter terms join, the values at the first k are subtracted
     // (shot-noise subtraction, reference pybird.py:799-800) and the stochastic templates are laid beside the row.  A thread takes its k for
     // every l (round 4: a third of the waves of the per-(k, l) form, the same arithmetic per output)
-    const int k = kx * blockDim.x + threadIdx.x;
-    if (k >= Nk) return;
+    const int k = kx * 256 + threadIdx.x;   // (one workgroup = 256 k: the launch may carry more threads than that)
+    if (threadIdx.x >= 256 || k >= Nk) return;
     const double* bw = bias + (size_t)w * NROW;
     const double kv = kk[k], p11 = P11[(size_t)w * Nk + k];
     double y22[3], q13[3], y0[3], q0[3];
@@ -926,11 +931,7 @@ __device__ __forceinline__ void regroup_plk_body(int kx, int w, int Nk, int Nl, 
         const double s21 = l == 0 ? 1.0 : 0.0, s22 = l == 0 ? kv * kv : 0.0, s23 = l == 1 ? kv * kv : 0.0;
         double tot = (b11 + bct * kv * kv) * p11 + ((y22[l] - y0[l]) + (q13[l] - q0[l]));
         if (stoch0) tot += bw[21] * s21 + bw[22] * s22 + bw[23] * s23;  // APst: the stochastic templates are distorted with the others
-        double* t = T + ((size_t)w * Nl + l) * NROW * Nk + k;
-        t[0] = tot;
-        t[(size_t)21 * Nk] = s21;
-        t[(size_t)22 * Nk] = s22;
-        t[(size_t)23 * Nk] = s23;
+        T[((size_t)w * Nl + l) * NROW * Nk + k] = tot;
     }
 }
 
@@ -1476,50 +1477,63 @@ __device__ __forceinline__ void resum_prep_plk_body(int w, int part, int nparts,
                                                     const double* __restrict__ XY, const double* __restrict__ C11, const double* __restrict__ Cct,
                                                     const double* __restrict__ YCF, double* __restrict__ CF) {
     // grid (cosmology, slice of the s range).  g_0[l'](s) = C11[w][l'][s], g_1[l'](s) = Cct[w][l'][s] + YCF[w][l'][s]: all three already carry their
-    // bias coefficients (build_rows_plk_kernel contracted the rows before the synthesis)
+    // bias coefficients (build_rows_plk_kernel contracted the rows before the synthesis).  A thread owns ONE entry c = (l, v, p) of the record
+    // and walks every second s of the slice: its eight Q(f) values sit in registers, g, X and Y of the slice in LDS (broadcast reads) -- the
+    // first form (entries x s flattened over the workgroup, X / Y from global memory inside the loop, Q(f) in LDS) took ten dependent global
+    // loads per thread: 29 us alone at 512 cosmologies per launch, a third of them in a second round of workgroups
     constexpr int NL = 3;
     const int ns = (NS + nparts - 1) / nparts, s0 = part * ns, s1 = min(NS, s0 + ns), nsl = s1 - s0;
     extern __shared__ double sm[];
-    double* s_q = sm;                        // [2 NL NL NN] the cosmology's Q(f)
-    double* s_g = s_q + 2 * NL * NL * NN;    // [2][NL][ns] g_a[l'](s0 + .)
-    for (int e = threadIdx.x; e < 2 * NL * NL * NN; e += blockDim.x) s_q[e] = Q[(size_t)w * 2 * NL * NL * NN + e];
+    double* s_g = sm;                  // [2][NL][ns] g_a[l'](s0 + .)
+    double* s_xy = sm + 2 * NL * ns;   // [2][ns] X, Y
     for (int e = threadIdx.x; e < NL * nsl; e += blockDim.x) {
         const int lp = e / nsl, sl = e % nsl, s = s0 + sl;
         s_g[lp * ns + sl] = C11[((size_t)w * NL + lp) * NS + s];
         s_g[(NL + lp) * ns + sl] = Cct[((size_t)w * NL + lp) * NS + s] + YCF[((size_t)w * BASC + lp) * NS + s];
     }
-    __syncthreads();
-    const double* xy = XY + (size_t)w * 2 * NS;
-    double* dst = CF + ((size_t)w * NS + s0) * RSD_REC;
-    for (int idx = threadIdx.x; idx < nsl * RSD_REC; idx += blockDim.x) {
-        const int sl = idx / RSD_REC, c = idx % RSD_REC, s = s0 + sl;
-        double v = 0.0;
-        if (c < 144) {
-            const int l = c / 48, vv = (c / 16) % 3, p = c % 16;
-            const double x = xy[s], y = xy[NS + s];
-            if (p < NIR) {
+    for (int e = threadIdx.x; e < 2 * nsl; e += blockDim.x) s_xy[(e / nsl) * ns + e % nsl] = XY[(size_t)w * 2 * NS + (size_t)(e / nsl) * NS + s0 + e % nsl];
+    const int c = threadIdx.x % RSD_REC, half = threadIdx.x / RSD_REC, nhalf = blockDim.x / RSD_REC;
+    const int l = c / 48, vv = (c / 16) % 3, p = c % 16;
+    const bool poly = c < 144 && p < NIR;
+    double qy[2][NL], qx[2] = {0.0, 0.0};
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {  // device Q[a]: 0 = the C11 series, 1 = the Cct / Cloopl series
+    for (int a = 0; a < 2; ++a)   // device Q[a]: 0 = the C11 series, 1 = the Cct / Cloopl series
 #pragma unroll
-                    for (int lp = 0; lp < NL; ++lp) {
-                        const double* qq = s_q + ((a * NL + l) * NL + lp) * NN + p * Na + vv;
-                        double term = y * qq[NIR * Na];
-                        if (lp == vv) term = fma(x, qq[0], term);
-                        v = fma(s_g[(a * NL + lp) * ns + sl], term, v);
-                    }
-                }
-                v = ldexp(v, 3 * p);  // RS_ZS^p, RS_ZS = 8
+        for (int lp = 0; lp < NL; ++lp) {
+            qy[a][lp] = 0.0;
+            if (poly) {
+                const double* qq = Q + (size_t)w * 2 * NL * NL * NN + ((a * NL + l) * NL + lp) * NN + p * Na + vv;
+                qy[a][lp] = qq[NIR * Na];
+                if (lp == vv) qx[a] = qq[0];
             }
-        } else if (c == 144) {
-            v = xy[s] * (1.0 / RS_ZS);
         }
-        dst[idx] = v;
+    __syncthreads();
+    if (half >= nhalf) return;
+    double* dst = CF + ((size_t)w * NS + s0) * RSD_REC + c;
+    for (int sl = half; sl < nsl; sl += nhalf) {
+        double v = 0.0;
+        if (poly) {
+            const double x = s_xy[sl], y = s_xy[ns + sl];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int lp = 0; lp < NL; ++lp) {
+                    double term = y * qy[a][lp];
+                    if (lp == vv) term = fma(x, qx[a], term);
+                    v = fma(s_g[(a * NL + lp) * ns + sl], term, v);
+                }
+            v = ldexp(v, 3 * p);  // RS_ZS^p, RS_ZS = 8
+        } else if (c == 144) {
+            v = s_xy[sl] * (1.0 / RS_ZS);
+        }
+        dst[(size_t)sl * RSD_REC] = v;
     }
 }
 
 // One launch for the two light kernels between the syntheses and the resummation of a direct-P_l run (a launch costs the host 4 us and the step is
 // bounded by the host): workgroups [0, nreg) = regroup_plk (k tile, cosmology, l), the rest = resum_prep_plk (cosmology, slice of the s range)
-__global__ __launch_bounds__(256) void back_prep_plk_kernel(int nreg, int nkx, int B, int nparts, int Nk, int Nl, const double* __restrict__ kk,
+constexpr int BPP_THREADS = 2 * RSD_REC;   // 320: the coefficient part's (entry, half of the s slice); the regrouping part uses the first 256
+__global__ __launch_bounds__(BPP_THREADS) void back_prep_plk_kernel(int nreg, int nkx, int B, int nparts, int Nk, int Nl, const double* __restrict__ kk,
                                                             const double* __restrict__ P11, const double* __restrict__ Y22,
                                                             const double* __restrict__ P13, const double* __restrict__ l11,
                                                             const double* __restrict__ lct, const double* __restrict__ bias, double* __restrict__ T,
@@ -2592,7 +2606,7 @@ __global__ __launch_bounds__(256) void ap_plk_kernel(int Nk, int nmu, const doub
 #pragma unroll
         for (int q = 0; q < 3; ++q) a += s_red[((size_t)q * NL + l) * 64 + lane];
         double tot = cnorm * a;
-        for (int r = direct0; r < NROW; ++r) tot = fma(bw[r], T[(((size_t)w * NL + l) * NROW + r) * Nk + k], tot);
+        for (int r = direct0; r < NROW; ++r) tot = fma(bw[r], stoch_template(l, r - (NROW - 3), kk[k]), tot);   // (direct0 = NROW - 3 or NROW)
         Plk[((size_t)w * NL + l) * Nk + k] = tot;
         if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = tot;  // latency mode: P_l lands in mapped host memory as it is formed
         if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
@@ -2719,7 +2733,7 @@ __global__ __launch_bounds__(256) void ap_plk_mom_kernel(int Nk, int nmu, const 
 #pragma unroll
         for (int q = 0; q < 3; ++q) a += red[((size_t)q * NL + l) * 64 + lane];
         double tot = cnorm * a;
-        for (int r = direct0; r < NROW; ++r) tot = fma(bw[r], T[(((size_t)w * NL + l) * NROW + r) * Nk + k], tot);
+        for (int r = direct0; r < NROW; ++r) tot = fma(bw[r], stoch_template(l, r - (NROW - 3), kk[k]), tot);   // (direct0 = NROW - 3 or NROW)
         Plk[((size_t)w * NL + l) * Nk + k] = tot;
         if (PlkHost) PlkHost[((size_t)w * NL + l) * Nk + k] = tot;  // latency mode: P_l lands in mapped host memory as it is formed
         if (nonfinite && !(fabs(tot) <= 1.79769313486231570815e308)) atomicMax(nonfinite, w + 1);
@@ -2850,7 +2864,7 @@ __global__ __launch_bounds__(64 * NW) void ap_plk_fused_kernel(int Nk, int nmu, 
 #pragma unroll
         for (int l = 0; l < NL; ++l)
 #pragma unroll
-            for (int r = 0; r < 3; ++r) tst[l][r] = live && NROW - 3 + r >= direct0 ? T[(((size_t)w * NL + l) * NROW + NROW - 3 + r) * Nk + k] : 0.0;
+            for (int r = 0; r < 3; ++r) tst[l][r] = live && NROW - 3 + r >= direct0 ? stoch_template(l, r, s_k[k]) : 0.0;
         auto cross = [&](double kb) -> int {  // first node that lies past knot kb (k'_j >= kb when rising, k'_j < kb when falling)
             const double rc = kb * inv_kq, x = (rc * rc - 1.0) * inv_g;  // mu^2 at the crossing (a seed: the fix-up below decides)
             int j = nmu;

@@ -1032,12 +1032,12 @@ static int launch_stages_impl(eftb_engine* e, int mask, int B, bool nnlo_pass, b
                 if (hipStreamWaitEvent(st, e->evRsDone[rslot], 0) != hipSuccess) return fail("eftb_run: stream wait failed");
             }
             if (full && direct) {
-                constexpr int nparts = 5;  // slices of the s range per cosmology (3 / 2 / 1 measured 17 / 21 / 37 us alone at B = 128 against 12.6)
+                constexpr int nparts = 5;  // slices of the s range per cosmology (2 ... 10 measured the same since the coefficient part keeps Q(f) in registers: 20-22 us alone at 512 per launch, 8 at 128)
                 const int nsl = (NS + nparts - 1) / nparts;
-                const size_t plds = ((size_t)2 * 3 * 3 * e->Nn + 2 * 3 * nsl) * sizeof(double);
+                const size_t plds = ((size_t)2 * 3 * nsl + 2 * nsl) * sizeof(double);
                 const int nkx = (Nk + 255) / 256, nreg = nkx * B;   // (regroup: one workgroup per (256 k, cosmology), all three l)
                 if (!WHATIF_SKIP(32))
-                hipLaunchKernelGGL(back_prep_plk_kernel, dim3(nreg + nparts * B), dim3(256), plds, st, nreg, nkx, B, nparts, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], e->Y22,
+                hipLaunchKernelGGL(back_prep_plk_kernel, dim3(nreg + nparts * B), dim3(BPP_THREADS), plds, st, nreg, nkx, B, nparts, Nk, Nl, tb<double>(e, EFTB_T_K), b[EFTB_B_P11], e->Y22,
                                    b[EFTB_B_P13], tb<double>(e, EFTB_T_L11), tb<double>(e, EFTB_T_LCT), b[EFTB_B_BIAS], b[EFTB_B_TEMPL], c.ap_stochastic ? 1 : 0,
                                    e->Nn, c.NIR, c.Na, b[EFTB_B_Q], b[EFTB_B_XY], c11, cct, e->YCF, e->RSAS);
                 trace_point(e, 3, st);
