@@ -330,6 +330,9 @@ def main():
         return d
 
     sets = [draw_set(i) for i in range(W + K)]
+    # the untimed extension of the warm-up (below) cycles through a ring of sixteen draw sets of its own (the W asked for + as many more as it takes)
+    NRING = 16
+    ring_sets = (sets[:W] + [draw_set(W + K + j) for j in range(max(0, NRING - W))])[:NRING] if W > 0 else []
     mask = eng.full_mask(reduce=True)
     # every timed step's P_l of this rank.  N = 1: a page-locked array the sampler owns -- each step's copy-out writes its slice directly
     # (eng.step(out=...) = eftb_set_step_output: no second host copy; EFTB_BENCH_OWN_OUTPUT=0: the engine's own host block and a copy by a second
@@ -337,7 +340,7 @@ def main():
     OWN_OUT = exchange == "none" and os.environ.get("EFTB_BENCH_OWN_OUTPUT", "1") != "0" and K * B * NL * NK * 8 <= (2 << 30)
     results = eng.pinned_empty((K, B, NL, NK)) if OWN_OUT else np.zeros((K, B, NL, NK))
     results.fill(0.0)                                                     # (touched: the sampler's output buffers exist before the clock starts, no first-touch page faults inside it)
-    warm_out = eng.pinned_empty((max(W, 1), B, NL, NK)) if OWN_OUT else None   # where the untimed warm-up steps deliver
+    warm_out = eng.pinned_empty((max(W, NRING), B, NL, NK)) if OWN_OUT else None   # where the untimed warm-up steps deliver
     # (multi-GPU: the root takes every step's gathered block [world, B, NL, NK] as a view of the engine's page-locked host copy -- 12.6 MB per
     # step at 8 ranks, more than one host thread can copy again in a step's time -- and keeps a copy of its own rank's slice for the check below)
 
@@ -378,18 +381,21 @@ def main():
         view = eng.fetch_previous("PLK", (B, NL, NK), back=back, copy=False)   # (waits for the step; with OWN_OUT the view IS the step's slice of `results`)
         if keep and keeper is not None:
             keeper.put(view, idx)
+        if keep and STEP_TIMES is not None:
+            STEP_TIMES.append(time.perf_counter())
 
-    def loop(first, n, keep):
-        """n pipelined steps over sets[first : first + n]; every step's output is fetched to the host before the function returns.
+    def loop(first, n, keep, src=None):
+        """n pipelined steps over sets[first : first + n] (src: over that ring of draw sets instead, round and round); every step's output is fetched
+        to the host before the function returns.
         The output of step i - DEPTH is copied out after step i has been launched, so DEPTH steps are always queued on the GPU while the
         host copies and prepares (the engine keeps DEPTH + 1 sets of per-step inputs / outputs)."""
         for i in range(n):
             if exchange == "none":  # one library call per step: stage + launch + the view of the step DEPTH back (eftb_step)
-                d = sets[first + i]
+                d = sets[first + i] if src is None else src[i % len(src)]
                 if HOST_PROFILE is not None:
                     ta = time.perf_counter()
                 view = eng.step(mask, d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"], back=DEPTH if i >= DEPTH else -1, shape=(B, NL, NK),
-                                out=(results if keep else warm_out)[i] if OWN_OUT else None)
+                                out=(results[i] if keep else warm_out[i % len(warm_out)]) if OWN_OUT else None)
                 if HOST_PROFILE is not None:
                     tb = time.perf_counter()
                 if view is not None:
@@ -402,7 +408,7 @@ def main():
                     HOST_PROFILE[0] += tb - ta
                     HOST_PROFILE[1] += time.perf_counter() - tb
                 continue
-            stage_and_run(sets[first + i])
+            stage_and_run(sets[first + i] if src is None else src[i % len(src)])
             if exchange == "rccl":
                 eng.gather_plk(B, root=0)
                 if i >= DEPTH and rank == 0:
@@ -440,22 +446,27 @@ def main():
     # templates_first_evaluations_per_s, and both loops' outputs are compared below.  EFTB_BENCH_DIRECT=0: templates first as `value`.
     eng.set_plk_direct(DIRECT)
     loop(0, W, keep=False)
-    warm_ms, warm_steps = float(os.environ.get("EFTB_BENCH_PREWARM_MS", "50")), W
-    tw = time.perf_counter()
-    while W > 0 and (time.perf_counter() - tw) * 1e3 < warm_ms:
-        loop(0, W, keep=False)
-        warm_steps += W
     # HIP events around every second launch of the dominant kernel inside the timed region, on the stream it runs on (every launch costs the loop
-    # about 1.5 %: two more packets per step on the queue the resummation waits in)
+    # about 1.5 %: two more packets per step on the queue the resummation waits in) -- switched on before the warm-up extension, so that nothing
+    # but the resets below stands between its last step and the timed region
     eng.time_kernels(7 if DIRECT else 1)  # direct-P_l runs have three kernels of about the same weight: all three are timed, the largest is reported
     eng.time_dominant(0 if os.environ.get("EFTB_BENCH_NO_EVENTS") else int(os.environ.get("EFTB_BENCH_EVENT_EVERY", "2")))
-    for kind in range(3):
-        eng.kernel_time(kind, reset=True)
-    eng.submit_stats(enable=True, reset=True)   # host clocks of the staged steps (two steady_clock reads per call: ~50 ns)
     import gc
 
     gc.collect()
     gc.disable()   # (a generation-2 collection inside a 2.5 ms timed region is a 20 % outlier; the loop allocates next to nothing)
+    # The extension: the same untimed loop, CONTINUOUSLY, in chunks of WARM_CHUNK steps over a ring of draw sets until WARM_MS of wall time have passed.
+    # (Second session of round 4: repeating the W-step loop -- mostly pipeline fill and drain at W = 5 -- left the GPU short of its sustained state: of
+    # three 200-step passes run back to back the first took 89.8 us per step, the others 82.9 and 81.2.)
+    warm_ms, warm_steps, WARM_CHUNK = float(os.environ.get("EFTB_BENCH_PREWARM_MS", "50")), W, int(os.environ.get("EFTB_BENCH_PREWARM_CHUNK", "200"))
+    tw = time.perf_counter()
+    # (every rank runs the same number of chunks: each step ends in a collective, so the decision is taken together)
+    while W > 0 and cp.max(1.0 if (time.perf_counter() - tw) * 1e3 < warm_ms else 0.0) > 0.0:
+        loop(0, WARM_CHUNK, keep=False, src=ring_sets)
+        warm_steps += WARM_CHUNK
+    for kind in range(3):
+        eng.kernel_time(kind, reset=True)
+    eng.submit_stats(enable=True, reset=True)   # host clocks of the staged steps (two steady_clock reads per call: ~50 ns)
     cp.barrier()
     t0 = time.perf_counter()
     loop(W, K, keep=True)
@@ -494,6 +505,8 @@ def main():
         direct_results = results.copy()
         eng.set_plk_direct(False)
         loop(0, W, keep=False)
+        if W > 0 and warm_ms > 0:
+            loop(0, WARM_CHUNK // 2, keep=False, src=ring_sets)   # (the templates-first loop's own warm-up: ~35 ms of it)
         eng.time_kernels(1)   # resum_mfma_kernel inside THIS loop: the in-pipeline time `roofline_templates_first` is priced with
         eng.time_dominant(0 if os.environ.get("EFTB_BENCH_NO_EVENTS") else int(os.environ.get("EFTB_BENCH_EVENT_EVERY", "2")))
         eng.kernel_time(0, reset=True)
@@ -750,8 +763,9 @@ def main():
             "valid": bool(valid), "timed_steps_checked_against_sync_path": steps_checked,
             "host_us_per_step": host_stats,
             "warmup_steps_run": warm_steps,
-            "warmup_note": f"{W} untimed pipelined steps as asked, then the same untimed loop repeated until {warm_ms:.0f} ms had passed ({warm_steps} steps in all): "
-                           "the timed region (a few ms) otherwise runs at the clocks of a GPU that has just left idle; EFTB_BENCH_PREWARM_MS=0 switches the extension off",
+            "warmup_note": f"{W} untimed pipelined steps as asked, then the same untimed loop run continuously (chunks of {WARM_CHUNK} steps over a ring of {NRING} further draw sets) until "
+                           f"{warm_ms:.0f} ms had passed ({warm_steps} steps in all): the timed region (a few ms) otherwise runs in the state of a GPU that has just left idle -- of three "
+                           "200-step passes back to back the first takes 10 % longer per step than the others; EFTB_BENCH_PREWARM_MS=0 switches the extension off",
             "roofline": roofline,
         }
         if not valid:

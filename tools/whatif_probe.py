@@ -49,6 +49,8 @@ def child():
         t0 = time.perf_counter()
         loop(K)
         best = min(best, (time.perf_counter() - t0) / K)
+        if os.environ.get("WI_VERBOSE"):
+            print(f"pass: {(time.perf_counter() - t0) / K * 1e6:.1f} us per step", file=sys.stderr)
     print(json.dumps({"ms_per_step": best * 1e3}))
     eng.close()
 
