@@ -32,7 +32,18 @@ def _pointwise(got, want):
     return float(np.max(np.abs(got - want)[big] / np.abs(want)[big]))
 
 
-def cfg3_rates(device=0, npoints=42, steps=20, depth=6):
+COALESCE = int(os.environ.get("EFTB_CFG_COALESCE", "4"))   # queued steps leave as one launch, as in bench.py's own loop
+
+
+def _warm(run, ms=40.0, chunk=40):
+    """Untimed warm-up: the loop about to be timed, run continuously (chunks of `chunk` steps over the warm-up draw sets) for `ms` of wall time -- a GPU
+    that has just left idle runs its first milliseconds ~10 % below its sustained state (bench.py, warmup_note)."""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        run(chunk)
+
+
+def cfg3_rates(device=0, npoints=42, steps=20, depth=int(os.environ.get("EFTB_CFG_DEPTH", "12"))):
     import cfg3_util as U
     from eftpipe_amd import _lib as L
     from eftpipe_amd import tables as TB
@@ -47,7 +58,7 @@ def cfg3_rates(device=0, npoints=42, steps=20, depth=6):
     t0 = U.TRACERS[0]
     B = npoints * NTR
     eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, APst=True, DA_AP=float(g[t0 + "_DA_AP"]), H_AP=float(g[t0 + "_H_AP"])),
-                 max_batch=B, device=device)
+                 max_batch=B, device=device, coalesce=COALESCE)
     nb = max(g[t + "_kout"].size for t in U.TRACERS)
     ops = []
     for t in U.TRACERS:
@@ -93,10 +104,10 @@ def cfg3_rates(device=0, npoints=42, steps=20, depth=6):
     shape = (B, 3, nb)
     worst = 0.0
 
-    def loop(first, n, check):
+    def loop(first, n, check, ring=0):
         nonlocal worst
         for i in range(n):
-            d = sets[first + i]
+            d = sets[first + (i % ring if ring else i)]
             view = eng.step(mask, d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"], back=depth if i >= depth else -1, shape=shape)
             if view is not None and check:
                 for j, t in enumerate(U.TRACERS):
@@ -110,7 +121,7 @@ def cfg3_rates(device=0, npoints=42, steps=20, depth=6):
                     worst = max(worst, _pointwise(view[j][: ref.shape[0], : ref.shape[1]], ref))
         eng.sync()
 
-    loop(steps, 3, False)
+    _warm(lambda n: loop(steps, n, False, ring=3))
     t1 = time.perf_counter()
     loop(0, steps, True)
     dt = (time.perf_counter() - t1) / steps
@@ -139,10 +150,10 @@ def cfg3_rates(device=0, npoints=42, steps=20, depth=6):
     MarginalLikelihood(eng, index, model * 1.01, np.diag(1.0 / sig**2), np.zeros(nG), np.full(nG, 2.0))
     lmask = eng.full_mask() | L.S_LOGP
 
-    def lloop(first, n):
+    def lloop(first, n, ring=0):
         last = None
         for i in range(n):
-            d = sets[first + i]
+            d = sets[first + (i % ring if ring else i)]
             v = eng.step(lmask, d["Pin"], d["f"], d["DA"], d["H"], rows=rows, back=depth if i >= depth else -1, fetch="LOGP", shape=(npoints, 26))
             last = v if v is not None else last
         for back in range(min(depth, n) - 1, -1, -1):
@@ -150,11 +161,16 @@ def cfg3_rates(device=0, npoints=42, steps=20, depth=6):
         eng.sync()
         return last
 
-    lloop(steps, 3)
+    _warm(lambda n: lloop(steps, n, ring=3))
     t1 = time.perf_counter()
     lp = lloop(0, steps)
     dt = (time.perf_counter() - t1) / steps
     assert np.all(np.isfinite(lp[:, 0])), "cfg 3: non-finite marginalised ln P"
+    lp = lp.copy()
+    d = sets[steps - 1]   # the last timed step once more, by itself: same bits whatever launch it left in
+    eng.step(lmask, d["Pin"], d["f"], d["DA"], d["H"], rows=rows)
+    alone = eng.fetch_previous("LOGP", (npoints, 26), back=0, copy=False)
+    assert np.array_equal(alone, lp), "cfg 3: ln P of a step launched with others differs from the same step by itself"
     out["cfg3_likelihood_points_per_s"] = npoints / dt
     out["cfg3_likelihood_theory_evaluations_per_s"] = B / dt
     out["cfg3_note"] = (f"{npoints} likelihood points x 3 tracers (LRG, ELG chained, X) per step at Nl = 3, Nk = 512, DR16 windows at accboost {int(g['accboost'])} / windowk "
@@ -166,7 +182,7 @@ def cfg3_rates(device=0, npoints=42, steps=20, depth=6):
     return out
 
 
-def cfg5_rate(device=0, walkers=64, steps=10, depth=4):
+def cfg5_rate(device=0, walkers=64, steps=int(os.environ.get("EFTB_CFG5_STEPS", "20")), depth=int(os.environ.get("EFTB_CFG5_DEPTH", "10"))):
     from eftpipe_amd import synth
     from eftpipe_amd import tables as TB
     from eftpipe_amd.engine import Engine
@@ -177,7 +193,7 @@ def cfg5_rate(device=0, walkers=64, steps=10, depth=4):
     g, f = _golden("cfg5_acc4"), _golden("caseF")
     k, NK, NTR = f["k"], f["k"].size, 2
     B = walkers * NTR
-    eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(f["DA_AP"]), H_AP=float(f["H_AP"])), max_batch=B, device=device)
+    eng = Engine(EngineConfig(Nl=3, k=k, with_resum=True, with_ap=True, DA_AP=float(f["DA_AP"]), H_AP=float(f["H_AP"])), max_batch=B, device=device, coalesce=COALESCE)
     Bm, _, _, _ = TB.binning_operator(k, g["kout"])
     nb = g["kout"].size
     ops = []
@@ -210,10 +226,10 @@ def cfg5_rate(device=0, walkers=64, steps=10, depth=4):
     shape = (B, 3, nb)
     worst = 0.0
 
-    def loop(first, n, check):
+    def loop(first, n, check, ring=0):
         nonlocal worst
         for i in range(n):
-            d = sets[first + i]
+            d = sets[first + (i % ring if ring else i)]
             view = eng.step(mask, d["Pin"], d["f"], d["DA"], d["H"], bias=d["bias"], back=depth if i >= depth else -1, shape=shape)
             if view is not None and check:
                 worst = max(worst, _pointwise(view[0], want))
@@ -223,7 +239,7 @@ def cfg5_rate(device=0, walkers=64, steps=10, depth=4):
                 worst = max(worst, _pointwise(view[0], want))
         eng.sync()
 
-    loop(steps, 2, False)
+    _warm(lambda n: loop(steps, n, False, ring=2))
     t1 = time.perf_counter()
     loop(0, steps, True)
     dt = (time.perf_counter() - t1) / steps
