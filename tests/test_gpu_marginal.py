@@ -200,3 +200,61 @@ def test_pipelined_steps_to_log_posterior(golden):
     for s, res in enumerate(eng.pipeline(steps, fetch="LOGP")):
         assert res.shape == (B, 26) and np.array_equal(res[:, 0], want[s]), s
     eng.close()
+
+
+def test_coalesced_steps_to_log_posterior(golden):
+    """Engine(coalesce=4) with a likelihood: staged steps with their own Gaussian rows, held in the queue so that they leave as ONE launch (ragged batch
+    sizes), then a free-running loop -- every step's ln P must be the bits of the synchronous eftb_eval_logp_batch on the same inputs."""
+    from eftpipe_amd import _lib as L
+    from eftpipe_amd import tables as TB
+    from eftpipe_amd.engine import Engine
+    from eftpipe_amd.marginal import MarginalLikelihood, data_index, gaussian_rows
+    from eftpipe_amd.tables import EngineConfig
+
+    g = golden("caseC")
+    k = g["k"]
+    Bm, _, _, _ = TB.binning_operator(k, g["kout"])
+    nb = len(g["kout"])
+    B = 6
+    eng = Engine(EngineConfig(Nl=3, with_resum=True, with_ap=True, DA_AP=float(g["DA_AP"]), H_AP=float(g["H_AP"])), max_batch=B, coalesce=4)
+    eng.set_pipeline_operator(eng.add_operator(TB.compose_operator(3, k.size, binning=Bm)))
+    index = data_index([0, 2], {0: slice(0, nb), 2: slice(1, nb - 1)}, nb)
+    rng = np.random.default_rng(22)
+    f0, DA0, H0 = float(g["f"]), float(g["DA"]), float(g["H"])
+    sizes = [6, 4, 6, 1, 6, 6, 3, 6]
+
+    def mk(n):
+        st = dict(Pin=g["Pin"][None] * (1.0 + 0.1 * rng.uniform(-1, 1, (n, 1))), f=f0 * (1.0 + 0.03 * rng.uniform(-1, 1, n)),
+                  DA=DA0 * (1.0 + 0.02 * rng.uniform(-1, 1, n)), H=H0 * (1.0 + 0.02 * rng.uniform(-1, 1, n)))
+        st["rows"] = np.stack([gaussian_rows(fi, (2.0 + 0.1 * rng.uniform(), 0.5, 0.3), None, 0.7, 0.25, 4.5e-5) for fi in st["f"]])
+        return st
+
+    steps = [mk(n) for n in sizes]
+    templ = eng.eval_batch(steps[0]["Pin"], steps[0]["f"], steps[0]["DA"], steps[0]["H"])
+    model = np.einsum("r,lrx->lx", steps[0]["rows"][0, 0], templ[0]).reshape(-1)[index]
+    sig = 0.05 * np.abs(model) + 10.0
+    like = MarginalLikelihood(eng, index, model * 1.02, np.diag(1.0 / sig**2), np.zeros(7), np.full(7, 3.0))
+    want = [like.eval_logp(st["Pin"], st["f"], st["DA"], st["H"], st["rows"]) for st in steps]
+    mask = eng.full_mask() | L.S_LOGP
+    eng.set_latency_mode(False)
+    eng.set_submit_thread(2)
+    eng.submit_stats(enable=True, reset=True)
+    for a, b in [(0, 4), (4, 7), (7, 8)]:   # steps [a, b) leave together
+        eng.hold_submissions(True)
+        for i in range(a, b):
+            st = steps[i]
+            eng.step(mask, st["Pin"], st["f"], st["DA"], st["H"], rows=st["rows"])
+        eng.hold_submissions(False)
+        for i in range(a, b):
+            got = eng.fetch_previous("LOGP", (sizes[i], 26), back=b - 1 - i)
+            assert np.array_equal(got[:, 0], want[i]), (a, b, i)
+    st = eng.submit_stats(enable=False)
+    assert st["steps"] == 8 and st["launches"] == 3, st
+    eng.set_submit_thread(1)
+    depth = 3
+    for i in range(16):   # free running: whatever grouping the timing produces
+        st = steps[i % 8]
+        view = eng.step(mask, st["Pin"], st["f"], st["DA"], st["H"], rows=st["rows"], back=depth if i >= depth else -1, fetch="LOGP", shape=(sizes[(i - depth) % 8], 26))
+        if i >= depth:
+            assert np.array_equal(view[:, 0], want[(i - depth) % 8]), i
+    eng.close()

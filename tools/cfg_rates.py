@@ -174,7 +174,7 @@ def cfg3_rates(device=0, npoints=42, steps=20, depth=int(os.environ.get("EFTB_CF
     out["cfg3_likelihood_points_per_s"] = npoints / dt
     out["cfg3_likelihood_theory_evaluations_per_s"] = B / dt
     out["cfg3_note"] = (f"{npoints} likelihood points x 3 tracers (LRG, ELG chained, X) per step at Nl = 3, Nk = 512, DR16 windows at accboost {int(g['accboost'])} / windowk "
-                        f"{float(g['windowk'])}, binned onto {nds} data k; new inputs staged every step.  cfg3_plk_*: P_l of every tracer fetched (direct-P_l runs, "
+                        f"{float(g['windowk'])}, binned onto {nds} data k; new inputs staged every step, {depth} steps ahead of the one fetched, Engine(coalesce={COALESCE}).  cfg3_plk_*: P_l of every tracer fetched (direct-P_l runs, "
                         "operators on one row per cosmology); walker 0 of every step is the point of tests/golden/cfg3_nk512.npz and its P_l is compared with the "
                         f"reference's inside the loop (max pointwise {worst:.1e}).  cfg3_likelihood_*: {index.size} data points, {nG} jointly marginalised parameters, "
                         "one ln P per point fetched (templates first; synthetic data vector around the model)")
@@ -247,7 +247,7 @@ def cfg5_rate(device=0, walkers=64, steps=int(os.environ.get("EFTB_CFG5_STEPS", 
     eng.close()
     return {"cfg5_evaluations_per_s": B / dt, "cfg5_ms_per_step": dt * 1e3, "cfg5_max_rel_err_vs_reference": worst,
             "cfg5_note": (f"single-GPU half of cfg 5: Nk = {NK}, Nl = 3, IR-resum + AP, two tracers (LRG, ELG chained) x {walkers} walkers per step, window at accboost "
-                          f"{int(g['accboost'])} / windowk {float(g['windowk'])} + binning onto {nb} data k, direct-P_l runs, new inputs staged and P_l fetched every step; entry 0 "
+                          f"{int(g['accboost'])} / windowk {float(g['windowk'])} + binning onto {nb} data k, direct-P_l runs, new inputs staged and P_l fetched every step ({depth} steps ahead, Engine(coalesce={COALESCE})); entry 0 "
                           "of every step is the cosmology of tests/golden/cfg5_acc4.npz (the real reference's binned LRG templates, contracted with the bias) and is "
                           f"compared inside the loop (max pointwise {worst:.1e}); the ELG window has no reference fixture at this accuracy")}
 
