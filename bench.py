@@ -563,6 +563,8 @@ def main():
                 eng.run(mask, B, sync=False)
             eng.sync()
             extras["resident_evaluations_per_s"] = B * K / (time.perf_counter() - t1)
+            extras["resident_note"] = (f"eftb_run over inputs that stay in HBM, one launch per {B} cosmologies, nothing fetched: no staging and no copy-out, but no "
+                                       f"coalescing either -- the staged loop of `value` sends up to {COALESCE} queued steps as one launch, which is why it can be the faster of the two")
             # (2) host inputs in, the whole template block [B][3][24][512] (37.7 MB) back into page-locked memory, synchronous call
             pin = eng.pinned_empty((B, NL, 24, NK))
             eng.eval_batch(d0["Pin"], d0["f"], d0["DA"], d0["H"], out=pin)
@@ -726,7 +728,8 @@ def main():
                 "frac": step_flops / (ms_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms_per_step": ms_step,
                 "frac_resident_inputs": (step_flops / (B / res) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if res else None,
                 "note": "sum over the launches of one direct-P_l step of the FP64 flops they execute (compiled-loop counts for the resummation, 2 M N K for the matrix-core "
-                        "products, sums' shapes for the rest) / ms_per_step of the timed loop / FP64 peak; frac_resident_inputs: the same over the step time of the resident loop"}
+                        "products, sums' shapes for the rest) / ms_per_step of the timed loop / FP64 peak (vector and matrix FP64 instructions share one arithmetic budget on "
+                        "gfx950: tools/probe/mixed_f64_probe.hip); frac_resident_inputs: the same over the step time of the resident loop"}
 
         def check_fracs(node, path="roofline"):
             # no utilisation above 1 leaves this program: such a number is a pricing error, not a measurement
