@@ -428,6 +428,8 @@ def main():
                         keeper.put(block[rank], n - 1 - back)
                 keeper.join()
         elif exchange == "none":
+            if not os.environ.get("EFTB_BENCH_NO_FLUSH"):
+                eng.flush()   # (the burst ends here: the last queued steps do not wait for a launch to fill)
             for back in range(min(DEPTH, n) - 1, -1, -1):  # (back = 0: the step launched last)
                 take(n - 1 - back, back, keep)
             if keeper is not None:

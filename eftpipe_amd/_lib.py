@@ -37,7 +37,7 @@ S_PREP, S_LOOPS, S_CF, S_REGROUP, S_RESUM, S_AP, S_PROJECT, S_REDUCE, K_P22, K_C
 
 EXPORTS = ("eftb_create eftb_set_table eftb_finalize eftb_set_option eftb_dominant_time eftb_kernel_time eftb_kernel_time_ex eftb_set_likelihood eftb_destroy eftb_add_operator eftb_apply_operator "
            "eftb_set_operator_stochastic eftb_set_tracers eftb_set_pipeline_operator_tracer eftb_set_pipeline_operator eftb_set_template_dims eftb_put eftb_get eftb_buffer_size eftb_run "
-           "eftb_sync eftb_run_timed eftb_stage_inputs eftb_run_staged eftb_fetch_previous eftb_fetch_back eftb_fetch_view eftb_step eftb_set_step_output eftb_step_trace eftb_submit_stats eftb_eval_batch eftb_eval_logp_batch eftb_host_alloc eftb_host_free eftb_comm_unique_id eftb_comm_init eftb_gather_plk eftb_fetch_gathered eftb_gathered_view "
+           "eftb_sync eftb_run_timed eftb_stage_inputs eftb_run_staged eftb_fetch_previous eftb_fetch_back eftb_fetch_view eftb_step eftb_flush eftb_set_step_output eftb_step_trace eftb_submit_stats eftb_eval_batch eftb_eval_logp_batch eftb_host_alloc eftb_host_free eftb_comm_unique_id eftb_comm_init eftb_gather_plk eftb_fetch_gathered eftb_gathered_view "
            "eftb_window_precompute eftb_mfma_f64_peak eftb_stream_read_probe eftb_last_error eftb_version eftb_source_hash").split()
 
 _lib = None
@@ -83,6 +83,7 @@ def load():
     lib.eftb_fetch_back.argtypes, lib.eftb_fetch_back.restype = [vp, i32, i32, dp, sz], i32
     lib.eftb_fetch_view.argtypes, lib.eftb_fetch_view.restype = [vp, i32, i32, C.POINTER(dp), C.POINTER(sz)], i32
     lib.eftb_step.argtypes, lib.eftb_step.restype = [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(vp), C.POINTER(sz)], i32
+    lib.eftb_flush.argtypes, lib.eftb_flush.restype = [vp], i32
     lib.eftb_set_step_output.argtypes, lib.eftb_set_step_output.restype = [vp, vp, sz], i32
     lib.eftb_step_trace.argtypes, lib.eftb_step_trace.restype = [vp, dp, i32, C.POINTER(i32)], i32
     lib.eftb_submit_stats.argtypes, lib.eftb_submit_stats.restype = [vp, i32, i32, dp], i32

@@ -254,6 +254,7 @@ struct eftb_engine {
     SubCmd sub_ring[SUBQ];
     std::atomic<unsigned long long> sub_tail{0};   // commands pushed (caller's thread)
     std::atomic<unsigned long long> sub_head{0};   // commands completed (submission thread)
+    std::atomic<bool> sub_flush{false};            // eftb_flush: what is queued leaves now (the flow control does not wait for a full group); cleared once the queue is empty
     std::atomic<bool> sub_sleeping{false}, sub_stop{false}, sub_hold{false};   // sub_hold (EFTB_O_SUBMIT_HOLD, tests): queued steps are not taken until it is cleared
     std::mutex sub_mx;
     std::condition_variable sub_cv;
@@ -2441,7 +2442,8 @@ static void sub_main(eftb_engine* e) {
                 const long long inflight = (long long)(e->launch_seq - e->launch_done);
                 // go: below the in-flight limit AND (a full group is waiting, or the GPU is about to run dry: fewer than sub_low launches left)
                 if (inflight < e->sub_inflight &&
-                    (inflight < e->sub_low || (long long)(e->sub_tail.load(std::memory_order_acquire) - head) >= e->coalesce_max)) break;
+                    (inflight < e->sub_low || (long long)(e->sub_tail.load(std::memory_order_acquire) - head) >= e->coalesce_max ||
+                     e->sub_flush.load(std::memory_order_acquire))) break;
                 if (inflight > 0 && launch_finished(e, e->launch_done)) { ++e->launch_done; continue; }
                 for (int i = 0; i < 16; ++i) cpu_pause();
                 // (a launch that never finishes must not hold the queue -- and with it every entry point that drains it -- for ever: the steps go
@@ -2461,6 +2463,7 @@ static void sub_main(eftb_engine* e) {
         }
         (void)issue_and_publish(e, grp, n, false, false);
         head += n;
+        if (head == e->sub_tail.load(std::memory_order_acquire)) e->sub_flush.store(false, std::memory_order_release);  // (a step queued from here on waits for its group again)
         e->sub_head.store(head, std::memory_order_release);
     }
 }
@@ -2552,6 +2555,12 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     stage_fill(e, slot, B, Pin, f, DA, H, bias, rows);
     if (e->sub_stats) e->fill_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf0).count();
     e->stg_slot = slot; e->stg_B = B; e->stg_rows = rows ? 1 : 0;
+    return 0;
+}
+
+int eftb_flush(eftb_engine* e) {
+    if (!e) return fail("eftb_flush: null engine");
+    if (e->sub_started && !sub_quiescent(e)) e->sub_flush.store(true, std::memory_order_release);
     return 0;
 }
 

@@ -407,6 +407,10 @@ class Engine:
             self._views[key] = view
         return view
 
+    def flush(self):
+        """No more steps for now: what is queued leaves at once instead of waiting for a launch to fill (``eftb_flush``) -- before fetching the tail of a burst."""
+        L.check(self.lib.eftb_flush(self._h))
+
     def fetch_previous(self, name, shape, out=None, back=1, copy=True):
         """PLK / LOGP of the step launched `back` (0: the last one; 1 ... 15) steps before the last one (``out``: a C-contiguous float64 array of ``shape``
         to fill).  back=3 keeps three steps queued while the host works (see ``pipeline``).  copy=False: a read-only view of the engine's page-locked

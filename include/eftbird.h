@@ -284,6 +284,10 @@ int  eftb_fetch_back(eftb_engine* e, int back, int buffer_id, double* host, size
  * (*count = its capacity in elements), valid until NSETS - 1 = 15 more steps have been staged.  For samplers that consume P_l in place (the
  * dependent loop of reference likelihood.py:570-594: chi^2 from P_l, then the next proposal). */
 int  eftb_fetch_view(eftb_engine* e, int back, int buffer_id, const double** block, size_t* count);
+/* The end of a burst: the steps queued so far leave now, in as few launches as eftb_config.step_batch allows, instead of waiting for more steps to
+ * fill a launch (the submission thread lets the queue grow while two launches are in flight).  Returns at once; a sampler calls it before it
+ * fetches the last steps of a batch of proposals (reference: the end of one Cobaya `Model.logposterior` sweep over the walkers). */
+int  eftb_flush(eftb_engine* e);
 /* Where the P_l of the staged step launched NEXT goes: the caller's own page-locked array (eftb_host_alloc / hipHostMalloc / hipHostRegister;
  * `count` doubles, at least B x Nl x Nx of the step's output) instead of the engine's host block -- the copy-out behind the step writes it with
  * the DMA engine, so a sampler that keeps every step's P_l (emulator training sets, the chains' derived output of cobaya's `output_params`,

@@ -348,8 +348,10 @@ def test_coalesced_steps_return_the_bits_of_separate_steps(direct):
         view = eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], back=depth, shape=(B, bench.NL, bench.NK))
         if i >= depth:
             assert np.array_equal(view, ref[(i - depth) % 5]), i
+    eng.flush()   # the burst ends: whatever is still queued leaves now (and a flush with nothing queued is a no-op)
     for back in range(depth - 1, -1, -1):
         assert np.array_equal(eng.fetch_previous("PLK", (B, bench.NL, bench.NK), back=back), ref[(K - 1 - back) % 5]), back
+    eng.flush()
     eng.close()
 
 
