@@ -2509,7 +2509,15 @@ static int sub_wait_launched(eftb_engine* e, unsigned long long step, const char
 
 int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f, const double* DA, const double* H, const double* bias,
                       const double* rows) {
-    if (!e || !Pin || !f) return fail("eftb_stage_inputs: null argument");
+    if (!e || !Pin || !f) {
+        if (e) e->stg_out = nullptr;
+        return fail("eftb_stage_inputs: null argument");
+    }
+    struct OutGuard {   // a step that is refused here takes the destination named for it (eftb_set_step_output) with it: it must not pass to the next step
+        eftb_engine* e;
+        bool staged = false;
+        ~OutGuard() { if (!staged) e->stg_out = nullptr; }
+    } guard{e};
     if (!e->finalized) return fail("eftb_stage_inputs: engine not finalized");
     const eftb_config& c = e->c;
     const int step_max = c.step_batch > 0 ? c.step_batch : c.max_batch;
@@ -2555,6 +2563,7 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     stage_fill(e, slot, B, Pin, f, DA, H, bias, rows);
     if (e->sub_stats) e->fill_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf0).count();
     e->stg_slot = slot; e->stg_B = B; e->stg_rows = rows ? 1 : 0;
+    guard.staged = true;
     return 0;
 }
 

@@ -430,6 +430,14 @@ def test_steps_deliver_into_the_callers_own_array(direct):
     eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=small)
     with pytest.raises(L.EftbError, match="destination of eftb_set_step_output holds"):
         eng.fetch_previous("PLK", shape(0), back=0)
+    # a step refused at staging takes its destination with it: the next step (which names none) must not deliver there
+    dest[1].fill(-1.0)
+    bad = s["Pin"].copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(L.EftbError):
+        eng.step(mask, bad, s["f"], s["DA"], s["H"], bias=s["bias"], out=dest[1])
+    eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"])
+    assert np.array_equal(eng.fetch_previous("PLK", shape(0), back=0), ref[0]) and np.all(dest[1] == -1.0)
     # ... and the engine goes on
     eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=dest[0])
     eng.fetch_previous("PLK", shape(0), back=0, copy=False)
