@@ -2347,6 +2347,8 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
             int j1 = j + 1, rows = cmds[j].B;
             if (!cmds[j].out)
                 for (; j1 < n && !cmds[j1].out; ++j1) rows += cmds[j1].B;
+            else   // destinations that follow each other in memory (the slices of one results array) travel as one transfer too
+                for (; j1 < n && cmds[j1].out == cmds[j].out + (size_t)rows * per; ++j1) rows += cmds[j1].B;
             const double* src = e->buf[EFTB_B_PLK] + (size_t)row * per;
             double* dst = cmds[j].out ? cmds[j].out : e->plk_host[q] + (size_t)row * per;
             if (dma) HIPCHK(hipMemcpyAsync(dst, src, (size_t)rows * per * sizeof(double), hipMemcpyDeviceToHost, st));

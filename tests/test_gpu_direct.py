@@ -406,6 +406,18 @@ def test_steps_deliver_into_the_callers_own_array(direct):
         else:
             assert np.all(dest[i] == -1.0), i
     assert eng.submit_stats(enable=False)["launches"] == 1
+    # (b2) three full-size steps into NEIGHBOURING slices, one launch: their copy-outs merge into one transfer
+    dest.fill(-1.0)
+    eng.set_submit_thread(2)
+    eng.hold_submissions(True)
+    for i in (4, 5, 6):
+        s = sets[i]
+        eng.step(mask, s["Pin"], s["f"], s["DA"], s["H"], bias=s["bias"], out=dest[i])
+    eng.hold_submissions(False)
+    for i in (4, 5, 6):
+        eng.fetch_previous("PLK", shape(i), back=6 - i, copy=False)
+        assert np.array_equal(dest[i], ref[i]), i
+    assert np.all(dest[:4] == -1.0)
     # (c) a free-running loop, every step into its own slice
     dest.fill(-1.0)
     eng.set_submit_thread(1)
