@@ -2537,7 +2537,9 @@ int eftb_stage_inputs(eftb_engine* e, int B, const double* Pin, const double* f,
     if (e->slot_step[slot]) {
         (void)sub_wait_launched(e, e->slot_step[slot] - 1, "eftb_stage_inputs");  // (a failed launch left nothing to wait for; its fetch reports it)
         const eftb_engine::StepRec& r = e->rec[(e->slot_step[slot] - 1) % eftb_engine::SUBREC];
-        if (r.launch != ~0ull) {
+        // (a launch whose completion word has been written is over, its upload with it: no runtime call -- hipEventSynchronize costs this thread 6 us per step)
+        const bool over = r.launch != ~0ull && e->set_word[r.set] >= r.launch + 1 && e->set_done[r.set] >= r.launch + 1;
+        if (r.launch != ~0ull && !over) {
             const int lr = (int)(r.launch % eftb_engine::NLRING);
             // ... and the block is free again (the upload from it has finished; a latency-mode step's first kernel read P_lin from the block itself:
             // that step must be over too -- it almost always is)
