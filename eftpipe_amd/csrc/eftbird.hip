@@ -2297,9 +2297,10 @@ static int issue_group(eftb_engine* e, const eftb_engine::SubCmd* cmds, int n, b
     e->status_slot = q;  // this launch's kernels raise this set's flags (cleared here: whatever an abandoned step left is void)
     e->status[2 * q] = e->status[2 * q + 1] = 0;
     ++e->epoch;  // (captured graphs hold the other set's pointers)
-    HIPCHK(hipStreamWaitEvent(e->stream, e->evStagedR[lr], 0));  // the side stream forks from here, so it inherits the wait
-    HIPCHK(hipStreamWaitEvent(e->pre, e->evStagedR[lr], 0));
-    HIPCHK(hipStreamWaitEvent(e->side, e->evStagedR[lr], 0));
+    const hipStream_t staged_on = lat ? e->stream : cs;   // (where evStagedR was recorded: that stream is behind it already -- a call saved per launch)
+    if (staged_on != e->stream) HIPCHK(hipStreamWaitEvent(e->stream, e->evStagedR[lr], 0));  // the side stream forks from here, so it inherits the wait
+    if (staged_on != e->pre) HIPCHK(hipStreamWaitEvent(e->pre, e->evStagedR[lr], 0));
+    if (staged_on != e->side) HIPCHK(hipStreamWaitEvent(e->side, e->evStagedR[lr], 0));
     // latency mode: one queue for the whole step; P_lin is read from the page-locked staging block (its device copy arrives behind evStagedAllR);
     // P_l goes to mapped host memory from the kernel that forms it (REDUCE, or the AP epilogue) unless the NNLO pass adds to it afterwards
     const bool plk_direct = (lat || (e->plk_direct && !e->comm)) && e->plk_host[q] && (mask & EFTB_S_REDUCE) && !c.with_nnlo;
