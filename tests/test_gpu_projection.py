@@ -581,4 +581,11 @@ def test_cfg5_window_at_shipped_accuracy_nk2048(golden):
         assert relerr(got, want) < TOL
         big = np.abs(want) > 1e-3 * np.abs(want).max(axis=-1, keepdims=True)
         assert np.max(np.abs(got - want)[big] / np.abs(want)[big]) < 1e-6
+    # a staged step behind the PROJECT stage delivers its (binned) rows into the caller's page-locked array: exactly plk_d.size elements suffice
+    dest = eng.pinned_empty(plk_d.shape)
+    dest.fill(-1.0)
+    Pin2, f2, DA2, H2 = args
+    eng.step(eng.full_mask(reduce=True), Pin2, np.full(2, f2), np.full(2, DA2), np.full(2, H2), bias=bias, out=dest)   # (the mask carries PROJECT: the engine has a pipeline operator)
+    eng.fetch_previous("PLK", plk_d.shape, back=0, copy=False)
+    assert np.array_equal(dest, plk_d)
     eng.close()
