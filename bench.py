@@ -333,6 +333,8 @@ def main():
     # the untimed extension of the warm-up (below) cycles through a ring of sixteen draw sets of its own (the W asked for + as many more as it takes)
     NRING = 16
     ring_sets = (sets[:W] + [draw_set(W + K + j) for j in range(max(0, NRING - W))])[:NRING] if W > 0 else []
+    # ... and K more for the side key bare_warmup_*: the same K-step loop timed right behind the W warm-up steps asked for, before the extension
+    bare_sets = [draw_set(W + K + NRING + j) for j in range(K)] if W > 0 and os.environ.get("EFTB_BENCH_BARE", "1") != "0" else []
     mask = eng.full_mask(reduce=True)
     # every timed step's P_l of this rank.  N = 1: a page-locked array the sampler owns -- each step's copy-out writes its slice directly
     # (eng.step(out=...) = eftb_set_step_output: no second host copy; EFTB_BENCH_OWN_OUTPUT=0: the engine's own host block and a copy by a second
@@ -448,6 +450,13 @@ def main():
     # templates_first_evaluations_per_s, and both loops' outputs are compared below.  EFTB_BENCH_DIRECT=0: templates first as `value`.
     eng.set_plk_direct(DIRECT)
     loop(0, W, keep=False)
+    bare_elapsed = None
+    if bare_sets and float(os.environ.get("EFTB_BENCH_PREWARM_MS", "50")) > 0:
+        cp.barrier()
+        tb0 = time.perf_counter()
+        loop(0, K, keep=False, src=bare_sets)
+        cp.barrier()
+        bare_elapsed = cp.max(time.perf_counter() - tb0)
     # HIP events around every second launch of the dominant kernel inside the timed region, on the stream it runs on (every launch costs the loop
     # about 1.5 %: two more packets per step on the queue the resummation waits in) -- switched on before the warm-up extension, so that nothing
     # but the resets below stands between its last step and the timed region
@@ -534,6 +543,10 @@ def main():
 
     if rank == 0:
         extras = {}
+        if bare_elapsed is not None:
+            extras["bare_warmup_evaluations_per_s"], extras["bare_warmup_ms_per_step"] = B * world * K / bare_elapsed, bare_elapsed / K * 1e3
+            extras["bare_warmup_note"] = (f"the same {K}-step loop over {K} other draw sets, timed right behind the {W} warm-up steps asked for and BEFORE the warm-up extension "
+                                          "(warmup_note): what the first milliseconds after idle look like; `value` is the loop in the GPU's sustained state")
         if tf_elapsed is not None:
             extras["templates_first_evaluations_per_s"], extras["templates_first_ms_per_step"] = B * world * K / tf_elapsed, tf_elapsed / K * 1e3
             extras["templates_first_note"] = ("the same timed loop with EFTB_O_PLK_DIRECT off: the 24 templates per multipole go through resummation and AP and the "
